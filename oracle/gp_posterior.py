@@ -1,0 +1,236 @@
+"""Oracle: matrix-variate GP posterior over F(x) = [f(x) g(x)]  (test infrastructure).
+
+numpy/scipy restatement of the reference's hand-written prediction path.  Notation
+(SURVEY.md section 0): N train points, n state dim, m ctrl dim, UH[N,1+m] rows [1,u_i],
+Bm[(1+m),(1+m)] covariance over "controls", A[n,n] covariance over state dims,
+ell[n] ARD lengthscale, s2 outputscale, M0[(1+m),n] constant prior mean.
+
+Randomness is never drawn here: every `torch.rand` of the reference (the `make_psd`
+jitter) is an explicit argument.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+
+# --------------------------------------------------------------------------- kernels
+def softplus(x):
+    """gpytorch's positive-constraint transform (third-party, published definition)."""
+    x = np.asarray(x, dtype=np.float64)
+    return np.log1p(np.exp(-np.abs(x))) + np.maximum(x, 0.0)
+
+
+def rbf_ard_kernel(X1, X2, ell, s2):
+    """k(x,x') = s2 * exp(-1/2 sum_d ((x_d - x'_d)/ell_d)^2).
+
+    gpytorch ScaleKernel(RBFKernel(ard_num_dims=n)) as constructed at
+    bayes_cbf/control_affine_model.py:164-171 (arithmetic lives in gpytorch; restated from
+    its published definition; cross-checked by the analytic RBF of
+    bayes_cbf/trigger_interval.py:32-43 and tests/test_gp_algebra.py:91-127).
+    X1[a,n], X2[b,n] -> [a,b].
+    """
+    X1 = np.atleast_2d(X1)
+    X2 = np.atleast_2d(X2)
+    d = (X1[:, None, :] - X2[None, :, :]) / np.asarray(ell).reshape(1, 1, -1)
+    return s2 * np.exp(-0.5 * np.sum(d * d, axis=-1))
+
+
+def index_kernel_covar(covar_factor, raw_var):
+    """gpytorch IndexKernel.covar_matrix = F F^T + diag(softplus(raw_var)); used for A and B
+    (bayes_cbf/matrix_variate_multitask_kernel.py:37-41, control_affine_model.py:158-163)."""
+    F = np.asarray(covar_factor, dtype=np.float64)
+    return F @ F.T + np.diag(softplus(raw_var))
+
+
+def homogeneous_controls(U, fill=1.0):
+    """UH = [fill, u]  (control_affine_model.py:186-193 for training rows, :428-434 for queries)."""
+    U = np.atleast_2d(U)
+    return np.concatenate([np.full((U.shape[0], 1), fill, dtype=U.dtype), U], axis=1)
+
+
+# --------------------------------------------------------------------------- refit state
+def kb_matrix(X, UH, Bm, ell, s2):
+    """K_b = k(X,X) o (UH Bm UH^T)   (control_affine_model.py:370-372)."""
+    return rbf_ard_kernel(X, X, ell, s2) * (UH @ Bm @ UH.T)
+
+
+def make_psd(Kb, rand_draws, cholesky_tries=10, perturb_init=1e-5, perturb_scale=10):
+    """Jittered Cholesky with x10 retry  (control_affine_model.py:899-921).
+
+    rand_draws[t] is the U[0,1)^N vector the reference draws with torch.rand on try t.
+    Returns (Kb + diag(jitter), L, tries_used); raises LinAlgError after the last try.
+    """
+    rand_draws = np.atleast_2d(rand_draws)
+    factor = perturb_init
+    for ntry in range(cholesky_tries):
+        r = rand_draws[min(ntry, rand_draws.shape[0] - 1)]
+        Kbp = Kb + factor * np.diag(r)
+        try:
+            L = np.linalg.cholesky(Kbp)
+            return Kbp, L, ntry + 1
+        except np.linalg.LinAlgError:
+            if ntry == cholesky_tries - 1:
+                raise
+            factor = factor * perturb_scale
+    raise AssertionError("unreachable")
+
+
+def perturbed_cholesky(X, UH, Bm, ell, s2, rand_draws):
+    """L = chol(K_b + jitter)   (control_affine_model.py:366-377)."""
+    _, L, _ = make_psd(kb_matrix(X, UH, Bm, ell, s2), rand_draws)
+    return L
+
+
+def residual_targets(Xdot, UH, M0):
+    """Y = Xdot - M0^T uh_i per row   (control_affine_model.py:525-532, 1033-1042).
+
+    The reference evaluates its mean module on raw X (no mask column) which, for a constant
+    mean, gives vec(M0) on every row unless x[0]==1.0 exactly; M0 is
+    therefore an explicit [(1+m),n] input here.
+    """
+    return Xdot - UH @ M0
+
+
+def cholesky_solve(Y, L):
+    """K^-1 Y given K = L L^T  (torch.cholesky_solve, control_affine_model.py:545,1053)."""
+    return sla.solve_triangular(L, sla.solve_triangular(L, Y, lower=True), lower=True, trans='T')
+
+
+# --------------------------------------------------------------------------- vector-variate view
+def custom_predict(X, UH, Y, L, A, Bm, ell, s2, M0, Xtest, UHtest, Xtestp=None, UHtestp=None,
+                   compute_cov=True):
+    """ControlAffineRegressor.custom_predict  (control_affine_model.py:390-613), grad_gp=False.
+
+    Returns (mean[b,n], scalar_var[b,b'], cov[1, b*n, b'*n] = kron(scalar_var, A)).
+    """
+    Xtest = np.atleast_2d(Xtest)
+    if Xtestp is None:
+        Xtestp = Xtest
+    if UHtestp is None:
+        UHtestp = UHtest
+    fu_mean_test = UHtest @ M0                                   # :485-493
+    kb_star = rbf_ard_kernel(X, Xtest, ell, s2) * (UH @ Bm @ UHtest.T)        # :536
+    alpha = cholesky_solve(Y, L)                                 # :545
+    mean = fu_mean_test + kb_star.T @ alpha                      # :547
+    if not compute_cov:
+        return mean, None, 0 * A
+    kb_star_p = rbf_ard_kernel(X, Xtestp, ell, s2) * (UH @ Bm @ UHtestp.T)    # :550-552
+    kb_ss = rbf_ard_kernel(Xtest, Xtestp, ell, s2) * (UHtest @ Bm @ UHtestp.T)  # :553
+    v = sla.solve_triangular(L, kb_star, lower=True)             # :565 (general solve of a triangular L)
+    vp = sla.solve_triangular(L, kb_star_p, lower=True)          # :575
+    scalar_var = kb_ss - v.T @ vp                                # :586
+    cov = np.kron(scalar_var, A)[None]                           # :602
+    return mean, scalar_var, cov
+
+
+# --------------------------------------------------------------------------- matrix-variate view
+def custom_predict_matrix(X, UH, Y, L, A, Bm, ell, s2, M0, Xtest, Xtestp=None, compute_cov=True,
+                          rand_draws2=None):
+    """ControlAffineRegressorExact._custom_predict_matrix  (control_affine_model.py:983-1096).
+
+    Returns (mean_k[b,n,1+m], A, BkXX[b,b',1+m,1+m]).  `rand_draws2` are the U[0,1)^{b(1+m)}
+    vectors of the second make_psd (:1089); None adds no jitter (the pure formula A.2).
+    """
+    Xtest = np.atleast_2d(Xtest)
+    if Xtestp is None:
+        Xtestp = Xtest
+    b, bp = Xtest.shape[0], Xtestp.shape[0]
+    N = X.shape[0]
+    m1 = UH.shape[1]
+    fX_mean_test = np.broadcast_to(M0.T[None], (b, M0.shape[1], m1))          # :1022-1023
+    kb_star = rbf_ard_kernel(Xtest, X, ell, s2)[:, :, None] * (UH @ Bm)[None]  # :1051  [b,N,1+m]
+    Bdagger = np.stack([cholesky_solve(kb_star[i], L) for i in range(b)])      # :1053
+    mean_k = fX_mean_test + np.einsum('kn,bkc->bnc', Y, Bdagger)              # :1055
+    if not compute_cov:
+        return mean_k, A, np.zeros((b, bp, m1, m1))
+    kb_star_p = rbf_ard_kernel(Xtestp, X, ell, s2)[:, :, None] * (UH @ Bm)[None]
+    # The reference reuses kb_star for both sides (it only supports Xtestp is Xtest there,
+    # :1079-1088); with Xtestp given we follow the formula of its docstring.
+    Bdagger_p = Bdagger if Xtestp is Xtest else np.stack(
+        [cholesky_solve(kb_star_p[i], L) for i in range(bp)])
+    KB = np.kron(rbf_ard_kernel(Xtest, Xtestp, ell, s2), Bm)                  # :1062-1063
+    lhs = kb_star.transpose(0, 2, 1).reshape(b * m1, N)                        # :1082-1083
+    rhs = Bdagger_p.transpose(1, 0, 2).reshape(N, bp * m1)                     # :1085-1086
+    BkXX = KB - lhs @ rhs                                                      # :1079-1088
+    if rand_draws2 is not None:
+        BkXX, _, _ = make_psd(BkXX, rand_draws2)                               # :1089
+    BkXX = BkXX.reshape(b, m1, bp, m1).transpose(0, 2, 1, 3)                   # :1091
+    return mean_k, A, BkXX
+
+
+def exact_custom_predict(X, UH, Y, L, A, Bm, ell, s2, M0, Xtest, UHtest, Xtestp=None,
+                         UHtestp=None, compute_cov=True, rand_draws2=None):
+    """ControlAffineRegressorExact.custom_predict  (control_affine_model.py:931-961).
+
+    Returns (meanFXU[b,n], varFXU[b,b',n,n])."""
+    mean_k, A, BkXX = custom_predict_matrix(X, UH, Y, L, A, Bm, ell, s2, M0, Xtest, Xtestp,
+                                            compute_cov, rand_draws2)
+    if UHtestp is None:
+        UHtestp = UHtest
+    meanFXU = np.einsum('bnc,bc->bn', mean_k, UHtest)                          # :954
+    if not compute_cov:
+        return meanFXU, np.zeros((mean_k.shape[0], BkXX.shape[1]) + A.shape)
+    s = np.einsum('bc,bpcd,pd->bp', UHtest, BkXX, UHtestp)                     # :956-958
+    return meanFXU, s[:, :, None, None] * A
+
+
+def custom_predict_fullmat(X, UH, Y, L, A, Bm, ell, s2, M0, Xtest, rand_draws2=None):
+    """ControlAffineRegressorExact.custom_predict_fullmat  (control_affine_model.py:963-980).
+
+    Returns (vec(M_k)[b(1+m)n], kron(B_k, A)[b(1+m)n, b(1+m)n])."""
+    mean_k, A, BkXX = custom_predict_matrix(X, UH, Y, L, A, Bm, ell, s2, M0, Xtest, None, True,
+                                            rand_draws2)
+    b, n, m1 = mean_k.shape
+    meanFX = mean_k.transpose(0, 2, 1)                                         # :974
+    Bk2 = BkXX.transpose(0, 2, 1, 3).reshape(b * m1, b * m1)                   # :975
+    return meanFX.reshape(-1), np.kron(Bk2, A)
+
+
+# --------------------------------------------------------------------------- per-step
+def posterior_step(L, alpha, X, UHB, ell, s2, Bm, M0, xq, jitter2=None):
+    """One query per independent instance (regime I): closed form of SURVEY Appendix A.2.
+
+    Phi = diag(k*(x)) UH Bm;  W = L^-1 Phi;  M_k = M0^T + alpha^T Phi;  B_k = k(x,x) Bm - W^T W
+    (same arithmetic as control_affine_model.py:1051-1088 with b=1).  Leading axis = instance.
+    L[Bt,N,N], alpha[Bt,N,n], X[Bt,N,n], UHB[Bt,N,1+m] (=UH Bm), ell[Bt,n], s2[Bt], Bm[Bt,1+m,1+m],
+    M0[Bt,1+m,n], xq[Bt,n]; jitter2[Bt,1+m] is added to diag(B_k) (the explicit second
+    make_psd jitter, :1089).  Returns (Mk[Bt,n,1+m], Bk[Bt,1+m,1+m]).
+    """
+    Bt = L.shape[0]
+    n = X.shape[2]
+    m1 = UHB.shape[2]
+    Mk = np.empty((Bt, n, m1))
+    Bk = np.empty((Bt, m1, m1))
+    for i in range(Bt):
+        kstar = rbf_ard_kernel(X[i], xq[i][None], ell[i], s2[i])[:, 0]
+        Phi = kstar[:, None] * UHB[i]
+        W = sla.solve_triangular(L[i], Phi, lower=True)
+        Mk[i] = M0[i].T + alpha[i].T @ Phi
+        Bk[i] = s2[i] * Bm[i] - W.T @ W
+        if jitter2 is not None:
+            Bk[i] += np.diag(jitter2[i])
+    return Mk, Bk
+
+
+def refit_state(X, U, Xdot, Bm, ell, s2, M0, rand_draws):
+    """Everything a refit produces for one instance: UH, K_b, L, Y, alpha, UHB."""
+    UH = homogeneous_controls(U)
+    Kb = kb_matrix(X, UH, Bm, ell, s2)
+    Kbp, L, tries = make_psd(Kb, rand_draws)
+    Y = residual_targets(Xdot, UH, M0)
+    alpha = cholesky_solve(Y, L)
+    return dict(UH=UH, Kb=Kb, Kbp=Kbp, L=L, tries=tries, Y=Y, alpha=alpha, UHB=UH @ Bm)
+
+
+def chol_append(L, knew, kappa):
+    """Bordered Cholesky: chol([[K,k],[k^T,kappa]]) from L=chol(K)  (no reference counterpart;
+    parity is defined against full re-factorisation)."""
+    N = L.shape[0]
+    l = sla.solve_triangular(L, knew, lower=True)
+    d2 = kappa - l @ l
+    if d2 <= 0:
+        raise np.linalg.LinAlgError("appended point makes K_b non positive definite")
+    Lnew = np.zeros((N + 1, N + 1))
+    Lnew[:N, :N] = L
+    Lnew[N, :N] = l
+    Lnew[N, N] = np.sqrt(d2)
+    return Lnew

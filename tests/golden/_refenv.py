@@ -1,0 +1,51 @@
+"""Bootstrap for importing the reference (/root/reference, read-only) in the build container.
+
+Only used by the golden-vector generators in this directory.  Puts the third-party
+test doubles of `_shims/` and the reference on sys.path, provides
+`torch.utils.tensorboard.SummaryWriter` (import-time name, reference misc.py:17) and
+maps the removed `torch.eig` onto `torch.linalg.eig` (reference gp_algebra.py:385,389).
+"""
+import os
+import sys
+import types
+
+REFERENCE = os.environ.get("BCBF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def available():
+    return os.path.isdir(os.path.join(REFERENCE, "bayes_cbf"))
+
+
+def setup():
+    if not available():
+        raise RuntimeError("reference tree not found at %s (golden vectors are generated in the "
+                           "build container only)" % REFERENCE)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    for p in (os.path.join(HERE, "_shims"), REFERENCE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    if "torch.utils.tensorboard" not in sys.modules:
+        tb = types.ModuleType("torch.utils.tensorboard")
+
+        class SummaryWriter:
+            def __init__(self, *a, **k):
+                pass
+
+            def add_scalar(self, *a, **k):
+                pass
+
+            def close(self):
+                pass
+
+        tb.SummaryWriter = SummaryWriter
+        sys.modules["torch.utils.tensorboard"] = tb
+        torch.utils.tensorboard = tb
+    if not hasattr(torch, "eig"):
+        def eig(A, eigenvectors=False):
+            w, V = torch.linalg.eig(A)
+            return torch.stack([w.real, w.imag], dim=-1), V.real
+        torch.eig = eig
+    return torch

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors of tests/golden/*.npz by EXECUTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; see `_refenv.py` and `_shims/`).
+The reference's own modules (`bayes_cbf.control_affine_model`, `gp_algebra`, `cbc2`,
+`unicycle_move_to_pose`) are imported unmodified; hyper-parameters are *set*, not fitted
+(fit() needs the real gpytorch); every `torch.rand` the reference draws is recorded so the
+oracle / device path can replay it as an explicit input.
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.npz
+
+Only the .npz outputs travel to the GPU box.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refenv  # noqa: E402
+
+torch = _refenv.setup()
+import bayes_cbf.unicycle_move_to_pose as ump  # noqa: E402  (sets default dtype float64, :50)
+import bayes_cbf.control_affine_model as cam  # noqa: E402
+from bayes_cbf.cbc2 import cbc2_quadratic_terms  # noqa: E402
+from bayes_cbf.planner import PiecewiseLinearPlanner  # noqa: E402
+
+
+class RandRecorder:
+    """Records every torch.rand(...) result drawn while active (reference make_psd :907-910,
+    _clc_terms/_cbc_terms linearisation point unicycle_move_to_pose.py:894,913)."""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self._orig = torch.rand
+
+        def rec(*a, **k):
+            out = self._orig(*a, **k)
+            self.draws.append(out.detach().clone().double().numpy())
+            return out
+        torch.rand = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+        return False
+
+
+def t2n(x):
+    return x.detach().cpu().double().numpy()
+
+
+def make_regressor(cls, n, m, N, seed, spread=1.5):
+    """A regressor with set (random, seeded) hyper-parameters and a training set."""
+    torch.manual_seed(seed)
+    reg = cls(n, m, device='cpu')
+    model = reg.model
+    with torch.no_grad():
+        model.input_covar.base_kernel.raw_lengthscale.copy_(0.3 * torch.randn(1, n))
+        model.input_covar.raw_outputscale.copy_(0.3 * torch.randn(()))
+        for bm in model.mean_module.base_means:
+            bm.constant.copy_(0.2 * torch.randn(1))
+    X = spread * (2 * torch.rand(N, n) - 1)
+    U = torch.randn(N, m)
+    # a smooth synthetic control-affine truth + small noise as targets
+    Wf = torch.randn(n, n)
+    Wg = torch.randn(n, n, m)
+    Xdot = (torch.sin(X @ Wf.t())
+            + torch.einsum('bn,knm,bm->bk', torch.cos(X), Wg, U) * 0.5
+            + 1e-3 * torch.randn(N, n))
+    model.set_train_data(X, U, Xdot)
+    return reg, X, U, Xdot
+
+
+def hyper(reg, n, m):
+    A = t2n(reg.get_kernel_param('A'))
+    B = t2n(reg.get_kernel_param('B'))
+    ell = t2n(reg.get_kernel_param('lengthscale')).reshape(-1)
+    s2 = float(t2n(reg.get_kernel_param('scalefactor')))
+    consts = np.array([float(bm.constant.detach()) for bm in reg.model.mean_module.base_means])
+    M0 = consts.reshape(1 + m, n)                 # matrix_variate_multitask_model.py:54-57
+    return dict(A=A, B=B, ell=ell, s2=s2, M0=M0)
+
+
+def gen_posterior(tag, n, m, N, b, seed, rank_one):
+    out = {}
+    # ---- vector-variate view: ControlAffineRegressor.custom_predict (:390-613)
+    cls = cam.ControlAffineRegressorRankOne if rank_one else cam.ControlAffineRegressor
+    reg, X, U, Xdot = make_regressor(cls, n, m, N, seed)
+    out.update(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), **hyper(reg, n, m))
+    torch.manual_seed(seed + 1)
+    Xtest = 1.2 * (2 * torch.rand(b, n) - 1)
+    Utest = torch.randn(b, m)
+    Xtestp = 1.2 * (2 * torch.rand(b, n) - 1)
+    Utestp = torch.randn(b, m)
+    out.update(Xtest=t2n(Xtest), Utest=t2n(Utest), Xtestp=t2n(Xtestp), Utestp=t2n(Utestp))
+    torch.manual_seed(seed + 2)
+    with RandRecorder() as rr:
+        mean, cov = reg.custom_predict(Xtest, Utest)
+        L = reg._cache["perturbed_cholesky"]
+        mean_x, cov_x = reg.custom_predict(Xtest, Utest, Xtestp_in=Xtestp, Utestp_in=Utestp)
+        mean_f, cov_f = reg.custom_predict(Xtest)                       # f only: uh = e0
+        mean_gu, cov_gu = reg.custom_predict(Xtest, Utest, UHfill=0)    # g(x)u only
+        # single-state GP views used by gp_algebra / cbc2 (:707-818)
+        fu_mean1 = reg.fu_func_mean(Utest[0], Xtest[0])
+        fu_knl1 = reg.fu_func_knl(Utest[0], Xtest[0], Xtestp[0])
+        covar_fu_f1 = reg.covar_fu_f(Utest[0], Xtest[0], Xtestp[0])
+        f_knl1 = reg.f_func_knl(Xtest[0], Xtestp[0])
+    assert len(rr.draws) == 1 and rr.draws[0].shape == (N,)
+    out.update(jitter_rand=np.stack(rr.draws), L=t2n(L),
+               vec_mean=t2n(mean), vec_cov=t2n(cov), vec_mean_x=t2n(mean_x), vec_cov_x=t2n(cov_x),
+               vec_mean_f=t2n(mean_f), vec_cov_f=t2n(cov_f), vec_mean_gu=t2n(mean_gu),
+               vec_cov_gu=t2n(cov_gu), fu_mean1=t2n(fu_mean1), fu_knl1=t2n(fu_knl1),
+               covar_fu_f1=t2n(covar_fu_f1), f_knl1=t2n(f_knl1))
+
+    # ---- matrix-variate view: ControlAffineRegressorExact (:930-1096), same data & hyper-parameters
+    clsE = cam.ControlAffineRegressorExactRankOne if rank_one else cam.ControlAffineRegressorExact
+    regE, XE, UE, XdotE = make_regressor(clsE, n, m, N, seed)
+    assert torch.equal(XE, X) and np.allclose(hyper(regE, n, m)['B'], out['B'])
+    torch.manual_seed(seed + 2)
+    with RandRecorder() as rr:
+        mean_k, A_, BkXX = regE._custom_predict_matrix(Xtest)
+        LE = regE._cache["perturbed_cholesky"]
+        meanFXU, varFXU = regE.custom_predict(Xtest, Utest)
+        fullmean, fullvar = regE.custom_predict_fullmat(Xtest)
+        mean_k1, _, BkXX1 = regE._custom_predict_matrix(Xtest[:1])
+    assert [d.shape for d in rr.draws] == [(N,), (b * (1 + m),), (b * (1 + m),), (b * (1 + m),), (1 + m,)]
+    assert np.allclose(rr.draws[0], out['jitter_rand'][0]) and np.allclose(t2n(LE), out['L'])
+    out.update(mat_jitter2=rr.draws[1], mat_mean_k=t2n(mean_k), mat_BkXX=t2n(BkXX),
+               exact_jitter2=rr.draws[2], exact_meanFXU=t2n(meanFXU), exact_varFXU=t2n(varFXU),
+               full_jitter2=rr.draws[3], full_mean=t2n(fullmean), full_var=t2n(fullvar),
+               one_jitter2=rr.draws[4], one_mean_k=t2n(mean_k1), one_BkXX=t2n(BkXX1))
+    np.savez_compressed(os.path.join(HERE, 'posterior_%s.npz' % tag), **out)
+    print('posterior_%s: N=%d n=%d m=%d b=%d' % (tag, N, n, m, b))
+
+
+def gen_unicycle_terms(tag, N, seed, enable_learning, max_risk=0.01):
+    """ControllerCLFBayesian._clc_terms / _cbcs on the unicycle (unicycle_move_to_pose.py:880-920)."""
+    n, m = 3, 2
+    torch.manual_seed(seed)
+    x0 = torch.tensor([-3.0, -1.0, -np.pi / 4])
+    xg = torch.tensor([0.0, 0.0, np.pi / 4])
+    dt, numSteps = 0.01, 200
+    kernel_diag_A = [1e-2, 2e-2, 3e-2]
+    mean_L, Kp = 4.0, [0.9, 1.5, 0.0]
+    cbf_gammas = [5.0, 5.0]
+    term_weights = [0.7, 0.3]
+    out = dict(x0=t2n(x0), xg=t2n(xg), dt=dt, numSteps=numSteps, mean_L=mean_L, Kp=np.array(Kp),
+               cbf_gammas=np.array(cbf_gammas), term_weights=np.array(term_weights), clf_gamma=10.0,
+               kernel_diag_A=np.array(kernel_diag_A), enable_learning=enable_learning,
+               max_risk=max_risk, frac_time_to_reach_goal=0.95)
+    if enable_learning:
+        reg, X, U, Xdot = make_regressor(cam.ControlAffineRegressorExactRankOne, n, m, N, seed, spread=3.0)
+        out.update(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), **hyper(reg, n, m))
+    else:
+        reg = None
+    dyn = ump.LearnedShiftInvariantDynamics(
+        dt=dt, learned_dynamics=reg,
+        mean_dynamics=ump.AckermannDrive(L=mean_L, kernel_diag_A=kernel_diag_A),
+        enable_learning=enable_learning)
+    ctrl = ump.ControllerCLFBayesian(
+        PiecewiseLinearPlanner(x0, xg, numSteps, dt, frac_time_to_reach_goal=0.95),
+        coordinate_converter=lambda x, x_g: x,
+        dynamics=dyn,
+        clf=ump.CLFCartesian(Kp=torch.tensor(Kp)),
+        cbfs=ump.obstacles_at_mid_from_start_and_goal(x0, xg, term_weights=term_weights),
+        cbf_gammas=cbf_gammas, max_risk=max_risk)
+    states, ts, recs = [], [], []
+    torch.manual_seed(seed + 7)
+    for i in range(6):
+        x = torch.tensor([-3.0, -1.0, -np.pi / 4]) + torch.tensor([0.5 * i, 0.17 * i, 0.1 * i]) \
+            + 0.05 * torch.randn(3)
+        t = 5 + 30 * i
+        state_goal = ctrl.planner.plan(t)
+        rec = dict(plan=t2n(state_goal), dot_plan=t2n(ctrl.planner.dot_plan(t)))
+        with RandRecorder() as rr:
+            # raw terms exactly as _clc_terms / _cbc_terms obtain them (:892-894, :911-913)
+            u0 = torch.rand(m)
+            (bfe, e), (V, bfv, v), mean, var = cbc2_quadratic_terms(
+                lambda u: ctrl._clc(x, state_goal, u, t) * -1.0, x, u0)
+            rec['clc_raw'] = [t2n(z) for z in (bfe, e, V, bfv, v, mean, var)]
+            rec['clc_socp'] = [t2n(z) for z in ump.ControllerCLFBayesian.convert_cbc_terms_to_socp_terms(
+                bfe, e, V, bfv, v, 0)]
+            rec['cbc_raw'], rec['cbc_socp'] = [], []
+            for cbf, gam in zip(ctrl.cbfs, ctrl.cbf_gammas):
+                u0 = torch.rand(m)
+                (bfe, e), (V, bfv, v), mean, var = cbc2_quadratic_terms(
+                    lambda u: ctrl._cbc(cbf, gam, x, u, t), x, u0)
+                rec['cbc_raw'].append([t2n(z) for z in (bfe, e, V, bfv, v, mean, var)])
+                rec['cbc_socp'].append([t2n(z) for z in
+                                        ump.ControllerCLFBayesian.convert_cbc_terms_to_socp_terms(
+                                            bfe, e, V, bfv, v, 0)])
+            rec['h'] = [float(cbf.cbf(x)) for cbf in ctrl.cbfs]
+            rec['grad_h'] = [t2n(cbf.grad_cbf(x)) for cbf in ctrl.cbfs]
+            rec['V'] = float(ctrl.clf.clf_terms(x, state_goal).sum())
+            rec['grad_V'] = t2n(ctrl.clf.grad_clf(x, state_goal))
+            rec['grad_V_goal'] = t2n(ctrl.clf.grad_clf_wrt_goal(x, state_goal))
+        rec['draws'] = rr.draws
+        states.append(t2n(x))
+        ts.append(t)
+        recs.append(rec)
+    out.update(states=np.stack(states), ts=np.array(ts))
+    out['rho'] = ctrl._factor()
+    out['obst_centers'] = np.stack([t2n(c.center) for c in ctrl.cbfs])
+    out['obst_radii'] = np.array([float(c.radius) for c in ctrl.cbfs])
+    if enable_learning:
+        out['L'] = t2n(reg._cache["perturbed_cholesky"])
+    for i, rec in enumerate(recs):
+        p = 's%d_' % i
+        out[p + 'plan'] = rec['plan']
+        out[p + 'dot_plan'] = rec['dot_plan']
+        for j, name in enumerate(('bfe', 'e', 'V', 'bfv', 'v', 'mean', 'var')):
+            out[p + 'clc_' + name] = rec['clc_raw'][j]
+            out[p + 'cbc_' + name] = np.stack([r[j] for r in rec['cbc_raw']])
+        for j, name in enumerate(('A', 'b', 'c', 'd')):
+            out[p + 'clc_socp_' + name] = rec['clc_socp'][j]
+            out[p + 'cbc_socp_' + name] = np.stack([r[j] for r in rec['cbc_socp']])
+        out[p + 'h'] = np.array(rec['h'])
+        out[p + 'grad_h'] = np.stack(rec['grad_h'])
+        out[p + 'V'] = rec['V']
+        out[p + 'grad_V'] = rec['grad_V']
+        out[p + 'grad_V_goal'] = rec['grad_V_goal']
+        out[p + 'ndraws'] = len(rec['draws'])
+        for k, d in enumerate(rec['draws']):
+            out[p + 'draw%d' % k] = d
+    np.savez_compressed(os.path.join(HERE, 'unicycle_terms_%s.npz' % tag), **out)
+    print('unicycle_terms_%s: learning=%s draws/state=%s' % (
+        tag, enable_learning, [len(r['draws']) for r in recs]))
+
+
+def main():
+    gen_posterior('n2m1_N8', n=2, m=1, N=8, b=3, seed=11, rank_one=False)
+    gen_posterior('n2m1_N64', n=2, m=1, N=64, b=5, seed=12, rank_one=True)
+    gen_posterior('n3m2_N8', n=3, m=2, N=8, b=2, seed=13, rank_one=True)
+    gen_posterior('n3m2_N64', n=3, m=2, N=64, b=4, seed=14, rank_one=False)
+    gen_posterior('n1m2_N16', n=1, m=2, N=16, b=3, seed=15, rank_one=False)
+    gen_unicycle_terms('fixed', N=0, seed=21, enable_learning=False)
+    gen_unicycle_terms('learned_N40', N=40, seed=22, enable_learning=True)
+
+
+if __name__ == '__main__':
+    main()

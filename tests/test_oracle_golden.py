@@ -1,0 +1,157 @@
+"""Pin the CPU oracle against golden vectors recorded from the executed reference
+(tests/golden/gen_golden.py) -- SURVEY.md 8c.  fp64, tolerance 1e-10 relative: it is the same
+arithmetic, only reassociated."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gp_posterior as gp
+from oracle import cbc, unicycle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSTERIOR_FILES = sorted(glob.glob(os.path.join(GOLDEN, "posterior_*.npz")))
+RTOL, ATOL = 1e-9, 1e-11
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_golden_files_present():
+    assert len(POSTERIOR_FILES) >= 5
+
+
+@pytest.mark.parametrize("path", POSTERIOR_FILES, ids=os.path.basename)
+def test_posterior_matches_reference(path):
+    g = np.load(path)
+    X, U, Xdot = g["X"], g["U"], g["Xdot"]
+    A, B, ell, s2, M0 = g["A"], g["B"], g["ell"], float(g["s2"]), g["M0"]
+    st = gp.refit_state(X, U, Xdot, B, ell, s2, M0, g["jitter_rand"])
+    assert st["tries"] == 1
+    close(st["L"], g["L"])
+    UH, Y, L = st["UH"], st["Y"], st["L"]
+    Xt, Ut, Xtp, Utp = g["Xtest"], g["Utest"], g["Xtestp"], g["Utestp"]
+    UHt, UHtp = gp.homogeneous_controls(Ut), gp.homogeneous_controls(Utp)
+    e0 = np.zeros_like(UHt)
+    e0[:, 0] = 1
+
+    # vector-variate view (ControlAffineRegressor.custom_predict)
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt, UHt)
+    close(mean, g["vec_mean"])
+    close(cov, g["vec_cov"])
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt, UHt, Xtp, UHtp)
+    close(mean, g["vec_mean_x"])
+    close(cov, g["vec_cov_x"])
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt, e0)
+    close(mean, g["vec_mean_f"])
+    close(cov, g["vec_cov_f"])
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt, gp.homogeneous_controls(Ut, 0.0))
+    close(mean, g["vec_mean_gu"])
+    close(cov, g["vec_cov_gu"])
+    # single-state views: fu_func_mean / fu_func_knl / covar_fu_f / f_func_knl (:707-818)
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt[:1], UHt[:1], Xtp[:1], UHt[:1])
+    close(mean[0], g["fu_mean1"])
+    close(cov[0], g["fu_knl1"])
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt[:1], UHt[:1], Xtp[:1], e0[:1])
+    close(cov[0], g["covar_fu_f1"])
+    mean, sv, cov = gp.custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt[:1], e0[:1], Xtp[:1], e0[:1])
+    close(cov[0], g["f_knl1"])
+
+    # matrix-variate view (ControlAffineRegressorExact)
+    mean_k, _, BkXX = gp.custom_predict_matrix(X, UH, Y, L, A, B, ell, s2, M0, Xt,
+                                               rand_draws2=g["mat_jitter2"])
+    close(mean_k, g["mat_mean_k"])
+    close(BkXX, g["mat_BkXX"])
+    meanFXU, varFXU = gp.exact_custom_predict(X, UH, Y, L, A, B, ell, s2, M0, Xt, UHt,
+                                              rand_draws2=g["exact_jitter2"])
+    close(meanFXU, g["exact_meanFXU"])
+    close(varFXU, g["exact_varFXU"])
+    fm, fv = gp.custom_predict_fullmat(X, UH, Y, L, A, B, ell, s2, M0, Xt, rand_draws2=g["full_jitter2"])
+    close(fm, g["full_mean"])
+    close(fv, g["full_var"])
+
+    # per-step closed form == the b=1 matrix-variate call, jitter made explicit
+    Mk, Bk = gp.posterior_step(L[None], st["alpha"][None], X[None], st["UHB"][None], ell[None],
+                               np.array([s2]), B[None], M0[None], Xt[:1],
+                               jitter2=1e-5 * g["one_jitter2"][None])
+    close(Mk[0], g["one_mean_k"][0])
+    close(Bk[0], g["one_BkXX"][0, 0])
+
+
+def test_chol_append_equals_refactorisation():
+    g = np.load(POSTERIOR_FILES[0])
+    st = gp.refit_state(g["X"], g["U"], g["Xdot"], g["B"], g["ell"], float(g["s2"]), g["M0"], g["jitter_rand"])
+    Kbp = st["Kbp"]
+    N = Kbp.shape[0]
+    Lnew = gp.chol_append(np.linalg.cholesky(Kbp[:N - 1, :N - 1]), Kbp[N - 1, :N - 1], Kbp[N - 1, N - 1])
+    close(Lnew, st["L"])
+
+
+def _model_at(g, x, draws_jit2):
+    """(Mk, Bk, A, fhat, ghat) of the dynamics model the golden controller used at state x."""
+    fhat = unicycle.ackermann_f(x)
+    ghat = unicycle.ackermann_g(x, float(g["mean_L"]))
+    if not bool(g["enable_learning"]):
+        # AckermannDrive.fu_func_gp: knl = (uh' I uh) diag(kernel_diag_A)  (unicycle_move_to_pose.py:262-275)
+        return np.zeros((3, 3)), np.eye(3), np.diag(g["kernel_diag_A"]), fhat, ghat
+    X, U, Xdot = g["X"], g["U"], g["Xdot"]
+    B, ell, s2, M0 = g["B"], g["ell"], float(g["s2"]), g["M0"]
+    UH = gp.homogeneous_controls(U)
+    L = g["L"]
+    Y = gp.residual_targets(Xdot, UH, M0)
+    alpha = gp.cholesky_solve(Y, L)
+    Mk, Bk = gp.posterior_step(L[None], alpha[None], X[None], (UH @ B)[None], ell[None], np.array([s2]),
+                               B[None], M0[None], x[None], jitter2=1e-5 * draws_jit2[None])
+    return Mk[0], Bk[0], g["A"], fhat, ghat
+
+
+@pytest.mark.parametrize("tag", ["fixed", "learned_N40"])
+def test_unicycle_constraint_terms_match_reference(tag):
+    g = np.load(os.path.join(GOLDEN, "unicycle_terms_%s.npz" % tag))
+    learning = bool(g["enable_learning"])
+    planner = unicycle.PiecewiseLinearPlanner(g["x0"], g["xg"], int(g["numSteps"]), float(g["dt"]),
+                                              float(g["frac_time_to_reach_goal"]))
+    clf = unicycle.CLFCartesian(g["Kp"])
+    cbfs = unicycle.obstacles_at_mid_from_start_and_goal(g["x0"], g["xg"], tuple(g["term_weights"]))
+    close(np.stack([c.center for c in cbfs]), g["obst_centers"])
+    close(np.array([c.radius for c in cbfs]), g["obst_radii"])
+    close(cbc.cbc1_safety_factor(float(g["max_risk"])), float(g["rho"]))
+    for i, (x, t) in enumerate(zip(g["states"], g["ts"])):
+        p = "s%d_" % i
+        t = int(t)
+        plan, dplan = planner.plan(t), planner.dot_plan(t)
+        close(plan, g[p + "plan"])
+        close(dplan, g[p + "dot_plan"])
+        close(clf.clf(x, plan), g[p + "V"])
+        close(clf.grad_clf(x, plan), g[p + "grad_V"])
+        close(clf.grad_clf_wrt_goal(x, plan), g[p + "grad_V_goal"])
+        close([c.cbf(x) for c in cbfs], g[p + "h"])
+        close(np.stack([c.grad_cbf(x) for c in cbfs]), g[p + "grad_h"])
+        draws = [g[p + "draw%d" % k] for k in range(int(g[p + "ndraws"]))]
+        if learning and i == 0:
+            assert draws[1].shape == (g["X"].shape[0],)      # the K_b jitter of the cached Cholesky
+            draws = [draws[0]] + draws[2:]
+        # per constraint: [u0, jitter2 of the differentiated evaluation, jitter2 of the returned var]
+        per = 3 if learning else 1
+        zero = np.zeros(3)
+        # CLC: -(grad_V'(f+gu) + grad_goal_V' xdot_plan + gamma V)   (:880-899)
+        j2 = draws[1] if learning else zero
+        Mk, Bk, A, fhat, ghat = _model_at(g, x, j2)
+        const = clf.grad_clf_wrt_goal(x, plan) @ dplan + float(g["clf_gamma"]) * clf.clf(x, plan)
+        bfe, e, V, bfv, v = cbc.reldeg1_terms(Mk, Bk, A, clf.grad_clf(x, plan), const, fhat, ghat, sign=-1.0)
+        for name, val in zip(("bfe", "e", "V", "bfv", "v"), (bfe, e, V, bfv, v)):
+            close(val, g[p + "clc_" + name], rtol=1e-8, atol=1e-10)
+        Ac, bc, cc, dc = cbc.convert_cbc_terms_to_socp_terms(bfe, e, V, bfv, v, 0)
+        for name, val in zip(("A", "b", "c", "d"), (Ac, bc, cc, dc)):
+            close(val, g[p + "clc_socp_" + name], rtol=1e-8, atol=1e-10)
+        for k, (cbf_k, gam) in enumerate(zip(cbfs, g["cbf_gammas"])):
+            j2 = draws[per * (k + 1) + 1] if learning else zero
+            Mk, Bk, A, fhat, ghat = _model_at(g, x, j2)
+            bfe, e, V, bfv, v = cbc.reldeg1_terms(Mk, Bk, A, cbf_k.grad_cbf(x), gam * cbf_k.cbf(x), fhat, ghat)
+            for name, val in zip(("bfe", "e", "V", "bfv", "v"), (bfe, e, V, bfv, v)):
+                close(val, g[p + "cbc_" + name][k], rtol=1e-8, atol=1e-10)
+            Ac, bc, cc, dc = cbc.convert_cbc_terms_to_socp_terms(bfe, e, V, bfv, v, 0)
+            for name, val in zip(("A", "b", "c", "d"), (Ac, bc, cc, dc)):
+                close(val, g[p + "cbc_socp_" + name][k], rtol=1e-8, atol=1e-10)
