@@ -1,0 +1,71 @@
+"""ctypes binding of libbcbf.so (the C ABI of include/bcbf.h).  No fallbacks: if the HIP library
+is missing or does not export a symbol, importing this module raises."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the ROCm runtime first so libbcbf binds to the same libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbcbf.so")
+
+c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+c_float, c_double = ctypes.c_float, ctypes.c_double
+P = c_void_p
+
+# name -> (restype, argtypes); "{T}" entries are instantiated for f32 (c_float) and f64 (c_double)
+_SIGS = {
+    "bcbf_version": (c_int, []),
+    "bcbf_last_error": (ctypes.c_char_p, []),
+    "bcbf_lop_elems_f32": (c_size_t, [c_int]),
+    "bcbf_lop_elems_f64": (c_size_t, [c_int]),
+    "bcbf_coneqp_f64": (c_int, [P, P, P, P, c_int, c_int, ctypes.POINTER(c_int), c_int, P, P, P, c_int, c_int, P]),
+}
+_TSIGS = {
+    "bcbf_kb_build": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_refit": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_potrf": [P, P, P, P, c_int, c_int, P],
+    "bcbf_potrs": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_chol_append": [P, P, P, P, P, c_int, c_int, P],
+    "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_socp": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_unicycle_constraints": [P, P, P, P, "T", P, P, P, P, "T", P, P, P, P, c_int, c_int, P],
+    "bcbf_unicycle_step": [P, P, "T", "T", c_int, P],
+}
+
+
+def declared_symbols():
+    names = list(_SIGS)
+    for base in _TSIGS:
+        names += [base + "_f32", base + "_f64"]
+    return names
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libbcbf.so not found at %s -- build it with `python -m bayesian_cbf_amd.build` "
+            "(hipcc, --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for base, args in _TSIGS.items():
+        for suf, ct in (("_f32", c_float), ("_f64", c_double)):
+            fn = getattr(lib, base + suf)
+            fn.restype = c_int
+            fn.argtypes = [ct if a == "T" else a for a in args]
+    return lib
+
+
+lib = _load()
+
+
+class BcbfError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.bcbf_last_error().decode() if rc == -2 else "invalid argument"
+        raise BcbfError("%s failed (rc=%d): %s" % (what, rc, msg))

@@ -1,0 +1,69 @@
+"""Build libbcbf.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m bayesian_cbf_amd.build          # incremental; --force rebuilds everything
+
+hipcc cross-compiles without a GPU.  The shared object is written next to this file so that
+it travels with the source tree to the GPU box and shows up as an in-tree native library.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libbcbf.so")
+ARCH = "gfx950"
+SOURCES = ["common.hip", "posterior_step.hip", "refit.hip", "solve.hip", "cbc_terms.hip", "socp.hip",
+           "unicycle.hip"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+         "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(a, bs):
+    if not os.path.exists(a):
+        return False
+    ta = os.path.getmtime(a)
+    return all(os.path.getmtime(b) <= ta for b in bs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "bcbf_common.h"), os.path.join(ROOT, "include", "bcbf.h")]
+    if not force and _newer(obj, deps):
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in results]
+    if force or any(changed for _, changed in results) or not _newer(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,249 @@
+// K4+K5+K6+K7: per-instance GP posterior query -- the HBM-bound hot kernel of the control step.
+//
+// One workgroup per independent instance.  Thread t owns the mirrored pair of V-row blocks
+// (t, nrb-1-t) of the forward substitution  W = L^-1 Phi,  so every lane streams the same
+// number of bytes of the packed operator (include/bcbf.h "Lop": column-major, 32x32 diagonal
+// blocks pre-inverted).  Per 32-column block J:
+//   1. owners of rows in J publish their residual r_J to LDS,
+//   2. wave 0 forms w_J = inv(L_JJ) r_J (a 32x32 triangular mat-vec, 16 columns per half-wave),
+//      accumulates the Gram W'W (fp64) and Vw'W, and publishes w_J,
+//   3. every lane subtracts L[rows below, J] w_J from its residuals: one 16-byte load per lane
+//      per column (contiguous across the wave), w_J broadcast from LDS.
+// Algorithmic HBM bytes per instance: sizeof(T) * [Np(Np+V)/2 + N(2n + C)]  (Lop + X + Vw + UHB).
+#include "bcbf_common.h"
+
+namespace bcbf {
+
+template <typename T> __device__ inline T texp(T x);
+template <> __device__ inline float texp<float>(float x) { return expf(x); }
+template <> __device__ inline double texp<double>(double x) { return exp(x); }
+
+template <typename T, int C>
+__global__ void __launch_bounds__(256)
+posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
+                      const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
+                      const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
+                      const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
+                      int N, int Np, int n) {
+    constexpr int V = Vec<T>::V;
+    using VecT = typename Vec<T>::type;
+    constexpr int RPB = NB / V;          // row blocks per diagonal block
+    constexpr int CP = 4;                // padded RHS count in LDS
+    constexpr int NG = C * (C + 1) / 2;
+    __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
+    __shared__ __attribute__((aligned(16))) T wbuf[NB][CP];
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nrb = Np / V;
+    const int npairs = nrb / 2;
+    const bool live = tid < npairs;
+    const int rbA = tid, rbB = nrb - 1 - tid;
+    const T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const T* __restrict__ Xb = X + (size_t)b * N * n;
+    const T* __restrict__ UHBb = UHB + (size_t)b * N * C;
+    const T* __restrict__ Vwb = Vw + (size_t)b * N * n;
+
+    // ---- prologue: r = Phi rows owned by this thread:  phi_i = s2 exp(-1/2 |(x_i - xq)/ell|^2) * UHB_i
+    T xqr[BCBF_MAX_STATE_DIM], iell[BCBF_MAX_STATE_DIM];
+#pragma unroll
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+        xqr[d] = d < n ? xq[(size_t)b * n + d] : T(0);
+        iell[d] = d < n ? T(1) / ell[(size_t)b * n + d] : T(0);
+    }
+    const T s2 = s2p[b];
+    T acc[2][V][C];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int rb = r == 0 ? rbA : rbB;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int i = rb * V + v;
+            T k = T(0);
+            if (live && i < N) {
+                T d2 = T(0);
+#pragma unroll
+                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                    if (d < n) { const T z = (Xb[(size_t)i * n + d] - xqr[d]) * iell[d]; d2 += z * z; }
+                k = s2 * texp<T>(T(-0.5) * d2);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[r][v][c] = (live && i < N) ? k * UHBb[(size_t)i * C + c] : T(0);
+        }
+    }
+
+    double gram[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) gram[g] = 0.0;
+    T mk[BCBF_MAX_STATE_DIM][C];
+#pragma unroll
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+#pragma unroll
+        for (int c = 0; c < C; ++c) mk[d][c] = T(0);
+
+    const int nblk = Np / NB;
+    for (int J = 0; J < nblk; ++J) {
+        const int row0 = J * NB;
+        // 1. publish r_J
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int rb = r == 0 ? rbA : rbB;
+            if (live && rb / RPB == J) {
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) rbuf[rb * V + v - row0][c] = acc[r][v][c];
+            }
+        }
+        __syncthreads();
+        // 2. diagonal block: w_J = inv(L_JJ) r_J  (wave 0; lane = (row i, column half h))
+        if (tid < 64) {
+            const int i = tid & 31, h = tid >> 5;
+            T w[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) w[c] = T(0);
+#pragma unroll
+            for (int q = 0; q < NB / 2; ++q) {
+                const int jj = h * (NB / 2) + q;
+                const int j = row0 + jj;
+                if (i >= (jj / V) * V) {
+                    const T val = lop[lop_base<V>(j, Np) + row0 + i];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) w[c] += val * rbuf[jj][c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) w[c] += __shfl_xor(w[c], 32, 64);
+            if (h == 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) wbuf[i][c] = w[c];
+                int g = 0;
+#pragma unroll
+                for (int a = 0; a < C; ++a)
+#pragma unroll
+                    for (int c = a; c < C; ++c) gram[g++] += (double)w[a] * (double)w[c];
+                const int row = row0 + i;
+                if (row < N) {
+#pragma unroll
+                    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                        if (d < n) {
+                            const T vw = Vwb[(size_t)row * n + d];
+#pragma unroll
+                            for (int c = 0; c < C; ++c) mk[d][c] += vw * w[c];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        // 3. rows below the block:  r -= L[:, J] w_J
+        const int rbmin = (J + 1) * RPB;
+        const bool actA = live && rbA >= rbmin;
+        const bool actB = live && rbB >= rbmin;
+        if (J + 1 < nblk) {
+            constexpr int UNR = 8;
+            for (int jj0 = 0; jj0 < NB; jj0 += UNR) {
+                VecT la[UNR], lb[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int base = lop_base<V>(row0 + jj0 + u, Np);
+                    if (actA) la[u] = *reinterpret_cast<const VecT*>(lop + base + rbA * V);
+                    if (actB) lb[u] = *reinterpret_cast<const VecT*>(lop + base + rbB * V);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    T wj[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) wj[c] = wbuf[jj0 + u][c];
+                    const T* pa = reinterpret_cast<const T*>(&la[u]);
+                    const T* pb = reinterpret_cast<const T*>(&lb[u]);
+                    if (actA) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[0][v][c] -= pa[v] * wj[c];
+                    }
+                    if (actB) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[1][v][c] -= pb[v] * wj[c];
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
+    if (tid < 64) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gram[g] = wave_sum(gram[g]);
+#pragma unroll
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+            if (d < n) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) mk[d][c] = wave_sum(mk[d][c]);
+            }
+        if (tid == 0) {
+            const T* M0b = M0 + (size_t)b * C * n;
+            T* Mkb = Mk + (size_t)b * n * C;
+#pragma unroll
+            for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                if (d < n) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) Mkb[d * C + c] = M0b[c * n + d] + mk[d][c];
+                }
+            const T* Bmb = Bm + (size_t)b * C * C;
+            T* Bkb = Bk + (size_t)b * C * C;
+            int g = 0;
+#pragma unroll
+            for (int a = 0; a < C; ++a)
+#pragma unroll
+                for (int c = a; c < C; ++c) {
+                    const double G = gram[g++];
+                    double v1 = (double)s2 * (double)Bmb[a * C + c] - G;
+                    double v2 = (double)s2 * (double)Bmb[c * C + a] - G;
+                    if (a == c && jitter2 != nullptr) { v1 += (double)jitter2[(size_t)b * C + a]; v2 = v1; }
+                    Bkb[a * C + c] = (T)v1;
+                    Bkb[c * C + a] = (T)v2;
+                }
+        }
+    }
+}
+
+template <typename T>
+static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
+                                 const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
+                                 int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    constexpr int V = Vec<T>::V;
+    const int Np = round_up(N, NB);
+    const int npairs = Np / V / 2;
+    const int threads = round_up(npairs, 64);
+    if (threads > 256) return BCBF_EINVAL;   // N <= 2048 (f32) / 1024 (f64)
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(Bt), block(threads);
+    switch (m) {
+        case 1: hipLaunchKernelGGL((posterior_step_kernel<T, 2>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n); break;
+        case 2: hipLaunchKernelGGL((posterior_step_kernel<T, 3>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n); break;
+        case 3: hipLaunchKernelGGL((posterior_step_kernel<T, 4>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n); break;
+        default: return BCBF_EINVAL;
+    }
+    return check_launch("posterior_step");
+}
+
+}  // namespace bcbf
+
+extern "C" int bcbf_posterior_step_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                       const float* ell, const float* s2, const float* Bm, const float* M0,
+                                       const float* xq, const float* jitter2, float* Mk, float* Bk,
+                                       int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Bt, N, n, m, stream);
+}
+extern "C" int bcbf_posterior_step_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                       const double* ell, const double* s2, const double* Bm, const double* M0,
+                                       const double* xq, const double* jitter2, double* Mk, double* Bk,
+                                       int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Bt, N, n, m, stream);
+}

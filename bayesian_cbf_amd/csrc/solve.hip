@@ -1,0 +1,303 @@
+// K3: triangular solves against the packed operator (refit path, once per refit).
+//   forward :  Vw    = L^-1 Y,      Y = Xdot - UH M0
+//   backward:  alpha = L^-T Vw  (= K_b^-1 Y)
+// Thread-per-row; the 32x32 diagonal blocks are stored inverted, so each block step is a
+// mat-vec, and the rows below / columns above are reached with loads that are contiguous
+// across the workgroup (the operator is column-major).
+#include "bcbf_common.h"
+
+namespace bcbf {
+
+constexpr int ST = 256;
+constexpr int SMAXR = 8;                       // rows per thread (N <= 2048)
+constexpr int SC = BCBF_MAX_STATE_DIM;         // max RHS columns
+
+template <typename T>
+__device__ inline void block_sum(T* vals, int count, T* scratch /* [4][SC] */) {
+    // sum `count` (<= SC) values over the 256-thread workgroup; result valid in every thread
+    for (int c = 0; c < count; ++c) vals[c] = wave_sum(vals[c]);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < count; ++c) scratch[w * SC + c] = vals[c];
+    __syncthreads();
+    for (int c = 0; c < count; ++c)
+        vals[c] = scratch[c] + scratch[SC + c] + scratch[2 * SC + c] + scratch[3 * SC + c];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(ST)
+potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __restrict__ UH,
+             const T* __restrict__ M0, T* __restrict__ Vw, T* __restrict__ alpha, int N, int Np, int n, int C) {
+    constexpr int V = Vec<T>::V;
+    __shared__ T rbuf[NB][SC];
+    __shared__ T wbuf[NB][SC];
+    __shared__ T scratch[4 * SC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const int rpt = (Np + ST - 1) / ST;
+    const int nblk = Np / NB;
+
+    // ---- Y rows owned by this thread
+    T y[SMAXR][SC];
+#pragma unroll
+    for (int r = 0; r < SMAXR; ++r) {
+        const int i = tid + r * ST;
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            T v = T(0);
+            if (r < rpt && i < N && c < n) {
+                v = Xdot[((size_t)b * N + i) * n + c];
+                for (int a = 0; a < C; ++a) v -= UH[((size_t)b * N + i) * C + a] * M0[((size_t)b * C + a) * n + c];
+            }
+            y[r][c] = v;
+        }
+    }
+    // ---- forward substitution
+    for (int J = 0; J < nblk; ++J) {
+        const int col0 = J * NB;
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i >= col0 && i < col0 + NB) {
+#pragma unroll
+                for (int c = 0; c < SC; ++c) rbuf[i - col0][c] = y[r][c];
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            T w[SC];
+#pragma unroll
+            for (int c = 0; c < SC; ++c) w[c] = T(0);
+            for (int jj = 0; jj <= tid; ++jj) {
+                const T val = lop[lop_base<V>(col0 + jj, Np) + col0 + tid];
+#pragma unroll
+                for (int c = 0; c < SC; ++c) w[c] += val * rbuf[jj][c];
+            }
+#pragma unroll
+            for (int c = 0; c < SC; ++c) wbuf[tid][c] = w[c];
+            if (col0 + tid < N)
+                for (int c = 0; c < n; ++c) Vw[((size_t)b * N + col0 + tid) * n + c] = w[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i >= col0 + NB && i < Np) {
+                for (int jj = 0; jj < NB; ++jj) {
+                    const T val = lop[lop_base<V>(col0 + jj, Np) + i];
+#pragma unroll
+                    for (int c = 0; c < SC; ++c) y[r][c] -= val * wbuf[jj][c];
+                }
+            }
+            if (r < rpt && i >= col0 && i < col0 + NB) {   // keep Vw rows in registers for the backward pass
+#pragma unroll
+                for (int c = 0; c < SC; ++c) y[r][c] = wbuf[i - col0][c];
+            }
+        }
+        __syncthreads();
+    }
+    if (alpha == nullptr) return;
+
+    // ---- backward substitution: y holds Vw rows; solved rows are overwritten with alpha
+    for (int J = nblk - 1; J >= 0; --J) {
+        const int col0 = J * NB;
+        // t_J[jj] = Vw[jj] - sum_{i in blocks > J} L[i][col0+jj] alpha[i]
+        for (int jj = 0; jj < NB; ++jj) {
+            T s[SC];
+#pragma unroll
+            for (int c = 0; c < SC; ++c) s[c] = T(0);
+            const int base = lop_base<V>(col0 + jj, Np);
+#pragma unroll
+            for (int r = 0; r < SMAXR; ++r) {
+                const int i = tid + r * ST;
+                if (r < rpt && i >= col0 + NB && i < Np) {
+                    const T val = lop[base + i];
+#pragma unroll
+                    for (int c = 0; c < SC; ++c) s[c] += val * y[r][c];
+                }
+            }
+            block_sum(s, n, scratch);
+            if (tid == 0)
+                for (int c = 0; c < SC; ++c) rbuf[jj][c] = c < n ? s[c] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i >= col0 && i < col0 + NB) {
+#pragma unroll
+                for (int c = 0; c < SC; ++c) rbuf[i - col0][c] = y[r][c] - rbuf[i - col0][c];
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {   // alpha_J = inv(L_JJ)^T t_J : lane jj walks its own (contiguous) column
+            T a[SC];
+#pragma unroll
+            for (int c = 0; c < SC; ++c) a[c] = T(0);
+            const int base = lop_base<V>(col0 + tid, Np) + col0;
+            for (int ii = tid; ii < NB; ++ii) {
+                const T val = lop[base + ii];
+#pragma unroll
+                for (int c = 0; c < SC; ++c) a[c] += val * rbuf[ii][c];
+            }
+#pragma unroll
+            for (int c = 0; c < SC; ++c) wbuf[tid][c] = a[c];
+            if (col0 + tid < N)
+                for (int c = 0; c < n; ++c) alpha[((size_t)b * N + col0 + tid) * n + c] = a[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i >= col0 && i < col0 + NB) {
+#pragma unroll
+                for (int c = 0; c < SC; ++c) y[r][c] = wbuf[i - col0][c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+static int launch_potrs(const T* Lop, const T* Xdot, const T* UH, const T* M0, T* Vw, T* alpha,
+                        int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !Xdot || !UH || !M0 || !Vw) return BCBF_EINVAL;
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    const int Np = round_up(N, NB);
+    if (Np > ST * SMAXR) return BCBF_EINVAL;
+    hipLaunchKernelGGL((potrs_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Xdot, UH, M0, Vw, alpha,
+                       N, Np, n, m + 1);
+    return check_launch("potrs");
+}
+
+
+// --------------------------------------------------------------------------------------------
+// K11: bordered Cholesky -- append one training point to the packed operator.
+//   l = L^-1 knew,  d = sqrt(kappa - l'l);  new last row of L = [l', d].
+// The new row lands in diagonal block J* = N/32: its inverse gains the row
+// [-(1/d) l_J*' inv(L_J*J*), 1/d]; every other stored element is copied (re-laid out when the
+// padded size grows by a block).
+template <typename T>
+__global__ void __launch_bounds__(ST)
+chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const T* __restrict__ kappa,
+                   T* __restrict__ Lout, int* __restrict__ info, int N, int NpI, int NpO) {
+    constexpr int V = Vec<T>::V;
+    __shared__ T rbuf[NB];
+    __shared__ T wbuf[NB];
+    __shared__ T lrow[ST * SMAXR];      // l, all rows
+    __shared__ T scratch[4 * SC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* __restrict__ lin = Lin + (size_t)b * lop_elems<V>(NpI);
+    T* __restrict__ lout = Lout + (size_t)b * lop_elems<V>(NpO);
+    const int rpt = (NpI + ST - 1) / ST;
+    const int nblk = NpI / NB;
+
+    // ---- forward solve l = L^-1 knew on the old operator
+    T y[SMAXR];
+#pragma unroll
+    for (int r = 0; r < SMAXR; ++r) {
+        const int i = tid + r * ST;
+        y[r] = (r < rpt && i < N) ? knew[(size_t)b * N + i] : T(0);
+    }
+    for (int J = 0; J < nblk; ++J) {
+        const int col0 = J * NB;
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i >= col0 && i < col0 + NB) rbuf[i - col0] = y[r];
+        }
+        __syncthreads();
+        if (tid < NB) {
+            T w = T(0);
+            for (int jj = 0; jj <= tid; ++jj) w += lin[lop_base<V>(col0 + jj, NpI) + col0 + tid] * rbuf[jj];
+            wbuf[tid] = w;
+            lrow[col0 + tid] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i >= col0 + NB && i < NpI) {
+                T acc = y[r];
+                for (int jj = 0; jj < NB; ++jj) acc -= lin[lop_base<V>(col0 + jj, NpI) + i] * wbuf[jj];
+                y[r] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    T ss[SC];
+#pragma unroll
+    for (int c = 0; c < SC; ++c) ss[c] = T(0);
+    for (int i = tid; i < N; i += ST) ss[0] += lrow[i] * lrow[i];
+    block_sum(ss, 1, scratch);
+    const T d2 = kappa[b] - ss[0];
+    const bool ok = d2 > T(0);
+    const T d = ok ? (T)sqrt((double)d2) : T(1);
+    if (tid == 0) info[b] = ok ? 0 : N + 1;
+
+    // ---- copy / re-layout the old operator
+    if (lout != lin) {
+        for (int j = 0; j < NpO; ++j) {
+            const int first = (j / V) * V;
+            const int bo = lop_base<V>(j, NpO);
+            if (j < NpI) {
+                const int bi = lop_base<V>(j, NpI);
+                for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i < NpI ? lin[bi + i] : T(0);
+            } else {
+                for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i == j ? T(1) : T(0);
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the new row N
+    const int Js = N / NB, col0 = Js * NB, rr = N - col0;
+    for (int j = tid; j < col0; j += ST) lout[lop_base<V>(j, NpO) + N] = lrow[j];
+    if (tid <= rr) {
+        const int jj = tid;          // column inside the diagonal block
+        T val;
+        if (jj == rr) val = T(1) / d;
+        else {
+            T acc = T(0);
+            for (int ii = jj; ii < rr; ++ii) acc += lrow[col0 + ii] * lout[lop_base<V>(col0 + jj, NpO) + col0 + ii];
+            val = -acc / d;
+        }
+        lout[lop_base<V>(col0 + jj, NpO) + N] = val;
+    }
+}
+
+template <typename T>
+static int launch_chol_append(const T* Lin, const T* knew, const T* kappa, T* Lout, int* info, int Bt, int N,
+                              void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lin || !knew || !kappa || !Lout || !info || N < 1) return BCBF_EINVAL;
+    const int NpI = round_up(N, NB), NpO = round_up(N + 1, NB);
+    if (NpO > ST * SMAXR) return BCBF_EINVAL;
+    if (Lin == Lout && NpI != NpO) return BCBF_EINVAL;
+    hipLaunchKernelGGL((chol_append_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, knew, kappa, Lout,
+                       info, N, NpI, NpO);
+    return check_launch("chol_append");
+}
+
+}  // namespace bcbf
+
+extern "C" {
+int bcbf_potrs_f32(const float* Lop, const float* Xdot, const float* UH, const float* M0,
+                   float* Vw, float* alpha, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_potrs<float>(Lop, Xdot, UH, M0, Vw, alpha, Bt, N, n, m, stream);
+}
+int bcbf_potrs_f64(const double* Lop, const double* Xdot, const double* UH, const double* M0,
+                   double* Vw, double* alpha, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_potrs<double>(Lop, Xdot, UH, M0, Vw, alpha, Bt, N, n, m, stream);
+}
+int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
+                         int* info, int Bt, int N, void* stream) {
+    return bcbf::launch_chol_append<float>(Lop_in, knew, kappa, Lop_out, info, Bt, N, stream);
+}
+int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double* kappa, double* Lop_out,
+                         int* info, int Bt, int N, void* stream) {
+    return bcbf::launch_chol_append<double>(Lop_in, knew, kappa, Lop_out, info, Bt, N, stream);
+}
+}

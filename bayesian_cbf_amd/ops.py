@@ -1,0 +1,225 @@
+"""Thin host wrappers over the C ABI: torch tensors in, torch tensors out, on the caller's HIP
+stream.  PyTorch is only the allocator / stream provider here; all arithmetic is in libbcbf."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_SUF = {torch.float32: "_f32", torch.float64: "_f64"}
+
+
+def _suf(t):
+    try:
+        return _SUF[t.dtype]
+    except KeyError:
+        raise TypeError("libbcbf supports float32 / float64 tensors, got %s" % t.dtype)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _chk(*ts):
+    ref = ts[0]
+    if not ref.is_cuda:
+        raise RuntimeError("libbcbf kernels need ROCm device tensors (got a CPU tensor); there is no CPU path")
+    for t in ts:
+        if t is None:
+            continue
+        if t.device != ref.device:
+            raise RuntimeError("all tensors must live on the same device")
+        if t.dtype not in (ref.dtype, torch.int32):
+            raise TypeError("mixed dtypes: %s vs %s" % (t.dtype, ref.dtype))
+        if not t.is_contiguous():
+            raise RuntimeError("libbcbf needs contiguous row-major tensors")
+
+
+def lop_elems(N, dtype):
+    return int(getattr(lib, "bcbf_lop_elems" + _SUF[dtype])(N))
+
+
+def kb_build(X, UH, Bm, ell, s2, jitter=None):
+    """K_b[Bt,N,N]  (control_affine_model.py:370-372 + make_psd diagonal :907-910)."""
+    _chk(X, UH, Bm, ell, s2, jitter)
+    Bt, N, n = X.shape
+    m = UH.shape[2] - 1
+    Kb = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device)
+    check(getattr(lib, "bcbf_kb_build" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Kb),
+                                                  Bt, N, n, m, _stream(X)), "bcbf_kb_build")
+    return Kb
+
+
+def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False):
+    """Fused K_b build + Cholesky + packing.  Returns (Lop[Bt,E], UHB[Bt,N,C], info[Bt], Ldense|None)."""
+    _chk(X, UH, Bm, ell, s2, jitter)
+    Bt, N, n = X.shape
+    C = UH.shape[2]
+    Lop = torch.empty(Bt, lop_elems(N, X.dtype), dtype=X.dtype, device=X.device)
+    UHB = torch.empty(Bt, N, C, dtype=X.dtype, device=X.device)
+    info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+    Ld = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device) if want_dense else None
+    check(getattr(lib, "bcbf_refit" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
+                                               _p(Ld), _p(info), Bt, N, n, C - 1, _stream(X)), "bcbf_refit")
+    return Lop, UHB, info, Ld
+
+
+def potrf(Kb, want_dense=False):
+    """Cholesky of caller-supplied SPD matrices (torch.linalg.cholesky, control_affine_model.py:911)."""
+    _chk(Kb)
+    Bt, N, _ = Kb.shape
+    Lop = torch.empty(Bt, lop_elems(N, Kb.dtype), dtype=Kb.dtype, device=Kb.device)
+    info = torch.empty(Bt, dtype=torch.int32, device=Kb.device)
+    Ld = torch.empty(Bt, N, N, dtype=Kb.dtype, device=Kb.device) if want_dense else None
+    check(getattr(lib, "bcbf_potrf" + _suf(Kb))(_p(Kb), _p(Lop), _p(Ld), _p(info), Bt, N, _stream(Kb)), "bcbf_potrf")
+    return Lop, info, Ld
+
+
+def potrs(Lop, Xdot, UH, M0, want_alpha=True):
+    """Vw = L^-1 (Xdot - UH M0), alpha = K_b^-1 (Xdot - UH M0)  (control_affine_model.py:525-545)."""
+    _chk(Lop, Xdot, UH, M0)
+    Bt, N, n = Xdot.shape
+    m = UH.shape[2] - 1
+    Vw = torch.empty(Bt, N, n, dtype=Xdot.dtype, device=Xdot.device)
+    alpha = torch.empty_like(Vw) if want_alpha else None
+    check(getattr(lib, "bcbf_potrs" + _suf(Xdot))(_p(Lop), _p(Xdot), _p(UH), _p(M0), _p(Vw), _p(alpha),
+                                                  Bt, N, n, m, _stream(Xdot)), "bcbf_potrs")
+    return Vw, alpha
+
+
+def chol_append(Lop, knew, kappa, N):
+    _chk(Lop, knew, kappa)
+    Bt = Lop.shape[0]
+    out = torch.empty(Bt, lop_elems(N + 1, Lop.dtype), dtype=Lop.dtype, device=Lop.device)
+    info = torch.empty(Bt, dtype=torch.int32, device=Lop.device)
+    check(getattr(lib, "bcbf_chol_append" + _suf(Lop))(_p(Lop), _p(knew), _p(kappa), _p(out), _p(info), Bt, N,
+                                                       _stream(Lop)), "bcbf_chol_append")
+    return out, info
+
+
+def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None):
+    """(Mk[Bt,n,C], Bk[Bt,C,C]) at one query per instance  (control_affine_model.py:1051-1091, b=1)."""
+    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)
+    Bt, N, n = X.shape
+    C = UHB.shape[2]
+    if out is None:
+        Mk = torch.empty(Bt, n, C, dtype=X.dtype, device=X.device)
+        Bk = torch.empty(Bt, C, C, dtype=X.dtype, device=X.device)
+    else:
+        Mk, Bk = out
+    check(getattr(lib, "bcbf_posterior_step" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm),
+                                                        _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk), Bt, N, n, C - 1,
+                                                        _stream(X)), "bcbf_posterior_step")
+    return Mk, Bk
+
+
+def terms_width(m):
+    return m + 1 + m * m + m + 1
+
+
+def cone_width(m):
+    return (m + 1) * m + (m + 1) + m + 1
+
+
+def cbc_terms(Mk, Bk, A, grad, cst, sign, fhat, ghat, want_terms=True, out=None):
+    """Rel-degree-1 constraint terms + cone form (cbc2.py:7-23, unicycle_move_to_pose.py:837-916)."""
+    _chk(Mk, Bk, A, grad, cst, sign, fhat, ghat)
+    Bt, K, n = grad.shape
+    m = ghat.shape[2]
+    if out is None:
+        terms = torch.empty(Bt, K, terms_width(m), dtype=Mk.dtype, device=Mk.device) if want_terms else None
+        cones = torch.empty(Bt, K, cone_width(m), dtype=Mk.dtype, device=Mk.device)
+        cstatus = torch.empty(Bt, K, dtype=torch.int32, device=Mk.device)
+    else:
+        terms, cones, cstatus = out
+    check(getattr(lib, "bcbf_cbc_terms" + _suf(Mk))(_p(Mk), _p(Bk), _p(A), _p(grad), _p(cst), _p(sign), _p(fhat),
+                                                    _p(ghat), _p(terms), _p(cones), _p(cstatus), Bt, K, n, m,
+                                                    _stream(Mk)), "bcbf_cbc_terms")
+    return terms, cones, cstatus
+
+
+def unpack_terms(terms, m):
+    o = 0
+    bfe = terms[..., o:o + m]; o += m
+    e = terms[..., o]; o += 1
+    V = terms[..., o:o + m * m].reshape(*terms.shape[:-1], m, m); o += m * m
+    bfv = terms[..., o:o + m]; o += m
+    v = terms[..., o]
+    return bfe, e, V, bfv, v
+
+
+def unpack_cones(cones, m):
+    o = 0
+    A = cones[..., o:o + (m + 1) * m].reshape(*cones.shape[:-1], m + 1, m); o += (m + 1) * m
+    b = cones[..., o:o + m + 1]; o += m + 1
+    c = cones[..., o:o + m]; o += m
+    d = cones[..., o]
+    return A, b, c, d
+
+
+def pack_cones(A, b, c, d):
+    lead = A.shape[:-2]
+    return torch.cat([A.reshape(*lead, -1), b, c, d.reshape(*lead, 1)], dim=-1).contiguous()
+
+
+def socp(w, r, cones, relax_mask, rho, max_iters=100, out=None):
+    """The CLF-CBF program of ControllerCLFBayesian.control (unicycle_move_to_pose.py:926-953).
+    Returns (y[Bt,m+1] = [u, relax], status[Bt], iters[Bt])."""
+    _chk(w, r, cones, relax_mask, rho)
+    Bt, K, _ = cones.shape
+    m = r.shape[1]
+    if out is None:
+        y = torch.empty(Bt, m + 1, dtype=w.dtype, device=w.device)
+        status = torch.empty(Bt, dtype=torch.int32, device=w.device)
+        iters = torch.empty(Bt, dtype=torch.int32, device=w.device)
+    else:
+        y, status, iters = out
+    check(getattr(lib, "bcbf_socp" + _suf(w))(_p(w), _p(r), _p(cones), _p(relax_mask), _p(rho), _p(y), _p(status),
+                                              _p(iters), Bt, K, m, max_iters, _stream(w)), "bcbf_socp")
+    return y, status, iters
+
+
+def coneqp(P, q, G, h, l, qdims, max_iters=100):
+    """Generic small cone QP, fp64 (optimizers.py:42-116)."""
+    _chk(P, q, G, h)
+    if P.dtype != torch.float64:
+        raise TypeError("coneqp is fp64 only")
+    Bt, nv = q.shape
+    qd = (ctypes.c_int * max(1, len(qdims)))(*qdims)
+    x = torch.empty(Bt, nv, dtype=P.dtype, device=P.device)
+    status = torch.empty(Bt, dtype=torch.int32, device=P.device)
+    iters = torch.empty(Bt, dtype=torch.int32, device=P.device)
+    check(lib.bcbf_coneqp_f64(_p(P), _p(q), _p(G), _p(h), nv, l, qd, len(qdims), _p(x), _p(status), _p(iters), Bt,
+                              max_iters, _stream(P)), "bcbf_coneqp")
+    return x, status, iters
+
+
+def unicycle_constraints(x, plan, dot_plan, Kp, clf_gamma, centers, radii, tw, gammas, L_mean, out=None):
+    """CLC row + obstacle rows: (grad[Bt,1+Kob,3], cst[Bt,1+Kob], fhat[Bt,3], ghat[Bt,3,2])."""
+    _chk(x, plan, dot_plan, Kp, centers, radii, tw, gammas)
+    Bt = x.shape[0]
+    Kob = 0 if centers is None else centers.shape[1]
+    if out is None:
+        grad = torch.empty(Bt, 1 + Kob, 3, dtype=x.dtype, device=x.device)
+        cst = torch.empty(Bt, 1 + Kob, dtype=x.dtype, device=x.device)
+        fhat = torch.empty(Bt, 3, dtype=x.dtype, device=x.device)
+        ghat = torch.empty(Bt, 3, 2, dtype=x.dtype, device=x.device)
+    else:
+        grad, cst, fhat, ghat = out
+    check(getattr(lib, "bcbf_unicycle_constraints" + _suf(x))(
+        _p(x), _p(plan), _p(dot_plan), _p(Kp), clf_gamma, _p(centers), _p(radii), _p(tw), _p(gammas), L_mean,
+        _p(grad), _p(cst), _p(fhat), _p(ghat), Bt, Kob, _stream(x)), "bcbf_unicycle_constraints")
+    return grad, cst, fhat, ghat
+
+
+def unicycle_step(x, u, dt, L_true):
+    """In-place explicit Euler step of the Ackermann plant (unicycle_move_to_pose.py:277-282)."""
+    _chk(x, u)
+    check(getattr(lib, "bcbf_unicycle_step" + _suf(x))(_p(x), _p(u), dt, L_true, x.shape[0], _stream(x)),
+          "bcbf_unicycle_step")
+    return x

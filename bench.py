@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched GP-posterior + CBF/CLF chance-constraint + SOCP control steps.
+
+Workload = BASELINE.json configs[2]: unicycle (x in R^3, u in R^2), N_train = 512,
+batch = 4096 independent control-loop instances per GPU (regime I: every instance owns its GP),
+fp32.  One "step" = one pass of the hot path over the batch:
+    unicycle_constraints -> posterior_step -> cbc_terms -> socp -> plant Euler step
+with all inputs resident in HBM.  Multi-GPU = more instances (weak scaling), one process per GPU,
+no collective inside the loop, one RCCL all-reduce of a small statistics vector at the end.
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = instance control-steps/s over all GPUs
+(= batch x batched-steps/s; `batched_steps_per_s` is reported beside it).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--ntrain", type=int, default=512)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--variant", default="dense")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="instances timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of a captured graph")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_instance(N, n, m, itemsize):
+    """packed factor + whitened targets + train inputs + UH*B, each read once."""
+    return itemsize * (N * (N + 1) // 2 + N * n + N * n + N * (1 + m))
+
+
+def cpu_baseline(p, task, sample, N, n, m):
+    """The oracle (a numpy port of the reference's arithmetic, reference-style: one instance at a
+    time, Cholesky cached) timed on this host for `sample` instances of the same workload."""
+    import scipy.linalg as sla
+    from oracle import gp_posterior as ogp, cbc as ocbc, socp as osocp, unicycle as ouni
+    h = {k: v[:sample].double().cpu().numpy() for k, v in {**p, **task}.items() if v.dim() > 0 and v.shape[0] >= sample}
+    sign, relax_mask = task["sign"].double().cpu().numpy(), task["relax_mask"].double().cpu().numpy()
+    Kp, tw, gammas = (task[k].double().cpu().numpy() for k in ("Kp", "tw", "gammas"))
+    states = []
+    for i in range(sample):     # refit state: not timed (cached in the reference between refits)
+        states.append(ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i],
+                                      h["M0"][i], h["jitter"][i][None] / 1e-5))
+    clf = ouni.CLFCartesian(Kp)
+    t0 = time.perf_counter()
+    nopt = 0
+    for i in range(sample):
+        st = states[i]
+        x = h["x"][i]
+        Mk, Bk = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None],
+                                    h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], x[None])
+        fhat, ghat = ouni.ackermann_f(x), ouni.ackermann_g(x, 4.0)
+        plan, dplan = h["plan"][i], h["dot_plan"][i]
+        const = clf.grad_clf_wrt_goal(x, plan) @ dplan + 10.0 * clf.clf(x, plan)
+        terms = [ocbc.reldeg1_terms(Mk[0], Bk[0], h["A"][i], clf.grad_clf(x, plan), const, fhat, ghat, sign=-1.0)]
+        for k in range(2):
+            ob = ouni.ObstacleCBF(h["centers"][i, k], h["radii"][i, k], tuple(tw))
+            terms.append(ocbc.reldeg1_terms(Mk[0], Bk[0], h["A"][i], ob.grad_cbf(x), gammas[k] * ob.cbf(x), fhat, ghat))
+        cones = [ocbc.convert_cbc_terms_to_socp_terms(*tm, 0) for tm in terms]
+        sol = osocp.clf_cbf_socp(h["w"][i], h["r"][i], cones, h["rho"][i], relax_mask)
+        nopt += sol["status"] == "optimal"
+    el = time.perf_counter() - t0
+    return dict(value=sample / el, unit="control steps/s (instance-steps)", cores=int(torch.get_num_threads()),
+                kind="port",
+                sample="%d instances of the same N=%d,n=%d,m=%d workload, one at a time, factor cached "
+                       "(numpy/scipy oracle: triangular solve + closed-form terms + coneqp), %.1f s" % (sample, N, n, m, el))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from bayesian_cbf_amd import ops
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    Bt, N, n, m = args.batch, args.ntrain, 3, 2
+    K = 3
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=dev, seed=1234 + rank, variant=args.variant)
+    task = make_unicycle_task(Bt, dtype=dtype, device=dev, seed=99 + rank)
+    # ---- refit (not timed: once per refit, cached between control steps in the reference)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    torch.cuda.synchronize()
+    assert int((info != 0).sum()) == 0, "Cholesky failed on the synthetic workload"
+
+    x = task["x"].clone()
+    grad = torch.empty(Bt, K, 3, dtype=dtype, device=dev)
+    cst = torch.empty(Bt, K, dtype=dtype, device=dev)
+    fhat = torch.empty(Bt, 3, dtype=dtype, device=dev)
+    ghat = torch.empty(Bt, 3, 2, dtype=dtype, device=dev)
+    Mk = torch.empty(Bt, n, 1 + m, dtype=dtype, device=dev)
+    Bk = torch.empty(Bt, 1 + m, 1 + m, dtype=dtype, device=dev)
+    cones = torch.empty(Bt, K, ops.cone_width(m), dtype=dtype, device=dev)
+    cstatus = torch.empty(Bt, K, dtype=torch.int32, device=dev)
+    y = torch.empty(Bt, m + 1, dtype=dtype, device=dev)
+    status = torch.empty(Bt, dtype=torch.int32, device=dev)
+    iters = torch.empty(Bt, dtype=torch.int32, device=dev)
+    u = torch.empty(Bt, m, dtype=dtype, device=dev)
+    dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
+
+    def constraints():
+        ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], 10.0, task["centers"], task["radii"],
+                                 task["tw"], task["gammas"], L_mean, out=(grad, cst, fhat, ghat))
+
+    def posterior():
+        ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], x, out=(Mk, Bk))
+
+    def solve():
+        ops.cbc_terms(Mk, Bk, p["A"], grad, cst, task["sign"], fhat, ghat, out=(None, cones, cstatus))
+        ops.socp(task["w"], task["r"], cones, task["relax_mask"], task["rho"], out=(y, status, iters))
+        u.copy_(y[:, :m])
+        ops.unicycle_step(x, u, dt_plant, L_true)
+
+    def step():
+        constraints()
+        posterior()
+        solve()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    # ---- timed region: exactly `steps` steps, HIP events around the dominant kernel
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        constraints()
+        ev[s][0].record()
+        posterior()
+        ev[s][1].record()
+        solve()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    n_opt = int((status == 0).sum())
+    stats = torch.tensor([elapsed, float(n_opt), float(Bt), float(iters.float().mean())], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats[1:3], op=dist.ReduceOp.SUM)      # the final (only) reduction: a few numbers over RCCL
+        elapsed = float(tmax[0])
+    total_instances = float(stats[2])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_instances * args.steps / elapsed
+
+    if rank == 0:
+        bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bt
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; HBM GB/s vs peak" % (N, Bt),
+            "value": value,
+            "unit": "control steps/s (instance-steps: batch x batched steps/s)",
+            "batched_steps_per_s": args.steps / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints (1 CLC + 2 obstacle "
+                                   "CBCs) + SOCP per step, independent GP per instance",
+                       "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
+                       "regime": "independent GPs (I)", "inputs": args.variant, "parallelism": "instances sharded, dp%d" % world},
+            "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
+            "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(p, task, args.cpu_sample, N, n, m)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

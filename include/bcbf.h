@@ -1,0 +1,179 @@
+/*
+ * libbcbf -- MI355X (gfx950) kernels for the Bayesian-CBF hot path: matrix-variate GP posterior
+ * over F(x) = [f(x) g(x)], control-barrier / control-Lyapunov chance-constraint terms and the
+ * per-step second-order-cone program, batched over independent control-loop instances.
+ *
+ * This is the drop-in boundary.  The reference (wecacuee/Bayesian_CBF) has no
+ * FFI layer: its "operator API" is the Python call surface of bayes_cbf/control_affine_model.py,
+ * cbc2.py, unicycle_move_to_pose.py and optimizers.py, executed with torch CPU/GPU tensors.  Each
+ * entry point below cites the reference arithmetic it replaces (file:line, relative to the
+ * upstream checkout); INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to a contiguous row-major array; leading axis Bt = number
+ *    of independent instances (one GP / one control loop each); the caller owns all memory and
+ *    the library allocates nothing;
+ *  - N = #training points per instance, n = state dim, m = control dim, C = 1+m;
+ *  - `_f32` / `_f64` select the storage + arithmetic type of the GP kernels (the conic solver
+ *    always iterates in fp64 and converts at its boundary);
+ *  - `stream` is a hipStream_t (pass 0 for the default stream); calls are asynchronous and
+ *    re-entrant; no randomness is drawn inside the library (jitter vectors are inputs);
+ *  - return value: 0 on success, <0 on a bad argument / launch failure (BCBF_E*); per-instance
+ *    numerical outcomes are reported through `info` / `status` arrays.
+ */
+#ifndef BCBF_H
+#define BCBF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCBF_VERSION_MAJOR 0
+#define BCBF_VERSION_MINOR 1
+
+#define BCBF_OK 0
+#define BCBF_EINVAL (-1)   /* unsupported size / null pointer */
+#define BCBF_ELAUNCH (-2)  /* HIP launch error (see bcbf_last_error) */
+
+/* diagonal-block size of the packed triangular operator ("Lop") */
+#define BCBF_NB 32
+/* limits of the compiled kernels */
+#define BCBF_MAX_STATE_DIM 8
+#define BCBF_MAX_CTRL_DIM 3
+#define BCBF_MAX_CONSTRAINTS 4
+
+/* solver status codes (per instance) */
+#define BCBF_SOCP_OPTIMAL 0
+#define BCBF_SOCP_MAXITER 1
+#define BCBF_SOCP_DIVERGED 2   /* infeasible program: the reference raises there (optimizers.py:74-86) */
+#define BCBF_SOCP_BADCONE 3    /* [[v,bfv'/2],[bfv/2,V]] not positive definite (unicycle_move_to_pose.py:861) */
+
+int bcbf_version(void);
+const char* bcbf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Packed triangular operator "Lop" (the HBM layout the per-step kernel streams).
+ * Np = N rounded up to BCBF_NB; V = 16/sizeof(T) (4 for f32, 2 for f64).  Column j stores rows
+ * V*floor(j/V) .. Np-1 contiguously (column-major, zero above the diagonal), columns one after
+ * another; element (i,j) holds L[i][j] when i is below j's 32x32 diagonal block and
+ * inv(L_JJ)[i][j] inside the block (the block's triangular inverse).  Rows/cols >= N are identity.
+ * Elements per instance = Np*(Np+V)/2.
+ * ------------------------------------------------------------------------------------------- */
+size_t bcbf_lop_elems_f32(int N);
+size_t bcbf_lop_elems_f64(int N);
+
+/* K1: K_b[i][j] = s2*exp(-1/2 |(x_i-x_j)/ell|^2) * uh_i' Bm uh_j  (+ jitter[i] on the diagonal).
+ * Replaces control_affine_model.py:370-372 (+ the diagonal perturbation of make_psd :907-910).
+ * X[Bt,N,n] UH[Bt,N,C] Bm[Bt,C,C] ell[Bt,n] s2[Bt] jitter[Bt,N] (may be NULL) -> Kb[Bt,N,N] (full, symmetric). */
+int bcbf_kb_build_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                      const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream);
+int bcbf_kb_build_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                      const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream);
+
+/* K1+K2 fused refit: builds K_b (+jitter) on the fly, factors it (blocked left-looking Cholesky),
+ * inverts the diagonal blocks and writes the packed operator; also UHB = UH Bm.
+ * Replaces _perturbed_cholesky_compute + make_psd (control_affine_model.py:366-377, 899-921).
+ * info[b] = 0 ok, k>0: pivot k (1-based) not positive -> caller retries with jitter x10 (:913-919).
+ * Ldense (optional, may be NULL): row-major dense L[Bt,N,N] for callers that want the factor itself. */
+int bcbf_refit_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                   const float* jitter, float* Lop, float* UHB, float* Ldense, int* info,
+                   int Bt, int N, int n, int m, void* stream);
+int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                   const double* jitter, double* Lop, double* UHB, double* Ldense, int* info,
+                   int Bt, int N, int n, int m, void* stream);
+
+/* K2 on a caller-supplied dense SPD matrix (lower triangle of Kb[Bt,N,N] is read): same outputs.
+ * Replaces torch.linalg.cholesky (control_affine_model.py:911). */
+int bcbf_potrf_f32(const float* Kb, float* Lop, float* Ldense, int* info, int Bt, int N, void* stream);
+int bcbf_potrf_f64(const double* Kb, double* Lop, double* Ldense, int* info, int Bt, int N, void* stream);
+
+/* K3: whitened targets Vw = L^-1 Y and alpha = K_b^-1 Y = L^-T Vw from the packed operator.
+ * Replaces torch.cholesky_solve (control_affine_model.py:545); Y = Xdot - UH M0 (:525-532) is
+ * formed here.  Xdot[Bt,N,n] UH[Bt,N,C] M0[Bt,C,n] -> Vw[Bt,N,n], alpha[Bt,N,n] (alpha may be NULL). */
+int bcbf_potrs_f32(const float* Lop, const float* Xdot, const float* UH, const float* M0,
+                   float* Vw, float* alpha, int Bt, int N, int n, int m, void* stream);
+int bcbf_potrs_f64(const double* Lop, const double* Xdot, const double* UH, const double* M0,
+                   double* Vw, double* alpha, int Bt, int N, int n, int m, void* stream);
+
+/* K11: append one training point to the packed operator (bordered Cholesky).  knew[Bt,N] = new
+ * row of K_b against the old points, kappa[Bt] its diagonal (incl. jitter).  Lop_in has N points,
+ * Lop_out N+1 (may not alias).  No reference counterpart (the reference refactorises). */
+int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
+                         int* info, int Bt, int N, void* stream);
+int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double* kappa, double* Lop_out,
+                         int* info, int Bt, int N, void* stream);
+
+/* K4+K5+K6+K7: one posterior query per instance (the HBM-bound hot kernel).
+ *   Phi = diag(k(X, xq)) UHB;  W = L^-1 Phi;  Mk = M0' + Vw' W;  Bk = s2*Bm - W'W (+ diag(jitter2))
+ * Replaces ControlAffineRegressorExact._custom_predict_matrix with b = 1
+ * (control_affine_model.py:1051-1091; same numbers as custom_predict :536-602).
+ * Lop[Bt,lop_elems] Vw[Bt,N,n] X[Bt,N,n] UHB[Bt,N,C] ell[Bt,n] s2[Bt] Bm[Bt,C,C] M0[Bt,C,n]
+ * xq[Bt,n] jitter2[Bt,C] (may be NULL) -> Mk[Bt,n,C], Bk[Bt,C,C]. */
+int bcbf_posterior_step_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                            const float* ell, const float* s2, const float* Bm, const float* M0,
+                            const float* xq, const float* jitter2, float* Mk, float* Bk,
+                            int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_step_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                            const double* ell, const double* s2, const double* Bm, const double* M0,
+                            const double* xq, const double* jitter2, double* Mk, double* Bk,
+                            int Bt, int N, int n, int m, void* stream);
+
+/* K8 (rel-degree 1) + K9: constraint terms and their cone form, K constraints per instance.
+ *   mean(u) = bfe'u + e,  var(u) = u'V u + bfv'u + v   for  sign*(grad' (fhat + ghat u + F(x)[1;u]) + cst)
+ * Replaces cbc2_quadratic_terms on a rel-degree-1 expression (cbc2.py:7-23, gp_algebra.py:109-223,
+ * unicycle_move_to_pose.py:880-916) and convert_cbc_terms_to_socp_terms (:837-878).
+ * Mk[Bt,n,C] Bk[Bt,C,C] A[Bt,n,n] grad[Bt,K,n] cst[Bt,K] sign[K] fhat[Bt,n] ghat[Bt,n,m]
+ * -> terms[Bt,K,T] with T = m + 1 + m*m + m + 1 packed (bfe,e,V,bfv,v);
+ *    cones[Bt,K,Q] with Q = (m+1)*m + (m+1) + m + 1 packed (A[(m+1),m], b[m+1], c[m], d);
+ *    cstatus[Bt,K] = 0 or BCBF_SOCP_BADCONE.  terms / cones may be NULL. */
+int bcbf_cbc_terms_f32(const float* Mk, const float* Bk, const float* A, const float* grad, const float* cst,
+                       const float* sign, const float* fhat, const float* ghat,
+                       float* terms, float* cones, int* cstatus, int Bt, int K, int n, int m, void* stream);
+int bcbf_cbc_terms_f64(const double* Mk, const double* Bk, const double* A, const double* grad, const double* cst,
+                       const double* sign, const double* fhat, const double* ghat,
+                       double* terms, double* cones, int* cstatus, int Bt, int K, int n, int m, void* stream);
+
+/* K10: the per-step program of ControllerCLFBayesian.control (unicycle_move_to_pose.py:926-953):
+ *   min sum_i w_i (u_i - r_i)^2 + w_m relax^2   s.t.  c_k'u + d_k + relax_mask_k relax >= rho |A_k u + b_k|
+ * Replaces cvxpy+GUROBI (and cvxopt socp, optimizers.py:42-102).  One primal-dual interior-point
+ * solve (NT scaling, Mehrotra correction) per instance in registers, fp64.
+ * w[Bt,m+1] r[Bt,m] cones[Bt,K,Q] (layout above) relax_mask[K] rho[Bt]
+ * -> y[Bt,m+1] = [u, relax], status[Bt], iters[Bt] (iters may be NULL). */
+int bcbf_socp_f32(const float* w, const float* r, const float* cones, const float* relax_mask, const float* rho,
+                  float* y, int* status, int* iters, int Bt, int K, int m, int max_iters, void* stream);
+int bcbf_socp_f64(const double* w, const double* r, const double* cones, const double* relax_mask, const double* rho,
+                  double* y, int* status, int* iters, int Bt, int K, int m, int max_iters, void* stream);
+
+/* Generic small cone QP (the reference's optimizer_socp_* / optimizer_qp_cvxpy, optimizers.py:42-116):
+ *   min 1/2 x'P x + q'x  s.t.  G x + s = h,  s in R_+^l x Q^{q_1} x ... x Q^{q_nq}
+ * P[Bt,nv,nv] q[Bt,nv] G[Bt,Kt,nv] h[Bt,Kt], Kt = l + sum(qdims) <= 16, nv <= 6, nq <= 4;
+ * qdims is a HOST array.  -> x[Bt,nv], status[Bt], iters[Bt] (may be NULL). */
+int bcbf_coneqp_f64(const double* P, const double* q, const double* G, const double* h,
+                    int nv, int l, const int* qdims, int nq,
+                    double* x, int* status, int* iters, int Bt, int max_iters, void* stream);
+
+/* Unicycle task functions, batched (unicycle_move_to_pose.py:522-615 CLFCartesian, :618-696
+ * ObstacleCBF, :235-257 AckermannDrive.g_func, planner.py:54-64 PiecewiseLinearPlanner).
+ * x[Bt,3] plan[Bt,3] dot_plan[Bt,3] Kp[3] clf_gamma; obstacles: centers[Bt,Kob,2] radii[Bt,Kob]
+ * tw[2] gammas[Kob]; L_mean -> grad[Bt,1+Kob,3], cst[Bt,1+Kob], fhat[Bt,3], ghat[Bt,3,2].
+ * Row 0 is the CLC (sign -1 is applied by bcbf_cbc_terms via `sign`), rows 1.. the obstacles. */
+int bcbf_unicycle_constraints_f32(const float* x, const float* plan, const float* dot_plan, const float* Kp,
+                                  float clf_gamma, const float* centers, const float* radii, const float* tw,
+                                  const float* gammas, float L_mean, float* grad, float* cst, float* fhat,
+                                  float* ghat, int Bt, int Kob, void* stream);
+int bcbf_unicycle_constraints_f64(const double* x, const double* plan, const double* dot_plan, const double* Kp,
+                                  double clf_gamma, const double* centers, const double* radii, const double* tw,
+                                  const double* gammas, double L_mean, double* grad, double* cst, double* fhat,
+                                  double* ghat, int Bt, int Kob, void* stream);
+
+/* Explicit-Euler plant step x += (g(x; L_true) u) dt  (unicycle_move_to_pose.py:277-282, sampling.py:68-74). */
+int bcbf_unicycle_step_f32(float* x, const float* u, float dt, float L_true, int Bt, void* stream);
+int bcbf_unicycle_step_f64(double* x, const double* u, double dt, double L_true, int Bt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCBF_H */

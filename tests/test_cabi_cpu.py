@@ -1,0 +1,42 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/bcbf.h declares, and the host wrappers refuse to run without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bayesian_cbf_amd.build import build
+    build()
+    from bayesian_cbf_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "bcbf.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bcbf_\w+)\s*\(", header))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib.lib, name), "libbcbf.so does not export %s" % name
+    assert declared == set(lib.declared_symbols())
+
+
+def test_version_and_layout_helpers(lib):
+    assert lib.lib.bcbf_version() == 1
+    # Np*(Np+V)/2 elements: N=512 f32 -> 512*516/2, N=256 f64 -> 256*258/2, N=40 -> padded to 64
+    assert lib.lib.bcbf_lop_elems_f32(512) == 512 * 516 // 2
+    assert lib.lib.bcbf_lop_elems_f64(256) == 256 * 258 // 2
+    assert lib.lib.bcbf_lop_elems_f32(40) == 64 * 68 // 2
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    from bayesian_cbf_amd import ops
+    X = torch.zeros(1, 8, 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.kb_build(X, torch.zeros(1, 8, 2), torch.eye(2)[None], torch.ones(1, 2), torch.ones(1))

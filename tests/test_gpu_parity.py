@@ -1,0 +1,378 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors recorded from the executed reference.  Tolerances (BASELINE.json north_star):
+fp64 1e-5 relative (we hold 1e-8 or better), fp32 1e-3 relative -- relative to the scale of the
+quantity (for the posterior covariance: the prior scale s2*|Bm|, because B_k is a difference of
+nearly equal numbers near training data; see DESIGN.md "Tolerances")."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cbc as ocbc
+from oracle import gp_posterior as ogp
+from oracle import socp as osocp
+from oracle import unicycle as ouni
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSTERIOR_FILES = sorted(glob.glob(os.path.join(GOLDEN, "posterior_*.npz")))
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from bayesian_cbf_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV).contiguous()
+
+
+def host(t):
+    return t.detach().cpu().double().numpy()
+
+
+def rel_close(actual, desired, rtol, scale=None, what=""):
+    actual, desired = np.asarray(actual), np.asarray(desired)
+    sc = np.abs(desired).max() if scale is None else scale
+    err = np.abs(actual - desired).max()
+    assert err <= rtol * max(sc, 1e-300), "%s: max abs err %.3e > %.1e * scale %.3e" % (what, err, rtol, sc)
+
+
+TOL = {torch.float64: 1e-8, torch.float32: 1e-3}
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("path", POSTERIOR_FILES, ids=os.path.basename)
+def test_refit_and_posterior_vs_reference_golden(ops, path, dtype):
+    """K1+K2+K3+K5 on the golden cases recorded from the reference (N in {8,16,64}: padding paths)."""
+    g = np.load(path)
+    tol = TOL[dtype]
+    X, U, Xdot = g["X"], g["U"], g["Xdot"]
+    N, n = X.shape
+    m = U.shape[1]
+    UH = ogp.homogeneous_controls(U)
+    jit = 1e-5 * g["jitter_rand"][0]
+    args = [dev(a[None], dtype) for a in (X, UH, g["B"], g["ell"], np.array(float(g["s2"])), jit)]
+    Kb = ops.kb_build(*args)
+    Kb_ref = ogp.kb_matrix(X, UH, g["B"], g["ell"], float(g["s2"])) + np.diag(jit)
+    rel_close(host(Kb)[0], Kb_ref, 1e-12 if dtype == torch.float64 else 1e-6, what="Kb")
+    Lop, UHB, info, Ld = ops.refit(*args, want_dense=True)
+    assert int(info[0]) == 0
+    rel_close(host(Ld)[0], g["L"], tol, what="L")
+    rel_close(host(UHB)[0], UH @ g["B"], tol, what="UHB")
+    # potrf on the dense matrix gives the same operator
+    Lop2, info2, Ld2 = ops.potrf(Kb, want_dense=True)
+    assert int(info2[0]) == 0
+    rel_close(host(Ld2)[0], g["L"], tol, what="L(potrf)")
+    rel_close(host(Lop2), host(Lop), tol, what="Lop(potrf)")
+    Vw, alpha = ops.potrs(Lop, dev(Xdot[None], dtype), args[1], dev(g["M0"][None], dtype))
+    Y = ogp.residual_targets(Xdot, UH, g["M0"])
+    import scipy.linalg as sla
+    rel_close(host(Vw)[0], sla.solve_triangular(g["L"], Y, lower=True), tol, what="Vw")
+    rel_close(host(alpha)[0], ogp.cholesky_solve(Y, g["L"]), tol * 50, what="alpha")
+    # per-step posterior at the golden single query, explicit second jitter
+    xq = g["Xtest"][:1]
+    j2 = 1e-5 * g["one_jitter2"][None]
+    Mk, Bk = ops.posterior_step(Lop, Vw, args[0], UHB, args[3], args[4], args[2], dev(g["M0"][None], dtype),
+                                dev(xq, dtype), dev(j2, dtype))
+    prior = float(g["s2"]) * np.abs(g["B"]).max()
+    rel_close(host(Mk)[0], g["one_mean_k"][0], tol, scale=max(1.0, np.abs(g["one_mean_k"]).max()), what="Mk")
+    rel_close(host(Bk)[0], g["one_BkXX"][0, 0], tol, scale=prior, what="Bk")
+
+
+@pytest.mark.parametrize("dtype,N,n,m,variant", [
+    (torch.float64, 256, 2, 1, "dense"),      # BASELINE config 2 shape
+    (torch.float32, 512, 3, 2, "dense"),      # BASELINE config 3 shape
+    (torch.float64, 512, 3, 2, "theta"),      # rank-deficient shift-invariant inputs, fp64
+    (torch.float32, 100, 3, 2, "dense"),      # ragged N (padding to 128)
+    (torch.float32, 1024, 3, 3, "dense"),     # 2 waves per instance, m = 3
+    (torch.float64, 96, 1, 1, "dense"),
+])
+def test_posterior_pipeline_vs_oracle(ops, dtype, N, n, m, variant):
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt = 6
+    tol = TOL[dtype]
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=7 + N, variant=variant)
+    Lop, UHB, info, Ld = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"], want_dense=True)
+    assert (info == 0).all()
+    Vw, alpha = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    Mk, Bk = ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"], p["jitter2"])
+    h = {k: host(v) for k, v in p.items()}
+    for i in range(Bt):
+        st = ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                             h["jitter"][i][None] / 1e-5)
+        Lref = st["L"]
+        # factor: compare through the reconstruction (robust to conditioning), fp32 only loosely
+        Lg = host(Ld)[i]
+        rec = Lg @ Lg.T
+        rel_close(rec, st["Kbp"], 1e-12 if dtype == torch.float64 else 2e-6, what="L L' = Kb")
+        if dtype == torch.float64 and variant == "dense":
+            rel_close(Lg, Lref, 1e-8, what="L")
+        Mk_o, Bk_o = ogp.posterior_step(Lref[None], st["alpha"][None], h["X"][i][None], st["UHB"][None],
+                                        h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None],
+                                        h["xq"][i][None], jitter2=h["jitter2"][i][None])
+        prior = h["s2"][i] * np.abs(h["Bm"][i]).max()
+        t = tol if variant == "dense" else 1e-5
+        rel_close(host(Mk)[i], Mk_o[0], t, scale=max(1.0, np.abs(Mk_o).max()), what="Mk[%d]" % i)
+        rel_close(host(Bk)[i], Bk_o[0], t, scale=prior, what="Bk[%d]" % i)
+
+
+def test_cholesky_failure_is_reported_per_instance(ops):
+    """info = 1-based index of the failing pivot; healthy instances are unaffected (make_psd retry
+    protocol, control_affine_model.py:905-919)."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    p = make_instances(3, 64, 2, 1, dtype=torch.float64, device=DEV, seed=3)
+    X = p["X"].clone()
+    X[1, 40] = X[1, 7]                      # duplicated point ...
+    UH = p["UH"].clone()
+    UH[1, 40] = UH[1, 7]
+    jit = p["jitter"].clone()
+    jit[1] = 0.0                            # ... and no jitter: K_b is singular
+    jit[1, 40] = -1e-3
+    Lop, UHB, info, _ = ops.refit(X, UH, p["Bm"], p["ell"], p["s2"], jit)
+    info = info.cpu().numpy()
+    assert info[0] == 0 and info[2] == 0 and info[1] == 41
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_chol_append_equals_refit(ops, dtype):
+    from bayesian_cbf_amd.synthetic import make_instances
+    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    for N in (31, 32, 45, 64):     # append inside a block, across a block boundary
+        p = make_instances(4, N + 1, 3, 2, dtype=dtype, device=DEV, seed=N)
+        full = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+        Lop_full, info_f, Ld_full = ops.potrf(full, want_dense=True)
+        Lop_N, info_n, _ = ops.potrf(full[:, :N, :N].contiguous())
+        knew = full[:, N, :N].contiguous()
+        kappa = full[:, N, N].contiguous()
+        Lop_app, info_a = ops.chol_append(Lop_N, knew, kappa, N)
+        assert (info_a == 0).all() and (info_f == 0).all()
+        rel_close(host(Lop_app), host(Lop_full), tol, what="chol_append N=%d" % N)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("tag", ["fixed", "learned_N40"])
+def test_unicycle_terms_vs_reference_golden(ops, tag, dtype):
+    """Task functions (K8 inputs), rel-degree-1 terms and cone conversion against the vectors
+    recorded from ControllerCLFBayesian._clc_terms/_cbc_terms (jitter replayed explicitly)."""
+    g = np.load(os.path.join(GOLDEN, "unicycle_terms_%s.npz" % tag))
+    learning = bool(g["enable_learning"])
+    tol = 1e-8 if dtype == torch.float64 else 2e-4
+    S = len(g["ts"])
+    x = dev(g["states"], dtype)
+    plan = dev(np.stack([g["s%d_plan" % i] for i in range(S)]), dtype)
+    dplan = dev(np.stack([g["s%d_dot_plan" % i] for i in range(S)]), dtype)
+    centers = dev(np.broadcast_to(g["obst_centers"], (S, 2, 2)), dtype)
+    radii = dev(np.broadcast_to(g["obst_radii"], (S, 2)), dtype)
+    grad, cst, fhat, ghat = ops.unicycle_constraints(x, plan, dplan, dev(g["Kp"], dtype), float(g["clf_gamma"]),
+                                                     centers, radii, dev(g["term_weights"], dtype),
+                                                     dev(g["cbf_gammas"], dtype), float(g["mean_L"]))
+    for i in range(S):
+        p = "s%d_" % i
+        rel_close(host(grad)[i, 0], g[p + "grad_V"], tol, scale=max(1.0, np.abs(g[p + "grad_V"]).max()), what="grad_V")
+        rel_close(host(grad)[i, 1:], g[p + "grad_h"], tol, scale=max(1.0, np.abs(g[p + "grad_h"]).max()), what="grad_h")
+        rel_close(host(cst)[i, 1:], g["cbf_gammas"] * g[p + "h"], tol, scale=max(1.0, np.abs(g[p + "h"]).max() * 5), what="gamma h")
+    # model at each state
+    if learning:
+        X, U, Xdot = g["X"], g["U"], g["Xdot"]
+        UH = ogp.homogeneous_controls(U)
+        rep = lambda a: dev(np.broadcast_to(a, (S,) + np.shape(a)), dtype)
+        Lop, info, _ = ops.potrf(rep(g["L"] @ g["L"].T))
+        assert (info == 0).all()
+        Vw, _ = ops.potrs(Lop, rep(Xdot), rep(UH), rep(g["M0"]))
+        A = rep(g["A"])
+    else:
+        A = dev(np.broadcast_to(np.diag(g["kernel_diag_A"]), (S, 3, 3)), dtype)
+    sign = dev(np.array([-1.0, 1.0, 1.0]), dtype)
+    names = ("bfe", "e", "V", "bfv", "v")
+    for k in range(3):       # constraint k uses its own jitter draw in the reference -> one pass per k
+        if learning:
+            j2 = []
+            for i in range(S):
+                draws = [g["s%d_draw%d" % (i, q)] for q in range(int(g["s%d_ndraws" % i]))]
+                if i == 0:
+                    draws = [draws[0]] + draws[2:]
+                j2.append(1e-5 * draws[3 * k + 1])
+            Mk, Bk = ops.posterior_step(Lop, Vw, rep(X), rep(UH @ g["B"]), rep(g["ell"]), rep(np.array(float(g["s2"]))),
+                                        rep(g["B"]), rep(g["M0"]), x, dev(np.stack(j2), dtype))
+        else:
+            Mk = torch.zeros(S, 3, 3, dtype=dtype, device=DEV)
+            Bk = torch.eye(3, dtype=dtype, device=DEV).expand(S, 3, 3).contiguous()
+        terms, cones, cstatus = ops.cbc_terms(Mk, Bk, A, grad, cst, sign, fhat, ghat)
+        assert (cstatus == 0).all()
+        got = [host(t) for t in ops.unpack_terms(terms, 2)]
+        gotc = [host(t) for t in ops.unpack_cones(cones, 2)]
+        for i in range(S):
+            p = "s%d_" % i
+            for name, val in zip(names, got):
+                ref = g[p + "clc_" + name] if k == 0 else g[p + "cbc_" + name][k - 1]
+                rel_close(val[i, k], ref, tol, scale=max(np.abs(ref).max(), 1e-2), what="%s[%d,%d]" % (name, i, k))
+            for name, val in zip(("A", "b", "c", "d"), gotc):
+                ref = g[p + "clc_socp_" + name] if k == 0 else g[p + "cbc_socp_" + name][k - 1]
+                rel_close(val[i, k], ref, tol * 5, scale=max(np.abs(ref).max(), 1e-2), what="cone %s[%d,%d]" % (name, i, k))
+
+
+# --------------------------------------------------------------------------------------------
+def _random_programs(rng, Bt, m=2, K=3, rho=2.326):
+    A = np.zeros((Bt, K, m + 1, m)); b = np.zeros((Bt, K, m + 1)); c = np.zeros((Bt, K, m)); d = np.zeros((Bt, K))
+    for i in range(Bt):
+        u_f = rng.normal(size=m)
+        for k in range(K):
+            Asq = rng.normal(size=(m + 1, m + 1))
+            Asq = Asq @ Asq.T * rng.uniform(0.001, 1) + 1e-4 * np.eye(m + 1)
+            Lc = np.linalg.cholesky(Asq)
+            A[i, k], b[i, k] = Lc.T[:, 1:], Lc.T[:, 0]
+            c[i, k] = rng.normal(size=m) * 3
+            slack = rng.uniform(0.01, 2.0) * (1 if k else rng.choice([-1, 1]))
+            d[i, k] = rho * np.linalg.norm(A[i, k] @ u_f + b[i, k]) - c[i, k] @ u_f + slack
+    return A, b, c, d
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m,K", [(2, 3), (1, 2), (3, 4), (2, 1)])
+def test_socp_vs_oracle(ops, dtype, m, K):
+    rng = np.random.default_rng(100 + 10 * m + K)
+    Bt, rho = 96, 2.326
+    A, b, c, d = _random_programs(rng, Bt, m, K, rho)
+    relax_mask = np.zeros(K); relax_mask[0] = 1.0
+    w = np.full((Bt, m + 1), 0.33) * rng.uniform(0.5, 2.0, size=(Bt, m + 1))
+    r = rng.normal(size=(Bt, m)) * 0.3
+    cones = ops.pack_cones(dev(A, dtype), dev(b, dtype), dev(c, dtype), dev(d, dtype))
+    y, status, iters = ops.socp(dev(w, dtype), dev(r, dtype), cones, dev(relax_mask, dtype), dev(np.full(Bt, rho), dtype))
+    assert (status == 0).all(), status.cpu().numpy()
+    assert int(iters.max()) <= 40
+    yh = host(y)
+    for i in range(Bt):
+        sol = osocp.clf_cbf_socp(w[i], r[i], [(A[i, k], b[i, k], c[i, k], d[i, k]) for k in range(K)], rho, relax_mask)
+        assert sol["status"] == "optimal"
+        np.testing.assert_allclose(yh[i], sol["x"], rtol=1e-6 if dtype == torch.float64 else 1e-3,
+                                   atol=1e-7 if dtype == torch.float64 else 1e-3)
+
+
+def test_socp_flags_infeasible_instances_without_disturbing_others(ops):
+    rng = np.random.default_rng(0)
+    A, b, c, d = _random_programs(rng, 8)
+    # instance 3: two contradictory half-planes (u0 >= 2 and u0 <= -2), no relaxation on them
+    A[3, 1] = A[3, 2] = np.eye(3)[:, 1:]
+    b[3, 1] = b[3, 2] = [1.0, 0, 0]
+    c[3, 1], c[3, 2] = [1.0, 0.0], [-1.0, 0.0]
+    d[3, 1] = d[3, 2] = -1.0
+    dt = torch.float64
+    cones = ops.pack_cones(dev(A, dt), dev(b, dt), dev(c, dt), dev(d, dt))
+    y, status, _ = ops.socp(dev(np.full((8, 3), 0.33), dt), dev(np.zeros((8, 2)), dt), cones,
+                            dev(np.array([1.0, 0, 0]), dt), dev(np.full(8, 1.0), dt))
+    st = status.cpu().numpy()
+    assert st[3] != 0 and (np.delete(st, 3) == 0).all()
+
+
+def test_coneqp_known_answer_from_reference_tests(ops):
+    """tests/test_optimizers.py:6-26 of the reference (cvxopt doc SOCP): x = [-5.02,-5.77,-8.52]."""
+    from kat import cvxopt_doc_example
+    lin, cons = cvxopt_doc_example()
+    _, Gqs, hqs = osocp.convert_socp_to_cvxopt_format(lin, cons)
+    G = np.vstack(Gqs); h = np.concatenate([q[:, 0] for q in hqs])
+    dt = torch.float64
+    x, status, iters = ops.coneqp(dev(np.zeros((1, 3, 3)), dt), dev(lin[None], dt), dev(G[None], dt), dev(h[None], dt),
+                                  0, [3, 4])
+    assert int(status[0]) == 0
+    np.testing.assert_allclose(host(x)[0], [-5.02, -5.77, -8.52], rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(host(x)[0], osocp.optimizer_socp(lin, cons)["x"], rtol=1e-7, atol=1e-8)
+    # QP with linear inequalities (optimizer_qp_cvxpy shape): min |A y + b|^2 s.t. 0 <= c'y + d
+    rng = np.random.default_rng(4)
+    Aq, bq = rng.normal(size=(3, 2)), rng.normal(size=3)
+    lincons = [("a", (np.array([1.0, 0.5]), 0.3)), ("b", (np.array([-0.2, 1.0]), -0.1))]
+    sol = osocp.optimizer_qp((Aq, bq), lincons)
+    P = 2 * Aq.T @ Aq; q = 2 * Aq.T @ bq
+    Gl = np.stack([-cc for _, (cc, _) in lincons]); hl = np.array([dd for _, (_, dd) in lincons])
+    x, status, _ = ops.coneqp(dev(P[None], dt), dev(q[None], dt), dev(Gl[None], dt), dev(hl[None], dt), 2, [])
+    assert int(status[0]) == 0
+    np.testing.assert_allclose(host(x)[0], sol["x"], rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["saved_run_mean_cbf_maxrisk0p5", "saved_run_bayes_cbf_maxrisk0p01"])
+def test_saved_run_controls_end_to_end(ops, name):
+    """All 200 logged states of the reference's committed runs at once: task functions -> terms ->
+    cones -> SOCP on the GPU reproduces the logged GUROBI controls, and one Euler step of the
+    true plant reproduces the logged next state."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dt_, T = float(g["dt"]), int(g["numSteps"])
+    x0, xg = g["state_start"], g["state_goal"]
+    planner = ouni.PiecewiseLinearPlanner(x0, xg, T, dt_, frac_time_to_reach_goal=0.95)
+    cbfs = ouni.obstacles_at_mid_from_start_and_goal(x0, xg, tuple(g["term_weights"]))
+    dt = torch.float64
+    S = T
+    x = dev(g["state"].astype(np.float64), dt)
+    plan = dev(np.stack([planner.plan(t) for t in range(T)]), dt)
+    dplan = dev(np.stack([planner.dot_plan(t) for t in range(T)]), dt)
+    centers = dev(np.broadcast_to(np.stack([c.center for c in cbfs]), (S, 2, 2)), dt)
+    radii = dev(np.broadcast_to(np.array([c.radius for c in cbfs]), (S, 2)), dt)
+    grad, cst, fhat, ghat = ops.unicycle_constraints(x, plan, dplan, dev(np.array([0.9, 1.5, 0.0]), dt),
+                                                     float(g["clf_gamma"]), centers, radii, dev(g["term_weights"], dt),
+                                                     dev(g["cbf_gammas"], dt), float(g["mean_L"]))
+    Mk = torch.zeros(S, 3, 3, dtype=dt, device=DEV)
+    Bk = torch.eye(3, dtype=dt, device=DEV).expand(S, 3, 3).contiguous()
+    A = dev(np.broadcast_to(np.diag(g["kernel_diag_A"]), (S, 3, 3)), dt)
+    terms, cones, cstatus = ops.cbc_terms(Mk, Bk, A, grad, cst, dev(np.array([-1.0, 1, 1]), dt), fhat, ghat)
+    assert (cstatus == 0).all()
+    rho = ocbc.cbc1_safety_factor(float(g["max_risk"]))
+    y, status, iters = ops.socp(dev(np.broadcast_to(g["cost_weights"], (S, 3)), dt), torch.zeros(S, 2, dtype=dt, device=DEV),
+                                cones, dev(np.array([1.0, 0, 0]), dt), dev(np.full(S, rho), dt))
+    assert (status == 0).all()
+    yh = host(y)
+    np.testing.assert_allclose(yh[:, :2], g["uopt"], rtol=2e-3, atol=2e-3)
+    value = (g["cost_weights"] * yh ** 2).sum(axis=1)
+    np.testing.assert_allclose(value, g["opt_value"], rtol=1e-4, atol=1e-5)
+    xs = x.clone()
+    ops.unicycle_step(xs, dev(g["uopt"].astype(np.float64), dt), dt_, float(g["true_L"]))
+    np.testing.assert_allclose(host(xs)[:-1], g["state"][1:], atol=5e-6)
+
+
+# --------------------------------------------------------------------------------------------
+def test_full_size_properties_config3(ops):
+    """BASELINE config 3 at full size (N=512, n=3, m=2, batch=4096, fp32): size-independent
+    properties + a sampled comparison with the oracle."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, N, n, m = 4096, 512, 3, 2
+    dtype = torch.float32
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=1234)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert (info == 0).all()
+    Vw, alpha = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    Mk, Bk = ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+    assert torch.isfinite(Mk).all() and torch.isfinite(Bk).all()
+    prior = p["s2"][:, None, None] * p["Bm"]
+    # (1) symmetry, (2) 0 <= B_k <= prior on the diagonal (variance reduction), (3) PSD up to rounding
+    assert (Bk - Bk.transpose(1, 2)).abs().max() == 0
+    d, dp = torch.diagonal(Bk, dim1=1, dim2=2), torch.diagonal(prior, dim1=1, dim2=2)
+    assert (d <= dp * (1 + 1e-5)).all() and (d >= -1e-3 * dp).all()
+    ev = torch.linalg.eigvalsh(Bk.double().cpu())
+    assert (ev.min(dim=1).values >= -1e-3 * dp.double().cpu().max(dim=1).values).all()
+    # (4) a query at a training point reproduces that point's fitted target: Mk [1;u_j] ~ xdot_j
+    xq2 = p["X"][:, 17, :].contiguous()
+    Mk2, Bk2 = ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq2)
+    pred = torch.einsum("bnc,bc->bn", Mk2, p["UH"][:, 17, :])
+    assert (pred - p["Xdot"][:, 17, :]).abs().max() < 5e-2
+    var_at_train = torch.einsum("bc,bcd,bd->b", p["UH"][:, 17, :], Bk2, p["UH"][:, 17, :])
+    assert (var_at_train.abs() < 1e-2 * torch.einsum("bc,bcd,bd->b", p["UH"][:, 17, :], prior, p["UH"][:, 17, :])).all()
+    # (5) linearity of the mean in the targets: doubling Xdot doubles Mk (M0 = 0)
+    Vw2, _ = ops.potrs(Lop, 2 * p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    Mk3, _ = ops.posterior_step(Lop, Vw2, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+    assert (Mk3 - 2 * Mk).abs().max() <= 1e-4 * max(1.0, float(Mk.abs().max()))
+    # (6) sampled instances against the oracle
+    h = {k: host(v) for k, v in p.items()}
+    for i in (0, 1337, 4095):
+        st = ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                             h["jitter"][i][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None],
+                                        h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None],
+                                        h["xq"][i][None])
+        rel_close(host(Mk)[i], Mk_o[0], 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk[%d]" % i)
+        rel_close(host(Bk)[i], Bk_o[0], 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk[%d]" % i)

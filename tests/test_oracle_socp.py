@@ -8,18 +8,9 @@ import pytest
 from scipy.optimize import minimize
 
 from oracle import cbc, socp, unicycle
+from kat import cvxopt_doc_example
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-def cvxopt_doc_example():
-    linear_objective = np.array([-2., 1., 5.])
-    A = [np.array([[-13., 3., 5.], [-12., 12., -6.]]),
-         np.array([[-3., 6., 2.], [1., 9., 2.], [-1., -19., 3.]])]
-    b = [np.array([-3., -2.]), np.array([0., 3., -42.])]
-    c = [np.array([-12., -6., 5.]), np.array([-3., 6., -10.])]
-    d = [np.array(-12.), np.array(27.)]
-    return linear_objective, list(zip(("1", "2"), zip(A, b, c, d)))
 
 
 def test_convert_socp_to_cvxopt_format_known_answer():
