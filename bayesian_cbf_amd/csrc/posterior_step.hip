@@ -12,14 +12,52 @@
 // Algorithmic HBM bytes per instance: sizeof(T) * [Np(Np+V)/2 + N(2n + C)]  (Lop + X + Vw + UHB).
 #include "bcbf_common.h"
 
+#ifndef BCBF_PS_DUNR
+#define BCBF_PS_DUNR 4     // unroll of the diagonal-block mat-vec
+#endif
+#ifndef BCBF_PS_WAVES
+#define BCBF_PS_WAVES 4   // occupancy target (waves per SIMD) -> VGPR cap
+#endif
+#ifndef BCBF_PS_UNR
+#define BCBF_PS_UNR 2      // columns per software-pipeline stage of the streaming loop
+#endif
+
 namespace bcbf {
 
 template <typename T> __device__ inline T texp(T x);
 template <> __device__ inline float texp<float>(float x) { return expf(x); }
 template <> __device__ inline double texp<double>(double x) { return exp(x); }
 
-template <typename T, int C>
-__global__ void __launch_bounds__(256)
+// Bounds-checked buffer loads: a lane whose byte offset is >= the descriptor's size gets zeros and
+// generates no memory traffic, so the triangular structure needs no divergent branches (a branch
+// around a load makes hipcc wait vmcnt(0) before every load, serialising the stream).
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
+using u32x2 = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
+constexpr int OOB = 0x40000000;   // > any operator size; voffset + soffset stays below 2^31
+
+template <typename T> struct BufLoad;
+template <> struct BufLoad<float> {
+    static __device__ inline float4 vec(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return __builtin_bit_cast(float4, v);
+    }
+    static __device__ inline float one(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+};
+template <> struct BufLoad<double> {
+    static __device__ inline double2 vec(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return __builtin_bit_cast(double2, v);
+    }
+    static __device__ inline double one(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return __builtin_bit_cast(double, v);
+    }
+};
+
+template <typename T, int C, int NS>
+__global__ void __launch_bounds__(256, BCBF_PS_WAVES)
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
@@ -40,14 +78,16 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const bool live = tid < npairs;
     const int rbA = tid, rbB = nrb - 1 - tid;
     const T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(lop), 0, (int)(lop_elems<V>(Np) * sizeof(T)), 0x00020000);
     const T* __restrict__ Xb = X + (size_t)b * N * n;
     const T* __restrict__ UHBb = UHB + (size_t)b * N * C;
     const T* __restrict__ Vwb = Vw + (size_t)b * N * n;
 
     // ---- prologue: r = Phi rows owned by this thread:  phi_i = s2 exp(-1/2 |(x_i - xq)/ell|^2) * UHB_i
-    T xqr[BCBF_MAX_STATE_DIM], iell[BCBF_MAX_STATE_DIM];
+    T xqr[NS], iell[NS];
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+    for (int d = 0; d < NS; ++d) {
         xqr[d] = d < n ? xq[(size_t)b * n + d] : T(0);
         iell[d] = d < n ? T(1) / ell[(size_t)b * n + d] : T(0);
     }
@@ -63,7 +103,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             if (live && i < N) {
                 T d2 = T(0);
 #pragma unroll
-                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                for (int d = 0; d < NS; ++d)
                     if (d < n) { const T z = (Xb[(size_t)i * n + d] - xqr[d]) * iell[d]; d2 += z * z; }
                 k = s2 * texp<T>(T(-0.5) * d2);
             }
@@ -75,9 +115,9 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     double gram[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) gram[g] = 0.0;
-    T mk[BCBF_MAX_STATE_DIM][C];
+    T mk[NS][C];
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+    for (int d = 0; d < NS; ++d)
 #pragma unroll
         for (int c = 0; c < C; ++c) mk[d][c] = T(0);
 
@@ -102,15 +142,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             T w[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) w[c] = T(0);
-#pragma unroll
+#pragma unroll BCBF_PS_DUNR
             for (int q = 0; q < NB / 2; ++q) {
                 const int jj = h * (NB / 2) + q;
                 const int j = row0 + jj;
-                if (i >= (jj / V) * V) {
-                    const T val = lop[lop_base<V>(j, Np) + row0 + i];
+                const int voff = (i >= (jj / V) * V) ? (row0 + i) * (int)sizeof(T) : OOB;
+                const T val = BufLoad<T>::one(rsrc, voff, lop_base<V>(j, Np) * (int)sizeof(T));
 #pragma unroll
-                    for (int c = 0; c < C; ++c) w[c] += val * rbuf[jj][c];
-                }
+                for (int c = 0; c < C; ++c) w[c] += val * rbuf[jj][c];
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) w[c] += __shfl_xor(w[c], 32, 64);
@@ -125,7 +164,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 const int row = row0 + i;
                 if (row < N) {
 #pragma unroll
-                    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                    for (int d = 0; d < NS; ++d)
                         if (d < n) {
                             const T vw = Vwb[(size_t)row * n + d];
 #pragma unroll
@@ -140,15 +179,23 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         const bool actA = live && rbA >= rbmin;
         const bool actB = live && rbB >= rbmin;
         if (J + 1 < nblk) {
-            constexpr int UNR = 8;
-            for (int jj0 = 0; jj0 < NB; jj0 += UNR) {
-                VecT la[UNR], lb[UNR];
+            // Software pipeline over groups of UNR columns: the loads of group g+1 are in flight while
+            // group g is consumed.  The group loop stays rolled (two groups per trip, ping-pong
+            // register sets) so that the compiler cannot hoist every LDS read / load of the block.
+            constexpr int UNR = BCBF_PS_UNR, NGRP = NB / UNR;
+            static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
+            const int voffA = actA ? rbA * V * (int)sizeof(T) : OOB;
+            const int voffB = actB ? rbB * V * (int)sizeof(T) : OOB;
+            VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
+            auto issue = [&](VecT* la, VecT* lb, int col) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int base = lop_base<V>(row0 + jj0 + u, Np);
-                    if (actA) la[u] = *reinterpret_cast<const VecT*>(lop + base + rbA * V);
-                    if (actB) lb[u] = *reinterpret_cast<const VecT*>(lop + base + rbB * V);
+                    const int soff = lop_base<V>(col + u, Np) * (int)sizeof(T);
+                    la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
+                    lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
                 }
+            };
+            auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     T wj[C];
@@ -156,19 +203,22 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     for (int c = 0; c < C; ++c) wj[c] = wbuf[jj0 + u][c];
                     const T* pa = reinterpret_cast<const T*>(&la[u]);
                     const T* pb = reinterpret_cast<const T*>(&lb[u]);
-                    if (actA) {
 #pragma unroll
-                        for (int v = 0; v < V; ++v)
+                    for (int v = 0; v < V; ++v)
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[0][v][c] -= pa[v] * wj[c];
-                    }
-                    if (actB) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v)
-#pragma unroll
-                            for (int c = 0; c < C; ++c) acc[1][v][c] -= pb[v] * wj[c];
-                    }
+                        for (int c = 0; c < C; ++c) {
+                            acc[0][v][c] -= pa[v] * wj[c];
+                            acc[1][v][c] -= pb[v] * wj[c];
+                        }
                 }
+            };
+            issue(la0, lb0, row0);
+#pragma unroll 1
+            for (int g = 0; g < NGRP; g += 2) {
+                issue(la1, lb1, row0 + (g + 1) * UNR);
+                consume(la0, lb0, g * UNR);
+                if (g + 2 < NGRP) issue(la0, lb0, row0 + (g + 2) * UNR);
+                consume(la1, lb1, (g + 1) * UNR);
             }
         }
     }
@@ -178,7 +228,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
         for (int g = 0; g < NG; ++g) gram[g] = wave_sum(gram[g]);
 #pragma unroll
-        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+        for (int d = 0; d < NS; ++d)
             if (d < n) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) mk[d][c] = wave_sum(mk[d][c]);
@@ -187,7 +237,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             const T* M0b = M0 + (size_t)b * C * n;
             T* Mkb = Mk + (size_t)b * n * C;
 #pragma unroll
-            for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+            for (int d = 0; d < NS; ++d)
                 if (d < n) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) Mkb[d * C + c] = M0b[c * n + d] + mk[d][c];
@@ -224,12 +274,23 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (threads > 256) return BCBF_EINVAL;   // N <= 2048 (f32) / 1024 (f64)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-    switch (m) {
-        case 1: hipLaunchKernelGGL((posterior_step_kernel<T, 2>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n); break;
-        case 2: hipLaunchKernelGGL((posterior_step_kernel<T, 3>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n); break;
-        case 3: hipLaunchKernelGGL((posterior_step_kernel<T, 4>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n); break;
-        default: return BCBF_EINVAL;
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n)
+    if (n <= 4) {
+        switch (m) {
+            case 1: BCBF_PS_LAUNCH(2, 4); break;
+            case 2: BCBF_PS_LAUNCH(3, 4); break;
+            case 3: BCBF_PS_LAUNCH(4, 4); break;
+            default: return BCBF_EINVAL;
+        }
+    } else {
+        switch (m) {
+            case 1: BCBF_PS_LAUNCH(2, BCBF_MAX_STATE_DIM); break;
+            case 2: BCBF_PS_LAUNCH(3, BCBF_MAX_STATE_DIM); break;
+            case 3: BCBF_PS_LAUNCH(4, BCBF_MAX_STATE_DIM); break;
+            default: return BCBF_EINVAL;
+        }
     }
+#undef BCBF_PS_LAUNCH
     return check_launch("posterior_step");
 }
 

@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--ntrain", type=int, default=512)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--variant", default="dense")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="instances timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of a captured graph")
     return ap.parse_args()
 
