@@ -29,8 +29,10 @@ _TSIGS = {
     "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_socp": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_cbc_socp": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_unicycle_constraints": [P, P, P, P, "T", P, P, P, P, "T", P, P, P, P, c_int, c_int, P],
     "bcbf_unicycle_step": [P, P, "T", "T", c_int, P],
+    "bcbf_unicycle_control_step": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, P, P, P],
 }
 
 

@@ -16,10 +16,10 @@
 #define BCBF_PS_DUNR 4     // unroll of the diagonal-block mat-vec
 #endif
 #ifndef BCBF_PS_WAVES
-#define BCBF_PS_WAVES 4   // occupancy target (waves per SIMD) -> VGPR cap
+#define BCBF_PS_WAVES 2   // occupancy target (waves per SIMD) -> VGPR cap
 #endif
 #ifndef BCBF_PS_UNR
-#define BCBF_PS_UNR 2      // columns per software-pipeline stage of the streaming loop
+#define BCBF_PS_UNR 4      // columns per software-pipeline stage of the streaming loop
 #endif
 
 namespace bcbf {
@@ -112,9 +112,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         }
     }
 
-    double gram[NG];
+    // Gram W'W: per-lane partial sums in T (32 rows x nblk terms each), reduced and subtracted in fp64
+    T gram[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) gram[g] = 0.0;
+    for (int g = 0; g < NG; ++g) gram[g] = T(0);
     T mk[NS][C];
 #pragma unroll
     for (int d = 0; d < NS; ++d)
@@ -122,6 +123,52 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         for (int c = 0; c < C; ++c) mk[d][c] = T(0);
 
     const int nblk = Np / NB;
+    // Streaming pipeline state.  Column groups of UNR columns form ONE stream over all blocks: the
+    // loads of the next group (also across a block boundary) and the diagonal-block values of the
+    // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
+    constexpr int UNR = BCBF_PS_UNR, NGRP = NB / UNR, HALF = NB / 2;
+    static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
+    VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
+    T dval[HALF];
+    const int di = tid & 31, dh = (tid >> 5) & 1;
+    auto issue = [&](VecT* la, VecT* lb, int J, int g) {
+        const int rbmin = (J + 1) * RPB;
+        const int voffA = (live && rbA >= rbmin) ? rbA * V * (int)sizeof(T) : OOB;
+        const int voffB = (live && rbB >= rbmin) ? rbB * V * (int)sizeof(T) : OOB;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int soff = lop_base<V>(J * NB + g * UNR + u, Np) * (int)sizeof(T);
+            la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
+            lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
+        }
+    };
+    auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            T wj[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) wj[c] = wbuf[jj0 + u][c];
+            const T* pa = reinterpret_cast<const T*>(&la[u]);
+            const T* pb = reinterpret_cast<const T*>(&lb[u]);
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc[0][v][c] -= pa[v] * wj[c];
+                    acc[1][v][c] -= pb[v] * wj[c];
+                }
+        }
+    };
+    auto issue_diag = [&](int J) {      // inv(L_JJ)[di][dh*16 + q], wave 0 only (others: out of range -> 0)
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) {
+            const int jj = dh * HALF + q;
+            const int voff = (tid < 64 && di >= (jj / V) * V) ? (J * NB + di) * (int)sizeof(T) : OOB;
+            dval[q] = BufLoad<T>::one(rsrc, voff, lop_base<V>(J * NB + jj, Np) * (int)sizeof(T));
+        }
+    };
+    issue_diag(0);
+    if (nblk > 1) issue(la0, lb0, 0, 0);
     for (int J = 0; J < nblk; ++J) {
         const int row0 = J * NB;
         // 1. publish r_J
@@ -136,32 +183,27 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             }
         }
         __syncthreads();
-        // 2. diagonal block: w_J = inv(L_JJ) r_J  (wave 0; lane = (row i, column half h))
+        // 2. diagonal block: w_J = inv(L_JJ) r_J  (wave 0; lane = (row di, column half dh))
         if (tid < 64) {
-            const int i = tid & 31, h = tid >> 5;
             T w[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) w[c] = T(0);
-#pragma unroll BCBF_PS_DUNR
-            for (int q = 0; q < NB / 2; ++q) {
-                const int jj = h * (NB / 2) + q;
-                const int j = row0 + jj;
-                const int voff = (i >= (jj / V) * V) ? (row0 + i) * (int)sizeof(T) : OOB;
-                const T val = BufLoad<T>::one(rsrc, voff, lop_base<V>(j, Np) * (int)sizeof(T));
 #pragma unroll
-                for (int c = 0; c < C; ++c) w[c] += val * rbuf[jj][c];
+            for (int q = 0; q < HALF; ++q) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) w[c] += dval[q] * rbuf[dh * HALF + q][c];
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) w[c] += __shfl_xor(w[c], 32, 64);
-            if (h == 0) {
+            if (dh == 0) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) wbuf[i][c] = w[c];
+                for (int c = 0; c < C; ++c) wbuf[di][c] = w[c];
                 int g = 0;
 #pragma unroll
                 for (int a = 0; a < C; ++a)
 #pragma unroll
-                    for (int c = a; c < C; ++c) gram[g++] += (double)w[a] * (double)w[c];
-                const int row = row0 + i;
+                    for (int c = a; c < C; ++c) gram[g++] += w[a] * w[c];
+                const int row = row0 + di;
                 if (row < N) {
 #pragma unroll
                     for (int d = 0; d < NS; ++d)
@@ -174,50 +216,15 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             }
         }
         __syncthreads();
-        // 3. rows below the block:  r -= L[:, J] w_J
-        const int rbmin = (J + 1) * RPB;
-        const bool actA = live && rbA >= rbmin;
-        const bool actB = live && rbB >= rbmin;
+        // 3. rows below the block:  r -= L[:, J] w_J   (group 0 of this block is already in flight)
         if (J + 1 < nblk) {
-            // Software pipeline over groups of UNR columns: the loads of group g+1 are in flight while
-            // group g is consumed.  The group loop stays rolled (two groups per trip, ping-pong
-            // register sets) so that the compiler cannot hoist every LDS read / load of the block.
-            constexpr int UNR = BCBF_PS_UNR, NGRP = NB / UNR;
-            static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
-            const int voffA = actA ? rbA * V * (int)sizeof(T) : OOB;
-            const int voffB = actB ? rbB * V * (int)sizeof(T) : OOB;
-            VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
-            auto issue = [&](VecT* la, VecT* lb, int col) {
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int soff = lop_base<V>(col + u, Np) * (int)sizeof(T);
-                    la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
-                    lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
-                }
-            };
-            auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    T wj[C];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) wj[c] = wbuf[jj0 + u][c];
-                    const T* pa = reinterpret_cast<const T*>(&la[u]);
-                    const T* pb = reinterpret_cast<const T*>(&lb[u]);
-#pragma unroll
-                    for (int v = 0; v < V; ++v)
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            acc[0][v][c] -= pa[v] * wj[c];
-                            acc[1][v][c] -= pb[v] * wj[c];
-                        }
-                }
-            };
-            issue(la0, lb0, row0);
+            issue_diag(J + 1);
 #pragma unroll 1
             for (int g = 0; g < NGRP; g += 2) {
-                issue(la1, lb1, row0 + (g + 1) * UNR);
+                issue(la1, lb1, J, g + 1);
                 consume(la0, lb0, g * UNR);
-                if (g + 2 < NGRP) issue(la0, lb0, row0 + (g + 2) * UNR);
+                if (g + 2 < NGRP) issue(la0, lb0, J, g + 2);
+                else if (J + 2 < nblk) issue(la0, lb0, J + 1, 0);
                 consume(la1, lb1, (g + 1) * UNR);
             }
         }
@@ -225,8 +232,9 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 
     // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
     if (tid < 64) {
+        double gsum[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) gram[g] = wave_sum(gram[g]);
+        for (int g = 0; g < NG; ++g) gsum[g] = wave_sum((double)gram[g]);
 #pragma unroll
         for (int d = 0; d < NS; ++d)
             if (d < n) {
@@ -249,7 +257,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             for (int a = 0; a < C; ++a)
 #pragma unroll
                 for (int c = a; c < C; ++c) {
-                    const double G = gram[g++];
+                    const double G = gsum[g++];
                     double v1 = (double)s2 * (double)Bmb[a * C + c] - G;
                     double v2 = (double)s2 * (double)Bmb[c * C + a] - G;
                     if (a == c && jitter2 != nullptr) { v1 += (double)jitter2[(size_t)b * C + a]; v2 = v1; }

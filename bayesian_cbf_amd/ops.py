@@ -184,6 +184,25 @@ def socp(w, r, cones, relax_mask, rho, max_iters=100, out=None):
     return y, status, iters
 
 
+def cbc_socp(Mk, Bk, A, grad, cst, sign, fhat, ghat, w, r, relax_mask, rho, max_iters=100, want_terms=False):
+    """cbc_terms + socp in one launch (four lanes per instance).  Returns (y, status, iters, cones, cstatus, terms)."""
+    _chk(Mk, Bk, A, grad, cst, sign, fhat, ghat, w, r, relax_mask, rho)
+    Bt, K, n = grad.shape
+    m = ghat.shape[2]
+    f = dict(dtype=Mk.dtype, device=Mk.device)
+    terms = torch.empty(Bt, K, terms_width(m), **f) if want_terms else None
+    cones = torch.empty(Bt, K, cone_width(m), **f)
+    cstatus = torch.empty(Bt, K, dtype=torch.int32, device=Mk.device)
+    y = torch.empty(Bt, m + 1, **f)
+    status = torch.empty(Bt, dtype=torch.int32, device=Mk.device)
+    iters = torch.empty(Bt, dtype=torch.int32, device=Mk.device)
+    check(getattr(lib, "bcbf_cbc_socp" + _suf(Mk))(_p(Mk), _p(Bk), _p(A), _p(grad), _p(cst), _p(sign), _p(fhat),
+                                                   _p(ghat), _p(w), _p(r), _p(relax_mask), _p(rho), _p(terms),
+                                                   _p(cones), _p(cstatus), _p(y), _p(status), _p(iters), Bt, K, n, m,
+                                                   max_iters, _stream(Mk)), "bcbf_cbc_socp")
+    return y, status, iters, cones, cstatus, terms
+
+
 def coneqp(P, q, G, h, l, qdims, max_iters=100):
     """Generic small cone QP, fp64 (optimizers.py:42-116)."""
     _chk(P, q, G, h)
@@ -223,3 +242,37 @@ def unicycle_step(x, u, dt, L_true):
     check(getattr(lib, "bcbf_unicycle_step" + _suf(x))(_p(x), _p(u), dt, L_true, x.shape[0], _stream(x)),
           "bcbf_unicycle_step")
     return x
+
+
+def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,
+                          ev_start=None, ev_stop=None):
+    """One control step for a batch of unicycle instances in ONE host call
+    (ControllerCLFBayesian.control, unicycle_move_to_pose.py:926-995).
+
+    gp:   dict(Lop, Vw, X, UHB, ell, s2, Bm, M0, A);  task: dict(plan, dot_plan, Kp, centers, radii, tw, gammas,
+    w, r, sign, relax_mask, rho);  ws: dict of workspaces (grad, cst, fhat, ghat, Mk, Bk, cones, cstatus, y,
+    status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y']."""
+    _chk(x, gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], task["plan"], ws["y"])
+    Bt, N = gp["X"].shape[0], gp["X"].shape[1]
+    Kob = task["centers"].shape[1]
+    ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
+    ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
+    check(getattr(lib, "bcbf_unicycle_control_step" + _suf(x))(
+        _p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
+        _p(gp["M0"]), _p(gp["A"]), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
+        _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
+        _p(task["r"]), _p(task["sign"]), _p(task["relax_mask"]), _p(task["rho"]), _p(ws["grad"]), _p(ws["cst"]),
+        _p(ws["fhat"]), _p(ws["ghat"]), _p(ws["Mk"]), _p(ws["Bk"]), _p(ws["cones"]), _p(ws["cstatus"]), _p(ws["y"]),
+        _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, ev0, ev1, _stream(x)),
+        "bcbf_unicycle_control_step")
+    return ws["y"]
+
+
+def control_workspace(Bt, Kob, dtype, device, n=3, m=2):
+    K = 1 + Kob
+    f = dict(dtype=dtype, device=device)
+    i = dict(dtype=torch.int32, device=device)
+    return dict(grad=torch.empty(Bt, K, n, **f), cst=torch.empty(Bt, K, **f), fhat=torch.empty(Bt, n, **f),
+                ghat=torch.empty(Bt, n, m, **f), Mk=torch.empty(Bt, n, 1 + m, **f), Bk=torch.empty(Bt, 1 + m, 1 + m, **f),
+                cones=torch.empty(Bt, K, cone_width(m), **f), cstatus=torch.empty(Bt, K, **i),
+                y=torch.empty(Bt, m + 1, **f), status=torch.empty(Bt, **i), iters=torch.empty(Bt, **i))

@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--ntrain", type=int, default=512)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--variant", default="dense")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
-    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of a captured graph")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="instances timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--chunks", type=int, default=1, help="independent sub-batches, one HIP stream each")
     return ap.parse_args()
 
 
@@ -113,38 +113,40 @@ def main():
     torch.cuda.synchronize()
     assert int((info != 0).sum()) == 0, "Cholesky failed on the synthetic workload"
 
-    x = task["x"].clone()
-    grad = torch.empty(Bt, K, 3, dtype=dtype, device=dev)
-    cst = torch.empty(Bt, K, dtype=dtype, device=dev)
-    fhat = torch.empty(Bt, 3, dtype=dtype, device=dev)
-    ghat = torch.empty(Bt, 3, 2, dtype=dtype, device=dev)
-    Mk = torch.empty(Bt, n, 1 + m, dtype=dtype, device=dev)
-    Bk = torch.empty(Bt, 1 + m, 1 + m, dtype=dtype, device=dev)
-    cones = torch.empty(Bt, K, ops.cone_width(m), dtype=dtype, device=dev)
-    cstatus = torch.empty(Bt, K, dtype=torch.int32, device=dev)
-    y = torch.empty(Bt, m + 1, dtype=dtype, device=dev)
-    status = torch.empty(Bt, dtype=torch.int32, device=dev)
-    iters = torch.empty(Bt, dtype=torch.int32, device=dev)
-    u = torch.empty(Bt, m, dtype=dtype, device=dev)
+    # ---- the batch is processed as `chunks` independent sub-batches, each on its own HIP stream:
+    # instances never interact, so sub-batch A's SOCP (latency-bound, few waves) overlaps
+    # sub-batch B's posterior kernel (HBM-bound) -- also across consecutive steps.
+    S = max(1, args.chunks)
+    assert Bt % S == 0
+    Bc = Bt // S
     dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
-    def constraints():
-        ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], 10.0, task["centers"], task["radii"],
-                                 task["tw"], task["gammas"], L_mean, out=(grad, cst, fhat, ghat))
+    class Chunk:
+        def __init__(self, c):
+            sl = slice(c * Bc, (c + 1) * Bc)
+            q = {k: v[sl] for k, v in p.items()}
+            self.gp = dict(Lop=Lop[sl], Vw=Vw[sl], X=q["X"], UHB=UHB[sl], ell=q["ell"], s2=q["s2"], Bm=q["Bm"],
+                           M0=q["M0"], A=q["A"])
+            self.task = {k: (v[sl] if v.dim() > 0 and v.shape[0] == Bt else v) for k, v in task.items()}
+            self.x = task["x"][sl].clone()
+            self.ws = ops.control_workspace(Bc, 2, dtype, dev)
 
-    def posterior():
-        ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], x, out=(Mk, Bk))
+        def step(self, ev0=None, ev1=None):
+            # one host call: constraints -> posterior -> terms -> SOCP -> plant step, on the current stream
+            ops.unicycle_control_step(self.gp, self.task, self.ws, self.x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
+                                      clf_gamma=10.0, max_iters=20, ev_start=ev0, ev_stop=ev1)
 
-    def solve():
-        ops.cbc_terms(Mk, Bk, p["A"], grad, cst, task["sign"], fhat, ghat, out=(None, cones, cstatus))
-        ops.socp(task["w"], task["r"], cones, task["relax_mask"], task["rho"], out=(y, status, iters))
-        u.copy_(y[:, :m])
-        ops.unicycle_step(x, u, dt_plant, L_true)
+    chunks = [Chunk(c) for c in range(S)]
+    torch.cuda.synchronize()
 
-    def step():
-        constraints()
-        posterior()
-        solve()
+    def step(ev=None):
+        for c, ch in enumerate(chunks):
+            with torch.cuda.stream(streams[c]):
+                if ev is None:
+                    ch.step()
+                else:
+                    ch.step(ev[c][0], ev[c][1])
 
     for _ in range(args.warmup):
         step()
@@ -155,21 +157,24 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    # ---- timed region: exactly `steps` steps, HIP events around the dominant kernel
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # ---- timed region: exactly `steps` steps, HIP events around the dominant kernel (on its stream)
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
+          for _ in range(args.steps)]
+    for row in ev:                      # instantiate the hipEvent handles (torch creates them on first record)
+        for c, (e0, e1) in enumerate(row):
+            e0.record(streams[c])
+            e1.record(streams[c])
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        constraints()
-        ev[s][0].record()
-        posterior()
-        ev[s][1].record()
-        solve()
+        step(ev[s])
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for row in ev for a, b in row]))
+    status = torch.cat([ch.ws["status"] for ch in chunks])
+    iters = torch.cat([ch.ws["iters"] for ch in chunks])
 
     n_opt = int((status == 0).sum())
     stats = torch.tensor([elapsed, float(n_opt), float(Bt), float(iters.float().mean())], dtype=torch.float64, device=dev)
@@ -184,7 +189,7 @@ def main():
     value = total_instances * args.steps / elapsed
 
     if rank == 0:
-        bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bt
+        bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bc
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; HBM GB/s vs peak" % (N, Bt),
@@ -203,11 +208,11 @@ def main():
             "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints (1 CLC + 2 obstacle "
                                    "CBCs) + SOCP per step, independent GP per instance",
                        "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
-                       "regime": "independent GPs (I)", "inputs": args.variant, "parallelism": "instances sharded, dp%d" % world},
+                       "regime": "independent GPs (I)", "inputs": args.variant, "streams": S, "parallelism": "instances sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
             "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(p, task, args.cpu_sample, N, n, m)

@@ -14,8 +14,8 @@
  *    of independent instances (one GP / one control loop each); the caller owns all memory and
  *    the library allocates nothing;
  *  - N = #training points per instance, n = state dim, m = control dim, C = 1+m;
- *  - `_f32` / `_f64` select the storage + arithmetic type of the GP kernels (the conic solver
- *    always iterates in fp64 and converts at its boundary);
+ *  - `_f32` / `_f64` select the storage + arithmetic type (the fp32 conic solver keeps fp32 iterates and
+ *    factors its reduced KKT system in fp64; bcbf_coneqp is fp64 only);
  *  - `stream` is a hipStream_t (pass 0 for the default stream); calls are asynchronous and
  *    re-entrant; no randomness is drawn inside the library (jitter vectors are inputs);
  *  - return value: 0 on success, <0 on a bad argument / launch failure (BCBF_E*); per-instance
@@ -139,13 +139,24 @@ int bcbf_cbc_terms_f64(const double* Mk, const double* Bk, const double* A, cons
 /* K10: the per-step program of ControllerCLFBayesian.control (unicycle_move_to_pose.py:926-953):
  *   min sum_i w_i (u_i - r_i)^2 + w_m relax^2   s.t.  c_k'u + d_k + relax_mask_k relax >= rho |A_k u + b_k|
  * Replaces cvxpy+GUROBI (and cvxopt socp, optimizers.py:42-102).  One primal-dual interior-point
- * solve (NT scaling, Mehrotra correction) per instance in registers, fp64.
+ * solve (NT scaling, Mehrotra correction) per instance in registers, four lanes per instance.
  * w[Bt,m+1] r[Bt,m] cones[Bt,K,Q] (layout above) relax_mask[K] rho[Bt]
  * -> y[Bt,m+1] = [u, relax], status[Bt], iters[Bt] (iters may be NULL). */
 int bcbf_socp_f32(const float* w, const float* r, const float* cones, const float* relax_mask, const float* rho,
                   float* y, int* status, int* iters, int Bt, int K, int m, int max_iters, void* stream);
 int bcbf_socp_f64(const double* w, const double* r, const double* cones, const double* relax_mask, const double* rho,
                   double* y, int* status, int* iters, int Bt, int K, int m, int max_iters, void* stream);
+
+/* K8+K9+K10 fused: bcbf_cbc_terms followed by bcbf_socp in one launch (four lanes per instance, lane k
+ * owns constraint k); same inputs and outputs, terms / cones / cstatus optional (may be NULL). */
+int bcbf_cbc_socp_f32(const float* Mk, const float* Bk, const float* A, const float* grad, const float* cst,
+                      const float* sign, const float* fhat, const float* ghat, const float* w, const float* r,
+                      const float* relax_mask, const float* rho, float* terms, float* cones, int* cstatus,
+                      float* y, int* status, int* iters, int Bt, int K, int n, int m, int max_iters, void* stream);
+int bcbf_cbc_socp_f64(const double* Mk, const double* Bk, const double* A, const double* grad, const double* cst,
+                      const double* sign, const double* fhat, const double* ghat, const double* w, const double* r,
+                      const double* relax_mask, const double* rho, double* terms, double* cones, int* cstatus,
+                      double* y, int* status, int* iters, int Bt, int K, int n, int m, int max_iters, void* stream);
 
 /* Generic small cone QP (the reference's optimizer_socp_* / optimizer_qp_cvxpy, optimizers.py:42-116):
  *   min 1/2 x'P x + q'x  s.t.  G x + s = h,  s in R_+^l x Q^{q_1} x ... x Q^{q_nq}
@@ -172,6 +183,29 @@ int bcbf_unicycle_constraints_f64(const double* x, const double* plan, const dou
 /* Explicit-Euler plant step x += (g(x; L_true) u) dt  (unicycle_move_to_pose.py:277-282, sampling.py:68-74). */
 int bcbf_unicycle_step_f32(float* x, const float* u, float dt, float L_true, int Bt, void* stream);
 int bcbf_unicycle_step_f64(double* x, const double* u, double dt, double L_true, int Bt, void* stream);
+
+/* One host call per control step of ControllerCLFBayesian.control on the unicycle
+ * (unicycle_move_to_pose.py:926-995): bcbf_unicycle_constraints -> bcbf_posterior_step (n=3, m=2) ->
+ * bcbf_cbc_terms (K = 1+Kob, sign[K]) -> bcbf_socp -> x += g(x; L_true) u dt (skipped when dt <= 0),
+ * all on `stream`.  Arguments are those of the individual entry points; grad/cst/fhat/ghat/Mk/Bk/cones/
+ * cstatus are caller-provided workspaces that also expose the intermediates; y[Bt,3] = [u, relax].
+ * ev_start / ev_stop (optional hipEvent_t) are recorded around the posterior kernel for profiling. */
+int bcbf_unicycle_control_step_f32(
+    const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+    const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
+    const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
+    float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
+    float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
+    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters,
+    void* ev_start, void* ev_stop, void* stream);
+int bcbf_unicycle_control_step_f64(
+    const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
+    const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
+    const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,
+    const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
+    const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
+    double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
+    int N, int Kob, int max_iters, void* ev_start, void* ev_stop, void* stream);
 
 #ifdef __cplusplus
 }

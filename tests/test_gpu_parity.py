@@ -265,6 +265,32 @@ def test_socp_vs_oracle(ops, dtype, m, K):
                                    atol=1e-7 if dtype == torch.float64 else 3e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_fused_cbc_socp_equals_two_step_path(ops, dtype):
+    """bcbf_cbc_socp (terms + cones + solve in one launch) == bcbf_cbc_terms followed by bcbf_socp."""
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+    Bt = 70                                  # not a multiple of 64: exercises the shadow quads
+    p = make_instances(Bt, 64, 3, 2, dtype=dtype, device=DEV, seed=31)
+    t = make_unicycle_task(Bt, dtype=dtype, device=DEV, seed=32)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    Mk, Bk = ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], t["x"])
+    grad, cst, fhat, ghat = ops.unicycle_constraints(t["x"], t["plan"], t["dot_plan"], t["Kp"], 10.0, t["centers"],
+                                                     t["radii"], t["tw"], t["gammas"], 4.0)
+    terms, cones, cstatus = ops.cbc_terms(Mk, Bk, p["A"], grad, cst, t["sign"], fhat, ghat)
+    y1, st1, it1 = ops.socp(t["w"], t["r"], cones, t["relax_mask"], t["rho"])
+    y2, st2, it2, cones2, cstatus2, terms2 = ops.cbc_socp(Mk, Bk, p["A"], grad, cst, t["sign"], fhat, ghat, t["w"],
+                                                          t["r"], t["relax_mask"], t["rho"], want_terms=True)
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    rel_close(host(terms2), host(terms), tol, what="terms")
+    rel_close(host(cones2), host(cones), tol, what="cones")
+    assert torch.equal(cstatus, cstatus2) and torch.equal(st1, st2)
+    ok = (st1 == 0).cpu().numpy()
+    assert ok.sum() >= 10          # (this small-N synthetic task leaves many programs infeasible)
+    np.testing.assert_allclose(host(y2)[ok], host(y1)[ok], rtol=1e-6 if dtype == torch.float64 else 2e-3,
+                               atol=1e-7 if dtype == torch.float64 else 2e-3)
+
+
 def test_socp_flags_infeasible_instances_without_disturbing_others(ops):
     rng = np.random.default_rng(0)
     A, b, c, d = _random_programs(rng, 8)

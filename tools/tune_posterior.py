@@ -17,11 +17,11 @@ VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 
 VARIANTS = {
-    "u2_w4": ["-DBCBF_PS_UNR=2", "-DBCBF_PS_WAVES=4"],
+    "u4_w2": ["-DBCBF_PS_UNR=4", "-DBCBF_PS_WAVES=2"],
     "u4_w3": ["-DBCBF_PS_UNR=4", "-DBCBF_PS_WAVES=3"],
-    "u4_w4": ["-DBCBF_PS_UNR=4", "-DBCBF_PS_WAVES=4"],
-    "u2_w5": ["-DBCBF_PS_UNR=2", "-DBCBF_PS_WAVES=5"],
     "u8_w2": ["-DBCBF_PS_UNR=8", "-DBCBF_PS_WAVES=2"],
+    "u8_w1": ["-DBCBF_PS_UNR=8", "-DBCBF_PS_WAVES=1"],
+    "u16_w1": ["-DBCBF_PS_UNR=16", "-DBCBF_PS_WAVES=1"],
 }
 
 
