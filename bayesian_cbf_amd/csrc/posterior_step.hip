@@ -62,7 +62,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
-                      int N, int Np, int n) {
+                      T* __restrict__ Wout, int shared, int N, int Np, int n) {
     constexpr int V = Vec<T>::V;
     using VecT = typename Vec<T>::type;
     constexpr int RPB = NB / V;          // row blocks per diagonal block
@@ -72,26 +72,27 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     __shared__ __attribute__((aligned(16))) T wbuf[NB][CP];
 
     const int b = blockIdx.x;
+    const int gb = shared ? 0 : b;      // regime S: every query reads the one shared GP (instance 0)
     const int tid = threadIdx.x;
     const int nrb = Np / V;
     const int npairs = nrb / 2;
     const bool live = tid < npairs;
     const int rbA = tid, rbB = nrb - 1 - tid;
-    const T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const T* __restrict__ lop = Lop + (size_t)gb * lop_elems<V>(Np);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(lop), 0, (int)(lop_elems<V>(Np) * sizeof(T)), 0x00020000);
-    const T* __restrict__ Xb = X + (size_t)b * N * n;
-    const T* __restrict__ UHBb = UHB + (size_t)b * N * C;
-    const T* __restrict__ Vwb = Vw + (size_t)b * N * n;
+    const T* __restrict__ Xb = X + (size_t)gb * N * n;
+    const T* __restrict__ UHBb = UHB + (size_t)gb * N * C;
+    const T* __restrict__ Vwb = Vw + (size_t)gb * N * n;
 
     // ---- prologue: r = Phi rows owned by this thread:  phi_i = s2 exp(-1/2 |(x_i - xq)/ell|^2) * UHB_i
     T xqr[NS], iell[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
         xqr[d] = d < n ? xq[(size_t)b * n + d] : T(0);
-        iell[d] = d < n ? T(1) / ell[(size_t)b * n + d] : T(0);
+        iell[d] = d < n ? T(1) / ell[(size_t)gb * n + d] : T(0);
     }
-    const T s2 = s2p[b];
+    const T s2 = s2p[gb];
     T acc[2][V][C];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -198,6 +199,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             if (dh == 0) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) wbuf[di][c] = w[c];
+                if (Wout != nullptr) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) Wout[((size_t)b * Np + row0 + di) * C + c] = w[c];
+                }
                 int g = 0;
 #pragma unroll
                 for (int a = 0; a < C; ++a)
@@ -242,7 +247,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 for (int c = 0; c < C; ++c) mk[d][c] = wave_sum(mk[d][c]);
             }
         if (tid == 0) {
-            const T* M0b = M0 + (size_t)b * C * n;
+            const T* M0b = M0 + (size_t)gb * C * n;
             T* Mkb = Mk + (size_t)b * n * C;
 #pragma unroll
             for (int d = 0; d < NS; ++d)
@@ -250,7 +255,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                     for (int c = 0; c < C; ++c) Mkb[d * C + c] = M0b[c * n + d] + mk[d][c];
                 }
-            const T* Bmb = Bm + (size_t)b * C * C;
+            const T* Bmb = Bm + (size_t)gb * C * C;
             T* Bkb = Bk + (size_t)b * C * C;
             int g = 0;
 #pragma unroll
@@ -271,7 +276,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 template <typename T>
 static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                  const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
-                                 int Bt, int N, int n, int m, void* stream) {
+                                 T* Wout, int shared, int Bt, int N, int n, int m, void* stream) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
@@ -282,7 +287,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (threads > 256) return BCBF_EINVAL;   // N <= 2048 (f32) / 1024 (f64)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, N, Np, n)
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, shared, N, Np, n)
     if (n <= 4) {
         switch (m) {
             case 1: BCBF_PS_LAUNCH(2, 4); break;
@@ -308,11 +313,28 @@ extern "C" int bcbf_posterior_step_f32(const float* Lop, const float* Vw, const 
                                        const float* ell, const float* s2, const float* Bm, const float* M0,
                                        const float* xq, const float* jitter2, float* Mk, float* Bk,
                                        int Bt, int N, int n, int m, void* stream) {
-    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Bt, N, n, m, stream);
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, 0, Bt, N, n, m, stream);
 }
 extern "C" int bcbf_posterior_step_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
                                        const double* ell, const double* s2, const double* Bm, const double* M0,
                                        const double* xq, const double* jitter2, double* Mk, double* Bk,
                                        int Bt, int N, int n, int m, void* stream) {
-    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Bt, N, n, m, stream);
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, 0, Bt, N, n, m, stream);
+}
+
+// Query variant: `shared` != 0 -> all Bt queries go against ONE GP (the reference's own batched
+// API, custom_predict with b test points, control_affine_model.py:536,1051); W (optional,
+// [Bt, Np, C] with Np = N rounded up to 32) = L^-1 Phi(x_b) lets the caller form cross-covariances
+// between different queries, B_k(x,x') = k(x,x') Bm - W(x)'W(x')  (:586, :1079-1088).
+extern "C" int bcbf_posterior_query_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                        const float* ell, const float* s2, const float* Bm, const float* M0,
+                                        const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                        int shared, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream);
+}
+extern "C" int bcbf_posterior_query_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                        const double* ell, const double* s2, const double* Bm, const double* M0,
+                                        const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                        int shared, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream);
 }

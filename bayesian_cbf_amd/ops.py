@@ -118,6 +118,26 @@ def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None)
     return Mk, Bk
 
 
+def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=True, want_W=False):
+    """b queries against one shared GP (shared=True; GP tensors carry a leading axis of 1) or one query per
+    instance.  Returns (Mk[b,n,C], Bk[b,C,C], W[b,Np,C] | None)."""
+    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)
+    N, n = X.shape[1], X.shape[2]
+    C = UHB.shape[2]
+    b = xq.shape[0]
+    if shared and X.shape[0] != 1:
+        raise ValueError("shared query: GP tensors must have a leading axis of 1")
+    Mk = torch.empty(b, n, C, dtype=X.dtype, device=X.device)
+    Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
+    Np = (N + 31) // 32 * 32
+    W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
+    check(getattr(lib, "bcbf_posterior_query" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm),
+                                                         _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk), _p(W),
+                                                         1 if shared else 0, b, N, n, C - 1, _stream(X)),
+          "bcbf_posterior_query")
+    return Mk, Bk, W
+
+
 def terms_width(m):
     return m + 1 + m * m + m + 1
 

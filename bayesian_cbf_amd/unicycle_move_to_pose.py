@@ -1,0 +1,163 @@
+"""Mirror of the hot-path classes of bayes_cbf/unicycle_move_to_pose.py on libbcbf.
+
+`ControllerCLFBayesian.control(x, t)` keeps the reference's signature (:926) and accepts either
+one state [3] (reference behaviour) or a batch of states [Bt, 3] -- one independent control loop
+per row (new capability).  The chance-constraint assembly and the SOCP run in one fused launch
+sequence (`ops.unicycle_control_step`); infeasible programs raise `ValueError` for a single state,
+exactly like the reference (:954-964), and are masked (status != 0, control = ctrl_ref) in a batch."""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .cbc2 import cbc1_safety_factor
+from .planner import PiecewiseLinearPlanner  # noqa: F401  (re-export, as in the reference module)
+
+
+class AckermannDrive:
+    """Plant / prior mean dynamics (unicycle_move_to_pose.py:200-292)."""
+    state_size, ctrl_size = 3, 2
+
+    def __init__(self, L=0.2, kernel_diag_A=(1.0, 1.0, 1.0)):
+        self.L = L
+        self.kernel_diag_A = torch.as_tensor(kernel_diag_A, dtype=torch.float64)
+        self.current_state = None
+
+    def set_init_state(self, x):
+        self.current_state = x.clone()
+
+    def f_func(self, x):
+        return torch.zeros_like(x)
+
+    def g_func(self, state_in):
+        state = state_in.unsqueeze(0) if state_in.dim() <= 1 else state_in
+        th = state[..., 2]
+        z, o = torch.zeros_like(th), torch.ones_like(th)
+        gX = torch.stack([torch.stack([th.cos(), z], -1), torch.stack([th.sin(), z], -1),
+                          torch.stack([z, o / self.L], -1)], -2)
+        return gX.squeeze(0) if state_in.dim() <= 1 else gX
+
+    def step(self, u, dt):
+        """Explicit Euler (:277-282); device batches go through the HIP kernel."""
+        x = self.current_state
+        if x.is_cuda and x.dim() == 2:
+            ops.unicycle_step(x, u.contiguous(), float(dt), float(self.L))
+            return dict(x=x, xdot=None)
+        xdot = self.f_func(x) + (self.g_func(x) @ u.unsqueeze(-1)).squeeze(-1)
+        self.current_state = x + xdot * dt
+        return dict(xdot=xdot, x=self.current_state)
+
+
+class CLFCartesian:
+    """Parameters of the reference's CLFCartesian (:522-615); evaluated inside bcbf_unicycle_constraints."""
+
+    def __init__(self, Kp=(0.9, 1.5, 4.0)):
+        self.Kp = torch.as_tensor(Kp, dtype=torch.float64)
+
+
+class ObstacleCBF:
+    """Parameters of the reference's ObstacleCBF (:618-696)."""
+
+    def __init__(self, center, radius, term_weights=(0.5, 0.5)):
+        self.center = torch.as_tensor(center, dtype=torch.float64)
+        self.radius = torch.as_tensor(radius, dtype=torch.float64)
+        self.term_weights = tuple(term_weights)
+
+
+def obstacles_at_mid_from_start_and_goal(x, x_g, term_weights=(0.5, 0.5)):
+    """unicycle_move_to_pose.py:1562-1570 (x, x_g: [3] or [Bt,3])."""
+    R90 = torch.tensor([[0.0, -1.0], [1.0, 0.0]], dtype=x.dtype, device=x.device)
+    d = x[..., :2] - x_g[..., :2]
+    mid = (x[..., :2] + x_g[..., :2]) / 2
+    off = d @ R90.T / 3
+    rad = d.norm(dim=-1) / 4
+    return [ObstacleCBF(mid + off, rad, term_weights), ObstacleCBF(mid - off, rad, term_weights)]
+
+
+class ControllerCLFBayesian:
+    """unicycle_move_to_pose.py:801-998.  `dynamics` is a `BatchedControlAffineGP` (learned residual,
+    regime I), or None for the fixed-kernel model of AckermannDrive.fu_func_gp (:262-275:
+    M_k = 0, B_k = I, A = diag(kernel_diag_A))."""
+
+    def __init__(self, planner, u_dim=2, coordinate_converter=None, dynamics=None, clf=None, clf_gamma=10.0,
+                 cost_weights=(0.33, 0.33, 0.33), cbfs=(), cbf_gammas=(), ctrl_min=(-10.0, -np.pi * 5),
+                 ctrl_max=(10.0, np.pi * 5), ctrl_ref=(0.0, 0.0), max_risk=1e-2, visualizer=None,
+                 mean_dynamics=None, device="cuda", dtype=torch.float64):
+        self.u_dim = 2
+        self.planner, self.dynamics, self.clf = planner, dynamics, clf or CLFCartesian()
+        self.clf_gamma, self.cost_weights = clf_gamma, cost_weights
+        self.cbfs, self.cbf_gammas = list(cbfs), list(cbf_gammas)
+        self.ctrl_min, self.ctrl_max, self.ctrl_ref = np.array(ctrl_min), np.array(ctrl_max), np.array(ctrl_ref)
+        self.max_risk = max_risk
+        self.mean_dynamics = mean_dynamics or AckermannDrive(L=1.0)
+        self.device, self.dtype = torch.device(device), dtype
+        self._ws = None
+
+    def _factor(self):
+        assert 0 <= self.max_risk <= 0.5
+        return 0.0 if self.max_risk == 0.5 else cbc1_safety_factor(self.max_risk)
+
+    def _task(self, Bt, t):
+        f = dict(dtype=self.dtype, device=self.device)
+        exp = lambda v: torch.as_tensor(v, **f).reshape(-1, v.shape[-1] if hasattr(v, "shape") and v.ndim else 1)
+        plan = self.planner.plan(t).to(**f)
+        dplan = self.planner.dot_plan(t).to(**f)
+        plan = plan.expand(Bt, 3).contiguous() if plan.dim() == 1 else plan.contiguous()
+        dplan = dplan.expand(Bt, 3).contiguous() if dplan.dim() == 1 else dplan.contiguous()
+        Kob = len(self.cbfs)
+        centers = torch.stack([c.center.to(**f).expand(Bt, 2) if c.center.dim() == 1 else c.center.to(**f)
+                               for c in self.cbfs], dim=1).contiguous()
+        radii = torch.stack([c.radius.to(**f).expand(Bt) if c.radius.dim() == 0 else c.radius.to(**f)
+                             for c in self.cbfs], dim=1).contiguous()
+        tw = torch.tensor(self.cbfs[0].term_weights if Kob else (0.5, 0.5), **f)
+        return dict(plan=plan, dot_plan=dplan, Kp=self.clf.Kp.to(**f), centers=centers, radii=radii, tw=tw,
+                    gammas=torch.tensor(list(self.cbf_gammas), **f),
+                    w=torch.tensor(list(self.cost_weights), **f).expand(Bt, 3).contiguous(),
+                    r=torch.tensor(self.ctrl_ref, **f).expand(Bt, 2).contiguous(),
+                    sign=torch.tensor([-1.0] + [1.0] * Kob, **f),
+                    relax_mask=torch.tensor([1.0] + [0.0] * Kob, **f),
+                    rho=torch.full((Bt,), self._factor(), **f))
+
+    def _gp(self, Bt):
+        f = dict(dtype=self.dtype, device=self.device)
+        if self.dynamics is not None:
+            return self.dynamics.as_dict()
+        raise NotImplementedError
+
+    def control(self, x_torch, t):
+        single = x_torch.dim() == 1
+        x = x_torch.reshape(-1, 3).to(device=self.device, dtype=self.dtype).contiguous()
+        Bt = x.shape[0]
+        task = self._task(Bt, t)
+        Kob = len(self.cbfs)
+        if self._ws is None or self._ws["y"].shape[0] != Bt:
+            self._ws = ops.control_workspace(Bt, Kob, self.dtype, self.device)
+        ws = self._ws
+        L_mean = float(self.mean_dynamics.L)
+        if self.dynamics is not None:
+            ops.unicycle_control_step(self.dynamics.as_dict(), task, ws, x, dt=0.0, L_mean=L_mean,
+                                      clf_gamma=float(self.clf_gamma))
+        else:   # fixed-kernel model: no posterior kernel, M_k = 0, B_k = I
+            ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], float(self.clf_gamma),
+                                     task["centers"], task["radii"], task["tw"], task["gammas"], L_mean,
+                                     out=(ws["grad"], ws["cst"], ws["fhat"], ws["ghat"]))
+            ws["Mk"].zero_()
+            ws["Bk"].copy_(torch.eye(3, dtype=self.dtype, device=self.device).expand(Bt, 3, 3))
+            A = torch.diag(self.mean_dynamics.kernel_diag_A.to(dtype=self.dtype, device=self.device)).expand(Bt, 3, 3).contiguous()
+            y, status, iters, cones, cstatus, _ = ops.cbc_socp(ws["Mk"], ws["Bk"], A, ws["grad"], ws["cst"], task["sign"],
+                                                              ws["fhat"], ws["ghat"], task["w"], task["r"],
+                                                              task["relax_mask"], task["rho"])
+            ws["y"].copy_(y)
+            ws["status"].copy_(status)
+        u = ws["y"][:, :2]
+        if single:
+            st = int(ws["status"][0])
+            if st != 0:
+                raise ValueError({1: "max_iterations", 2: "infeasible", 3: "bad_cone"}.get(st, "solver_error"))
+            return u[0].to(device=x_torch.device, dtype=x_torch.dtype)
+        bad = ws["status"] != 0
+        if bool(bad.any()):
+            u = torch.where(bad[:, None], task["r"], u)
+        self.last_status = ws["status"]
+        return u.to(dtype=x_torch.dtype)

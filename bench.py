@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--ntrain", type=int, default=512)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--variant", default="dense")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="instances timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
     ap.add_argument("--chunks", type=int, default=1, help="independent sub-batches, one HIP stream each")
     return ap.parse_args()
 
@@ -63,6 +63,8 @@ def cpu_baseline(p, task, sample, N, n, m):
         states.append(ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i],
                                       h["M0"][i], h["jitter"][i][None] / 1e-5))
     clf = ouni.CLFCartesian(Kp)
+    from threadpoolctl import threadpool_limits
+    limiter = threadpool_limits(limits=1)          # a scalar, single-thread port: cores = 1
     t0 = time.perf_counter()
     nopt = 0
     for i in range(sample):
@@ -81,10 +83,12 @@ def cpu_baseline(p, task, sample, N, n, m):
         sol = osocp.clf_cbf_socp(h["w"][i], h["r"][i], cones, h["rho"][i], relax_mask)
         nopt += sol["status"] == "optimal"
     el = time.perf_counter() - t0
-    return dict(value=sample / el, unit="control steps/s (instance-steps)", cores=int(torch.get_num_threads()),
+    limiter.restore_original_limits()
+    return dict(value=sample / el, unit="control steps/s (instance-steps)", cores=1,
                 kind="port",
                 sample="%d instances of the same N=%d,n=%d,m=%d workload, one at a time, factor cached "
-                       "(numpy/scipy oracle: triangular solve + closed-form terms + coneqp), %.1f s" % (sample, N, n, m, el))
+                       "(numpy/scipy oracle, BLAS limited to 1 thread: triangular solve + closed-form terms + coneqp), %.1f s; "
+                       "host has %d hardware threads" % (sample, N, n, m, el, os.cpu_count()))
 
 
 def main():

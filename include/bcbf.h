@@ -121,6 +121,19 @@ int bcbf_posterior_step_f64(const double* Lop, const double* Vw, const double* X
                             const double* xq, const double* jitter2, double* Mk, double* Bk,
                             int Bt, int N, int n, int m, void* stream);
 
+/* Same kernel, query form.  shared != 0: all Bt queries are evaluated against ONE GP (instance 0 of
+ * Lop/Vw/X/UHB/ell/s2/Bm/M0) -- the reference's own batched API, custom_predict with b test points
+ * (control_affine_model.py:536, 1051).  W (optional, [Bt, Np, C], Np = N rounded up to 32) receives
+ * L^-1 Phi(x_b) so the caller can form cross-covariances B_k(x,x') = k(x,x') Bm - W(x)'W(x') (:586, :1079-1088). */
+int bcbf_posterior_query_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                             const float* ell, const float* s2, const float* Bm, const float* M0,
+                             const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                             int shared, int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_query_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                             const double* ell, const double* s2, const double* Bm, const double* M0,
+                             const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                             int shared, int Bt, int N, int n, int m, void* stream);
+
 /* K8 (rel-degree 1) + K9: constraint terms and their cone form, K constraints per instance.
  *   mean(u) = bfe'u + e,  var(u) = u'V u + bfv'u + v   for  sign*(grad' (fhat + ghat u + F(x)[1;u]) + cst)
  * Replaces cbc2_quadratic_terms on a rel-degree-1 expression (cbc2.py:7-23, gp_algebra.py:109-223,
