@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0.  `value` = instance control-steps/s over all GPU
 (= batch x batched-steps/s; `batched_steps_per_s` is reported beside it).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -43,6 +44,22 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
     ap.add_argument("--chunks", type=int, default=1, help="independent sub-batches, one HIP stream each")
     return ap.parse_args()
+
+
+def measured_traffic(N, Bt, dtype_name, bytes_launch):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied).  A counter run cannot
+    be nested inside this process, so the number is attached only when the profiled workload is this workload."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if w.get("N_train") == N and w.get("dtype") == dtype_name and w.get("batch"):
+            best = d["hbm_bytes_per_launch"] * (Bt / float(w["batch"]))    # per-instance traffic is batch independent
+    return best
 
 
 def algorithmic_bytes_per_instance(N, n, m, itemsize):
@@ -215,7 +232,7 @@ def main():
                        "regime": "independent GPs (I)", "inputs": args.variant, "streams": S, "parallelism": "instances sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
             "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, Bc, args.dtype, bytes_launch),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
         }
         if world == 1 and args.cpu_sample > 0:
