@@ -96,6 +96,174 @@ static int launch_cbc_terms(const T* Mk, const T* Bk, const T* A, const T* grad,
     return check_launch("cbc_terms");
 }
 
+
+// --------------------------------------------------------------------------------------------
+// K8, rel-degree 2: CBC2 = grad(L_f h)'(f + g u) + ka0 h + ka1 L_f h as a GP in u, from the posterior jets
+// (closed form of cbc2_gp + cbc2_quadratic_terms, cbc2.py:7-33, gp_algebra.py:133-168, 319-402;
+// SURVEY.md A.4).  One lane per instance, fp64 internally.
+//   out[Bt, m + 1 + m*m + m + 1 + 2] = (mean_A[m], mean_b, Q[m,m], p[m], r, mean(u0), var(u0))
+//   status: 0 ok, 1 = kernel Hessian has an eigenvalue < -2e-3 (the reference asserts, gp_algebra.py:386).
+template <typename T>
+__global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict__ Bk, const T* __restrict__ G,
+                                  const T* __restrict__ Mj, const T* __restrict__ A, const T* __restrict__ Bm,
+                                  const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ hval,
+                                  const T* __restrict__ gh_, const T* __restrict__ Hh_, const T* __restrict__ kalpha,
+                                  const T* __restrict__ u0_, T* __restrict__ out, int* __restrict__ status,
+                                  int Bt, int n, int m) {
+    constexpr int NN = 4, MM = BCBF_MAX_CTRL_DIM, CC = MM + 1;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Bt) return;
+    const int C = m + 1, CT = C * (1 + n);
+    const T* Gb = G + (size_t)b * CT * CT;
+    const T* Mjb = Mj + (size_t)b * n * CT;
+    auto Gat = [&](int blk_a, int a, int blk_c, int c) { return (double)Gb[(blk_a * C + a) * CT + blk_c * C + c]; };
+    double Bkd[CC][CC], Ad[NN][NN], gh[NN], Hh[NN][NN], m0[NN], Mt[NN][MM], u0[MM], a0[CC];
+    for (int a = 0; a < CC; ++a) for (int c = 0; c < CC; ++c) Bkd[a][c] = (a < C && c < C) ? (double)Bk[((size_t)b * C + a) * C + c] : 0.0;
+    for (int i = 0; i < NN; ++i) {
+        gh[i] = i < n ? (double)gh_[(size_t)b * n + i] : 0.0;
+        m0[i] = i < n ? (double)Mk[((size_t)b * n + i) * C] : 0.0;
+        for (int j = 0; j < NN; ++j) {
+            Ad[i][j] = (i < n && j < n) ? (double)A[((size_t)b * n + i) * n + j] : 0.0;
+            Hh[i][j] = (i < n && j < n) ? (double)Hh_[((size_t)b * n + i) * n + j] : 0.0;
+        }
+        for (int j = 0; j < MM; ++j) Mt[i][j] = (i < n && j < m) ? (double)Mk[((size_t)b * n + i) * C + 1 + j] : 0.0;
+    }
+    a0[0] = 1.0;
+    for (int j = 0; j < MM; ++j) { u0[j] = j < m ? (double)u0_[(size_t)b * m + j] : 0.0; a0[1 + j] = u0[j]; }
+    const double ka0 = (double)kalpha[0], ka1 = (double)kalpha[1], h = (double)hval[b];
+    const double s2 = (double)s2p[b], B00 = (double)Bm[(size_t)b * C * C];
+    double Agh[NN], HAg[NN], g[NN];
+    double phi0 = 0.0;
+    for (int i = 0; i < NN; ++i) { double t = 0; for (int j = 0; j < NN; ++j) t += Ad[i][j] * gh[j]; Agh[i] = t; }
+    for (int i = 0; i < NN; ++i) phi0 += gh[i] * Agh[i];
+    for (int i = 0; i < NN; ++i) { double t = 0; for (int j = 0; j < NN; ++j) t += Hh[i][j] * Agh[j]; HAg[i] = t; }
+    // g = Hh' m0 + [gh' dMk_i e0]_i,   dMk_i e0 = Mj[:, (1+i) C]
+    for (int i = 0; i < NN; ++i) {
+        double t = 0;
+        for (int j = 0; j < NN; ++j) t += Hh[j][i] * m0[j];
+        if (i < n) for (int j = 0; j < n; ++j) t += gh[j] * (double)Mjb[j * CT + (1 + i) * C];
+        g[i] = i < n ? t : 0.0;
+    }
+    // total derivative of s(z,a;z,a') : -(a'(G10_i + G10_i')a'),  G10_i = dW_i'W = G[(1+i) blk, 0 blk]
+    auto dsdz = [&](const double* a, const double* ap, int i) {
+        double t = 0;
+        for (int p_ = 0; p_ < C; ++p_) for (int q = 0; q < C; ++q) t += a[p_] * (Gat(1 + i, p_, 0, q) + Gat(1 + i, q, 0, p_)) * ap[q];
+        return -t;
+    };
+    double e0[CC];
+    for (int a = 0; a < CC; ++a) e0[a] = a == 0 ? 1.0 : 0.0;
+    const double s00 = Bkd[0][0];
+    double s_i[NN], H[NN][NN];
+    for (int i = 0; i < NN; ++i) s_i[i] = i < n ? -Gat(1 + i, 0, 0, 0) : 0.0;
+    for (int i = 0; i < NN; ++i)
+        for (int j = 0; j < NN; ++j) {
+            double hah = 0;
+            for (int p_ = 0; p_ < NN; ++p_) for (int q = 0; q < NN; ++q) hah += Hh[i][p_] * Ad[p_][q] * Hh[q][j];
+            double sij = 0;
+            if (i < n && j < n) {
+                const double li = (double)ell[(size_t)b * n + i];
+                sij = (i == j ? s2 / (li * li) * B00 : 0.0) - Gat(1 + i, 0, 1 + j, 0);
+            }
+            H[i][j] = hah * s00 + HAg[i] * s_i[j] + s_i[i] * HAg[j] + phi0 * sij;
+        }
+    // smallest eigenvalue check by a few Jacobi sweeps on the symmetric part (n <= 4)
+    int st = 0;
+    {
+        double S[NN][NN], Vv[NN][NN];
+        for (int i = 0; i < NN; ++i) for (int j = 0; j < NN; ++j) { S[i][j] = 0.5 * (H[i][j] + H[j][i]); Vv[i][j] = i == j ? 1.0 : 0.0; }
+        for (int sweep = 0; sweep < 12; ++sweep)
+            for (int p_ = 0; p_ < n; ++p_)
+                for (int q = p_ + 1; q < n; ++q) {
+                    if (fabs(S[p_][q]) < 1e-300) continue;
+                    const double th = 0.5 * (S[q][q] - S[p_][p_]) / S[p_][q];
+                    const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                    for (int k = 0; k < n; ++k) { const double a_ = S[k][p_], b_ = S[k][q]; S[k][p_] = cs * a_ - sn * b_; S[k][q] = sn * a_ + cs * b_; }
+                    for (int k = 0; k < n; ++k) { const double a_ = S[p_][k], b_ = S[q][k]; S[p_][k] = cs * a_ - sn * b_; S[q][k] = sn * a_ + cs * b_; }
+                    for (int k = 0; k < n; ++k) { const double a_ = Vv[k][p_], b_ = Vv[k][q]; Vv[k][p_] = cs * a_ - sn * b_; Vv[k][q] = sn * a_ + cs * b_; }
+                }
+        bool neg = false;
+        for (int i = 0; i < n; ++i) { if (S[i][i] < -2e-3) st = 1; if (S[i][i] < 0.0) neg = true; }
+        if (neg && st == 0) {      // zero the small negative eigenvalues (gp_algebra.py:387-392)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double t = 0;
+                    for (int k = 0; k < n; ++k) t += Vv[i][k] * fmax(S[k][k], 0.0) * Vv[j][k];
+                    H[i][j] = t;
+                }
+        }
+    }
+    // C(a) = (d/dz [A gh(z) s(z,a;z,e0)])',  J[k][i] = (A Hh)[k][i] s(a,e0) + Agh[k] dsdz_i(a,e0)
+    double Cu0[NN][NN], C0[NN][NN];
+    for (int which = 0; which < 2; ++which) {
+        const double* a = which == 0 ? a0 : e0;
+        double sa0 = 0;
+        for (int p_ = 0; p_ < C; ++p_) sa0 += a[p_] * Bkd[p_][0];
+        for (int i = 0; i < NN; ++i) {
+            const double ds = i < n ? dsdz(a, e0, i) : 0.0;
+            for (int k = 0; k < NN; ++k) {
+                double ahh = 0;
+                for (int q = 0; q < NN; ++q) ahh += Ad[k][q] * Hh[q][i];
+                const double Jki = ahh * sa0 + Agh[k] * ds;
+                if (which == 0) Cu0[i][k] = Jki; else C0[i][k] = Jki;
+            }
+        }
+    }
+    double dq[NN];
+    for (int i = 0; i < NN; ++i) dq[i] = i < n ? dsdz(e0, e0, i) * phi0 + s00 * 2.0 * HAg[i] : 0.0;
+    double gAg = 0, gAgh = 0, trC = 0, ell1 = 0;
+    for (int i = 0; i < NN; ++i) { double t = 0; for (int j = 0; j < NN; ++j) t += Ad[i][j] * g[j]; gAg += g[i] * t; gAgh += g[i] * Agh[i]; trC += Cu0[i][i]; ell1 += gh[i] * m0[i]; }
+    // helper vectors
+    double Hsm0[NN], Ctg[NN], C0gh[NN];       // (H+H')m0, Cu0' g, C0 gh
+    for (int i = 0; i < NN; ++i) {
+        double t1 = 0, t2 = 0, t3 = 0;
+        for (int j = 0; j < NN; ++j) { t1 += (H[i][j] + H[j][i]) * m0[j]; t2 += Cu0[j][i] * g[j]; t3 += C0[i][j] * gh[j]; }
+        Hsm0[i] = t1; Ctg[i] = t2; C0gh[i] = t3;
+    }
+    T* o = out + (size_t)b * (m + 1 + m * m + m + 1 + 2);
+    double meanA[MM], Q[MM][MM], pp[MM];
+    double gm0 = 0, m0Hm0 = 0, m0Ctg = 0, m0dq = 0, m0C0gh = 0;
+    for (int i = 0; i < NN; ++i) { gm0 += g[i] * m0[i]; m0Ctg += m0[i] * Ctg[i]; m0dq += m0[i] * dq[i]; m0C0gh += m0[i] * C0gh[i];
+                                   for (int j = 0; j < NN; ++j) m0Hm0 += m0[i] * H[i][j] * m0[j]; }
+    for (int a = 0; a < MM; ++a) {
+        double ma = 0, p1 = 0, p3 = 0, p5 = 0, p6 = 0;
+        for (int i = 0; i < NN; ++i) { ma += Mt[i][a] * g[i]; p1 += Mt[i][a] * Hsm0[i]; p3 += Mt[i][a] * Ctg[i]; p5 += Mt[i][a] * dq[i]; p6 += Mt[i][a] * C0gh[i]; }
+        meanA[a] = ma;
+        pp[a] = p1 + 2.0 * gAg * Bkd[1 + a][0] + 2.0 * p3 + ka1 * (2.0 * gAgh * Bkd[1 + a][0] + p5 + p6);
+        for (int c = 0; c < MM; ++c) {
+            double q_ = 0;
+            for (int i = 0; i < NN; ++i) for (int j = 0; j < NN; ++j) q_ += Mt[i][a] * (H[i][j] + H[j][i]) * Mt[j][c];
+            Q[a][c] = 0.5 * q_ + gAg * Bkd[1 + a][1 + c];
+        }
+    }
+    const double mean_b = gm0 + trC + ka0 * h + ka1 * ell1;
+    const double rr = 2.0 * trC * trC + m0Hm0 + gAg * Bkd[0][0] + 2.0 * m0Ctg + ka1 * ka1 * phi0 * s00
+                      + ka1 * (2.0 * gAgh * Bkd[0][0] + m0dq + m0C0gh);
+    double mean = mean_b, var = rr;
+    for (int a = 0; a < m; ++a) { mean += meanA[a] * u0[a]; var += pp[a] * u0[a]; for (int c = 0; c < m; ++c) var += u0[a] * Q[a][c] * u0[c]; }
+    int k = 0;
+    for (int a = 0; a < m; ++a) o[k++] = (T)meanA[a];
+    o[k++] = (T)mean_b;
+    for (int a = 0; a < m; ++a) for (int c = 0; c < m; ++c) o[k++] = (T)Q[a][c];
+    for (int a = 0; a < m; ++a) o[k++] = (T)pp[a];
+    o[k++] = (T)rr;
+    o[k++] = (T)mean;
+    o[k++] = (T)var;
+    if (status) status[b] = st;
+}
+
+template <typename T>
+static int launch_cbc2_terms(const T* Mk, const T* Bk, const T* G, const T* Mj, const T* A, const T* Bm, const T* ell,
+                             const T* s2, const T* h, const T* gh, const T* Hh, const T* kalpha, const T* u0, T* out,
+                             int* status, int Bt, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Mk || !Bk || !G || !Mj || !A || !Bm || !ell || !s2 || !h || !gh || !Hh || !kalpha || !u0 || !out) return BCBF_EINVAL;
+    if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    hipLaunchKernelGGL((cbc2_terms_kernel<T>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, Mk, Bk, G, Mj, A,
+                       Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m);
+    return check_launch("cbc2_terms");
+}
+
 }  // namespace bcbf
 
 extern "C" {
@@ -108,5 +276,17 @@ int bcbf_cbc_terms_f64(const double* Mk, const double* Bk, const double* A, cons
                        const double* sign, const double* fhat, const double* ghat,
                        double* terms, double* cones, int* cstatus, int Bt, int K, int n, int m, void* stream) {
     return bcbf::launch_cbc_terms<double>(Mk, Bk, A, grad, cst, sign, fhat, ghat, terms, cones, cstatus, Bt, K, n, m, stream);
+}
+int bcbf_cbc2_terms_f32(const float* Mk, const float* Bk, const float* G, const float* Mj, const float* A,
+                        const float* Bm, const float* ell, const float* s2, const float* h, const float* gh,
+                        const float* Hh, const float* kalpha, const float* u0, float* out, int* status,
+                        int Bt, int n, int m, void* stream) {
+    return bcbf::launch_cbc2_terms<float>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, stream);
+}
+int bcbf_cbc2_terms_f64(const double* Mk, const double* Bk, const double* G, const double* Mj, const double* A,
+                        const double* Bm, const double* ell, const double* s2, const double* h, const double* gh,
+                        const double* Hh, const double* kalpha, const double* u0, double* out, int* status,
+                        int Bt, int n, int m, void* stream) {
+    return bcbf::launch_cbc2_terms<double>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, stream);
 }
 }

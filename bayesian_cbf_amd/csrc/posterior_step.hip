@@ -56,18 +56,24 @@ template <> struct BufLoad<double> {
     }
 };
 
-template <typename T, int C, int NS>
-__global__ void __launch_bounds__(256, BCBF_PS_WAVES)
+// NJ = 0: values only (the control-step kernel).  NJ = n > 0: also the first x-derivative jets --
+// right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] (CT = C (1+n) columns of the same stream); outputs the full
+// Gram Wj'Wj [CT,CT] and Vw'Wj [n,CT], from which the rel-degree-2 terms are formed.
+template <typename T, int C, int NS, int NJ>
+__global__ void __launch_bounds__(256, (NJ > 0 ? 1 : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
-                      T* __restrict__ Wout, int shared, int N, int Np, int n) {
+                      T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
+                      int n) {
     constexpr int V = Vec<T>::V;
+    constexpr int CT = C * (1 + NJ);     // right-hand-side columns
     using VecT = typename Vec<T>::type;
     constexpr int RPB = NB / V;          // row blocks per diagonal block
-    constexpr int CP = 4;                // padded RHS count in LDS
-    constexpr int NG = C * (C + 1) / 2;
+    constexpr int CP = (CT + 3) / 4 * 4; // padded RHS count in LDS
+    constexpr int NG = CT * (CT + 1) / 2;
+    auto gidx = [](int a, int c) { return a * CT - a * (a - 1) / 2 + (c - a); };   // (a <= c) in the upper triangle
     __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
     __shared__ __attribute__((aligned(16))) T wbuf[NB][CP];
 
@@ -93,7 +99,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         iell[d] = d < n ? T(1) / ell[(size_t)gb * n + d] : T(0);
     }
     const T s2 = s2p[gb];
-    T acc[2][V][C];
+    T acc[2][V][CT];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int rb = r == 0 ? rbA : rbB;
@@ -109,7 +115,15 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 k = s2 * texp<T>(T(-0.5) * d2);
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[r][v][c] = (live && i < N) ? k * UHBb[(size_t)i * C + c] : T(0);
+            for (int c = 0; c < C; ++c) {
+                const T ub = (live && i < N) ? UHBb[(size_t)i * C + c] : T(0);
+                acc[r][v][c] = k * ub;
+#pragma unroll
+                for (int d = 0; d < NJ; ++d) {     // d Phi / d x_d = -(x_d - X_id)/ell_d^2 * Phi
+                    const T dz = (live && i < N) ? (Xb[(size_t)i * n + d] - xqr[d]) * iell[d] * iell[d] : T(0);
+                    acc[r][v][(1 + d) * C + c] = dz * k * ub;
+                }
+            }
         }
     }
 
@@ -117,17 +131,17 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     T gram[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) gram[g] = T(0);
-    T mk[NS][C];
+    T mk[NS][CT];
 #pragma unroll
     for (int d = 0; d < NS; ++d)
 #pragma unroll
-        for (int c = 0; c < C; ++c) mk[d][c] = T(0);
+        for (int c = 0; c < CT; ++c) mk[d][c] = T(0);
 
     const int nblk = Np / NB;
     // Streaming pipeline state.  Column groups of UNR columns form ONE stream over all blocks: the
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
-    constexpr int UNR = BCBF_PS_UNR, NGRP = NB / UNR, HALF = NB / 2;
+    constexpr int UNR = NJ > 0 ? 2 : BCBF_PS_UNR, NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
@@ -146,15 +160,15 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            T wj[C];
+            T wj[CT];
 #pragma unroll
-            for (int c = 0; c < C; ++c) wj[c] = wbuf[jj0 + u][c];
+            for (int c = 0; c < CT; ++c) wj[c] = wbuf[jj0 + u][c];
             const T* pa = reinterpret_cast<const T*>(&la[u]);
             const T* pb = reinterpret_cast<const T*>(&lb[u]);
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
+                for (int c = 0; c < CT; ++c) {
                     acc[0][v][c] -= pa[v] * wj[c];
                     acc[1][v][c] -= pb[v] * wj[c];
                 }
@@ -180,34 +194,34 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                 for (int v = 0; v < V; ++v)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) rbuf[rb * V + v - row0][c] = acc[r][v][c];
+                    for (int c = 0; c < CT; ++c) rbuf[rb * V + v - row0][c] = acc[r][v][c];
             }
         }
         __syncthreads();
         // 2. diagonal block: w_J = inv(L_JJ) r_J  (wave 0; lane = (row di, column half dh))
         if (tid < 64) {
-            T w[C];
+            T w[CT];
 #pragma unroll
-            for (int c = 0; c < C; ++c) w[c] = T(0);
+            for (int c = 0; c < CT; ++c) w[c] = T(0);
 #pragma unroll
             for (int q = 0; q < HALF; ++q) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) w[c] += dval[q] * rbuf[dh * HALF + q][c];
+                for (int c = 0; c < CT; ++c) w[c] += dval[q] * rbuf[dh * HALF + q][c];
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) w[c] += __shfl_xor(w[c], 32, 64);
+            for (int c = 0; c < CT; ++c) w[c] += __shfl_xor(w[c], 32, 64);
             if (dh == 0) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) wbuf[di][c] = w[c];
+                for (int c = 0; c < CT; ++c) wbuf[di][c] = w[c];
                 if (Wout != nullptr) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) Wout[((size_t)b * Np + row0 + di) * C + c] = w[c];
                 }
                 int g = 0;
 #pragma unroll
-                for (int a = 0; a < C; ++a)
+                for (int a = 0; a < CT; ++a)
 #pragma unroll
-                    for (int c = a; c < C; ++c) gram[g++] += w[a] * w[c];
+                    for (int c = a; c < CT; ++c) gram[g++] += w[a] * w[c];
                 const int row = row0 + di;
                 if (row < N) {
 #pragma unroll
@@ -215,7 +229,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         if (d < n) {
                             const T vw = Vwb[(size_t)row * n + d];
 #pragma unroll
-                            for (int c = 0; c < C; ++c) mk[d][c] += vw * w[c];
+                            for (int c = 0; c < CT; ++c) mk[d][c] += vw * w[c];
                         }
                 }
             }
@@ -244,9 +258,23 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         for (int d = 0; d < NS; ++d)
             if (d < n) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) mk[d][c] = wave_sum(mk[d][c]);
+                for (int c = 0; c < CT; ++c) mk[d][c] = wave_sum(mk[d][c]);
             }
         if (tid == 0) {
+            if (NJ > 0 && Gfull != nullptr && Mfull != nullptr) {
+                T* Gb = Gfull + (size_t)b * CT * CT;
+                T* Mb = Mfull + (size_t)b * n * CT;
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+#pragma unroll
+                    for (int c = a; c < CT; ++c) { Gb[a * CT + c] = (T)gsum[gidx(a, c)]; Gb[c * CT + a] = (T)gsum[gidx(a, c)]; }
+#pragma unroll
+                for (int d = 0; d < NS; ++d)
+                    if (d < n) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) Mb[d * CT + c] = mk[d][c];
+                    }
+            }
             const T* M0b = M0 + (size_t)gb * C * n;
             T* Mkb = Mk + (size_t)b * n * C;
 #pragma unroll
@@ -257,12 +285,11 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 }
             const T* Bmb = Bm + (size_t)gb * C * C;
             T* Bkb = Bk + (size_t)b * C * C;
-            int g = 0;
 #pragma unroll
             for (int a = 0; a < C; ++a)
 #pragma unroll
                 for (int c = a; c < C; ++c) {
-                    const double G = gsum[g++];
+                    const double G = gsum[gidx(a, c)];
                     double v1 = (double)s2 * (double)Bmb[a * C + c] - G;
                     double v2 = (double)s2 * (double)Bmb[c * C + a] - G;
                     if (a == c && jitter2 != nullptr) { v1 += (double)jitter2[(size_t)b * C + a]; v2 = v1; }
@@ -276,7 +303,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 template <typename T>
 static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                  const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
-                                 T* Wout, int shared, int Bt, int N, int n, int m, void* stream) {
+                                 T* Wout, int shared, int Bt, int N, int n, int m, void* stream,
+                                 T* Gfull = nullptr, T* Mfull = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
@@ -287,8 +315,16 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (threads > 256) return BCBF_EINVAL;   // N <= 2048 (f32) / 1024 (f64)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, shared, N, Np, n)
-    if (n <= 4) {
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, Gfull, Mfull, shared, N, Np, n)
+    if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
+        if (!Mfull) return BCBF_EINVAL;
+        if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
+        else if (n == 3 && m == 2) BCBF_PJ_LAUNCH(3, 3);
+        else if (n == 2 && m == 2) BCBF_PJ_LAUNCH(3, 2);
+        else if (n == 1 && m == 1) BCBF_PJ_LAUNCH(2, 1);
+        else return BCBF_EINVAL;
+    } else if (n <= 4) {
         switch (m) {
             case 1: BCBF_PS_LAUNCH(2, 4); break;
             case 2: BCBF_PS_LAUNCH(3, 4); break;
@@ -304,6 +340,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
         }
     }
 #undef BCBF_PS_LAUNCH
+#undef BCBF_PJ_LAUNCH
     return check_launch("posterior_step");
 }
 
@@ -337,4 +374,24 @@ extern "C" int bcbf_posterior_query_f64(const double* Lop, const double* Vw, con
                                         const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                         int shared, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream);
+}
+
+// Jets: value + first x-derivatives of the posterior factors at one query per instance (or per query of
+// a shared GP).  CT = (1+m)(1+n) columns [Phi, dPhi/dx_1..dPhi/dx_n]:  G[Bt,CT,CT] = Wj'Wj,
+// Mj[Bt,n,CT] = Vw'Wj (so Mk = M0' + Mj[:, :C], dMk/dx_d = Mj[:, (1+d)C:(2+d)C]).  Feeds bcbf_cbc2_terms.
+// Replaces autograd through custom_predict in GradientGP (gp_algebra.py:340-402).  Compiled for
+// (n,m) in {(1,1),(2,1),(2,2),(3,2)}.
+extern "C" int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                       const float* ell, const float* s2, const float* Bm, const float* M0,
+                                       const float* xq, float* Mk, float* Bk, float* G, float* Mj, int shared,
+                                       int Bt, int N, int n, int m, void* stream) {
+    if (!G || !Mj) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, nullptr, shared, Bt, N, n, m, stream, G, Mj);
+}
+extern "C" int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                       const double* ell, const double* s2, const double* Bm, const double* M0,
+                                       const double* xq, double* Mk, double* Bk, double* G, double* Mj, int shared,
+                                       int Bt, int N, int n, int m, void* stream) {
+    if (!G || !Mj) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, nullptr, shared, Bt, N, n, m, stream, G, Mj);
 }

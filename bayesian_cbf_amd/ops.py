@@ -138,6 +138,44 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
     return Mk, Bk, W
 
 
+def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False):
+    """(Mk, Bk, G[b,CT,CT], Mj[b,n,CT]) with CT = (1+m)(1+n): value + first x-derivative jets
+    (replaces autograd through custom_predict in GradientGP, gp_algebra.py:340-402)."""
+    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq)
+    N, n = X.shape[1], X.shape[2]
+    C = UHB.shape[2]
+    b = xq.shape[0]
+    CT = C * (1 + n)
+    f = dict(dtype=X.dtype, device=X.device)
+    Mk, Bk = torch.empty(b, n, C, **f), torch.empty(b, C, C, **f)
+    G, Mj = torch.empty(b, CT, CT, **f), torch.empty(b, n, CT, **f)
+    check(getattr(lib, "bcbf_posterior_jets" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm),
+                                                        _p(M0), _p(xq), _p(Mk), _p(Bk), _p(G), _p(Mj),
+                                                        1 if shared else 0, b, N, n, C - 1, _stream(X)),
+          "bcbf_posterior_jets")
+    return Mk, Bk, G, Mj
+
+
+def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0):
+    """Rel-degree-2 terms (cbc2_gp + cbc2_quadratic_terms, cbc2.py:7-33).  Returns
+    ((mean_A[b,m], mean_b[b]), (Q[b,m,m], p[b,m], r[b]), mean[b], var[b], status[b])."""
+    _chk(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0)
+    b, n, C = Mk.shape
+    m = C - 1
+    out = torch.empty(b, m + 1 + m * m + m + 1 + 2, dtype=Mk.dtype, device=Mk.device)
+    status = torch.empty(b, dtype=torch.int32, device=Mk.device)
+    check(getattr(lib, "bcbf_cbc2_terms" + _suf(Mk))(_p(Mk), _p(Bk), _p(G), _p(Mj), _p(A), _p(Bm), _p(ell), _p(s2),
+                                                     _p(h), _p(gh), _p(Hh), _p(kalpha), _p(u0), _p(out), _p(status),
+                                                     b, n, m, _stream(Mk)), "bcbf_cbc2_terms")
+    o = 0
+    mean_A = out[:, o:o + m]; o += m
+    mean_b = out[:, o]; o += 1
+    Q = out[:, o:o + m * m].reshape(b, m, m); o += m * m
+    p = out[:, o:o + m]; o += m
+    r = out[:, o]; o += 1
+    return (mean_A, mean_b), (Q, p, r), out[:, o], out[:, o + 1], status
+
+
 def terms_width(m):
     return m + 1 + m * m + m + 1
 

@@ -134,6 +134,35 @@ int bcbf_posterior_query_f64(const double* Lop, const double* Vw, const double* 
                              const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                              int shared, int Bt, int N, int n, int m, void* stream);
 
+/* Posterior jets: value and first x-derivatives of the posterior factors (one query per instance, or per
+ * query of a shared GP).  CT = (1+m)(1+n) right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] of the same stream:
+ *   G[Bt,CT,CT] = Wj'Wj,  Mj[Bt,n,CT] = Vw'Wj   (Mk = M0' + Mj[:, :C]; dMk/dx_d = Mj[:, (1+d)C:(2+d)C]),
+ * plus Mk, Bk as bcbf_posterior_step.  Replaces autograd through custom_predict inside GradientGP
+ * (gp_algebra.py:340-402).  Compiled for (n,m) in {(1,1),(2,1),(2,2),(3,2)}. */
+int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                            const float* ell, const float* s2, const float* Bm, const float* M0,
+                            const float* xq, float* Mk, float* Bk, float* G, float* Mj, int shared,
+                            int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                            const double* ell, const double* s2, const double* Bm, const double* M0,
+                            const double* xq, double* Mk, double* Bk, double* G, double* Mj, int shared,
+                            int Bt, int N, int n, int m, void* stream);
+
+/* K8, rel-degree 2: CBC2 = grad(L_f h)'(f + g u) + kalpha[0] h + kalpha[1] L_f h as a GP in u, closed form of
+ * cbc2_gp + cbc2_quadratic_terms (cbc2.py:7-33; gp_algebra.py:133-168, 319-402) from the jets.
+ * h[Bt], gh[Bt,n], Hh[Bt,n,n] = barrier value, gradient, Hessian at x; u0[Bt,m] linearisation point (the
+ * cross term cov(grad L_f h, f+gu) is frozen there, as the reference's autograd does); kalpha[2].
+ * out[Bt, m+1+m*m+m+1+2] = (mean_A[m], mean_b, Q[m,m], p[m], r, mean(u0), var(u0));
+ * status[Bt] (optional): 1 if the kernel Hessian has an eigenvalue < -2e-3 (the reference asserts). */
+int bcbf_cbc2_terms_f32(const float* Mk, const float* Bk, const float* G, const float* Mj, const float* A,
+                        const float* Bm, const float* ell, const float* s2, const float* h, const float* gh,
+                        const float* Hh, const float* kalpha, const float* u0, float* out, int* status,
+                        int Bt, int n, int m, void* stream);
+int bcbf_cbc2_terms_f64(const double* Mk, const double* Bk, const double* G, const double* Mj, const double* A,
+                        const double* Bm, const double* ell, const double* s2, const double* h, const double* gh,
+                        const double* Hh, const double* kalpha, const double* u0, double* out, int* status,
+                        int Bt, int n, int m, void* stream);
+
 /* K8 (rel-degree 1) + K9: constraint terms and their cone form, K constraints per instance.
  *   mean(u) = bfe'u + e,  var(u) = u'V u + bfv'u + v   for  sign*(grad' (fhat + ghat u + F(x)[1;u]) + cst)
  * Replaces cbc2_quadratic_terms on a rel-degree-1 expression (cbc2.py:7-23, gp_algebra.py:109-223,

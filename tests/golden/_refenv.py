@@ -43,9 +43,8 @@ def setup():
         tb.SummaryWriter = SummaryWriter
         sys.modules["torch.utils.tensorboard"] = tb
         torch.utils.tensorboard = tb
-    if not hasattr(torch, "eig"):
-        def eig(A, eigenvectors=False):
-            w, V = torch.linalg.eig(A)
-            return torch.stack([w.real, w.imag], dim=-1), V.real
-        torch.eig = eig
+    def eig(A, eigenvectors=False):          # torch.eig was removed in torch 1.13 (the stub left behind raises)
+        w, V = torch.linalg.eig(A)
+        return torch.stack([w.real, w.imag], dim=-1), V.real
+    torch.eig = eig
     return torch

@@ -241,5 +241,73 @@ def main():
     gen_unicycle_terms('learned_N40', N=40, seed=22, enable_learning=True)
 
 
+
+
+# ----------------------------------------------------------------------------------------------
+# rel-degree-2: cbc2_gp + cbc2_quadratic_terms  (bayes_cbf/cbc2.py:7-33, gp_algebra.py:319-402)
+def _h_funcs(kind, n):
+    """Test barrier functions with analytic gradient / Hessian (the generator records the Hessian the
+    oracle needs; the reference differentiates grad_h with autograd)."""
+    if kind == "radial":          # RadialCBFRelDegree2 of bayes_cbf/pendulum.py:675-696
+        import math
+        dc, tc = math.pi / 8, math.pi / 4
+        h = lambda x: math.cos(dc) - torch.cos(x[0] - tc)
+
+        def gh(x):
+            return torch.cat([torch.sin(x[0:1] - tc), x.new_zeros(n - 1)])
+
+        def hess(x):
+            H = x.new_zeros(n, n)
+            H[0, 0] = torch.cos(x[0] - tc)
+            return H
+        return h, gh, hess
+    Qm = torch.tensor([[1.0, 0.3, -0.2], [0.3, 0.7, 0.1], [-0.2, 0.1, 1.3]], dtype=torch.float64)[:n, :n]
+    wv = torch.tensor([0.5, -0.8, 0.3], dtype=torch.float64)[:n]
+    h = lambda x: 0.5 * x @ Qm @ x + torch.sin(wv @ x) - 0.2
+    gh = lambda x: Qm @ x + torch.cos(wv @ x) * wv
+    hess = lambda x: Qm - torch.sin(wv @ x) * torch.outer(wv, wv)
+    return h, gh, hess
+
+
+def gen_cbc2(tag, n, m, N, seed, kind):
+    from bayes_cbf.cbc2 import cbc2_gp
+    reg, X, U, Xdot = make_regressor(cam.ControlAffineRegressor, n, m, N, seed)
+    out = dict(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), kind=kind, **hyper(reg, n, m))
+    h, gh, hess = _h_funcs(kind, n)
+    k_alpha = [1.0, 3.0]
+    out["k_alpha"] = np.array(k_alpha)
+    torch.manual_seed(seed + 3)
+    S = 4
+    xs = 0.8 * (2 * torch.rand(S, n) - 1)
+    u0s = torch.rand(S, m)
+    recs = {k: [] for k in ("mean_A", "mean_b", "Q", "p", "r", "mean", "var", "h", "gh", "hess")}
+    with RandRecorder() as rr:
+        for i in range(S):
+            x, u0 = xs[i].clone(), u0s[i].clone()
+            (mA, mb), (Q, p_, r_), mean, var = cbc2_quadratic_terms(
+                lambda u: cbc2_gp(h, gh, reg, u, k_alpha), x, u0)
+            for k, v in zip(("mean_A", "mean_b", "Q", "p", "r", "mean", "var"), (mA, mb, Q, p_, r_, mean, var)):
+                recs[k].append(t2n(v))
+            recs["h"].append(t2n(h(x)))
+            recs["gh"].append(t2n(gh(x)))
+            recs["hess"].append(t2n(hess(x)))
+    assert len(rr.draws) == 1            # only the K_b jitter (vector-variate regressor)
+    out.update(jitter_rand=np.stack(rr.draws), L=t2n(reg._cache["perturbed_cholesky"]), xs=t2n(xs), u0s=t2n(u0s))
+    for k, v in recs.items():
+        out["t_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "cbc2_%s.npz" % tag), **out)
+    print("cbc2_%s: n=%d m=%d N=%d kind=%s" % (tag, n, m, N, kind))
+
+
+def main_cbc2():
+    gen_cbc2("pendulum_N16", n=2, m=1, N=16, seed=41, kind="radial")
+    gen_cbc2("pendulum_N40", n=2, m=1, N=40, seed=42, kind="radial")
+    gen_cbc2("n3m2_N24", n=3, m=2, N=24, seed=43, kind="generic")
+
+
 if __name__ == '__main__':
-    main()
+    if 'cbc2' in sys.argv:
+        main_cbc2()
+    else:
+        main()
+        main_cbc2()

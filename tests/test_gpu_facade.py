@@ -148,3 +148,21 @@ def test_batched_rollout_with_learned_gp_runs_and_stays_finite():
     assert X.shape == (6, Bt, 3) and U.shape == (5, Bt, 2)
     assert torch.isfinite(X).all() and torch.isfinite(U).all()
     assert int((ctrl.last_status == 0).sum()) >= Bt // 2
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "cbc2_*.npz"))), ids=os.path.basename)
+def test_cbc2_quadratic_terms_reldeg2_facade(path):
+    """cbc2_quadratic_terms(cbc2_gp(...)) of the reference (rel-degree 2) through the façade."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    from bayesian_cbf_amd.cbc2 import cbc2_quadratic_terms
+    g = np.load(path)
+    reg = make(ControlAffineRegressor, g, [g["jitter_rand"][0]])
+    hs = {tuple(np.round(x, 12)): (h, gh, H) for x, h, gh, H in zip(g["xs"], g["t_h"], g["t_gh"], g["t_hess"])}
+    look = lambda x: hs[tuple(np.round(x.detach().cpu().numpy(), 12))]
+    for i in range(len(g["xs"])):
+        (mA, mb), (Q, p, r), mean, var = cbc2_quadratic_terms(
+            reg, lambda x: look(x)[0], lambda x: look(x)[1], lambda x: look(x)[2], t(g["xs"][i]), t(g["u0s"][i]),
+            g["k_alpha"])
+        for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
+            ref = g["t_" + name][i]
+            np.testing.assert_allclose(val.detach().cpu().numpy().reshape(np.shape(ref)), ref, rtol=1e-6, atol=1e-8)

@@ -410,3 +410,51 @@ def test_full_size_properties_config3(ops):
                                         h["xq"][i][None])
         rel_close(host(Mk)[i], Mk_o[0], 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk[%d]" % i)
         rel_close(host(Bk)[i], Bk_o[0], 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk[%d]" % i)
+
+
+# --------------------------------------------------------------------------------------------
+CBC2_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cbc2_*.npz")))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("path", CBC2_FILES, ids=os.path.basename)
+def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
+    """Posterior jets + rel-degree-2 terms (cbc2_gp / GradientGP path) against vectors recorded from the
+    reference's autograd-based cbc2_quadratic_terms."""
+    from oracle import cbc2 as oc2
+    g = np.load(path)
+    X, U, Xdot = g["X"], g["U"], g["Xdot"]
+    N, n = X.shape
+    m = U.shape[1]
+    S = len(g["xs"])
+    UH = ogp.homogeneous_controls(U)
+    rep = lambda a: dev(np.broadcast_to(a, (S,) + np.shape(a)), dtype)
+    jit = 1e-5 * g["jitter_rand"][0]
+    Lop, UHB, info, _ = ops.refit(rep(X), rep(UH), rep(g["B"]), rep(g["ell"]), rep(np.array(float(g["s2"]))), rep(jit))
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, rep(Xdot), rep(UH), rep(g["M0"]), want_alpha=False)
+    xs = dev(g["xs"], dtype)
+    Mk, Bk, G, Mj = ops.posterior_jets(Lop, Vw, rep(X), UHB, rep(g["ell"]), rep(np.array(float(g["s2"]))), rep(g["B"]),
+                                       rep(g["M0"]), xs)
+    st = ogp.refit_state(X, U, Xdot, g["B"], g["ell"], float(g["s2"]), g["M0"], g["jitter_rand"])
+    C = m + 1
+    tol = 1e-8 if dtype == torch.float64 else 2e-3
+    for i in range(S):
+        jets = oc2.posterior_jets(st["L"], st["Y"], X, st["UHB"], g["ell"], float(g["s2"]), g["B"], g["M0"], g["xs"][i])
+        rel_close(host(Mk)[i], jets["Mk"], tol, scale=max(1.0, np.abs(jets["Mk"]).max()), what="Mk")
+        Gh, Mjh = host(G)[i], host(Mj)[i]
+        gscale = max(np.abs(jets["G11"]).max(), np.abs(jets["G10"]).max(), 1e-3)
+        for d in range(n):
+            rel_close(Gh[(1 + d) * C:(2 + d) * C, :C], jets["G10"][d], tol, scale=gscale, what="G10")
+            rel_close(Mjh[:, (1 + d) * C:(2 + d) * C], jets["dMk"][d], tol, scale=max(1.0, np.abs(jets["dMk"]).max()), what="dMk")
+            for e in range(n):
+                rel_close(Gh[(1 + d) * C:(2 + d) * C, (1 + e) * C:(2 + e) * C], jets["G11"][d][e], tol, scale=gscale, what="G11")
+    out = ops.cbc2_terms(Mk, Bk, G, Mj, rep(g["A"]), rep(g["B"]), rep(g["ell"]), rep(np.array(float(g["s2"]))),
+                         dev(g["t_h"].reshape(S), dtype), dev(g["t_gh"], dtype), dev(g["t_hess"], dtype),
+                         dev(g["k_alpha"], dtype), dev(g["u0s"], dtype))
+    (mA, mb), (Q, p, r), mean, var, status = out
+    assert (status == 0).all()
+    ttol = 1e-7 if dtype == torch.float64 else 5e-3
+    for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
+        ref = g["t_" + name].reshape(host(val).shape)
+        rel_close(host(val), ref, ttol, scale=max(np.abs(ref).max(), 1e-2), what=name)

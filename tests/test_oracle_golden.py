@@ -155,3 +155,25 @@ def test_unicycle_constraint_terms_match_reference(tag):
             Ac, bc, cc, dc = cbc.convert_cbc_terms_to_socp_terms(bfe, e, V, bfv, v, 0)
             for name, val in zip(("A", "b", "c", "d"), (Ac, bc, cc, dc)):
                 close(val, g[p + "cbc_socp_" + name][k], rtol=1e-8, atol=1e-10)
+
+
+CBC2_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cbc2_*.npz")))
+
+
+@pytest.mark.parametrize("path", CBC2_FILES, ids=os.path.basename)
+def test_reldeg2_terms_match_reference(path):
+    """cbc2_gp + cbc2_quadratic_terms (rel-degree 2, GradientGP by autograd in the reference) against
+    the closed form from posterior jets, 4 states per file."""
+    from oracle import cbc2 as oc2
+    g = np.load(path)
+    X, U, Xdot = g["X"], g["U"], g["Xdot"]
+    A, B, ell, s2, M0 = g["A"], g["B"], g["ell"], float(g["s2"]), g["M0"]
+    st = gp.refit_state(X, U, Xdot, B, ell, s2, M0, g["jitter_rand"])
+    close(st["L"], g["L"])
+    for i in range(len(g["xs"])):
+        jets = oc2.posterior_jets(st["L"], st["Y"], X, st["UHB"], ell, s2, B, M0, g["xs"][i])
+        (mA, mb), (Q, p, r), mean, var = oc2.cbc2_terms(jets, A, B, ell, s2, float(g["t_h"][i]), g["t_gh"][i],
+                                                       g["t_hess"][i], g["k_alpha"], g["u0s"][i])
+        for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
+            ref = g["t_" + name][i]
+            np.testing.assert_allclose(np.asarray(val).reshape(np.shape(ref)), ref, rtol=1e-9, atol=1e-11)
