@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: Monte-Carlo safety rollouts of the unicycle Bayes-CBF controller, trajectories sharded
+over the GPUs of one node, one RCCL reduction at the end.
+
+    python examples_mc_rollouts.py --trajectories 4096 --steps 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        examples_mc_rollouts.py --trajectories 32768 --steps 200
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trajectories", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--max-risk", type=float, default=0.01)
+    ap.add_argument("--learned", type=int, default=0, help="N_train of a per-trajectory learned GP (0 = fixed kernel)")
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from bayesian_cbf_amd.distributed import shard_range
+    from bayesian_cbf_amd.rollouts import monte_carlo_safety_rollouts
+    a, b = shard_range(args.trajectories, rank, world)
+    gp = None
+    if args.learned:
+        from bayesian_cbf_amd.control_affine_model import BatchedControlAffineGP
+        from bayesian_cbf_amd.synthetic import make_instances
+        p = make_instances(b - a, args.learned, 3, 2, dtype=torch.float64, device="cuda", seed=100 + rank)
+        gp = BatchedControlAffineGP(p["X"], p["U"], 0.05 * p["Xdot"], 1e-2 * p["A"], 1e-2 * p["Bm"], p["ell"], p["s2"],
+                                    p["M0"]).as_dict()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = monte_carlo_safety_rollouts(b - a, numSteps=args.steps, gp=gp, max_risk=args.max_risk, seed=rank)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps(dict(trajectories=args.trajectories, steps=args.steps, n_gpus=world, seconds=el,
+                              trajectory_steps_per_s=args.trajectories * args.steps / el, **out["stats"])))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,3 +166,22 @@ def test_cbc2_quadratic_terms_reldeg2_facade(path):
         for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
             ref = g["t_" + name][i]
             np.testing.assert_allclose(val.detach().cpu().numpy().reshape(np.shape(ref)), ref, rtol=1e-6, atol=1e-8)
+
+
+def test_monte_carlo_rollouts_reproduce_saved_run_from_the_logged_start():
+    """Config-4 driver: with zero start noise every trajectory is the reference's committed run
+    (max_risk 0.01, true L = 12): the batched closed loop reproduces the logged 200-step state sequence."""
+    from bayesian_cbf_amd.rollouts import monte_carlo_safety_rollouts
+    g = np.load(os.path.join(GOLDEN, "saved_run_bayes_cbf_maxrisk0p01.npz"))
+    out = monte_carlo_safety_rollouts(8, numSteps=int(g["numSteps"]), dt=float(g["dt"]), start_noise=0.0,
+                                      kernel_diag_A=tuple(g["kernel_diag_A"]), L_mean=float(g["mean_L"]),
+                                      L_true=float(g["true_L"]), max_risk=float(g["max_risk"]), record=True)
+    traj = out["traj"].cpu().numpy()
+    assert np.abs(traj[:, 0] - traj[:, 7]).max() == 0.0          # identical instances stay identical
+    T = int(g["numSteps"])
+    err = np.abs(traj[:T, 0] - g["state"]).max(axis=1)
+    assert err[:50].max() < 5e-3 and err.max() < 5e-2, (err[:50].max(), err.max())
+    assert out["stats"]["count"] == 8 and out["stats"]["solver_failures"] == 0
+    # the Bayes-CBF run stays out of the obstacles; with noise the statistics are finite and sane
+    out2 = monte_carlo_safety_rollouts(256, numSteps=60, dt=float(g["dt"]), start_noise=0.05, seed=3)
+    assert np.isfinite(out2["stats"]["min_h"]) and out2["stats"]["count"] == 256
