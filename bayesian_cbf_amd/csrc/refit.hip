@@ -319,10 +319,15 @@ int bcbf_kb_build_f64(const double* X, const double* UH, const double* Bm, const
                       const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream);
 }
+// fp32 goes to the matrix-core kernel (refit_mfma.hip); the VALU kernel above serves fp64.
+extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                                   const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense,
+                                   int* info, int Bt, int N, int n, int m, void* stream);
 int bcbf_refit_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                    const float* jitter, float* Lop, float* UHB, float* Ldense, int* info,
                    int Bt, int N, int n, int m, void* stream) {
-    return bcbf::launch_refit<float>(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
+    if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+    return bcbf_refit_mfma_f32(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
 }
 int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                    const double* jitter, double* Lop, double* UHB, double* Ldense, int* info,
@@ -331,7 +336,7 @@ int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const do
 }
 int bcbf_potrf_f32(const float* Kb, float* Lop, float* Ldense, int* info, int Bt, int N, void* stream) {
     if (!Kb) return BCBF_EINVAL;
-    return bcbf::launch_refit<float>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Kb, Lop, nullptr, Ldense, info, Bt, N, 0, 0, stream);
+    return bcbf_refit_mfma_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Kb, Lop, nullptr, Ldense, info, Bt, N, 0, 0, stream);
 }
 int bcbf_potrf_f64(const double* Kb, double* Lop, double* Ldense, int* info, int Bt, int N, void* stream) {
     if (!Kb) return BCBF_EINVAL;

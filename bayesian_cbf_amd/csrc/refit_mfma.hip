@@ -1,0 +1,272 @@
+// K1 + K2 on the matrix cores (fp32): blocked left-looking Cholesky, one 256-thread workgroup per
+// instance, every rank-32 update and every panel solve as v_mfma_f32_32x32x2_f32 tiles whose operands
+// come straight from the packed operator (column-major => a lane reads 32 consecutive rows of one
+// column, fully coalesced) -- no LDS staging, no transposes:
+//
+//   block column J, row tile I (32 rows), transposed tile  S'[c][i] = K_b(i, 32J+c) - sum_kk L_J[c][kk] L_I[i][kk]
+//     MFMA step kk..kk+1:  A[c][k] = L[32J+c][kk+k],  B[k][i] = L[32I+i][kk+k]   (one dword per lane each)
+//   the accumulator of S' has the row index i on the lane and c in the registers, so
+//     L_I,J' = inv(L_JJ) S'   is again an MFMA chain with the accumulator registers as B operands
+//     (register r holds rows rho(r), rho(r)+4  ->  A_r[c][k] = inv(L_JJ)[c][rho(r) + 4k]),
+//   and its result is stored column-major with 128-byte contiguous segments.
+// The 32x32 diagonal tile goes through LDS once to wave 0, which factors and inverts it in registers.
+// fp32 MFMA runs at the fp32 vector rate on gfx950: the gain is operand traffic / instruction count
+// (2 loads + 1 MFMA per 2048 MACs instead of LDS broadcasts), not peak.
+#include "bcbf_common.h"
+
+namespace bcbf {
+
+using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+
+constexpr int MT = 256;          // threads
+constexpr int MAXT = 2;          // row tiles a wave processes together (shares the A operand)
+
+__device__ inline int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// broadcast of one lane's value through an SGPR (v_readlane_b32, compile-time lane): no VGPR, no LDS crossbar
+__device__ inline float rlane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+template <bool FROM_DENSE>
+__global__ void __launch_bounds__(MT, 2)
+refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, const float* __restrict__ Bm,
+                  const float* __restrict__ ell, const float* __restrict__ s2p, const float* __restrict__ jitter,
+                  const float* __restrict__ Kdense, float* __restrict__ Lop, float* __restrict__ UHBout,
+                  float* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C) {
+    constexpr int V = 4;
+    __shared__ float dS[NB][NB + 1];                         // diagonal tile S_JJ (row c, col i)
+    __shared__ float dinv[NB][NB + 1];                       // inv(L_JJ)[c][c']
+    __shared__ float colX[NB][BCBF_MAX_STATE_DIM];
+    __shared__ float colUH[NB][BCBF_MAX_CTRL_DIM + 1];
+    __shared__ int fail;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const float* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
+    const float* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
+    const float* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
+    float* Ld = Ldense ? Ldense + (size_t)b * N * N : nullptr;
+    float iell[BCBF_MAX_STATE_DIM], Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+    float s2 = 0.f;
+    if (!FROM_DENSE) {
+        s2 = s2p[b];
+#pragma unroll
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) iell[d] = d < n ? 1.f / ell[(size_t)b * n + d] : 0.f;
+#pragma unroll
+        for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a)
+            Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : 0.f;
+        for (int i = tid; i < N; i += MT)
+            for (int c = 0; c < C; ++c) {
+                float s = 0.f;
+                for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                UHBout[((size_t)b * N + i) * C + c] = s;
+            }
+    }
+    if (tid == 0) fail = 0;
+    if (Ld)
+        for (int e = tid; e < N * N; e += MT) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.f; }
+    __syncthreads();
+
+    const int nblk = Np / NB;
+    for (int J = 0; J < nblk; ++J) {
+        const int col0 = J * NB;
+        if (!FROM_DENSE) {
+            for (int e = tid; e < NB * n; e += MT) {
+                const int c = e / n, d = e - c * n;
+                colX[c][d] = (col0 + c < N) ? Xb[(size_t)(col0 + c) * n + d] : 0.f;
+            }
+            for (int e = tid; e < NB * C; e += MT) {
+                const int c = e / C, a = e - c * C;
+                colUH[c][a] = (col0 + c < N) ? UHb[(size_t)(col0 + c) * C + a] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int ntile = nblk - J;                          // row tiles I = J .. nblk-1
+        // Tile schedule.  Group 0: wave 0 takes ONLY the diagonal tile, then factors and inverts it while
+        // waves 1-3 run the updates of tiles 1 .. 3*MAXT -- the serial factorization hides behind their MFMA
+        // streams.  Later groups: the remaining tiles round-robin over all four waves, MAXT per wave.
+        const int first = 1 + 3 * MAXT;
+        const int ngroups = ntile <= first ? 1 : 1 + (ntile - first + 4 * MAXT - 1) / (4 * MAXT);
+        for (int g = 0; g < ngroups; ++g) {                      // uniform trip count: barrier (B) is inside
+            f32x16 acc[MAXT];
+            int irow[MAXT], tix[MAXT];
+            bool live[MAXT];
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                int t;
+                if (g == 0) t = wave == 0 ? (q == 0 ? 0 : ntile) : 1 + (wave - 1) + 3 * q;
+                else t = first + (g - 1) * 4 * MAXT + wave + 4 * q;
+                tix[q] = t;
+                const int I = J + t;
+                live[q] = t < ntile;
+                irow[q] = live[q] ? I * NB + li : col0 + li;         // dead slots shadow the diagonal tile (no stores)
+                // ---- initial value: K_b'(c, i) for this lane's row i and the 16 c's of its accumulator rows
+                const int i = irow[q];
+                float xi[BCBF_MAX_STATE_DIM], ub[BCBF_MAX_CTRL_DIM + 1], jit = 0.f;
+                if (!FROM_DENSE && i < N) {
+#pragma unroll
+                    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) xi[d] = d < n ? Xb[(size_t)i * n + d] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) {
+                        float s = 0.f;
+                        if (c < C) for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                        ub[c] = s;
+                    }
+                    jit = jitter ? jitter[(size_t)b * N + i] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = acc_row(r, lh), j = col0 + c;
+                    float val;
+                    if (i >= N || j >= N) val = (i == j) ? 1.f : 0.f;          // padding: identity
+                    else if (FROM_DENSE) val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
+                    else {
+                        float d2 = 0.f, uu = 0.f;
+#pragma unroll
+                        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                            if (d < n) { const float z = (xi[d] - colX[c][d]) * iell[d]; d2 += z * z; }
+#pragma unroll
+                        for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a)
+                            if (a < C) uu += ub[a] * colUH[c][a];
+                        val = s2 * expf(-0.5f * d2) * uu + (i == j ? jit : 0.f);
+                    }
+                    acc[q][r] = val;
+                }
+            }
+            // ---- S' -= L_J L_I'  over all previous columns: stages of KS MFMA k-steps (2 columns each),
+            //      the next stage's operands are in flight while the current stage's MFMAs issue
+            constexpr int KS = 4;
+            const int kend = col0;                                            // multiple of 32
+            float a_nxt[KS], b_nxt[KS][MAXT];
+            auto fetch = [&](int kk) {
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const int base = lop_base<V>(kk + 2 * s_ + lh, Np);
+                    a_nxt[s_] = lop[base + col0 + li];
+#pragma unroll
+                    for (int q = 0; q < MAXT; ++q) b_nxt[s_][q] = lop[base + irow[q]];
+                }
+            };
+#ifndef BCBF_ABL_SKIP_KLOOP
+            if (kend > 0) fetch(0);
+            for (int kk = 0; kk < kend; kk += 2 * KS) {
+                float a_cur[KS], b_cur[KS][MAXT];
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    a_cur[s_] = -a_nxt[s_];                                   // D = (-A) B + C
+#pragma unroll
+                    for (int q = 0; q < MAXT; ++q) b_cur[s_][q] = b_nxt[s_][q];
+                }
+                if (kk + 2 * KS < kend) fetch(kk + 2 * KS);
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                    for (int q = 0; q < MAXT; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s_], b_cur[s_][q], acc[q], 0, 0, 0);
+            }
+#endif
+            // ---- diagonal tile -> LDS (tile I == J is slot q = 0 of wave 0, first group)
+            if (g == 0) {
+            // ---- wave 0: diagonal tile -> LDS -> factor + invert in registers (lane = row); written and read by
+            //      this wave only, so no workgroup barrier: LDS operations of one wave complete in order
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dS[acc_row(r, lh)][li] = acc[0][r];
+                __builtin_amdgcn_wave_barrier();
+                float row[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) row[c] = lane < NB ? dS[c][lane] : 0.f;      // S symmetric: S[lane][c] = S'[c][lane]
+                int bad = 0;
+                float idiag[NB];           // 1 / L[c][c] (wave-uniform values)
+#ifndef BCBF_ABL_SKIP_FACTOR
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const float piv = rlane(row[c], c);
+                    if (!(piv > 0.f) && bad == 0) bad = col0 + c + 1;
+                    const float inv = __builtin_amdgcn_rsqf(piv > 0.f ? piv : 1.f), lcc = piv * inv;   // 1-ulp rsq
+                    idiag[c] = inv;
+                    row[c] = lane == c ? lcc : (lane > c ? row[c] * inv : 0.f);
+#pragma unroll
+                    for (int c2 = c + 1; c2 < NB; ++c2) row[c2] -= row[c] * rlane(row[c], c2);
+                }
+                float x[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float s = lane == i ? 1.f : 0.f;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) s -= rlane(row[k], i) * x[k];
+                    x[i] = s * idiag[i];
+                }
+#else
+                float x[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) x[i] = lane == i ? 1.f : row[i] * 1e-6f;
+#endif
+                if (lane < NB) {
+                    const int j = col0 + lane, base = lop_base<V>(j, Np), first = (lane / V) * V;
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        dinv[i][lane] = x[i];
+                        if (i >= first) lop[base + col0 + i] = x[i];
+                    }
+                    if (Ld && j < N) {
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) if (c <= lane && col0 + c < N) Ld[(size_t)j * N + col0 + c] = row[c];
+                    }
+                }
+                if (lane == 0 && bad != 0 && bad <= N) fail = bad;
+            }
+            __syncthreads();          // (B) inv(L_JJ) visible
+            }
+            if (fail == 0) {
+                // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of S' are the B operands)
+                float ainv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ainv[r] = dinv[li][acc_row(r, lh)];
+#pragma unroll
+                for (int q = 0; q < MAXT; ++q) {
+                    const bool is_diag = tix[q] == 0;
+                    if (!live[q] || is_diag) continue;
+                    f32x16 y = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        y = __builtin_amdgcn_mfma_f32_32x32x2f32(ainv[r], acc[q][r], y, 0, 0, 0);
+                    const int i = irow[q];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = acc_row(r, lh);
+                        lop[lop_base<V>(col0 + c, Np) + i] = y[r];
+                        if (Ld && i < N && col0 + c < N) Ld[(size_t)i * N + col0 + c] = y[r];
+                    }
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (fail != 0) break;
+    }
+    if (tid == 0) info[b] = fail;
+}
+
+}  // namespace bcbf
+
+extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                                   const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense,
+                                   int* info, int Bt, int N, int n, int m, void* stream) {
+    using namespace bcbf;
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !info || N < 1) return BCBF_EINVAL;
+    const int Np = round_up(N, NB);
+    hipStream_t st = (hipStream_t)stream;
+    if (Kdense) {
+        hipLaunchKernelGGL((refit_mfma_kernel<true>), dim3(Bt), dim3(MT), 0, st, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
+    } else {
+        if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+        hipLaunchKernelGGL((refit_mfma_kernel<false>), dim3(Bt), dim3(MT), 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
+                           Lop, UHB, Ldense, info, N, Np, n, m + 1);
+    }
+    return check_launch("refit_mfma");
+}
