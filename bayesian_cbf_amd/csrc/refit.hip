@@ -201,7 +201,7 @@ refit_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restr
             if (lane < NB) {
                 const int j = col0 + lane;
                 const int base = lop_base<V>(j, Np);
-                const int first = (lane / V) * V;
+                const int first = 0;          // the whole diagonal-block column is stored (zeros above the diagonal)
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     dblk[i][lane] = x[i];                       // dblk[c][c'] = inv(L_JJ)[c][c']

@@ -204,7 +204,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                 for (int i = 0; i < NB; ++i) x[i] = lane == i ? 1.f : row[i] * 1e-6f;
 #endif
                 if (lane < NB) {
-                    const int j = col0 + lane, base = lop_base<V>(j, Np), first = (lane / V) * V;
+                    const int j = col0 + lane, base = lop_base<V>(j, Np), first = 0;   // whole block column stored
 #pragma unroll
                     for (int i = 0; i < NB; ++i) {
                         dinv[i][lane] = x[i];

@@ -240,7 +240,7 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
     // ---- copy / re-layout the old operator
     if (lout != lin) {
         for (int j = 0; j < NpO; ++j) {
-            const int first = (j / V) * V;
+            const int first = lop_first(j);
             const int bo = lop_base<V>(j, NpO);
             if (j < NpI) {
                 const int bi = lop_base<V>(j, NpI);

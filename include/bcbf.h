@@ -56,11 +56,11 @@ const char* bcbf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Packed triangular operator "Lop" (the HBM layout the per-step kernel streams).
- * Np = N rounded up to BCBF_NB; V = 16/sizeof(T) (4 for f32, 2 for f64).  Column j stores rows
- * V*floor(j/V) .. Np-1 contiguously (column-major, zero above the diagonal), columns one after
- * another; element (i,j) holds L[i][j] when i is below j's 32x32 diagonal block and
+ * Np = N rounded up to BCBF_NB (32).  Column j stores rows 32*floor(j/32) .. Np-1 contiguously (column-major, the
+ * whole column from the top of its diagonal block, zero above the diagonal), columns back to back: every column
+ * starts on a 128-byte boundary.  Element (i,j) holds L[i][j] when i is below j's 32x32 diagonal block and
  * inv(L_JJ)[i][j] inside the block (the block's triangular inverse).  Rows/cols >= N are identity.
- * Elements per instance = Np*(Np+V)/2.
+ * Elements per instance = Np*(Np+32)/2 (same for f32 and f64).
  * ------------------------------------------------------------------------------------------- */
 size_t bcbf_lop_elems_f32(int N);
 size_t bcbf_lop_elems_f64(int N);

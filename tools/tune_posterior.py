@@ -17,11 +17,9 @@ VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 
 VARIANTS = {
-    "u4_w2": ["-DBCBF_PS_UNR=4", "-DBCBF_PS_WAVES=2"],
-    "u4_w3": ["-DBCBF_PS_UNR=4", "-DBCBF_PS_WAVES=3"],
-    "u8_w2": ["-DBCBF_PS_UNR=8", "-DBCBF_PS_WAVES=2"],
+    "base": [],
+    "u2_w3": ["-DBCBF_PS_UNR=2", "-DBCBF_PS_WAVES=3"],
     "u8_w1": ["-DBCBF_PS_UNR=8", "-DBCBF_PS_WAVES=1"],
-    "u16_w1": ["-DBCBF_PS_UNR=16", "-DBCBF_PS_WAVES=1"],
 }
 
 
@@ -42,7 +40,7 @@ def build():
             raise SystemExit("build failed: " + name)
         lines = err.splitlines()
         for i, l in enumerate(lines):
-            if "Function Name" in l and "IfLi3ELi4" in l:
+            if "Function Name" in l and "IfLi3ELi4ELi0" in l:
                 info = " ".join(x.split("remark:")[1].strip().replace(" [-Rpass-analysis=kernel-resource-usage]", "")
                                 for x in lines[i + 1:i + 12] if ("VGPRs:" in x or "ScratchSize" in x or "Occupancy" in x))
                 print(name, info)
