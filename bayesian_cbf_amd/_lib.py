@@ -18,6 +18,7 @@ _SIGS = {
     "bcbf_last_error": (ctypes.c_char_p, []),
     "bcbf_lop_elems_f32": (c_size_t, [c_int]),
     "bcbf_lop_elems_f64": (c_size_t, [c_int]),
+    "bcbf_posterior_shared_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_coneqp_f64": (c_int, [P, P, P, P, c_int, c_int, ctypes.POINTER(c_int), c_int, P, P, P, c_int, c_int, P]),
 }
 _TSIGS = {

@@ -113,10 +113,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (one-GPU boxes): BCBF_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, BCBF_BENCH_BACKEND=gloo
+    # replaces RCCL -- the N>1 code path is then exercised without a second GPU
+    if os.environ.get("BCBF_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BCBF_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -201,9 +209,13 @@ def main():
     stats = torch.tensor([elapsed, float(n_opt), float(Bt), float(iters.float().mean())], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
+        if backend != "nccl":
+            stats = stats.cpu()
         tmax = stats[:1].clone()
+        sums = stats[1:3].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats[1:3], op=dist.ReduceOp.SUM)      # the final (only) reduction: a few numbers over RCCL
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)            # the final (only) reduction: a few numbers over RCCL
+        stats[1:3] = sums
         elapsed = float(tmax[0])
     total_instances = float(stats[2])
     ms_per_step = elapsed / args.steps * 1e3

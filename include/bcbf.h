@@ -134,6 +134,15 @@ int bcbf_posterior_query_f64(const double* Lop, const double* Vw, const double* 
                              const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                              int shared, int Bt, int N, int n, int m, void* stream);
 
+/* Regime S on the matrix cores (fp32, N <= 1280): Bt queries against ONE GP (instance 0 of the GP tensors), 8
+ * queries per wavefront, blocked forward substitution with v_mfma_f32_32x32x2_f32 against the cache-resident
+ * factor.  Same outputs as bcbf_posterior_query_f32(shared=1), which routes here for Bt >= 16.  Replaces
+ * custom_predict with b test points (control_affine_model.py:536-602, 1051-1091). */
+int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                              const float* ell, const float* s2, const float* Bm, const float* M0,
+                              const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                              int Bt, int N, int n, int m, void* stream);
+
 /* Posterior jets: value and first x-derivatives of the posterior factors (one query per instance, or per
  * query of a shared GP).  CT = (1+m)(1+n) right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] of the same stream:
  *   G[Bt,CT,CT] = Wj'Wj,  Mj[Bt,n,CT] = Vw'Wj   (Mk = M0' + Mj[:, :C]; dMk/dx_d = Mj[:, (1+d)C:(2+d)C]),

@@ -458,3 +458,38 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
     for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
         ref = g["t_" + name].reshape(host(val).shape)
         rel_close(host(val), ref, ttol, scale=max(np.abs(ref).max(), 1e-2), what=name)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,n,m,b", [(512, 3, 2, 203), (100, 3, 2, 8), (256, 2, 1, 64), (1024, 3, 3, 37), (64, 1, 1, 5)])
+def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b):
+    """Regime S (custom_predict with b test points, control_affine_model.py:536, 1051): the MFMA kernel against the
+    fp64 oracle, ragged b (not a multiple of the 8 queries a wave holds) and ragged N (padding rows)."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    dtype = torch.float32
+    p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=3 + N)
+    Lop, UHB, info = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert int(info[0]) == 0
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    g = torch.Generator(device="cpu").manual_seed(11)
+    idx = torch.randint(0, N, (b,), generator=g)
+    xq = (p["X"][0, idx.to(DEV)] + 0.3 * torch.randn(b, n, generator=g).to(DEV, dtype)).contiguous()
+    j2 = (1e-5 * torch.rand(b, m + 1, generator=g)).to(DEV, dtype)
+    Mk, Bk, W = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, want_W=True)
+    h = {k: host(v) for k, v in p.items()}
+    st = ogp.refit_state(h["X"][0], h["U"][0], h["Xdot"][0], h["Bm"][0], h["ell"][0], h["s2"][0], h["M0"][0],
+                         h["jitter"][0][None] / 1e-5)
+    rep = lambda a: np.broadcast_to(a[None], (b,) + a.shape)
+    Mk_o, Bk_o = ogp.posterior_step(rep(st["L"]), rep(st["alpha"]), rep(h["X"][0]), rep(st["UHB"]), rep(h["ell"][0]),
+                                    rep(h["s2"][0]), rep(h["Bm"][0]), rep(h["M0"][0]), host(xq), jitter2=host(j2))
+    prior = h["s2"][0] * np.abs(h["Bm"][0]).max()
+    rel_close(host(Mk), Mk_o, 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+    rel_close(host(Bk), Bk_o, 1e-3, scale=prior, what="Bk")
+    # W'W reproduces the Gram the kernel accumulated (and the routed query entry gives the same numbers)
+    Wh = host(W)
+    G = np.einsum("bic,bid->bcd", Wh, Wh)
+    Bk_w = prior * 0 + h["s2"][0] * h["Bm"][0][None] - G + np.stack([np.diag(r) for r in host(j2)])
+    rel_close(host(Bk), Bk_w, 1e-4, scale=prior, what="Bk from W")
+    Mk2, Bk2, _ = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, shared=True)
+    rel_close(host(Mk2), Mk_o, 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk(query)")
+    rel_close(host(Bk2), Bk_o, 1e-3, scale=prior, what="Bk(query)")
