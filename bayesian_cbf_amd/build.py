@@ -20,6 +20,9 @@ SOURCES = ["common.hip", "posterior_step.hip", "posterior_shared.hip", "refit.hi
            "unicycle.hip", "control_step.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+# per-file extras.  posterior_shared: MFMA results are consumed by VALU code every block, so keep the accumulators
+# in VGPRs (no v_accvgpr round trips)
+EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():
@@ -38,10 +41,11 @@ def _newer(a, bs):
 
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "bcbf_common.h"), os.path.join(ROOT, "include", "bcbf.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "bcbf_common.h"), os.path.join(ROOT, "include", "bcbf.h"),
+            os.path.abspath(__file__)]
     if not force and _newer(obj, deps):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))

@@ -1,125 +1,297 @@
 // Regime S: many queries against ONE GP (the reference's own batched API -- custom_predict with b test
 // points, control_affine_model.py:536, 1051; Monte-Carlo rollouts of a fixed learned model).
 //
-// L (<= 1 MB) stays in L2 / Infinity Cache and the work is a triangular solve with b*(1+m) right-hand
-// sides: compute bound, so it runs on the matrix cores.  One wave = 8 queries = 32 right-hand-side columns
-// (4 per query, the 4th zero for m = 2): blocked forward substitution with v_mfma_f32_32x32x2_f32,
-//     acc_I  = Phi_I - sum_{K<I} L_IK W_K          A = -L_IK (one dword per lane from the packed operator,
-//                                                   coalesced),  B = W_K rows from LDS (the wave's W slab)
-//     W_I    = inv(L_II) acc_I                      A = stored inverse,  B = accumulator registers of acc_I
-// and the per-query Gram W'W / mean Vw'W are accumulated from the accumulator registers with quad
-// broadcasts (the 4 columns of a query sit in 4 adjacent lanes).  fp32 only; N <= 1024.
+// L (<= 2 MB) stays in L2 / Infinity Cache and the work is a triangular solve with b*(1+m) right-hand
+// sides: compute bound, so it runs on the matrix cores.  One wave = 4 queries = 16 right-hand-side columns
+// (4 per query, unused ones zero) and walks the blocked forward substitution with v_mfma_f32_16x16x4_f32:
+//     acc    = -Phi_I + sum_{K<I} L_IK W_K       A = L_IK (8-byte loads from the packed operator),
+//                                                B = W_K from the wave's slab in LDS
+//     W_I    = inv(L_II) (-acc)                  A = stored inverse, B = the accumulator registers themselves
+// Rows inside a 32-block are interleaved over the two 16-row MFMA tiles (tile u, lane group g, register r hold
+// row 8g + 2r + u) so that one 8-byte load feeds both tiles, and the k index of every MFMA is ordered the same
+// way, which makes the accumulator registers directly usable as the B operand of the diagonal step.
+// The per-query Gram W'W and mean Vw'W are accumulated from the accumulator registers with quad broadcasts
+// (the 4 columns of a query sit in 4 adjacent lanes).  X, UHB and Vw are staged in LDS once per workgroup so
+// the only vector-memory traffic in the loop is the prefetched stream of L tiles.  fp32 only.
+#include <type_traits>
+
 #include "bcbf_common.h"
 
 namespace bcbf {
 
-using f32x16s = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+using f32x4s = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+using u32x2s = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
 
-__device__ inline int acc_row_s(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 template <int CTRL> __device__ inline float dpp_q(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+__device__ inline int blk_row(int u, int g, int r) { return 8 * g + 2 * r + u; }   // row inside the 32-block
 
-template <int C>
-__global__ void __launch_bounds__(64)
+constexpr int PSH_DEPTH = 4;      // L tiles in flight per wave
+
+template <int C, int NS, bool WANTW>
+__global__ void __launch_bounds__(256)
 posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__ Vw, const float* __restrict__ X,
                         const float* __restrict__ UHB, const float* __restrict__ ell, const float* __restrict__ s2p,
                         const float* __restrict__ Bm, const float* __restrict__ M0, const float* __restrict__ xq,
                         const float* __restrict__ jitter2, float* __restrict__ Mk, float* __restrict__ Bk,
                         float* __restrict__ Wout, int nq, int N, int Np, int n) {
-    constexpr int V = 4, QW = 8;                      // queries per wave
-    extern __shared__ float Wl[];                     // [Np][32]: the wave's W slab, row-major
-    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
-    const int ql = li >> 2, c = li & 3;               // query slot in the wave, component
-    const int q = blockIdx.x * QW + ql;
+    constexpr int V = 4, QW = 4;                      // queries per wave
+#ifdef BCBF_PSH_PROFILE
+    const long long t_start = clock64();
+#endif
+    extern __shared__ float smem[];
+    const int nwave = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    float* Xs = smem;                                 // [Np][NS]  (state dim padded to NS with zeros)
+    float* Us = Xs + (size_t)Np * NS;                 // [Np][C]
+    float* Vs = Us + (size_t)Np * C;                  // [Np][NS]
+    float* Wl = Vs + (size_t)Np * NS + (size_t)wave * Np * 16;    // this wave's slab: [Np (k-ordered inside a block)][16]
+    // staging: branch-free loads, several in flight per thread (a plain copy loop waits out one full memory
+    // latency per element)
+    {
+        constexpr int UN = 4;
+        const int E = Np * NS, EU = Np * C, bd = blockDim.x;
+        for (int i0 = threadIdx.x; i0 < E; i0 += bd * UN) {
+            float vx[UN], vv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + bd * u, row = i / NS, d = i - row * NS;
+                const bool ok = row < N && d < n;
+                const int si = ok ? row * n + d : 0;
+                const float tx = X[si], tv = Vw[si];
+                vx[u] = ok ? tx : 0.f;
+                vv[u] = ok ? tv : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + bd * u;
+                if (i < E) { Xs[i] = vx[u]; Vs[i] = vv[u]; }
+            }
+        }
+        for (int i0 = threadIdx.x; i0 < EU; i0 += bd * UN) {
+            float vu[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + bd * u;
+                const bool ok = i < N * C;
+                const float t = UHB[ok ? i : 0];
+                vu[u] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + bd * u;
+                if (i < EU) Us[i] = vu[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int ql = j >> 2, c = j & 3;                 // query slot in the wave, component
+    const int q = (blockIdx.x * nwave + wave) * QW + ql;
     const bool qok = q < nq, cok = c < C;
     const int qq = qok ? q : nq - 1;
-    const float* __restrict__ lop = Lop;
+    if ((blockIdx.x * nwave + wave) * QW >= nq) return;           // whole wave idle (no further barriers below)
 
-    float xqr[BCBF_MAX_STATE_DIM], iell[BCBF_MAX_STATE_DIM];
+    float xqr[NS], iell[NS];
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+    for (int d = 0; d < NS; ++d) {
         xqr[d] = d < n ? xq[(size_t)qq * n + d] : 0.f;
         iell[d] = d < n ? 1.f / ell[d] : 0.f;
     }
     const float s2 = s2p[0];
-    float gram[C], mk[BCBF_MAX_STATE_DIM];
+    float gram[C], mk[NS];
 #pragma unroll
     for (int a = 0; a < C; ++a) gram[a] = 0.f;
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) mk[d] = 0.f;
+    for (int d = 0; d < NS; ++d) mk[d] = 0.f;
 
     const int nblk = Np / NB;
-    for (int I = 0; I < nblk; ++I) {
-        const int row0 = I * NB;
-        // ---- Phi tile: acc[r] = k(X_row, x_q) UHB[row][c], row = row0 + rho(r) + 4h.  The exp is computed once
-        //      per (query,row) by the lane whose component equals r & 3 and broadcast inside the quad.
-        f32x16s acc;
+    const int cc = cok ? c : 0;
+    const float cmask = cok ? 1.f : 0.f;
+    f32x4s acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // tile u: sum_K L_IK W_K, rows 8g+2r+u, column j
+    float phi[8], phin[8], pend[8];                       // Phi tile of the current block, W tile awaiting its epilogue,
+                                                      // B operand (rows of W_K) of the next off-diagonal tile
+
+    // Phi tile of block I (index u*4+r).  The exp of (query,row) is evaluated once, by the lane whose component
+    // equals r, and broadcast inside the quad.  Padded rows need no test: their UHB rows are zero in the staged copy.
+    auto phi_tile = [&](int I) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int rmine = 4 * r4 + c;                                   // the register this lane evaluates
-            const int row_m = row0 + acc_row_s(rmine, lh);
-            float kmine = 0.f;
-            if (row_m < N) {
-                float d2 = 0.f;
+        for (int u = 0; u < 2; ++u) {
+            const int row_m = I * NB + blk_row(u, g, c);
+            float d2 = 0.f;
 #pragma unroll
-                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
-                    if (d < n) { const float z = (X[(size_t)row_m * n + d] - xqr[d]) * iell[d]; d2 += z * z; }
-                kmine = s2 * expf(-0.5f * d2);
-            }
-            const float k0 = dpp_q<0x00>(kmine), k1 = dpp_q<0x55>(kmine), k2 = dpp_q<0xAA>(kmine), k3 = dpp_q<0xFF>(kmine);
-            const float kk[4] = {k0, k1, k2, k3};
+            for (int d = 0; d < NS; ++d) { const float z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
+            const float kmine = s2 * __expf(-0.5f * d2);
+            const float kk[4] = {dpp_q<0x00>(kmine), dpp_q<0x55>(kmine), dpp_q<0xAA>(kmine), dpp_q<0xFF>(kmine)};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * r4 + j, row = row0 + acc_row_s(r, lh);
-                acc[r] = (cok && row < N) ? kk[j] * UHB[(size_t)row * C + c] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) phin[u * 4 + r] = kk[r] * Us[(I * NB + blk_row(u, g, r)) * C + cc] * cmask;
         }
-        // ---- acc -= L_IK W_K for K < I, then W_I = inv(L_II) acc  (K == I, fresh accumulator)
-        for (int K = 0; K < I; ++K) {
-            const float* wk = Wl + (size_t)K * NB * 32;
-#pragma unroll 4
-            for (int s_ = 0; s_ < NB / 2; ++s_) {
-                const float a = -lop[lop_base<V>(K * NB + 2 * s_ + lh, Np) + row0 + li];
-                const float bq = wk[(2 * s_ + lh) * 32 + li];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
-            }
+    };
+    // Gram row / mean column of this lane's query from the W tile of block Ib held in pend[]
+    auto epilogue = [&](int Ib) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = pend[e];
+            const int row = (Ib < 0 ? 0 : Ib) * NB + blk_row(e >> 2, g, e & 3);    // Ib = -1: pend is zero
+            const float vb[4] = {dpp_q<0x00>(v), dpp_q<0x55>(v), dpp_q<0xAA>(v), dpp_q<0xFF>(v)};
+#pragma unroll
+            for (int a_ = 0; a_ < C; ++a_) gram[a_] += v * vb[a_];              // lane c: G[c][a]
+#pragma unroll
+            for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;         // lane c: (Vw'W)[d][c]
         }
-        f32x16s w = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    };
+
+    // L tile (I,K): step s = (u,r) feeds k rows {8g + 2r + u}; one 8-byte load covers output rows 2i, 2i+1.
+    // Element (row, col) sits at lop_base(col) + row and lop_base is affine in the column inside a block column, so
+    // all 8 loads of a tile share one per-lane offset and differ only in the scalar offset.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Lop), 0, (int)(lop_elems<V>(Np) * sizeof(float)), 0x00020000);
+    int Il = 0, Kl = 0;                               // load cursor (runs PSH_DEPTH - 1 tiles ahead)
+    int lbase = 0, lstride = Np;                      // lop_base(Kl*NB), column stride of block column Kl
+    // Branch-free and unconditional: a wave issues one instruction every 4 cycles, so every scalar instruction and
+    // branch of the step shows up in the run time unless it hides behind an MFMA.  Past the last tile the cursor
+    // runs out of the operator and the buffer bounds check returns zeros.
+    auto issue = [&](float2 (&a)[8]) {
+        const int voff = (8 * g * lstride + 2 * j) * (int)sizeof(float);
+        const int st4 = lstride * (int)sizeof(float);
+        int off[8];
+        off[0] = (lbase + Il * NB) * (int)sizeof(float);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = lop[lop_base<V>(row0 + acc_row_s(r, lh), Np) + row0 + li];     // inv(L_II)[li][rho(r)+4h]
-            w = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[r], w, 0, 0, 0);
+        for (int cs = 1; cs < 8; ++cs) off[cs] = off[cs - 1] + st4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int cs = 2 * (s & 3) + (s >> 2);                            // blk_row(u, 0, r)
+#ifdef BCBF_PSH_ABL_NOLOAD
+            a[s] = make_float2(1e-3f * (cs + Il), 1e-3f * j);
+#else
+            const u32x2s v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, off[cs], 0);
+            a[s] = __builtin_bit_cast(float2, v);
+#endif
         }
-        // ---- publish W_I to the slab, accumulate the per-query Gram row and mean column
-        float* wi = Wl + (size_t)I * NB * 32;
+        const bool adv = Kl < Il;
+        lbase = adv ? lbase + NB * lstride - NB : 0;
+        lstride = adv ? lstride - NB : Np;
+        Il = adv ? Il : Il + 1;
+        Kl = adv ? Kl + 1 : 0;
+    };
+    auto load_b = [&](float (&b)[8], int Kb) {
+        const float* wk = Wl + (size_t)Kb * NB * 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = acc_row_s(r, lh), row = row0 + rr;
-            const float v = w[r];
-            wi[rr * 32 + li] = v;
-            if (Wout != nullptr && qok && cok) Wout[((size_t)q * Np + row) * C + c] = v;
-            const float v0 = dpp_q<0x00>(v), v1 = dpp_q<0x55>(v), v2 = dpp_q<0xAA>(v), v3 = dpp_q<0xFF>(v);
-            const float vb[4] = {v0, v1, v2, v3};
+        for (int s = 0; s < 8; ++s) b[s] = wk[(4 * s + g) * 16 + j];
+    };
+
+    int I = 0, K = 0;                                 // compute cursor
+#ifdef BCBF_PSH_PROFILE
+    const long long t_begin = clock64();
+    long long t_diag = 0, t_first = 0;
+#endif
+    // One step = consume the oldest tile in flight, refill the slot behind it, fetch the B rows of the next
+    // off-diagonal tile.  Two shapes, each ONE basic block so that the scheduler can place the loads and the cursor
+    // arithmetic in the shadow of the MFMAs (a lone wave issues one instruction per 4 cycles):
+    //   off-diagonal : 16 MFMAs
+    //   diagonal     : W_I = inv(L_II) (Phi_I - acc) -- a dependent MFMA chain with idle issue slots, which take
+    //                  the epilogue of block I-1 and the Phi tile of block I+1 -- then publish W_I to the slab
+    auto off_step = [&](const float2 (&a)[8], float2 (&fill)[8], const float (&bc)[8], float (&bn)[8]) {
+        issue(fill);
+        load_b(bn, K + 1 < I ? K + 1 : 0);            // W_0 after the diagonal step
+#ifndef BCBF_PSH_ABL_NOOFF
 #pragma unroll
-            for (int a = 0; a < C; ++a) gram[a] += v * vb[a];               // lane c: G[c][a]
-            if (row < N) {
-#pragma unroll
-                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
-                    if (d < n) mk[d] += Vw[(size_t)row * n + d] * v;        // lane c: (Vw'W)[d][c]
-            }
+        for (int s = 0; s < 8; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, bc[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, bc[s], acc1, 0, 0, 0);
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): the slab rows are visible to this wave's next reads
-        __builtin_amdgcn_wave_barrier();
+#else
+        acc0[0] += a[0].x * bc[0]; acc1[0] += a[0].y * bc[7];
+#endif
+#ifndef BCBF_PSH_NOSCHED
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                // one MFMA, then a slice of everything else
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+        }
+#endif
+        ++K;
+    };
+    auto diag_step = [&](const float2 (&a)[8], float2 (&fill)[8], float (&bn)[8]) {
+        f32x4s w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float b_ = phi[s] - ((s >> 2) ? acc1[s & 3] : acc0[s & 3]);
+            w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b_, w0, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, b_, w1, 0, 0, 0);
+        }
+        issue(fill);                                  // (not first: a prefix shared with off_step gets hoisted above
+                                                      //  the branch by the compiler, out of the MFMA shadow)
+        epilogue(I - 1);                              // pend = W_{I-1} (zeros for I = 0)
+        phi_tile(I + 1);                              // into phin (past the last block: staged garbage, never used)
+#ifndef BCBF_PSH_NOSCHED
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 10, 0);
+        }
+#endif
+        float* wi = Wl + (size_t)I * NB * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (e >> 2) ? w1[e & 3] : w0[e & 3];
+            pend[e] = v;
+            wi[(e * 4 + g) * 16 + j] = v;                                      // k-ordered: position u*4+r, then g
+            if (WANTW && qok && cok) Wout[((size_t)q * Np + I * NB + blk_row(e >> 2, g, e & 3)) * C + c] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) phi[e] = phin[e];
+        load_b(bn, 0);                                // the next tile is (I+1, 0): B = W_0 (just written when I = 0)
+        ++I; K = 0;
+    };
+
+    float2 A0[8], A1[8], A2[8], A3[8];
+    float B0[8], B1[8];                               // B rows of the current / next off-diagonal tile (by slot parity)
+    static_assert(PSH_DEPTH == 4, "the pipeline below is written for 4 tiles in flight");
+    phi_tile(0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { phi[e] = phin[e]; pend[e] = 0.f; B0[e] = 0.f; B1[e] = 0.f; }
+    issue(A0); issue(A1); issue(A2);
+#ifdef BCBF_PSH_PROFILE
+#define BCBF_PSH_TIMED(var, expr) { const long long t0_ = clock64(); expr; var += clock64() - t0_; }
+#else
+#define BCBF_PSH_TIMED(var, expr) { expr; }
+#endif
+#define BCBF_PSH_STEP(cur, fill, bc, bn)                                                     \
+    if (K < I) {                                                                             \
+        off_step(cur, fill, bc, bn);                                                         \
+    } else {                                                                                 \
+        BCBF_PSH_TIMED(t_diag, diag_step(cur, fill, bn))                                     \
+        if (I >= nblk) break;                                                                \
     }
-    // ---- the two lane halves hold different rows: combine, then write Mk[q][d][c], Bk[q][c][a]
+    for (;;) {
+        BCBF_PSH_STEP(A0, A3, B0, B1)
+        BCBF_PSH_STEP(A1, A0, B1, B0)
+        BCBF_PSH_STEP(A2, A1, B0, B1)
+        BCBF_PSH_STEP(A3, A2, B1, B0)
+    }
+#undef BCBF_PSH_STEP
+#undef BCBF_PSH_TIMED
+    epilogue(nblk - 1);
+#ifdef BCBF_PSH_PROFILE
+    const long long t_total = clock64() - t_begin;
+#endif
+
+    // ---- the four lane groups hold different rows: combine, then write Mk[q][d][c], Bk[q][c][a]
 #pragma unroll
-    for (int a = 0; a < C; ++a) gram[a] += __shfl_xor(gram[a], 32, 64);
+    for (int a = 0; a < C; ++a) { gram[a] += __shfl_xor(gram[a], 16, 64); gram[a] += __shfl_xor(gram[a], 32, 64); }
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) mk[d] += __shfl_xor(mk[d], 32, 64);
-    if (lh == 0 && qok && cok) {
+    for (int d = 0; d < NS; ++d) { mk[d] += __shfl_xor(mk[d], 16, 64); mk[d] += __shfl_xor(mk[d], 32, 64); }
+    if (g == 0 && qok && cok) {
 #pragma unroll
-        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+        for (int d = 0; d < NS; ++d)
             if (d < n) Mk[((size_t)q * n + d) * C + c] = M0[c * n + d] + mk[d];
 #pragma unroll
         for (int a = 0; a < C; ++a) {
@@ -128,6 +300,55 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
             Bk[((size_t)q * C + c) * C + a] = v;
         }
     }
+#ifdef BCBF_PSH_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Bk[0] = (float)(t_begin - t_start); Bk[1] = (float)t_total; Bk[2] = (float)(clock64() - t_start); Bk[3] = (float)t_diag; Bk[4] = (float)t_first;
+    }
+#endif
+}
+
+static int padded_state_dim(int n) { return n <= 4 ? n : (n <= 6 ? 6 : 8); }
+
+bool posterior_shared_fits(int N, int n, int m) {
+    const size_t Np = round_up(N, NB);
+    return Np * (2 * padded_state_dim(n) + m + 1 + 16) * sizeof(float) <= 160 * 1024;
+}
+
+template <int C, int NS>
+static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Lop, const float* Vw,
+                          const float* X, const float* UHB, const float* ell, const float* s2, const float* Bm,
+                          const float* M0, const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                          int nq, int N, int Np, int n) {
+    if (W != nullptr) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<C, NS, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((posterior_shared_kernel<C, NS, true>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
+                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<C, NS, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((posterior_shared_kernel<C, NS, false>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
+                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+    }
+}
+
+template <int C>
+static void launch_shared_c(int NSp, dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Lop,
+                            const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+                            const float* Bm, const float* M0, const float* xq, const float* jitter2, float* Mk,
+                            float* Bk, float* W, int nq, int N, int Np, int n) {
+#define BCBF_PSH(NSV) launch_shared<C, NSV>(grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
+    switch (NSp) {
+        case 1: BCBF_PSH(1); break;
+        case 2: BCBF_PSH(2); break;
+        case 3: BCBF_PSH(3); break;
+        case 4: BCBF_PSH(4); break;
+        case 6: BCBF_PSH(6); break;
+        default: BCBF_PSH(8); break;
+    }
+#undef BCBF_PSH
 }
 
 }  // namespace bcbf
@@ -140,24 +361,21 @@ extern "C" int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, cons
     if (nq <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > 3) return BCBF_EINVAL;
-    const int Np = round_up(N, NB);
-    const size_t lds = (size_t)Np * 32 * sizeof(float);
-    if (lds > 160 * 1024) return BCBF_EINVAL;            // N <= 1280: the W slab of a wave lives in LDS
+    const int Np = round_up(N, NB), C = m + 1, NSp = padded_state_dim(n);
+    if (!posterior_shared_fits(N, n, m)) return BCBF_EINVAL;      // the W slab of a wave lives in LDS
+    const size_t stage = (size_t)Np * (2 * NSp + C) * sizeof(float), slab = (size_t)Np * 16 * sizeof(float);
+    const size_t cap = 160 * 1024;
+    int nwave = (int)((cap - stage) / slab);
+    if (nwave > 4) nwave = 4;
+    const int waves = (nq + 3) / 4;
+    if (nwave > waves) nwave = waves;
+    const size_t lds = stage + nwave * slab;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((nq + 7) / 8), block(64);
-#define BCBF_PSH(CC)                                                                                                    \
-    do {                                                                                                                \
-        if (lds > 64 * 1024)                                                                                            \
-            (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((posterior_shared_kernel<CC>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq,   \
-                           jitter2, Mk, Bk, W, nq, N, Np, n);                                                              \
-    } while (0)
+    dim3 grid((waves + nwave - 1) / nwave), block(64 * nwave);
     switch (m) {
-        case 1: BCBF_PSH(2); break;
-        case 2: BCBF_PSH(3); break;
-        case 3: BCBF_PSH(4); break;
-        default: return BCBF_EINVAL;
+        case 1: launch_shared_c<2>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 2: launch_shared_c<3>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        default: launch_shared_c<4>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
     }
-#undef BCBF_PSH
     return check_launch("posterior_shared");
 }

@@ -374,7 +374,7 @@ extern "C" int bcbf_posterior_query_f32(const float* Lop, const float* Vw, const
                                         const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                                         int shared, int Bt, int N, int n, int m, void* stream) {
     // many queries of one GP: the factor stays in cache and the solve is compute bound -> matrix-core kernel
-    if (shared && Bt >= 16 && N <= 1280)
+    if (shared && Bt >= 16 && bcbf::posterior_shared_fits(N, n, m))
         return bcbf_posterior_shared_f32(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, Bt, N, n, m, stream);
     return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream);
 }

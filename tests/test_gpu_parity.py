@@ -461,14 +461,14 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
 
 
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,n,m,b", [(512, 3, 2, 203), (100, 3, 2, 8), (256, 2, 1, 64), (1024, 3, 3, 37), (64, 1, 1, 5)])
+@pytest.mark.parametrize("N,n,m,b", [(512, 3, 2, 203), (100, 3, 2, 8), (256, 3, 1, 64), (1024, 3, 3, 37), (64, 3, 1, 5), (1280, 3, 2, 17)])
 def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b):
     """Regime S (custom_predict with b test points, control_affine_model.py:536, 1051): the MFMA kernel against the
     fp64 oracle, ragged b (not a multiple of the 8 queries a wave holds) and ragged N (padding rows)."""
     from bayesian_cbf_amd.synthetic import make_instances
     dtype = torch.float32
     p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=3 + N)
-    Lop, UHB, info = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     assert int(info[0]) == 0
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
     g = torch.Generator(device="cpu").manual_seed(11)

@@ -1,5 +1,6 @@
 """Micro-benchmark of regime S (b queries of one GP): MFMA kernel vs the streaming kernel."""
-import sys, time
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
@@ -7,7 +8,7 @@ from bayesian_cbf_amd.synthetic import make_instances
 N, n, m = 512, 3, 2
 dev = "cuda"
 p = make_instances(1, N, n, m, dtype=torch.float32, device=dev, seed=1)
-Lop, UHB, info = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
 Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
 for b in (8, 512, 4096, 16384, 65536):
     xq = (p["X"][0, torch.randint(0, N, (b,), device=dev)] + 0.3 * torch.randn(b, n, device=dev)).contiguous()
