@@ -23,15 +23,18 @@ __global__ void apply_control_kernel(T* __restrict__ x, const T* __restrict__ y,
         const T* A, T* x, const T* plan, const T* dot_plan, const T* Kp, T clf_gamma, const T* centers,               \
         const T* radii, const T* tw, const T* gammas, T L_mean, const T* w, const T* r, const T* sign,                \
         const T* relax_mask, const T* rho, T* grad, T* cst, T* fhat, T* ghat, T* Mk, T* Bk, T* cones, int* cstatus,   \
-        T* y, int* status, int* iters, T dt, T L_true, int Bt, int N, int Kob, int max_iters, void* ev_start,         \
-        void* ev_stop, void* stream) {                                                                                 \
+        T* y, int* status, int* iters, T dt, T L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,          \
+        void* ev_start, void* ev_stop, void* stream) {                                                                                 \
         if (Bt <= 0) return BCBF_OK;                                                                                   \
         hipStream_t st = (hipStream_t)stream;                                                                          \
         int rc = bcbf_unicycle_constraints_##SUF(x, plan, dot_plan, Kp, clf_gamma, centers, radii, tw, gammas, L_mean,\
                                                  grad, cst, fhat, ghat, Bt, Kob, stream);                              \
         if (rc) return rc;                                                                                             \
         if (ev_start) hipEventRecord((hipEvent_t)ev_start, st);                                                        \
-        rc = bcbf_posterior_step_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, Bt, N, 3, 2, stream);    \
+        rc = shared_gp ? bcbf_posterior_query_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, 1, \
+                                                    Bt, N, 3, 2, stream)                                               \
+                       : bcbf_posterior_step_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, Bt, N, 3, 2,  \
+                                                   stream);                                                            \
         if (ev_stop) hipEventRecord((hipEvent_t)ev_stop, st);                                                          \
         if (rc) return rc;                                                                                             \
         rc = bcbf_cbc_socp_##SUF(Mk, Bk, A, grad, cst, sign, fhat, ghat, w, r, relax_mask, rho, nullptr, cones, cstatus,  \

@@ -330,19 +330,30 @@ def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_g
 
     gp:   dict(Lop, Vw, X, UHB, ell, s2, Bm, M0, A);  task: dict(plan, dot_plan, Kp, centers, radii, tw, gammas,
     w, r, sign, relax_mask, rho);  ws: dict of workspaces (grad, cst, fhat, ghat, Mk, Bk, cones, cstatus, y,
-    status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y']."""
+    status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y'].
+    GP tensors with a leading axis of 1 and Bt > 1 = one learned model shared by all instances (Monte-Carlo
+    rollouts of a fixed model): the posterior runs as a shared query (fp32: the matrix-core kernel)."""
     _chk(x, gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], task["plan"], ws["y"])
-    Bt, N = gp["X"].shape[0], gp["X"].shape[1]
+    Bt, N = x.shape[0], gp["X"].shape[1]
+    shared = gp["X"].shape[0] == 1 and Bt > 1
+    if not shared and gp["X"].shape[0] != Bt:
+        raise ValueError("GP tensors must carry a leading axis of 1 (shared model) or Bt")
+    A = gp["A"]
+    if A.shape[0] != Bt:                     # per-instance kernel matrix A for the fused terms+SOCP kernel
+        if ws.get("A_shared_src") is not A:
+            ws["A_shared"], ws["A_shared_src"] = A.expand(Bt, *A.shape[1:]).contiguous(), A
+        A = ws["A_shared"]
     Kob = task["centers"].shape[1]
     ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
     ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
     check(getattr(lib, "bcbf_unicycle_control_step" + _suf(x))(
         _p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
-        _p(gp["M0"]), _p(gp["A"]), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
+        _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
         _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
         _p(task["r"]), _p(task["sign"]), _p(task["relax_mask"]), _p(task["rho"]), _p(ws["grad"]), _p(ws["cst"]),
         _p(ws["fhat"]), _p(ws["ghat"]), _p(ws["Mk"]), _p(ws["Bk"]), _p(ws["cones"]), _p(ws["cstatus"]), _p(ws["y"]),
-        _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, ev0, ev1, _stream(x)),
+        _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, 1 if shared else 0, ev0, ev1,
+        _stream(x)),
         "bcbf_unicycle_control_step")
     return ws["y"]
 

@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--variant", default="dense")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
     ap.add_argument("--chunks", type=int, default=1, help="independent sub-batches, one HIP stream each")
+    ap.add_argument("--regime", choices=["independent", "shared"], default="independent",
+                    help="independent: every instance owns its GP (headline, HBM bound); shared: one learned model, "
+                         "`batch` closed loops (Monte-Carlo rollouts, BASELINE configs[3]; matrix-core bound)")
     return ap.parse_args()
 
 
@@ -134,7 +138,9 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     Bt, N, n, m = args.batch, args.ntrain, 3, 2
     K = 3
-    p = make_instances(Bt, N, n, m, dtype=dtype, device=dev, seed=1234 + rank, variant=args.variant)
+    shared = args.regime == "shared"
+    Bgp = 1 if shared else Bt                # GP instances held by this rank
+    p = make_instances(Bgp, N, n, m, dtype=dtype, device=dev, seed=1234 + rank, variant=args.variant)
     task = make_unicycle_task(Bt, dtype=dtype, device=dev, seed=99 + rank)
     # ---- refit (not timed: once per refit, cached between control steps in the reference)
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
@@ -154,8 +160,9 @@ def main():
     class Chunk:
         def __init__(self, c):
             sl = slice(c * Bc, (c + 1) * Bc)
-            q = {k: v[sl] for k, v in p.items()}
-            self.gp = dict(Lop=Lop[sl], Vw=Vw[sl], X=q["X"], UHB=UHB[sl], ell=q["ell"], s2=q["s2"], Bm=q["Bm"],
+            gsl = slice(0, 1) if shared else sl
+            q = {k: v[gsl] for k, v in p.items()}
+            self.gp = dict(Lop=Lop[gsl], Vw=Vw[gsl], X=q["X"], UHB=UHB[gsl], ell=q["ell"], s2=q["s2"], Bm=q["Bm"],
                            M0=q["M0"], A=q["A"])
             self.task = {k: (v[sl] if v.dim() > 0 and v.shape[0] == Bt else v) for k, v in task.items()}
             self.x = task["x"][sl].clone()
@@ -221,7 +228,30 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_instances * args.steps / elapsed
 
-    if rank == 0:
+    if rank == 0 and shared:
+        # regime S: the factor is cache resident; the kernel is a triangular solve with (1+m) right-hand sides per
+        # query on the matrix cores: N^2 flop per column (N^2/2 multiply-adds) -- Gram / mean accumulation not counted
+        flops_launch = float(Bc) * (1 + m) * N * N
+        achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; shared learned model" % (N, Bt),
+            "value": value, "unit": "control steps/s (instance-steps: batch x batched steps/s)",
+            "batched_steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints + SOCP per step, "
+                                   "ONE learned model queried by every closed loop (Monte-Carlo rollouts)",
+                       "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
+                       "regime": "shared GP (S)", "inputs": args.variant, "streams": S,
+                       "parallelism": "closed loops sharded, dp%d" % world},
+            "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
+            "roofline": {"bound": "mfma", "kernel": "posterior_shared_kernel", "achieved": achieved,
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops_launch,
+                         "queries_per_launch": Bc},
+        }
+        print(json.dumps(out))
+    elif rank == 0:
         bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bc
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         out = {

@@ -240,14 +240,17 @@ int bcbf_unicycle_step_f64(double* x, const double* u, double dt, double L_true,
  * bcbf_cbc_terms (K = 1+Kob, sign[K]) -> bcbf_socp -> x += g(x; L_true) u dt (skipped when dt <= 0),
  * all on `stream`.  Arguments are those of the individual entry points; grad/cst/fhat/ghat/Mk/Bk/cones/
  * cstatus are caller-provided workspaces that also expose the intermediates; y[Bt,3] = [u, relax].
- * ev_start / ev_stop (optional hipEvent_t) are recorded around the posterior kernel for profiling. */
+ * ev_start / ev_stop (optional hipEvent_t) are recorded around the posterior kernel for profiling.
+ * shared_gp != 0: every instance queries ONE learned model (instance 0 of Lop/Vw/X/UHB/ell/s2/Bm/M0; A stays per
+ * instance) -- Monte-Carlo rollouts of a fixed model; the posterior then runs as bcbf_posterior_query(shared=1),
+ * which for fp32 is the matrix-core kernel. */
 int bcbf_unicycle_control_step_f32(
     const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
     const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
     const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
     float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
     float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
-    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters,
+    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
     void* ev_start, void* ev_stop, void* stream);
 int bcbf_unicycle_control_step_f64(
     const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
@@ -256,7 +259,7 @@ int bcbf_unicycle_control_step_f64(
     const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
     const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
     double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
-    int N, int Kob, int max_iters, void* ev_start, void* ev_stop, void* stream);
+    int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream);
 
 #ifdef __cplusplus
 }

@@ -493,3 +493,39 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b):
     Mk2, Bk2, _ = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, shared=True)
     rel_close(host(Mk2), Mk_o, 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk(query)")
     rel_close(host(Bk2), Bk_o, 1e-3, scale=prior, what="Bk(query)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_control_step_shared_model_equals_replicated_model(ops, dtype):
+    """bcbf_unicycle_control_step with shared_gp=1 (one learned model, Bt closed loops: BASELINE config 4) gives the
+    controls of the per-instance path run on Bt copies of the model, and both equal the composed entry points."""
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+    Bt, N = 100, 128
+    p = make_instances(1, N, 3, 2, dtype=dtype, device=DEV, seed=41)
+    t = make_unicycle_task(Bt, dtype=dtype, device=DEV, seed=42)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    A = (0.01 * p["A"]).contiguous()
+    shared = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=A)
+    rep = {k: v.expand(Bt, *v.shape[1:]).contiguous() for k, v in shared.items()}
+    x1, x2 = t["x"].clone(), t["x"].clone()
+    ws1, ws2 = ops.control_workspace(Bt, 2, dtype, DEV), ops.control_workspace(Bt, 2, dtype, DEV)
+    ops.unicycle_control_step(shared, t, ws1, x1, dt=0.05, L_true=12.0, L_mean=4.0, max_iters=40)
+    ops.unicycle_control_step(rep, t, ws2, x2, dt=0.05, L_true=12.0, L_mean=4.0, max_iters=40)
+    tol = 1e-9 if dtype == torch.float64 else 1e-3
+    prior = float(p["s2"][0]) * float(p["Bm"][0].abs().max())
+    rel_close(host(ws1["Mk"]), host(ws2["Mk"]), tol, scale=max(1.0, float(ws2["Mk"].abs().max())), what="Mk")
+    rel_close(host(ws1["Bk"]), host(ws2["Bk"]), tol, scale=prior, what="Bk")
+    ok = ((ws1["status"] == 0) & (ws2["status"] == 0)).cpu().numpy()
+    assert ok.sum() >= Bt // 2
+    ytol = 1e-6 if dtype == torch.float64 else 5e-3
+    np.testing.assert_allclose(host(ws1["y"])[ok], host(ws2["y"])[ok], rtol=ytol, atol=ytol)
+    np.testing.assert_allclose(host(x1)[ok], host(x2)[ok], rtol=ytol, atol=ytol)
+    # composed path on the same inputs
+    Mk, Bk, _ = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], t["x"], shared=True)
+    grad, cst, fhat, ghat = ops.unicycle_constraints(t["x"], t["plan"], t["dot_plan"], t["Kp"], 10.0, t["centers"],
+                                                     t["radii"], t["tw"], t["gammas"], 4.0)
+    y, st, it, _, _, _ = ops.cbc_socp(Mk, Bk, rep["A"], grad, cst, t["sign"], fhat, ghat, t["w"], t["r"],
+                                      t["relax_mask"], t["rho"], max_iters=40)
+    assert torch.equal(st, ws1["status"])
+    np.testing.assert_allclose(host(y)[ok], host(ws1["y"])[ok], rtol=1e-12, atol=1e-12)
