@@ -329,10 +329,14 @@ int bcbf_refit_f32(const float* X, const float* UH, const float* Bm, const float
     if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
     return bcbf_refit_mfma_f32(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
 }
+extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const double* Bm, const double* ell,
+                                   const double* s2, const double* jitter, const double* Kdense, double* Lop,
+                                   double* UHB, double* Ldense, int* info, int Bt, int N, int n, int m, void* stream);
 int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                    const double* jitter, double* Lop, double* UHB, double* Ldense, int* info,
                    int Bt, int N, int n, int m, void* stream) {
-    return bcbf::launch_refit<double>(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
+    if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+    return bcbf_refit_mfma_f64(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
 }
 int bcbf_potrf_f32(const float* Kb, float* Lop, float* Ldense, int* info, int Bt, int N, void* stream) {
     if (!Kb) return BCBF_EINVAL;
@@ -340,6 +344,6 @@ int bcbf_potrf_f32(const float* Kb, float* Lop, float* Ldense, int* info, int Bt
 }
 int bcbf_potrf_f64(const double* Kb, double* Lop, double* Ldense, int* info, int Bt, int N, void* stream) {
     if (!Kb) return BCBF_EINVAL;
-    return bcbf::launch_refit<double>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Kb, Lop, nullptr, Ldense, info, Bt, N, 0, 0, stream);
+    return bcbf_refit_mfma_f64(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Kb, Lop, nullptr, Ldense, info, Bt, N, 0, 0, stream);
 }
 }

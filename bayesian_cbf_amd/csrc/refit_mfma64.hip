@@ -1,0 +1,320 @@
+// K1 + K2 on the matrix cores, fp64 (BASELINE configs[1]: batched kernel build + Cholesky, N = 256, fp64):
+// the blocked left-looking Cholesky of refit_mfma.hip on v_mfma_f64_16x16x4_f64.
+//
+//   block column J, row tile I (32 rows).  The transposed 32x32 tile  S'[c][i] = K_b(i, 32J+c) - sum_k L_J[c][k] L_I[i][k]
+//   is four 16x16 MFMA tiles (cb, ib); lane (g = lane/16, j = lane%16), register r of tile (cb, ib) holds
+//   c = 16cb + 4r + g, i = 16ib + j  (the fp64 accumulator interleaves rows over the lane groups: probed on gfx950).
+//     update step k..k+3:  A[c][k'] = L[32J+16cb+j][k+g],  B[k'][i] = L[32I+16ib+j][k+g]   (one f64 per lane each, read
+//                          straight from the packed operator: 16 consecutive rows of one column per lane group)
+//     panel  L_IJ' = inv(L_JJ) S':  the accumulator registers are the B operands again -- MFMA (cb, r) contracts over
+//                          c = 16cb + 4r + g, so A[c'][k'=g] = inv(L_JJ)[16cb'+j][16cb+4r+g]  (from LDS)
+//   and the result stores column-major as 128-byte segments.
+// Wave 0 factors and inverts the 32x32 diagonal tile in registers (lane = row, v_readlane broadcasts) while waves 1-3
+// run their update streams.  fp64 MFMA peak on MI355X is 78.6 TFLOP/s = the fp64 vector peak; as in fp32 the gain over
+// the VALU kernel is operand traffic and instruction count.
+#include "bcbf_common.h"
+
+namespace bcbf {
+
+using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+
+#ifndef BCBF_R64_MAXT
+#define BCBF_R64_MAXT 1
+#endif
+#ifndef BCBF_R64_OCC
+#define BCBF_R64_OCC 2
+#endif
+#ifndef BCBF_R64_KS
+#define BCBF_R64_KS 4
+#endif
+constexpr int MT64 = 256;                  // threads
+constexpr int MAXT64 = BCBF_R64_MAXT;      // row tiles a wave processes together (share the A operands)
+
+__device__ inline double rlane64(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// 1/sqrt(p): hardware estimate + two Newton steps (full double precision; a divide per pivot would serialise wave 0)
+__device__ inline double rsqrt_nr(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    y = y * (1.5 - 0.5 * p * y * y);
+    y = y * (1.5 - 0.5 * p * y * y);
+    return y;
+}
+
+template <bool FROM_DENSE>
+__global__ void __launch_bounds__(MT64, BCBF_R64_OCC)
+refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH, const double* __restrict__ Bm,
+                    const double* __restrict__ ell, const double* __restrict__ s2p, const double* __restrict__ jitter,
+                    const double* __restrict__ Kdense, double* __restrict__ Lop, double* __restrict__ UHBout,
+                    double* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C) {
+    constexpr int V = 2;
+    __shared__ double dS[NB][NB + 1];                        // diagonal tile S_JJ (row c, col i)
+    __shared__ double dinv[NB][NB + 1];                      // inv(L_JJ)[c'][c]
+    __shared__ double colX[NB][BCBF_MAX_STATE_DIM];
+    __shared__ double colUH[NB][BCBF_MAX_CTRL_DIM + 1];
+    __shared__ double idg[NB];                               // 1 / L_JJ[c][c]
+    __shared__ int fail;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, j16 = lane & 15, g = lane >> 4;
+    double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const double* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
+    const double* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
+    const double* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
+    double* Ld = Ldense ? Ldense + (size_t)b * N * N : nullptr;
+    double iell[BCBF_MAX_STATE_DIM], Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+    double s2 = 0.0;
+    if (!FROM_DENSE) {
+        s2 = s2p[b];
+#pragma unroll
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) iell[d] = d < n ? 1.0 / ell[(size_t)b * n + d] : 0.0;
+#pragma unroll
+        for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a)
+            Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : 0.0;
+        for (int i = tid; i < N; i += MT64)
+            for (int c = 0; c < C; ++c) {
+                double s = 0.0;
+                for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                UHBout[((size_t)b * N + i) * C + c] = s;
+            }
+    }
+    if (tid == 0) fail = 0;
+    if (Ld)
+        for (int e = tid; e < N * N; e += MT64) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.0; }
+    __syncthreads();
+
+    const int nblk = Np / NB;
+    for (int J = 0; J < nblk; ++J) {
+        const int col0 = J * NB;
+        if (!FROM_DENSE) {
+            for (int e = tid; e < NB * n; e += MT64) {
+                const int c = e / n, d = e - c * n;
+                colX[c][d] = (col0 + c < N) ? Xb[(size_t)(col0 + c) * n + d] : 0.0;
+            }
+            for (int e = tid; e < NB * C; e += MT64) {
+                const int c = e / C, a = e - c * C;
+                colUH[c][a] = (col0 + c < N) ? UHb[(size_t)(col0 + c) * C + a] : 0.0;
+            }
+        }
+        __syncthreads();
+        const int ntile = nblk - J;                          // row tiles I = J .. nblk-1
+        // Tile schedule (as refit_mfma.hip).  Group 0: wave 0 takes ONLY the diagonal tile, then factors and inverts
+        // it while waves 1-3 run the updates of tiles 1 .. 3*MAXT64.  Later groups: round-robin over all four waves.
+        const int first = 1 + 3 * MAXT64;
+        const int ngroups = ntile <= first ? 1 : 1 + (ntile - first + 4 * MAXT64 - 1) / (4 * MAXT64);
+        for (int gq = 0; gq < ngroups; ++gq) {                   // uniform trip count: barrier (B) is inside
+            f64x4 acc[MAXT64][2][2];                             // [slot][cb][ib]
+            int irow[MAXT64], tix[MAXT64];
+            bool live[MAXT64];
+#pragma unroll
+            for (int q = 0; q < MAXT64; ++q) {
+                int t;
+                if (gq == 0) t = wave == 0 ? (q == 0 ? 0 : ntile) : 1 + (wave - 1) + 3 * q;
+                else t = first + (gq - 1) * 4 * MAXT64 + wave + 4 * q;
+                tix[q] = t;
+                live[q] = t < ntile;
+                irow[q] = (live[q] ? (J + t) * NB : col0) + j16;    // + 16*ib; dead slots shadow the diagonal tile (no stores)
+                // ---- initial value: K_b'(c, i) for this lane's two rows and the 8 c's per row of its accumulators
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = irow[q] + 16 * ib;
+                    double xi[BCBF_MAX_STATE_DIM], ub[BCBF_MAX_CTRL_DIM + 1], jit = 0.0;
+                    if (!FROM_DENSE && i < N) {
+#pragma unroll
+                        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) xi[d] = d < n ? Xb[(size_t)i * n + d] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) {
+                            double s = 0.0;
+                            if (c < C) for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                            ub[c] = s;
+                        }
+                        jit = jitter ? jitter[(size_t)b * N + i] : 0.0;
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * cb + 4 * r + g, j = col0 + c;
+                            double val;
+                            if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;          // padding: identity
+                            else if (FROM_DENSE) val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
+                            else {
+                                double d2 = 0.0, uu = 0.0;
+#pragma unroll
+                                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                                    if (d < n) { const double z = (xi[d] - colX[c][d]) * iell[d]; d2 += z * z; }
+#pragma unroll
+                                for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a)
+                                    if (a < C) uu += ub[a] * colUH[c][a];
+#ifdef BCBF_R64_ABL_NOEXP
+                                val = s2 * (1.0 - 0.01 * d2) * uu + (i == j ? jit + 10.0 : 0.0);
+#else
+                                val = s2 * exp(-0.5 * d2) * uu + (i == j ? jit : 0.0);
+#endif
+                            }
+                            acc[q][cb][ib][r] = val;
+                        }
+                }
+            }
+            // ---- S' -= L_J L_I'  over all previous columns: stages of KS k-steps (4 columns each); the next stage's
+            //      operands are in flight while the current stage's MFMAs issue
+            constexpr int KS = BCBF_R64_KS;
+            const int kend = col0;                                            // multiple of 32
+            double a_nxt[KS][2], b_nxt[KS][MAXT64][2];
+            auto fetch = [&](int kk) {
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const int base = lop_base<V>(kk + 4 * s_ + g, Np);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) a_nxt[s_][cb] = lop[base + col0 + 16 * cb + j16];
+#pragma unroll
+                    for (int q = 0; q < MAXT64; ++q)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) b_nxt[s_][q][ib] = lop[base + irow[q] + 16 * ib];
+                }
+            };
+#ifndef BCBF_R64_ABL_NOKLOOP
+            if (kend > 0) fetch(0);
+            for (int kk = 0; kk < kend; kk += 4 * KS) {
+                double a_cur[KS][2], b_cur[KS][MAXT64][2];
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) a_cur[s_][cb] = -a_nxt[s_][cb];        // D = (-A) B + C
+#pragma unroll
+                    for (int q = 0; q < MAXT64; ++q)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) b_cur[s_][q][ib] = b_nxt[s_][q][ib];
+                }
+                if (kk + 4 * KS < kend) fetch(kk + 4 * KS);
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                    for (int q = 0; q < MAXT64; ++q)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib)
+                                acc[q][cb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s_][cb], b_cur[s_][q][ib],
+                                                                                      acc[q][cb][ib], 0, 0, 0);
+            }
+#endif
+            if (gq == 0) {
+                // ---- wave 0: diagonal tile -> LDS -> factor + invert in registers (lane = row); written and read by
+                //      this wave only, so no workgroup barrier: LDS operations of one wave complete in order
+                if (wave == 0) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dS[16 * cb + 4 * r + g][16 * ib + j16] = acc[0][cb][ib][r];
+                    __builtin_amdgcn_wave_barrier();
+                    // Left-looking 32x32 Cholesky and triangular inverse with lane = row (resp. column), entirely out of
+                    // LDS with rolled loops: a register formulation (row[32], x[32] doubles, v_readlane broadcasts) costs
+                    // 128+ VGPRs, which caps the kernel at one workgroup per CU, and is no faster.  S is symmetric, so
+                    // row c of S' is column c of S; it is overwritten by column c of L as soon as it has been consumed.
+                    const int ln = lane & (NB - 1), lh = lane >> 5;
+                    int bad = 0;
+#ifndef BCBF_R64_ABL_NOFACTOR
+                    for (int c = 0; c < NB; ++c) {
+                        double v = lh ? 0.0 : dS[c][ln];                                  // S[lane][c]
+#pragma unroll 4
+                        for (int k = lh; k < c; k += 2) v -= dS[k][ln] * dS[k][c];        // L[lane][k] L[c][k]: even k in the
+                        v += __shfl_xor(v, 32, 64);                                       // low half of the wave, odd k in the high
+                        const double piv = rlane64(v, c);
+                        if (!(piv > 0.0) && bad == 0) bad = col0 + c + 1;
+                        const double inv = rsqrt_nr(piv > 0.0 ? piv : 1.0);
+                        if (lane < NB) dS[c][lane] = lane == c ? piv * inv : (lane > c ? v * inv : 0.0);   // L[lane][c]
+                        if (lane == c) idg[c] = inv;
+                    }
+                    if (Ld && lane < NB && col0 + lane < N) {
+                        for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dS[c][lane];
+                    }
+                    {
+                        const int base = lop_base<V>(col0 + ln, Np);                     // whole block column stored
+                        for (int i = 0; i < NB; ++i) {
+                            double s_ = (ln == i && !lh) ? 1.0 : 0.0;
+#pragma unroll 4
+                            for (int k = lh; k < i; k += 2) s_ -= dS[k][i] * dinv[k][ln]; // L[i][k] X[k][lane]
+                            s_ += __shfl_xor(s_, 32, 64);
+                            const double xi = s_ * idg[i];
+                            if (lane < NB) { dinv[i][lane] = xi; lop[base + col0 + i] = xi; }
+                        }
+                    }
+#else
+                    if (lane < NB) {
+                        const int base = lop_base<V>(col0 + lane, Np);
+                        for (int i = 0; i < NB; ++i) { const double xi = lane == i ? 1.0 : 1e-6 * dS[i][lane]; dinv[i][lane] = xi; lop[base + col0 + i] = xi; }
+                    }
+#endif
+                    if (lane == 0 && bad != 0 && bad <= N) fail = bad;
+                }
+                __syncthreads();          // (B) inv(L_JJ) visible
+            }
+            if (fail == 0) {
+                // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of S' are the B operands)
+                double ainv[2][2][4];                             // [cb'][cb][r]; inv(L_JJ) is lower triangular: (0,1) = 0
+#pragma unroll
+                for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                    for (int cb = 0; cb <= cbp; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = dinv[16 * cbp + j16][16 * cb + 4 * r + g];
+#pragma unroll
+                for (int q = 0; q < MAXT64; ++q) {
+                    const bool is_diag = tix[q] == 0;
+                    if (!live[q] || is_diag) continue;
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        const int i = irow[q] + 16 * ib;
+#pragma unroll
+                        for (int cbp = 0; cbp < 2; ++cbp) {
+                            f64x4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int cb = 0; cb <= cbp; ++cb)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    y = __builtin_amdgcn_mfma_f64_16x16x4f64(ainv[cbp][cb][r], acc[q][cb][ib][r], y, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 16 * cbp + 4 * r + g;
+                                lop[lop_base<V>(col0 + c, Np) + i] = y[r];
+                                if (Ld && i < N && col0 + c < N) Ld[(size_t)i * N + col0 + c] = y[r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (fail != 0) break;
+    }
+    if (tid == 0) info[b] = fail;
+}
+
+}  // namespace bcbf
+
+extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const double* Bm, const double* ell,
+                                   const double* s2, const double* jitter, const double* Kdense, double* Lop,
+                                   double* UHB, double* Ldense, int* info, int Bt, int N, int n, int m, void* stream) {
+    using namespace bcbf;
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !info || N < 1) return BCBF_EINVAL;
+    const int Np = round_up(N, NB);
+    hipStream_t st = (hipStream_t)stream;
+    if (Kdense) {
+        hipLaunchKernelGGL((refit_mfma64_kernel<true>), dim3(Bt), dim3(MT64), 0, st, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
+    } else {
+        if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+        hipLaunchKernelGGL((refit_mfma64_kernel<false>), dim3(Bt), dim3(MT64), 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
+                           Lop, UHB, Ldense, info, N, Np, n, m + 1);
+    }
+    return check_launch("refit_mfma64");
+}

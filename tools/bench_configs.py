@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Timings of the non-headline BASELINE configs on one GPU (development / DESIGN.md numbers).
+C2: batched kernel build + Cholesky + posterior, N=256, n=2, m=1, batch 1024, fp64.
+C3 pieces in fp64.  C5: growing N with chol_append."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bayesian_cbf_amd import ops
+from bayesian_cbf_amd.synthetic import make_instances
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def config(Bt, N, n, m, dtype, name):
+    p = make_instances(Bt, N, n, m, dtype=dtype, device="cuda", seed=5)
+    isz = p["X"].element_size()
+    out = {"config": name, "batch": Bt, "N": N, "n": n, "m": m, "dtype": str(dtype)}
+    t = timeit(lambda: ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"]))
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert int((info != 0).sum()) == 0
+    flops = Bt * (N ** 3 / 3.0)
+    out["refit_ms"] = t
+    out["refit_TFLOPs"] = flops / (t * 1e-3) / 1e12
+    out["refit_write_GBs"] = Bt * ops.lop_elems(N, dtype) * isz / (t * 1e-3) / 1e9
+    t = timeit(lambda: ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False))
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    out["potrs_ms"] = t
+    t = timeit(lambda: ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"]), reps=20)
+    by = Bt * isz * (N * (N + 1) // 2 + 2 * N * n + N * (1 + m))
+    out["posterior_ms"] = t
+    out["posterior_GBs_algorithmic"] = by / (t * 1e-3) / 1e9
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    config(1024, 256, 2, 1, torch.float64, "C2")
+    config(4096, 512, 3, 2, torch.float64, "C3 in fp64")
+    config(4096, 512, 3, 2, torch.float32, "C3")
+    config(1024, 1024, 3, 2, torch.float64, "N=1024 fp64")
