@@ -27,8 +27,11 @@ __device__ inline float rlane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+#ifndef BCBF_R32_OCC
+#define BCBF_R32_OCC 4
+#endif
 template <bool FROM_DENSE>
-__global__ void __launch_bounds__(MT, 2)
+__global__ void __launch_bounds__(MT, BCBF_R32_OCC)
 refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, const float* __restrict__ Bm,
                   const float* __restrict__ ell, const float* __restrict__ s2p, const float* __restrict__ jitter,
                   const float* __restrict__ Kdense, float* __restrict__ Lop, float* __restrict__ UHBout,
@@ -38,6 +41,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
     __shared__ float dinv[NB][NB + 1];                       // inv(L_JJ)[c][c']
     __shared__ float colX[NB][BCBF_MAX_STATE_DIM];
     __shared__ float colUH[NB][BCBF_MAX_CTRL_DIM + 1];
+    __shared__ float idg[NB];                                // 1 / L_JJ[c][c]
     __shared__ int fail;
 
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -168,53 +172,48 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
 #endif
             // ---- diagonal tile -> LDS (tile I == J is slot q = 0 of wave 0, first group)
             if (g == 0) {
-            // ---- wave 0: diagonal tile -> LDS -> factor + invert in registers (lane = row); written and read by
-            //      this wave only, so no workgroup barrier: LDS operations of one wave complete in order
+            // ---- wave 0: diagonal tile -> LDS -> factor + invert there; written and read by this wave only, so no
+            //      workgroup barrier: LDS operations of one wave complete in order
             if (wave == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dS[acc_row(r, lh)][li] = acc[0][r];
                 __builtin_amdgcn_wave_barrier();
-                float row[NB];
-#pragma unroll
-                for (int c = 0; c < NB; ++c) row[c] = lane < NB ? dS[c][lane] : 0.f;      // S symmetric: S[lane][c] = S'[c][lane]
+                // Left-looking 32x32 Cholesky and triangular inverse out of LDS with rolled loops (lane = row resp. column,
+                // even k in the low half of the wave, odd k in the high half): see refit_mfma64.hip.
+                const int ln = lane & (NB - 1), lhh = lane >> 5;
                 int bad = 0;
-                float idiag[NB];           // 1 / L[c][c] (wave-uniform values)
-#ifndef BCBF_ABL_SKIP_FACTOR
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    const float piv = rlane(row[c], c);
-                    if (!(piv > 0.f) && bad == 0) bad = col0 + c + 1;
-                    const float inv = __builtin_amdgcn_rsqf(piv > 0.f ? piv : 1.f), lcc = piv * inv;   // 1-ulp rsq
-                    idiag[c] = inv;
-                    row[c] = lane == c ? lcc : (lane > c ? row[c] * inv : 0.f);
-#pragma unroll
-                    for (int c2 = c + 1; c2 < NB; ++c2) row[c2] -= row[c] * rlane(row[c], c2);
-                }
-                float x[NB];
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    float s = lane == i ? 1.f : 0.f;
-#pragma unroll
-                    for (int k = 0; k < i; ++k) s -= rlane(row[k], i) * x[k];
-                    x[i] = s * idiag[i];
+#if defined(BCBF_ABL_SKIP_FACTOR)
+                if (lane < NB) {
+                    const int base = lop_base<V>(col0 + lane, Np);
+                    for (int i = 0; i < NB; ++i) { const float xi = lane == i ? 1.f : 1e-6f * dS[i][lane]; dinv[i][lane] = xi; lop[base + col0 + i] = xi; }
                 }
 #else
-                float x[NB];
-#pragma unroll
-                for (int i = 0; i < NB; ++i) x[i] = lane == i ? 1.f : row[i] * 1e-6f;
-#endif
-                if (lane < NB) {
-                    const int j = col0 + lane, base = lop_base<V>(j, Np), first = 0;   // whole block column stored
-#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    float v = lhh ? 0.f : dS[c][ln];                                      // S[lane][c]
+#pragma unroll 4
+                    for (int k = lhh; k < c; k += 2) v -= dS[k][ln] * dS[k][c];           // L[lane][k] L[c][k]
+                    v += __shfl_xor(v, 32, 64);
+                    const float piv = rlane(v, c);
+                    if (!(piv > 0.f) && bad == 0) bad = col0 + c + 1;
+                    const float inv = __builtin_amdgcn_rsqf(piv > 0.f ? piv : 1.f);      // 1-ulp rsq
+                    if (lane < NB) dS[c][lane] = lane == c ? piv * inv : (lane > c ? v * inv : 0.f);   // L[lane][c]
+                    if (lane == c) idg[c] = inv;
+                }
+                if (Ld && lane < NB && col0 + lane < N) {
+                    for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dS[c][lane];
+                }
+                {
+                    const int base = lop_base<V>(col0 + ln, Np);                         // whole block column stored
                     for (int i = 0; i < NB; ++i) {
-                        dinv[i][lane] = x[i];
-                        if (i >= first) lop[base + col0 + i] = x[i];
-                    }
-                    if (Ld && j < N) {
-#pragma unroll
-                        for (int c = 0; c < NB; ++c) if (c <= lane && col0 + c < N) Ld[(size_t)j * N + col0 + c] = row[c];
+                        float s_ = (ln == i && !lhh) ? 1.f : 0.f;
+#pragma unroll 4
+                        for (int k = lhh; k < i; k += 2) s_ -= dS[k][i] * dinv[k][ln];    // L[i][k] X[k][lane]
+                        s_ += __shfl_xor(s_, 32, 64);
+                        const float xi = s_ * idg[i];
+                        if (lane < NB) { dinv[i][lane] = xi; lop[base + col0 + i] = xi; }
                     }
                 }
+#endif
                 if (lane == 0 && bad != 0 && bad <= N) fail = bad;
             }
             __syncthreads();          // (B) inv(L_JJ) visible

@@ -4,8 +4,8 @@ import ctypes, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
-VARIANTS = {"full": [], "nofactor": ["-DBCBF_ABL_SKIP_FACTOR"], "nokloop": ["-DBCBF_ABL_SKIP_KLOOP"],
-            "neither": ["-DBCBF_ABL_SKIP_FACTOR", "-DBCBF_ABL_SKIP_KLOOP"]}
+VARIANTS = {"full": [], "lds": ["-DBCBF_R32_LDS_FACTOR"], "lds_o3": ["-DBCBF_R32_LDS_FACTOR", "-DBCBF_R32_OCC=3"],
+            "lds_o4": ["-DBCBF_R32_LDS_FACTOR", "-DBCBF_R32_OCC=4"], "nofactor": ["-DBCBF_ABL_SKIP_FACTOR"]}
 def build():
     os.makedirs(VDIR, exist_ok=True)
     ps = []
