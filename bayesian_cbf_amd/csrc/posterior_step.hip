@@ -66,7 +66,7 @@ template <> struct BufLoad<double> {
 // right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] (CT = C (1+n) columns of the same stream); outputs the full
 // Gram Wj'Wj [CT,CT] and Vw'Wj [n,CT], from which the rel-degree-2 terms are formed.
 template <typename T, int C, int NS, int NJ>
-__global__ void __launch_bounds__(256, (NJ > 0 ? 1 : BCBF_PS_WAVES))
+__global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256), (NJ > 0 ? 1 : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
@@ -318,7 +318,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     const int Np = round_up(N, NB);
     const int npairs = Np / V / 2;
     const int threads = round_up(npairs, 64);
-    if (threads > 256) return BCBF_EINVAL;   // N <= 2048 (f32) / 1024 (f64)
+    if (threads > (sizeof(T) == 8 && Gfull == nullptr ? 512 : 256)) return BCBF_EINVAL;   // N <= 2048 (fp64 jets: 1024)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
 #define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n)

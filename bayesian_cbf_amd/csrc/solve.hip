@@ -179,10 +179,20 @@ static int launch_potrs(const T* Lop, const T* Xdot, const T* UH, const T* M0, T
 // The new row lands in diagonal block J* = N/32: its inverse gains the row
 // [-(1/d) l_J*' inv(L_J*J*), 1/d]; every other stored element is copied (re-laid out when the
 // padded size grows by a block).
+// FUSED (bcbf_gp_append): the whole online update of one observation (x, uh, xdot) per instance -- the new kernel
+// column k(X, x) o (UH B uh) and its diagonal are formed here instead of being read, and the whitened-target row
+// Vw[N] = (y - l' Vw) / d and the new rows of X / UH B are appended to the (re-packed) per-refit arrays.
 template <typename T>
+struct AppendFused {
+    const T *Vw_in, *X_in, *UHB_in, *ell, *s2, *Bm, *M0, *x_new, *uh_new, *xdot_new, *jitter_new;
+    T *Vw_out, *X_out, *UHB_out;
+    int n, C;
+};
+
+template <typename T, bool FUSED>
 __global__ void __launch_bounds__(ST)
 chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const T* __restrict__ kappa,
-                   T* __restrict__ Lout, int* __restrict__ info, int N, int NpI, int NpO) {
+                   T* __restrict__ Lout, int* __restrict__ info, int N, int NpI, int NpO, AppendFused<T> f) {
     constexpr int V = Vec<T>::V;
     __shared__ T rbuf[NB];
     __shared__ T wbuf[NB];
@@ -196,10 +206,48 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
 
     // ---- forward solve l = L^-1 knew on the old operator
     T y[SMAXR];
+    T kap = T(0);
+    if (FUSED) {
+        const int n = f.n, C = f.C;
+        T xn[BCBF_MAX_STATE_DIM], ie[BCBF_MAX_STATE_DIM];
+        const T s2v = f.s2[b];
 #pragma unroll
-    for (int r = 0; r < SMAXR; ++r) {
-        const int i = tid + r * ST;
-        y[r] = (r < rpt && i < N) ? knew[(size_t)b * N + i] : T(0);
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+            xn[d] = d < n ? f.x_new[(size_t)b * n + d] : T(0);
+            ie[d] = d < n ? T(1) / f.ell[(size_t)b * n + d] : T(0);
+        }
+        T q = T(0);
+#pragma unroll
+        for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) {
+            T sacc = T(0);
+            if (c < C) for (int a = 0; a < C; ++a) sacc += f.Bm[((size_t)b * C + c) * C + a] * f.uh_new[(size_t)b * C + a];
+            if (c < C) q += f.uh_new[(size_t)b * C + c] * sacc;
+        }
+        kap = s2v * q + (f.jitter_new ? f.jitter_new[b] : T(0));
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            T v = T(0);
+            if (r < rpt && i < N) {
+                T d2 = T(0), uu = T(0);
+#pragma unroll
+                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                    if (d < n) { const T z = (f.X_in[((size_t)b * N + i) * n + d] - xn[d]) * ie[d]; d2 += z * z; }
+                // UHB_i . uh_new  (Bm symmetric: (UH_i Bm) uh = UH_i (Bm uh))
+#pragma unroll
+                for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
+                    if (c < C) uu += f.UHB_in[((size_t)b * N + i) * C + c] * f.uh_new[(size_t)b * C + c];
+                v = s2v * (T)exp((double)(T(-0.5) * d2)) * uu;
+            }
+            y[r] = v;
+        }
+    } else {
+        kap = kappa[b];
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            y[r] = (r < rpt && i < N) ? knew[(size_t)b * N + i] : T(0);
+        }
     }
     for (int J = 0; J < nblk; ++J) {
         const int col0 = J * NB;
@@ -232,7 +280,7 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
     for (int c = 0; c < SC; ++c) ss[c] = T(0);
     for (int i = tid; i < N; i += ST) ss[0] += lrow[i] * lrow[i];
     block_sum(ss, 1, scratch);
-    const T d2 = kappa[b] - ss[0];
+    const T d2 = kap - ss[0];
     const bool ok = d2 > T(0);
     const T d = ok ? (T)sqrt((double)d2) : T(1);
     if (tid == 0) info[b] = ok ? 0 : N + 1;
@@ -266,6 +314,37 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
         }
         lout[lop_base<V>(col0 + jj, NpO) + N] = val;
     }
+    if (FUSED) {
+        const int n = f.n, C = f.C;
+        // Vw[N] = (y - l' Vw) / d,  y = xdot_new - M0' uh_new
+        T vs[SC];
+#pragma unroll
+        for (int c = 0; c < SC; ++c) vs[c] = T(0);
+        for (int i = tid; i < N; i += ST) {
+            const T li = lrow[i];
+#pragma unroll
+            for (int c = 0; c < SC; ++c) if (c < n) vs[c] += li * f.Vw_in[((size_t)b * N + i) * n + c];
+        }
+        block_sum(vs, n, scratch);
+        const size_t N1 = (size_t)N + 1;
+        if (tid < n) {
+            T yv = f.xdot_new[(size_t)b * n + tid];
+            for (int a = 0; a < C; ++a) yv -= f.uh_new[(size_t)b * C + a] * f.M0[((size_t)b * C + a) * n + tid];
+            f.Vw_out[((size_t)b * N1 + N) * n + tid] = (yv - vs[tid]) / d;
+            f.X_out[((size_t)b * N1 + N) * n + tid] = f.x_new[(size_t)b * n + tid];
+        }
+        if (tid < C) {
+            T sacc = T(0);
+            for (int a = 0; a < C; ++a) sacc += f.uh_new[(size_t)b * C + a] * f.Bm[((size_t)b * C + a) * C + tid];
+            f.UHB_out[((size_t)b * N1 + N) * C + tid] = sacc;
+        }
+        // re-pack the per-refit arrays (batch stride N -> N+1)
+        for (int e = tid; e < N * n; e += ST) {
+            f.Vw_out[(size_t)b * N1 * n + e] = f.Vw_in[(size_t)b * N * n + e];
+            f.X_out[(size_t)b * N1 * n + e] = f.X_in[(size_t)b * N * n + e];
+        }
+        for (int e = tid; e < N * C; e += ST) f.UHB_out[(size_t)b * N1 * C + e] = f.UHB_in[(size_t)b * N * C + e];
+    }
 }
 
 template <typename T>
@@ -276,9 +355,30 @@ static int launch_chol_append(const T* Lin, const T* knew, const T* kappa, T* Lo
     const int NpI = round_up(N, NB), NpO = round_up(N + 1, NB);
     if (NpO > ST * SMAXR) return BCBF_EINVAL;
     if (Lin == Lout && NpI != NpO) return BCBF_EINVAL;
-    hipLaunchKernelGGL((chol_append_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, knew, kappa, Lout,
-                       info, N, NpI, NpO);
+    hipLaunchKernelGGL((chol_append_kernel<T, false>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, knew, kappa,
+                       Lout, info, N, NpI, NpO, AppendFused<T>{});
     return check_launch("chol_append");
+}
+
+template <typename T>
+static int launch_gp_append(const T* Lin, const T* Vw_in, const T* X_in, const T* UHB_in, const T* ell, const T* s2,
+                            const T* Bm, const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,
+                            const T* jitter_new, T* Lout, T* Vw_out, T* X_out, T* UHB_out, int* info, int Bt, int N,
+                            int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lin || !Vw_in || !X_in || !UHB_in || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !Lout ||
+        !Vw_out || !X_out || !UHB_out || !info || N < 1)
+        return BCBF_EINVAL;
+    if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    if (Vw_out == Vw_in || X_out == X_in || UHB_out == UHB_in) return BCBF_EINVAL;     // batch stride changes
+    const int NpI = round_up(N, NB), NpO = round_up(N + 1, NB);
+    if (NpO > ST * SMAXR) return BCBF_EINVAL;
+    if (Lin == Lout && NpI != NpO) return BCBF_EINVAL;
+    AppendFused<T> f{Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, Vw_out, X_out, UHB_out,
+                     n, m + 1};
+    hipLaunchKernelGGL((chol_append_kernel<T, true>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, nullptr, nullptr,
+                       Lout, info, N, NpI, NpO, f);
+    return check_launch("gp_append");
 }
 
 }  // namespace bcbf
@@ -291,6 +391,21 @@ int bcbf_potrs_f32(const float* Lop, const float* Xdot, const float* UH, const f
 int bcbf_potrs_f64(const double* Lop, const double* Xdot, const double* UH, const double* M0,
                    double* Vw, double* alpha, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_potrs<double>(Lop, Xdot, UH, M0, Vw, alpha, Bt, N, n, m, stream);
+}
+int bcbf_gp_append_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                       const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                       const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                       float* Vw_out, float* X_out, float* UHB_out, int* info, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_gp_append<float>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                         jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream);
+}
+int bcbf_gp_append_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                       const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                       const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                       double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
+                       void* stream) {
+    return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                          jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream);
 }
 int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
                          int* info, int Bt, int N, void* stream) {

@@ -102,6 +102,25 @@ def chol_append(Lop, knew, kappa, N):
     return out, info
 
 
+def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new=None):
+    """Online update: one observation per instance enters the GP without refactorisation.
+    Returns (Lop', Vw'[Bt,N+1,n], X'[Bt,N+1,n], UHB'[Bt,N+1,C], info).  The operator is updated in place
+    (the returned Lop' IS Lop) while N+1 stays inside the same 32-row padding, re-packed otherwise."""
+    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new)
+    Bt, N, n = X.shape
+    C = UHB.shape[2]
+    f = dict(dtype=X.dtype, device=X.device)
+    same_pad = (N + 31) // 32 == (N + 32) // 32
+    Lout = Lop if same_pad else torch.empty(Bt, lop_elems(N + 1, X.dtype), **f)
+    Vw2, X2, UHB2 = torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, C, **f)
+    info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+    check(getattr(lib, "bcbf_gp_append" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0),
+                                                   _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(Lout),
+                                                   _p(Vw2), _p(X2), _p(UHB2), _p(info), Bt, N, n, C - 1, _stream(X)),
+          "bcbf_gp_append")
+    return Lout, Vw2, X2, UHB2, info
+
+
 def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None):
     """(Mk[Bt,n,C], Bk[Bt,C,C]) at one query per instance  (control_affine_model.py:1051-1091, b=1)."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)

@@ -87,3 +87,60 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     stats = reduce_rollout_stats(collided.sum(), min_h.min(), cost.sum() / numSteps, (fails > 0).sum(), Bt)
     dist_to_goal = (x[:, :2] - xg[:2]).norm(dim=1)
     return dict(stats=stats, x_final=x, min_h=min_h, dist_to_goal=dist_to_goal, traj=traj)
+
+
+def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True):
+    """BASELINE configs[4]: every instance starts from an N0-point GP and takes one observation per control step
+    until it holds N1 points; each observation enters through `ops.gp_append` (bordered Cholesky on the packed
+    operator, whitened targets and per-refit arrays updated in the same launch) -- the reference refits from scratch
+    every `train_every_n_steps` (unicycle_move_to_pose.py:340-386).  Returns per-octave timings (HIP events) and the
+    deviation of the final posterior from a from-scratch refit of all N1 points."""
+    from .synthetic import make_instances, make_unicycle_task
+    dev = torch.device(device)
+    n, m = 3, 2
+    p = make_instances(Bt, N1, n, m, dtype=dtype, device=dev, seed=seed)
+    task = make_unicycle_task(Bt, dtype=dtype, device=dev, seed=seed + 1)
+    cut = lambda t, N: t[:, :N].contiguous()
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], N0), cut(p["UH"], N0), p["Bm"], p["ell"], p["s2"], cut(p["jitter"], N0))
+    assert int((info != 0).sum()) == 0
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N0), cut(p["UH"], N0), p["M0"], want_alpha=False)
+    X = cut(p["X"], N0)
+    A = (0.01 * p["A"]).contiguous()
+    ws = ops.control_workspace(Bt, 2, dtype, dev)
+    x = task["x"].clone()
+    # pre-slice the observation stream (contiguous [N1][Bt,.]) so the timed loop holds only the path's own launches
+    obs = [t.transpose(0, 1).contiguous() for t in (p["X"], p["UH"], p["Xdot"], p["jitter"])]
+    edges = sorted({N0, N1} | {k for k in (256, 512, 1024, 2048) if N0 < k < N1})
+    segs, fails = [], 0
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_step = t_app = 0.0
+        torch.cuda.synchronize()
+        for N in range(lo, hi):
+            e[0].record()
+            if with_control:
+                gp = dict(Lop=Lop, Vw=Vw, X=X, UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=A)
+                ops.unicycle_control_step(gp, task, ws, x, dt=0.0, L_mean=4.0, max_iters=20)
+            e[1].record()
+            Lop, Vw, X, UHB, info = ops.gp_append(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], obs[0][N],
+                                                  obs[1][N], obs[2][N], obs[3][N])
+            e[2].record()
+            torch.cuda.synchronize()
+            t_step += e[0].elapsed_time(e[1])
+            t_app += e[1].elapsed_time(e[2])
+            fails += int((info != 0).sum())
+        k = hi - lo
+        isz = X.element_size()
+        segs.append(dict(N_from=lo, N_to=hi, control_step_ms=t_step / k, append_ms=t_app / k,
+                         append_GBs_algorithmic=Bt * isz * ((lo + hi) / 2) ** 2 / 2 / (t_app / k * 1e-3) / 1e9))
+    out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype), segments=segs, append_failures=fails)
+    if check:
+        Lr, UHBr, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+        Vr, _ = ops.potrs(Lr, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+        Mk, Bk = ops.posterior_step(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+        Mr, Br = ops.posterior_step(Lr, Vr, p["X"], UHBr, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+        prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+        out["refit_failures"] = int((info != 0).sum())
+        out["final_vs_refit"] = dict(Mk=float((Mk - Mr).abs().max() / max(1.0, float(Mr.abs().max()))),
+                                     Bk=float((Bk - Br).abs().max() / prior))
+    return out

@@ -106,6 +106,23 @@ int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* ka
 int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double* kappa, double* Lop_out,
                          int* info, int Bt, int N, void* stream);
 
+/* Online update (BASELINE configs[4]): one observation (x_new[Bt,n], uh_new[Bt,1+m] = [1,u],
+ * xdot_new[Bt,n]) per instance enters the GP without refactorisation -- the kernel column k(X,x) o (UH B uh) and
+ * its diagonal (+ jitter_new[Bt], may be NULL) are formed in the kernel, the packed operator gains the row
+ * (bcbf_chol_append), Vw gains (y - l'Vw)/d with y = xdot_new - M0'uh_new, X and UH*B gain their rows.
+ * Inputs hold N points ([Bt,N,.]), outputs N+1 ([Bt,N+1,.], distinct buffers: the batch stride changes);
+ * Lop_out may alias Lop_in while N+1 stays inside the same 32-row padding.  Equals bcbf_refit + bcbf_potrs on the
+ * N+1 points (the reference refits from scratch: unicycle_move_to_pose.py:340-386, control_affine_model.py:268-335). */
+int bcbf_gp_append_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                       const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                       const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                       float* Vw_out, float* X_out, float* UHB_out, int* info, int Bt, int N, int n, int m, void* stream);
+int bcbf_gp_append_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                       const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                       const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                       double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
+                       void* stream);
+
 /* K4+K5+K6+K7: one posterior query per instance (the HBM-bound hot kernel).
  *   Phi = diag(k(X, xq)) UHB;  W = L^-1 Phi;  Mk = M0' + Vw' W;  Bk = s2*Bm - W'W (+ diag(jitter2))
  * Replaces ControlAffineRegressorExact._custom_predict_matrix with b = 1
