@@ -29,8 +29,8 @@ def reldeg1_quadratic_terms(Mk, Bk, A, grad, cst, sign, fhat, ghat):
     return (bfe, e), (V, bfv, v)
 
 
-def cbc2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
-    """Rel-degree-2 counterpart of the reference call
+def reldeg2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
+    """Closed form of the reference call
         cbc2_quadratic_terms(lambda u: cbc2_gp(h, grad_h, regressor, u, k_alpha), x, u0)   (cbc2.py:7-33)
     for a `ControlAffineRegressor` façade object.  `hess_h(x)` replaces the autograd pass through
     `grad_h` that GradientGP performs (gp_algebra.py:340-345).  x[n] or [b,n], u0[m] or [b,m].
@@ -55,3 +55,74 @@ def cbc2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
     if single:
         return (mA[0], mb[0]), (Q[0], p[0], r[0]), mean[0], var[0]
     return (mA, mb), (Q, p, r), mean, var
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference's own call shapes (cbc2.py:7-66, cbc1.py:17-52).  The reference builds a GP expression tree
+# (`grad_h.t() @ f_gp`, GradientGP, ...) and differentiates it with autograd; here `cbc2_gp` / `RelDeg*Safety.cbc`
+# return a light handle that remembers (h, grad_h, model, u, k_alpha) and evaluates through the closed-form kernels.
+def _hessian_of(grad_h, x):
+    """d grad_h / dx by autograd on the user's deterministic task function (n <= 8): what GradientGP obtains by
+    differentiating through grad_h (gp_algebra.py:340-345)."""
+    xr = x.detach().clone().requires_grad_(True)
+    return torch.autograd.functional.jacobian(lambda z: torch.as_tensor(grad_h(z), dtype=z.dtype, device=z.device), xr)
+
+
+class CBCExpr:
+    """Value of `cbc(u)`: a scalar GP in x for the fixed control u, with the reference's `.mean(x)` / `.knl(x, x)`."""
+
+    def __init__(self, rel_degree, h, grad_h, model, u, k_alpha=None, gamma=None, hess_h=None):
+        self.rel_degree, self.h, self.grad_h, self.model, self.u = rel_degree, h, grad_h, model, u
+        self.k_alpha, self.gamma, self.hess_h = k_alpha, gamma, hess_h
+
+    def quadratic_terms(self, x, u0):
+        if self.rel_degree == 2:
+            hess = self.hess_h if self.hess_h is not None else (lambda z: _hessian_of(self.grad_h, z))
+            return reldeg2_quadratic_terms(self.model, self.h, self.grad_h, hess, x, u0, self.k_alpha)
+        reg = self.model
+        xb = reg._ensure_device_dtype(x.reshape(1, -1)).contiguous()
+        st, Mk, Bk, _ = reg._query(xb, want_W=False)
+        f = dict(dtype=xb.dtype, device=xb.device)
+        n, m = reg.x_dim, reg.u_dim
+        grad = torch.as_tensor(self.grad_h(xb[0]), **f).reshape(1, 1, n).contiguous()
+        cst = (self.gamma * torch.as_tensor(self.h(xb[0]), **f)).reshape(1, 1).contiguous()
+        (bfe, e), (V, bfv, v) = reldeg1_quadratic_terms(Mk, Bk, st["A"], grad, cst, torch.ones(1, **f),
+                                                        torch.zeros(1, n, **f), torch.zeros(1, n, m, **f))
+        u = reg._ensure_device_dtype(u0.reshape(-1))
+        mA, mb, Q, p, r = bfe[0, 0], e[0, 0], V[0, 0], bfv[0, 0], v[0, 0]
+        return (mA, mb), (Q, p, r), mA @ u + mb, u @ Q @ u + p @ u + r
+
+    def mean(self, x):
+        return self.quadratic_terms(x, self.u)[2]
+
+    def knl(self, x, xp):
+        if xp is not x and not torch.equal(x, xp):
+            raise NotImplementedError("cross-covariance of a constraint between two states is not on the hot path")
+        return self.quadratic_terms(x, self.u)[3]
+
+
+def cbc2_gp(h, grad_h, learned_model, utest, k_alpha, hess_h=None):
+    """cbc2.py:26-33: L_f^2 h + k_alpha[0] h + k_alpha[1] L_f h as a GP in x for the control `utest`."""
+    return CBCExpr(2, h, grad_h, learned_model, utest, k_alpha=k_alpha, hess_h=hess_h)
+
+
+def cbc2_quadratic_terms(cbc2, x, u, *more):
+    """cbc2.py:7-23 -- `cbc2` is the reference's callable `u -> GP` (e.g. `safety.cbc`); returns
+    ((mean_A, mean_b), (k_Q, k_p, k_r), mean(u), var(u)).  (The explicit closed-form signature
+    `(regressor, h, grad_h, hess_h, x, u0, k_alpha)` is `reldeg2_quadratic_terms`; it is still accepted here.)"""
+    if more:
+        return reldeg2_quadratic_terms(cbc2, x, u, *more)
+    expr = cbc2(u)
+    if not isinstance(expr, CBCExpr):
+        raise TypeError("cbc2(u) must come from cbc2_gp / RelDeg1Safety.cbc / RelDeg2Safety.cbc of this package")
+    return expr.quadratic_terms(x, u)
+
+
+class RelDeg2Safety:
+    """cbc2.py:42-66: subclasses provide k_alpha, model, max_unsafe_prob, cbf(x), grad_cbf(x)."""
+
+    def cbc(self, u0):
+        return cbc2_gp(self.cbf, self.grad_cbf, self.model, u0, self.k_alpha, hess_h=getattr(self, "hess_cbf", None))
+
+    def safety_factor(self):
+        return cbc2_safety_factor(self.max_unsafe_prob)

@@ -161,3 +161,55 @@ class ControllerCLFBayesian:
             u = torch.where(bad[:, None], task["r"], u)
         self.last_status = ws["status"]
         return u.to(dtype=x_torch.dtype)
+
+
+class ControllerCLF(ControllerCLFBayesian):
+    """unicycle_move_to_pose.py:703-791: the mean-only CLF-CBF quadratic program (also the data-generating
+    controller of the reference's speed tests, :2075-2080)
+        min |u|^2 + clf_relax_weight * relax
+        s.t. ctrl_min <= u <= ctrl_max,   a_clc'u + b_clc - relax <= 0,   a_k'u + b_k >= 0  (one per obstacle)
+    with a = grad' g(x), b = grad' f(x) + const from the same task-function kernel as the Bayesian controller.
+    Batched over independent states; solved by the generic cone-QP kernel (`bcbf_coneqp_f64`).
+    NB the reference's constructor ignores its clf_gamma / clf_relax_weight arguments (:720-721: 10 and 10)."""
+
+    def __init__(self, planner, u_dim=2, coordinate_converter=None, dynamics=None, clf=None, clf_gamma=10.0,
+                 clf_relax_weight=10.0, cbfs=(), cbf_gammas=(), visualizer=None, device="cuda", dtype=torch.float64,
+                 **kw):
+        super().__init__(planner, u_dim=u_dim, dynamics=None, clf=clf, clf_gamma=10.0, cbfs=cbfs,
+                         cbf_gammas=cbf_gammas, mean_dynamics=dynamics if isinstance(dynamics, AckermannDrive) else None,
+                         device=device, dtype=dtype, **kw)
+        self.clf_relax_weight = 10.0
+
+    def control(self, x_torch, t):
+        single = x_torch.dim() == 1
+        f64 = dict(dtype=torch.float64, device=self.device)
+        x = x_torch.reshape(-1, 3).to(**f64).contiguous()
+        Bt, Kob = x.shape[0], len(self.cbfs)
+        dtype, self.dtype = self.dtype, torch.float64            # the generic solver is fp64
+        task = self._task(Bt, t)
+        self.dtype = dtype
+        grad, cst, fhat, ghat = ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"],
+                                                         float(self.clf_gamma), task["centers"], task["radii"],
+                                                         task["tw"], task["gammas"], float(self.mean_dynamics.L))
+        a = torch.einsum("bkn,bnm->bkm", grad, ghat)             # [Bt, 1+Kob, 2]
+        b = torch.einsum("bkn,bn->bk", grad, fhat) + cst
+        nv, K = 3, 4 + 1 + Kob                                   # y = [u0, u1, relax];  G y <= h
+        P = torch.zeros(Bt, nv, nv, **f64)
+        P[:, 0, 0] = P[:, 1, 1] = 2.0
+        q = torch.zeros(Bt, nv, **f64)
+        q[:, 2] = self.clf_relax_weight
+        G = torch.zeros(Bt, K, nv, **f64)
+        h = torch.zeros(Bt, K, **f64)
+        lo, hi = torch.as_tensor(self.ctrl_min, **f64), torch.as_tensor(self.ctrl_max, **f64)
+        G[:, 0, 0] = G[:, 1, 1] = -1.0; h[:, 0], h[:, 1] = -lo[0], -lo[1]
+        G[:, 2, 0] = G[:, 3, 1] = 1.0; h[:, 2], h[:, 3] = hi[0], hi[1]
+        G[:, 4, :2], G[:, 4, 2], h[:, 4] = a[:, 0], -1.0, -b[:, 0]
+        G[:, 5:, :2], h[:, 5:] = -a[:, 1:], b[:, 1:]
+        y, status, iters = ops.coneqp(P.contiguous(), q, G.contiguous(), h.contiguous(), K, [])
+        self.last_status = status
+        u = y[:, :2]
+        if single:
+            if int(status[0]) != 0:
+                raise ValueError({1: "max_iterations", 2: "infeasible"}.get(int(status[0]), "solver_error"))
+            return u[0].to(device=x_torch.device, dtype=x_torch.dtype)
+        return u.to(dtype=x_torch.dtype)

@@ -166,6 +166,23 @@ def test_cbc2_quadratic_terms_reldeg2_facade(path):
         for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
             ref = g["t_" + name][i]
             np.testing.assert_allclose(val.detach().cpu().numpy().reshape(np.shape(ref)), ref, rtol=1e-6, atol=1e-8)
+    # the reference's own call shape: a RelDeg2Safety subclass, cbc2_quadratic_terms(safety.cbc, x, u0)
+    from bayesian_cbf_amd.cbc2 import RelDeg2Safety
+
+    class Safety(RelDeg2Safety):
+        k_alpha, model, max_unsafe_prob = g["k_alpha"], reg, 0.01
+        cbf = staticmethod(lambda x: look(x)[0])
+        grad_cbf = staticmethod(lambda x: look(x)[1])
+        hess_cbf = staticmethod(lambda x: look(x)[2])
+
+    sf = Safety()
+    (mA, mb), (Q, p, r), mean, var = cbc2_quadratic_terms(sf.cbc, t(g["xs"][0]), t(g["u0s"][0]))
+    np.testing.assert_allclose(mean.detach().cpu().numpy().reshape(()), g["t_mean"][0], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(Q.detach().cpu().numpy(), g["t_Q"][0], rtol=1e-6, atol=1e-8)
+    expr = sf.cbc(t(g["u0s"][0]))
+    np.testing.assert_allclose(float(expr.mean(t(g["xs"][0]))), float(np.ravel(g["t_mean"][0])[0]), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(float(expr.knl(t(g["xs"][0]), t(g["xs"][0]))), float(np.ravel(g["t_var"][0])[0]), rtol=1e-6, atol=1e-8)
+    assert abs(sf.safety_factor() - np.sqrt(0.99 / 0.01)) < 1e-12
 
 
 def test_monte_carlo_rollouts_reproduce_saved_run_from_the_logged_start():
@@ -185,3 +202,69 @@ def test_monte_carlo_rollouts_reproduce_saved_run_from_the_logged_start():
     # the Bayes-CBF run stays out of the obstacles; with noise the statistics are finite and sane
     out2 = monte_carlo_safety_rollouts(256, numSteps=60, dt=float(g["dt"]), start_noise=0.05, seed=3)
     assert np.isfinite(out2["stats"]["min_h"]) and out2["stats"]["count"] == 256
+
+
+def test_reldeg1_safety_class_matches_fu_func_gp_views():
+    """cbc1.RelDeg1Safety.cbc(u) = grad_h' fu_gp(u) + gamma h (cbc1.py:38-46): its mean / variance at x must equal
+    grad_h' fu_mean and grad_h' fu_knl grad_h of the GP views (themselves pinned to the reference above), and
+    cbc2_quadratic_terms(safety.cbc, x, u) must reproduce them as a polynomial in u."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    from bayesian_cbf_amd.cbc1 import RelDeg1Safety
+    from bayesian_cbf_amd.cbc2 import cbc2_quadratic_terms
+    g = np.load(POSTERIOR_FILES[-1])
+    reg = make(ControlAffineRegressor, g, [g["jitter_rand"][0]])
+    n = g["X"].shape[1]
+    w = t(np.linspace(0.3, -0.7, n))
+
+    class Safety(RelDeg1Safety):
+        gamma, model, max_unsafe_prob = 2.5, reg, 0.05
+        cbf = staticmethod(lambda x: (w * x).sum() + 0.1)
+        grad_cbf = staticmethod(lambda x: w)
+
+    sf = Safety()
+    x, u = t(g["Xtest"][0]), t(g["Utest"][0])
+    expr = sf.cbc(u)
+    mean_ref = w @ reg.fu_func_mean(u, x) + 2.5 * ((w * x).sum() + 0.1)
+    var_ref = w @ reg.fu_func_knl(u, x, x) @ w
+    close(expr.mean(x).reshape(()), mean_ref.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    close(expr.knl(x, x).reshape(()), var_ref.cpu().numpy(), rtol=1e-8, atol=1e-12)
+    (mA, mb), (Q, p, r), mean, var = cbc2_quadratic_terms(sf.cbc, x, u)
+    close((mA @ u + mb).reshape(()), mean_ref.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    close((u @ Q @ u + p @ u + r).reshape(()), var_ref.cpu().numpy(), rtol=1e-8, atol=1e-12)
+    from scipy.special import erfinv
+    assert abs(sf.safety_factor() - np.sqrt(2) * erfinv(0.9)) < 1e-12
+
+
+def test_mean_only_controller_clf_solves_the_reference_qp():
+    """ControllerCLF.control (unicycle_move_to_pose.py:757-788): the batched device solution of
+    min |u|^2 + 10 relax  s.t. box, CLC <= relax, CBCs >= 0  against the CPU oracle solver on every instance."""
+    from bayesian_cbf_amd import ops
+    from bayesian_cbf_amd.planner import PiecewiseLinearPlanner
+    from bayesian_cbf_amd.unicycle_move_to_pose import (ControllerCLF, AckermannDrive, CLFCartesian,
+                                                         obstacles_at_mid_from_start_and_goal)
+    x0, xg = t([-3.0, -1.0, -np.pi / 4]), t([0.0, 0.0, np.pi / 4])
+    planner = PiecewiseLinearPlanner(x0, xg, 200, 0.05, frac_time_to_reach_goal=0.95)
+    cbfs = obstacles_at_mid_from_start_and_goal(x0, xg, term_weights=[0.7, 0.3])
+    ctrl = ControllerCLF(planner, dynamics=AckermannDrive(L=1.0), clf=CLFCartesian(), cbfs=cbfs, cbf_gammas=[5.0, 5.0])
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    xs = (x0.cpu() + torch.tensor([0.3, 0.3, 0.5], dtype=torch.float64) * torch.randn(12, 3, generator=gen, dtype=torch.float64)).to(DEV)
+    u = ctrl.control(xs, 7)
+    assert (ctrl.last_status == 0).all()
+    u1 = ctrl.control(xs[0], 7)
+    close(u1, u[0].cpu().numpy(), rtol=1e-12, atol=1e-12)
+    task = ctrl._task(12, 7)
+    grad, cst, fhat, ghat = ops.unicycle_constraints(xs, task["plan"], task["dot_plan"], task["Kp"], 10.0, task["centers"],
+                                                     task["radii"], task["tw"], task["gammas"], 1.0)
+    a = torch.einsum("bkn,bnm->bkm", grad, ghat).cpu().numpy()
+    b = (torch.einsum("bkn,bn->bk", grad, fhat) + cst).cpu().numpy()
+    from oracle import socp as osocp          # checker: the CPU restatement of cvxopt coneqp (pinned to the reference's KAT)
+    for i in range(12):
+        P = np.diag([2.0, 2.0, 0.0]); q = np.array([0.0, 0.0, 10.0])
+        G = np.zeros((7, 3)); h = np.zeros(7)
+        G[0, 0] = G[1, 1] = -1; h[0], h[1] = 10, 5 * np.pi
+        G[2, 0] = G[3, 1] = 1; h[2], h[3] = 10, 5 * np.pi
+        G[4, :2], G[4, 2], h[4] = a[i, 0], -1, -b[i, 0]
+        G[5:, :2], h[5:] = -a[i, 1:], b[i, 1:]
+        sol = osocp.coneqp(P, q, G, h, dict(l=7, q=[]))
+        assert sol["status"] == "optimal"
+        np.testing.assert_allclose(u[i].cpu().numpy(), sol["x"][:2], rtol=1e-6, atol=1e-7)
