@@ -19,6 +19,8 @@ Exact class draws a second b(1+m)-vector per covariance prediction, :1089); pass
 from functools import partial
 
 import numpy as np
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -86,6 +88,7 @@ class ControlAffineRegressor:
         self.x_dim, self.u_dim = x_dim, u_dim
         self.model = KernelParams(x_dim, u_dim, rank=rank, dtype=dtype).to(self.device)
         self.generator = generator
+        self.gamma_length_scale_prior = gamma_length_scale_prior
         # every random draw of the reference (make_psd jitter) goes through this hook, in the reference's
         # order; tests replace it to replay recorded draws
         self.rand_fn = lambda k: torch.rand(k, dtype=self.dtype, device=self.device, generator=self.generator)
@@ -191,14 +194,78 @@ class ControlAffineRegressor:
 
     # ---------------------------------------------------------------- training data
     def fit(self, Xtrain_in, Utrain_in, XdotTrain_in, training_iter=50, lr=0.1, **kw):
-        """Store the training set (control_affine_model.py:274-290).  Hyper-parameters are NOT optimised
-        here (SURVEY.md 8f #1); they keep their current values."""
+        """Store the training set and optimise the hyper-parameters (control_affine_model.py:268-335):
+        `training_iter` Adam steps (lr, MultiStepLR at 30/60/80/90 %) on -log p(Y)/(N n), targets perturbed by
+        1 + 1e-6 rand each iteration as in the reference.  The likelihood and its gradient come from the device
+        (K_b build + Cholesky, solves, `bcbf_mll_grad`); torch only carries the parameter transforms
+        (softplus, W W' + diag) and the optimiser state.  Parity with the reference's gpytorch fit is
+        statistical only (unpinned); `training_iter=0` just stores the data."""
         if Xtrain_in.shape[0] == 0:
             return self
         self.Xtrain, self.Utrain, self.XdotTrain = [self._ensure_device_dtype(X).contiguous()
                                                     for X in (Xtrain_in, Utrain_in, XdotTrain_in)]
         self.clear_cache()
+        if training_iter <= 0:
+            return self
+        self._require_gpu()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        optimizer = torch.optim.Adam(params, lr=lr)
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(
+            optimizer, milestones=[int(round(f * training_iter)) for f in (0.3, 0.6, 0.8, 0.9)])
+        self.fit_losses = []
+        for _ in range(training_iter):
+            optimizer.zero_grad()
+            self.fit_losses.append(self.neg_mll_backward(perturb_targets=True))
+            optimizer.step()
+            scheduler.step()
+        self.clear_cache()
         return self
+
+    def neg_mll_backward(self, perturb_targets=False, jitter=None):
+        """loss = -log p(Y) / (N n) (- log prior / (N n)) at the current hyper-parameters; its gradient is accumulated
+        into the raw parameters' .grad.  Returns the loss as a float."""
+        m = self.model
+        ell, s2, A, B, M0 = m.lengthscale, m.outputscale, m.A, m.B, m.M0          # carry the autograd graph
+        hp = self._hyper()
+        X = self.Xtrain[None]
+        UH = torch.cat([torch.ones_like(self.Utrain[:, :1]), self.Utrain], dim=1)[None].contiguous()
+        N, n = self.Xtrain.shape
+        Y = self.XdotTrain
+        if perturb_targets:
+            Y = Y * (1 + 1e-6 * torch.rand_like(Y))                                # :318-321
+        Y = Y[None].contiguous()
+        factor = 1e-5
+        for ntry in range(10):
+            jit = (factor * self.rand_fn(N))[None].contiguous() if jitter is None else jitter
+            Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit)
+            if int(info[0]) == 0:
+                break
+            if ntry == 9 or jitter is not None:
+                raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
+            factor *= 10
+        _, alpha = ops.potrs(Lop, Y, UH, hp["M0"])
+        R = (Y - UH @ hp["M0"]).contiguous()
+        Kinv = ops.kb_inverse(Lop, N)
+        Ad = hp["A"][0]
+        Ainv = torch.linalg.inv(Ad)
+        g_ell, g_s2, g_B, logdetK, RtA, UHtA = ops.mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv[None].contiguous(),
+                                                            hp["Bm"], hp["ell"], hp["s2"])
+        scale = 1.0 / (N * n)
+        nll = 0.5 * torch.trace(Ainv @ RtA[0]) + 0.5 * n * logdetK[0] + 0.5 * N * torch.logdet(Ad) \
+            + 0.5 * N * n * math.log(2 * math.pi)
+        gA = 0.5 * Ainv @ RtA[0] @ Ainv - 0.5 * N * Ainv                           # d log p / dA
+        gM0 = UHtA[0] @ Ainv                                                       # d log p / dM0  [C,n]
+        torch.autograd.backward(
+            [ell, s2, A, B, M0],
+            [(-scale * g_ell[0]).reshape(ell.shape), (-scale * g_s2[0]).reshape(s2.shape), -scale * gA,
+             -scale * g_B[0], -scale * gM0])
+        loss = float(nll) * scale
+        if self.gamma_length_scale_prior is not None:                              # GammaPrior on the lengthscale (:164-171)
+            c, r = self.gamma_length_scale_prior
+            lp = (c * math.log(r) - math.lgamma(c) + (c - 1) * torch.log(m.lengthscale) - r * m.lengthscale).sum()
+            (-scale * lp).backward()
+            loss -= float(lp) * scale
+        return loss
 
     # ---------------------------------------------------------------- refit state (cached, :379-388)
     def _hyper(self):
@@ -400,8 +467,8 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
         return meanFX.transpose(-2, -1).reshape(-1), torch_kron(Bk2, A)
 
 
-ControlAffineRegressorRankOne = partial(ControlAffineRegressor, rank=1)
-ControlAffineRegressorExactRankOne = partial(ControlAffineRegressorExact, rank=1)
+ControlAffineRegressorRankOne = partial(ControlAffineRegressor, rank=1, gamma_length_scale_prior=(1e-3, 1e-3))   # :923-927
+ControlAffineRegressorExactRankOne = partial(ControlAffineRegressorExact, rank=1, gamma_length_scale_prior=(1e-3, 1e-3))
 ControlAffineRegMatrixDiag = partial(ControlAffineRegressorExact, rank=0)
 
 

@@ -1,0 +1,166 @@
+// K12: the O(N^2) part of the marginal-log-likelihood gradient of the matrix-variate GP,
+//   log p(Y) = -1/2 tr(A^-1 R' K_b^-1 R) - n/2 logdet K_b - N/2 logdet A - N n/2 log 2 pi,   R = Y - UH M0,
+// which the reference obtains from gpytorch's ExactMarginalLogLikelihood + autograd
+// (control_affine_model.py:268-335, matrix_variate_multitask_kernel.py:99-204).  With alpha = K_b^-1 R:
+//   G = d log p / d K_b = 1/2 (alpha A^-1 alpha' - n K_b^-1),      K_b = s2 k(X,X) o (UH B UH')
+//   d/d s2 = sum_ij G_ij k_ij u_ij,   d/d ell_d = sum_ij G_ij K_ij (x_id - x_jd)^2 / ell_d^3,
+//   d/d B  = UH' (s2 G o k) UH,       logdet K_b = -2 sum_i log inv(L)_ii   (diagonal blocks are stored inverted)
+// plus the two small products R' alpha [n,n] and UH' alpha [C,n] the host needs for d/dA, d/dM0 and the value.
+// One workgroup per GP (a fit is one model at a time; N^2 pair terms, nothing to tile).
+#include "bcbf_common.h"
+
+namespace bcbf {
+
+constexpr int MG_T = 256;
+constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 1 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
+
+template <typename T>
+__global__ void __launch_bounds__(MG_T)
+mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T* __restrict__ Kinv,
+                const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ R, const T* __restrict__ Ainv,
+                const T* __restrict__ Bm, const T* __restrict__ ell, const T* __restrict__ s2p,
+                T* __restrict__ g_ell, T* __restrict__ g_s2, T* __restrict__ g_B, T* __restrict__ logdetK,
+                T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C) {
+    constexpr int V = Vec<T>::V;
+    __shared__ double red[4][MG_MAXOUT];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* Xb = X + (size_t)b * N * n;
+    const T* UHb = UH + (size_t)b * N * C;
+    const T* Rb = R + (size_t)b * N * n;
+    const T* al = alpha + (size_t)b * N * n;
+    const T* Kib = Kinv + (size_t)b * N * N;
+    const T* lop = Lop + (size_t)b * lop_elems<V>(Np);
+    double iell[BCBF_MAX_STATE_DIM], Ai[BCBF_MAX_STATE_DIM][BCBF_MAX_STATE_DIM];
+    double Bl[BCBF_MAX_CTRL_DIM + 1][BCBF_MAX_CTRL_DIM + 1];
+    const double s2 = (double)s2p[b];
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+        iell[d] = d < n ? 1.0 / (double)ell[(size_t)b * n + d] : 0.0;
+        for (int e = 0; e < BCBF_MAX_STATE_DIM; ++e) Ai[d][e] = (d < n && e < n) ? (double)Ainv[((size_t)b * n + d) * n + e] : 0.0;
+    }
+    for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a)
+        for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) Bl[a][c] = (a < C && c < C) ? (double)Bm[((size_t)b * C + a) * C + c] : 0.0;
+
+    // ---- phase 1: the N^2 pair terms (register accumulators, fully unrolled over the compile-time maxima)
+    double gl[BCBF_MAX_STATE_DIM], gB[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)], gs = 0.0;
+#pragma unroll
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] = 0.0;
+#pragma unroll
+    for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) gB[a] = 0.0;
+    for (long long idx = tid; idx < (long long)N * N; idx += MG_T) {
+        const int i = (int)(idx / N), j = (int)(idx - (long long)i * N);
+        double d2 = 0.0, dz2[BCBF_MAX_STATE_DIM];
+#pragma unroll
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+            const double z = d < n ? ((double)Xb[(size_t)i * n + d] - (double)Xb[(size_t)j * n + d]) * iell[d] : 0.0;
+            dz2[d] = z * z;
+            d2 += z * z;
+        }
+        const double kij = exp(-0.5 * d2);
+        double ui[BCBF_MAX_CTRL_DIM + 1], uj[BCBF_MAX_CTRL_DIM + 1], uij = 0.0;
+#pragma unroll
+        for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a) {
+            ui[a] = a < C ? (double)UHb[(size_t)i * C + a] : 0.0;
+            uj[a] = a < C ? (double)UHb[(size_t)j * C + a] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) t += Bl[a][c] * uj[c];
+            uij += ui[a] * t;
+        }
+        double q = 0.0;                                      // alpha_i' A^-1 alpha_j
+#pragma unroll
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
+            if (d < n) {
+                double t = 0.0;
+#pragma unroll
+                for (int e = 0; e < BCBF_MAX_STATE_DIM; ++e)
+                    if (e < n) t += Ai[d][e] * (double)al[(size_t)j * n + e];
+                q += (double)al[(size_t)i * n + d] * t;
+            }
+        }
+        const double G = 0.5 * (q - (double)n * (double)Kib[(size_t)i * N + j]);
+        const double Gk = G * kij;
+        gs += Gk * uij;
+        const double GK = Gk * s2 * uij;                     // G_ij K_ij
+#pragma unroll
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] += GK * dz2[d] * iell[d];       // z^2 / ell = dx^2 / ell^3
+#pragma unroll
+        for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a)
+#pragma unroll
+            for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) gB[a * (BCBF_MAX_CTRL_DIM + 1) + c] += Gk * s2 * ui[a] * uj[c];
+    }
+    // workgroup reduction of the 8 + 1 + 16 sums
+    constexpr int NR = BCBF_MAX_STATE_DIM + 1 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
+    double vals[NR];
+#pragma unroll
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) vals[d] = wave_sum(gl[d]);
+    vals[BCBF_MAX_STATE_DIM] = wave_sum(gs);
+#pragma unroll
+    for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) vals[BCBF_MAX_STATE_DIM + 1 + a] = wave_sum(gB[a]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int o = 0; o < NR; ++o) red[tid >> 6][o] = vals[o];
+    }
+    __syncthreads();
+    if (tid < NR) {
+        const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid < BCBF_MAX_STATE_DIM) { if (tid < n) g_ell[(size_t)b * n + tid] = (T)v; }
+        else if (tid == BCBF_MAX_STATE_DIM) g_s2[b] = (T)v;
+        else {
+            const int o = tid - BCBF_MAX_STATE_DIM - 1, a = o / (BCBF_MAX_CTRL_DIM + 1), c = o % (BCBF_MAX_CTRL_DIM + 1);
+            if (a < C && c < C) g_B[((size_t)b * C + a) * C + c] = (T)v;
+        }
+    }
+    // ---- phase 2: the small products (one output per thread, a loop over the N rows) and logdet (last wave)
+    if (tid < n * n) {
+        const int d = tid / n, e = tid - d * n;
+        double v = 0.0;
+        for (int i = 0; i < N; ++i) v += (double)Rb[(size_t)i * n + d] * (double)al[(size_t)i * n + e];
+        RtA[(size_t)b * n * n + tid] = (T)v;
+    } else if (tid >= 64 && tid < 64 + C * n) {
+        const int o = tid - 64, a = o / n, d = o - a * n;
+        double v = 0.0;
+        for (int i = 0; i < N; ++i) v += (double)UHb[(size_t)i * C + a] * (double)al[(size_t)i * n + d];
+        UHtA[(size_t)b * C * n + o] = (T)v;
+    } else if (tid >= 192) {
+        double v = 0.0;
+        for (int i = tid - 192; i < N; i += 64) v -= 2.0 * log((double)lop[lop_base<V>(i, Np) + i]);
+        v = wave_sum(v);
+        if (tid == 192) logdetK[b] = (T)v;
+    }
+}
+
+template <typename T>
+static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T* X, const T* UH, const T* R,
+                           const T* Ainv, const T* Bm, const T* ell, const T* s2, T* g_ell, T* g_s2, T* g_B, T* logdetK,
+                           T* RtA, T* UHtA, int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !alpha || !Kinv || !X || !UH || !R || !Ainv || !Bm || !ell || !s2 || !g_ell || !g_s2 || !g_B || !logdetK ||
+        !RtA || !UHtA)
+        return BCBF_EINVAL;
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    hipLaunchKernelGGL((mll_grad_kernel<T>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv, X, UH, R,
+                       Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1);
+    return check_launch("mll_grad");
+}
+
+}  // namespace bcbf
+
+extern "C" {
+int bcbf_mll_grad_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                      const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
+                      float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
+                      void* stream) {
+    return bcbf::launch_mll_grad<float>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                        UHtA, Bt, N, n, m, stream);
+}
+int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
+                      const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
+                      double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
+                      int n, int m, void* stream) {
+    return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                         UHtA, Bt, N, n, m, stream);
+}
+}

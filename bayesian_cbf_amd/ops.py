@@ -121,6 +121,37 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
     return Lout, Vw2, X2, UHB2, info
 
 
+def kb_inverse(Lop, N):
+    """Dense K_b^-1 [Bt,N,N] from the packed factor: bcbf_potrs on identity columns, 8 at a time (fit path only)."""
+    Bt = Lop.shape[0]
+    f = dict(dtype=Lop.dtype, device=Lop.device)
+    Kinv = torch.empty(Bt, N, N, **f)
+    UH0, M00 = torch.zeros(Bt, N, 2, **f), torch.zeros(Bt, 2, 8, **f)
+    eye = torch.eye(N, **f)
+    for j0 in range(0, N, 8):
+        w = min(8, N - j0)
+        rhs = torch.zeros(Bt, N, 8, **f)
+        rhs[:, :, :w] = eye[:, j0:j0 + w]
+        _, sol = potrs(Lop, rhs, UH0, M00)
+        Kinv[:, :, j0:j0 + w] = sol[:, :, :w]
+    return Kinv
+
+
+def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2):
+    """O(N^2) sums of the marginal-log-likelihood gradient (bcbf.h K12).  Returns
+    (g_ell[Bt,n], g_s2[Bt], g_B[Bt,C,C], logdetK[Bt], RtA[Bt,n,n], UHtA[Bt,C,n])."""
+    _chk(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2)
+    Bt, N, n = X.shape
+    C = UH.shape[2]
+    f = dict(dtype=X.dtype, device=X.device)
+    g_ell, g_s2, g_B = torch.empty(Bt, n, **f), torch.empty(Bt, **f), torch.empty(Bt, C, C, **f)
+    logdet, RtA, UHtA = torch.empty(Bt, **f), torch.empty(Bt, n, n, **f), torch.empty(Bt, C, n, **f)
+    check(getattr(lib, "bcbf_mll_grad" + _suf(X))(_p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm),
+                                                  _p(ell), _p(s2), _p(g_ell), _p(g_s2), _p(g_B), _p(logdet), _p(RtA),
+                                                  _p(UHtA), Bt, N, n, C - 1, _stream(X)), "bcbf_mll_grad")
+    return g_ell, g_s2, g_B, logdet, RtA, UHtA
+
+
 def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None):
     """(Mk[Bt,n,C], Bk[Bt,C,C]) at one query per instance  (control_affine_model.py:1051-1091, b=1)."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)

@@ -123,6 +123,21 @@ int bcbf_gp_append_f64(const double* Lop_in, const double* Vw_in, const double* 
                        double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
                        void* stream);
 
+/* K12 -- hyper-parameter fit support (ControlAffineRegressor.fit, control_affine_model.py:268-335):
+ * the O(N^2) sums of the gradient of  log p(Y) = -1/2 tr(A^-1 R'K_b^-1 R) - n/2 logdet K_b - N/2 logdet A - Nn/2 log 2pi
+ * (R = Xdot - UH M0) with respect to the data-kernel parameters and B, for given alpha = K_b^-1 R [Bt,N,n] (bcbf_potrs)
+ * and dense K_b^-1 [Bt,N,N] (bcbf_potrs on identity columns):
+ *   g_ell[Bt,n] = d/d ell, g_s2[Bt] = d/d s2, g_B[Bt,C,C] = d/dB (B treated as unconstrained, symmetric result),
+ *   logdetK[Bt], RtA[Bt,n,n] = R'alpha, UHtA[Bt,C,n] = UH'alpha  (value, d/dA and d/dM0 follow on the host from these). */
+int bcbf_mll_grad_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                      const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
+                      float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
+                      void* stream);
+int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
+                      const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
+                      double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
+                      int n, int m, void* stream);
+
 /* K4+K5+K6+K7: one posterior query per instance (the HBM-bound hot kernel).
  *   Phi = diag(k(X, xq)) UHB;  W = L^-1 Phi;  Mk = M0' + Vw' W;  Bk = s2*Bm - W'W (+ diag(jitter2))
  * Replaces ControlAffineRegressorExact._custom_predict_matrix with b = 1

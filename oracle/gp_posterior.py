@@ -234,3 +234,23 @@ def chol_append(L, knew, kappa):
     Lnew[N, :N] = l
     Lnew[N, N] = np.sqrt(d2)
     return Lnew
+
+
+# --------------------------------------------------------------------------- marginal likelihood (fit)
+def marginal_log_likelihood(X, UH, Y, A, Bm, ell, s2, M0, jitter):
+    """log p(vec Y) of the training set under the matrix-variate prior: covariance K_b (x) A over (points, state dims)
+    (HetergeneousMatrixVariateKernel on mask-1 rows, matrix_variate_multitask_kernel.py:112-118: K11 = (H K(x)B H') (x) A,
+    H K(x)B H' = k(X,X) o (UH B UH')), constant mean UH M0, no observation noise (IdentityLikelihood,
+    control_affine_model.py:244).  This is what ExactMarginalLogLikelihood evaluates inside `fit`
+    (control_affine_model.py:309-321) up to its 1/num_data factor and gpytorch's own jitter policy -- the arithmetic
+    lives in the un-vendored gpytorch fork: PARITY UNPINNED, restated from the Gaussian log density.
+      log p = -1/2 tr(A^-1 R' K_b^-1 R) - n/2 logdet K_b - N/2 logdet A - N n/2 log 2 pi,   R = Y - UH M0."""
+    N, n = Y.shape
+    Kb = kb_matrix(X, UH, Bm, ell, s2) + np.diag(np.asarray(jitter, dtype=np.float64))
+    L = np.linalg.cholesky(Kb)
+    R = Y - UH @ M0
+    W = sla.solve_triangular(L, R, lower=True)
+    quad = np.trace(np.linalg.solve(A, W.T @ W))
+    logdetK = 2.0 * np.log(np.diag(L)).sum()
+    logdetA = np.linalg.slogdet(A)[1]
+    return -0.5 * quad - 0.5 * n * logdetK - 0.5 * N * logdetA - 0.5 * N * n * np.log(2.0 * np.pi)
