@@ -264,7 +264,7 @@ class ControlAffineRegressor:
             c, r = self.gamma_length_scale_prior
             lp = (c * math.log(r) - math.lgamma(c) + (c - 1) * torch.log(m.lengthscale) - r * m.lengthscale).sum()
             (-scale * lp).backward()
-            loss -= float(lp) * scale
+            loss -= float(lp.detach()) * scale
         return loss
 
     # ---------------------------------------------------------------- refit state (cached, :379-388)

@@ -75,6 +75,99 @@ def obstacles_at_mid_from_start_and_goal(x, x_g, term_weights=(0.5, 0.5)):
     return [ObstacleCBF(mid + off, rad, term_weights), ObstacleCBF(mid - off, rad, term_weights)]
 
 
+class LearnedShiftInvariantDynamics:
+    """unicycle_move_to_pose.py:295-428: prior mean dynamics + a learned control-affine residual.  `train(x, u)` buffers
+    the closed-loop samples and every `train_every_n_steps` refits the regressor on finite-difference targets minus the
+    prior mean (random subsample to `max_train`), exactly the reference's schedule; inputs are made shift invariant
+    ((x, y) zeroed) for f_func / g_func / fit / custom_predict_fullmat but -- as in the reference (:388-397) -- not for
+    the GP the controller queries."""
+    state_size, ctrl_size = 3, 2
+
+    def __init__(self, dt=None, learned_dynamics=None, learned_dynamics_class=None, mean_dynamics=None, max_train=200,
+                 training_iter=100, shift_invariant=True, train_every_n_steps=20, enable_learning=True, device="cuda",
+                 dtype=torch.float64):
+        from .control_affine_model import ControlAffineRegressorExactRankOne
+        self.max_train, self.training_iter, self.dt = max_train, training_iter, dt
+        self.mean_dynamics = mean_dynamics or AckermannDrive()
+        cls = learned_dynamics_class or ControlAffineRegressorExactRankOne
+        self.learned_dynamics = learned_dynamics if learned_dynamics is not None else cls(
+            self.state_size, self.ctrl_size, device=device, dtype=dtype)
+        self.shift_invariant = shift_invariant
+        self.train_every_n_steps, self.enable_learning = train_every_n_steps, enable_learning
+        self.Xtrain, self.Utrain = [], []
+        self.current_state = None
+
+    def _trans_invariant_wrapper(self, X):
+        if not self.shift_invariant:
+            return X
+        return torch.cat([torch.zeros_like(X[..., :self.state_size - 1]), X[..., self.state_size - 1:]], dim=-1)
+
+    def f_func(self, X):
+        x0 = self._trans_invariant_wrapper(X)
+        return self.mean_dynamics.f_func(x0) + self.learned_dynamics.f_func(x0).to(x0)
+
+    def g_func(self, X):
+        x0 = self._trans_invariant_wrapper(X)
+        return self.mean_dynamics.g_func(x0) + self.learned_dynamics.g_func(x0).to(x0)
+
+    def train(self, xi, uopt):
+        if len(self.Xtrain) > 0 and len(self.Xtrain) % int(self.train_every_n_steps) == 0 and self.enable_learning:
+            Xtrain = torch.cat(self.Xtrain).reshape(-1, self.Xtrain[0].shape[-1])
+            Utrain = torch.cat(self.Utrain).reshape(-1, self.Utrain[0].shape[-1])
+            XdotTrain = (Xtrain[1:, :] - Xtrain[:-1, :]) / self.dt
+            self.fit(Xtrain[:-1, :], Utrain[:-1, :], XdotTrain)
+        self.Xtrain.append(xi.detach())
+        self.Utrain.append(uopt.detach())
+
+    def get_kernel_param(self, name):
+        return self.learned_dynamics.get_kernel_param(name)
+
+    def fit(self, Xtrain, Utrain, XdotTrain, training_iter=None):
+        if not len(Xtrain):
+            return
+        Xtrain = self._trans_invariant_wrapper(Xtrain)
+        md = self.mean_dynamics
+        XdotMean = md.f_func(Xtrain) + (md.g_func(Xtrain) @ Utrain.unsqueeze(-1)).squeeze(-1)
+        XdotError = XdotTrain - XdotMean
+        if XdotTrain.shape[0] > self.max_train:
+            idx = np.arange(XdotTrain.shape[0])
+            np.random.shuffle(idx)
+            idx = torch.from_numpy(idx[:self.max_train]).to(Xtrain.device)
+            Xtrain, Utrain, XdotError = Xtrain[idx], Utrain[idx], XdotError[idx]
+        self.learned_dynamics.fit(Xtrain, Utrain, XdotError,
+                                  training_iter=self.training_iter if training_iter is None else training_iter)
+
+    def fu_func_gp(self, U):
+        if self.enable_learning:
+            return self.learned_dynamics.fu_func_gp(U)          # + the deterministic prior mean, added by the controller
+        raise NotImplementedError("fixed-kernel model: use ControllerCLFBayesian(dynamics=None, mean_dynamics=...)")
+
+    def step(self, u_torch, dt):
+        x = self.current_state
+        xdot = self.f_func(x) + self.g_func(x) @ u_torch
+        self.current_state = x + xdot * dt
+        return dict(xdot=xdot, x=self.current_state)
+
+    def custom_predict_fullmat(self, Xtest_in, **kw):
+        Xtest = Xtest_in.unsqueeze(0) if Xtest_in.ndim == 1 else Xtest_in
+        x0 = self._trans_invariant_wrapper(Xtest)
+        diffFX, diffVarFX = self.learned_dynamics.custom_predict_fullmat(x0, **kw)
+        md = self.mean_dynamics
+        F = torch.cat([md.f_func(x0).unsqueeze(-1), md.g_func(x0)], dim=-1).to(diffFX)       # [b, n, 1+m]
+        return F.transpose(-2, -1).reshape(-1) + diffFX, diffVarFX
+
+    def clear_cache(self):
+        self.learned_dynamics.clear_cache()
+
+    def as_dict(self):
+        """GP tensors for `ops.unicycle_control_step` (one shared learned model), or None before the first fit."""
+        reg = self.learned_dynamics
+        if not self.enable_learning or reg.Xtrain is None:
+            return None
+        st = reg._state()
+        return {k: st[k] for k in ("Lop", "Vw", "X", "UHB", "ell", "s2", "Bm", "M0", "A")}
+
+
 class ControllerCLFBayesian:
     """unicycle_move_to_pose.py:801-998.  `dynamics` is a `BatchedControlAffineGP` (learned residual,
     regime I), or None for the fixed-kernel model of AckermannDrive.fu_func_gp (:262-275:
@@ -135,9 +228,27 @@ class ControllerCLFBayesian:
             self._ws = ops.control_workspace(Bt, Kob, self.dtype, self.device)
         ws = self._ws
         L_mean = float(self.mean_dynamics.L)
-        if self.dynamics is not None:
-            ops.unicycle_control_step(self.dynamics.as_dict(), task, ws, x, dt=0.0, L_mean=L_mean,
-                                      clf_gamma=float(self.clf_gamma))
+        learned = isinstance(self.dynamics, LearnedShiftInvariantDynamics)
+        if learned:
+            L_mean = float(self.dynamics.mean_dynamics.L)
+        gp = self.dynamics.as_dict() if self.dynamics is not None else None
+        if gp is not None:
+            ops.unicycle_control_step(gp, task, ws, x, dt=0.0, L_mean=L_mean, clf_gamma=float(self.clf_gamma))
+        elif learned and self.dynamics.enable_learning:   # learning enabled, no data yet: the GP prior (M0, s2 B, A)
+            m = self.dynamics.learned_dynamics.model
+            f = dict(dtype=self.dtype, device=self.device)
+            ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], float(self.clf_gamma),
+                                     task["centers"], task["radii"], task["tw"], task["gammas"], L_mean,
+                                     out=(ws["grad"], ws["cst"], ws["fhat"], ws["ghat"]))
+            with torch.no_grad():
+                ws["Mk"].copy_(m.M0.t().to(**f).expand(Bt, 3, 3))
+                ws["Bk"].copy_((m.outputscale * m.B).to(**f).expand(Bt, 3, 3))
+                A = m.A.to(**f).expand(Bt, 3, 3).contiguous()
+            y, status, iters, cones, cstatus, _ = ops.cbc_socp(ws["Mk"], ws["Bk"], A, ws["grad"], ws["cst"], task["sign"],
+                                                              ws["fhat"], ws["ghat"], task["w"], task["r"],
+                                                              task["relax_mask"], task["rho"])
+            ws["y"].copy_(y)
+            ws["status"].copy_(status)
         else:   # fixed-kernel model: no posterior kernel, M_k = 0, B_k = I
             ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], float(self.clf_gamma),
                                      task["centers"], task["radii"], task["tw"], task["gammas"], L_mean,
@@ -155,7 +266,10 @@ class ControllerCLFBayesian:
             st = int(ws["status"][0])
             if st != 0:
                 raise ValueError({1: "max_iterations", 2: "infeasible", 3: "bad_cone"}.get(st, "solver_error"))
-            return u[0].to(device=x_torch.device, dtype=x_torch.dtype)
+            uopt = u[0].to(device=x_torch.device, dtype=x_torch.dtype)
+            if hasattr(self.dynamics, "train"):            # :990-993: the controller feeds the learner
+                self.dynamics.train(x_torch, uopt)
+            return uopt
         bad = ws["status"] != 0
         if bool(bad.any()):
             u = torch.where(bad[:, None], task["r"], u)

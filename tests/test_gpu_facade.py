@@ -325,3 +325,47 @@ def test_fit_improves_likelihood_and_recovers_the_training_function():
     truth = f(Xt) + np.einsum("bnm,bm->bn", gfun(Xt), Ut)
     err = np.abs(mean.cpu().numpy() - truth).max() / np.abs(truth).max()
     assert err < 0.1, err
+
+
+def test_online_learning_closed_loop_as_in_the_reference_recipe():
+    """unicycle_learning_helps_avoid_getting_stuck shape (unicycle_move_to_pose.py:1948-1969): plant with true L = 1,
+    controller model = AckermannDrive(L = 12) + learned residual.  (1) fit() on exploratory samples moves the model's
+    turn-rate gain from the prior's 1/12 to the plant's 1/1 (hyper-parameters fitted on the device);  (2) in closed loop
+    the controller feeds `train`, which buffers samples and refits on schedule from finite-difference targets with
+    shift-invariant inputs."""
+    from bayesian_cbf_amd.planner import PiecewiseLinearPlanner
+    from bayesian_cbf_amd.unicycle_move_to_pose import (ControllerCLFBayesian, AckermannDrive, CLFCartesian,
+                                                         LearnedShiftInvariantDynamics,
+                                                         obstacles_at_mid_from_start_and_goal)
+    torch.manual_seed(0); np.random.seed(0)
+    dt, numSteps = 0.01, 400
+    x0, xg = t([-3.0, -1.0, -np.pi / 4]), t([0.0, 0.0, np.pi / 4])
+    plant = AckermannDrive(L=1.0)
+    plant.set_init_state(x0)
+    dyn = LearnedShiftInvariantDynamics(dt=dt, mean_dynamics=AckermannDrive(L=12.0), training_iter=60,
+                                        train_every_n_steps=20, device=DEV)
+    # (1) exploratory data: random headings and controls, exact plant derivatives
+    rng = np.random.default_rng(1)
+    Xe = t(np.concatenate([rng.uniform(-3, 0, (120, 2)), rng.uniform(-np.pi, np.pi, (120, 1))], axis=1))
+    Ue = t(rng.normal(size=(120, 2)) * np.array([2.0, 3.0]))
+    Xdot = (plant.g_func(Xe) @ Ue.unsqueeze(-1)).squeeze(-1)
+    assert abs(float(dyn.g_func(x0)[2, 1]) - 1.0) > 0.5                    # random-init residual: far from the plant
+    dyn.fit(Xe, Ue, Xdot)
+    assert float(dyn.learned_dynamics.Xtrain[:, :2].abs().max()) == 0.0    # shift-invariant inputs
+    G = dyn.g_func(x0)
+    close(G, plant.g_func(x0).cpu().numpy(), rtol=0.1, atol=0.05)          # reference tests: rel 0.1
+    # (2) closed loop with the schedule of the recipe (refits keep the fitted hyper-parameters: training_iter = 0)
+    dyn.training_iter = 0
+    planner = PiecewiseLinearPlanner(x0, xg, numSteps, dt, frac_time_to_reach_goal=0.95)
+    ctrl = ControllerCLFBayesian(planner, dynamics=dyn, clf=CLFCartesian(Kp=(0.9, 1.5, 0.0)),
+                                 cbfs=obstacles_at_mid_from_start_and_goal(x0, xg, term_weights=[0.7, 0.3]),
+                                 cbf_gammas=[5.0, 5.0], max_risk=0.01)
+    x = x0.clone()
+    for step in range(45):
+        u = ctrl.control(x, step)
+        assert torch.isfinite(u).all()
+        x = plant.step(u, dt)["x"]
+    reg = dyn.learned_dynamics
+    assert len(dyn.Xtrain) == 45 and reg.Xtrain.shape[0] == 39             # second refit: samples 0..39 -> 39 differences
+    assert float(reg.Xtrain[:, :2].abs().max()) == 0.0
+    assert float((x[:2] - xg[:2]).norm()) < float((x0[:2] - xg[:2]).norm())   # and it makes progress towards the goal
