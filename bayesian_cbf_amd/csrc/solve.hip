@@ -25,7 +25,9 @@ __device__ inline void block_sum(T* vals, int count, T* scratch /* [4][SC] */) {
         vals[c] = scratch[c] + scratch[SC + c] + scratch[2 * SC + c] + scratch[3 * SC + c];
 }
 
-template <typename T>
+// IDENT (bcbf_potri): the right-hand sides are 8 columns of the identity -- workgroup (chunk, b) solves columns
+// 8 chunk .. 8 chunk + 7 of K_b^-1 and writes them straight into the dense inverse Kinv[Bt,N,N] (`alpha`, row stride N).
+template <typename T, bool IDENT>
 __global__ void __launch_bounds__(ST)
 potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __restrict__ UH,
              const T* __restrict__ M0, T* __restrict__ Vw, T* __restrict__ alpha, int N, int Np, int n, int C) {
@@ -33,10 +35,13 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
     __shared__ T rbuf[NB][SC];
     __shared__ T wbuf[NB][SC];
     __shared__ T scratch[4 * SC];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = IDENT ? blockIdx.y : blockIdx.x, tid = threadIdx.x;
+    const int j0 = IDENT ? blockIdx.x * SC : 0;          // first identity column of this workgroup
+    const int ostride = IDENT ? N : n;                   // row stride of the alpha output
     const T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
     const int rpt = (Np + ST - 1) / ST;
     const int nblk = Np / NB;
+    if (IDENT) n = (N - j0 < SC) ? N - j0 : SC;
 
     // ---- Y rows owned by this thread
     T y[SMAXR][SC];
@@ -46,7 +51,8 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
 #pragma unroll
         for (int c = 0; c < SC; ++c) {
             T v = T(0);
-            if (r < rpt && i < N && c < n) {
+            if (IDENT) v = (r < rpt && i == j0 + c && c < n) ? T(1) : T(0);
+            else if (r < rpt && i < N && c < n) {
                 v = Xdot[((size_t)b * N + i) * n + c];
                 for (int a = 0; a < C; ++a) v -= UH[((size_t)b * N + i) * C + a] * M0[((size_t)b * C + a) * n + c];
             }
@@ -76,7 +82,7 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
             }
 #pragma unroll
             for (int c = 0; c < SC; ++c) wbuf[tid][c] = w[c];
-            if (col0 + tid < N)
+            if (!IDENT && col0 + tid < N)
                 for (int c = 0; c < n; ++c) Vw[((size_t)b * N + col0 + tid) * n + c] = w[c];
         }
         __syncthreads();
@@ -144,7 +150,7 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
 #pragma unroll
             for (int c = 0; c < SC; ++c) wbuf[tid][c] = a[c];
             if (col0 + tid < N)
-                for (int c = 0; c < n; ++c) alpha[((size_t)b * N + col0 + tid) * n + c] = a[c];
+                for (int c = 0; c < n; ++c) alpha[((size_t)b * N + col0 + tid) * ostride + j0 + c] = a[c];
         }
         __syncthreads();
 #pragma unroll
@@ -167,9 +173,20 @@ static int launch_potrs(const T* Lop, const T* Xdot, const T* UH, const T* M0, T
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     if (Np > ST * SMAXR) return BCBF_EINVAL;
-    hipLaunchKernelGGL((potrs_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Xdot, UH, M0, Vw, alpha,
-                       N, Np, n, m + 1);
+    hipLaunchKernelGGL((potrs_kernel<T, false>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Xdot, UH, M0, Vw,
+                       alpha, N, Np, n, m + 1);
     return check_launch("potrs");
+}
+
+template <typename T>
+static int launch_potri(const T* Lop, T* Kinv, int Bt, int N, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !Kinv || N < 1) return BCBF_EINVAL;
+    const int Np = round_up(N, NB);
+    if (Np > ST * SMAXR) return BCBF_EINVAL;
+    hipLaunchKernelGGL((potrs_kernel<T, true>), dim3((N + SC - 1) / SC, Bt), dim3(ST), 0, (hipStream_t)stream, Lop,
+                       nullptr, nullptr, nullptr, nullptr, Kinv, N, Np, SC, 0);
+    return check_launch("potri");
 }
 
 
@@ -391,6 +408,12 @@ int bcbf_potrs_f32(const float* Lop, const float* Xdot, const float* UH, const f
 int bcbf_potrs_f64(const double* Lop, const double* Xdot, const double* UH, const double* M0,
                    double* Vw, double* alpha, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_potrs<double>(Lop, Xdot, UH, M0, Vw, alpha, Bt, N, n, m, stream);
+}
+int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream) {
+    return bcbf::launch_potri<float>(Lop, Kinv, Bt, N, stream);
+}
+int bcbf_potri_f64(const double* Lop, double* Kinv, int Bt, int N, void* stream) {
+    return bcbf::launch_potri<double>(Lop, Kinv, Bt, N, stream);
 }
 int bcbf_gp_append_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
                        const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,

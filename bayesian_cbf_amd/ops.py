@@ -122,18 +122,11 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
 
 
 def kb_inverse(Lop, N):
-    """Dense K_b^-1 [Bt,N,N] from the packed factor: bcbf_potrs on identity columns, 8 at a time (fit path only)."""
+    """Dense K_b^-1 [Bt,N,N] from the packed factor (bcbf_potri; fit path only)."""
+    _chk(Lop)
     Bt = Lop.shape[0]
-    f = dict(dtype=Lop.dtype, device=Lop.device)
-    Kinv = torch.empty(Bt, N, N, **f)
-    UH0, M00 = torch.zeros(Bt, N, 2, **f), torch.zeros(Bt, 2, 8, **f)
-    eye = torch.eye(N, **f)
-    for j0 in range(0, N, 8):
-        w = min(8, N - j0)
-        rhs = torch.zeros(Bt, N, 8, **f)
-        rhs[:, :, :w] = eye[:, j0:j0 + w]
-        _, sol = potrs(Lop, rhs, UH0, M00)
-        Kinv[:, :, j0:j0 + w] = sol[:, :, :w]
+    Kinv = torch.empty(Bt, N, N, dtype=Lop.dtype, device=Lop.device)
+    check(getattr(lib, "bcbf_potri" + _suf(Lop))(_p(Lop), _p(Kinv), Bt, N, _stream(Lop)), "bcbf_potri")
     return Kinv
 
 

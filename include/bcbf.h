@@ -123,10 +123,15 @@ int bcbf_gp_append_f64(const double* Lop_in, const double* Vw_in, const double* 
                        double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
                        void* stream);
 
+/* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
+ * 8 columns. */
+int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream);
+int bcbf_potri_f64(const double* Lop, double* Kinv, int Bt, int N, void* stream);
+
 /* K12 -- hyper-parameter fit support (ControlAffineRegressor.fit, control_affine_model.py:268-335):
  * the O(N^2) sums of the gradient of  log p(Y) = -1/2 tr(A^-1 R'K_b^-1 R) - n/2 logdet K_b - N/2 logdet A - Nn/2 log 2pi
  * (R = Xdot - UH M0) with respect to the data-kernel parameters and B, for given alpha = K_b^-1 R [Bt,N,n] (bcbf_potrs)
- * and dense K_b^-1 [Bt,N,N] (bcbf_potrs on identity columns):
+ * and dense K_b^-1 [Bt,N,N] (bcbf_potri):
  *   g_ell[Bt,n] = d/d ell, g_s2[Bt] = d/d s2, g_B[Bt,C,C] = d/dB (B treated as unconstrained, symmetric result),
  *   logdetK[Bt], RtA[Bt,n,n] = R'alpha, UHtA[Bt,C,n] = UH'alpha  (value, d/dA and d/dM0 follow on the host from these). */
 int bcbf_mll_grad_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,

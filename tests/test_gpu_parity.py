@@ -564,3 +564,20 @@ def test_online_gp_append_equals_refit(ops, dtype):
     if dtype == torch.float64:
         rel_close(host(Lop), host(Lop_r), 1e-8, what="Lop")
         rel_close(host(Vw), host(Vw_r), 1e-8, what="Vw")
+
+
+@pytest.mark.parametrize("dtype,N", [(torch.float64, 100), (torch.float64, 256), (torch.float32, 64)])
+def test_potri_dense_inverse(ops, dtype, N):
+    """bcbf_potri: K_b^-1 from the packed factor (ragged N: the last column chunk is partial)."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    p = make_instances(3, N, 3, 2, dtype=dtype, device=DEV, seed=21)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert (info == 0).all()
+    Kinv = ops.kb_inverse(Lop, N)
+    Kb = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    eye = torch.eye(N, dtype=torch.float64, device=DEV)
+    res = (Kb.double() @ Kinv.double() - eye).abs().max()
+    # K_b is ill conditioned (cond ~ 1e5..1e8 with the 1e-5 jitter): residual relative to |K_b| |K_b^-1|
+    scale = float(Kb.double().abs().max() * Kinv.double().abs().max())
+    assert float(res) <= (1e-10 if dtype == torch.float64 else 2e-3) * max(scale, 1.0), (float(res), scale)
+    assert float((Kinv - Kinv.transpose(1, 2)).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-1) * float(Kinv.abs().max())
