@@ -293,8 +293,10 @@ class ControlAffineRegressor:
             if ntry == cholesky_tries - 1:
                 raise RuntimeError("cholesky: pivot %d is not positive after %d jitter retries" % (int(info[0]), cholesky_tries))
             factor = factor * cholesky_perturb_scale
-        Vw, alpha = ops.potrs(Lop, self.XdotTrain[None], UH, hp["M0"])
-        st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, alpha=alpha, N=N, jitter=jitter[None].contiguous())
+        # only the whitened targets Vw = L^-1 Y enter the posterior (alpha = K_b^-1 Y is the fit's business): skip
+        # the backward substitution
+        Vw, _ = ops.potrs(Lop, self.XdotTrain[None], UH, hp["M0"], want_alpha=False)
+        st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, N=N, jitter=jitter[None].contiguous())
         self._cache["state"] = st
         return st
 
@@ -497,7 +499,7 @@ class BatchedControlAffineGP:
             factor *= 10       # x10 on the failing instances only (make_psd protocol, per instance)
             jit = torch.where(bad[:, None], factor * draw(), jit)
         self.jitter = jit
-        self.Vw, self.alpha = ops.potrs(self.Lop, self.Xdot, self.UH, self.M0)
+        self.Vw, _ = ops.potrs(self.Lop, self.Xdot, self.UH, self.M0, want_alpha=False)
         return self
 
     def posterior(self, xq, jitter2=None, out=None):

@@ -30,8 +30,10 @@ __device__ inline float rlane(float v, int lane) {
 #ifndef BCBF_R32_OCC
 #define BCBF_R32_OCC 4
 #endif
-template <bool FROM_DENSE>
-__global__ void __launch_bounds__(MT, BCBF_R32_OCC)
+// NW waves per workgroup: 4 for batches (several workgroups per CU), more when only a few instances are in flight
+// (one GP at a time, the reference's own use): the row tiles of a block column then run side by side.
+template <bool FROM_DENSE, int NW>
+__global__ void __launch_bounds__(64 * NW, (NW == 4 ? BCBF_R32_OCC : 1))
 refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, const float* __restrict__ Bm,
                   const float* __restrict__ ell, const float* __restrict__ s2p, const float* __restrict__ jitter,
                   const float* __restrict__ Kdense, float* __restrict__ Lop, float* __restrict__ UHBout,
@@ -44,6 +46,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
     __shared__ float idg[NB];                                // 1 / L_JJ[c][c]
     __shared__ int fail;
 
+    constexpr int MTT = 64 * NW;                              // threads
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
@@ -60,7 +63,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
 #pragma unroll
         for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a)
             Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : 0.f;
-        for (int i = tid; i < N; i += MT)
+        for (int i = tid; i < N; i += MTT)
             for (int c = 0; c < C; ++c) {
                 float s = 0.f;
                 for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
@@ -69,18 +72,18 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
     }
     if (tid == 0) fail = 0;
     if (Ld)
-        for (int e = tid; e < N * N; e += MT) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.f; }
+        for (int e = tid; e < N * N; e += MTT) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.f; }
     __syncthreads();
 
     const int nblk = Np / NB;
     for (int J = 0; J < nblk; ++J) {
         const int col0 = J * NB;
         if (!FROM_DENSE) {
-            for (int e = tid; e < NB * n; e += MT) {
+            for (int e = tid; e < NB * n; e += MTT) {
                 const int c = e / n, d = e - c * n;
                 colX[c][d] = (col0 + c < N) ? Xb[(size_t)(col0 + c) * n + d] : 0.f;
             }
-            for (int e = tid; e < NB * C; e += MT) {
+            for (int e = tid; e < NB * C; e += MTT) {
                 const int c = e / C, a = e - c * C;
                 colUH[c][a] = (col0 + c < N) ? UHb[(size_t)(col0 + c) * C + a] : 0.f;
             }
@@ -90,8 +93,8 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
         // Tile schedule.  Group 0: wave 0 takes ONLY the diagonal tile, then factors and inverts it while
         // waves 1-3 run the updates of tiles 1 .. 3*MAXT -- the serial factorization hides behind their MFMA
         // streams.  Later groups: the remaining tiles round-robin over all four waves, MAXT per wave.
-        const int first = 1 + 3 * MAXT;
-        const int ngroups = ntile <= first ? 1 : 1 + (ntile - first + 4 * MAXT - 1) / (4 * MAXT);
+        const int first = 1 + (NW - 1) * MAXT;
+        const int ngroups = ntile <= first ? 1 : 1 + (ntile - first + NW * MAXT - 1) / (NW * MAXT);
         for (int g = 0; g < ngroups; ++g) {                      // uniform trip count: barrier (B) is inside
             f32x16 acc[MAXT];
             int irow[MAXT], tix[MAXT];
@@ -99,8 +102,8 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
 #pragma unroll
             for (int q = 0; q < MAXT; ++q) {
                 int t;
-                if (g == 0) t = wave == 0 ? (q == 0 ? 0 : ntile) : 1 + (wave - 1) + 3 * q;
-                else t = first + (g - 1) * 4 * MAXT + wave + 4 * q;
+                if (g == 0) t = wave == 0 ? (q == 0 ? 0 : ntile) : 1 + (wave - 1) + (NW - 1) * q;
+                else t = first + (g - 1) * NW * MAXT + wave + NW * q;
                 tix[q] = t;
                 const int I = J + t;
                 live[q] = t < ntile;
@@ -258,13 +261,19 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
+    const bool wide = Bt < 128 && N > 512;   // few large instances: 16 waves per workgroup (measured: 3.1 -> 2.6 ms at N=1024, Bt=1)
+#define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
+    do {                                                                                                \
+        if (wide) hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 16>), dim3(Bt), dim3(1024), __VA_ARGS__);              \
+        else hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 4>), dim3(Bt), dim3(256), __VA_ARGS__);                     \
+    } while (0)
     if (Kdense) {
-        hipLaunchKernelGGL((refit_mfma_kernel<true>), dim3(Bt), dim3(MT), 0, st, nullptr, nullptr, nullptr, nullptr,
+        BCBF_REFIT_LAUNCH(true, 0, st, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
     } else {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
-        hipLaunchKernelGGL((refit_mfma_kernel<false>), dim3(Bt), dim3(MT), 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
+        BCBF_REFIT_LAUNCH(false, 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
                            Lop, UHB, Ldense, info, N, Np, n, m + 1);
     }
     return check_launch("refit_mfma");

@@ -44,8 +44,10 @@ __device__ inline double rsqrt_nr(double p) {
     return y;
 }
 
-template <bool FROM_DENSE>
-__global__ void __launch_bounds__(MT64, BCBF_R64_OCC)
+// NW waves per workgroup: 4 for batches (several workgroups per CU), more when only a few instances are in flight
+// (one GP at a time, the reference's own use): the row tiles of a block column then run side by side.
+template <bool FROM_DENSE, int NW>
+__global__ void __launch_bounds__(64 * NW, (NW == 4 ? BCBF_R64_OCC : 2))
 refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH, const double* __restrict__ Bm,
                     const double* __restrict__ ell, const double* __restrict__ s2p, const double* __restrict__ jitter,
                     const double* __restrict__ Kdense, double* __restrict__ Lop, double* __restrict__ UHBout,
@@ -58,6 +60,7 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
     __shared__ double idg[NB];                               // 1 / L_JJ[c][c]
     __shared__ int fail;
 
+    constexpr int MTT = 64 * NW;                              // threads
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, j16 = lane & 15, g = lane >> 4;
     double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
@@ -74,7 +77,7 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 #pragma unroll
         for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a)
             Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : 0.0;
-        for (int i = tid; i < N; i += MT64)
+        for (int i = tid; i < N; i += MTT)
             for (int c = 0; c < C; ++c) {
                 double s = 0.0;
                 for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
@@ -83,18 +86,18 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
     }
     if (tid == 0) fail = 0;
     if (Ld)
-        for (int e = tid; e < N * N; e += MT64) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.0; }
+        for (int e = tid; e < N * N; e += MTT) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.0; }
     __syncthreads();
 
     const int nblk = Np / NB;
     for (int J = 0; J < nblk; ++J) {
         const int col0 = J * NB;
         if (!FROM_DENSE) {
-            for (int e = tid; e < NB * n; e += MT64) {
+            for (int e = tid; e < NB * n; e += MTT) {
                 const int c = e / n, d = e - c * n;
                 colX[c][d] = (col0 + c < N) ? Xb[(size_t)(col0 + c) * n + d] : 0.0;
             }
-            for (int e = tid; e < NB * C; e += MT64) {
+            for (int e = tid; e < NB * C; e += MTT) {
                 const int c = e / C, a = e - c * C;
                 colUH[c][a] = (col0 + c < N) ? UHb[(size_t)(col0 + c) * C + a] : 0.0;
             }
@@ -103,8 +106,8 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
         const int ntile = nblk - J;                          // row tiles I = J .. nblk-1
         // Tile schedule (as refit_mfma.hip).  Group 0: wave 0 takes ONLY the diagonal tile, then factors and inverts
         // it while waves 1-3 run the updates of tiles 1 .. 3*MAXT64.  Later groups: round-robin over all four waves.
-        const int first = 1 + 3 * MAXT64;
-        const int ngroups = ntile <= first ? 1 : 1 + (ntile - first + 4 * MAXT64 - 1) / (4 * MAXT64);
+        const int first = 1 + (NW - 1) * MAXT64;
+        const int ngroups = ntile <= first ? 1 : 1 + (ntile - first + NW * MAXT64 - 1) / (NW * MAXT64);
         for (int gq = 0; gq < ngroups; ++gq) {                   // uniform trip count: barrier (B) is inside
             f64x4 acc[MAXT64][2][2];                             // [slot][cb][ib]
             int irow[MAXT64], tix[MAXT64];
@@ -112,8 +115,8 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 #pragma unroll
             for (int q = 0; q < MAXT64; ++q) {
                 int t;
-                if (gq == 0) t = wave == 0 ? (q == 0 ? 0 : ntile) : 1 + (wave - 1) + 3 * q;
-                else t = first + (gq - 1) * 4 * MAXT64 + wave + 4 * q;
+                if (gq == 0) t = wave == 0 ? (q == 0 ? 0 : ntile) : 1 + (wave - 1) + (NW - 1) * q;
+                else t = first + (gq - 1) * NW * MAXT64 + wave + NW * q;
                 tix[q] = t;
                 live[q] = t < ntile;
                 irow[q] = (live[q] ? (J + t) * NB : col0) + j16;    // + 16*ib; dead slots shadow the diagonal tile (no stores)
@@ -307,13 +310,19 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
+    const bool wide = Bt < 128 && N >= 512;  // few large instances: 8 waves per workgroup (16 would cap the VGPRs at 128: spills)
+#define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
+    do {                                                                                                \
+        if (wide) hipLaunchKernelGGL((refit_mfma64_kernel<DENSE, 8>), dim3(Bt), dim3(512), __VA_ARGS__);                \
+        else hipLaunchKernelGGL((refit_mfma64_kernel<DENSE, 4>), dim3(Bt), dim3(256), __VA_ARGS__);                     \
+    } while (0)
     if (Kdense) {
-        hipLaunchKernelGGL((refit_mfma64_kernel<true>), dim3(Bt), dim3(MT64), 0, st, nullptr, nullptr, nullptr, nullptr,
+        BCBF_REFIT_LAUNCH(true, 0, st, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
     } else {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
-        hipLaunchKernelGGL((refit_mfma64_kernel<false>), dim3(Bt), dim3(MT64), 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
+        BCBF_REFIT_LAUNCH(false, 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
                            Lop, UHB, Ldense, info, N, Np, n, m + 1);
     }
     return check_launch("refit_mfma64");
