@@ -11,6 +11,7 @@
 // Everything a lane needs stays in registers; 64 instances x 4 lanes = 4 waves per 64 instances, so a
 // 4096-instance batch is 256 waves instead of 64.
 #include "bcbf_common.h"
+#include "unicycle_task.h"
 
 namespace bcbf {
 
@@ -211,7 +212,10 @@ __device__ inline void chol3_solve(const double (*H)[NV], double* b) {
 }
 
 // FROM_TERMS: build the cone rows from the GP posterior (cbc_terms fused); else read packed cones.
-template <typename T, int M_, bool FROM_TERMS>
+// UNI (with FROM_TERMS, n = 3, m = 2): the unicycle step in one launch -- each lane also forms its own task row
+// (CLC / obstacle k-1: unicycle_task.h) from the state instead of reading grad/cst/fhat/ghat, and lane 0 advances the
+// plant with the solution (explicit Euler, unicycle_move_to_pose.py:277-282).
+template <typename T, int M_, bool FROM_TERMS, bool UNI>
 __global__ void __launch_bounds__(64)
 socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __restrict__ cones_in,
                  const T* __restrict__ relax_mask, const T* __restrict__ rho,
@@ -220,7 +224,8 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
                  const T* __restrict__ grad, const T* __restrict__ cst, const T* __restrict__ sign,
                  const T* __restrict__ fhat, const T* __restrict__ ghat, int n,
                  T* __restrict__ terms_out, T* __restrict__ cones_out, int* __restrict__ cstatus,
-                 T* __restrict__ y, int* __restrict__ status, int* __restrict__ iters, int Bt, int K, int max_iters) {
+                 T* __restrict__ y, int* __restrict__ status, int* __restrict__ iters, int Bt, int K, int max_iters,
+                 UnicycleTask<T> task) {
     using R = T;
     constexpr int NV = M_ + 1, D = M_ + 2, C = M_ + 1;
     constexpr int Q = (M_ + 1) * M_ + (M_ + 1) + M_ + 1;
@@ -242,25 +247,48 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
             const T* Mkb = Mk + (size_t)bb * n * C;
             const T* Bkb = Bk + (size_t)bb * C * C;
             const T* Ab = A + (size_t)bb * n * n;
-            const T* g = grad + ((size_t)bb * K + kk) * n;
             const double sg = (double)sign[kk];
             double gd[BCBF_MAX_STATE_DIM];
+            T urow[3], ucst = T(0), uG[3][2];          // UNI: this lane's task row and the prior input matrix
+            if (UNI) {
+                const T px = task.x[(size_t)bb * 3], py = task.x[(size_t)bb * 3 + 1], th = task.x[(size_t)bb * 3 + 2];
+                unicycle_row<T>(kk, px, py, th, task.plan + (size_t)bb * 3, task.dot_plan + (size_t)bb * 3, task.Kp,
+                                task.clf_gamma, task.centers + (size_t)bb * task.Kob * 2, task.radii + (size_t)bb * task.Kob,
+                                task.tw, task.gammas, urow, ucst);
+                ackermann_g<T>(th, task.L_mean, uG);
 #pragma unroll
-            for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gd[d] = d < n ? (double)g[d] : 0.0;
+                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gd[d] = d < 3 ? (double)urow[d < 3 ? d : 0] : 0.0;
+                if (inst_ok && active && task.grad != nullptr) {
+                    for (int d = 0; d < 3; ++d) task.grad[((size_t)b * K + k) * 3 + d] = urow[d];
+                    task.cst[(size_t)b * K + k] = ucst;
+                    if (k == 0)
+                        for (int d = 0; d < 3; ++d) {
+                            task.fhat[(size_t)b * 3 + d] = T(0);
+                            task.ghat[((size_t)b * 3 + d) * 2] = uG[d][0];
+                            task.ghat[((size_t)b * 3 + d) * 2 + 1] = uG[d][1];
+                        }
+                }
+            } else {
+                const T* g = grad + ((size_t)bb * K + kk) * n;
+#pragma unroll
+                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gd[d] = d < n ? (double)g[d] : 0.0;
+            }
             double a_h = 0.0;
             for (int d = 0; d < n; ++d) {
                 double t = 0.0;
                 for (int e2 = 0; e2 < n; ++e2) t += (double)Ab[d * n + e2] * gd[e2];
                 a_h += gd[d] * t;
             }
-            double e = (double)cst[(size_t)bb * K + kk];
-            for (int d = 0; d < n; ++d) e += gd[d] * ((double)fhat[(size_t)bb * n + d] + (double)Mkb[d * C]);
+            double e = UNI ? (double)ucst : (double)cst[(size_t)bb * K + kk];
+            for (int d = 0; d < n; ++d) e += gd[d] * ((UNI ? 0.0 : (double)fhat[(size_t)bb * n + d]) + (double)Mkb[d * C]);
             e *= sg;
             double bfe[M_], Asq[C][C], L[C][C];
 #pragma unroll
             for (int i = 0; i < M_; ++i) {
                 double s_ = 0.0;
-                for (int d = 0; d < n; ++d) s_ += ((double)ghat[((size_t)bb * n + d) * M_ + i] + (double)Mkb[d * C + 1 + i]) * gd[d];
+                for (int d = 0; d < n; ++d)
+                    s_ += ((UNI ? (double)uG[d < 3 ? d : 0][i < 2 ? i : 0] : (double)ghat[((size_t)bb * n + d) * M_ + i]) +
+                           (double)Mkb[d * C + 1 + i]) * gd[d];
                 bfe[i] = sg * s_;
             }
 #pragma unroll
@@ -562,6 +590,13 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
         for (int i = 0; i < NV; ++i) y[(size_t)b * NV + i] = (T)x[i];
         status[b] = st_code;
         if (iters) iters[b] = it;
+        if (UNI && task.dt > T(0)) {             // plant step with y = [u0, u1, relax] (as stored: rounded to T)
+            T* xs = task.x + (size_t)b * 3;
+            const T th = xs[2], u0 = (T)x[0], u1 = (T)x[1];
+            xs[0] += cos(th) * u0 * task.dt;
+            xs[1] += sin(th) * u0 * task.dt;
+            xs[2] += u1 / task.L_true * task.dt;
+        }
     }
 }
 
@@ -569,11 +604,16 @@ template <typename T, bool FROM_TERMS>
 static int launch_quad(const T* w, const T* r, const T* cones_in, const T* relax_mask, const T* rho, const T* Mk,
                        const T* Bk, const T* A, const T* grad, const T* cst, const T* sign, const T* fhat,
                        const T* ghat, int n, T* terms_out, T* cones_out, int* cstatus, T* y, int* status, int* iters,
-                       int Bt, int K, int m, int max_iters, void* stream) {
+                       int Bt, int K, int m, int max_iters, void* stream, const UnicycleTask<T>* task = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!w || !r || !relax_mask || !rho || !y || !status) return BCBF_EINVAL;
     if (K < 1 || K > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
-    if (FROM_TERMS) {
+    if (FROM_TERMS && task != nullptr) {
+        if (!Mk || !Bk || !A || !sign || n != 3 || m != 2 || K != 1 + task->Kob || !task->x || !task->plan ||
+            !task->dot_plan || !task->Kp || (task->Kob > 0 && (!task->centers || !task->radii || !task->tw || !task->gammas)))
+            return BCBF_EINVAL;
+        if (task->grad != nullptr && (!task->cst || !task->fhat || !task->ghat)) return BCBF_EINVAL;
+    } else if (FROM_TERMS) {
         if (!Mk || !Bk || !A || !grad || !cst || !sign || !fhat || !ghat || n < 1 || n > BCBF_MAX_STATE_DIM) return BCBF_EINVAL;
     } else if (!cones_in) return BCBF_EINVAL;
     if (max_iters <= 0) max_iters = 100;
@@ -581,7 +621,13 @@ static int launch_quad(const T* w, const T* r, const T* cones_in, const T* relax
     const long lanes = (long)Bt * 4;
     dim3 grid((unsigned)((lanes + threads - 1) / threads)), block(threads);
     hipStream_t st = (hipStream_t)stream;
-#define BCBF_Q(MM) hipLaunchKernelGGL((socp_quad_kernel<T, MM, FROM_TERMS>), grid, block, 0, st, w, r, cones_in, relax_mask, rho, Mk, Bk, A, grad, cst, sign, fhat, ghat, n, terms_out, cones_out, cstatus, y, status, iters, Bt, K, max_iters)
+    if (FROM_TERMS && task != nullptr) {
+        hipLaunchKernelGGL((socp_quad_kernel<T, 2, FROM_TERMS, FROM_TERMS>), grid, block, 0, st, w, r, cones_in, relax_mask,
+                           rho, Mk, Bk, A, grad, cst, sign, fhat, ghat, n, terms_out, cones_out, cstatus, y, status, iters,
+                           Bt, K, max_iters, *task);
+        return check_launch("unicycle_socp");
+    }
+#define BCBF_Q(MM) hipLaunchKernelGGL((socp_quad_kernel<T, MM, FROM_TERMS, false>), grid, block, 0, st, w, r, cones_in, relax_mask, rho, Mk, Bk, A, grad, cst, sign, fhat, ghat, n, terms_out, cones_out, cstatus, y, status, iters, Bt, K, max_iters, UnicycleTask<T>{})
     switch (m) {
         case 1: BCBF_Q(1); break;
         case 2: BCBF_Q(2); break;
@@ -591,6 +637,21 @@ static int launch_quad(const T* w, const T* r, const T* cones_in, const T* relax
 #undef BCBF_Q
     return check_launch("socp_quad");
 }
+
+// internal entry of the fused unicycle step (control_step.hip)
+template <typename T>
+int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, const T* w, const T* r, const T* relax_mask,
+                         const T* rho, T* cones, int* cstatus, T* y, int* status, int* iters, int Bt, int max_iters,
+                         const UnicycleTask<T>& task, void* stream) {
+    return launch_quad<T, true>(w, r, nullptr, relax_mask, rho, Mk, Bk, A, nullptr, nullptr, sign, nullptr, nullptr, 3,
+                                nullptr, cones, cstatus, y, status, iters, Bt, 1 + task.Kob, 2, max_iters, stream, &task);
+}
+template int launch_unicycle_socp<float>(const float*, const float*, const float*, const float*, const float*, const float*,
+                                         const float*, const float*, float*, int*, float*, int*, int*, int, int,
+                                         const UnicycleTask<float>&, void*);
+template int launch_unicycle_socp<double>(const double*, const double*, const double*, const double*, const double*,
+                                          const double*, const double*, const double*, double*, int*, double*, int*, int*,
+                                          int, int, const UnicycleTask<double>&, void*);
 
 }  // namespace bcbf
 
