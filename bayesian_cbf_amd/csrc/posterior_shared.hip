@@ -37,9 +37,6 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
                         const float* __restrict__ jitter2, float* __restrict__ Mk, float* __restrict__ Bk,
                         float* __restrict__ Wout, int nq, int N, int Np, int n) {
     constexpr int V = 4, QW = 4;                      // queries per wave
-#ifdef BCBF_PSH_PROFILE
-    const long long t_start = clock64();
-#endif
     extern __shared__ float smem[];
     const int nwave = blockDim.x >> 6, wave = threadIdx.x >> 6;
     float* Xs = smem;                                 // [Np][NS]  (state dim padded to NS with zeros)
@@ -162,12 +159,8 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int cs = 2 * (s & 3) + (s >> 2);                            // blk_row(u, 0, r)
-#ifdef BCBF_PSH_ABL_NOLOAD
-            a[s] = make_float2(1e-3f * (cs + Il), 1e-3f * j);
-#else
             const u32x2s v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, off[cs], 0);
             a[s] = __builtin_bit_cast(float2, v);
-#endif
         }
         const bool adv = Kl < Il;
         lbase = adv ? lbase + NB * lstride - NB : 0;
@@ -182,10 +175,6 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
     };
 
     int I = 0, K = 0;                                 // compute cursor
-#ifdef BCBF_PSH_PROFILE
-    const long long t_begin = clock64();
-    long long t_diag = 0, t_first = 0;
-#endif
     // One step = consume the oldest tile in flight, refill the slot behind it, fetch the B rows of the next
     // off-diagonal tile.  Two shapes, each ONE basic block so that the scheduler can place the loads and the cursor
     // arithmetic in the shadow of the MFMAs (a lone wave issues one instruction per 4 cycles):
@@ -195,16 +184,11 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
     auto off_step = [&](const float2 (&a)[8], float2 (&fill)[8], const float (&bc)[8], float (&bn)[8]) {
         issue(fill);
         load_b(bn, K + 1 < I ? K + 1 : 0);            // W_0 after the diagonal step
-#ifndef BCBF_PSH_ABL_NOOFF
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, bc[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, bc[s], acc1, 0, 0, 0);
         }
-#else
-        acc0[0] += a[0].x * bc[0]; acc1[0] += a[0].y * bc[7];
-#endif
-#ifndef BCBF_PSH_NOSCHED
 #pragma unroll
         for (int s = 0; s < 16; ++s) {                // one MFMA, then a slice of everything else
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -212,7 +196,6 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
         }
-#endif
         ++K;
     };
     auto diag_step = [&](const float2 (&a)[8], float2 (&fill)[8], float (&bn)[8]) {
@@ -227,7 +210,6 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
                                                       //  the branch by the compiler, out of the MFMA shadow)
         epilogue(I - 1);                              // pend = W_{I-1} (zeros for I = 0)
         phi_tile(I + 1);                              // into phin (past the last block: staged garbage, never used)
-#ifndef BCBF_PSH_NOSCHED
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -235,7 +217,6 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x006, 10, 0);
         }
-#endif
         float* wi = Wl + (size_t)I * NB * 16;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -259,16 +240,11 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) { phi[e] = phin[e]; pend[e] = 0.f; B0[e] = 0.f; B1[e] = 0.f; }
     issue(A0); issue(A1); issue(A2);
-#ifdef BCBF_PSH_PROFILE
-#define BCBF_PSH_TIMED(var, expr) { const long long t0_ = clock64(); expr; var += clock64() - t0_; }
-#else
-#define BCBF_PSH_TIMED(var, expr) { expr; }
-#endif
 #define BCBF_PSH_STEP(cur, fill, bc, bn)                                                     \
     if (K < I) {                                                                             \
         off_step(cur, fill, bc, bn);                                                         \
     } else {                                                                                 \
-        BCBF_PSH_TIMED(t_diag, diag_step(cur, fill, bn))                                     \
+        diag_step(cur, fill, bn);                                                            \
         if (I >= nblk) break;                                                                \
     }
     for (;;) {
@@ -278,11 +254,7 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
         BCBF_PSH_STEP(A3, A2, B1, B0)
     }
 #undef BCBF_PSH_STEP
-#undef BCBF_PSH_TIMED
     epilogue(nblk - 1);
-#ifdef BCBF_PSH_PROFILE
-    const long long t_total = clock64() - t_begin;
-#endif
 
     // ---- the four lane groups hold different rows: combine, then write Mk[q][d][c], Bk[q][c][a]
 #pragma unroll
@@ -300,11 +272,6 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
             Bk[((size_t)q * C + c) * C + a] = v;
         }
     }
-#ifdef BCBF_PSH_PROFILE
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Bk[0] = (float)(t_begin - t_start); Bk[1] = (float)t_total; Bk[2] = (float)(clock64() - t_start); Bk[3] = (float)t_diag; Bk[4] = (float)t_first;
-    }
-#endif
 }
 
 static int padded_state_dim(int n) { return n <= 4 ? n : (n <= 6 ? 6 : 8); }

@@ -20,11 +20,13 @@ template <> struct QTol<double> {
     static __device__ inline double feas() { return 1e-9; }
     static __device__ inline double gap() { return 1e-9; }
     static __device__ inline double accept() { return 1e-7; }
+    static __device__ inline double infeas() { return 1e-8; }
 };
 template <> struct QTol<float> {
     static __device__ inline float feas() { return 2e-5f; }
     static __device__ inline float gap() { return 1e-6f; }
     static __device__ inline float accept() { return 2e-4f; }
+    static __device__ inline float infeas() { return 1e-5f; }
 };
 
 __device__ inline float qdv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
@@ -498,6 +500,17 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
                 for (int i = 0; i < NV; ++i) xbest[i] = x[i];
             }
             if (stall >= 3 && best <= QTol<R>::accept()) break;
+        }
+        {
+            // Certificate of primal infeasibility (z in K*, G'z = 0, h'z < 0; cvxopt's conelp test pinfres): on an
+            // infeasible program z runs off along such a ray, so the instance can leave long before the iteration cap
+            R hz = 0, gzn = 0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) hz += h[a] * cone.z[a];
+            hz = quad_sum(active ? hz : R(0));
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gzn += gz[i] * gz[i];
+            if (hz < R(0) && qsq(gzn) <= QTol<R>::infeas() * resx0 * (-hz)) { st_code = BCBF_SOCP_DIVERGED; break; }
         }
         R xmax = 0;
 #pragma unroll
