@@ -245,7 +245,9 @@ def main():
                        "regime": "shared GP (S)", "inputs": args.variant, "streams": S,
                        "parallelism": "closed loops sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
-            "roofline": {"bound": "mfma", "kernel": "posterior_shared_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "posterior_shared_kernel" if args.dtype == "f32" and N <= 1536 else
+                         "posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernel is fp32, N <= ~1600)",
+                         "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops_launch,
                          "queries_per_launch": Bc},
