@@ -173,6 +173,15 @@ struct ConeLane {
     }
 };
 
+// 1/sqrt(d) in double: hardware estimate + two Newton steps (a divide or a sqrt in fp64 is a ~15-instruction dependent
+// chain, and the reduced KKT system is factored and solved twice per iteration)
+__device__ inline double rsqrt_d(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    return y;
+}
+// Cholesky H = L L' in place; the diagonal holds 1 / L_jj so that the solves multiply.
 template <int NV>
 __device__ inline bool chol3(double (*H)[NV]) {
     bool ok = true;
@@ -182,8 +191,8 @@ __device__ inline bool chol3(double (*H)[NV]) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) if (k < j) d -= H[j][k] * H[j][k];
         if (!(d > 0.0)) { ok = false; d = 1.0; }
-        const double ljj = __builtin_sqrt(d), il = 1.0 / ljj;
-        H[j][j] = ljj;
+        const double il = rsqrt_d(d);
+        H[j][j] = il;
 #pragma unroll
         for (int i = 0; i < NV; ++i) if (i > j) {
             double v = H[i][j];
@@ -201,7 +210,7 @@ __device__ inline void chol3_solve(const double (*H)[NV], double* b) {
         double v = b[i];
 #pragma unroll
         for (int k = 0; k < NV; ++k) if (k < i) v -= H[i][k] * b[k];
-        b[i] = v / H[i][i];
+        b[i] = v * H[i][i];
     }
 #pragma unroll
     for (int ii = 0; ii < NV; ++ii) {
@@ -209,7 +218,7 @@ __device__ inline void chol3_solve(const double (*H)[NV], double* b) {
         double v = b[i];
 #pragma unroll
         for (int k = 0; k < NV; ++k) if (k > i) v -= H[k][i] * b[k];
-        b[i] = v / H[i][i];
+        b[i] = v * H[i][i];
     }
 }
 
