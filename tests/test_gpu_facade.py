@@ -405,3 +405,17 @@ def test_pendulum_radial_cbf_reldeg2_through_the_jet_kernel():
         truth = L2 + 1.0 * (np.cos(np.pi / 8) - c) + 3.0 * Lfh
         assert abs(float(mean) - truth) <= 0.1 * abs(truth) + 0.1, (float(mean), truth)
         assert float(var) >= 0.0
+
+
+def test_reference_regression_fixture_fit_and_predict():
+    """tests/test_control_affine_regression.py:237-247 on the device: fit + predict on the reference's fixture must not
+    raise and must give finite numbers."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    d = np.load(os.path.join(GOLDEN, "reference_fixture_Xtrain_Utrain_X.npz"))
+    Xtr, Utr, Xt = d["Xtrain"], d["Utrain"], d["X"]
+    torch.manual_seed(0)
+    dgp = ControlAffineRegressor(Xtr.shape[-1], Utr.shape[-1], device=DEV, dtype=torch.float64)
+    dgp.fit(t(Xtr[:-1]), t(Utr), t(Xtr[1:] - Xtr[:-1]))
+    mean, cov = dgp.custom_predict(t(Xt))
+    assert torch.isfinite(mean).all() and torch.isfinite(cov).all()
+    assert len(dgp.fit_losses) == 50 and np.isfinite(dgp.fit_losses).all()
