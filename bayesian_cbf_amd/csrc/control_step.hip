@@ -26,7 +26,8 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
         if (!x || !grad || !cst || !fhat || !ghat || Kob < 0 || Kob + 1 > BCBF_MAX_CONSTRAINTS) return BCBF_EINVAL;    \
         hipStream_t st = (hipStream_t)stream;                                                                          \
         if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);                                                  \
-        int rc = shared_gp ? bcbf_posterior_query_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, \
+        /* Lop == NULL: no learned model in the loop -- (Mk, Bk) are the caller's (fixed-kernel model: 0 and I) */    \
+        int rc = !Lop ? BCBF_OK : shared_gp ? bcbf_posterior_query_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, \
                                                         1, Bt, N, 3, 2, stream)                                        \
                            : bcbf_posterior_step_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, Bt, N, 3, \
                                                        2, stream);                                                     \

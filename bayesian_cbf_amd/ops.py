@@ -371,16 +371,23 @@ def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_g
     """One control step for a batch of unicycle instances in ONE host call
     (ControllerCLFBayesian.control, unicycle_move_to_pose.py:926-995).
 
-    gp:   dict(Lop, Vw, X, UHB, ell, s2, Bm, M0, A);  task: dict(plan, dot_plan, Kp, centers, radii, tw, gammas,
+    gp:   dict(Lop, Vw, X, UHB, ell, s2, Bm, M0, A), or dict(A) alone for the fixed-kernel model (then ws['Mk'], ws['Bk']
+    are inputs: 0 and I);  task: dict(plan, dot_plan, Kp, centers, radii, tw, gammas,
     w, r, sign, relax_mask, rho);  ws: dict of workspaces (grad, cst, fhat, ghat, Mk, Bk, cones, cstatus, y,
     status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y'].
     GP tensors with a leading axis of 1 and Bt > 1 = one learned model shared by all instances (Monte-Carlo
     rollouts of a fixed model): the posterior runs as a shared query (fp32: the matrix-core kernel)."""
-    _chk(x, gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], task["plan"], ws["y"])
-    Bt, N = x.shape[0], gp["X"].shape[1]
-    shared = gp["X"].shape[0] == 1 and Bt > 1
-    if not shared and gp["X"].shape[0] != Bt:
-        raise ValueError("GP tensors must carry a leading axis of 1 (shared model) or Bt")
+    Bt = x.shape[0]
+    if gp.get("Lop") is None:              # fixed-kernel model: ws["Mk"], ws["Bk"] are inputs, gp carries only A
+        _chk(x, gp["A"], task["plan"], ws["y"], ws["Mk"], ws["Bk"])
+        N, shared = 0, False
+        gp = dict(gp, Lop=None, Vw=None, X=None, UHB=None, ell=None, s2=None, Bm=None, M0=None)
+    else:
+        _chk(x, gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], task["plan"], ws["y"])
+        N = gp["X"].shape[1]
+        shared = gp["X"].shape[0] == 1 and Bt > 1
+        if not shared and gp["X"].shape[0] != Bt:
+            raise ValueError("GP tensors must carry a leading axis of 1 (shared model) or Bt")
     A = gp["A"]
     if A.shape[0] != Bt:                     # per-instance kernel matrix A for the fused terms+SOCP kernel
         if ws.get("A_shared_src") is not A:

@@ -50,8 +50,9 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     ws = ops.control_workspace(Bt, 2, dtype, dev)
     if gp is None:
         A = torch.diag(torch.tensor(kernel_diag_A, **f)).expand(Bt, 3, 3).contiguous()
-        Mk0 = torch.zeros(Bt, 3, 3, **f)
-        Bk0 = torch.eye(3, **f).expand(Bt, 3, 3).contiguous()
+        ws["Mk"].zero_()                                   # fixed-kernel model: M_k = 0, B_k = I are inputs of the step
+        ws["Bk"].copy_(torch.eye(3, **f).expand(Bt, 3, 3))
+        fixed = dict(A=A)
     min_h = torch.full((Bt,), float("inf"), **f)
     cost = torch.zeros(Bt, **f)
     fails = torch.zeros(Bt, dtype=torch.int32, device=dev)
@@ -62,20 +63,9 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     for t in range(numSteps):
         task["plan"] = planner.plan(t).to(**f).expand(Bt, 3).contiguous()
         task["dot_plan"] = planner.dot_plan(t).to(**f).expand(Bt, 3).contiguous()
-        if gp is not None:
-            ops.unicycle_control_step(gp, task, ws, x, dt=dt, L_true=L_true, L_mean=L_mean, max_iters=max_iters)
-        else:
-            ops.unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], 10.0, task["centers"], task["radii"],
-                                     task["tw"], task["gammas"], L_mean, out=(ws["grad"], ws["cst"], ws["fhat"], ws["ghat"]))
-            y, status, iters, _, _, _ = ops.cbc_socp(Mk0, Bk0, A, ws["grad"], ws["cst"], task["sign"], ws["fhat"],
-                                                     ws["ghat"], task["w"], task["r"], task["relax_mask"], task["rho"],
-                                                     max_iters=max_iters)
-            ws["y"].copy_(y)
-            ws["status"].copy_(status)
-            bad = status != 0
-            if bool(bad.any()):      # infeasible instances are masked (reference control), not fatal
-                ws["y"][bad] = 0
-            ops.unicycle_step(x, ws["y"][:, :2].contiguous(), dt, L_true)
+        # one host call, two launches (one for the fixed-kernel model: no posterior): rows -> terms -> SOCP -> plant step
+        ops.unicycle_control_step(gp if gp is not None else fixed, task, ws, x, dt=dt, L_true=L_true, L_mean=L_mean,
+                                  max_iters=max_iters)
         # safety bookkeeping: h_k(x_t) = cst_k / gamma_k for the obstacle rows (before the step)
         h = ws["cst"][:, 1:] / gam
         min_h = torch.minimum(min_h, h.min(dim=1).values)

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--max-risk", type=float, default=0.01)
     ap.add_argument("--learned", type=int, default=0, help="N_train of a per-trajectory learned GP (0 = fixed kernel)")
+    ap.add_argument("--shared-learned", type=int, default=0,
+                    help="N_train of ONE learned GP queried by every trajectory (fp32: matrix-core posterior)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
     torch.cuda.set_device(local)
@@ -36,9 +38,17 @@ def main():
         p = make_instances(b - a, args.learned, 3, 2, dtype=torch.float64, device="cuda", seed=100 + rank)
         gp = BatchedControlAffineGP(p["X"], p["U"], 0.05 * p["Xdot"], 1e-2 * p["A"], 1e-2 * p["Bm"], p["ell"], p["s2"],
                                     p["M0"]).as_dict()
+    dtype = torch.float64
+    if args.shared_learned:
+        from bayesian_cbf_amd.control_affine_model import BatchedControlAffineGP
+        from bayesian_cbf_amd.synthetic import make_instances
+        dtype = torch.float32
+        p = make_instances(1, args.shared_learned, 3, 2, dtype=dtype, device="cuda", seed=100)     # same model on every rank
+        gp = BatchedControlAffineGP(p["X"], p["U"], 0.05 * p["Xdot"], 1e-2 * p["A"], 1e-2 * p["Bm"], p["ell"], p["s2"],
+                                    p["M0"]).as_dict()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = monte_carlo_safety_rollouts(b - a, numSteps=args.steps, gp=gp, max_risk=args.max_risk, seed=rank)
+    out = monte_carlo_safety_rollouts(b - a, numSteps=args.steps, gp=gp, max_risk=args.max_risk, seed=rank, dtype=dtype)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if rank == 0:
