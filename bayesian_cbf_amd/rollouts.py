@@ -60,23 +60,32 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     traj = torch.empty(numSteps + 1, Bt, 3, **f) if record else None
     if record:
         traj[0] = x
+    # the whole plan goes to the device once; per step two broadcast copies into the task buffers
+    plan_all = torch.stack([planner.plan(t).to(dtype=dtype) for t in range(numSteps)]).to(dev)
+    dplan_all = torch.stack([planner.dot_plan(t).to(dtype=dtype) for t in range(numSteps)]).to(dev)
+    task["plan"], task["dot_plan"] = torch.empty(Bt, 3, **f), torch.empty(Bt, 3, **f)
+    igam = (1.0 / gam).contiguous()
+    import time
+    torch.cuda.synchronize(dev)
+    t_loop = time.perf_counter()
     for t in range(numSteps):
-        task["plan"] = planner.plan(t).to(**f).expand(Bt, 3).contiguous()
-        task["dot_plan"] = planner.dot_plan(t).to(**f).expand(Bt, 3).contiguous()
+        task["plan"].copy_(plan_all[t])
+        task["dot_plan"].copy_(dplan_all[t])
         # one host call, two launches (one for the fixed-kernel model: no posterior): rows -> terms -> SOCP -> plant step
         ops.unicycle_control_step(gp if gp is not None else fixed, task, ws, x, dt=dt, L_true=L_true, L_mean=L_mean,
                                   max_iters=max_iters)
         # safety bookkeeping: h_k(x_t) = cst_k / gamma_k for the obstacle rows (before the step)
-        h = ws["cst"][:, 1:] / gam
-        min_h = torch.minimum(min_h, h.min(dim=1).values)
-        cost += (task["w"] * ws["y"] ** 2).sum(dim=1)
-        fails += (ws["status"] != 0).to(torch.int32)
+        torch.minimum(min_h, (ws["cst"][:, 1:] * igam).amin(dim=1), out=min_h)
+        cost.add_((task["w"] * ws["y"] * ws["y"]).sum(dim=1))
+        fails.add_(ws["status"] != 0)
         if record:
             traj[t + 1] = x
+    torch.cuda.synchronize(dev)
+    t_loop = time.perf_counter() - t_loop
     collided = (min_h < 0)
     stats = reduce_rollout_stats(collided.sum(), min_h.min(), cost.sum() / numSteps, (fails > 0).sum(), Bt)
     dist_to_goal = (x[:, :2] - xg[:2]).norm(dim=1)
-    return dict(stats=stats, x_final=x, min_h=min_h, dist_to_goal=dist_to_goal, traj=traj)
+    return dict(stats=stats, x_final=x, min_h=min_h, dist_to_goal=dist_to_goal, traj=traj, loop_seconds=t_loop)
 
 
 def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True):

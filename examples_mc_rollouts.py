@@ -52,8 +52,9 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps(dict(trajectories=args.trajectories, steps=args.steps, n_gpus=world, seconds=el,
-                              trajectory_steps_per_s=args.trajectories * args.steps / el, **out["stats"])))
+        print(json.dumps(dict(trajectories=args.trajectories, steps=args.steps, n_gpus=world, seconds=el, loop_seconds=out["loop_seconds"],
+                              trajectory_steps_per_s=args.trajectories * args.steps / el,
+                              trajectory_steps_per_s_loop_only=(b - a) * world * args.steps / out["loop_seconds"], **out["stats"])))
     if world > 1:
         dist.destroy_process_group()
 
