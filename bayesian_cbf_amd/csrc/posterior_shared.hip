@@ -287,15 +287,27 @@ static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, con
                           const float* M0, const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                           int nq, int N, int Np, int n) {
     if (W != nullptr) {
-        if (lds > 64 * 1024)
+        static int lds_opt_in_dev[64] = {0};          // largest dynamic LDS size opted into, per device
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        int& lds_opt_in = lds_opt_in_dev[dev_ & 63];
+        if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
             (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<C, NS, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_opt_in = (int)lds;
+        }
         hipLaunchKernelGGL((posterior_shared_kernel<C, NS, true>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
                            M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
     } else {
-        if (lds > 64 * 1024)
+        static int lds_opt_in_dev[64] = {0};          // largest dynamic LDS size opted into, per device
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        int& lds_opt_in = lds_opt_in_dev[dev_ & 63];
+        if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
             (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<C, NS, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_opt_in = (int)lds;
+        }
         hipLaunchKernelGGL((posterior_shared_kernel<C, NS, false>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
                            M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
     }

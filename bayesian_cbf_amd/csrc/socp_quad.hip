@@ -612,9 +612,9 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
         for (int i = 0; i < NV; ++i) y[(size_t)b * NV + i] = (T)x[i];
         status[b] = st_code;
         if (iters) iters[b] = it;
-        if (UNI && task.dt > T(0) && st_code == BCBF_SOCP_OPTIMAL) {   // plant step with y = [u0, u1, relax] (as stored:
-            T* xs = task.x + (size_t)b * 3;                            // rounded to T); an instance whose program was
-            const T th = xs[2], u0 = (T)x[0], u1 = (T)x[1];            // not solved stays where it is (status says why)
+        if (UNI && task.dt > T(0)) {             // plant step with y = [u0, u1, relax] as stored (rounded to T), whatever
+            T* xs = task.x + (size_t)b * 3;      // the status: a caller that wants unsolved instances masked passes dt = 0
+            const T th = xs[2], u0 = (T)x[0], u1 = (T)x[1];   // and applies bcbf_unicycle_step to the controls it accepts
             xs[0] += cos(th) * u0 * task.dt;
             xs[1] += sin(th) * u0 * task.dt;
             xs[2] += u1 / task.L_true * task.dt;

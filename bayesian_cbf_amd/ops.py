@@ -366,17 +366,8 @@ def unicycle_step(x, u, dt, L_true):
     return x
 
 
-def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,
-                          ev_start=None, ev_stop=None):
-    """One control step for a batch of unicycle instances in ONE host call
-    (ControllerCLFBayesian.control, unicycle_move_to_pose.py:926-995).
-
-    gp:   dict(Lop, Vw, X, UHB, ell, s2, Bm, M0, A), or dict(A) alone for the fixed-kernel model (then ws['Mk'], ws['Bk']
-    are inputs: 0 and I);  task: dict(plan, dot_plan, Kp, centers, radii, tw, gammas,
-    w, r, sign, relax_mask, rho);  ws: dict of workspaces (grad, cst, fhat, ghat, Mk, Bk, cones, cstatus, y,
-    status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y'].
-    GP tensors with a leading axis of 1 and Bt > 1 = one learned model shared by all instances (Monte-Carlo
-    rollouts of a fixed model): the posterior runs as a shared query (fp32: the matrix-core kernel)."""
+def _control_step_args(gp, task, ws, x):
+    """Argument checks shared by the two forms below: returns (gp with every key present, A[Bt,n,n], N, shared)."""
     Bt = x.shape[0]
     if gp.get("Lop") is None:              # fixed-kernel model: ws["Mk"], ws["Bk"] are inputs, gp carries only A
         _chk(x, gp["A"], task["plan"], ws["y"], ws["Mk"], ws["Bk"])
@@ -393,19 +384,50 @@ def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_g
         if ws.get("A_shared_src") is not A:
             ws["A_shared"], ws["A_shared_src"] = A.expand(Bt, *A.shape[1:]).contiguous(), A
         A = ws["A_shared"]
+    return gp, A, N, shared
+
+
+def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,
+                          ev_start=None, ev_stop=None):
+    """One control step for a batch of unicycle instances in ONE host call
+    (ControllerCLFBayesian.control, unicycle_move_to_pose.py:926-995).
+
+    gp:   dict(Lop, Vw, X, UHB, ell, s2, Bm, M0, A), or dict(A) alone for the fixed-kernel model (then ws['Mk'], ws['Bk']
+    are inputs: 0 and I);  task: dict(plan, dot_plan, Kp, centers, radii, tw, gammas,
+    w, r, sign, relax_mask, rho);  ws: dict of workspaces (grad, cst, fhat, ghat, Mk, Bk, cones, cstatus, y,
+    status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y'].
+    GP tensors with a leading axis of 1 and Bt > 1 = one learned model shared by all instances (Monte-Carlo
+    rollouts of a fixed model): the posterior runs as a shared query (fp32: the matrix-core kernel)."""
+    return unicycle_control_step_prepare(gp, task, ws, x, dt, L_true, L_mean, clf_gamma, max_iters)(ev_start, ev_stop)
+
+
+def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100):
+    """Bind every argument of `unicycle_control_step` once and return `step(ev_start=None, ev_stop=None)`.
+    A closed loop calls the same entry point with the same buffers thousands of times; converting ~40 tensors to
+    pointers per call costs more host time than the two launches take on the device for small batches.  The tensors
+    must keep their storage (update them in place); the closure keeps them alive."""
+    gp, A, N, shared = _control_step_args(gp, task, ws, x)
+    Bt = x.shape[0]
     Kob = task["centers"].shape[1]
-    ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
-    ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
-    check(getattr(lib, "bcbf_unicycle_control_step" + _suf(x))(
-        _p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
-        _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
-        _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
-        _p(task["r"]), _p(task["sign"]), _p(task["relax_mask"]), _p(task["rho"]), _p(ws["grad"]), _p(ws["cst"]),
-        _p(ws["fhat"]), _p(ws["ghat"]), _p(ws["Mk"]), _p(ws["Bk"]), _p(ws["cones"]), _p(ws["cstatus"]), _p(ws["y"]),
-        _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, 1 if shared else 0, ev0, ev1,
-        _stream(x)),
-        "bcbf_unicycle_control_step")
-    return ws["y"]
+    fn = getattr(lib, "bcbf_unicycle_control_step" + _suf(x))
+    head = (_p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
+            _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
+            _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
+            _p(task["r"]), _p(task["sign"]), _p(task["relax_mask"]), _p(task["rho"]), _p(ws["grad"]), _p(ws["cst"]),
+            _p(ws["fhat"]), _p(ws["ghat"]), _p(ws["Mk"]), _p(ws["Bk"]), _p(ws["cones"]), _p(ws["cstatus"]), _p(ws["y"]),
+            _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, 1 if shared else 0)
+    keep = (dict(gp), dict(task), dict(ws), x, A)      # the pointers above are only valid while these live
+    dev, y = x.device, ws["y"]
+
+    def step(ev_start=None, ev_stop=None):
+        ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
+        ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
+        rc = fn(*head, ev0, ev1, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc:
+            check(rc, "bcbf_unicycle_control_step")
+        return y
+    step.keep = keep
+    return step
 
 
 def control_workspace(Bt, Kob, dtype, device, n=3, m=2):

@@ -65,6 +65,8 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     dplan_all = torch.stack([planner.dot_plan(t).to(dtype=dtype) for t in range(numSteps)]).to(dev)
     task["plan"], task["dot_plan"] = torch.empty(Bt, 3, **f), torch.empty(Bt, 3, **f)
     igam = (1.0 / gam).contiguous()
+    step = ops.unicycle_control_step_prepare(gp if gp is not None else fixed, task, ws, x, dt=dt, L_true=L_true,
+                                             L_mean=L_mean, max_iters=max_iters)
     import time
     torch.cuda.synchronize(dev)
     t_loop = time.perf_counter()
@@ -72,8 +74,7 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
         task["plan"].copy_(plan_all[t])
         task["dot_plan"].copy_(dplan_all[t])
         # one host call, two launches (one for the fixed-kernel model: no posterior): rows -> terms -> SOCP -> plant step
-        ops.unicycle_control_step(gp if gp is not None else fixed, task, ws, x, dt=dt, L_true=L_true, L_mean=L_mean,
-                                  max_iters=max_iters)
+        step()
         # safety bookkeeping: h_k(x_t) = cst_k / gamma_k for the obstacle rows (before the step)
         torch.minimum(min_h, (ws["cst"][:, 1:] * igam).amin(dim=1), out=min_h)
         cost.add_((task["w"] * ws["y"] * ws["y"]).sum(dim=1))

@@ -167,11 +167,12 @@ def main():
             self.task = {k: (v[sl] if v.dim() > 0 and v.shape[0] == Bt else v) for k, v in task.items()}
             self.x = task["x"][sl].clone()
             self.ws = ops.control_workspace(Bc, 2, dtype, dev)
+            # one host call per step: constraints -> posterior -> terms -> SOCP -> plant step, on the current stream
+            self._step = ops.unicycle_control_step_prepare(self.gp, self.task, self.ws, self.x, dt=dt_plant, L_true=L_true,
+                                                           L_mean=L_mean, clf_gamma=10.0, max_iters=20)
 
         def step(self, ev0=None, ev1=None):
-            # one host call: constraints -> posterior -> terms -> SOCP -> plant step, on the current stream
-            ops.unicycle_control_step(self.gp, self.task, self.ws, self.x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
-                                      clf_gamma=10.0, max_iters=20, ev_start=ev0, ev_stop=ev1)
+            self._step(ev0, ev1)
 
     chunks = [Chunk(c) for c in range(S)]
     torch.cuda.synchronize()

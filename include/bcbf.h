@@ -275,8 +275,9 @@ int bcbf_unicycle_step_f64(double* x, const double* u, double dt, double L_true,
 /* One host call per control step of ControllerCLFBayesian.control on the unicycle
  * (unicycle_move_to_pose.py:926-995), TWO launches on `stream`: the posterior kernel (n=3, m=2), then one kernel
  * that does what bcbf_unicycle_constraints -> bcbf_cbc_terms (K = 1+Kob, sign[K]) -> bcbf_socp ->
- * x += g(x; L_true) u dt (skipped when dt <= 0, and for instances whose status != 0) do separately (each lane forms
- * its own task row from the state).
+ * x += g(x; L_true) u dt (skipped when dt <= 0; applied with y as stored whatever the status -- mask and step
+ * yourself with dt = 0 + bcbf_unicycle_step if unsolved instances must not move) do separately (each lane forms its
+ * own task row from the state).
  * Arguments are those of the individual entry points; grad/cst/fhat/ghat/Mk/Bk/cones/cstatus are caller-provided
  * workspaces that also expose the intermediates; y[Bt,3] = [u, relax].
  * ev_start / ev_stop (optional hipEvent_t) are recorded around the posterior kernel for profiling.
