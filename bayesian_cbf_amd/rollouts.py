@@ -35,10 +35,12 @@ def unicycle_task_tensors(Bt, x0, xg, dtype, device, term_weights=(0.7, 0.3), cb
 def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_A=(1e-2, 1e-2, 1e-2),
                                 L_mean=1.0, L_true=12.0, start=(-3.0, -1.0, -math.pi / 4), goal=(0.0, 0.0, math.pi / 4),
                                 start_noise=0.05, max_risk=0.01, dtype=torch.float64, device="cuda", seed=0,
-                                record=False, max_iters=30):
+                                record=False, max_iters=30, use_graph=False):
     """Run Bt closed loops for numSteps steps.  `gp`: dict from BatchedControlAffineGP.as_dict() (learned
     residual, one GP per trajectory) or None (fixed-kernel model M_k = 0, B_k = I, A = diag(kernel_diag_A)).
-    Returns dict(stats..., x_final[Bt,3], traj (if record)).  Collectives: one, at the end."""
+    Returns dict(stats..., x_final[Bt,3], traj (if record)).  Collectives: one, at the end.
+    use_graph: capture one closed-loop step (plan row gather, the fused control step, the safety bookkeeping) in a HIP
+    graph and replay it numSteps times -- the loop is launch bound for small batches (about ten launches per step)."""
     dev = torch.device(device)
     f = dict(dtype=dtype, device=dev)
     gen = torch.Generator(device=dev).manual_seed(seed)
@@ -68,17 +70,48 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     step = ops.unicycle_control_step_prepare(gp if gp is not None else fixed, task, ws, x, dt=dt, L_true=L_true,
                                              L_mean=L_mean, max_iters=max_iters)
     import time
-    torch.cuda.synchronize(dev)
-    t_loop = time.perf_counter()
-    for t in range(numSteps):
-        task["plan"].copy_(plan_all[t])
-        task["dot_plan"].copy_(dplan_all[t])
-        # one host call, two launches (one for the fixed-kernel model: no posterior): rows -> terms -> SOCP -> plant step
-        step()
+    w_cost = task["w"]
+
+    def one_step(t):
+        # plan row t -> task buffers (t is a python int, or a device index tensor inside the captured graph)
+        if torch.is_tensor(t):
+            task["plan"].copy_(plan_all.index_select(0, t))
+            task["dot_plan"].copy_(dplan_all.index_select(0, t))
+        else:
+            task["plan"].copy_(plan_all[t])
+            task["dot_plan"].copy_(dplan_all[t])
+        step()       # one host call, two launches (one for the fixed-kernel model): rows -> terms -> SOCP -> plant step
         # safety bookkeeping: h_k(x_t) = cst_k / gamma_k for the obstacle rows (before the step)
         torch.minimum(min_h, (ws["cst"][:, 1:] * igam).amin(dim=1), out=min_h)
-        cost.add_((task["w"] * ws["y"] * ws["y"]).sum(dim=1))
+        cost.add_((w_cost * ws["y"] * ws["y"]).sum(dim=1))
         fails.add_(ws["status"] != 0)
+
+    torch.cuda.synchronize(dev)
+    graph = None
+    if use_graph and not record:
+        tctr = torch.zeros(1, dtype=torch.long, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        saved = [v.clone() for v in (x, min_h, cost, fails)]
+        with torch.cuda.stream(side):                   # warm-up on the capture stream (allocator, lazy module load)
+            one_step(tctr)
+        side.synchronize()
+        for dst, src in zip((x, min_h, cost, fails), saved):
+            dst.copy_(src)
+        tctr.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            one_step(tctr)
+            tctr.add_(1)
+        for dst, src in zip((x, min_h, cost, fails), saved):    # capture does not execute, but keep the state explicit
+            dst.copy_(src)
+        tctr.zero_()
+        torch.cuda.synchronize(dev)
+    t_loop = time.perf_counter()
+    for t in range(numSteps):
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step(t)
         if record:
             traj[t + 1] = x
     torch.cuda.synchronize(dev)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--max-risk", type=float, default=0.01)
     ap.add_argument("--learned", type=int, default=0, help="N_train of a per-trajectory learned GP (0 = fixed kernel)")
+    ap.add_argument("--graph", action="store_true", help="replay the closed-loop step from a captured HIP graph")
     ap.add_argument("--shared-learned", type=int, default=0,
                     help="N_train of ONE learned GP queried by every trajectory (fp32: matrix-core posterior)")
     args = ap.parse_args()
@@ -48,7 +49,8 @@ def main():
                                     p["M0"]).as_dict()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = monte_carlo_safety_rollouts(b - a, numSteps=args.steps, gp=gp, max_risk=args.max_risk, seed=rank, dtype=dtype)
+    out = monte_carlo_safety_rollouts(b - a, numSteps=args.steps, gp=gp, max_risk=args.max_risk, seed=rank, dtype=dtype,
+                                      use_graph=args.graph)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if rank == 0:

@@ -419,3 +419,13 @@ def test_reference_regression_fixture_fit_and_predict():
     mean, cov = dgp.custom_predict(t(Xt))
     assert torch.isfinite(mean).all() and torch.isfinite(cov).all()
     assert len(dgp.fit_losses) == 50 and np.isfinite(dgp.fit_losses).all()
+
+
+def test_rollout_loop_replayed_from_a_hip_graph_gives_the_same_statistics():
+    """monte_carlo_safety_rollouts(use_graph=True): the captured step (plan gather + fused control step + bookkeeping)
+    replayed numSteps times equals the eager loop bit for bit."""
+    from bayesian_cbf_amd.rollouts import monte_carlo_safety_rollouts
+    a = monte_carlo_safety_rollouts(512, numSteps=60, start_noise=0.05, seed=5)
+    b = monte_carlo_safety_rollouts(512, numSteps=60, start_noise=0.05, seed=5, use_graph=True)
+    assert torch.equal(a["x_final"], b["x_final"]) and torch.equal(a["min_h"], b["min_h"])
+    assert a["stats"] == b["stats"]
