@@ -394,6 +394,7 @@ extern "C" int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const 
                                        const float* ell, const float* s2, const float* Bm, const float* M0,
                                        const float* xq, float* Mk, float* Bk, float* G, float* Mj, int shared,
                                        int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
     if (!G || !Mj) return BCBF_EINVAL;
     return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, nullptr, shared, Bt, N, n, m, stream, G, Mj);
 }
@@ -401,6 +402,7 @@ extern "C" int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, cons
                                        const double* ell, const double* s2, const double* Bm, const double* M0,
                                        const double* xq, double* Mk, double* Bk, double* G, double* Mj, int shared,
                                        int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
     if (!G || !Mj) return BCBF_EINVAL;
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, nullptr, shared, Bt, N, n, m, stream, G, Mj);
 }

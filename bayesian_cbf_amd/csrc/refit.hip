@@ -74,6 +74,7 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
 int bcbf_refit_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                    const float* jitter, float* Lop, float* UHB, float* Ldense, int* info,
                    int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
     if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
     return bcbf_refit_mfma_f32(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
 }
@@ -83,14 +84,17 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
 int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                    const double* jitter, double* Lop, double* UHB, double* Ldense, int* info,
                    int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
     if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
     return bcbf_refit_mfma_f64(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
 }
 int bcbf_potrf_f32(const float* Kb, float* Lop, float* Ldense, int* info, int Bt, int N, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
     if (!Kb) return BCBF_EINVAL;
     return bcbf_refit_mfma_f32(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Kb, Lop, nullptr, Ldense, info, Bt, N, 0, 0, stream);
 }
 int bcbf_potrf_f64(const double* Kb, double* Lop, double* Ldense, int* info, int Bt, int N, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
     if (!Kb) return BCBF_EINVAL;
     return bcbf_refit_mfma_f64(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Kb, Lop, nullptr, Ldense, info, Bt, N, 0, 0, stream);
 }

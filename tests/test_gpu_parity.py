@@ -584,3 +584,47 @@ def test_potri_dense_inverse(ops, dtype, N):
     scale = float(Kb.double().abs().max() * Kinv.double().abs().max())
     assert float(res) <= (1e-10 if dtype == torch.float64 else 2e-3) * max(scale, 1.0), (float(res), scale)
     assert float((Kinv - Kinv.transpose(1, 2)).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-1) * float(Kinv.abs().max())
+
+
+def test_edge_cases_empty_batch_single_point_and_maximum_size(ops):
+    """Empty batch (every entry point returns without launching), N = 1, and the maximum supported N = 2048 (fp64 and
+    fp32) against the oracle."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    # ---- empty batch
+    p = make_instances(1, 8, 3, 2, dtype=torch.float64, device=DEV, seed=1)
+    e = {k: v[:0].contiguous() for k, v in p.items()}
+    Lop, UHB, info, _ = ops.refit(e["X"], e["UH"], e["Bm"], e["ell"], e["s2"], e["jitter"])
+    assert Lop.shape[0] == 0 and info.numel() == 0
+    Vw, _ = ops.potrs(Lop, e["Xdot"], e["UH"], e["M0"])
+    Mk, Bk = ops.posterior_step(Lop, Vw, e["X"], UHB, e["ell"], e["s2"], e["Bm"], e["M0"], e["xq"])
+    assert Mk.shape == (0, 3, 3) and Bk.shape == (0, 3, 3)
+    # ---- N = 1
+    q = make_instances(3, 1, 3, 2, dtype=torch.float64, device=DEV, seed=2)
+    Lop, UHB, info, _ = ops.refit(q["X"], q["UH"], q["Bm"], q["ell"], q["s2"], q["jitter"])
+    Vw, _ = ops.potrs(Lop, q["Xdot"], q["UH"], q["M0"], want_alpha=False)
+    Mk, Bk = ops.posterior_step(Lop, Vw, q["X"], UHB, q["ell"], q["s2"], q["Bm"], q["M0"], q["xq"])
+    h = {k: host(v) for k, v in q.items()}
+    for i in range(3):
+        st = ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                             h["jitter"][i][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None], h["ell"][i][None],
+                                        h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], h["xq"][i][None])
+        rel_close(host(Mk)[i], Mk_o[0], 1e-10, scale=max(1.0, np.abs(Mk_o).max()), what="Mk N=1")
+        rel_close(host(Bk)[i], Bk_o[0], 1e-10, scale=h["s2"][i] * np.abs(h["Bm"][i]).max(), what="Bk N=1")
+    # ---- N = 2048: well-conditioned inputs (wide box) so that fp32 factors too
+    for dtype, tol in ((torch.float64, 1e-8), (torch.float32, 2e-3)):
+        r = make_instances(2, 2048, 3, 2, dtype=torch.float64, device=DEV, seed=3)
+        r["X"] = (r["X"] * 6.0).contiguous()                 # spread the points: K_b stays positive definite in fp32
+        r["xq"] = (r["xq"] * 6.0).contiguous()
+        rr = {k: v.to(dtype).contiguous() for k, v in r.items()}
+        Lop, UHB, info, _ = ops.refit(rr["X"], rr["UH"], rr["Bm"], rr["ell"], rr["s2"], rr["jitter"])
+        assert (info == 0).all()
+        Vw, _ = ops.potrs(Lop, rr["Xdot"], rr["UH"], rr["M0"], want_alpha=False)
+        Mk, Bk = ops.posterior_step(Lop, Vw, rr["X"], UHB, rr["ell"], rr["s2"], rr["Bm"], rr["M0"], rr["xq"])
+        h = {k: host(v) for k, v in r.items()}
+        st = ogp.refit_state(h["X"][0], h["U"][0], h["Xdot"][0], h["Bm"][0], h["ell"][0], h["s2"][0], h["M0"][0],
+                             h["jitter"][0][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][0][None], st["UHB"][None], h["ell"][0][None],
+                                        h["s2"][0][None], h["Bm"][0][None], h["M0"][0][None], h["xq"][0][None])
+        rel_close(host(Mk)[0], Mk_o[0], tol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk N=2048")
+        rel_close(host(Bk)[0], Bk_o[0], tol, scale=h["s2"][0] * np.abs(h["Bm"][0]).max(), what="Bk N=2048")
