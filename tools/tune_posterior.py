@@ -16,11 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 
-VARIANTS = {
-    "base": [],
-    "u2_w3": ["-DBCBF_PS_UNR=2", "-DBCBF_PS_WAVES=3"],
-    "u8_w1": ["-DBCBF_PS_UNR=8", "-DBCBF_PS_WAVES=1"],
-}
+VARIANTS = {"base": []}
+for u in (2, 4, 8):
+    for w in (1, 2, 3, 4):
+        VARIANTS["u%d_w%d" % (u, w)] = ["-DBCBF_PS_UNR=%d" % u, "-DBCBF_PS_WAVES=%d" % w]
 
 
 def build():
@@ -30,7 +29,7 @@ def build():
         out = os.path.join(VDIR, name + ".so")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + flags + [
-               os.path.join(CSRC, "posterior_step.hip"), os.path.join(CSRC, "common.hip"), "-o", out,
+               os.path.join(CSRC, "posterior_step.hip"), os.path.join(CSRC, "posterior_shared.hip"), os.path.join(CSRC, "common.hip"), "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", out,
                "-Rpass-analysis=kernel-resource-usage"]
         procs.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for name, p in procs:
@@ -51,8 +50,10 @@ def run():
     sys.path.insert(0, ROOT)
     from bayesian_cbf_amd import ops
     from bayesian_cbf_amd.synthetic import make_instances
-    Bt, N, n, m = 4096, 512, 3, 2
-    p = make_instances(Bt, N, n, m, dtype=torch.float32, device="cuda", seed=1234)
+    f64 = "f64" in sys.argv
+    Bt, N, n, m = (1024, 256, 2, 1) if "c2" in sys.argv else (4096, 512, 3, 2)
+    dt = torch.float64 if f64 else torch.float32
+    p = make_instances(Bt, N, n, m, dtype=dt, device="cuda", seed=1234)
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
     Mk_ref, Bk_ref = ops.posterior_step(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
@@ -68,14 +69,14 @@ def run():
     Bk = torch.empty_like(Bk_ref)
 
     def call(lib):
-        rc = lib.bcbf_posterior_step_f32(P(Lop.data_ptr()), P(Vw.data_ptr()), P(p["X"].data_ptr()), P(UHB.data_ptr()),
+        rc = getattr(lib, "bcbf_posterior_step_f64" if f64 else "bcbf_posterior_step_f32")(P(Lop.data_ptr()), P(Vw.data_ptr()), P(p["X"].data_ptr()), P(UHB.data_ptr()),
                                          P(p["ell"].data_ptr()), P(p["s2"].data_ptr()), P(p["Bm"].data_ptr()),
                                          P(p["M0"].data_ptr()), P(p["xq"].data_ptr()), None, P(Mk.data_ptr()),
                                          P(Bk.data_ptr()), Bt, N, n, m, st)
         assert rc == 0
-    bytes_alg = 4 * (N * (N + 1) // 2 + N * (2 * n + 1 + m)) * Bt
+    bytes_alg = (8 if f64 else 4) * (N * (N + 1) // 2 + N * (2 * n + 1 + m)) * Bt
     times = {k: [] for k in libs}
-    for rnd in range(6):
+    for rnd in range(4):
         for name, lib in libs.items():
             call(lib)
             torch.cuda.synchronize()
