@@ -15,19 +15,28 @@ template <> struct Vec<double> { using type = double2; static constexpr int V = 
 
 __host__ __device__ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
-// Packed operator.  Column j stores rows lop_first(j) = 32*floor(j/32) .. Np-1 (the whole column from the top of
-// its diagonal block), columns back to back: every column starts on a 128-byte boundary and has a multiple of
-// 128 bytes, so a wave's 16-byte-per-lane loads never straddle a line shared with another column and the row-256
-// split between a lane's two row blocks is line aligned.  Element (i, j) lives at lop_base(j) + i.
+// Packed operator (bcbf.h "Lop"), Np = N padded to 32, nblk = Np / 32:
+//   * off-diagonal part first: column j of block column J = j / 32 stores rows 32 (J+1) .. Np-1 (everything BELOW its
+//     32x32 diagonal block), columns back to back.  Every column starts on a 128-byte boundary and is a whole number of
+//     128-byte lines, so a wave's 16-byte-per-lane loads never straddle a line shared with another column.
+//     Element (i, j), i >= 32 (J+1), lives at lop_base(j) + i.
+//   * then the INVERTED diagonal blocks, lower triangles only, column-major packed, LOP_DB = 544 elements per block
+//     (528 used: a block starts on a 128-byte line): inv(L_JJ)[r][c], r >= c, lives at lop_dinv(J, r, c).
+// Total Np (Np + 2) / 2 elements: the exact triangle plus half a row of padding per block.
 // (The template parameter V is the vector width of the caller; the layout itself does not depend on it.)
-__host__ __device__ inline int lop_first(int j) { return (j / NB) * NB; }
+constexpr int LOP_DB = 544;
 template <int V>
 __host__ __device__ inline int lop_base(int j, int Np) {
     const int J = j / NB, c = j - J * NB;
-    return NB * (J * Np - NB * (J * (J - 1) / 2)) + c * (Np - NB * J) - NB * J;
+    return NB * J * Np - 512 * J * (J + 1) + c * (Np - NB * (J + 1)) - NB * (J + 1);
 }
+__host__ __device__ inline int lop_offd_elems(int Np) { return Np * Np / 2 - 16 * Np; }
+__host__ __device__ inline int lop_dinv_col(int c) { return NB * c - c * (c - 1) / 2 - c; }   // start of column c, minus c
+// offset of inv(L_JJ)[r][c] (r >= c):  lop_dinv_block(J) + lop_dinv_col(c) + r
+__host__ __device__ inline int lop_dinv_block(int J, int Np) { return lop_offd_elems(Np) + LOP_DB * J; }
+__host__ __device__ inline int lop_dinv(int J, int r, int c, int Np) { return lop_dinv_block(J, Np) + lop_dinv_col(c) + r; }
 template <int V>
-__host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + NB) / 2; }
+__host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + 2) / 2; }
 
 void set_error(const char* what, hipError_t err);
 int check_launch(const char* what);

@@ -126,7 +126,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
         UHtA[(size_t)b * C * n + o] = (T)v;
     } else if (tid >= 192) {
         double v = 0.0;
-        for (int i = tid - 192; i < N; i += 64) v -= 2.0 * log((double)lop[lop_base<V>(i, Np) + i]);
+        for (int i = tid - 192; i < N; i += 64) v -= 2.0 * log((double)lop[lop_dinv(i / NB, i % NB, i % NB, Np)]);
         v = wave_sum(v);
         if (tid == 192) logdetK[b] = (T)v;
     }

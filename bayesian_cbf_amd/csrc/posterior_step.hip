@@ -153,12 +153,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     T dval[HALF];
     const int di = tid & 31, dh = (tid >> 5) & 1;
     auto issue = [&](VecT* la, VecT* lb, int J, int g) {
+        // column j of block column J stores rows 32 (J+1) .. Np-1: per-lane offset relative to the first stored row,
+        // scalar offset = start of the column (lop_base(j) + 32 (J+1) >= 0: buffer offsets are unsigned)
         const int rbmin = (J + 1) * RPB;
-        const int voffA = (live && rbA >= rbmin) ? rbA * V * (int)sizeof(T) : OOB;
-        const int voffB = (live && rbB >= rbmin) ? rbB * V * (int)sizeof(T) : OOB;
+        const int voffA = (live && rbA >= rbmin) ? (rbA - rbmin) * V * (int)sizeof(T) : OOB;
+        const int voffB = (live && rbB >= rbmin) ? (rbB - rbmin) * V * (int)sizeof(T) : OOB;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int soff = lop_base<V>(J * NB + g * UNR + u, Np) * (int)sizeof(T);
+            const int soff = (lop_base<V>(J * NB + g * UNR + u, Np) + (J + 1) * NB) * (int)sizeof(T);
             la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
             lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
         }
@@ -180,12 +182,12 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 }
         }
     };
-    auto issue_diag = [&](int J) {      // inv(L_JJ)[di][dh*16 + q], wave 0 only (others: out of range -> 0)
-#pragma unroll
+    auto issue_diag = [&](int J) {      // inv(L_JJ)[di][dh*16 + q], wave 0 only (others, and the zeros above the
+#pragma unroll                          // diagonal, which are not stored: out of range -> 0, no traffic)
         for (int q = 0; q < HALF; ++q) {
             const int jj = dh * HALF + q;
-            const int voff = tid < 64 ? (J * NB + di) * (int)sizeof(T) : OOB;    // (zeros above the diagonal are stored)
-            dval[q] = BufLoad<T>::one(rsrc, voff, lop_base<V>(J * NB + jj, Np) * (int)sizeof(T));
+            const int voff = (tid < 64 && di >= jj) ? (lop_dinv_col(jj) + di) * (int)sizeof(T) : OOB;
+            dval[q] = BufLoad<T>::one(rsrc, voff, lop_dinv_block(J, Np) * (int)sizeof(T));
         }
     };
     issue_diag(0);

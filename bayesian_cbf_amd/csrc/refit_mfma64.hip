@@ -238,22 +238,23 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                         for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dS[c][lane];
                     }
                     {
-                        const int base = lop_base<V>(col0 + ln, Np);                     // whole block column stored
+                        const int base = lop_dinv_block(J, Np) + lop_dinv_col(ln);       // lower triangle, packed
                         for (int i = 0; i < NB; ++i) {
                             double s_ = (ln == i && !lh) ? 1.0 : 0.0;
 #pragma unroll 4
                             for (int k = lh; k < i; k += 2) s_ -= dS[k][i] * dinv[k][ln]; // L[i][k] X[k][lane]
                             s_ += __shfl_xor(s_, 32, 64);
                             const double xi = s_ * idg[i];
-                            if (lane < NB) { dinv[i][lane] = xi; lop[base + col0 + i] = xi; }
+                            if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; }
                         }
                     }
 #else
                     if (lane < NB) {
-                        const int base = lop_base<V>(col0 + lane, Np);
-                        for (int i = 0; i < NB; ++i) { const double xi = lane == i ? 1.0 : 1e-6 * dS[i][lane]; dinv[i][lane] = xi; lop[base + col0 + i] = xi; }
+                        const int base = lop_dinv_block(J, Np) + lop_dinv_col(lane);
+                        for (int i = 0; i < NB; ++i) { const double xi = lane == i ? 1.0 : 1e-6 * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; }
                     }
 #endif
+                    if (lane < LOP_DB - 528) lop[lop_dinv_block(J, Np) + 528 + lane] = 0.0;      // the block's padding
                     if (lane == 0 && bad != 0 && bad <= N) fail = bad;
                 }
                 __syncthreads();          // (B) inv(L_JJ) visible

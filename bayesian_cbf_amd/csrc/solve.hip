@@ -76,7 +76,7 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
 #pragma unroll
             for (int c = 0; c < SC; ++c) w[c] = T(0);
             for (int jj = 0; jj <= tid; ++jj) {
-                const T val = lop[lop_base<V>(col0 + jj, Np) + col0 + tid];
+                const T val = lop[lop_dinv(J, tid, jj, Np)];
 #pragma unroll
                 for (int c = 0; c < SC; ++c) w[c] += val * rbuf[jj][c];
             }
@@ -141,7 +141,7 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
             T a[SC];
 #pragma unroll
             for (int c = 0; c < SC; ++c) a[c] = T(0);
-            const int base = lop_base<V>(col0 + tid, Np) + col0;
+            const int base = lop_dinv_block(J, Np) + lop_dinv_col(tid);
             for (int ii = tid; ii < NB; ++ii) {
                 const T val = lop[base + ii];
 #pragma unroll
@@ -276,7 +276,7 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
         __syncthreads();
         if (tid < NB) {
             T w = T(0);
-            for (int jj = 0; jj <= tid; ++jj) w += lin[lop_base<V>(col0 + jj, NpI) + col0 + tid] * rbuf[jj];
+            for (int jj = 0; jj <= tid; ++jj) w += lin[lop_dinv(J, tid, jj, NpI)] * rbuf[jj];
             wbuf[tid] = w;
             lrow[col0 + tid] = w;
         }
@@ -304,15 +304,28 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
 
     // ---- copy / re-layout the old operator
     if (lout != lin) {
+        // off-diagonal part: column j keeps its rows below its diagonal block; rows / columns of the new padding are zero
         for (int j = 0; j < NpO; ++j) {
-            const int first = lop_first(j);
+            const int first = (j / NB + 1) * NB;
             const int bo = lop_base<V>(j, NpO);
             if (j < NpI) {
                 const int bi = lop_base<V>(j, NpI);
                 for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i < NpI ? lin[bi + i] : T(0);
             } else {
-                for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i == j ? T(1) : T(0);
+                for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = T(0);
             }
+        }
+        // inverted diagonal blocks: copied; a new padding block is the identity
+        const int nbI = NpI / NB, nbO = NpO / NB;
+        for (int e = tid; e < nbO * LOP_DB; e += ST) {
+            const int Jb = e / LOP_DB, o = e - Jb * LOP_DB;
+            T v;
+            if (Jb < nbI) v = lin[lop_dinv_block(Jb, NpI) + o];
+            else {                       // identity: o is a diagonal position iff o == lop_dinv_col(c) + c for some c
+                v = T(0);
+                for (int c = 0; c < NB; ++c) if (o == lop_dinv_col(c) + c) v = T(1);
+            }
+            lout[lop_dinv_block(Jb, NpO) + o] = v;
         }
     }
     __threadfence_block();
@@ -326,10 +339,10 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
         if (jj == rr) val = T(1) / d;
         else {
             T acc = T(0);
-            for (int ii = jj; ii < rr; ++ii) acc += lrow[col0 + ii] * lout[lop_base<V>(col0 + jj, NpO) + col0 + ii];
+            for (int ii = jj; ii < rr; ++ii) acc += lrow[col0 + ii] * lout[lop_dinv(Js, ii, jj, NpO)];
             val = -acc / d;
         }
-        lout[lop_base<V>(col0 + jj, NpO) + N] = val;
+        lout[lop_dinv(Js, rr, jj, NpO)] = val;
     }
     if (FUSED) {
         const int n = f.n, C = f.C;

@@ -56,11 +56,13 @@ const char* bcbf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Packed triangular operator "Lop" (the HBM layout the per-step kernel streams).
- * Np = N rounded up to BCBF_NB (32).  Column j stores rows 32*floor(j/32) .. Np-1 contiguously (column-major, the
- * whole column from the top of its diagonal block, zero above the diagonal), columns back to back: every column
- * starts on a 128-byte boundary.  Element (i,j) holds L[i][j] when i is below j's 32x32 diagonal block and
- * inv(L_JJ)[i][j] inside the block (the block's triangular inverse).  Rows/cols >= N are identity.
- * Elements per instance = Np*(Np+32)/2 (same for f32 and f64).
+ * Np = N rounded up to BCBF_NB (32), J = floor(j/32).  Two parts:
+ *   off-diagonal: column j stores L[i][j] for the rows i = 32 (J+1) .. Np-1 below its 32x32 diagonal block, contiguously,
+ *     columns back to back -- every column starts on a 128-byte boundary and is a whole number of 128-byte lines;
+ *   then the diagonal blocks, INVERTED (inv(L_JJ)), lower triangles only, column-major packed, 544 elements per block
+ *     (528 used).
+ * Rows/cols >= N are identity.  Elements per instance = Np*(Np+2)/2 (same for f32 and f64): the exact triangle plus
+ * half a row of padding per block.  The layout is private to the library (bcbf_common.h: lop_base, lop_dinv).
  * ------------------------------------------------------------------------------------------- */
 size_t bcbf_lop_elems_f32(int N);
 size_t bcbf_lop_elems_f64(int N);
