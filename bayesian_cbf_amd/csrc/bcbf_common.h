@@ -22,7 +22,12 @@ __host__ __device__ inline int round_up(int x, int q) { return (x + q - 1) / q *
 //     Element (i, j), i >= 32 (J+1), lives at lop_base(j) + i.
 //   * then the INVERTED diagonal blocks, lower triangles only, column-major packed, LOP_DB = 544 elements per block
 //     (528 used: a block starts on a 128-byte line): inv(L_JJ)[r][c], r >= c, lives at lop_dinv(J, r, c).
-// Total Np (Np + 2) / 2 elements: the exact triangle plus half a row of padding per block.
+//     This is what the per-instance streaming kernels read: Np (Np + 2) / 2 elements, the exact triangle plus half a
+//     row of padding per block.
+//   * last, a second copy of the inverted diagonal blocks as full 32x32 column-major tiles (zeros above the diagonal):
+//     inv(L_JJ)[r][c] at lop_dfull(J, r, c).  Only the shared-model matrix-core kernel reads it (its factor is cache
+//     resident, bytes do not matter there, but an MFMA operand tile wants the same affine addressing as the
+//     off-diagonal tiles); the streaming kernels never touch it, so it costs capacity (+1024 per block), not traffic.
 // (The template parameter V is the vector width of the caller; the layout itself does not depend on it.)
 constexpr int LOP_DB = 544;
 template <int V>
@@ -35,8 +40,10 @@ __host__ __device__ inline int lop_dinv_col(int c) { return NB * c - c * (c - 1)
 // offset of inv(L_JJ)[r][c] (r >= c):  lop_dinv_block(J) + lop_dinv_col(c) + r
 __host__ __device__ inline int lop_dinv_block(int J, int Np) { return lop_offd_elems(Np) + LOP_DB * J; }
 __host__ __device__ inline int lop_dinv(int J, int r, int c, int Np) { return lop_dinv_block(J, Np) + lop_dinv_col(c) + r; }
+__host__ __device__ inline int lop_dfull_block(int J, int Np) { return Np * (Np + 2) / 2 + NB * NB * J; }
+__host__ __device__ inline int lop_dfull(int J, int r, int c, int Np) { return lop_dfull_block(J, Np) + NB * c + r; }
 template <int V>
-__host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + 2) / 2; }
+__host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + 2) / 2 + (size_t)NB * Np; }
 
 void set_error(const char* what, hipError_t err);
 int check_launch(const char* what);

@@ -146,33 +146,24 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
         const_cast<float*>(Lop), 0, (int)(lop_elems<V>(Np) * sizeof(float)), 0x00020000);
     int Il = 0, Kl = 0;                               // load cursor (runs PSH_DEPTH - 1 tiles ahead)
     int lbase = -NB, lstride = Np - NB;               // lop_base(Kl*NB), column stride of block column Kl
-    // Diagonal tiles (Kl == Il) come from the packed lower triangles of the inverted blocks: per-lane offsets of the
-    // element (2j, 8g + cs) inside a block, out of range where both rows 2j, 2j+1 lie above the diagonal (-> zeros);
-    // where only row 2j does, the first half of the 8-byte load is a neighbour's value and is masked at use.
-    int vdiag[8];
-    bool dmask[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int cc_ = 8 * g + 2 * (s & 3) + (s >> 2);
-        vdiag[s] = (2 * j + 1 >= cc_) ? (lop_dinv_col(cc_) + 2 * j) * (int)sizeof(float) : 0x40000000;
-        dmask[s] = 2 * j >= cc_;
-    }
     // Branch-free and unconditional: a wave issues one instruction every 4 cycles, so every scalar instruction and
-    // branch of the step shows up in the run time unless it hides behind an MFMA.  Past the last tile the cursor
-    // runs out of the operator and the buffer bounds check returns zeros.
+    // branch of the step shows up in the run time unless it hides behind an MFMA.  A diagonal tile (Kl == Il) is the
+    // full-tile copy of the inverted block: the same affine form with column stride 32 -- two scalar selects.  Past
+    // the last tile the cursor runs out of the operator and the buffer bounds check returns zeros.
     auto issue = [&](float2 (&a)[8]) {
         const bool isdiag = Kl == Il;
-        const int voff = (8 * g * lstride + 2 * j) * (int)sizeof(float);
-        const int st4 = lstride * (int)sizeof(float);
-        const int dblk = lop_dinv_block(Il, Np) * (int)sizeof(float);
+        const int stride = isdiag ? NB : lstride;
+        const int base = isdiag ? lop_dfull_block(Il, Np) : lbase + Il * NB;        // element (row 0 of the tile, column 0)
+        const int voff = (8 * g * stride + 2 * j) * (int)sizeof(float);
+        const int st4 = stride * (int)sizeof(float);
         int off[8];
-        off[0] = (lbase + Il * NB) * (int)sizeof(float);
+        off[0] = base * (int)sizeof(float);
 #pragma unroll
         for (int cs = 1; cs < 8; ++cs) off[cs] = off[cs - 1] + st4;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int cs = 2 * (s & 3) + (s >> 2);                            // blk_row(u, 0, r)
-            const u32x2s v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, isdiag ? vdiag[s] : voff, isdiag ? dblk : off[cs], 0);
+            const u32x2s v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, off[cs], 0);
             a[s] = __builtin_bit_cast(float2, v);
         }
         const bool adv = Kl < Il;
@@ -216,7 +207,7 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float b_ = phi[s] - ((s >> 2) ? acc1[s & 3] : acc0[s & 3]);
-            w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dmask[s] ? a[s].x : 0.f, b_, w0, 0, 0, 0);
+            w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b_, w0, 0, 0, 0);
             w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, b_, w1, 0, 0, 0);
         }
         issue(fill);                                  // (not first: a prefix shared with off_step gets hoisted above

@@ -188,7 +188,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
 #if defined(BCBF_ABL_SKIP_FACTOR)
                 if (lane < NB) {
                     const int base = lop_dinv_block(J, Np) + lop_dinv_col(lane);
-                    for (int i = 0; i < NB; ++i) { const float xi = lane == i ? 1.f : 1e-6f * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; }
+                    for (int i = 0; i < NB; ++i) { const float xi = lane == i ? 1.f : 1e-6f * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                 }
 #else
                 for (int c = 0; c < NB; ++c) {
@@ -213,7 +213,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                         for (int k = lhh; k < i; k += 2) s_ -= dS[k][i] * dinv[k][ln];    // L[i][k] X[k][lane]
                         s_ += __shfl_xor(s_, 32, 64);
                         const float xi = s_ * idg[i];
-                        if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; }
+                        if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                     }
                 }
 #endif

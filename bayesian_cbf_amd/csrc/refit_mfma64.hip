@@ -245,13 +245,13 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                             for (int k = lh; k < i; k += 2) s_ -= dS[k][i] * dinv[k][ln]; // L[i][k] X[k][lane]
                             s_ += __shfl_xor(s_, 32, 64);
                             const double xi = s_ * idg[i];
-                            if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; }
+                            if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                         }
                     }
 #else
                     if (lane < NB) {
                         const int base = lop_dinv_block(J, Np) + lop_dinv_col(lane);
-                        for (int i = 0; i < NB; ++i) { const double xi = lane == i ? 1.0 : 1e-6 * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; }
+                        for (int i = 0; i < NB; ++i) { const double xi = lane == i ? 1.0 : 1e-6 * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                     }
 #endif
                     if (lane < LOP_DB - 528) lop[lop_dinv_block(J, Np) + 528 + lane] = 0.0;      // the block's padding

@@ -327,6 +327,11 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
             }
             lout[lop_dinv_block(Jb, NpO) + o] = v;
         }
+        // ... and their full-tile copies (read by the shared-model kernel)
+        for (int e = tid; e < nbO * NB * NB; e += ST) {
+            const int Jb = e / (NB * NB), o = e - Jb * NB * NB;
+            lout[lop_dfull_block(Jb, NpO) + o] = Jb < nbI ? lin[lop_dfull_block(Jb, NpI) + o] : ((o / NB == o % NB) ? T(1) : T(0));
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -343,6 +348,7 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
             val = -acc / d;
         }
         lout[lop_dinv(Js, rr, jj, NpO)] = val;
+        lout[lop_dfull(Js, rr, jj, NpO)] = val;
     }
     if (FUSED) {
         const int n = f.n, C = f.C;

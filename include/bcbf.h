@@ -61,8 +61,11 @@ const char* bcbf_last_error(void);
  *     columns back to back -- every column starts on a 128-byte boundary and is a whole number of 128-byte lines;
  *   then the diagonal blocks, INVERTED (inv(L_JJ)), lower triangles only, column-major packed, 544 elements per block
  *     (528 used).
- * Rows/cols >= N are identity.  Elements per instance = Np*(Np+2)/2 (same for f32 and f64): the exact triangle plus
- * half a row of padding per block.  The layout is private to the library (bcbf_common.h: lop_base, lop_dinv).
+ *   last, a second copy of the inverted diagonal blocks as full 32x32 tiles (1024 elements per block), read only by the
+ *     shared-model matrix-core kernel -- capacity, not traffic: the streaming kernels never touch it.
+ * Rows/cols >= N are identity.  Elements per instance = Np*(Np+2)/2 + 32*Np (same for f32 and f64); the streamed part
+ * is the exact triangle plus half a row of padding per block.  The layout is private to the library
+ * (bcbf_common.h: lop_base, lop_dinv, lop_dfull).
  * ------------------------------------------------------------------------------------------- */
 size_t bcbf_lop_elems_f32(int N);
 size_t bcbf_lop_elems_f64(int N);

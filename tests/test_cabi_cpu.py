@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_version_and_layout_helpers(lib):
     assert lib.lib.bcbf_version() == 1
-    # Np*(Np+2)/2 elements, Np = N padded to 32
-    assert lib.lib.bcbf_lop_elems_f32(512) == 512 * 514 // 2
-    assert lib.lib.bcbf_lop_elems_f64(256) == 256 * 258 // 2
-    assert lib.lib.bcbf_lop_elems_f32(40) == 64 * 66 // 2
+    # Np*(Np+2)/2 streamed elements + the full-tile copies of the diagonal blocks (32*Np), Np = N padded to 32
+    assert lib.lib.bcbf_lop_elems_f32(512) == 512 * 514 // 2 + 32 * 512
+    assert lib.lib.bcbf_lop_elems_f64(256) == 256 * 258 // 2 + 32 * 256
+    assert lib.lib.bcbf_lop_elems_f32(40) == 64 * 66 // 2 + 32 * 64
 
 
 def test_ops_refuse_cpu_tensors(lib):
