@@ -201,6 +201,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                     const float inv = __builtin_amdgcn_rsqf(piv > 0.f ? piv : 1.f);      // 1-ulp rsq
                     if (lane < NB) dS[c][lane] = lane == c ? piv * inv : (lane > c ? v * inv : 0.f);   // L[lane][c]
                     if (lane == c) idg[c] = inv;
+                    __builtin_amdgcn_wave_barrier();       // other lanes read this column through LDS
                 }
                 if (Ld && lane < NB && col0 + lane < N) {
                     for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dS[c][lane];
@@ -214,6 +215,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                         s_ += __shfl_xor(s_, 32, 64);
                         const float xi = s_ * idg[i];
                         if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
 #endif

@@ -233,6 +233,7 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                         const double inv = rsqrt_nr(piv > 0.0 ? piv : 1.0);
                         if (lane < NB) dS[c][lane] = lane == c ? piv * inv : (lane > c ? v * inv : 0.0);   // L[lane][c]
                         if (lane == c) idg[c] = inv;
+                        __builtin_amdgcn_wave_barrier();       // other lanes read this column through LDS
                     }
                     if (Ld && lane < NB && col0 + lane < N) {
                         for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dS[c][lane];
@@ -246,6 +247,7 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                             s_ += __shfl_xor(s_, 32, 64);
                             const double xi = s_ * idg[i];
                             if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
 #else

@@ -6,10 +6,7 @@ VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 VARIANTS = {}
 VARIANTS["default"] = []
-VARIANTS["t1_o2_k8"] = ["-DBCBF_R64_MAXT=1", "-DBCBF_R64_OCC=2", "-DBCBF_R64_KS=8"]
 VARIANTS["nofactor"] = ["-DBCBF_R64_ABL_NOFACTOR"]
-VARIANTS["nokloop"] = ["-DBCBF_R64_ABL_NOKLOOP"]
-VARIANTS["neither"] = ["-DBCBF_R64_ABL_NOKLOOP", "-DBCBF_R64_ABL_NOFACTOR"]
 def build():
     os.makedirs(VDIR, exist_ok=True)
     ps = []
