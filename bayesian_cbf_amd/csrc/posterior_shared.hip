@@ -233,6 +233,7 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
         for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) phi[e] = phin[e];
+        __builtin_amdgcn_wave_barrier();              // the slab rows just written are read by other lanes of this wave
         load_b(bn, 0);                                // the next tile is (I+1, 0): B = W_0 (just written when I = 0)
         ++I; K = 0;
     };
