@@ -19,7 +19,10 @@ namespace bcbf {
 using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
 
 constexpr int MT = 256;          // threads
-constexpr int MAXT = 2;          // row tiles a wave processes together (shares the A operand)
+#ifndef BCBF_R32_MAXT
+#define BCBF_R32_MAXT 1
+#endif
+constexpr int MAXT = BCBF_R32_MAXT;   // row tiles a wave processes together (shares the A operand)
 
 __device__ inline int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 // broadcast of one lane's value through an SGPR (v_readlane_b32, compile-time lane): no VGPR, no LDS crossbar
@@ -143,7 +146,10 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
             }
             // ---- S' -= L_J L_I'  over all previous columns: stages of KS MFMA k-steps (2 columns each),
             //      the next stage's operands are in flight while the current stage's MFMAs issue
-            constexpr int KS = 4;
+#ifndef BCBF_R32_KS
+#define BCBF_R32_KS 4
+#endif
+            constexpr int KS = BCBF_R32_KS;
             const int kend = col0;                                            // multiple of 32
             float a_nxt[KS], b_nxt[KS][MAXT];
             auto fetch = [&](int kk) {

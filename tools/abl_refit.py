@@ -4,8 +4,10 @@ import ctypes, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
-VARIANTS = {"full": [], "lds": ["-DBCBF_R32_LDS_FACTOR"], "lds_o3": ["-DBCBF_R32_LDS_FACTOR", "-DBCBF_R32_OCC=3"],
-            "lds_o4": ["-DBCBF_R32_LDS_FACTOR", "-DBCBF_R32_OCC=4"], "nofactor": ["-DBCBF_ABL_SKIP_FACTOR"]}
+VARIANTS = {"full": []}
+for ks in (2, 4, 8):
+    for occ in (3, 4):
+        VARIANTS["t1_k%d_o%d" % (ks, occ)] = ["-DBCBF_R32_MAXT=1", "-DBCBF_R32_KS=%d" % ks, "-DBCBF_R32_OCC=%d" % occ]
 def build():
     os.makedirs(VDIR, exist_ok=True)
     ps = []
