@@ -270,7 +270,7 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = Bt < 128 && N > 512;   // few large instances: 16 waves per workgroup (measured: 3.1 -> 2.6 ms at N=1024, Bt=1)
+    const bool wide = Bt < 128 && N >= 256;   // few instances: 16 waves per workgroup (Bt=1: 392 -> 346 us at N=256, 1.09 -> 0.87 ms at N=512, 3.1 -> 2.1 ms at N=1024)
 #define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
     do {                                                                                                \
         if (wide) hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 16>), dim3(Bt), dim3(1024), __VA_ARGS__);              \

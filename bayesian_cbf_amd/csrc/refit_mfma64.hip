@@ -313,7 +313,7 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = Bt < 128 && N >= 512;  // few large instances: 8 waves per workgroup (16 would cap the VGPRs at 128: spills)
+    const bool wide = Bt < 128 && N >= 256;  // few large instances: 8 waves per workgroup (16 would cap the VGPRs at 128: spills)
 #define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
     do {                                                                                                \
         if (wide) hipLaunchKernelGGL((refit_mfma64_kernel<DENSE, 8>), dim3(Bt), dim3(512), __VA_ARGS__);                \
