@@ -29,6 +29,57 @@ def reldeg1_quadratic_terms(Mk, Bk, A, grad, cst, sign, fhat, ghat):
     return (bfe, e), (V, bfv, v)
 
 
+def resolve_model(model):
+    """(regressor, [deterministic models]) of a Bayesian dynamics model: a `ControlAffineRegressor` itself, or a sum of
+    models (`controllers.SumDynamicModels` / `MeanAdjustedModel`, controllers.py:288-378) of which exactly one is a
+    regressor -- the others contribute f_func / g_func to the mean only (DeterministicGP, gp_algebra.py:70-106)."""
+    if hasattr(model, "_state") and hasattr(model, "model"):
+        return model, []
+    parts = getattr(model, "models", None)
+    if parts is None:
+        raise TypeError("model must be a ControlAffineRegressor or a sum of dynamics models, got %r" % type(model))
+    regs = [p for p in parts if hasattr(p, "_state")]
+    if len(regs) != 1:
+        raise TypeError("a summed model needs exactly one learned regressor, found %d" % len(regs))
+    return regs[0], [p for p in parts if p is not regs[0]]
+
+
+def _det_mean(dets, xb, reg, want_jac):
+    """fhat[b,n], ghat[b,n,m] (and dfhat/dx [b,n,n] by autograd on the user's deterministic functions)."""
+    b, n, m = xb.shape[0], reg.x_dim, reg.u_dim
+    fhat, ghat = xb.new_zeros(b, n), xb.new_zeros(b, n, m)
+    J = xb.new_zeros(b, n, n) if want_jac else None
+    for d in dets:
+        fhat = fhat + torch.as_tensor(d.f_func(xb), dtype=xb.dtype, device=xb.device).reshape(b, n)
+        ghat = ghat + torch.as_tensor(d.g_func(xb), dtype=xb.dtype, device=xb.device).reshape(b, n, m)
+        if want_jac:
+            for i in range(b):
+                Ji = torch.autograd.functional.jacobian(
+                    lambda z: torch.as_tensor(d.f_func(z), dtype=z.dtype, device=z.device).reshape(n), xb[i].clone())
+                J[i] += Ji.reshape(n, n)
+    return fhat.contiguous(), ghat.contiguous(), J
+
+
+def posterior_for(reg, xb, jets):
+    """(st, Mk, Bk, G, Mj) at the query states; the prior when the regressor holds no data
+    (control_affine_model.py:495-506)."""
+    b, n, C = xb.shape[0], reg.x_dim, 1 + reg.u_dim
+    if reg.Xtrain is None:
+        reg._require_gpu()
+        hp = reg._hyper()
+        Mk = hp["M0"].transpose(1, 2).expand(b, n, C).contiguous()
+        Bk = (hp["s2"].reshape(1, 1, 1) * hp["Bm"]).expand(b, C, C).contiguous()
+        CT = C * (1 + n)
+        return hp, Mk, Bk, xb.new_zeros(b, CT, CT), xb.new_zeros(b, n, CT)
+    st = reg._state()
+    if not jets:
+        _, Mk, Bk, _ = reg._query(xb, want_W=False)
+        return st, Mk, Bk, None, None
+    Mk, Bk, G, Mj = ops.posterior_jets(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
+                                       st["M0"], xb, shared=True)
+    return st, Mk, Bk, G, Mj
+
+
 def reldeg2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
     """Closed form of the reference call
         cbc2_quadratic_terms(lambda u: cbc2_gp(h, grad_h, regressor, u, k_alpha), x, u0)   (cbc2.py:7-33)
@@ -36,12 +87,19 @@ def reldeg2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
     `grad_h` that GradientGP performs (gp_algebra.py:340-345).  x[n] or [b,n], u0[m] or [b,m].
     Returns ((mean_A, mean_b), (k_Q, k_p, k_r), mean, var) like the reference."""
     single = x.dim() == 1
+    regressor, dets = resolve_model(regressor)
     xb = regressor._ensure_device_dtype(x.reshape(-1, regressor.x_dim)).contiguous()
     ub = regressor._ensure_device_dtype(u0.reshape(-1, regressor.u_dim)).contiguous()
     b = xb.shape[0]
-    st = regressor._state()
-    Mk, Bk, G, Mj = ops.posterior_jets(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
-                                       st["M0"], xb, shared=True)
+    st, Mk, Bk, G, Mj = posterior_for(regressor, xb, jets=True)
+    if dets:            # deterministic summands shift the mean of [f g] and of df/dx only
+        C = 1 + regressor.u_dim
+        fhat, ghat, J = _det_mean(dets, xb, regressor, want_jac=True)
+        Mk = Mk + torch.cat([fhat.unsqueeze(-1), ghat], dim=-1)
+        Mj = Mj.clone()
+        for i in range(regressor.x_dim):
+            Mj[:, :, (1 + i) * C] += J[:, :, i]
+        Mk, Mj = Mk.contiguous(), Mj.contiguous()
     f = dict(dtype=xb.dtype, device=xb.device)
     hv = torch.stack([torch.as_tensor(h(xi), **f).reshape(()) for xi in xb])
     gh = torch.stack([torch.as_tensor(grad_h(xi), **f) for xi in xb]).contiguous()
@@ -69,28 +127,53 @@ def _hessian_of(grad_h, x):
 
 
 class CBCExpr:
-    """Value of `cbc(u)`: a scalar GP in x for the fixed control u, with the reference's `.mean(x)` / `.knl(x, x)`."""
+    """Value of `cbc(u)`: a scalar GP in x for the fixed control u, with the reference's `.mean(x)` / `.knl(x, x)`.
+    `expr * c` (GaussianProcessMulExpr, gp_algebra.py:201-223) scales the mean by c and the variance by c^2 -- the
+    reference writes its Lyapunov condition as `cbc * -1.0` (unicycle_move_to_pose.py:880-888)."""
 
-    def __init__(self, rel_degree, h, grad_h, model, u, k_alpha=None, gamma=None, hess_h=None):
+    def __init__(self, rel_degree, h, grad_h, model, u, k_alpha=None, gamma=None, hess_h=None, scale=1.0):
         self.rel_degree, self.h, self.grad_h, self.model, self.u = rel_degree, h, grad_h, model, u
-        self.k_alpha, self.gamma, self.hess_h = k_alpha, gamma, hess_h
+        self.k_alpha, self.gamma, self.hess_h, self.scale = k_alpha, gamma, hess_h, float(scale)
+
+    def __mul__(self, c):
+        return CBCExpr(self.rel_degree, self.h, self.grad_h, self.model, self.u, k_alpha=self.k_alpha, gamma=self.gamma,
+                       hess_h=self.hess_h, scale=self.scale * float(c))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self * -1.0
+
+    def _scaled(self, res):
+        (mA, mb), (Q, p, r), mean, var = res
+        c = self.scale
+        if c == 1.0:
+            return res
+        return (c * mA, c * mb), (c * c * Q, c * c * p, c * c * r), c * mean, c * c * var
 
     def quadratic_terms(self, x, u0):
+        """((mean_A, mean_b), (Q, p, r), mean(u0), var(u0)); x[n] / u0[m], or a batch x[b,n] / u0[b,m]."""
         if self.rel_degree == 2:
             hess = self.hess_h if self.hess_h is not None else (lambda z: _hessian_of(self.grad_h, z))
-            return reldeg2_quadratic_terms(self.model, self.h, self.grad_h, hess, x, u0, self.k_alpha)
-        reg = self.model
-        xb = reg._ensure_device_dtype(x.reshape(1, -1)).contiguous()
-        st, Mk, Bk, _ = reg._query(xb, want_W=False)
+            return self._scaled(reldeg2_quadratic_terms(self.model, self.h, self.grad_h, hess, x, u0, self.k_alpha))
+        reg, dets = resolve_model(self.model)
+        single = x.dim() == 1
+        xb = reg._ensure_device_dtype(x.reshape(-1, reg.x_dim)).contiguous()
+        ub = reg._ensure_device_dtype(u0.reshape(-1, reg.u_dim))
+        b, n, m = xb.shape[0], reg.x_dim, reg.u_dim
+        st, Mk, Bk, _, _ = posterior_for(reg, xb, jets=False)
         f = dict(dtype=xb.dtype, device=xb.device)
-        n, m = reg.x_dim, reg.u_dim
-        grad = torch.as_tensor(self.grad_h(xb[0]), **f).reshape(1, 1, n).contiguous()
-        cst = (self.gamma * torch.as_tensor(self.h(xb[0]), **f)).reshape(1, 1).contiguous()
-        (bfe, e), (V, bfv, v) = reldeg1_quadratic_terms(Mk, Bk, st["A"], grad, cst, torch.ones(1, **f),
-                                                        torch.zeros(1, n, **f), torch.zeros(1, n, m, **f))
-        u = reg._ensure_device_dtype(u0.reshape(-1))
-        mA, mb, Q, p, r = bfe[0, 0], e[0, 0], V[0, 0], bfv[0, 0], v[0, 0]
-        return (mA, mb), (Q, p, r), mA @ u + mb, u @ Q @ u + p @ u + r
+        grad = torch.stack([torch.as_tensor(self.grad_h(xi), **f).reshape(n) for xi in xb]).reshape(b, 1, n).contiguous()
+        cst = torch.stack([(self.gamma * torch.as_tensor(self.h(xi), **f)).reshape(()) for xi in xb]).reshape(b, 1).contiguous()
+        fhat, ghat, _ = _det_mean(dets, xb, reg, want_jac=False)
+        A = st["A"].expand(b, n, n).contiguous()
+        (bfe, e), (V, bfv, v) = reldeg1_quadratic_terms(Mk, Bk, A, grad, cst, torch.ones(1, **f), fhat, ghat)
+        mA, mb, Q, p, r = bfe[:, 0], e[:, 0], V[:, 0], bfv[:, 0], v[:, 0]
+        mean = (mA * ub).sum(-1) + mb
+        var = torch.einsum("bi,bij,bj->b", ub, Q, ub) + (p * ub).sum(-1) + r
+        if single:
+            return self._scaled(((mA[0], mb[0]), (Q[0], p[0], r[0]), mean[0], var[0]))
+        return self._scaled(((mA, mb), (Q, p, r), mean, var))
 
     def mean(self, x):
         return self.quadratic_terms(x, self.u)[2]
@@ -99,6 +182,13 @@ class CBCExpr:
         if xp is not x and not torch.equal(x, xp):
             raise NotImplementedError("cross-covariance of a constraint between two states is not on the hot path")
         return self.quadratic_terms(x, self.u)[3]
+
+
+def pack_terms(res):
+    """((mean_A, mean_b), (Q, p, r), ..) -> the packed row [.., T] of bcbf_cbc_terms / bcbf_controller_cones."""
+    (mA, mb), (Q, p, r) = res[0], res[1]
+    lead = mA.shape[:-1]
+    return torch.cat([mA, mb.reshape(*lead, 1), Q.reshape(*lead, -1), p, r.reshape(*lead, 1)], dim=-1)
 
 
 def cbc2_gp(h, grad_h, learned_model, utest, k_alpha, hess_h=None):

@@ -340,6 +340,36 @@ def coneqp(P, q, G, h, l, qdims, max_iters=100):
     return x, status, iters
 
 
+def controller_cones(terms, u_ref, kinds, factors=None, ctrl_reg=1.0, relax_weight=1.0, extravars=2, objective=True):
+    """Rows (G[Bt,Kt,nv], h[Bt,Kt], qdims, l, cstatus) of the SOCPController / QPController program over
+    y = [extravars.., u] (controllers.py:396-540, 614-662) from packed quadratic terms[Bt,K,T]."""
+    K = len(kinds)
+    if K:
+        _chk(terms)
+    ref = terms if K else u_ref
+    Bt = ref.shape[0]
+    m = u_ref.shape[1] if u_ref is not None else None
+    if m is None:
+        T = terms.shape[2]
+        m = next(mm for mm in range(1, 8) if terms_width(mm) == T)
+    kd = (ctypes.c_int * max(1, K))(*kinds)
+    fc = (ctypes.c_double * max(1, K))(*([1.0] * K if factors is None else [float(f) for f in factors]))
+    Kt = lib.bcbf_controller_cones_rows(kd, K, m, int(bool(objective)))
+    if Kt < 0:
+        raise ValueError("bad constraint kinds %r" % (kinds,))
+    nv = extravars + m
+    G = torch.empty(Bt, Kt, nv, dtype=torch.float64, device=ref.device)
+    h = torch.empty(Bt, Kt, dtype=torch.float64, device=ref.device)
+    cstatus = torch.zeros(Bt, max(K, 1), dtype=torch.int32, device=ref.device)
+    check(getattr(lib, "bcbf_controller_cones" + _suf(ref))(
+        _p(terms if K else None), _p(u_ref.contiguous() if u_ref is not None else None), kd, fc, float(ctrl_reg),
+        float(relax_weight), extravars, int(bool(objective)), _p(G), _p(h), _p(cstatus), Bt, K, m, _stream(ref)),
+        "bcbf_controller_cones")
+    l = sum(1 for k in kinds if k == 2)
+    qdims = ([m + 2] if objective else []) + [m + 2 for k in kinds if k != 2]
+    return G, h, qdims, l, cstatus[:, :K]
+
+
 def unicycle_constraints(x, plan, dot_plan, Kp, clf_gamma, centers, radii, tw, gammas, L_mean, out=None):
     """CLC row + obstacle rows: (grad[Bt,1+Kob,3], cst[Bt,1+Kob], fhat[Bt,3], ghat[Bt,3,2])."""
     _chk(x, plan, dot_plan, Kp, centers, radii, tw, gammas)

@@ -259,6 +259,26 @@ int bcbf_coneqp_f64(const double* P, const double* q, const double* G, const dou
                     int nv, int l, const int* qdims, int nq,
                     double* x, int* status, int* iters, int Bt, int max_iters, void* stream);
 
+/* K9 for the generic controllers (controllers.py): rows of the cone program of SOCPController.control (:569-591)
+ * / QPController.control (:638-662) over y = [extravars.., u], in the layout bcbf_coneqp_f64 takes
+ * (optimizers.py:6-39: |A y + b| <= c'y + d  ->  Gq = [-c'; -A], hq = [d; b]).
+ * terms[Bt,K,T] packed (bfe,e,V,bfv,v) as written by bcbf_cbc_terms / bcbf_cbc2_terms; kind[K], factor[K] are
+ * HOST arrays.  kind 0 = convert_cbc_terms_to_socp_terms (:423-482, L' form, retry with +1e-3 I, relaxation
+ * column extravars-1), kind 1 = _socp_safety (:502-540, lower factor L as the reference has it, times factor;
+ * symmetric-eigen fallback sqrt(max(Lambda,0)) V' when a pivot is not positive), kind 2 = the linear row
+ * 0 <= c'y + d of QPController._qp_stability (:614-629).  objective != 0 (extravars == 2) adds the epigraph cone of
+ * _socp_objective (:396-420) built from u_ref[Bt,m], ctrl_reg, relax_weight.
+ * Row order: kind-2 rows, objective cone, then the kind-0/1 cones in input order (m+2 rows each);
+ * Kt = bcbf_controller_cones_rows(kind, K, m, objective).  -> G[Bt,Kt,extravars+m], h[Bt,Kt] (fp64),
+ * cstatus[Bt,K] (optional; BCBF_SOCP_BADCONE when kind 0 cannot be factored). */
+int bcbf_controller_cones_rows(const int* kind, int K, int m, int objective);
+int bcbf_controller_cones_f32(const float* terms, const float* u_ref, const int* kind, const double* factor,
+                              double ctrl_reg, double relax_weight, int extravars, int objective, double* G, double* h,
+                              int* cstatus, int Bt, int K, int m, void* stream);
+int bcbf_controller_cones_f64(const double* terms, const double* u_ref, const int* kind, const double* factor,
+                              double ctrl_reg, double relax_weight, int extravars, int objective, double* G, double* h,
+                              int* cstatus, int Bt, int K, int m, void* stream);
+
 /* Unicycle task functions, batched (unicycle_move_to_pose.py:522-615 CLFCartesian, :618-696
  * ObstacleCBF, :235-257 AckermannDrive.g_func, planner.py:54-64 PiecewiseLinearPlanner).
  * x[Bt,3] plan[Bt,3] dot_plan[Bt,3] Kp[3] clf_gamma; obstacles: centers[Bt,Kob,2] radii[Bt,Kob]

@@ -305,8 +305,83 @@ def main_cbc2():
     gen_cbc2("n3m2_N24", n=3, m=2, N=24, seed=43, kind="generic")
 
 
+def gen_controllers(tag, N, seed):
+    """SOCPController / QPController of bayes_cbf/controllers.py on the pendulum (n=2, m=1): the named cone
+    constraints the reference hands to its optimiser (:396-540, 542-567) and QPController's rows (:614-662)."""
+    import math
+    from bayes_cbf.controllers import SOCPController, QPController, to_numpy
+    from bayes_cbf.pendulum import RadialCBFRelDegree2
+    from bayes_cbf.cbc1 import RelDeg1Safety
+    n, m = 2, 1
+    reg, X, U, Xdot = make_regressor(cam.ControlAffineRegressor, n, m, N, seed)
+    out = dict(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), **hyper(reg, n, m))
+    cbf2 = RadialCBFRelDegree2(reg, dtype=torch.float64)
+
+    class EnergyCLC(RelDeg1Safety):            # V = w^2/2 + (1 - cos theta), as a rel-degree-1 condition on the learned model
+        gamma, model, max_unsafe_prob = 2.0, reg, 0.01
+
+        def cbf(self, x):
+            return 0.5 * x[1] ** 2 + (1 - torch.cos(x[0]))
+
+        def grad_cbf(self, x):
+            return torch.stack([torch.sin(x[0]), x[1]])
+
+        def clc(self, t, u):
+            return self.cbc(u) * -1.0
+
+    clf = EnergyCLC()
+
+    class Unsafe:
+        def __init__(self):
+            self.u = None
+
+        def control(self, x, t=None):
+            return self.u
+
+    unsafe = Unsafe()
+    ctrl_reg, relax_w = 1.0, 100.0
+    socp = SOCPController(n, m, ctrl_reg, relax_w, reg, [cbf2], clf, unsafe, None)
+    qp = QPController(n, m, ctrl_reg, relax_w, reg, [cbf2], clf, unsafe, None)
+    torch.manual_seed(seed + 5)
+    S = 4
+    xs = 0.8 * (2 * torch.rand(S, n) - 1)
+    urefs = 2 * torch.rand(S, m) - 1
+    recs = {}
+    with RandRecorder() as rr:
+        for i in range(S):
+            x, u_ref = xs[i].clone(), urefs[i].clone()
+            cons = socp._named_socp_constraints(7, x, u_ref, convert_out=to_numpy, extravars=2)
+            assert [c[0] for c in cons] == ["Objective", "Safety_0 gt 0", "Stability gt 0"]
+            for (name, (A, b, c, d)), key in zip(cons, ("obj", "safety", "stab")):
+                for k, v in zip("Abcd", (A, b, c, d)):
+                    recs.setdefault("%s_%s" % (key, k), []).append(np.asarray(v, dtype=np.float64))
+            (mA, mb), (Q, p_, r_), mean, var = cbc2_quadratic_terms(cbf2.cbc, x, u_ref)
+            recs.setdefault("safety_terms", []).append(np.concatenate([t2n(mA).ravel(), t2n(mb).ravel(), t2n(Q).ravel(),
+                                                                       t2n(p_).ravel(), t2n(r_).ravel()]))
+            (mA, mb), (Q, p_, r_), mean, var = cbc2_quadratic_terms(lambda u: clf.clc(7, u), x, u_ref)
+            recs.setdefault("stab_terms", []).append(np.concatenate([t2n(mA).ravel(), t2n(mb).ravel(), t2n(Q).ravel(),
+                                                                     t2n(p_).ravel(), t2n(r_).ravel()]))
+            bfc, d = qp._qp_stability(clf.clc, 7, x, u_ref, extravars=1)
+            recs.setdefault("qp_c", []).append(t2n(bfc))
+            recs.setdefault("qp_d", []).append(t2n(d))
+    assert len(rr.draws) == 1            # only the K_b jitter
+    out.update(jitter_rand=np.stack(rr.draws), xs=t2n(xs), urefs=t2n(urefs), ctrl_reg=ctrl_reg, relax_weight=relax_w,
+               safety_factor=cbf2.safety_factor(), k_alpha=np.array(cbf2.k_alpha), clf_gamma=clf.gamma, t=7)
+    for k, v in recs.items():
+        out["t_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "controllers_%s.npz" % tag), **out)
+    print("controllers_%s: N=%d" % (tag, N))
+
+
+def main_controllers():
+    gen_controllers("pendulum_N16", N=16, seed=51)
+    gen_controllers("pendulum_N40", N=40, seed=52)
+
+
 if __name__ == '__main__':
-    if 'cbc2' in sys.argv:
+    if 'controllers' in sys.argv:
+        main_controllers()
+    elif 'cbc2' in sys.argv:
         main_cbc2()
     else:
         main()

@@ -628,3 +628,84 @@ def test_edge_cases_empty_batch_single_point_and_maximum_size(ops):
                                         h["s2"][0][None], h["Bm"][0][None], h["M0"][0][None], h["xq"][0][None])
         rel_close(host(Mk)[0], Mk_o[0], tol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk N=2048")
         rel_close(host(Bk)[0], Bk_o[0], tol, scale=h["s2"][0] * np.abs(h["Bm"][0]).max(), what="Bk N=2048")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_controller_cones_rows_match_oracle(ops, m, dtype):
+    """bcbf_controller_cones: every constraint kind of SOCPController / QPController (controllers.py:396-540, 614-629),
+    positive-definite and indefinite Asq, a batch of instances, against the numpy restatement."""
+    from oracle import controllers as oc
+    rng = np.random.default_rng(100 + m)
+    Bt, K, ev = 37, 4, 2
+    kinds, factors = [1, 2, 0, 1], [1.7, 1.0, 1.0, 0.4]
+    T = m + 1 + m * m + m + 1
+    terms = np.zeros((Bt, K, T))
+    raw = []
+    for b in range(Bt):
+        row = []
+        for k in range(K):
+            R = rng.normal(size=(m + 1, m + 1))
+            Asq = R @ R.T + 0.05 * np.eye(m + 1)
+            if kinds[k] == 1 and b % 3 == 0:          # indefinite: exercises the eigen fallback
+                w, Q = np.linalg.eigh(Asq)
+                w[0] = -0.3 * abs(w[0]) - 0.01
+                Asq = (Q * w) @ Q.T
+            bfe, e = rng.normal(size=m), rng.normal()
+            V, bfv, v = Asq[1:, 1:], 2 * Asq[1:, 0], Asq[0, 0]
+            terms[b, k] = np.concatenate([bfe, [e], V.ravel(), bfv, [v]])
+            row.append((bfe, e, V, bfv, v))
+        raw.append(row)
+    u_ref = rng.normal(size=(Bt, m))
+    G, h, qdims, l, cst = ops.controller_cones(dev(terms, dtype), dev(u_ref, dtype), kinds, factors, ctrl_reg=0.7,
+                                               relax_weight=30.0, extravars=ev, objective=True)
+    assert G.dtype == torch.float64 and l == 1 and qdims == [m + 2] * 4 and int(cst.abs().max()) == 0
+    G, h = host(G), host(h)
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    if dtype == torch.float32:                            # the oracle sees the rounded inputs the kernel saw
+        terms = host(dev(terms, dtype)); u_ref = host(dev(u_ref, dtype))
+    nv = ev + m
+    for b in range(Bt):
+        tb = [(t_[:m], t_[m], t_[m + 1:m + 1 + m * m].reshape(m, m), t_[m + 1 + m * m:m + 1 + m * m + m], t_[-1]) for t_ in terms[b]]
+        # linear row first
+        _, _, c, d = oc.convert_cbc_terms_to_socp_terms(*tb[1], ev)
+        np.testing.assert_allclose(G[b, 0], -c, rtol=tol, atol=tol)
+        np.testing.assert_allclose(h[b, 0], d, rtol=tol, atol=tol)
+        Ro, ho, ao, bo = oc.socp_objective(u_ref[b], 0.7, 30.0, extravars=ev)
+        np.testing.assert_allclose(G[b, 1:m + 3], np.vstack([-ao, -Ro]), rtol=tol, atol=tol)
+        np.testing.assert_allclose(h[b, 1:m + 3], np.concatenate([[bo], ho]), rtol=tol, atol=tol)
+        r0 = m + 3
+        for k in (0, 2, 3):
+            if kinds[k] == 0:
+                A, bb, c, d = oc.convert_cbc_terms_to_socp_terms(*tb[k], ev)
+            else:
+                A, bb, c, d = oc.socp_safety(*tb[k], factors[k], ev)
+            Gk, hk = G[b, r0:r0 + m + 2], h[b, r0:r0 + m + 2]
+            np.testing.assert_allclose(Gk[0], -c, rtol=tol, atol=tol)
+            np.testing.assert_allclose(hk[0], d, rtol=tol, atol=tol)
+            Mg, Mr = np.column_stack([hk[1:], -Gk[1:, ev:]]), np.column_stack([bb, A[:, ev:]])
+            assert np.all(Gk[1:, :ev] == 0)
+            fallback = kinds[k] == 1 and b % 3 == 0
+            if fallback:                                   # rows = sqrt(lambda) v', up to the sign of v
+                np.testing.assert_allclose(Mg.T @ Mg, Mr.T @ Mr, rtol=50 * tol, atol=50 * tol)
+                np.testing.assert_allclose(np.abs(Mg), np.abs(Mr), rtol=200 * tol, atol=200 * tol)
+            else:
+                np.testing.assert_allclose(Mg, Mr, rtol=10 * tol, atol=10 * tol)
+            r0 += m + 2
+        assert r0 == G.shape[1]
+
+
+def test_controller_cones_flags_unfactorable_stability_terms(ops):
+    """kind 0 retries once with + 1e-3 I (controllers.py:464-469); a clearly indefinite Asq is reported per instance."""
+    m = 1
+    good = np.array([0.3, 0.1, 1.0, 0.2, 2.0])          # bfe, e, V, bfv, v
+    tiny = np.array([0.3, 0.1, 1.0, 2.0, 1.0 - 5e-4])   # v V - bfv^2/4 slightly negative: fixed by the 1e-3 shift
+    bad = np.array([0.3, 0.1, 1.0, 0.2, -2.0])
+    terms = dev(np.stack([good, tiny, bad])[:, None, :], torch.float64)
+    G, h, qd, l, cst = ops.controller_cones(terms, None, [0], extravars=1, objective=False)
+    c = host(cst).ravel()
+    assert c[0] == 0 and c[1] == 0 and c[2] != 0
+    from oracle import controllers as oc
+    A, b, c, d = oc.convert_cbc_terms_to_socp_terms(tiny[:1], tiny[1], tiny[2:3].reshape(1, 1), tiny[3:4], tiny[4], 1)
+    np.testing.assert_allclose(-host(G)[1, 1:], A, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(host(h)[1, 1:], b, rtol=1e-10, atol=1e-12)

