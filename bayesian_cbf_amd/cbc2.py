@@ -131,13 +131,14 @@ class CBCExpr:
     `expr * c` (GaussianProcessMulExpr, gp_algebra.py:201-223) scales the mean by c and the variance by c^2 -- the
     reference writes its Lyapunov condition as `cbc * -1.0` (unicycle_move_to_pose.py:880-888)."""
 
-    def __init__(self, rel_degree, h, grad_h, model, u, k_alpha=None, gamma=None, hess_h=None, scale=1.0):
+    def __init__(self, rel_degree, h, grad_h, model, u, k_alpha=None, gamma=None, hess_h=None, scale=1.0, cst_fn=None):
         self.rel_degree, self.h, self.grad_h, self.model, self.u = rel_degree, h, grad_h, model, u
         self.k_alpha, self.gamma, self.hess_h, self.scale = k_alpha, gamma, hess_h, float(scale)
+        self.cst_fn = cst_fn if cst_fn is not None else (lambda x: self.gamma * torch.as_tensor(self.h(x)))
 
     def __mul__(self, c):
         return CBCExpr(self.rel_degree, self.h, self.grad_h, self.model, self.u, k_alpha=self.k_alpha, gamma=self.gamma,
-                       hess_h=self.hess_h, scale=self.scale * float(c))
+                       hess_h=self.hess_h, scale=self.scale * float(c), cst_fn=self.cst_fn)
 
     __rmul__ = __mul__
 
@@ -164,7 +165,7 @@ class CBCExpr:
         st, Mk, Bk, _, _ = posterior_for(reg, xb, jets=False)
         f = dict(dtype=xb.dtype, device=xb.device)
         grad = torch.stack([torch.as_tensor(self.grad_h(xi), **f).reshape(n) for xi in xb]).reshape(b, 1, n).contiguous()
-        cst = torch.stack([(self.gamma * torch.as_tensor(self.h(xi), **f)).reshape(()) for xi in xb]).reshape(b, 1).contiguous()
+        cst = torch.stack([torch.as_tensor(self.cst_fn(xi), **f).reshape(()) for xi in xb]).reshape(b, 1).contiguous()
         fhat, ghat, _ = _det_mean(dets, xb, reg, want_jac=False)
         A = st["A"].expand(b, n, n).contiguous()
         (bfe, e), (V, bfv, v) = reldeg1_quadratic_terms(Mk, Bk, A, grad, cst, torch.ones(1, **f), fhat, ghat)
@@ -191,9 +192,47 @@ def pack_terms(res):
     return torch.cat([mA, mb.reshape(*lead, 1), Q.reshape(*lead, -1), p, r.reshape(*lead, 1)], dim=-1)
 
 
+def lie1_gradient(model, grad_gp, x, eigeps=2e-3):
+    """GradientGP(Det(grad_h).t() @ f_gp) at x: (grad of the mean [n], d2 k / dx dx' at x = x' [n,n]) from the posterior
+    jets (gp_algebra.py:340-402), with the reference's eigenvalue check (> -2e-3) and clean-up of the Hessian."""
+    reg, dets = resolve_model(model)
+    xb = reg._ensure_device_dtype(x.reshape(1, -1)).contiguous()
+    n, C = reg.x_dim, 1 + reg.u_dim
+    st, Mk, Bk, G, Mj = posterior_for(reg, xb, jets=True)
+    f = dict(dtype=xb.dtype, device=xb.device)
+    m0, dm0 = Mk[0, :, 0], torch.stack([Mj[0, :, (1 + i) * C] for i in range(n)], dim=1)     # dm0[j, i] = d m0_j / dx_i
+    if dets:
+        fhat, _, J = _det_mean(dets, xb, reg, want_jac=True)
+        m0, dm0 = m0 + fhat[0], dm0 + J[0]
+    gh = torch.as_tensor(grad_gp.mean(xb[0]), **f).reshape(n)
+    Hh = torch.as_tensor(grad_gp.jac(xb[0]) if grad_gp.jac is not None else _hessian_of(grad_gp.mean, xb[0]), **f)
+    A, B00, ell, s2 = st["A"][0], st["Bm"][0, 0, 0], st["ell"][0], st["s2"][0]
+    gmean = Hh.t() @ m0 + dm0.t() @ gh
+    idx = [(1 + i) * C for i in range(n)]
+    Gm = G[0]
+    s00, s_i = Bk[0, 0, 0], -Gm[idx, 0]
+    sij = torch.diag(s2 / (ell * ell) * B00) - Gm[idx][:, idx]
+    Agh = A @ gh
+    HAg = Hh @ Agh
+    H = (Hh @ A @ Hh) * s00 + torch.outer(HAg, s_i) + torch.outer(s_i, HAg) + (gh @ Agh) * sij
+    w, V = torch.linalg.eigh(0.5 * (H + H.t()))
+    assert bool((w > -eigeps).all()), " Hessian must be positive definite"
+    if bool((w < 0).any()):
+        H = (V * w.clamp_min(0.0)) @ V.t()
+    return gmean.to(dtype=x.dtype, device=x.device), H.to(dtype=x.dtype, device=x.device)
+
+
 def cbc2_gp(h, grad_h, learned_model, utest, k_alpha, hess_h=None):
-    """cbc2.py:26-33: L_f^2 h + k_alpha[0] h + k_alpha[1] L_f h as a GP in x for the control `utest`."""
-    return CBCExpr(2, h, grad_h, learned_model, utest, k_alpha=k_alpha, hess_h=hess_h)
+    """cbc2.py:26-33, written as the reference writes it; the expression lowers onto the jet kernel + closed-form
+    terms (gp_algebra.lower).  `hess_h` (optional) is the analytic d grad_h / dx; autograd on grad_h otherwise."""
+    from .gp_algebra import DeterministicGP, GradientGP
+    f_gp = learned_model.f_func_gp()
+    fu_gp = learned_model.fu_func_gp(utest)
+    h_gp = DeterministicGP(h, shape=(1,), name="h(x)")
+    grad_h_gp = DeterministicGP(grad_h, shape=(learned_model.state_size,), name="grad h(x)", jac=hess_h)
+    L1h = grad_h_gp.t() @ f_gp
+    L2h = GradientGP(L1h, x_shape=(learned_model.state_size,)).t() @ fu_gp
+    return L2h + h_gp * k_alpha[0] + L1h * k_alpha[1]
 
 
 def cbc2_quadratic_terms(cbc2, x, u, *more):
@@ -203,8 +242,8 @@ def cbc2_quadratic_terms(cbc2, x, u, *more):
     if more:
         return reldeg2_quadratic_terms(cbc2, x, u, *more)
     expr = cbc2(u)
-    if not isinstance(expr, CBCExpr):
-        raise TypeError("cbc2(u) must come from cbc2_gp / RelDeg1Safety.cbc / RelDeg2Safety.cbc of this package")
+    if not hasattr(expr, "quadratic_terms"):
+        raise TypeError("cbc2(u) must be a GP expression of this package (gp_algebra / cbc2_gp / RelDeg*Safety.cbc)")
     return expr.quadratic_terms(x, u)
 
 

@@ -94,7 +94,8 @@ class ControlAffineRegressor:
         self.rand_fn = lambda k: torch.rand(k, dtype=self.dtype, device=self.device, generator=self.generator)
         self.Xtrain = self.Utrain = self.XdotTrain = None
         self._cache = dict()
-        self._f_func_gp = GaussianProcess(self.f_func_mean, self.f_func_knl, (self.x_dim,), name="f")
+        self._f_func_gp = GaussianProcess(self.f_func_mean, self.f_func_knl, (self.x_dim,), name="f",
+                                          source=(self, "f", None))
 
     # ---------------------------------------------------------------- bookkeeping
     @property
@@ -417,7 +418,7 @@ class ControlAffineRegressor:
 
     def fu_func_gp(self, Utest_in):
         gp = GaussianProcess(mean=partial(self.fu_func_mean, Utest_in), knl=partial(self.fu_func_knl, Utest_in),
-                             shape=(self.x_dim,), name="F(.)u")
+                             shape=(self.x_dim,), name="F(.)u", source=(self, "fu", Utest_in))
         gp.register_covar(self._f_func_gp, partial(self.covar_fu_f, Utest_in))
         return gp
 

@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 from .cbc2 import cbc2_quadratic_terms, pack_terms
+from .gp_algebra import GaussianProcess
 from .optimizers import InfeasibleProblemError
 
 
@@ -103,33 +104,31 @@ class EpsilonGreedyController(ABC):
         return torch.max(torch.min(u, torch.as_tensor(max_).to(u)), torch.as_tensor(min_).to(u))
 
 
-class _SummedGP:
-    """fu_func_gp of a sum of models (GaussianProcessAddExpr, gp_algebra.py:109-130): means add; deterministic
-    summands carry no covariance, so the kernel is the learned model's."""
+class _SummedGP(GaussianProcess):
+    """f_func_gp / fu_func_gp of a sum of models (GaussianProcessAddExpr, gp_algebra.py:109-130): means add;
+    deterministic summands carry no covariance, so the kernel is the learned model's.  A leaf of the expression
+    algebra (`source` = the summed model): conditions built on it lower onto the kernels with the mean shifted."""
 
-    def __init__(self, learned_gp, det_means, shape):
-        self._gp, self._dets, self._shape = learned_gp, det_means, shape
+    def __init__(self, learned_gp, det_means, shape, source):
+        self._gp, self._dets = learned_gp, det_means
 
-    @property
-    def shape(self):
-        return self._shape
+        def mean(x):
+            out = self._gp.mean(x) if self._gp is not None else 0
+            for d in self._dets:
+                out = out + torch.as_tensor(d(x)).to(x)
+            return out
 
-    def mean(self, x):
-        out = self._gp.mean(x) if self._gp is not None else 0
-        for d in self._dets:
-            out = out + torch.as_tensor(d(x)).to(x)
-        return out
+        def knl(x, xp):
+            if self._gp is None:
+                return x.new_zeros(max(shape), max(shape))
+            return self._gp.knl(x, xp)
 
-    def knl(self, x, xp):
-        if self._gp is None:
-            k = max(self._shape)
-            return x.new_zeros(k, k)
-        return self._gp.knl(x, xp)
+        super().__init__(mean, knl, shape, name="sum", source=source)
 
     def covar(self, Z, x, xp):
         if self._gp is None:
-            return x.new_zeros(max(self._shape), max(Z.shape))
-        return self._gp.covar(Z, x, xp)
+            return x.new_zeros(max(self.shape), max(Z.shape))
+        return self._gp.covar(getattr(Z, "_gp", Z), x, xp)
 
 
 class SumDynamicModels:
@@ -158,7 +157,15 @@ class SumDynamicModels:
         dets = [m for m in self.models if not hasattr(m, "fu_func_gp")]
         assert len(learned) <= 1, "one learned summand (the cross-covariance of two learned models is not defined)"
         fu = lambda m: (lambda x: torch.as_tensor(m.f_func(x)).to(x) + torch.as_tensor(m.g_func(x)).to(x) @ u.to(x))
-        return _SummedGP(learned[0].fu_func_gp(u) if learned else None, [fu(m) for m in dets], (self.state_size,))
+        return _SummedGP(learned[0].fu_func_gp(u) if learned else None, [fu(m) for m in dets], (self.state_size,),
+                         source=(self, "fu", u))
+
+    def f_func_gp(self):
+        learned = [m for m in self.models if hasattr(m, "f_func_gp")]
+        dets = [m for m in self.models if not hasattr(m, "f_func_gp")]
+        f = lambda m: (lambda x: torch.as_tensor(m.f_func(x)).to(x))
+        return _SummedGP(learned[0].f_func_gp() if learned else None, [f(m) for m in dets], (self.state_size,),
+                         source=(self, "f", None))
 
 
 class MeanAdjustedModel(SumDynamicModels):

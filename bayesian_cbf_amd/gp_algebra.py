@@ -1,18 +1,54 @@
-"""Minimal mirror of the reference's GP views (bayes_cbf/gp_algebra.py:70-106, 258-315).
+"""Mirror of bayes_cbf/gp_algebra.py: the GP expression algebra the reference builds its safety conditions with.
 
-The reference builds an expression tree over these objects and differentiates it with autograd to
-obtain constraint terms; here the terms come from closed-form kernels (`ops.cbc_terms`,
-`ops.cbc_socp`), so only the leaf types that user code touches are kept: `GaussianProcess`
-(mean / knl / covar with registered cross-covariances) and `DeterministicGP`."""
+The reference evaluates an expression tree (`grad_h.t() @ fu_gp + h_gp`, `GradientGP(L1h).t() @ fu_gp + ...`) node by
+node with autograd through `custom_predict` (gp_algebra.py:109-255, 319-402).  Here the same operators build the same
+tree, but evaluation LOWERS the tree onto the closed-form device kernels:
+
+    sum_i c_i * Det(g_i).t() @ fu_gp  +  sum_j c_j * Det(s_j)                     -> rel-degree-1 condition
+        (bcbf_posterior_query + bcbf_cbc_terms: GaussianProcessAddExpr / DetMatmulExpr / MulExpr rules)
+    GradientGP(Det(grad_h).t() @ f_gp).t() @ fu_gp + c0 * Det(h) + c1 * (Det(grad_h).t() @ f_gp)   -> rel-degree 2
+        (bcbf_posterior_jets + bcbf_cbc2_terms: MatmulExpr product-of-Gaussians terms, GradientGP derivative kernels)
+    GradientGP(Det(grad_h).t() @ f_gp)   mean(x), knl(x, x)                        -> from the jets
+
+where `f_gp` / `fu_gp` are the leaves handed out by a `ControlAffineRegressor` (or a sum of dynamics models around
+one).  Any other shape of tree raises `NotImplementedError` -- there is no generic autograd evaluator (and no CPU path).
+Leaves keep the reference's `mean / knl / covar / register_covar` behaviour (gp_algebra.py:70-106, 258-315)."""
+import torch
 
 
 class GaussianProcessBase:
-    pass
+    def __add__(self, Y):
+        return GaussianProcessAddExpr(self, Y)
+
+    def __radd__(self, Y):                       # sum([...]) starts from 0
+        if isinstance(Y, (int, float)) and Y == 0:
+            return self
+        return GaussianProcessAddExpr(Y, self)
+
+    def __mul__(self, a):
+        return GaussianProcessMulExpr(self, a)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, a):
+        return GaussianProcessMulExpr(self, 1 / a)
+
+    def __neg__(self):
+        return GaussianProcessMulExpr(self, -1.0)
+
+    def __matmul__(self, Y):
+        return GaussianProcessMatmulExpr(self, Y)
+
+    def t(self):
+        return GaussianProcessTranspose(self)
 
 
 class DeterministicGP(GaussianProcessBase):
-    def __init__(self, mean, shape, name="{mean}"):
-        self._mean, self._shape = mean, shape
+    """A deterministic function seen as a GP with zero covariance (gp_algebra.py:70-106).  `jac` (optional) is the
+    analytic Jacobian d mean / dx used by GradientGP instead of autograd on `mean`."""
+
+    def __init__(self, mean, shape, name="{mean}", jac=None):
+        self._mean, self._shape, self.jac = mean, shape, jac
         self._name = name.format(mean=mean)
 
     @property
@@ -31,12 +67,16 @@ class DeterministicGP(GaussianProcessBase):
 
 
 class GaussianProcess(GaussianProcessBase):
-    def __init__(self, mean, knl, shape, assume_independence=False, name="{mean}"):
+    """Leaf GP with registered cross-covariances (gp_algebra.py:258-315).  `source = (model, kind, u)` with kind
+    'f' or 'fu' marks the leaves a dynamics model hands out; expressions over them evaluate on the device."""
+
+    def __init__(self, mean, knl, shape, assume_independence=False, name="{mean}", source=None):
         self._mean, self._knl, self._shape = mean, knl, shape
         self._covars = dict()
         self.register_covar(self, self.knl)
         self.assume_independence = assume_independence
         self._name = name.format(mean=mean)
+        self.source = source
 
     @property
     def shape(self):
@@ -61,3 +101,190 @@ class GaussianProcess(GaussianProcessBase):
         """One function for both directions, as the reference does (gp_algebra.py:306-309)."""
         self._covars[id(gp)] = covar_func
         gp._covars[id(self)] = covar_func
+
+
+# ------------------------------------------------------------------------------------------------ expression nodes
+class GaussianProcessExpr(GaussianProcessBase):
+    """Inner node: evaluates by lowering the whole tree (see module docstring)."""
+
+    def _lowered(self):
+        if getattr(self, "_low", None) is None:
+            self._low = lower(self)
+        return self._low
+
+    def quadratic_terms(self, x, u0):
+        return self._lowered().quadratic_terms(x, u0)
+
+    def mean(self, x):
+        return self._lowered().mean(x)
+
+    def knl(self, x, xp):
+        return self._lowered().knl(x, xp)
+
+    def covar(self, Z, x, xp):
+        raise NotImplementedError("cross-covariance of a composed expression with another GP is folded into the "
+                                  "closed-form terms; evaluate the full condition instead")
+
+
+class GaussianProcessAddExpr(GaussianProcessExpr):
+    def __init__(self, X, Y):
+        assert isinstance(X, GaussianProcessBase) and isinstance(Y, GaussianProcessBase)
+        self.lhs, self.rhs = X, Y
+
+    @property
+    def shape(self):
+        return self.lhs.shape
+
+
+class GaussianProcessMulExpr(GaussianProcessExpr):
+    def __init__(self, X, a):
+        assert isinstance(X, GaussianProcessBase)
+        assert isinstance(a, (float, int, torch.Tensor))
+        self.rhs, self.a = X, float(a)
+
+    @property
+    def shape(self):
+        return self.rhs.shape
+
+
+class GaussianProcessTranspose(GaussianProcessExpr):
+    def __init__(self, gp):
+        assert isinstance(gp, GaussianProcessBase)
+        self.gp = gp
+
+    @property
+    def shape(self):
+        s = self.gp.shape
+        return (s[1],) if len(s) == 2 else (1, s[0])
+
+    def t(self):
+        return self.gp
+
+    def mean(self, x):
+        return self.gp.mean(x)
+
+
+class GaussianProcessMatmulExpr(GaussianProcessExpr):
+    """X @ Y with X a transposed vector GP: the inner product X'Y, a scalar GP (gp_algebra.py:133-199; the
+    reference's DetMatmulExpr is the special case of a deterministic X)."""
+
+    def __init__(self, X, Y):
+        assert isinstance(X, GaussianProcessBase) and isinstance(Y, GaussianProcessBase)
+        assert X.shape[-1] == Y.shape[0]
+        self.lhs = X.t()          # the column vector, as the reference stores it
+        self.rhs = Y
+
+    @property
+    def shape(self):
+        return (1,)
+
+
+GaussianProcessDetMatmulExpr = GaussianProcessMatmulExpr
+
+
+class GradientGP(GaussianProcessExpr):
+    """grad_x of a scalar GP expression (gp_algebra.py:319-402).  Supported operand: Det(grad_h).t() @ f_gp (the Lie
+    derivative L_f h); mean(x) = grad (grad_h' m_f)(x), knl(x, x) = d2/dx dx' of its kernel, from the posterior jets."""
+
+    def __init__(self, f, x_shape, grad_check=False, analytical_hessian=True):
+        self.gp, self.x_shape = f, x_shape
+
+    @property
+    def shape(self):
+        return self.x_shape
+
+    def _lie1(self):
+        terms, _ = _flatten(self.gp, 1.0)
+        if len(terms) != 1 or terms[0][1][0] != "L1" or terms[0][0] != 1.0 or terms[0][1][2].source[1] != "f":
+            raise NotImplementedError("GradientGP is evaluated for Det(grad_h).t() @ f_func_gp() only")
+        _, (_, grad_gp, leaf) = terms[0]
+        return grad_gp, leaf
+
+    def mean(self, x):
+        from .cbc2 import lie1_gradient
+        grad_gp, leaf = self._lie1()
+        return lie1_gradient(leaf.source[0], grad_gp, x)[0]
+
+    def knl(self, x, xp):
+        from .cbc2 import lie1_gradient
+        if xp is not x and not torch.equal(x, xp):
+            raise NotImplementedError("derivative kernel between two different states is not on the hot path")
+        grad_gp, leaf = self._lie1()
+        return lie1_gradient(leaf.source[0], grad_gp, x)[1]
+
+
+# ------------------------------------------------------------------------------------------------ lowering
+def _flatten(e, coef):
+    """-> ([(coef, term)], None) with term one of
+        ("det", DeterministicGP)                                 scalar deterministic summand
+        ("L1", Det(grad), leaf)                                  Det(grad).t() @ leaf
+        ("L2", Det(grad), leaf_f, leaf_fu)                       GradientGP(Det(grad).t() @ leaf_f).t() @ leaf_fu"""
+    if isinstance(e, GaussianProcessAddExpr):
+        return _flatten(e.lhs, coef)[0] + _flatten(e.rhs, coef)[0], None
+    if isinstance(e, GaussianProcessMulExpr):
+        return _flatten(e.rhs, coef * e.a)[0], None
+    if isinstance(e, DeterministicGP):
+        return [(coef, ("det", e))], None
+    if isinstance(e, GaussianProcessMatmulExpr):
+        X, Y = e.lhs, e.rhs
+        if isinstance(Y, DeterministicGP) and not isinstance(X, DeterministicGP):
+            X, Y = Y, X                                        # inner product is symmetric
+        if isinstance(Y, GaussianProcess) and Y.source is not None:
+            if isinstance(X, DeterministicGP):
+                return [(coef, ("L1", X, Y))], None
+            if isinstance(X, GradientGP):
+                grad_gp, leaf_f = X._lie1()
+                return [(coef, ("L2", grad_gp, leaf_f, Y))], None
+    raise NotImplementedError("expression %s has no closed-form lowering (module docstring lists the supported shapes)"
+                              % type(e).__name__)
+
+
+def lower(expr):
+    """Expression tree -> cbc2.CBCExpr (rel-degree 1 or 2) evaluated by the device kernels."""
+    from .cbc2 import CBCExpr
+    terms, _ = _flatten(expr, 1.0)
+    dets = [(c, t[1]) for c, t in terms if t[0] == "det"]
+    l1s = [(c, t) for c, t in terms if t[0] == "L1"]
+    l2s = [(c, t) for c, t in terms if t[0] == "L2"]
+
+    def det_sum(scale=1.0):
+        def fn(x):
+            out = 0.0
+            for c, d in dets:
+                out = out + (c / scale) * torch.as_tensor(d.mean(x)).reshape(()).to(x)
+            return out if dets else x.new_zeros(())
+        return fn
+
+    if not l2s:
+        if not l1s:
+            raise NotImplementedError("expression has no random term")
+        leaf0 = l1s[0][1][2]
+        model, kind, u = leaf0.source
+        for _, t in l1s[1:]:
+            mdl, knd, uu = t[2].source
+            if t[2] is not leaf0 and (mdl is not model or knd != kind or uu is not u):
+                raise NotImplementedError("all random terms of a rel-degree-1 condition must be one model's f_func_gp() "
+                                          "or fu_func_gp(u) for one u")
+        if kind == "f":
+            u = torch.zeros(model.ctrl_size)
+
+        def grad_sum(x):
+            out = 0.0
+            for c, t in l1s:
+                out = out + c * torch.as_tensor(t[1].mean(x)).to(x)
+            return out
+        return CBCExpr(1, None, grad_sum, model, u, cst_fn=det_sum())
+    if len(l2s) != 1:
+        raise NotImplementedError("one second Lie derivative term per condition")
+    c2, (_, grad_gp, leaf_f, leaf_fu) = l2s[0]
+    model, _, u = leaf_fu.source
+    if leaf_f.source[0] is not model:
+        raise NotImplementedError("L_f h and f + g u must come from the same model")
+    ka1 = 0.0
+    for c, t in l1s:
+        if t[1] is not grad_gp or t[2].source[1] != "f" or t[2].source[0] is not model:
+            raise NotImplementedError("the first-order term of a rel-degree-2 condition must be the same L_f h")
+        ka1 += c / c2
+    hess = grad_gp.jac
+    # CBC2 / c2 = L_f^2 h + 1 * (sum_j c_j s_j / c2) + ka1 * L_f h
+    return CBCExpr(2, det_sum(c2), grad_gp.mean, model, u, k_alpha=[1.0, ka1], hess_h=hess, scale=c2)
