@@ -33,6 +33,9 @@ _TSIGS = {
     "bcbf_gp_append": [P] * 17 + [c_int, c_int, c_int, c_int, P],
     "bcbf_potri": [P, P, c_int, c_int, P],
     "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_kb_build_rbflin": [P] * 8 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_query_rbflin": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_mll_grad_rbflin": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_jets": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],

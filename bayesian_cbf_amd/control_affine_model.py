@@ -6,10 +6,10 @@ Same names, arguments and return shapes as the reference for the *prediction* pa
 :1099-1102, :1334-1341).  All arithmetic is in the HIP library; there is no CPU path -- the
 classes raise if the model device is not a ROCm GPU.
 
-What is NOT here ("next"): hyper-parameter optimisation.  `fit()` stores the
-training set and invalidates the cached factor exactly like the reference (:289-290) but leaves
-(A, B, lengthscale, outputscale, mean) at their current values; set them with
-`set_kernel_params` or `load_state_dict`.
+`fit()` optimises the hyper-parameters like the reference (:268-335: Adam + MultiStepLR on the negative marginal
+log-likelihood) with the likelihood and its gradient computed on the device; `training_iter=0` only stores the data,
+and `set_kernel_params` / `load_state_dict` set (A, B, lengthscale, outputscale, mean) by value.  The CoGP comparators
+(`ControlAffineRegressorVector`, `ControlAffineRegVectorDiag`, :1106-1357) are at the end of the file.
 
 Randomness: like the reference's `make_psd` (:899-921) the jitter vectors are drawn with
 `torch.rand` on the model device, in the reference's order (one N-vector per Cholesky try; the
@@ -510,3 +510,235 @@ class BatchedControlAffineGP:
     def as_dict(self):
         return dict(Lop=self.Lop, Vw=self.Vw, X=self.X, UHB=self.UHB, ell=self.ell, s2=self.s2, Bm=self.Bm,
                     M0=self.M0, A=self.A)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CoGP comparators: ControlAffineRegressorVector / ControlAffineRegVectorDiag
+# (control_affine_model.py:1106-1357, matrix_variate_multitask_kernel.py:207-316).
+class VectorKernelParams(torch.nn.Module):
+    """Hyper-parameters of ControlAffineVectorGP (:1106-1126): one task covariance Sigma over all (1+m) n outputs
+    (IndexKernel: W W' + diag softplus(v)), data kernel ScaleKernel(RBFKernel() + LinearKernel()) -- a single RBF
+    lengthscale, a linear variance, an output scale -- and the constant prior mean."""
+
+    def __init__(self, x_dim, u_dim, rank=None, dtype=None):
+        super().__init__()
+        n, C = x_dim, 1 + u_dim
+        dt = dtype or torch.get_default_dtype()
+        T_ = C * n
+        r = T_ if rank is None else rank
+        self.matshape = (C, n)
+        self.raw_lengthscale = torch.nn.Parameter(torch.zeros(1, 1, dtype=dt))
+        self.raw_variance = torch.nn.Parameter(torch.zeros(1, 1, dtype=dt))
+        self.raw_outputscale = torch.nn.Parameter(torch.zeros((), dtype=dt))
+        self.task_covar_factor = torch.nn.Parameter(torch.randn(T_, r, dtype=dt))
+        self.task_raw_var = torch.nn.Parameter(torch.randn(T_, dtype=dt))
+        self.mean_constants = torch.nn.Parameter(torch.zeros(T_, dtype=dt))
+
+    lengthscale = property(lambda self: F.softplus(self.raw_lengthscale))
+    variance = property(lambda self: F.softplus(self.raw_variance))
+    outputscale = property(lambda self: F.softplus(self.raw_outputscale))
+    M0 = property(lambda self: self.mean_constants.reshape(*self.matshape))
+
+    @property
+    def Sigma(self):
+        return self.task_covar_factor @ self.task_covar_factor.t() + torch.diag(F.softplus(self.task_raw_var))
+
+
+class ControlAffineRegressorVector(ControlAffineRegressor):
+    """Vector-variate ("CoGP") comparator: vec(F) ~ GP(vec(M), Sigma k(x,x')), an (N n) x (N n) system
+    (:1128-1330).  On the device it is the matrix-variate structure with expanded inputs -- sample (i,a) carries x_i
+    and the row UH'[(i,a), (p,a')] = uh_i[p] delta_aa' -- so the same factorisation / solve / query kernels run it
+    (K_b build and query with the `rbflin` data kernel).  Compiled for (1+m) n <= 4 outputs (the pendulum of the
+    published speed test)."""
+
+    def __init__(self, x_dim, u_dim, device=None, default_device=default_device, gamma_length_scale_prior=None,
+                 model_class=None, rank=None, dtype=None, generator=None):
+        super().__init__(x_dim, u_dim, device=device, default_device=default_device,
+                         gamma_length_scale_prior=gamma_length_scale_prior, rank=rank, dtype=dtype, generator=generator)
+        if (1 + u_dim) * x_dim > 4:
+            raise NotImplementedError("the CoGP comparator is compiled for (1+m) n <= 4 task outputs (pendulum)")
+        self.model = VectorKernelParams(x_dim, u_dim, rank=rank, dtype=dtype).to(self.device)
+
+    def get_kernel_param(self, name):
+        if name == "Sigma":
+            return self.model.Sigma
+        if name == "scalefactor":
+            return self.model.outputscale
+        if name == "lengthscale":
+            return self.model.lengthscale
+        if name == "variance":
+            return self.model.variance
+        raise ValueError("Unknown param %s" % name)
+
+    def set_kernel_params(self, Sigma=None, lengthscale=None, variance=None, scalefactor=None, M0=None):
+        with torch.no_grad():
+            inv_sp = lambda v: torch.log(torch.expm1(torch.as_tensor(v, dtype=torch.float64)))
+            m = self.model
+            if lengthscale is not None:
+                m.raw_lengthscale.copy_(inv_sp(lengthscale).reshape(1, 1).to(m.raw_lengthscale))
+            if variance is not None:
+                m.raw_variance.copy_(inv_sp(variance).reshape(1, 1).to(m.raw_variance))
+            if scalefactor is not None:
+                m.raw_outputscale.copy_(inv_sp(scalefactor).reshape(()).to(m.raw_outputscale))
+            if Sigma is not None:
+                val = torch.as_tensor(Sigma, dtype=torch.float64)
+                eps = 1e-10 * float(val.diagonal().mean())
+                Lf = torch.linalg.cholesky(val - eps * torch.eye(val.shape[0], dtype=torch.float64))
+                if m.task_covar_factor.shape[1] != val.shape[0]:
+                    m.task_covar_factor = torch.nn.Parameter(torch.zeros_like(val).to(m.task_raw_var))
+                m.task_covar_factor.copy_(Lf.to(m.task_covar_factor))
+                m.task_raw_var.copy_(inv_sp(torch.full((val.shape[0],), eps)).to(m.task_raw_var))
+            if M0 is not None:
+                m.mean_constants.copy_(torch.as_tensor(M0).reshape(-1).to(m.mean_constants))
+        self.clear_cache()
+        return self
+
+    # ---- expanded system
+    def _hyper(self):
+        m = self.model
+        with torch.no_grad():
+            n = self.x_dim
+            return dict(Bm=m.Sigma.detach()[None].contiguous(), ell=m.lengthscale.detach().reshape(1, 1).expand(1, n).contiguous(),
+                        s2=m.outputscale.detach().reshape(1).contiguous(), lin=m.variance.detach().reshape(1).contiguous(),
+                        M0=m.M0.detach().contiguous())
+
+    def _expand(self, X, U):
+        """X'[N n, n], UH'[N n, (1+m) n]: kron(UH, I_n) (torch_kron(UHtrain, In), :1203-1205)."""
+        n = self.x_dim
+        UH = torch.cat([torch.ones_like(U[:, :1]), U], dim=1)
+        eye = torch.eye(n, dtype=X.dtype, device=X.device)
+        return X.repeat_interleave(n, dim=0).contiguous(), torch.kron(UH, eye).contiguous(), UH
+
+    def _state(self, cholesky_tries=10, cholesky_perturb_init=1e-5, cholesky_perturb_scale=10):
+        if "state" in self._cache:
+            return self._cache["state"]
+        self._require_gpu()
+        hp = self._hyper()
+        n = self.x_dim
+        Xe, UHe, UH = self._expand(self.Xtrain, self.Utrain)
+        Ne = Xe.shape[0]
+        Ye = (self.XdotTrain - UH @ hp["M0"]).reshape(1, Ne, 1).contiguous()          # vec(Xdot - M(XU)), (i,a) order (:1252-1262)
+        factor = cholesky_perturb_init
+        for ntry in range(cholesky_tries):
+            jitter = factor * self.rand_fn(Ne)
+            Kb = ops.kb_build(Xe[None], UHe[None], hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous(), lin=hp["lin"])
+            Lop, info, _ = ops.potrf(Kb)
+            if int(info[0]) == 0:
+                break
+            if ntry == cholesky_tries - 1:
+                raise RuntimeError("cholesky: pivot %d is not positive after %d jitter retries" % (int(info[0]), cholesky_tries))
+            factor = factor * cholesky_perturb_scale
+        Ce = UHe.shape[1]
+        zeroM = Xe.new_zeros(1, Ce, 1)
+        Vw1, alpha = ops.potrs(Lop, Ye, UHe[None], zeroM)
+        Vw = Xe.new_zeros(1, Ne, n)                      # the query kernel reads n target columns; only the first is used
+        Vw[..., 0] = Vw1[..., 0]
+        st = dict(hp, X=Xe[None], UH=UHe[None], UHB=(UHe @ hp["Bm"][0])[None].contiguous(), Lop=Lop, Vw=Vw, alpha=alpha,
+                  Y=Ye, N=Ne, jitter=jitter[None].contiguous(), M0e=Xe.new_zeros(1, Ce, n))
+        self._cache["state"] = st
+        return st
+
+    def _data_knl(self, X1, X2):
+        m = self.model
+        with torch.no_grad():
+            d = (X1[:, None, :] - X2[None, :, :]) / m.lengthscale.detach().reshape(())
+            return m.outputscale.detach() * (torch.exp(-0.5 * (d * d).sum(-1)) + m.variance.detach().reshape(()) * (X1 @ X2.t()))
+
+    def _custom_predict_matrix(self, Xtest_in, Xtestp_in=None, compute_cov=True):
+        """(mean_k[b,n,1+m], KkXX[b,b',(1+m)n,(1+m)n])   (:1232-1330)."""
+        Xtest = self._ensure_device_dtype(Xtest_in)
+        Xtestp = self._ensure_device_dtype(Xtestp_in) if Xtestp_in is not None else Xtest
+        n, C = self.x_dim, 1 + self.u_dim
+        Ce = C * n
+        b = Xtest.shape[0]
+        Sigma = self.model.Sigma.detach()
+        M0 = self.model.M0.detach()
+        fX_mean_test = M0.t()[None].expand(b, n, C)
+        if self.Xtrain is None:
+            return fX_mean_test, Sigma * self._data_knl(Xtest, Xtestp)[:, :, None, None]
+        st = self._state()
+        Mk, Bk, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"], st["M0e"],
+                                        Xtest.contiguous(), shared=True, want_W=compute_cov, lin=st["lin"])
+        mean_k = fX_mean_test + Mk[:, 0, :].reshape(b, C, n).transpose(-2, -1)
+        if not compute_cov:
+            return mean_k, Xtest.new_zeros(b, Xtestp.shape[0], Ce, Ce)
+        vb = W[:, :st["N"], :].permute(1, 0, 2).reshape(st["N"], b * Ce)                  # (kn, b(1+m)n)  (:1312)
+        KkXX = torch_kron(self._data_knl(Xtest, Xtestp), Sigma) - vb.t() @ vb             # (:1313-1317; v of Xtest on both sides)
+        KkXX = KkXX + torch.diag(1e-5 * self.rand_fn(b * Ce))                             # make_psd (:1318)
+        return mean_k, KkXX.reshape(b, Ce, b, Ce).transpose(2, 1)
+
+    def custom_predict(self, Xtest_in, Utest_in=None, UHfill=1, Xtestp_in=None, Utestp_in=None, UHfillp=1,
+                       compute_cov=True):
+        """(meanFXU[b,n], varFXU[b,b',n,n])   (:1132-1169)."""
+        Xtest = self._ensure_device_dtype(Xtest_in)
+        Xtestp = self._ensure_device_dtype(Xtestp_in) if Xtestp_in is not None else Xtest
+        meanFX, KkXX = self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov=compute_cov)
+        UHtest = self._uh(Xtest, Utest_in, UHfill)
+        meanFXU = torch.einsum("bnc,bc->bn", meanFX, UHtest)
+        k, n = Xtest.shape
+        if not compute_cov:
+            return meanFXU, Xtest.new_zeros(k, Xtestp.shape[0], n, n)
+        eye = torch.eye(n, dtype=Xtest.dtype, device=Xtest.device)
+        blk = torch.stack([torch.kron(u[None], eye) for u in UHtest])                     # (k, n, (1+m)n)
+        varFXU = torch.matmul(torch.matmul(blk.reshape(k, 1, n, -1), KkXX), blk.reshape(1, k, n, -1).transpose(-2, -1))
+        return meanFXU, varFXU
+
+    def custom_predict_fullmat(self, Xtest_in, Xtestp_in=None):
+        """(vec(M_k)[b(1+m)n], [b(1+m)n]^2)   (:1171-1188)."""
+        meanFX, varFX = self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov=True)
+        b, n, C = meanFX.shape
+        return meanFX.transpose(-2, -1).reshape(-1), varFX.transpose(2, 1).reshape(b * C * n, b * C * n)
+
+    def _perturbed_cholesky(self, *a, **k):
+        st = self._state()
+        if "L" not in st:
+            Kb = ops.kb_build(st["X"], st["UH"], st["Bm"], st["ell"], st["s2"], st["jitter"], lin=st["lin"])
+            st["L"] = ops.potrf(Kb, want_dense=True)[2][0]
+        return st["L"]
+
+    def neg_mll_backward(self, perturb_targets=False, jitter=None):
+        """-log p(Y) / (N n) of the vector-variate GP and its gradient into the raw parameters (fit(), :268-335):
+        log p = -1/2 y'K^-1 y - 1/2 logdet K - N n / 2 log 2 pi with y = vec(Y - M(XU)); the O((N n)^2) gradient sums
+        come from `bcbf_mll_grad_rbflin` on the expanded system (one target column)."""
+        m = self.model
+        ell, s2, lin, Sigma, M0 = m.lengthscale, m.outputscale, m.variance, m.Sigma, m.M0
+        hp = self._hyper()
+        n = self.x_dim
+        Xe, UHe, UH = self._expand(self.Xtrain, self.Utrain)
+        Ne, Ce = Xe.shape[0], UHe.shape[1]
+        Y = self.XdotTrain
+        if perturb_targets:
+            Y = Y * (1 + 1e-6 * torch.rand_like(Y))
+        Ye = (Y - UH @ hp["M0"]).reshape(1, Ne, 1).contiguous()
+        factor = 1e-5
+        for ntry in range(10):
+            jit = (factor * self.rand_fn(Ne))[None].contiguous() if jitter is None else jitter
+            Kb = ops.kb_build(Xe[None], UHe[None], hp["Bm"], hp["ell"], hp["s2"], jit, lin=hp["lin"])
+            Lop, info, _ = ops.potrf(Kb)
+            if int(info[0]) == 0:
+                break
+            if ntry == 9 or jitter is not None:
+                raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
+            factor *= 10
+        _, alpha = ops.potrs(Lop, Ye, UHe[None], Xe.new_zeros(1, Ce, 1))
+        Kinv = ops.kb_inverse(Lop, Ne)
+        one = Xe.new_ones(1, 1, 1)
+        g_ell, g_s2, g_B, logdetK, RtA, UHtA, g_lin = ops.mll_grad(Lop, alpha, Kinv, Xe[None], UHe[None], Ye, one, hp["Bm"],
+                                                                    hp["ell"], hp["s2"], lin=hp["lin"])
+        scale = 1.0 / Ne
+        nll = 0.5 * RtA[0, 0, 0] + 0.5 * logdetK[0] + 0.5 * Ne * math.log(2 * math.pi)
+        gM0 = UHtA[0, :, 0].reshape(1 + self.u_dim, n)                                     # d log p / d M0 [1+m, n]
+        torch.autograd.backward(
+            [ell, s2, lin, Sigma, M0],
+            [(-scale * g_ell[0].sum()).reshape(ell.shape), (-scale * g_s2[0]).reshape(s2.shape),
+             (-scale * g_lin[0]).reshape(lin.shape), -scale * g_B[0], -scale * gM0])
+        loss = float(nll) * scale
+        if self.gamma_length_scale_prior is not None:
+            c, r = self.gamma_length_scale_prior
+            lp = (c * math.log(r) - math.lgamma(c) + (c - 1) * torch.log(m.lengthscale) - r * m.lengthscale).sum()
+            (-scale * lp).backward()
+            loss -= float(lp.detach()) * scale
+        return loss
+
+
+ControlAffineRegVectorDiag = partial(ControlAffineRegressorVector, rank=0)                 # :1349-1357

@@ -12,7 +12,7 @@
 namespace bcbf {
 
 constexpr int MG_T = 256;
-constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 1 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
+constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 2 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
 
 template <typename T>
 __global__ void __launch_bounds__(MG_T)
@@ -20,42 +20,49 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
                 const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ R, const T* __restrict__ Ainv,
                 const T* __restrict__ Bm, const T* __restrict__ ell, const T* __restrict__ s2p,
                 T* __restrict__ g_ell, T* __restrict__ g_s2, T* __restrict__ g_B, T* __restrict__ logdetK,
-                T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C) {
+                T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C, int nt,
+                const T* __restrict__ lin, T* __restrict__ g_lin) {
+    // nt = number of target columns of R / alpha / A (== n for the matrix-variate model; 1 for the expanded
+    // CoGP system); lin (optional) = weight of the linear part of the data kernel, k = exp(..) + lin x'x'.
     constexpr int V = Vec<T>::V;
     __shared__ double red[4][MG_MAXOUT];
     const int b = blockIdx.x, tid = threadIdx.x;
     const T* Xb = X + (size_t)b * N * n;
     const T* UHb = UH + (size_t)b * N * C;
-    const T* Rb = R + (size_t)b * N * n;
-    const T* al = alpha + (size_t)b * N * n;
+    const T* Rb = R + (size_t)b * N * nt;
+    const T* al = alpha + (size_t)b * N * nt;
     const T* Kib = Kinv + (size_t)b * N * N;
     const T* lop = Lop + (size_t)b * lop_elems<V>(Np);
     double iell[BCBF_MAX_STATE_DIM], Ai[BCBF_MAX_STATE_DIM][BCBF_MAX_STATE_DIM];
     double Bl[BCBF_MAX_CTRL_DIM + 1][BCBF_MAX_CTRL_DIM + 1];
     const double s2 = (double)s2p[b];
+    const double linv = lin != nullptr ? (double)lin[b] : 0.0;
     for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
         iell[d] = d < n ? 1.0 / (double)ell[(size_t)b * n + d] : 0.0;
-        for (int e = 0; e < BCBF_MAX_STATE_DIM; ++e) Ai[d][e] = (d < n && e < n) ? (double)Ainv[((size_t)b * n + d) * n + e] : 0.0;
+        for (int e = 0; e < BCBF_MAX_STATE_DIM; ++e) Ai[d][e] = (d < nt && e < nt) ? (double)Ainv[((size_t)b * nt + d) * nt + e] : 0.0;
     }
     for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a)
         for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) Bl[a][c] = (a < C && c < C) ? (double)Bm[((size_t)b * C + a) * C + c] : 0.0;
 
     // ---- phase 1: the N^2 pair terms (register accumulators, fully unrolled over the compile-time maxima)
-    double gl[BCBF_MAX_STATE_DIM], gB[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)], gs = 0.0;
+    double gl[BCBF_MAX_STATE_DIM], gB[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)], gs = 0.0, glin = 0.0;
 #pragma unroll
     for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] = 0.0;
 #pragma unroll
     for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) gB[a] = 0.0;
     for (long long idx = tid; idx < (long long)N * N; idx += MG_T) {
         const int i = (int)(idx / N), j = (int)(idx - (long long)i * N);
-        double d2 = 0.0, dz2[BCBF_MAX_STATE_DIM];
+        double d2 = 0.0, dz2[BCBF_MAX_STATE_DIM], dot = 0.0;
 #pragma unroll
         for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
-            const double z = d < n ? ((double)Xb[(size_t)i * n + d] - (double)Xb[(size_t)j * n + d]) * iell[d] : 0.0;
+            const double xi = d < n ? (double)Xb[(size_t)i * n + d] : 0.0, xj = d < n ? (double)Xb[(size_t)j * n + d] : 0.0;
+            const double z = (xi - xj) * iell[d];
             dz2[d] = z * z;
             d2 += z * z;
+            dot += xi * xj;
         }
-        const double kij = exp(-0.5 * d2);
+        const double krbf = exp(-0.5 * d2);
+        const double kij = krbf + linv * dot;
         double ui[BCBF_MAX_CTRL_DIM + 1], uj[BCBF_MAX_CTRL_DIM + 1], uij = 0.0;
 #pragma unroll
         for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a) {
@@ -72,18 +79,19 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
         double q = 0.0;                                      // alpha_i' A^-1 alpha_j
 #pragma unroll
         for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
-            if (d < n) {
+            if (d < nt) {
                 double t = 0.0;
 #pragma unroll
                 for (int e = 0; e < BCBF_MAX_STATE_DIM; ++e)
-                    if (e < n) t += Ai[d][e] * (double)al[(size_t)j * n + e];
-                q += (double)al[(size_t)i * n + d] * t;
+                    if (e < nt) t += Ai[d][e] * (double)al[(size_t)j * nt + e];
+                q += (double)al[(size_t)i * nt + d] * t;
             }
         }
-        const double G = 0.5 * (q - (double)n * (double)Kib[(size_t)i * N + j]);
+        const double G = 0.5 * (q - (double)nt * (double)Kib[(size_t)i * N + j]);
         const double Gk = G * kij;
         gs += Gk * uij;
-        const double GK = Gk * s2 * uij;                     // G_ij K_ij
+        glin += G * s2 * uij * dot;
+        const double GK = G * krbf * s2 * uij;               // G_ij times the RBF part of K_ij
 #pragma unroll
         for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] += GK * dz2[d] * iell[d];       // z^2 / ell = dx^2 / ell^3
 #pragma unroll
@@ -92,8 +100,9 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
             for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) gB[a * (BCBF_MAX_CTRL_DIM + 1) + c] += Gk * s2 * ui[a] * uj[c];
     }
     // workgroup reduction of the 8 + 1 + 16 sums
-    constexpr int NR = BCBF_MAX_STATE_DIM + 1 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
+    constexpr int NR = BCBF_MAX_STATE_DIM + 2 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
     double vals[NR];
+    vals[NR - 1] = wave_sum(glin);
 #pragma unroll
     for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) vals[d] = wave_sum(gl[d]);
     vals[BCBF_MAX_STATE_DIM] = wave_sum(gs);
@@ -108,22 +117,23 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
         const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         if (tid < BCBF_MAX_STATE_DIM) { if (tid < n) g_ell[(size_t)b * n + tid] = (T)v; }
         else if (tid == BCBF_MAX_STATE_DIM) g_s2[b] = (T)v;
+        else if (tid == NR - 1) { if (g_lin != nullptr) g_lin[b] = (T)v; }
         else {
             const int o = tid - BCBF_MAX_STATE_DIM - 1, a = o / (BCBF_MAX_CTRL_DIM + 1), c = o % (BCBF_MAX_CTRL_DIM + 1);
             if (a < C && c < C) g_B[((size_t)b * C + a) * C + c] = (T)v;
         }
     }
     // ---- phase 2: the small products (one output per thread, a loop over the N rows) and logdet (last wave)
-    if (tid < n * n) {
-        const int d = tid / n, e = tid - d * n;
+    if (tid < nt * nt) {
+        const int d = tid / nt, e = tid - d * nt;
         double v = 0.0;
-        for (int i = 0; i < N; ++i) v += (double)Rb[(size_t)i * n + d] * (double)al[(size_t)i * n + e];
-        RtA[(size_t)b * n * n + tid] = (T)v;
-    } else if (tid >= 64 && tid < 64 + C * n) {
-        const int o = tid - 64, a = o / n, d = o - a * n;
+        for (int i = 0; i < N; ++i) v += (double)Rb[(size_t)i * nt + d] * (double)al[(size_t)i * nt + e];
+        RtA[(size_t)b * nt * nt + tid] = (T)v;
+    } else if (tid >= 64 && tid < 64 + C * nt) {
+        const int o = tid - 64, a = o / nt, d = o - a * nt;
         double v = 0.0;
-        for (int i = 0; i < N; ++i) v += (double)UHb[(size_t)i * C + a] * (double)al[(size_t)i * n + d];
-        UHtA[(size_t)b * C * n + o] = (T)v;
+        for (int i = 0; i < N; ++i) v += (double)UHb[(size_t)i * C + a] * (double)al[(size_t)i * nt + d];
+        UHtA[(size_t)b * C * nt + o] = (T)v;
     } else if (tid >= 192) {
         double v = 0.0;
         for (int i = tid - 192; i < N; i += 64) v -= 2.0 * log((double)lop[lop_dinv(i / NB, i % NB, i % NB, Np)]);
@@ -135,14 +145,18 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
 template <typename T>
 static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T* X, const T* UH, const T* R,
                            const T* Ainv, const T* Bm, const T* ell, const T* s2, T* g_ell, T* g_s2, T* g_B, T* logdetK,
-                           T* RtA, T* UHtA, int Bt, int N, int n, int m, void* stream) {
+                           T* RtA, T* UHtA, int Bt, int N, int n, int m, void* stream, int nt = -1,
+                           const T* lin = nullptr, T* g_lin = nullptr) {
+    if (nt < 0) nt = n;
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !alpha || !Kinv || !X || !UH || !R || !Ainv || !Bm || !ell || !s2 || !g_ell || !g_s2 || !g_B || !logdetK ||
         !RtA || !UHtA)
         return BCBF_EINVAL;
-    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM || nt < 1 || nt > BCBF_MAX_STATE_DIM)
+        return BCBF_EINVAL;
     hipLaunchKernelGGL((mll_grad_kernel<T>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv, X, UH, R,
-                       Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1);
+                       Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin,
+                       g_lin);
     return check_launch("mll_grad");
 }
 
@@ -162,5 +176,23 @@ int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv
                       int n, int m, void* stream) {
     return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
                                          UHtA, Bt, N, n, m, stream);
+}
+// Same sums for the data kernel s2 (exp(..) + lin x'x') and nt target columns (R, alpha [Bt,N,nt], Ainv [Bt,nt,nt],
+// RtA [Bt,nt,nt], UHtA [Bt,C,nt]); g_lin[Bt] = d log p / d lin.  nt = 1 with expanded inputs is the CoGP comparator
+// (ControlAffineRegressorVector.fit, control_affine_model.py:268-335 on ControlAffineVectorGP :1106-1126).
+int bcbf_mll_grad_rbflin_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                             const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2,
+                             const float* lin, float* g_ell, float* g_s2, float* g_lin, float* g_B, float* logdetK,
+                             float* RtA, float* UHtA, int Bt, int N, int n, int m, int nt, void* stream) {
+    return bcbf::launch_mll_grad<float>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                        UHtA, Bt, N, n, m, stream, nt, lin, g_lin);
+}
+int bcbf_mll_grad_rbflin_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X,
+                             const double* UH, const double* R, const double* Ainv, const double* Bm, const double* ell,
+                             const double* s2, const double* lin, double* g_ell, double* g_s2, double* g_lin,
+                             double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N, int n, int m,
+                             int nt, void* stream) {
+    return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                         UHtA, Bt, N, n, m, stream, nt, lin, g_lin);
 }
 }

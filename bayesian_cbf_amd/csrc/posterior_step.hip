@@ -72,7 +72,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
                       T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
-                      int n) {
+                      int n, const T* __restrict__ lin) {
     constexpr int V = Vec<T>::V;
     constexpr int CT = C * (1 + NJ);     // right-hand-side columns
     using VecT = typename Vec<T>::type;
@@ -105,6 +105,9 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         iell[d] = d < n ? T(1) / ell[(size_t)gb * n + d] : T(0);
     }
     const T s2 = s2p[gb];
+    // optional linear part of the data kernel, k = s2 (exp(..) + lin x'x') (the CoGP comparator's RBF + Linear,
+    // control_affine_model.py:1121-1122); lin == NULL -> 0
+    const T linv = lin != nullptr ? lin[gb] : T(0);
     T acc[2][V][CT];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -114,11 +117,11 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             const int i = rb * V + v;
             T k = T(0);
             if (live && i < N) {
-                T d2 = T(0);
+                T d2 = T(0), dot = T(0);
 #pragma unroll
                 for (int d = 0; d < NS; ++d)
-                    if (d < n) { const T z = (Xb[(size_t)i * n + d] - xqr[d]) * iell[d]; d2 += z * z; }
-                k = s2 * texp<T>(T(-0.5) * d2);
+                    if (d < n) { const T xi = Xb[(size_t)i * n + d]; const T z = (xi - xqr[d]) * iell[d]; d2 += z * z; dot += xi * xqr[d]; }
+                k = s2 * (texp<T>(T(-0.5) * d2) + linv * dot);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -293,13 +296,20 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 }
             const T* Bmb = Bm + (size_t)gb * C * C;
             T* Bkb = Bk + (size_t)b * C * C;
+            double kss = (double)s2;                      // k(xq, xq) = s2 (1 + lin |xq|^2)
+            if (lin != nullptr) {
+                double q2 = 0.0;
+#pragma unroll
+                for (int d = 0; d < NS; ++d) q2 += (double)xqr[d] * (double)xqr[d];
+                kss *= 1.0 + (double)linv * q2;
+            }
 #pragma unroll
             for (int a = 0; a < C; ++a)
 #pragma unroll
                 for (int c = a; c < C; ++c) {
                     const double G = gsum[gidx(a, c)];
-                    double v1 = (double)s2 * (double)Bmb[a * C + c] - G;
-                    double v2 = (double)s2 * (double)Bmb[c * C + a] - G;
+                    double v1 = kss * (double)Bmb[a * C + c] - G;
+                    double v2 = kss * (double)Bmb[c * C + a] - G;
                     if (a == c && jitter2 != nullptr) { v1 += (double)jitter2[(size_t)b * C + a]; v2 = v1; }
                     Bkb[a * C + c] = (T)v1;
                     Bkb[c * C + a] = (T)v2;
@@ -312,7 +322,7 @@ template <typename T>
 static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                  const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
                                  T* Wout, int shared, int Bt, int N, int n, int m, void* stream,
-                                 T* Gfull = nullptr, T* Mfull = nullptr) {
+                                 T* Gfull = nullptr, T* Mfull = nullptr, const T* lin = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
@@ -323,10 +333,10 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (threads > (sizeof(T) == 8 && Gfull == nullptr ? 512 : 256)) return BCBF_EINVAL;   // N <= 2048 (fp64 jets: 1024)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n)
-#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, Gfull, Mfull, shared, N, Np, n)
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr)
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
-        if (!Mfull) return BCBF_EINVAL;
+        if (!Mfull || lin) return BCBF_EINVAL;
         if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
         else if (n == 3 && m == 2) BCBF_PJ_LAUNCH(3, 3);
         else if (n == 2 && m == 2) BCBF_PJ_LAUNCH(3, 2);
@@ -385,6 +395,24 @@ extern "C" int bcbf_posterior_query_f64(const double* Lop, const double* Vw, con
                                         const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                         int shared, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream);
+}
+
+// Same query with the data kernel k = s2 (exp(-1/2 |(x-x')/ell|^2) + lin x'x'), lin[Bt] (or [1] when shared): the
+// RBF + Linear kernel of the reference's CoGP comparator (ControlAffineVectorGP, control_affine_model.py:1106-1126),
+// whose (N n)-sample system is this kernel's MVGP structure with expanded inputs.
+extern "C" int bcbf_posterior_query_rbflin_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                               const float* ell, const float* s2, const float* lin, const float* Bm,
+                                               const float* M0, const float* xq, const float* jitter2, float* Mk,
+                                               float* Bk, float* W, int shared, int Bt, int N, int n, int m,
+                                               void* stream) {
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream, nullptr, nullptr, lin);
+}
+extern "C" int bcbf_posterior_query_rbflin_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                               const double* ell, const double* s2, const double* lin, const double* Bm,
+                                               const double* M0, const double* xq, const double* jitter2, double* Mk,
+                                               double* Bk, double* W, int shared, int Bt, int N, int n, int m,
+                                               void* stream) {
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream, nullptr, nullptr, lin);
 }
 
 // Jets: value + first x-derivatives of the posterior factors at one query per instance (or per query of

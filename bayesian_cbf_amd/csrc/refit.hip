@@ -16,7 +16,7 @@ template <> __device__ inline double texp2<double>(double x) { return exp(x); }
 template <typename T>
 __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                                 const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
-                                T* __restrict__ Kb, int N, int n, int C) {
+                                T* __restrict__ Kb, int N, int n, int C, const T* __restrict__ lin) {
     const int b = blockIdx.y;
     const int i = blockIdx.x;
     const T* Xb = X + (size_t)b * N * n;
@@ -29,14 +29,16 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
         ub[c] = s;
     }
     const T s2 = s2p[b];
+    const T linv = lin != nullptr ? lin[b] : T(0);        // optional linear part: k = s2 (exp(..) + lin x'x')
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
-        T d2 = T(0), uu = T(0);
+        T d2 = T(0), uu = T(0), dot = T(0);
         for (int d = 0; d < n; ++d) {
             const T z = (Xb[(size_t)i * n + d] - Xb[(size_t)j * n + d]) / ell[(size_t)b * n + d];
             d2 += z * z;
+            dot += Xb[(size_t)i * n + d] * Xb[(size_t)j * n + d];
         }
         for (int a = 0; a < C; ++a) uu += ub[a] * UHb[(size_t)j * C + a];
-        T val = s2 * texp2<T>(T(-0.5) * d2) * uu;
+        T val = s2 * (texp2<T>(T(-0.5) * d2) + linv * dot) * uu;
         if (i == j && jitter) val += jitter[(size_t)b * N + i];
         Kb[((size_t)b * N + i) * N + j] = val;
     }
@@ -44,12 +46,12 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
 
 template <typename T>
 static int launch_kb_build(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,
-                           T* Kb, int Bt, int N, int n, int m, void* stream) {
+                           T* Kb, int Bt, int N, int n, int m, void* stream, const T* lin = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!X || !UH || !Bm || !ell || !s2 || !Kb) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     hipLaunchKernelGGL((kb_build_kernel<T>), dim3(N, Bt), dim3(256), 0, (hipStream_t)stream, X, UH, Bm, ell, s2,
-                       jitter, Kb, N, n, m + 1);
+                       jitter, Kb, N, n, m + 1, lin);
     return check_launch("kb_build");
 }
 
@@ -66,6 +68,15 @@ int bcbf_kb_build_f32(const float* X, const float* UH, const float* Bm, const fl
 int bcbf_kb_build_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                       const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream);
+}
+int bcbf_kb_build_rbflin_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                             const float* lin, const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_kb_build<float>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, lin);
+}
+int bcbf_kb_build_rbflin_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                             const double* lin, const double* jitter, double* Kb, int Bt, int N, int n, int m,
+                             void* stream) {
+    return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, lin);
 }
 // both precisions factor on the matrix cores (refit_mfma.hip, refit_mfma64.hip)
 extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,

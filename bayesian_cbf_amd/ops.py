@@ -44,12 +44,17 @@ def lop_elems(N, dtype):
     return int(getattr(lib, "bcbf_lop_elems" + _SUF[dtype])(N))
 
 
-def kb_build(X, UH, Bm, ell, s2, jitter=None):
-    """K_b[Bt,N,N]  (control_affine_model.py:370-372 + make_psd diagonal :907-910)."""
-    _chk(X, UH, Bm, ell, s2, jitter)
+def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None):
+    """K_b[Bt,N,N]  (control_affine_model.py:370-372 + make_psd diagonal :907-910); lin[Bt] adds the linear part of
+    the CoGP comparator's data kernel, k = s2 (exp(..) + lin x'x') (:1121-1122)."""
+    _chk(X, UH, Bm, ell, s2, jitter, lin)
     Bt, N, n = X.shape
     m = UH.shape[2] - 1
     Kb = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device)
+    if lin is not None:
+        check(getattr(lib, "bcbf_kb_build_rbflin" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(lin), _p(jitter),
+                                                             _p(Kb), Bt, N, n, m, _stream(X)), "bcbf_kb_build_rbflin")
+        return Kb
     check(getattr(lib, "bcbf_kb_build" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Kb),
                                                   Bt, N, n, m, _stream(X)), "bcbf_kb_build")
     return Kb
@@ -130,13 +135,23 @@ def kb_inverse(Lop, N):
     return Kinv
 
 
-def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2):
+def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None):
     """O(N^2) sums of the marginal-log-likelihood gradient (bcbf.h K12).  Returns
-    (g_ell[Bt,n], g_s2[Bt], g_B[Bt,C,C], logdetK[Bt], RtA[Bt,n,n], UHtA[Bt,C,n])."""
-    _chk(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2)
+    (g_ell[Bt,n], g_s2[Bt], g_B[Bt,C,C], logdetK[Bt], RtA[Bt,nt,nt], UHtA[Bt,C,nt]) (+ g_lin[Bt] when `lin` is given:
+    RBF + Linear data kernel, nt = R.shape[2] target columns)."""
+    _chk(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin)
     Bt, N, n = X.shape
     C = UH.shape[2]
     f = dict(dtype=X.dtype, device=X.device)
+    if lin is not None:
+        nt = R.shape[2]
+        g_ell, g_s2, g_B, g_lin = torch.empty(Bt, n, **f), torch.empty(Bt, **f), torch.empty(Bt, C, C, **f), torch.empty(Bt, **f)
+        logdet, RtA, UHtA = torch.empty(Bt, **f), torch.empty(Bt, nt, nt, **f), torch.empty(Bt, C, nt, **f)
+        check(getattr(lib, "bcbf_mll_grad_rbflin" + _suf(X))(
+            _p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm), _p(ell), _p(s2), _p(lin), _p(g_ell),
+            _p(g_s2), _p(g_lin), _p(g_B), _p(logdet), _p(RtA), _p(UHtA), Bt, N, n, C - 1, nt, _stream(X)),
+            "bcbf_mll_grad_rbflin")
+        return g_ell, g_s2, g_B, logdet, RtA, UHtA, g_lin
     g_ell, g_s2, g_B = torch.empty(Bt, n, **f), torch.empty(Bt, **f), torch.empty(Bt, C, C, **f)
     logdet, RtA, UHtA = torch.empty(Bt, **f), torch.empty(Bt, n, n, **f), torch.empty(Bt, C, n, **f)
     check(getattr(lib, "bcbf_mll_grad" + _suf(X))(_p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm),
@@ -161,10 +176,10 @@ def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None)
     return Mk, Bk
 
 
-def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=True, want_W=False):
+def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=True, want_W=False, lin=None):
     """b queries against one shared GP (shared=True; GP tensors carry a leading axis of 1) or one query per
-    instance.  Returns (Mk[b,n,C], Bk[b,C,C], W[b,Np,C] | None)."""
-    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)
+    instance.  Returns (Mk[b,n,C], Bk[b,C,C], W[b,Np,C] | None).  lin: linear part of the data kernel (CoGP)."""
+    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, lin)
     N, n = X.shape[1], X.shape[2]
     C = UHB.shape[2]
     b = xq.shape[0]
@@ -174,6 +189,11 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
     Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
     Np = (N + 31) // 32 * 32
     W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
+    if lin is not None:
+        check(getattr(lib, "bcbf_posterior_query_rbflin" + _suf(X))(
+            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(lin), _p(Bm), _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk),
+            _p(W), 1 if shared else 0, b, N, n, C - 1, _stream(X)), "bcbf_posterior_query_rbflin")
+        return Mk, Bk, W
     check(getattr(lib, "bcbf_posterior_query" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm),
                                                          _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk), _p(W),
                                                          1 if shared else 0, b, N, n, C - 1, _stream(X)),

@@ -259,6 +259,39 @@ int bcbf_coneqp_f64(const double* P, const double* q, const double* G, const dou
                     int nv, int l, const int* qdims, int nq,
                     double* x, int* status, int* iters, int Bt, int max_iters, void* stream);
 
+/* ---- RBF + Linear data kernel (the CoGP / diag comparators of the published speed test) ----
+ * k(x,x') = s2 (exp(-1/2 |(x-x')/ell|^2) + lin x'x'),  lin[Bt]: gpytorch ScaleKernel(RBFKernel() + LinearKernel()) of
+ * ControlAffineVectorGP (control_affine_model.py:1106-1126).  The CoGP system of N n scalar observations,
+ *   K[(i,a),(j,c)] = k(x_i,x_j) [(uh_i' (x) I_n) Sigma (uh_j (x) I_n)]_ac            (:1203-1230),
+ * is the matrix-variate structure K = k(X',X') o (UH' Sigma UH'') with expanded inputs X'[(i,a)] = x_i,
+ * UH'[(i,a),(p,a')] = uh_i[p] delta_aa' (C' = (1+m) n <= 4 columns, one target column), so the factorisation,
+ * solve and query kernels above serve it unchanged; these entry points only add `lin` to the kernel function.
+ * Same arguments as the entry points they extend; lin == NULL means 0. */
+int bcbf_kb_build_rbflin_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                             const float* lin, const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream);
+int bcbf_kb_build_rbflin_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                             const double* lin, const double* jitter, double* Kb, int Bt, int N, int n, int m,
+                             void* stream);
+int bcbf_posterior_query_rbflin_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                    const float* ell, const float* s2, const float* lin, const float* Bm,
+                                    const float* M0, const float* xq, const float* jitter2, float* Mk,
+                                    float* Bk, float* W, int shared, int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_query_rbflin_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                    const double* ell, const double* s2, const double* lin, const double* Bm,
+                                    const double* M0, const double* xq, const double* jitter2, double* Mk,
+                                    double* Bk, double* W, int shared, int Bt, int N, int n, int m, void* stream);
+/* bcbf_mll_grad with nt target columns (R, alpha [Bt,N,nt]; Ainv, RtA [Bt,nt,nt]; UHtA [Bt,C,nt]) and the extra
+ * output g_lin[Bt] = d log p / d lin. */
+int bcbf_mll_grad_rbflin_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                             const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2,
+                             const float* lin, float* g_ell, float* g_s2, float* g_lin, float* g_B, float* logdetK,
+                             float* RtA, float* UHtA, int Bt, int N, int n, int m, int nt, void* stream);
+int bcbf_mll_grad_rbflin_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X,
+                             const double* UH, const double* R, const double* Ainv, const double* Bm, const double* ell,
+                             const double* s2, const double* lin, double* g_ell, double* g_s2, double* g_lin,
+                             double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N, int n, int m,
+                             int nt, void* stream);
+
 /* K9 for the generic controllers (controllers.py): rows of the cone program of SOCPController.control (:569-591)
  * / QPController.control (:638-662) over y = [extravars.., u], in the layout bcbf_coneqp_f64 takes
  * (optimizers.py:6-39: |A y + b| <= c'y + d  ->  Gq = [-c'; -A], hq = [d; b]).

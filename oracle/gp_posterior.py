@@ -254,3 +254,57 @@ def marginal_log_likelihood(X, UH, Y, A, Bm, ell, s2, M0, jitter):
     logdetK = 2.0 * np.log(np.diag(L)).sum()
     logdetA = np.linalg.slogdet(A)[1]
     return -0.5 * quad - 0.5 * n * logdetK - 0.5 * N * logdetA - 0.5 * N * n * np.log(2.0 * np.pi)
+
+
+# ------------------------------------------------------------------------------------------------
+# CoGP comparator: ControlAffineRegressorVector, control_affine_model.py:1106-1330.
+def rbf_linear_kernel(X1, X2, ell, s2, lin):
+    """ScaleKernel(RBFKernel() + LinearKernel()) (control_affine_model.py:1121-1122): one lengthscale,
+    k = s2 (exp(-1/2 |x-x'|^2/ell^2) + lin x'x')."""
+    X1, X2 = np.asarray(X1, dtype=np.float64), np.asarray(X2, dtype=np.float64)
+    d = (X1[:, None, :] - X2[None, :, :]) / float(np.ravel(ell)[0])
+    return s2 * (np.exp(-0.5 * (d * d).sum(-1)) + lin * (X1 @ X2.T))
+
+
+def cogp_kb_matrix(X, UH, Sigma, ell, s2, lin):
+    """K[(i,a),(j,c)] = k(x_i,x_j) [(uh_i' (x) I_n) Sigma (uh_j (x) I_n)]_ac   (:1190-1214)."""
+    N, n = X.shape
+    Hb = np.kron(UH, np.eye(n))                                   # (N n, (1+m) n), torch_kron(UHtrain, In)
+    S = Hb @ Sigma @ Hb.T
+    return np.kron(rbf_linear_kernel(X, X, ell, s2, lin), np.ones((n, n))) * S
+
+
+def cogp_refit_state(X, U, Xdot, Sigma, ell, s2, lin, M0, rand_draws):
+    UH = homogeneous_controls(U)
+    Kb = cogp_kb_matrix(X, UH, Sigma, ell, s2, lin)
+    Kbp, L, tries = make_psd(Kb, rand_draws)
+    Y = (Xdot - UH @ M0).reshape(-1)                              # vec over (sample, state) (:1252-1262)
+    return dict(UH=UH, L=L, Y=Y, alpha=cholesky_solve(Y[:, None], L)[:, 0], tries=tries, Kb=Kbp)
+
+
+def cogp_custom_predict_matrix(X, UH, Y, L, Sigma, ell, s2, lin, M0, Xtest, rand_draws2=None):
+    """(mean_k[b,n,1+m], KkXX[b,b,(1+m)n,(1+m)n])  (:1232-1330); rand_draws2[b(1+m)n] = the make_psd draw (:1318)."""
+    N, n = X.shape
+    C = UH.shape[1]
+    b = Xtest.shape[0]
+    Hb = np.kron(UH, np.eye(n))
+    HS = Hb @ Sigma                                               # (N n, (1+m) n)
+    kxs = rbf_linear_kernel(Xtest, X, ell, s2, lin)               # (b, N)
+    kb_star = np.repeat(kxs, n, axis=1)[:, :, None] * HS[None]    # (b, N n, (1+m) n)
+    alpha = cholesky_solve(Y[:, None], L)
+    mean_k = M0.T[None] + np.einsum("bkc,k->bc", kb_star, alpha[:, 0]).reshape(b, C, n).transpose(0, 2, 1)
+    v = np.stack([sla.solve_triangular(L, kb_star[i], lower=True) for i in range(b)])       # (b, N n, (1+m) n)
+    vb = v.transpose(1, 0, 2).reshape(N * n, b * C * n)
+    KkXX = np.kron(rbf_linear_kernel(Xtest, Xtest, ell, s2, lin), Sigma) - vb.T @ vb
+    if rand_draws2 is not None:
+        KkXX = KkXX + np.diag(1e-5 * np.asarray(rand_draws2))
+    return mean_k, KkXX.reshape(b, C * n, b, C * n).transpose(0, 2, 1, 3)
+
+
+def cogp_marginal_log_likelihood(X, UH, Y, Sigma, ell, s2, lin, jitter):
+    """log N(y; 0, K + diag(jitter)) of the vector-variate GP, y = vec(Y) (parity unpinned, like the MVGP fit)."""
+    K = cogp_kb_matrix(X, UH, Sigma, ell, s2, lin) + np.diag(jitter)
+    L = np.linalg.cholesky(K)
+    y = np.asarray(Y, dtype=np.float64).reshape(-1)
+    a = cholesky_solve(y[:, None], L)[:, 0]
+    return -0.5 * y @ a - np.log(np.diag(L)).sum() - 0.5 * y.size * np.log(2 * np.pi)

@@ -378,8 +378,57 @@ def main_controllers():
     gen_controllers("pendulum_N40", N=40, seed=52)
 
 
+
+def gen_cogp(tag, N, b, seed, diag):
+    """ControlAffineRegressorVector / ControlAffineRegVectorDiag on the pendulum shapes (n=2, m=1):
+    _custom_predict_matrix, custom_predict, custom_predict_fullmat (control_affine_model.py:1128-1330)."""
+    n, m = 2, 1
+    cls = cam.ControlAffineRegVectorDiag if diag else cam.ControlAffineRegressorVector
+    torch.manual_seed(seed)
+    reg = cls(n, m, device='cpu')
+    model = reg.model
+    with torch.no_grad():
+        rbf, linear = model.input_covar.base_kernel.kernels
+        rbf.raw_lengthscale.copy_(0.3 * torch.randn(1, 1))
+        linear.raw_variance.copy_(0.3 * torch.randn(1, 1) - 2.0)
+        model.input_covar.raw_outputscale.copy_(0.3 * torch.randn(()))
+        for bm in model.mean_module.base_means:
+            bm.constant.copy_(0.2 * torch.randn(1))
+    X = 1.5 * (2 * torch.rand(N, n) - 1)
+    U = torch.randn(N, m)
+    Xdot = torch.sin(X @ torch.randn(n, n).t()) + 0.5 * torch.cos(X) * U + 1e-3 * torch.randn(N, n)
+    model.set_train_data(X, U, Xdot)
+    Sigma = t2n(model.covar_module.task_covar_module.covar_matrix.evaluate())
+    out = dict(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), Sigma=Sigma, ell=t2n(rbf.lengthscale).reshape(-1),
+               lin=float(t2n(linear.variance)), s2=float(t2n(model.input_covar.outputscale)),
+               M0=np.array([float(bm.constant.detach()) for bm in model.mean_module.base_means]).reshape(1 + m, n),
+               diag=int(diag))
+    torch.manual_seed(seed + 1)
+    Xtest = 1.2 * (2 * torch.rand(b, n) - 1)
+    Utest = torch.randn(b, m)
+    with RandRecorder() as rr:
+        mean_k, KkXX = reg._custom_predict_matrix(Xtest)
+        L = reg._cache["perturbed_cholesky"]
+        meanFXU, varFXU = reg.custom_predict(Xtest, Utest)
+        fullmean, fullvar = reg.custom_predict_fullmat(Xtest)
+    assert [d.shape for d in rr.draws] == [(N * n,)] + [(b * (1 + m) * n,)] * 3
+    out.update(jitter_rand=rr.draws[0][None], L=t2n(L), Xtest=t2n(Xtest), Utest=t2n(Utest),
+               jitter2=np.stack(rr.draws[1:]), mean_k=t2n(mean_k), KkXX=t2n(KkXX), meanFXU=t2n(meanFXU),
+               varFXU=t2n(varFXU), full_mean=t2n(fullmean), full_var=t2n(fullvar))
+    np.savez_compressed(os.path.join(HERE, 'cogp_%s.npz' % tag), **out)
+    print('cogp_%s: N=%d b=%d diag=%s' % (tag, N, b, diag))
+
+
+def main_cogp():
+    gen_cogp('full_N12', N=12, b=3, seed=61, diag=False)
+    gen_cogp('full_N48', N=48, b=5, seed=62, diag=False)
+    gen_cogp('diag_N24', N=24, b=4, seed=63, diag=True)
+
+
 if __name__ == '__main__':
-    if 'controllers' in sys.argv:
+    if 'cogp' in sys.argv:
+        main_cogp()
+    elif 'controllers' in sys.argv:
         main_controllers()
     elif 'cbc2' in sys.argv:
         main_cbc2()

@@ -696,3 +696,82 @@ def test_cbc2_quadratic_terms_on_the_unicycle_clc_expression():
     assert float(bfe @ u0 + e) == pytest.approx(float(clc(u0).mean(x)), abs=1e-9, rel=1e-9)
     assert float(u0 @ Vq @ u0 + bfv @ u0 + v) == pytest.approx(float(clc(u0).knl(x, x)), abs=1e-9, rel=1e-7)
     assert float(clc(u0).mean(x)) == pytest.approx(-float(gradV(x) @ reg.fu_func_mean(u0, x) + 10.0 * V(x)), rel=1e-9)
+
+
+# ---------------------------------------------------------------- CoGP comparators
+COGP_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cogp_*.npz")))
+
+
+def make_cogp(g, draws, dtype=torch.float64):
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorVector, ControlAffineRegVectorDiag
+    cls = ControlAffineRegVectorDiag if int(g["diag"]) else ControlAffineRegressorVector
+    reg = cls(2, 1, device=DEV, dtype=dtype)
+    reg.set_kernel_params(Sigma=g["Sigma"], lengthscale=float(g["ell"][0]), variance=float(g["lin"]),
+                          scalefactor=float(g["s2"]), M0=g["M0"])
+    f = dict(dtype=dtype, device=DEV)
+    reg.fit(torch.as_tensor(g["X"], **f), torch.as_tensor(g["U"], **f), torch.as_tensor(g["Xdot"], **f), training_iter=0)
+    it = iter(draws)
+    reg.rand_fn = lambda k: torch.as_tensor(next(it)[:k], **f)
+    return reg
+
+
+@pytest.mark.parametrize("path", COGP_FILES, ids=os.path.basename)
+def test_cogp_regressor_matches_reference(path):
+    """ControlAffineRegressorVector / ControlAffineRegVectorDiag (control_affine_model.py:1128-1330) through the
+    expanded-input mapping onto the K_b build / Cholesky / solve / query kernels, against the executed reference."""
+    g = np.load(path)
+    reg = make_cogp(g, [g["jitter_rand"][0], g["jitter2"][0], g["jitter2"][1], g["jitter2"][2]])
+    mean_k, KkXX = reg._custom_predict_matrix(t(g["Xtest"]))
+    close(reg._perturbed_cholesky(), g["L"], rtol=1e-8, atol=1e-10)
+    close(mean_k, g["mean_k"], rtol=1e-7, atol=1e-9)
+    close(KkXX, g["KkXX"], rtol=1e-6, atol=1e-9)
+    meanFXU, varFXU = reg.custom_predict(t(g["Xtest"]), t(g["Utest"]))
+    close(meanFXU, g["meanFXU"], rtol=1e-7, atol=1e-9)
+    close(varFXU, g["varFXU"], rtol=1e-6, atol=1e-9)
+    fm, fv = reg.custom_predict_fullmat(t(g["Xtest"]))
+    close(fm, g["full_mean"], rtol=1e-7, atol=1e-9)
+    close(fv, g["full_var"], rtol=1e-6, atol=1e-9)
+    # fp32 model: same numbers to the fp32 tolerance of BASELINE.json (1e-3 of the prior scale)
+    reg32 = make_cogp(g, [g["jitter_rand"][0], g["jitter2"][0]], dtype=torch.float32)
+    mean32, K32 = reg32._custom_predict_matrix(torch.as_tensor(g["Xtest"], dtype=torch.float32, device=DEV))
+    scale = float(g["s2"]) * np.abs(g["Sigma"]).max()
+    np.testing.assert_allclose(mean32.cpu().double().numpy(), g["mean_k"], rtol=0, atol=2e-3 * max(1.0, np.abs(g["mean_k"]).max()))
+    np.testing.assert_allclose(K32.cpu().double().numpy(), g["KkXX"], rtol=0, atol=2e-3 * scale)
+
+
+def test_cogp_fit_gradient_matches_finite_differences_of_the_oracle_likelihood():
+    """fit() of the vector-variate comparator: device gradient of -log p / (N n) w.r.t. every raw parameter (single
+    lengthscale, linear variance, output scale, Sigma factors, mean) vs central differences of the oracle."""
+    from oracle import gp_posterior as ogp
+    g = np.load(COGP_FILES[-1])
+    reg = make_cogp(g, [])
+    N, n = g["X"].shape
+    UH = ogp.homogeneous_controls(g["U"])
+    jit = 1e-5 * np.linspace(0.1, 0.9, N * n)
+    reg.rand_fn = lambda k: t(np.linspace(0.1, 0.9, N * n)[:k])
+
+    def oracle_loss():
+        m = reg.model
+        with torch.no_grad():
+            Sigma, M0 = m.Sigma.cpu().numpy(), m.M0.cpu().numpy()
+            ell, s2, lin = m.lengthscale.cpu().numpy().ravel(), float(m.outputscale), float(m.variance)
+        return -ogp.cogp_marginal_log_likelihood(g["X"], UH, g["Xdot"] - UH @ M0, Sigma, ell, s2, lin, jit) / (N * n)
+
+    for p in reg.model.parameters():
+        p.grad = None
+    loss = reg.neg_mll_backward()
+    np.testing.assert_allclose(loss, oracle_loss(), rtol=1e-9, atol=1e-10)
+    for name, p in reg.model.named_parameters():
+        assert p.grad is not None, name
+        flat, gflat = p.data.view(-1), p.grad.view(-1)
+        for k in range(min(flat.numel(), 4)):
+            old, h = float(flat[k]), 1e-5
+            flat[k] = old + h; lp = oracle_loss()
+            flat[k] = old - h; lm = oracle_loss()
+            flat[k] = old
+            np.testing.assert_allclose(float(gflat[k]), (lp - lm) / (2 * h), rtol=2e-5, atol=2e-7, err_msg="%s[%d]" % (name, k))
+    # and a short fit lowers the loss
+    torch.manual_seed(0)
+    reg.rand_fn = lambda k: torch.rand(k, **T64)
+    reg.fit(t(g["X"]), t(g["U"]), t(g["Xdot"]), training_iter=20, lr=0.1)
+    assert reg.fit_losses[-1] < reg.fit_losses[0]

@@ -249,3 +249,37 @@ def test_generic_controller_programs_solve_to_kkt_points():
         uq, yq, solq = oc.qp_controller_control(g["urefs"][i], float(g["ctrl_reg"]), float(g["relax_weight"]), st)
         assert solq["status"] == "optimal"
         assert g["t_qp_c"][i] @ yq + g["t_qp_d"][i] > -1e-8
+
+
+COGP_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cogp_*.npz")))
+
+
+@pytest.mark.parametrize("path", COGP_FILES, ids=os.path.basename)
+def test_cogp_comparator_matches_reference(path):
+    """ControlAffineRegressorVector / ...VectorDiag (control_affine_model.py:1128-1330): factor, posterior mean matrix,
+    full covariance, the (x,u) prediction and the flattened fullmat output."""
+    g = np.load(path)
+    X, U, Xdot, Sigma, M0 = g["X"], g["U"], g["Xdot"], g["Sigma"], g["M0"]
+    ell, s2, lin = g["ell"], float(g["s2"]), float(g["lin"])
+    if int(g["diag"]):
+        assert np.allclose(Sigma, np.diag(np.diag(Sigma)))
+    st = gp.cogp_refit_state(X, U, Xdot, Sigma, ell, s2, lin, M0, g["jitter_rand"])
+    assert st["tries"] == 1
+    close(st["L"], g["L"])
+    n, C = X.shape[1], U.shape[1] + 1
+    b = g["Xtest"].shape[0]
+    mean_k, KkXX = gp.cogp_custom_predict_matrix(X, st["UH"], st["Y"], st["L"], Sigma, ell, s2, lin, M0, g["Xtest"],
+                                                 g["jitter2"][0])
+    close(mean_k, g["mean_k"])
+    close(KkXX, g["KkXX"], atol=1e-10)
+    # custom_predict (:1132-1169): (uh' (x) I) blocks on both sides
+    mean_k2, KkXX2 = gp.cogp_custom_predict_matrix(X, st["UH"], st["Y"], st["L"], Sigma, ell, s2, lin, M0, g["Xtest"],
+                                                   g["jitter2"][1])
+    UHt = gp.homogeneous_controls(g["Utest"])
+    close(np.einsum("bnc,bc->bn", mean_k2, UHt), g["meanFXU"])
+    blk = np.stack([np.kron(u[None], np.eye(n)) for u in UHt])
+    close(np.einsum("bnk,bpkl,pml->bpnm", blk, KkXX2, blk), g["varFXU"], atol=1e-10)
+    mean_k3, KkXX3 = gp.cogp_custom_predict_matrix(X, st["UH"], st["Y"], st["L"], Sigma, ell, s2, lin, M0, g["Xtest"],
+                                                   g["jitter2"][2])
+    close(mean_k3.transpose(0, 2, 1).reshape(-1), g["full_mean"])
+    close(KkXX3.transpose(0, 2, 1, 3).reshape(b * C * n, b * C * n), g["full_var"], atol=1e-10)

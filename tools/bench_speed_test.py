@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""The reference's published speed test (pendulum.py:1305-1394, `speed_test_matrix_vector`), matrix-variate
-regressor only: pendulum n=2, m=1, N_train in {256, 320, 384, 512}, fit(training_iter=50), then
+"""The reference's published speed test (pendulum.py:1305-1394, `speed_test_matrix_vector`), all four regressors
+(MVGP full / diag, CoGP full / diag): pendulum n=2, m=1, N_train in {256, 320, 384, 512}, fit(training_iter=50), then
 min(timeit.repeat('dgp.custom_predict_fullmat(Xtest); dgp.clear_cache()', repeat=5, number=50)) / 50 on a 20x20
 (theta, omega) grid.  Every call is followed by a device synchronize (the reference's timing is host side).
-Published values (unknown 2020 GPU): 0.0436 / 0.0453 / 0.0503 / 0.0775 s per call."""
+Published values (unknown 2020 GPU) are in PUBLISHED below."""
 import json, math, os, sys, time, timeit
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExact, ControlAffineRegMatrixDiag
+from bayesian_cbf_amd.control_affine_model import (ControlAffineRegressorExact, ControlAffineRegMatrixDiag,
+                                                   ControlAffineRegressorVector, ControlAffineRegVectorDiag)
 
 PUBLISHED = {"matrix": {256: 0.0436, 320: 0.0453, 384: 0.0503, 512: 0.0775},
-             "matrixdiag": {256: 0.0331, 320: 0.0363, 384: 0.0417, 512: 0.0511}}
+             "matrixdiag": {256: 0.0331, 320: 0.0363, 384: 0.0417, 512: 0.0511},
+             "vector": {256: 0.0643, 320: 0.0865, 384: 0.1168, 512: 0.1915},
+             "vectordiag": {256: 0.0590, 320: 0.0818, 384: 0.1123, 512: 0.1786}}
 
 
 def pendulum_data(D=2000, tau=0.01, theta0=5 * math.pi / 6, omega0=-0.01, mass=1.0, gravity=10.0, length=1.0, seed=0):
@@ -32,7 +35,8 @@ def main():
     X, U, dX = pendulum_data()
     order = np.random.default_rng(1).permutation(len(X) - 1)
     out = []
-    for cls_name, cls in (("matrix", ControlAffineRegressorExact), ("matrixdiag", ControlAffineRegMatrixDiag)):
+    for cls_name, cls in (("matrix", ControlAffineRegressorExact), ("matrixdiag", ControlAffineRegMatrixDiag),
+                          ("vector", ControlAffineRegressorVector), ("vectordiag", ControlAffineRegVectorDiag)):
         for N in (256, 320, 384, 512):
             idx = order[:N]
             t = lambda a: torch.as_tensor(a[idx], dtype=dtype, device=dev)
