@@ -101,7 +101,23 @@ def parse_events(path):
     return out
 
 
+def write_event_slice(nrec=150):
+    """First `nrec` raw records of one committed run's event file (a data file of the reference): the byte-exact
+    fixture of tests/test_tblog_cpu.py for the log writer / reader (SURVEY 8f #4)."""
+    rdir = os.path.join(REFERENCE, "docs", "saved-runs", RUNS["saved_run_bayes_cbf_maxrisk0p01"])
+    src = glob.glob(os.path.join(rdir, "events.out.tfevents.*"))[0]
+    data = open(src, "rb").read()
+    i = 0
+    for _ in range(nrec):
+        (ln,) = struct.unpack("<Q", data[i:i + 8])
+        i += 16 + ln
+    with open(os.path.join(HERE, "reference_events_slice.tfevents"), "wb") as f:
+        f.write(data[:i])
+    print("reference_events_slice.tfevents: %d records, %d bytes" % (nrec, i))
+
+
 def main():
+    write_event_slice()
     for name, d in RUNS.items():
         rdir = os.path.join(REFERENCE, "docs", "saved-runs", d)
         ev = parse_events(glob.glob(os.path.join(rdir, "events.out.tfevents.*"))[0])

@@ -775,3 +775,38 @@ def test_cogp_fit_gradient_matches_finite_differences_of_the_oracle_likelihood()
     reg.rand_fn = lambda k: torch.rand(k, **T64)
     reg.fit(t(g["X"]), t(g["U"]), t(g["Xdot"]), training_iter=20, lr=0.1)
     assert reg.fit_losses[-1] < reg.fit_losses[0]
+
+
+def test_closed_loop_logged_in_the_reference_format_and_played_back(tmp_path):
+    """SURVEY 8f #4 as a live regression: re-run the reference's committed run (same config, logged start state) with
+    ControllerCLFBayesian on the device, log it through TBLogger / RolloutLogger in the reference's event-file format,
+    play the directory back and compare with the trajectory GUROBI produced (explicit Euler, true L = 12)."""
+    from bayesian_cbf_amd import tblog
+    from bayesian_cbf_amd import unicycle_move_to_pose as ump
+    g = np.load(os.path.join(GOLDEN, "saved_run_bayes_cbf_maxrisk0p01.npz"))
+    x0, xg = t(g["state_start"]), t(g["state_goal"])
+    T, dt = 40, float(g["dt"])
+    planner = ump.PiecewiseLinearPlanner(x0, xg, int(g["numSteps"]), dt, frac_time_to_reach_goal=0.95)
+    ctrl = ump.ControllerCLFBayesian(
+        planner, coordinate_converter=lambda x, x_g: x, dynamics=None,
+        mean_dynamics=ump.AckermannDrive(L=float(g["mean_L"]), kernel_diag_A=g["kernel_diag_A"]),
+        clf=ump.CLFCartesian(Kp=[0.9, 1.5, 0.0]),
+        cbfs=ump.obstacles_at_mid_from_start_and_goal(x0, xg, term_weights=tuple(g["term_weights"])),
+        cbf_gammas=list(g["cbf_gammas"]), max_risk=float(g["max_risk"]), clf_gamma=float(g["clf_gamma"]),
+        cost_weights=list(g["cost_weights"]), device=DEV, dtype=torch.float64)
+    log = tblog.TBLogger(["unicycle_move_to_pose_fixed", "replay"], runs_dir=str(tmp_path))
+    log.write_config(dict(state_start=g["state_start"].tolist(), state_goal=g["state_goal"].tolist(), numSteps=T, dt=dt))
+    rl = tblog.RolloutLogger(planner, dt, log)
+    plant = ump.AckermannDrive(L=float(g["true_L"]))
+    x = t(g["state"][0].astype(np.float64))
+    for step in range(T):
+        u = ctrl.control(x, step)
+        rl.setStateCtrl(x, u, step)
+        x = x + (plant.f_func(x) + plant.g_func(x) @ u) * dt
+    log.summary_writer.close()
+    run = tblog.playback_logfile(log.experiment_logs_dir)
+    assert list(run["steps"]) == list(range(T)) and run["config"]["dt"] == dt
+    np.testing.assert_allclose(run["uopt"], g["uopt"][:T], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(run["state"], g["state"][:T], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(np.stack([run["info"]["plan_x"][s] for s in range(T)]),
+                               np.stack([planner.plan(s).cpu().numpy() for s in range(T)]), rtol=1e-6, atol=1e-7)

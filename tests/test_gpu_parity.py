@@ -709,3 +709,35 @@ def test_controller_cones_flags_unfactorable_stability_terms(ops):
     A, b, c, d = oc.convert_cbc_terms_to_socp_terms(tiny[:1], tiny[1], tiny[2:3].reshape(1, 1), tiny[3:4], tiny[4], 1)
     np.testing.assert_allclose(-host(G)[1, 1:], A, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(host(h)[1, 1:], b, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-4)], ids=["f64", "f32"])
+def test_rbf_plus_linear_data_kernel_entry_points(ops, dtype, tol):
+    """bcbf_kb_build_rbflin / bcbf_posterior_query_rbflin with independent instances (one `lin` per instance):
+    k = s2 (exp(-1/2 |x-x'|^2/ell^2) + lin x'x'), against numpy."""
+    rng = np.random.default_rng(7)
+    Bt, N, n, C = 5, 70, 2, 4
+    X = rng.uniform(-1.5, 1.5, (Bt, N, n)); UH = rng.normal(size=(Bt, N, C)); UH[..., 0] = 1
+    R = rng.normal(size=(Bt, C, C)); Bm = R @ R.transpose(0, 2, 1) + 0.2 * np.eye(C)
+    ell = np.repeat(rng.uniform(0.5, 1.2, (Bt, 1)), n, axis=1); s2 = rng.uniform(0.5, 1.5, Bt); lin = rng.uniform(0.05, 0.4, Bt)
+    jit = 1e-4 * rng.uniform(size=(Bt, N)) + (1e-3 if dtype == torch.float32 else 0.0)
+    Y = rng.normal(size=(Bt, N, n)); M0 = 0.1 * rng.normal(size=(Bt, C, n)); xq = rng.uniform(-1, 1, (Bt, n))
+    d = lambda a: dev(a, dtype)
+    Kb = ops.kb_build(d(X), d(UH), d(Bm), d(ell), d(s2), d(jit), lin=d(lin))
+    Lop, info, _ = ops.potrf(Kb)
+    assert int(info.abs().max()) == 0
+    Vw, _ = ops.potrs(Lop, d(Y), d(UH), d(M0), want_alpha=False)
+    UHB = np.einsum("bnc,bcd->bnd", UH, Bm)
+    Mk, Bk, W = ops.posterior_query(Lop, Vw, d(X), d(UHB), d(ell), d(s2), d(Bm), d(M0), d(xq), shared=False, want_W=True,
+                                    lin=d(lin))
+    for b in range(Bt):
+        Kref = ogp.rbf_linear_kernel(X[b], X[b], ell[b], s2[b], lin[b]) * (UH[b] @ Bm[b] @ UH[b].T) + np.diag(jit[b])
+        rel_close(host(Kb[b]), Kref, tol, what="K_b")
+        L = np.linalg.cholesky(Kref)
+        Phi = ogp.rbf_linear_kernel(X[b], xq[b:b + 1], ell[b], s2[b], lin[b]) * UHB[b]
+        Wr = np.linalg.solve(L, Phi)
+        Vr = np.linalg.solve(L, Y[b] - UH[b] @ M0[b])
+        rel_close(host(W[b, :N]), Wr, 20 * tol, what="W")
+        rel_close(host(Mk[b]), M0[b].T + Vr.T @ Wr, 20 * tol, what="Mk")
+        kss = s2[b] * (1 + lin[b] * xq[b] @ xq[b])
+        rel_close(host(Bk[b]), kss * Bm[b] - Wr.T @ Wr, 50 * tol, scale=kss * np.abs(Bm[b]).max(), what="Bk")
