@@ -37,6 +37,35 @@ def torch_kron(A, B):
     return torch.kron(A, B)
 
 
+class CatEncoder:
+    """Packs arrays by concatenating them along the last axis (control_affine_model.py:74-100): the reference's
+    training rows are MXU = [mask(1), x(n), uh(1+m)].  The device path keeps X, UH, Y as separate buffers; this is
+    the reference's container for code that builds or reads MXU rows."""
+
+    def __init__(self, *sizes):
+        self.sizes = list(sizes)
+
+    @classmethod
+    def from_data(cls, *arrays):
+        self = cls(*[A.shape[-1] for A in arrays])
+        return self, self.encode(*arrays)
+
+    def encode(self, *arrays):
+        if isinstance(arrays[0], torch.Tensor):
+            return torch.cat(arrays, dim=-1)
+        return np.concatenate(arrays, axis=-1)
+
+    def decode(self, X):
+        idxs = np.cumsum([0] + self.sizes)
+        return [X[..., s:e] for s, e in zip(idxs[:-1], idxs[1:])]
+
+    def state_dict(self):
+        return dict(sizes=self.sizes)
+
+    def load_state_dict(self, state_dict):
+        self.sizes = state_dict["sizes"]
+
+
 class KernelParams(torch.nn.Module):
     """Container of the hyper-parameters the reference keeps in gpytorch modules
     (control_affine_model.py:139-177): RBF-ARD lengthscale, outputscale, IndexKernel factors of A

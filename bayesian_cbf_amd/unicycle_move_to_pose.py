@@ -38,6 +38,16 @@ class AckermannDrive:
                           torch.stack([z, o / self.L], -1)], -2)
         return gX.squeeze(0) if state_in.dim() <= 1 else gX
 
+    def F_func(self, X):
+        return torch.cat([self.f_func(X).unsqueeze(-1), self.g_func(X)], dim=-1)
+
+    def fixed_kernel(self):
+        """(A, B) of the fixed-kernel GP ((u_hom' B u_hom) A, :261-275)."""
+        return torch.diag(self.kernel_diag_A), torch.eye(self.ctrl_size + 1, dtype=torch.float64)
+
+    def fu_func_gp(self, u):
+        return _fixed_kernel_gp(self, u, "AckermannDrive")
+
     def step(self, u, dt):
         """Explicit Euler (:277-282); device batches go through the HIP kernel."""
         x = self.current_state
@@ -47,6 +57,92 @@ class AckermannDrive:
         xdot = self.f_func(x) + (self.g_func(x) @ u.unsqueeze(-1)).squeeze(-1)
         self.current_state = x + xdot * dt
         return dict(xdot=xdot, x=self.current_state)
+
+
+def _fixed_kernel_gp(model, u, name):
+    """GaussianProcess(mean = f + g u, knl = (u_hom' B u_hom) A): a leaf of the expression algebra whose conditions
+    lower onto bcbf_cbc_terms with M_k = 0, B_k = B (gp_algebra.lower, cbc2.FixedKernelGP)."""
+    from .gp_algebra import GaussianProcess
+    A, B = model.fixed_kernel()
+
+    def mean(x):
+        return model.f_func(x) + model.g_func(x) @ u.to(x)
+
+    def knl(x, xp):
+        uh = torch.cat([torch.ones(1).to(x), u.to(x)])
+        return (uh @ B.to(x) @ uh) * A.to(x)
+
+    return GaussianProcess(mean=mean, knl=knl, shape=(model.state_size,), name=name, source=(model, "fu", u))
+
+
+class PolarDynamics:
+    """unicycle_move_to_pose.py:142-165 (rho, alpha, beta) kinematics."""
+    state_size, ctrl_size = 3, 2
+
+    def __init__(self):
+        self.current_state = None
+
+    def set_init_state(self, x0):
+        self.current_state = x0
+
+    def f_func(self, x):
+        return torch.zeros_like(x)
+
+    def g_func(self, x):
+        rho, alpha, beta = x
+        assert rho > 1e-6
+        z, o = torch.zeros_like(rho), torch.ones_like(rho)
+        return torch.stack([torch.stack([-torch.cos(alpha), z]), torch.stack([-torch.sin(alpha) / rho, o]),
+                            torch.stack([-torch.sin(alpha) / rho, z])])
+
+    def step(self, u_torch, dt):
+        x = self.current_state
+        xdot = self.f_func(x) + self.g_func(x) @ u_torch
+        self.current_state = x + xdot * dt
+        return dict(xdot=xdot, x=self.current_state)
+
+
+class CartesianDynamics(PolarDynamics):
+    """Unit-wheelbase unicycle with the kernel (u'u + 1) I (:168-197)."""
+
+    def g_func(self, state_in):
+        state = state_in.unsqueeze(0) if state_in.dim() <= 1 else state_in
+        th = state[..., 2]
+        z, o = torch.zeros_like(th), torch.ones_like(th)
+        gX = torch.stack([torch.stack([th.cos(), z], -1), torch.stack([th.sin(), z], -1), torch.stack([z, o], -1)], -2)
+        return gX.squeeze(0) if state_in.dim() <= 1 else gX
+
+    def fixed_kernel(self):
+        return torch.eye(self.state_size, dtype=torch.float64), torch.eye(self.ctrl_size + 1, dtype=torch.float64)
+
+    def fu_func_gp(self, u):
+        return _fixed_kernel_gp(self, u, "CartesianDynamics")
+
+
+class ZeroDynamicsModel:
+    """misc.py:194-213."""
+
+    def __init__(self, m, n):
+        self.m, self.n = m, n
+
+    ctrl_size = property(lambda self: self.m)
+    state_size = property(lambda self: self.n)
+
+    def f_func(self, X):
+        return torch.zeros_like(X)
+
+    def g_func(self, X):
+        return torch.zeros(*X.shape, self.m, dtype=X.dtype, device=X.device)
+
+
+class ZeroDynamicsBayesian(ZeroDynamicsModel):
+    """Zero mean, kernel (u'u + 1) I (:794-798)."""
+
+    def fixed_kernel(self):
+        return torch.eye(self.n, dtype=torch.float64), torch.eye(self.m + 1, dtype=torch.float64)
+
+    def fu_func_gp(self, U):
+        return _fixed_kernel_gp(self, U, "ZeroDynamicsBayesian")
 
 
 class CLFCartesian:

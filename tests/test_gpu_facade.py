@@ -810,3 +810,37 @@ def test_closed_loop_logged_in_the_reference_format_and_played_back(tmp_path):
     np.testing.assert_allclose(run["state"], g["state"][:T], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(np.stack([run["info"]["plan_x"][s] for s in range(T)]),
                                np.stack([planner.plan(s).cpu().numpy() for s in range(T)]), rtol=1e-6, atol=1e-7)
+
+
+def test_fixed_kernel_models_lower_onto_the_terms_kernel():
+    """AckermannDrive / CartesianDynamics / ZeroDynamicsBayesian.fu_func_gp (unicycle_move_to_pose.py:190-197, 261-275,
+    794-798): GP(f + g u, (u_hom' B u_hom) A).  A rel-degree-1 condition on such a leaf goes through bcbf_cbc_terms with
+    M_k = 0, B_k = B and must equal the closed form grad'(f + g u) + gamma h,  (1 + u'u) grad' A grad."""
+    from bayesian_cbf_amd import unicycle_move_to_pose as ump
+    from bayesian_cbf_amd.cbc1 import RelDeg1Safety
+    from bayesian_cbf_amd.cbc2 import cbc2_quadratic_terms
+    from bayesian_cbf_amd.control_affine_model import CatEncoder
+    torch.manual_seed(2)
+    x, u, u0 = torch.rand(3, **T64), torch.rand(2, **T64), torch.rand(2, **T64)
+    for model in (ump.AckermannDrive(L=0.7, kernel_diag_A=(0.5, 2.0, 1.5)), ump.CartesianDynamics(),
+                  ump.ZeroDynamicsBayesian(m=2, n=3)):
+        class Safety(RelDeg1Safety):
+            gamma, max_unsafe_prob = 5.0, 0.01
+            cbf = staticmethod(lambda z: (z[0] - 1.0) ** 2 + (z[1] + 0.5) ** 2 - 0.3)
+            grad_cbf = staticmethod(lambda z: torch.stack([2 * (z[0] - 1.0), 2 * (z[1] + 0.5), 0.1 * torch.cos(z[2])]))
+        sf = Safety()
+        sf.model = model
+        (bfe, e), (V, bfv, v), mean, var = cbc2_quadratic_terms(sf.cbc, x, u0)
+        A, B = model.fixed_kernel()
+        gh = Safety.grad_cbf(x)
+        g = torch.as_tensor(model.g_func(x)).to(x)
+        want_mean = gh @ (torch.as_tensor(model.f_func(x)).to(x) + g @ u) + 5.0 * Safety.cbf(x)
+        want_var = (1 + u @ u) * (gh @ A.to(x) @ gh)
+        assert float(bfe @ u + e) == pytest.approx(float(want_mean), rel=1e-12, abs=1e-12)
+        assert float(u @ V @ u + bfv @ u + v) == pytest.approx(float(want_var), rel=1e-12, abs=1e-12)
+        gp = model.fu_func_gp(u)                                    # the leaf's own views agree
+        assert float(gh @ gp.mean(x) + 5.0 * Safety.cbf(x)) == pytest.approx(float(want_mean), rel=1e-12)
+        assert float(gh @ gp.knl(x, x) @ gh) == pytest.approx(float(want_var), rel=1e-12)
+    enc, MXU = CatEncoder.from_data(torch.ones(4, 1), torch.rand(4, 3), torch.rand(4, 3))
+    M, X, UH = enc.decode(MXU)
+    assert enc.sizes == [1, 3, 3] and M.shape == (4, 1) and X.shape == (4, 3) and torch.equal(enc.encode(M, X, UH), MXU)
