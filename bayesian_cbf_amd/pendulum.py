@@ -67,3 +67,135 @@ class RadialCBFRelDegree2(RelDeg2Safety):
         H = x.new_zeros(2, 2)
         H[0, 0] = torch.cos(x[0] - self.cbf_col_theta)
         return H
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The learning demo of BASELINE configs[0]: pendulum.learn_dynamics_matrix_vector (pendulum.py:1052-1271).  Data come
+# from one simulated trajectory under a randomised controller; both regressors are fitted on a random subset, evaluated
+# on a 20 x 20 (theta, omega) grid with `custom_predict_fullmat`, logged in the reference's tags, and compared with the
+# variance-weighted error of `measure_batch_error`.  Plotting is out of scope.
+class ControlTrivial:
+    """u = m g sin(theta)  (pendulum.py:55-66)."""
+    needs_ground_truth = True
+
+    def __init__(self, m=1, mass=None, length=None, gravity=None, dt=None, true_model=None):
+        self.m, self.mass, self.length, self.gravity = m, mass, length, gravity
+
+    def control(self, xi, t=None):
+        return (self.mass * self.gravity * torch.sin(xi[0])).reshape(1)
+
+
+class ControlRandom:
+    """ControlTrivial scaled by U[0.6, 1.4)  (pendulum.py:69-78)."""
+    needs_ground_truth = True
+
+    def __init__(self, **kwargs):
+        self.control_trivial = ControlTrivial(**kwargs)
+
+    def control(self, xi, t=None):
+        return self.control_trivial.control(xi, t=t) * (torch.rand(1) * 0.8 + 0.60).to(xi)
+
+
+def sampling_pendulum_data(dynamics_model, D=100, dt=0.01, x0=None, controller=None, **_ignored):
+    """One explicit-Euler trajectory of D+1 states (theta wrapped to [-pi, pi)); returns (dX[D,2], X[D+1,2], U[D+1,1]) with
+    dX the finite differences, as pendulum.py:164-252 (host loop: one short trajectory, not a hot path)."""
+    assert controller is not None
+    x = torch.as_tensor(x0, dtype=torch.float64).clone()
+    X = torch.empty(D + 1, 2, dtype=torch.float64)
+    U = torch.empty(D + 1, 1, dtype=torch.float64)
+    for t in range(D + 1):
+        X[t] = x
+        u = controller(x, t=t).to(torch.float64)
+        U[t] = u
+        xdot = dynamics_model.f_func(x[None])[0] + dynamics_model.g_func(x) @ u
+        x = x + xdot * dt
+        x[0] = ((x[0] + math.pi) % (2 * math.pi)) - math.pi
+    dX = (X[1:] - X[:-1]) / dt
+    return dX, X, U
+
+
+def get_grid_from_Xtrain(Xtrain):
+    """20 x 20 grid over the training range (pendulum.py:421-428); [2, 20, 20] like np.mgrid."""
+    import numpy as np
+    th = slice(Xtrain[:, 0].min(), Xtrain[:, 0].max(), (Xtrain[:, 0].max() - Xtrain[:, 0].min()) / 20)
+    om = slice(Xtrain[:, 1].min(), Xtrain[:, 1].max(), (Xtrain[:, 1].max() - Xtrain[:, 1].min()) / 20)
+    return np.mgrid[th, om]
+
+
+def measure_batch_error(FX_learned, var_FX, FX_true):
+    """sqrt(mean_b (F - F^)' var_b^-1 (F - F^))  (pendulum.py:1091-1103)."""
+    N, D = FX_learned.shape
+    assert FX_true.shape == (N, D) and var_FX.shape == (N, D, D)
+    diff = (FX_true - FX_learned).unsqueeze(-1).double().cpu()           # an evaluation metric: tiny systems, host side
+    errors = diff.transpose(-2, -1) @ torch.linalg.solve(var_FX.double().cpu(), diff)
+    assert bool((errors > 0).all())
+    return float(torch.sqrt(errors.sum() / N))
+
+
+def log_learned_model(Xtrain, model, true_f_func, key="Fx", logger=None):
+    """Evaluate the model on the grid and log (Xtrain, grid, FX_learned, var_FX, FX_true) (pendulum.py:450-475);
+    returns the logged arrays."""
+    import numpy as np
+    grid = get_grid_from_Xtrain(Xtrain)
+    _, N_, M_ = grid.shape
+    n, m = model.x_dim, model.u_dim
+    Xtest = torch.as_tensor(grid.transpose(1, 2, 0).reshape(-1, 2), dtype=model.dtype, device=model.device)
+    FX_learned, var_FX = model.custom_predict_fullmat(Xtest)
+    assert FX_learned.shape == (N_ * M_ * (1 + m) * n,)
+    assert not torch.isnan(FX_learned).any() and not torch.isnan(var_FX).any()
+    FX_true = true_f_func(Xtest).transpose(-1, -2)                       # (b, 1+m, n)
+    out = dict(Xtrain=np.asarray(Xtrain), theta_omega_grid=grid,
+               FX_learned=FX_learned.reshape(N_, M_, 1 + m, n).cpu().numpy(),
+               var_FX=var_FX.reshape(N_, M_, 1 + m, n, N_, M_, 1 + m, n).cpu().numpy(),
+               FX_true=FX_true.reshape(N_, M_, 1 + m, n).cpu().numpy())
+    if logger is not None:
+        logger.add_tensors("/".join(("log_learned_model", key)), out, 0)
+    return out
+
+
+def learn_dynamics_from_data(dX, X, U, pend_env, regressor_class, logger, max_train, tags=(), training_iter=50,
+                             device="cuda", dtype=torch.float32):
+    """Random subset of the trajectory, fit (50 Adam steps), log the learned model (pendulum.py:345-371)."""
+    numSteps = X.shape[0]
+    N = min(numSteps - 1, max_train)
+    idx = torch.randint(numSteps - 1, size=(N,))
+    f = dict(dtype=dtype, device=device)
+    Xtrain, Utrain, XdotTrain = X[idx].to(**f), U[idx].to(**f), dX[idx].to(**f)
+    dgp = regressor_class(Xtrain.shape[-1], Utrain.shape[-1], device=device, dtype=dtype)
+    dgp.fit(Xtrain, Utrain, XdotTrain, training_iter=training_iter)
+    if logger is not None:
+        logger.add_tensors("train", dict(Xtrain=Xtrain, Utrain=Utrain), 0)
+    logged = log_learned_model(Xtrain.cpu().numpy(), dgp, pend_env.F_func, key="/".join(list(tags) + ["Fx"]), logger=logger)
+    return dgp, logged
+
+
+def learned_model_error(logged, n=2, m=1):
+    """The number learn_dynamics_matrix_vector_vis writes to vector_matrix_learning_error.txt (pendulum.py:1121-1139):
+    measure_batch_error with the per-point (1+m)n x (1+m)n covariance blocks."""
+    FXl = torch.as_tensor(logged["FX_learned"]).double()
+    b = int(FXl.shape[0] * FXl.shape[1])
+    T_ = (1 + m) * n
+    var = torch.as_tensor(logged["var_FX"]).double().reshape(b, T_, b, T_)
+    blocks = torch.stack([var[i, :, i, :] for i in range(b)])
+    return measure_batch_error(FXl.reshape(b, T_), blocks, torch.as_tensor(logged["FX_true"]).double().reshape(b, T_))
+
+
+def learn_dynamics_matrix_vector_exp(exps=None, theta0=5 * math.pi / 6, omega0=-0.01, tau=0.01, mass=1, gravity=10,
+                                     length=1, max_train=200, numSteps=1000, logger=None, device="cuda",
+                                     dtype=torch.float32, training_iter=50):
+    """pendulum.py:1052-1088: returns {name: (regressor, logged arrays, error)}."""
+    from .control_affine_model import ControlAffineRegressorExact, ControlAffineRegressorVector
+    exps = exps or dict(matrix=dict(regressor_class=ControlAffineRegressorExact),
+                        vector=dict(regressor_class=ControlAffineRegressorVector))
+    pend_env = PendulumDynamicsModel(m=1, n=2, mass=mass, gravity=gravity, length=length)
+    dX, X, U = sampling_pendulum_data(pend_env, D=numSteps, x0=torch.tensor([theta0, omega0]), dt=tau,
+                                      controller=ControlRandom(mass=mass, gravity=gravity, length=length).control)
+    if logger is not None:
+        for t, (dx, x, u) in enumerate(zip(dX, X, U)):
+            logger.add_tensors("traj", dict(dx=dx, x=x, u=u), t)
+    out = dict()
+    for name, kw in exps.items():
+        dgp, logged = learn_dynamics_from_data(dX, X, U, pend_env, kw["regressor_class"], logger, max_train=max_train,
+                                               tags=[name], training_iter=training_iter, device=device, dtype=dtype)
+        out[name] = (dgp, logged, learned_model_error(logged))
+    return out

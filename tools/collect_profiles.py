@@ -10,7 +10,8 @@ for tag, dst in (("prof_indep", "profiles/r01_bench_kernel_stats.csv"), ("prof_s
     print(dst, [(r[0].split("(")[0][-42:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
 for a, b in (("bench_default.json", "r01_bench_default.json"), ("bench_shared_prof.json", "r01_bench_shared_under_rocprof.json"),
              ("bench_shared.json", "r01_bench_shared.json"), ("configs.jsonl", "r01_configs_refit_potrs_posterior.jsonl"),
-             ("online_growth_f64.json", "r01_online_growth_f64.json"), ("speed_test.jsonl", "r01_speed_test_matrix_vector.jsonl")):
+             ("online_growth_f64.json", "r01_online_growth_f64.json"), ("speed_test.jsonl", "r01_speed_test_matrix_vector.jsonl"),
+             ("learn_matrix_vector.jsonl", "r01_learn_dynamics_matrix_vector.jsonl")):
     if os.path.exists(R + "gpurun_out/" + a):
         shutil.copy(R + "gpurun_out/" + a, R + "profiles/" + b)
 d = json.load(open(R + "profiles/r01_bench_default.json"))
@@ -19,6 +20,8 @@ d = json.load(open(R + "profiles/r01_bench_shared.json"))
 print("shared", d["value"], d["batched_steps_per_s"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel_ms"])
 out = {}
 for tag, pat in (("bench_shared", "gpurun_out/pmc_shared/*/*_counter_collection.csv"), ("bench_configs", "gpurun_out/pmc_refit/*/*_counter_collection.csv")):
+    if not glob.glob(R + pat):
+        continue                       # no fresh counter pass (tools/run_pmc_mfma.sh): keep the committed numbers
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(latest(pat))):
         k = r["Kernel_Name"]
@@ -37,10 +40,14 @@ for tag, pat in (("bench_shared", "gpurun_out/pmc_shared/*/*_counter_collection.
         out.setdefault(tag, []).append(dd)
         print(tag, dd["kernel"], dd["workgroups"], dd["mfma_util"])
 old = json.load(open(R + "profiles/r01_pmc_mfma.json"))
-json.dump(dict(note=old["note"], passes=out), open(R + "profiles/r01_pmc_mfma.json", "w"), indent=1)
+if out:
+    json.dump(dict(note=old["note"], passes=out), open(R + "profiles/r01_pmc_mfma.json", "w"), indent=1)
 for l in open(R + "profiles/r01_configs_refit_potrs_posterior.jsonl"):
     d = json.loads(l)
     print(d["config"], round(d["refit_ms"], 3), round(d["refit_TFLOPs"], 1), round(d["potrs_ms"], 3), round(d["posterior_ms"], 4), round(d["posterior_GBs_algorithmic"]))
 for l in open(R + "profiles/r01_speed_test_matrix_vector.jsonl"):
     d = json.loads(l)
     print(d["regressor"], d["N"], round(d["s_per_call"] * 1e3, 2), "ms", round(d["speedup_vs_published"], 1), round(d["fit_s"], 2), round(d["heldout_rel_rms_err"], 4))
+for l in open(R + "profiles/r01_learn_dynamics_matrix_vector.jsonl"):
+    d = json.loads(l)
+    print("learn", d["N_train"], d["seed"], round(d["seconds"], 2), "s  err matrix/vector", round(d["error_matrix"], 3), round(d["error_vector"], 3))
