@@ -122,7 +122,10 @@ def main():
     if os.environ.get("BCBF_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("BCBF_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # BCBF_BENCH_FORCE_DIST=1: run the N>1 code path (process group, barriers, the final reductions over RCCL) with a
+    # single rank too -- the only way to exercise RCCL itself on a one-GPU box
+    multi = world > 1 or os.environ.get("BCBF_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -196,7 +199,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if multi:
             import torch.distributed as dist
             dist.barrier()
 
@@ -221,7 +224,7 @@ def main():
 
     n_opt = int((status == 0).sum())
     stats = torch.tensor([elapsed, float(n_opt), float(Bt), float(iters.float().mean())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         if backend != "nccl":
             stats = stats.cpu()
@@ -289,7 +292,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(p, task, args.cpu_sample, N, n, m)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.destroy_process_group()
 
