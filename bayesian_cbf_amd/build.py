@@ -45,7 +45,8 @@ def _compile(src, force):
             os.path.abspath(__file__)]
     if not force and _newer(obj, deps):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    tuning = os.environ.get("BCBF_EXTRA_HIPCC_FLAGS", "").split()        # e.g. -DBCBF_PS_UNR=2 for tuning sweeps
+    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + tuning + ["-c", os.path.join(CSRC, src), "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
