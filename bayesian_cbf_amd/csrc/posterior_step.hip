@@ -11,6 +11,7 @@
 //      per column (contiguous across the wave), w_J broadcast from LDS.
 // Algorithmic HBM bytes per instance: sizeof(T) * [Np(Np+V)/2 + N(2n + C)]  (Lop + X + Vw + UHB).
 #include "bcbf_common.h"
+#include <type_traits>
 
 #ifndef BCBF_PS_DUNR
 #define BCBF_PS_DUNR 4     // unroll of the diagonal-block mat-vec
@@ -21,6 +22,12 @@
 #ifndef BCBF_PS_AUX
 #define BCBF_PS_AUX 2      // cache-policy bits of the streaming loads: 2 = non-temporal (each byte is read once;
                            // measured +9 % over the default policy, 462 -> 424 us)
+#endif
+#ifndef BCBF_PS_PKASM
+#define BCBF_PS_PKASM 1    // fp32: explicit v_pk_fma_f32 with op_sel broadcast of w (see consume)
+#endif
+#ifndef BCBF_PS_UNR8_MAXC
+#define BCBF_PS_UNR8_MAXC 3     // C = 4 would spill at 8 columns per stage
 #endif
 #ifndef BCBF_PS_UNR
 #define BCBF_PS_UNR 4      // columns per software-pipeline stage of the streaming loop
@@ -108,7 +115,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // optional linear part of the data kernel, k = s2 (exp(..) + lin x'x') (the CoGP comparator's RBF + Linear,
     // control_affine_model.py:1121-1122); lin == NULL -> 0
     const T linv = lin != nullptr ? lin[gb] : T(0);
-    T acc[2][V][CT];
+    // fp32 fast path: residuals held as register PAIRS over two consecutive rows, so that the update is one
+    // v_pk_fma_f32 per (row pair, column) with w broadcast by op_sel -- the compiler's own packing mixes row- and
+    // column-pairs and pays ~0.9 v_mov per packed multiply-add to shuffle the pairs (47 % of the loop's VALU issue).
+    constexpr bool PK = BCBF_PS_PKASM && std::is_same<T, float>::value;
+    using f32x2 = __attribute__((__vector_size__(2 * sizeof(float)))) float;
+    T acc[PK ? 1 : 2][PK ? 1 : V][PK ? 1 : CT];
+    f32x2 accp[PK ? 2 : 1][PK ? V / 2 : 1][PK ? CT : 1];
+#define BCBF_ACC(r, v, c) (*(PK ? reinterpret_cast<T*>(&accp[r][(v) >> 1][c]) + ((v) & 1) : &acc[PK ? 0 : (r)][PK ? 0 : (v)][PK ? 0 : (c)]))
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int rb = r == 0 ? rbA : rbB;
@@ -126,11 +140,11 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const T ub = (live && i < N) ? UHBb[(size_t)i * C + c] : T(0);
-                acc[r][v][c] = k * ub;
+                BCBF_ACC(r, v, c) = k * ub;
 #pragma unroll
                 for (int d = 0; d < NJ; ++d) {     // d Phi / d x_d = -(x_d - X_id)/ell_d^2 * Phi
                     const T dz = (live && i < N) ? (Xb[(size_t)i * n + d] - xqr[d]) * iell[d] * iell[d] : T(0);
-                    acc[r][v][(1 + d) * C + c] = dz * k * ub;
+                    BCBF_ACC(r, v, (1 + d) * C + c) = dz * k * ub;
                 }
             }
         }
@@ -150,7 +164,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // Streaming pipeline state.  Column groups of UNR columns form ONE stream over all blocks: the
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
-    constexpr int UNR = NJ > 0 ? 2 : BCBF_PS_UNR, NGRP = NB / UNR, HALF = NB / 2;
+    // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
+    constexpr int UNR = NJ > 0 ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
@@ -171,18 +186,49 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            T wj[CT];
+            if constexpr (PK) {
+                using f32x4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+                f32x2 wp[CP / 2];                                     // w_J row, two columns per register pair
 #pragma unroll
-            for (int c = 0; c < CT; ++c) wj[c] = wbuf[jj0 + u][c];
-            const T* pa = reinterpret_cast<const T*>(&la[u]);
-            const T* pb = reinterpret_cast<const T*>(&lb[u]);
-#pragma unroll
-            for (int v = 0; v < V; ++v)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    acc[0][v][c] -= pa[v] * wj[c];
-                    acc[1][v][c] -= pb[v] * wj[c];
+                for (int q = 0; q < CP / 4; ++q) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wbuf[jj0 + u][4 * q]);
+                    wp[2 * q] = __builtin_shufflevector(w4, w4, 0, 1);
+                    wp[2 * q + 1] = __builtin_shufflevector(w4, w4, 2, 3);
                 }
+                const f32x4 a4 = __builtin_bit_cast(f32x4, la[u]), b4 = __builtin_bit_cast(f32x4, lb[u]);
+                const f32x2 pa2[2] = {__builtin_shufflevector(a4, a4, 0, 1), __builtin_shufflevector(a4, a4, 2, 3)};
+                const f32x2 pb2[2] = {__builtin_shufflevector(b4, b4, 0, 1), __builtin_shufflevector(b4, b4, 2, 3)};
+#pragma unroll
+                for (int vp = 0; vp < 2; ++vp)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        // acc.{lo,hi} -= p.{lo,hi} * w[c]  (w[c] = low or high half of its pair, broadcast by op_sel)
+                        if (c & 1) {
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+                                : "+v"(accp[0][vp][c]) : "v"(pa2[vp]), "v"(wp[c >> 1]));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+                                : "+v"(accp[1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
+                        } else {
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+                                : "+v"(accp[0][vp][c]) : "v"(pa2[vp]), "v"(wp[c >> 1]));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+                                : "+v"(accp[1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
+                        }
+                    }
+            } else {
+                T wj[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) wj[c] = wbuf[jj0 + u][c];
+                const T* pa = reinterpret_cast<const T*>(&la[u]);
+                const T* pb = reinterpret_cast<const T*>(&lb[u]);
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        acc[0][v][c] -= pa[v] * wj[c];
+                        acc[1][v][c] -= pb[v] * wj[c];
+                    }
+            }
         }
     };
     auto issue_diag = [&](int J) {      // inv(L_JJ)[di][dh*16 + q], wave 0 only (others, and the zeros above the
@@ -205,7 +251,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                 for (int v = 0; v < V; ++v)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) rbuf[rb * V + v - row0][c] = acc[r][v][c];
+                    for (int c = 0; c < CT; ++c) rbuf[rb * V + v - row0][c] = BCBF_ACC(r, v, c);
             }
         }
         __syncthreads();
