@@ -26,6 +26,9 @@
 #ifndef BCBF_PS_PKASM
 #define BCBF_PS_PKASM 1    // fp32: explicit v_pk_fma_f32 with op_sel broadcast of w (see consume)
 #endif
+#ifndef BCBF_PS_VWPF
+#define BCBF_PS_VWPF 1     // fetch the Vw rows of a block one block ahead
+#endif
 #ifndef BCBF_PS_UNR8_MAXC
 #define BCBF_PS_UNR8_MAXC 3     // C = 4 would spill at 8 columns per stage
 #endif
@@ -239,6 +242,22 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             dval[q] = BufLoad<T>::one(rsrc, voff, lop_dinv_block(J, Np) * (int)sizeof(T));
         }
     };
+#if BCBF_PS_VWPF
+    // whitened targets of the block's 32 rows (lanes 0-31 of wave 0), fetched one block ahead with the same
+    // bounds-checked loads: the diagonal step is the serial part of the block, a global load there is exposed latency
+    const __amdgpu_buffer_rsrc_t rsrc_vw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(Vwb), 0, (int)((size_t)N * n * sizeof(T)), 0x00020000);
+    T vwn[NS];
+    auto issue_vw = [&](int J) {
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            const int row = J * NB + di;
+            const int voff = (tid < 32 && d < n) ? (row * n + d) * (int)sizeof(T) : OOB;      // row >= N: out of range
+            vwn[d] = BufLoad<T>::one(rsrc_vw, voff, 0);
+        }
+    };
+    issue_vw(0);
+#endif
     issue_diag(0);
     if (nblk > 1) issue(la0, lb0, 0, 0);
     for (int J = 0; J < nblk; ++J) {
@@ -279,6 +298,13 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 for (int a = 0; a < CT; ++a)
 #pragma unroll
                     for (int c = a; c < CT; ++c) gram[g++] += w[a] * w[c];
+#if BCBF_PS_VWPF
+#pragma unroll
+                for (int d = 0; d < NS; ++d) {            // Vw rows of this block were fetched a block ahead (zeros
+#pragma unroll                                            // beyond row N and state dimension n)
+                    for (int c = 0; c < CT; ++c) mk[d][c] += vwn[d] * w[c];
+                }
+#else
                 const int row = row0 + di;
                 if (row < N) {
 #pragma unroll
@@ -289,12 +315,16 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                             for (int c = 0; c < CT; ++c) mk[d][c] += vw * w[c];
                         }
                 }
+#endif
             }
         }
         __syncthreads();
         // 3. rows below the block:  r -= L[:, J] w_J   (group 0 of this block is already in flight)
         if (J + 1 < nblk) {
             issue_diag(J + 1);
+#if BCBF_PS_VWPF
+            issue_vw(J + 1);
+#endif
 #pragma unroll 1
             for (int g = 0; g < NGRP; g += 2) {
                 issue(la1, lb1, J, g + 1);
