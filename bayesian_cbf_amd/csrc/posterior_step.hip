@@ -126,27 +126,44 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     T acc[PK ? 1 : 2][PK ? 1 : V][PK ? 1 : CT];
     f32x2 accp[PK ? 2 : 1][PK ? V / 2 : 1][PK ? CT : 1];
 #define BCBF_ACC(r, v, c) (*(PK ? reinterpret_cast<T*>(&accp[r][(v) >> 1][c]) + ((v) & 1) : &acc[PK ? 0 : (r)][PK ? 0 : (v)][PK ? 0 : (c)]))
+    // The training-input loads of a row set (V rows) are issued together, bounds-checked (rows >= N, state dimensions
+    // >= n and idle lanes read zeros without a branch), then the kernel values are formed: one exposed load latency
+    // per row set instead of one per row.
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(Xb), 0, (int)((size_t)N * n * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(UHBb), 0, (int)((size_t)N * C * sizeof(T)), 0x00020000);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int rb = r == 0 ? rbA : rbB;
+        T xv[V][NS], uv[V][C];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const int i = rb * V + v;
-            T k = T(0);
-            if (live && i < N) {
-                T d2 = T(0), dot = T(0);
 #pragma unroll
-                for (int d = 0; d < NS; ++d)
-                    if (d < n) { const T xi = Xb[(size_t)i * n + d]; const T z = (xi - xqr[d]) * iell[d]; d2 += z * z; dot += xi * xqr[d]; }
-                k = s2 * (texp<T>(T(-0.5) * d2) + linv * dot);
+            for (int d = 0; d < NS; ++d)
+                xv[v][d] = BufLoad<T>::one(rsrc_x, (live && d < n) ? (i * n + d) * (int)sizeof(T) : OOB, 0);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                uv[v][c] = BufLoad<T>::one(rsrc_u, live ? (i * C + c) * (int)sizeof(T) : OOB, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            T d2 = T(0), dot = T(0);
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {         // d >= n: xv = xqr = iell = 0
+                const T z = (xv[v][d] - xqr[d]) * iell[d];
+                d2 += z * z;
+                dot += xv[v][d] * xqr[d];
             }
+            const T k = s2 * (texp<T>(T(-0.5) * d2) + linv * dot);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const T ub = (live && i < N) ? UHBb[(size_t)i * C + c] : T(0);
+                const T ub = uv[v][c];                 // 0 for rows >= N and idle lanes: the row contributes nothing
                 BCBF_ACC(r, v, c) = k * ub;
 #pragma unroll
                 for (int d = 0; d < NJ; ++d) {     // d Phi / d x_d = -(x_d - X_id)/ell_d^2 * Phi
-                    const T dz = (live && i < N) ? (Xb[(size_t)i * n + d] - xqr[d]) * iell[d] * iell[d] : T(0);
+                    const T dz = (xv[v][d] - xqr[d]) * iell[d] * iell[d];
                     BCBF_ACC(r, v, (1 + d) * C + c) = dz * k * ub;
                 }
             }
