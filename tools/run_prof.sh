@@ -5,3 +5,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_shared -
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_indep -- python3 bench.py --steps 50 --warmup 5 --cpu-sample 0 > gpurun_out/bench_indep_prof.json 2> gpurun_out/bench_indep_prof.err
 ls -R gpurun_out/prof_shared | head
 tail -c 600 gpurun_out/bench_default.json
+python bench.py --chunks 2 --cpu-sample 0 > gpurun_out/bench_chunks2.json 2>/dev/null
+python bench.py --dtype f64 --cpu-sample 0 > gpurun_out/bench_f64.json 2>/dev/null
