@@ -26,6 +26,9 @@
 #ifndef BCBF_PS_PKASM
 #define BCBF_PS_PKASM 1    // fp32: explicit v_pk_fma_f32 with op_sel broadcast of w (see consume)
 #endif
+#ifndef BCBF_PS_NQ
+#define BCBF_PS_NQ 2       // queries per workgroup of the fp64 shared-GP form (1 = off)
+#endif
 #ifndef BCBF_PS_VWPF
 #define BCBF_PS_VWPF 1     // fetch the Vw rows of a block one block ahead
 #endif
@@ -75,21 +78,30 @@ template <> struct BufLoad<double> {
 // NJ = 0: values only (the control-step kernel).  NJ = n > 0: also the first x-derivative jets --
 // right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] (CT = C (1+n) columns of the same stream); outputs the full
 // Gram Wj'Wj [CT,CT] and Vw'Wj [n,CT], from which the rel-degree-2 terms are formed.
-template <typename T, int C, int NS, int NJ>
+// NQ > 1 (values only, shared GP): one workgroup answers NQ queries with the same stream of L -- NQ C right-hand-side
+// columns -- so the factor crosses the L2 -> CU fabric once per NQ queries (the fp64 form of regime S, which has no
+// matrix-core kernel, is bound by exactly that traffic).
+template <typename T, int C, int NS, int NJ, int NQ = 1>
 __global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256), (NJ > 0 ? 1 : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
                       T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
-                      int n, const T* __restrict__ lin) {
+                      int n, const T* __restrict__ lin, int nq) {
+    static_assert(NQ == 1 || NJ == 0, "several queries per workgroup: values only");
     constexpr int V = Vec<T>::V;
-    constexpr int CT = C * (1 + NJ);     // right-hand-side columns
+    constexpr int CT = C * (1 + NJ) * NQ;     // right-hand-side columns
     using VecT = typename Vec<T>::type;
     constexpr int RPB = NB / V;          // row blocks per diagonal block
     constexpr int CP = (CT + 3) / 4 * 4; // padded RHS count in LDS
-    constexpr int NG = CT * (CT + 1) / 2;
-    auto gidx = [](int a, int c) { return a * CT - a * (a - 1) / 2 + (c - a); };   // (a <= c) in the upper triangle
+    constexpr int CQ = CT / NQ;                                // columns of one query
+    constexpr int NG = NQ * (CQ * (CQ + 1) / 2);               // Gram entries kept: per query, upper triangle
+    // (a <= c, same query) -> slot; with NQ = 1 this is the upper triangle of the full CT x CT Gram
+    auto gidx = [](int a, int c) {
+        const int qi = a / CQ, a_ = a - qi * CQ, c_ = c - qi * CQ;
+        return qi * (CQ * (CQ + 1) / 2) + a_ * CQ - a_ * (a_ - 1) / 2 + (c_ - a_);
+    };
     __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
     __shared__ __attribute__((aligned(16))) T wbuf[NB][CP];
 
@@ -108,10 +120,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const T* __restrict__ Vwb = Vw + (size_t)gb * N * n;
 
     // ---- prologue: r = Phi rows owned by this thread:  phi_i = s2 exp(-1/2 |(x_i - xq)/ell|^2) * UHB_i
-    T xqr[NS], iell[NS];
+    T xqr[NQ][NS], iell[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
-        xqr[d] = d < n ? xq[(size_t)b * n + d] : T(0);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {       // a query slot beyond the last query repeats the last one (not stored)
+            const int qx = NQ == 1 ? b : min(b * NQ + qi, nq - 1);
+            xqr[qi][d] = d < n ? xq[(size_t)qx * n + d] : T(0);
+        }
         iell[d] = d < n ? T(1) / ell[(size_t)gb * n + d] : T(0);
     }
     const T s2 = s2p[gb];
@@ -149,22 +165,25 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            T d2 = T(0), dot = T(0);
 #pragma unroll
-            for (int d = 0; d < NS; ++d) {         // d >= n: xv = xqr = iell = 0
-                const T z = (xv[v][d] - xqr[d]) * iell[d];
-                d2 += z * z;
-                dot += xv[v][d] * xqr[d];
-            }
-            const T k = s2 * (texp<T>(T(-0.5) * d2) + linv * dot);
+            for (int qi = 0; qi < NQ; ++qi) {
+                T d2 = T(0), dot = T(0);
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const T ub = uv[v][c];                 // 0 for rows >= N and idle lanes: the row contributes nothing
-                BCBF_ACC(r, v, c) = k * ub;
+                for (int d = 0; d < NS; ++d) {         // d >= n: xv = xqr = iell = 0
+                    const T z = (xv[v][d] - xqr[qi][d]) * iell[d];
+                    d2 += z * z;
+                    dot += xv[v][d] * xqr[qi][d];
+                }
+                const T k = s2 * (texp<T>(T(-0.5) * d2) + linv * dot);
 #pragma unroll
-                for (int d = 0; d < NJ; ++d) {     // d Phi / d x_d = -(x_d - X_id)/ell_d^2 * Phi
-                    const T dz = (xv[v][d] - xqr[d]) * iell[d] * iell[d];
-                    BCBF_ACC(r, v, (1 + d) * C + c) = dz * k * ub;
+                for (int c = 0; c < C; ++c) {
+                    const T ub = uv[v][c];             // 0 for rows >= N and idle lanes: the row contributes nothing
+                    BCBF_ACC(r, v, qi * C + c) = k * ub;
+#pragma unroll
+                    for (int d = 0; d < NJ; ++d) {     // d Phi / d x_d = -(x_d - X_id)/ell_d^2 * Phi
+                        const T dz = (xv[v][d] - xqr[qi][d]) * iell[d] * iell[d];
+                        BCBF_ACC(r, v, (1 + d) * C + c) = dz * k * ub;
+                    }
                 }
             }
         }
@@ -185,7 +204,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
-    constexpr int UNR = NJ > 0 ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR), NGRP = NB / UNR, HALF = NB / 2;
+    constexpr int UNR = (NJ > 0 || NQ > 1) ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
@@ -308,13 +327,19 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 for (int c = 0; c < CT; ++c) wbuf[di][c] = w[c];
                 if (Wout != nullptr) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) Wout[((size_t)b * Np + row0 + di) * C + c] = w[c];
+                    for (int qi = 0; qi < NQ; ++qi)
+                        if (NQ == 1 || b * NQ + qi < nq) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) Wout[((size_t)(b * NQ + qi) * Np + row0 + di) * C + c] = w[qi * C + c];
+                        }
                 }
                 int g = 0;
 #pragma unroll
-                for (int a = 0; a < CT; ++a)
+                for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-                    for (int c = a; c < CT; ++c) gram[g++] += w[a] * w[c];
+                    for (int a = 0; a < CQ; ++a)
+#pragma unroll
+                        for (int c = a; c < CQ; ++c) gram[g++] += w[qi * CQ + a] * w[qi * CQ + c];
 #if BCBF_PS_VWPF
 #pragma unroll
                 for (int d = 0; d < NS; ++d) {            // Vw rows of this block were fetched a block ahead (zeros
@@ -380,33 +405,38 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     }
             }
             const T* M0b = M0 + (size_t)gb * C * n;
-            T* Mkb = Mk + (size_t)b * n * C;
-#pragma unroll
-            for (int d = 0; d < NS; ++d)
-                if (d < n) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) Mkb[d * C + c] = M0b[c * n + d] + mk[d][c];
-                }
             const T* Bmb = Bm + (size_t)gb * C * C;
-            T* Bkb = Bk + (size_t)b * C * C;
-            double kss = (double)s2;                      // k(xq, xq) = s2 (1 + lin |xq|^2)
-            if (lin != nullptr) {
-                double q2 = 0.0;
 #pragma unroll
-                for (int d = 0; d < NS; ++d) q2 += (double)xqr[d] * (double)xqr[d];
-                kss *= 1.0 + (double)linv * q2;
-            }
+            for (int qi = 0; qi < NQ; ++qi) {
+                const int qx = b * NQ + qi;                      // this slot's query
+                if (NQ > 1 && qx >= nq) break;
+                T* Mkb = Mk + (size_t)qx * n * C;
 #pragma unroll
-            for (int a = 0; a < C; ++a)
+                for (int d = 0; d < NS; ++d)
+                    if (d < n) {
 #pragma unroll
-                for (int c = a; c < C; ++c) {
-                    const double G = gsum[gidx(a, c)];
-                    double v1 = kss * (double)Bmb[a * C + c] - G;
-                    double v2 = kss * (double)Bmb[c * C + a] - G;
-                    if (a == c && jitter2 != nullptr) { v1 += (double)jitter2[(size_t)b * C + a]; v2 = v1; }
-                    Bkb[a * C + c] = (T)v1;
-                    Bkb[c * C + a] = (T)v2;
+                        for (int c = 0; c < C; ++c) Mkb[d * C + c] = M0b[c * n + d] + mk[d][qi * C + c];
+                    }
+                T* Bkb = Bk + (size_t)qx * C * C;
+                double kss = (double)s2;                      // k(xq, xq) = s2 (1 + lin |xq|^2)
+                if (lin != nullptr) {
+                    double q2 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) q2 += (double)xqr[qi][d] * (double)xqr[qi][d];
+                    kss *= 1.0 + (double)linv * q2;
                 }
+#pragma unroll
+                for (int a = 0; a < C; ++a)
+#pragma unroll
+                    for (int c = a; c < C; ++c) {
+                        const double G = gsum[gidx(qi * C + a, qi * C + c)];
+                        double v1 = kss * (double)Bmb[a * C + c] - G;
+                        double v2 = kss * (double)Bmb[c * C + a] - G;
+                        if (a == c && jitter2 != nullptr) { v1 += (double)jitter2[(size_t)qx * C + a]; v2 = v1; }
+                        Bkb[a * C + c] = (T)v1;
+                        Bkb[c * C + a] = (T)v2;
+                    }
+            }
         }
     }
 }
@@ -426,8 +456,8 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (threads > (sizeof(T) == 8 && Gfull == nullptr ? 512 : 256)) return BCBF_EINVAL;   // N <= 2048 (fp64 jets: 1024)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin)
-#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr)
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt)
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
         if (!Mfull || lin) return BCBF_EINVAL;
         if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
@@ -435,6 +465,15 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
         else if (n == 2 && m == 2) BCBF_PJ_LAUNCH(3, 2);
         else if (n == 1 && m == 1) BCBF_PJ_LAUNCH(2, 1);
         else return BCBF_EINVAL;
+    } else if (BCBF_PS_NQ > 1 && shared && sizeof(T) == 8 && n <= 4 && m <= 2 && Bt >= 2 * BCBF_PS_NQ) {
+      if constexpr (sizeof(T) == 8) {
+        // fp64, one model, many queries: BCBF_PS_NQ queries per workgroup share the stream of L
+        const dim3 gridq((Bt + BCBF_PS_NQ - 1) / BCBF_PS_NQ);
+#define BCBF_PQ_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, BCBF_PS_NQ>), gridq, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt)
+        if (m == 1) BCBF_PQ_LAUNCH(2);
+        else BCBF_PQ_LAUNCH(3);
+#undef BCBF_PQ_LAUNCH
+      }
     } else if (n <= 4) {
         switch (m) {
             case 1: BCBF_PS_LAUNCH(2, 4); break;
