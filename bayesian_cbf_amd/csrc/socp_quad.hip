@@ -255,18 +255,41 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
     {
         R cA[C][M_], cb[C], cc[M_], cd;
         if (FROM_TERMS) {
-            const T* Mkb = Mk + (size_t)bb * n * C;
-            const T* Bkb = Bk + (size_t)bb * C * C;
-            const T* Ab = A + (size_t)bb * n * n;
-            const double sg = (double)sign[kk];
             double gd[BCBF_MAX_STATE_DIM];
-            T urow[3], ucst = T(0), uG[3][2];          // UNI: this lane's task row and the prior input matrix
-            if (UNI) {
-                const T px = task.x[(size_t)bb * 3], py = task.x[(size_t)bb * 3 + 1], th = task.x[(size_t)bb * 3 + 2];
-                unicycle_row<T>(kk, px, py, th, task.plan + (size_t)bb * 3, task.dot_plan + (size_t)bb * 3, task.Kp,
-                                task.clf_gamma, task.centers + (size_t)bb * task.Kob * 2, task.radii + (size_t)bb * task.Kob,
-                                task.tw, task.gammas, urow, ucst);
-                ackermann_g<T>(th, task.L_mean, uG);
+            double a_h = 0.0, e = 0.0;
+            double bfe[M_], Asq[C][C], L[C][C];
+            if constexpr (UNI) {
+                // the unicycle step (n = 3, m = 2): every input of this lane is loaded first, unconditionally, so the
+                // prologue pays ONE memory latency (it used to pay one per branch / use: ~20 round trips)
+                static_assert(M_ == 2, "unicycle: two controls");
+                T xs[3], pl[3], dp[3], kp[3], Mkl[9], Bkl[9], Al[9];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    xs[d] = task.x[(size_t)bb * 3 + d];
+                    pl[d] = task.plan[(size_t)bb * 3 + d];
+                    dp[d] = task.dot_plan[(size_t)bb * 3 + d];
+                    kp[d] = task.Kp[d];
+                }
+#pragma unroll
+                for (int a = 0; a < 9; ++a) {
+                    Mkl[a] = Mk[(size_t)bb * 9 + a];
+                    Bkl[a] = Bk[(size_t)bb * 9 + a];
+                    Al[a] = A[(size_t)bb * 9 + a];
+                }
+                const double sg = (double)sign[kk];
+                T cx = T(0), cy = T(0), rad = T(1), gam = T(0), tw0 = T(0), tw1 = T(0);
+                if (task.Kob > 0) {                              // uniform
+                    const int o = min(max(kk - 1, 0), task.Kob - 1);
+                    cx = task.centers[((size_t)bb * task.Kob + o) * 2];
+                    cy = task.centers[((size_t)bb * task.Kob + o) * 2 + 1];
+                    rad = task.radii[(size_t)bb * task.Kob + o];
+                    gam = task.gammas[o];
+                    tw0 = task.tw[0];
+                    tw1 = task.tw[1];
+                }
+                T urow[3], ucst = T(0), uG[3][2];          // this lane's task row and the prior input matrix
+                unicycle_row_vals<T>(kk, xs[0], xs[1], xs[2], pl, dp, kp, task.clf_gamma, cx, cy, rad, tw0, tw1, gam, urow, ucst);
+                ackermann_g<T>(xs[2], task.L_mean, uG);
 #pragma unroll
                 for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gd[d] = d < 3 ? (double)urow[d < 3 ? d : 0] : 0.0;
                 if (inst_ok && active && task.grad != nullptr) {
@@ -279,33 +302,56 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
                             task.ghat[((size_t)b * 3 + d) * 2 + 1] = uG[d][1];
                         }
                 }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int e2 = 0; e2 < 3; ++e2) t += (double)Al[d * 3 + e2] * gd[e2];
+                    a_h += gd[d] * t;
+                }
+                e = (double)ucst;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) e += gd[d] * (double)Mkl[d * 3];
+                e *= sg;
+#pragma unroll
+                for (int i = 0; i < M_; ++i) {
+                    double s_ = 0.0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s_ += ((double)uG[d][i] + (double)Mkl[d * 3 + 1 + i]) * gd[d];
+                    bfe[i] = sg * s_;
+                }
+#pragma unroll
+                for (int a = 0; a < C; ++a)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { Asq[a][c] = a_h * (double)Bkl[a * 3 + c]; L[a][c] = 0.0; }
             } else {
+                const T* Mkb = Mk + (size_t)bb * n * C;
+                const T* Bkb = Bk + (size_t)bb * C * C;
+                const T* Ab = A + (size_t)bb * n * n;
+                const double sg = (double)sign[kk];
                 const T* g = grad + ((size_t)bb * K + kk) * n;
 #pragma unroll
                 for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gd[d] = d < n ? (double)g[d] : 0.0;
-            }
-            double a_h = 0.0;
-            for (int d = 0; d < n; ++d) {
-                double t = 0.0;
-                for (int e2 = 0; e2 < n; ++e2) t += (double)Ab[d * n + e2] * gd[e2];
-                a_h += gd[d] * t;
-            }
-            double e = UNI ? (double)ucst : (double)cst[(size_t)bb * K + kk];
-            for (int d = 0; d < n; ++d) e += gd[d] * ((UNI ? 0.0 : (double)fhat[(size_t)bb * n + d]) + (double)Mkb[d * C]);
-            e *= sg;
-            double bfe[M_], Asq[C][C], L[C][C];
+                for (int d = 0; d < n; ++d) {
+                    double t = 0.0;
+                    for (int e2 = 0; e2 < n; ++e2) t += (double)Ab[d * n + e2] * gd[e2];
+                    a_h += gd[d] * t;
+                }
+                e = (double)cst[(size_t)bb * K + kk];
+                for (int d = 0; d < n; ++d) e += gd[d] * ((double)fhat[(size_t)bb * n + d] + (double)Mkb[d * C]);
+                e *= sg;
 #pragma unroll
-            for (int i = 0; i < M_; ++i) {
-                double s_ = 0.0;
-                for (int d = 0; d < n; ++d)
-                    s_ += ((UNI ? (double)uG[d < 3 ? d : 0][i < 2 ? i : 0] : (double)ghat[((size_t)bb * n + d) * M_ + i]) +
-                           (double)Mkb[d * C + 1 + i]) * gd[d];
-                bfe[i] = sg * s_;
+                for (int i = 0; i < M_; ++i) {
+                    double s_ = 0.0;
+                    for (int d = 0; d < n; ++d)
+                        s_ += ((double)ghat[((size_t)bb * n + d) * M_ + i] + (double)Mkb[d * C + 1 + i]) * gd[d];
+                    bfe[i] = sg * s_;
+                }
+#pragma unroll
+                for (int a = 0; a < C; ++a)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { Asq[a][c] = a_h * (double)Bkb[a * C + c]; L[a][c] = 0.0; }
             }
-#pragma unroll
-            for (int a = 0; a < C; ++a)
-#pragma unroll
-                for (int c = 0; c < C; ++c) { Asq[a][c] = a_h * (double)Bkb[a * C + c]; L[a][c] = 0.0; }
             if (terms_out && inst_ok && active) {
                 T* t = terms_out + ((size_t)b * K + k) * TW;
                 for (int i = 0; i < M_; ++i) t[i] = (T)bfe[i];

@@ -54,6 +54,40 @@ __device__ inline void unicycle_row(int k, T px, T py, T th, const T* __restrict
     }
 }
 
+// The same row from values already in registers (the fused per-step kernel loads every input of an instance up front,
+// one exposed memory latency instead of one per use): cen / rad / gam are those of THIS lane's obstacle.
+template <typename T>
+__device__ inline void unicycle_row_vals(int k, T px, T py, T th, const T (&plan)[3], const T (&dot_plan)[3],
+                                         const T (&Kp)[3], T clf_gamma, T cx, T cy, T rad, T tw0, T tw1, T gam,
+                                         T (&g)[3], T& cst) {
+    if (k == 0) {
+        const T xd = plan[0] - px, yd = plan[1] - py;
+        const T rho2 = xd * xd + yd * yd;
+        const T phi = atan2(yd, xd);
+        const T alpha = normalize_radians(th - phi), beta = normalize_radians(plan[2] - phi);
+        const T k0 = Kp[0], k1 = Kp[1], k2 = Kp[2];
+        const T Vx = T(0.5) * k0 * rho2 + k1 * (T(1) - cos(alpha)) + k2 * (T(1) - cos(beta));
+        const T sa = sin(alpha), sb = sin(beta);
+        g[0] = -k0 * xd - k1 * sa * yd / rho2 - k2 * sb * yd / rho2;
+        g[1] = -k0 * yd + k1 * sa * xd / rho2 + k2 * sb * xd / rho2;
+        g[2] = k1 * sa;
+        const T gg0 = k0 * xd + k1 * sa * yd / rho2 + k2 * sb * yd / rho2;
+        const T gg1 = k0 * yd - k1 * sa * xd / rho2 - k2 * sb * xd / rho2;
+        const T gg2 = k2 * sb;
+        cst = gg0 * dot_plan[0] + gg1 * dot_plan[1] + gg2 * dot_plan[2] + clf_gamma * Vx;
+    } else {
+        const T hx = px - cx, hy = py - cy;
+        const T r2 = hx * hx + hy * hy, rn = sqrt(r2);
+        const T radial = r2 - rad * rad;
+        const T heading = cos(th) * hx / rn + sin(th) * hy / rn;
+        const T al = atan2(hy, hx);
+        g[0] = tw0 * T(2) * hx + tw1 * (sin(al - th) * hy / r2);
+        g[1] = tw0 * T(2) * hy + tw1 * (-sin(al - th) * hx / r2);
+        g[2] = tw1 * (-sin(th - al));
+        cst = gam * (tw0 * radial + tw1 * heading);
+    }
+}
+
 // prior dynamics AckermannDrive(L_mean) (:222-257): f = 0, g = [[cos th, 0], [sin th, 0], [0, 1/L]]
 template <typename T> __device__ inline void ackermann_g(T th, T L, T (&G)[3][2]) {
     G[0][0] = cos(th); G[0][1] = T(0);
