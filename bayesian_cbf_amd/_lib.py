@@ -56,11 +56,29 @@ def declared_symbols():
     return names
 
 
+def _build_if_missing():
+    """A fresh checkout has no libbcbf.so (it is a build artefact): compile it once, under a file lock so that the
+    ranks of a multi-process launch do not race.  No hipcc -> the ImportError below; there is no CPU fallback."""
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB_PATH):
+                from . import build as _build
+                _build.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            "libbcbf.so not found at %s -- build it with `python -m bayesian_cbf_amd.build` "
-            "(hipcc, --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        try:
+            _build_if_missing()
+        except Exception as err:          # noqa: BLE001  (hipcc missing / compile error: report both facts)
+            raise ImportError(
+                "libbcbf.so not found at %s and building it failed (%s) -- build it with "
+                "`python -m bayesian_cbf_amd.build` (hipcc, --offload-arch=gfx950).  There is no CPU fallback."
+                % (LIB_PATH, err))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
