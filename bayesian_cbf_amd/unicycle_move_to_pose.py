@@ -423,3 +423,96 @@ class ControllerCLF(ControllerCLFBayesian):
                 raise ValueError({1: "max_iterations", 2: "infeasible"}.get(int(status[0]), "solver_error"))
             return u[0].to(device=x_torch.device, dtype=x_torch.dtype)
         return u.to(dtype=x_torch.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Entry points of the reference module (unicycle_move_to_pose.py:1689-2013): one closed loop per call, logged in the
+# reference's event-file format and read back by `tblog.playback_logfile` (plots / animation are out of scope).
+def track_trajectory_ackerman_clf_bayesian(x, x_g, dt=None, cbfs=None, cbf_gammas=None, numSteps=None,
+                                           enable_learning=True, mean_dynamics_gen=lambda: AckermannDrive(L=10.0),
+                                           true_dynamics_gen=lambda: AckermannDrive(L=1.0), visualizer_class=None,
+                                           controller_class=None, train_every_n_steps=20, logger=None, device="cuda",
+                                           dtype=torch.float64, learned_dynamics=None, training_iter=100, **kw):
+    """:1689-1733.  Returns (X[numSteps+1,3], U[numSteps,2]); `logger` (a tblog.TBLogger) receives every step."""
+    from . import tblog
+    controller_class = controller_class or ControllerCLFBayesian
+    f = dict(dtype=dtype, device=device)
+    x, x_g = torch.as_tensor(x, **f), torch.as_tensor(x_g, **f)
+    planner = PiecewiseLinearPlanner(x, x_g, numSteps, dt, frac_time_to_reach_goal=0.95)
+    mean_dynamics, plant = mean_dynamics_gen(), true_dynamics_gen()
+    dynamics = (LearnedShiftInvariantDynamics(dt=dt, mean_dynamics=mean_dynamics, enable_learning=True,
+                                              train_every_n_steps=train_every_n_steps, learned_dynamics=learned_dynamics,
+                                              training_iter=training_iter, device=device, dtype=dtype)
+                if enable_learning else None)
+    ctrl = controller_class(planner, coordinate_converter=lambda a, b: a, dynamics=dynamics, mean_dynamics=mean_dynamics,
+                            clf=CLFCartesian(Kp=[0.9, 1.5, 0.0]), cbfs=cbfs(x, x_g), cbf_gammas=list(cbf_gammas),
+                            device=device, dtype=dtype, **kw)
+    rl = tblog.RolloutLogger(planner, dt, logger) if logger is not None else None
+    X = torch.empty(numSteps + 1, 3, **f)
+    U = torch.empty(numSteps, 2, **f)
+    X[0] = x
+    for t in range(numSteps):
+        u = ctrl.control(X[t], t)
+        if rl is not None:
+            rl.setStateCtrl(X[t], u, t)
+        X[t + 1] = X[t] + (plant.f_func(X[t]) + plant.g_func(X[t]) @ u) * dt          # AckermannDrive.step (:277-282)
+        U[t] = u
+    return X, U
+
+
+def unicycle_demo(simulator, exp_tags=(), runs_dir="data/runs", state_start=(-3.0, -1.0, -math.pi / 4),
+                  state_goal=(0.0, 0.0, math.pi / 4), config=None):
+    """:1740-1778: run `simulator(x0, xg, logger=...)` into <runs_dir>/unicycle_move_to_pose_fixed_<tags>_<version>,
+    with its config.json; returns the directory."""
+    from . import tblog
+    logger = tblog.TBLogger(["unicycle_move_to_pose_fixed"] + list(exp_tags), runs_dir=runs_dir)
+    logger.write_config(dict(config or {}, state_start=list(state_start), state_goal=list(state_goal)))
+    simulator(torch.tensor(state_start, dtype=torch.float64), torch.tensor(state_goal, dtype=torch.float64), logger=logger)
+    logger.summary_writer.close()
+    return logger.experiment_logs_dir
+
+
+def _obstacle_recipe(max_risk, exp_tag, **over):
+    cfg = dict(dt=0.001, numSteps=2000, cbf_gammas=[5.0, 5.0], term_weights=[0.7, 0.3], max_risk=max_risk, true_L=12.0,
+               mean_L=1.0, kernel_diag_A=[1e-2, 1e-2, 1e-2], enable_learning=False, train_every_n_steps=20)
+    cfg.update(over)
+
+    def exp(runs_dir="data/runs", **kw):
+        c = dict(cfg, **kw)
+        sim = lambda x, xg, logger: track_trajectory_ackerman_clf_bayesian(
+            x, xg, dt=c["dt"], numSteps=c["numSteps"],
+            cbfs=lambda a, b: obstacles_at_mid_from_start_and_goal(a, b, term_weights=tuple(c["term_weights"])),
+            cbf_gammas=c["cbf_gammas"], enable_learning=c["enable_learning"], train_every_n_steps=c["train_every_n_steps"],
+            mean_dynamics_gen=lambda: AckermannDrive(L=c["mean_L"], kernel_diag_A=c["kernel_diag_A"]),
+            true_dynamics_gen=lambda: AckermannDrive(L=c["true_L"]), max_risk=c["max_risk"], logger=logger,
+            learned_dynamics=c.get("learned_dynamics"), training_iter=c.get("training_iter", 100))
+        return unicycle_demo(sim, exp_tags=[exp_tag], runs_dir=runs_dir,
+                             config={k: v for k, v in c.items() if k != "learned_dynamics"})
+    return exp
+
+
+# :1889-1945  fixed-kernel model, true L = 12 against a mean model with L = 1: the mean-only condition (max_risk 0.5)
+# collides, the Bayesian one (max_risk 0.01) keeps clear
+unicycle_mean_cbf_collides_obstacle_exp = _obstacle_recipe(0.5, "mean_cbf_collides")
+unicycle_bayes_cbf_safe_obstacle_exp = _obstacle_recipe(0.01, "bayes_cbf_safe_obstacle")
+# :1948-2013  learned residual on a deliberately wrong mean model (L = 12 vs 1): with periodic refits the loop passes
+# the obstacles, without (one refit beyond the horizon) it gets stuck
+unicycle_learning_helps_avoid_getting_stuck_exp = _obstacle_recipe(
+    0.01, "learning_helps_avoid_getting_stuck", true_L=1.0, mean_L=12.0, kernel_diag_A=[1.0, 1.0, 1.0],
+    enable_learning=True, train_every_n_steps=400)
+unicycle_no_learning_gets_stuck_exp = _obstacle_recipe(
+    0.01, "no_learning_gets_stuck", true_L=1.0, mean_L=12.0, kernel_diag_A=[1.0, 1.0, 1.0], enable_learning=True,
+    train_every_n_steps=2000)
+
+
+def _with_playback(exp):
+    def run(**kw):
+        from . import tblog
+        return tblog.playback_logfile(exp(**kw))
+    return run
+
+
+unicycle_mean_cbf_collides_obstacle = _with_playback(unicycle_mean_cbf_collides_obstacle_exp)
+unicycle_bayes_cbf_safe_obstacle = _with_playback(unicycle_bayes_cbf_safe_obstacle_exp)
+unicycle_learning_helps_avoid_getting_stuck = _with_playback(unicycle_learning_helps_avoid_getting_stuck_exp)
+unicycle_no_learning_gets_stuck = _with_playback(unicycle_no_learning_gets_stuck_exp)

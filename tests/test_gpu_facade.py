@@ -844,3 +844,29 @@ def test_fixed_kernel_models_lower_onto_the_terms_kernel():
     enc, MXU = CatEncoder.from_data(torch.ones(4, 1), torch.rand(4, 3), torch.rand(4, 3))
     M, X, UH = enc.decode(MXU)
     assert enc.sizes == [1, 3, 3] and M.shape == (4, 1) and X.shape == (4, 3) and torch.equal(enc.encode(M, X, UH), MXU)
+
+
+def test_reference_demo_entry_points(tmp_path):
+    """unicycle_bayes_cbf_safe_obstacle / unicycle_mean_cbf_collides_obstacle / unicycle_learning_helps_avoid_getting_stuck
+    (unicycle_move_to_pose.py:1889-2013) as callable recipes: the two fixed-kernel runs reproduce the first steps of
+    the runs the reference committed (GUROBI), the learning run trains on schedule and stays finite."""
+    from bayesian_cbf_amd import unicycle_move_to_pose as ump
+    for fn, name in ((ump.unicycle_bayes_cbf_safe_obstacle, "saved_run_bayes_cbf_maxrisk0p01"),
+                     (ump.unicycle_mean_cbf_collides_obstacle, "saved_run_mean_cbf_maxrisk0p5")):
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        run = fn(runs_dir=str(tmp_path), numSteps=int(g["numSteps"]), dt=float(g["dt"]))
+        T = 60
+        assert run["config"]["max_risk"] == float(g["max_risk"]) and len(run["steps"]) == int(g["numSteps"])
+        np.testing.assert_allclose(run["uopt"][:T], g["uopt"][:T], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(run["state"][:T], g["state"][:T], rtol=5e-3, atol=5e-3)
+    # the learning recipe: a regressor with a modest prior (the reference starts from gpytorch's random initialisation,
+    # whose prior uncertainty decides whether the first programs are feasible at all), refits every 30 steps
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExact
+    torch.manual_seed(0)
+    np.random.seed(0)
+    reg = ControlAffineRegressorExact(3, 2, device=DEV, dtype=torch.float64)
+    reg.set_kernel_params(A=0.05 * np.eye(3), B=0.05 * np.eye(3), lengthscale=[1.0, 1.0, 1.0], scalefactor=1.0)
+    run = ump.unicycle_learning_helps_avoid_getting_stuck(runs_dir=str(tmp_path), numSteps=90, train_every_n_steps=30,
+                                                          dt=0.01, learned_dynamics=reg, training_iter=10, mean_L=2.0)
+    assert len(run["steps"]) == 90 and np.isfinite(run["state"]).all() and np.isfinite(run["uopt"]).all()
+    assert reg.Xtrain is not None and reg.Xtrain.shape[0] >= 29            # the controller fed the learner and refit
