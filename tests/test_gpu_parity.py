@@ -98,6 +98,8 @@ def test_refit_and_posterior_vs_reference_golden(ops, path, dtype):
     (torch.float32, 100, 3, 2, "dense"),      # ragged N (padding to 128)
     (torch.float32, 1024, 3, 3, "dense"),     # 2 waves per instance, m = 3
     (torch.float64, 96, 1, 1, "dense"),
+    (torch.float32, 200, 6, 2, "dense"),      # state dimension > 4: the NS = 8 instantiations
+    (torch.float64, 130, 5, 3, "dense"),
 ])
 def test_posterior_pipeline_vs_oracle(ops, dtype, N, n, m, variant):
     from bayesian_cbf_amd.synthetic import make_instances
@@ -741,3 +743,34 @@ def test_rbf_plus_linear_data_kernel_entry_points(ops, dtype, tol):
         rel_close(host(Mk[b]), M0[b].T + Vr.T @ Wr, 20 * tol, what="Mk")
         kss = s2[b] * (1 + lin[b] * xq[b] @ xq[b])
         rel_close(host(Bk[b]), kss * Bm[b] - Wr.T @ Wr, 50 * tol, scale=kss * np.abs(Bm[b]).max(), what="Bk")
+
+
+@pytest.mark.parametrize("m", [1, 2])
+def test_fp64_shared_queries_two_per_workgroup(ops, m):
+    """fp64, one model, many queries: the streaming kernel answers two queries per workgroup (odd query count, W output,
+    second jitter).  Checked against the one-query-per-call path of the same kernel and against the oracle."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    N, n, b = 150, 3, 37
+    p = make_instances(1, N, n, m, dtype=torch.float64, device=DEV, seed=5)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert int(info[0]) == 0
+    Vw, alpha = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xq = (2 * torch.rand(b, n, dtype=torch.float64, device=DEV, generator=g) - 1).contiguous()
+    jit2 = (1e-5 * torch.rand(b, 1 + m, dtype=torch.float64, device=DEV, generator=g)).contiguous()
+    Mk, Bk, W = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, jit2, shared=True, want_W=True)
+    for i in (0, 1, 17, 36):                                   # one query per call: the NQ = 1 instantiation
+        Mk1, Bk1, W1 = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq[i:i + 1].contiguous(),
+                                           jit2[i:i + 1].contiguous(), shared=True, want_W=True)
+        rel_close(host(Mk[i]), host(Mk1[0]), 1e-12, scale=1.0, what="Mk vs single")
+        rel_close(host(Bk[i]), host(Bk1[0]), 1e-12, scale=1.0, what="Bk vs single")
+        rel_close(host(W[i]), host(W1[0]), 1e-12, scale=1.0, what="W vs single")
+    h = {k: host(v) for k, v in p.items()}
+    st = ogp.refit_state(h["X"][0], h["U"][0], h["Xdot"][0], h["Bm"][0], h["ell"][0], h["s2"][0], h["M0"][0],
+                         h["jitter"][0][None] / 1e-5)
+    for i in (0, 36):
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][0][None], st["UHB"][None], h["ell"][0][None],
+                                        h["s2"][0][None], h["Bm"][0][None], h["M0"][0][None], host(xq)[i][None],
+                                        jitter2=host(jit2)[i][None])
+        rel_close(host(Mk[i]), Mk_o[0], 1e-8, scale=max(1.0, np.abs(Mk_o).max()), what="Mk vs oracle")
+        rel_close(host(Bk[i]), Bk_o[0], 1e-8, scale=h["s2"][0] * np.abs(h["Bm"][0]).max(), what="Bk vs oracle")
