@@ -43,8 +43,9 @@ def config(Bt, N, n, m, dtype, name):
     print(json.dumps(out))
 
 
+CONFIGS = {"C2": (1024, 256, 2, 1, torch.float64, "C2"), "C3f64": (4096, 512, 3, 2, torch.float64, "C3 in fp64"),
+           "C3": (4096, 512, 3, 2, torch.float32, "C3"), "N1024f64": (1024, 1024, 3, 2, torch.float64, "N=1024 fp64")}
+
 if __name__ == "__main__":
-    config(1024, 256, 2, 1, torch.float64, "C2")
-    config(4096, 512, 3, 2, torch.float64, "C3 in fp64")
-    config(4096, 512, 3, 2, torch.float32, "C3")
-    config(1024, 1024, 3, 2, torch.float64, "N=1024 fp64")
+    for key in (sys.argv[1:] or list(CONFIGS)):          # e.g. `bench_configs.py C2` for a counter pass of one config
+        config(*CONFIGS[key])

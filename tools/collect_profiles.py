@@ -19,7 +19,11 @@ print("default", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["rooflin
 d = json.load(open(R + "profiles/r01_bench_shared.json"))
 print("shared", d["value"], d["batched_steps_per_s"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel_ms"])
 out = {}
-for tag, pat in (("bench_shared", "gpurun_out/pmc_shared/*/*_counter_collection.csv"), ("bench_configs", "gpurun_out/pmc_refit/*/*_counter_collection.csv")):
+for tag, pat in (("bench_shared", "gpurun_out/pmc_shared/*/*_counter_collection.csv"),
+                 ("bench_configs C2", "gpurun_out/pmc_refit_C2/*/*_counter_collection.csv"),
+                 ("bench_configs C3f64", "gpurun_out/pmc_refit_C3f64/*/*_counter_collection.csv"),
+                 ("bench_configs C3", "gpurun_out/pmc_refit_C3/*/*_counter_collection.csv"),
+                 ("bench_configs N1024f64", "gpurun_out/pmc_refit_N1024f64/*/*_counter_collection.csv")):
     if not glob.glob(R + pat):
         continue                       # no fresh counter pass (tools/run_pmc_mfma.sh): keep the committed numbers
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
