@@ -28,7 +28,7 @@ def config(Bt, N, n, m, dtype, name):
     out = {"config": name, "batch": Bt, "N": N, "n": n, "m": m, "dtype": str(dtype)}
     t = timeit(lambda: ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"]))
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
-    assert int((info != 0).sum()) == 0
+    assert int((info != 0).sum()) == 0 or os.environ.get("BCBF_ABLATION"), "Cholesky failed"      # ablation builds factor garbage
     flops = Bt * (N ** 3 / 3.0)
     out["refit_ms"] = t
     out["refit_TFLOPs"] = flops / (t * 1e-3) / 1e12
