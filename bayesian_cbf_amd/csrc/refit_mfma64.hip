@@ -36,6 +36,17 @@ __device__ inline double rlane64(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+// v(lane) + v(lane ^ 32) in every lane, on the VALU: gfx950's v_permlane32_swap hands each lane the low-half and the
+// high-half value of its column (a __shfl_xor would be an LDS round trip, 64 times per diagonal tile)
+__device__ inline double half_sum64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)(b & 0xffffffffLL), hi = (unsigned)(b >> 32);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double a = __builtin_bit_cast(double, ((long long)r1[0] << 32) | (long long)r0[0]);
+    const double c = __builtin_bit_cast(double, ((long long)r1[1] << 32) | (long long)r0[1]);
+    return a + c;
+}
 // 1/sqrt(p): hardware estimate + two Newton steps (full double precision; a divide per pivot would serialise wave 0)
 __device__ inline double rsqrt_nr(double p) {
     double y = __builtin_amdgcn_rsq(p);
@@ -223,11 +234,23 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     const int ln = lane & (NB - 1), lh = lane >> 5;
                     int bad = 0;
 #ifndef BCBF_R64_ABL_NOFACTOR
+                    // Both 32-step loops are FULLY unrolled: with c a compile-time constant every LDS address is a per-lane
+                    // base plus an immediate and no term needs a mask except the last one of an odd c.  Rolled, each
+                    // dot-product term cost ~12 instructions of address arithmetic / selects plus an LDS round trip (a
+                    // per-lane trip count even compiled to one read-wait-multiply per term): 31 k cycles per loop.
+                    const double* rowL = &dS[lh][ln];            // L[ln][lh + 2t]  at  rowL[2t (NB+1)]
+                    const double* colL = &dS[lh][0];             // L[c][lh + 2t]   at  colL[2t (NB+1) + c]
+                    const double* rowX = &dinv[lh][ln];          // X[lh + 2t][ln]  at  rowX[2t (NB+1)]
+#pragma unroll
                     for (int c = 0; c < NB; ++c) {
-                        double v = lh ? 0.0 : dS[c][ln];                                  // S[lane][c]
-#pragma unroll 4
-                        for (int k = lh; k < c; k += 2) v -= dS[k][ln] * dS[k][c];        // L[lane][k] L[c][k]: even k in the
-                        v += __shfl_xor(v, 32, 64);                                       // low half of the wave, odd k in the high
+                        double v = lh ? 0.0 : dS[c][ln], v2 = 0.0;                        // S[lane][c]; two partial sums
+#pragma unroll
+                        for (int t = 0; 2 * t < c; ++t) {                                 // k = 2t + lh: even k in the low half,
+                            const double term = rowL[2 * t * (NB + 1)] * colL[2 * t * (NB + 1) + c];   // odd k in the high
+                            const double tm = (2 * t + 1 < c || !lh) ? term : 0.0;
+                            if (t & 1) v2 -= tm; else v -= tm;
+                        }
+                        v = half_sum64(v + v2);
                         const double piv = rlane64(v, c);
                         if (!(piv > 0.0) && bad == 0) bad = col0 + c + 1;
                         const double inv = rsqrt_nr(piv > 0.0 ? piv : 1.0);
@@ -240,11 +263,16 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     }
                     {
                         const int base = lop_dinv_block(J, Np) + lop_dinv_col(ln);       // lower triangle, packed
+#pragma unroll
                         for (int i = 0; i < NB; ++i) {
-                            double s_ = (ln == i && !lh) ? 1.0 : 0.0;
-#pragma unroll 4
-                            for (int k = lh; k < i; k += 2) s_ -= dS[k][i] * dinv[k][ln]; // L[i][k] X[k][lane]
-                            s_ += __shfl_xor(s_, 32, 64);
+                            double s_ = (ln == i && !lh) ? 1.0 : 0.0, s2 = 0.0;
+#pragma unroll
+                            for (int t = 0; 2 * t < i; ++t) {                             // L[i][k] X[k][lane], k = 2t + lh
+                                const double term = colL[2 * t * (NB + 1) + i] * rowX[2 * t * (NB + 1)];
+                                const double tm = (2 * t + 1 < i || !lh) ? term : 0.0;
+                                if (t & 1) s2 -= tm; else s_ -= tm;
+                            }
+                            s_ = half_sum64(s_ + s2);
                             const double xi = s_ * idg[i];
                             if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                             __builtin_amdgcn_wave_barrier();
