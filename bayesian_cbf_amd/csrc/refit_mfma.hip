@@ -16,6 +16,14 @@
 
 namespace bcbf {
 
+// v(lane) + v(lane ^ 32) in every lane on the VALU (gfx950 v_permlane32_swap; a __shfl_xor is an LDS round trip)
+__device__ inline float half_sum32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+
 using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
 
 constexpr int MT = 256;          // threads
@@ -197,6 +205,52 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                     for (int i = 0; i < NB; ++i) { const float xi = lane == i ? 1.f : 1e-6f * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                 }
 #else
+                if constexpr (NW != 4) {      // few instances in flight: latency of one GP counts; the batch form (NW = 4, 128 VGPRs) would spill
+                // Fully unrolled (see refit_mfma64.hip): constant LDS offsets, the half-wave sums on the VALU
+                // (v_permlane32_swap), two partial sums per dot product.
+                const float* rowL = &dS[lhh][ln];            // L[ln][lhh + 2t]  at  rowL[2t (NB+1)]
+                const float* colL = &dS[lhh][0];             // L[c][lhh + 2t]   at  colL[2t (NB+1) + c]
+                const float* rowX = &dinv[lhh][ln];          // X[lhh + 2t][ln]  at  rowX[2t (NB+1)]
+                constexpr int LDW = sizeof(dS[0]) / sizeof(float);           // row pitch of dS / dinv
+                static_assert(sizeof(dS[0]) == sizeof(dinv[0]), "one pitch for both tiles");
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    float v = lhh ? 0.f : dS[c][ln], v2 = 0.f;                            // S[lane][c]
+#pragma unroll
+                    for (int t = 0; 2 * t < c; ++t) {                                     // k = 2t + lhh
+                        const float term = rowL[2 * t * LDW] * colL[2 * t * LDW + c];     // L[lane][k] L[c][k]
+                        const float tm = (2 * t + 1 < c || !lhh) ? term : 0.f;
+                        if (t & 1) v2 -= tm; else v -= tm;
+                    }
+                    v = half_sum32(v + v2);
+                    const float piv = rlane(v, c);
+                    if (!(piv > 0.f) && bad == 0) bad = col0 + c + 1;
+                    const float inv = __builtin_amdgcn_rsqf(piv > 0.f ? piv : 1.f);      // 1-ulp rsq
+                    if (lane < NB) dS[c][lane] = lane == c ? piv * inv : (lane > c ? v * inv : 0.f);   // L[lane][c]
+                    if (lane == c) idg[c] = inv;
+                    __builtin_amdgcn_wave_barrier();       // other lanes read this column through LDS
+                }
+                if (Ld && lane < NB && col0 + lane < N) {
+                    for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dS[c][lane];
+                }
+                {
+                    const int base = lop_dinv_block(J, Np) + lop_dinv_col(ln);           // lower triangle, packed
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        float s_ = (ln == i && !lhh) ? 1.f : 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int t = 0; 2 * t < i; ++t) {                                 // L[i][k] X[k][lane], k = 2t + lhh
+                            const float term = colL[2 * t * LDW + i] * rowX[2 * t * LDW];
+                            const float tm = (2 * t + 1 < i || !lhh) ? term : 0.f;
+                            if (t & 1) s2 -= tm; else s_ -= tm;
+                        }
+                        s_ = half_sum32(s_ + s2);
+                        const float xi = s_ * idg[i];
+                        if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                } else {
                 for (int c = 0; c < NB; ++c) {
                     float v = lhh ? 0.f : dS[c][ln];                                      // S[lane][c]
 #pragma unroll 4
@@ -223,6 +277,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                         if (lane < NB) { dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                         __builtin_amdgcn_wave_barrier();
                     }
+                }
                 }
 #endif
                 if (lane < LOP_DB - 528) lop[lop_dinv_block(J, Np) + 528 + lane] = 0.f;      // the block's padding
@@ -270,7 +325,7 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = Bt < 128 && N >= 256;   // few instances: 16 waves per workgroup (Bt=1: 392 -> 346 us at N=256, 1.09 -> 0.87 ms at N=512, 3.1 -> 2.1 ms at N=1024)
+    const bool wide = Bt < 128 && N >= 128;   // few instances: 16 waves per workgroup and the unrolled diagonal-tile code (Bt=1: 145 -> 117 us at N=128, 346 -> 273 at 256, 869 -> 725 at 512, 2115 -> 1990 at 1024)
 #define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
     do {                                                                                                \
         if (wide) hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 16>), dim3(Bt), dim3(1024), __VA_ARGS__);              \
