@@ -244,7 +244,8 @@ def lie1_gradient(model, grad_gp, x, eigeps=2e-3):
     Agh = A @ gh
     HAg = Hh @ Agh
     H = (Hh @ A @ Hh) * s00 + torch.outer(HAg, s_i) + torch.outer(s_i, HAg) + (gh @ Agh) * sij
-    w, V = torch.linalg.eigh(0.5 * (H + H.t()))
+    w, V = torch.linalg.eigh((0.5 * (H + H.t())).cpu())          # n x n, n <= 4: host side
+    w, V = w.to(H), V.to(H)
     assert bool((w > -eigeps).all()), " Hessian must be positive definite"
     if bool((w < 0).any()):
         H = (V * w.clamp_min(0.0)) @ V.t()

@@ -277,11 +277,14 @@ class ControlAffineRegressor:
         R = (Y - UH @ hp["M0"]).contiguous()
         Kinv = ops.kb_inverse(Lop, N)
         Ad = hp["A"][0]
-        Ainv = torch.linalg.inv(Ad)
+        # n x n (n <= 8) inverse and log-determinant on the host: not worth pulling the device solver library in
+        Ad_h = Ad.double().cpu()
+        Ainv = torch.linalg.inv(Ad_h).to(Ad)
+        logdetA = float(torch.logdet(Ad_h))
         g_ell, g_s2, g_B, logdetK, RtA, UHtA = ops.mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv[None].contiguous(),
                                                             hp["Bm"], hp["ell"], hp["s2"])
         scale = 1.0 / (N * n)
-        nll = 0.5 * torch.trace(Ainv @ RtA[0]) + 0.5 * n * logdetK[0] + 0.5 * N * torch.logdet(Ad) \
+        nll = 0.5 * torch.trace(Ainv @ RtA[0]) + 0.5 * n * logdetK[0] + 0.5 * N * logdetA \
             + 0.5 * N * n * math.log(2 * math.pi)
         gA = 0.5 * Ainv @ RtA[0] @ Ainv - 0.5 * N * Ainv                           # d log p / dA
         gM0 = UHtA[0] @ Ainv                                                       # d log p / dM0  [C,n]

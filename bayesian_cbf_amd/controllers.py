@@ -84,7 +84,7 @@ class GreedyController(Controller):
             Gx = self.dt * torch.as_tensor(self.model.g_func(x.unsqueeze(0)), **f).squeeze(0)
             Q = lam * R + (1 - lam) * Gx.T @ P @ Gx
             c = (1 - lam) * Gx.T @ P @ (x_g - x - fx)
-            return torch.linalg.solve(Q, c.unsqueeze(-1)).reshape(-1)
+            return torch.linalg.solve(Q.cpu(), c.unsqueeze(-1).cpu()).reshape(-1).to(x)      # m x m, host side
 
 
 class EpsilonGreedyController(ABC):
