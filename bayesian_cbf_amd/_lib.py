@@ -46,6 +46,7 @@ _TSIGS = {
     "bcbf_unicycle_constraints": [P, P, P, P, "T", P, P, P, P, "T", P, P, P, P, c_int, c_int, P],
     "bcbf_unicycle_step": [P, P, "T", "T", c_int, P],
     "bcbf_unicycle_control_step": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "bcbf_unicycle_control_step_2s": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
 }
 
 

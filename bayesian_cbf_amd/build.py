@@ -19,7 +19,7 @@ ARCH = "gfx950"
 SOURCES = ["common.hip", "posterior_step.hip", "posterior_shared.hip", "refit.hip", "refit_mfma.hip", "refit_mfma64.hip", "solve.hip", "mll_grad.hip", "cbc_terms.hip", "controller_cones.hip", "socp.hip", "socp_quad.hip",
            "unicycle.hip", "control_step.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-         "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+         "-I" + CSRC, "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]
 # per-file extras.  posterior_shared: MFMA results are consumed by VALU code every block, so keep the accumulators
 # in VGPRs (no v_accvgpr round trips)
 EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -41,8 +41,8 @@ def _newer(a, bs):
 
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "bcbf_common.h"), os.path.join(ROOT, "include", "bcbf.h"),
-            os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, src), os.path.join(ROOT, "include", "bcbf.h"), os.path.abspath(__file__)]
+    deps += [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]     # every shared header
     if not force and _newer(obj, deps):
         return obj, False
     tuning = os.environ.get("BCBF_EXTRA_HIPCC_FLAGS", "").split()        # e.g. -DBCBF_PS_UNR=2 for tuning sweeps
@@ -59,10 +59,15 @@ def build(force=False, verbose=False):
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in results]
     if force or any(changed for _, changed in results) or not _newer(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        # link to a temporary name and rename: another rank of a multi-process launch never sees a half-written library
+        tmp = "%s.tmp.%d" % (LIB, os.getpid())
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+        os.replace(tmp, LIB)
         if verbose:
             print("built", LIB)
     elif verbose:

@@ -474,10 +474,26 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
         BkXX = (self._prior_knl(Xtest, Xtestp)[:, :, None, None] * B
                 - torch.einsum("bnc,pnd->bpcd", W, Wp))
         # make_psd(BkXX) on the [b(1+m)] x [b'(1+m)] matrix: 1e-5 * rand on its diagonal (:1089, :907-910)
+        # with its retry schedule: x10 until the perturbed matrix factors, RuntimeError after 10 tries (:903-919).
+        # The factorisation is the library's (bcbf_potrf, one instance of size b(1+m) <= 2048; larger query sets keep the
+        # first draw unchecked -- the reference would spend O((b(1+m))^3) there)
         if b == bp:
-            jit = 1e-5 * self.rand_fn(b * C)
             idx = torch.arange(b, device=self.device)
-            BkXX[idx, idx] += torch.diag_embed(jit.reshape(b, C))
+            factor, tries = 1e-5, 10
+            for ntry in range(tries):
+                jit = factor * self.rand_fn(b * C)
+                out = BkXX.clone()
+                out[idx, idx] += torch.diag_embed(jit.reshape(b, C))
+                if b * C > 2048:
+                    break
+                _, info, _ = ops.potrf(out.permute(0, 2, 1, 3).reshape(1, b * C, b * C).contiguous())
+                if int(info[0]) == 0:
+                    break
+                if ntry == tries - 1:
+                    raise RuntimeError("cholesky: posterior block B_k is not positive definite after %d jitter retries "
+                                       "(pivot %d)" % (tries, int(info[0])))
+                factor *= 10
+            BkXX = out
         return Mk, A, BkXX
 
     def custom_predict(self, Xtest_in, Utest_in=None, UHfill=1, Xtestp_in=None, Utestp_in=None, UHfillp=1,

@@ -5,10 +5,9 @@ constraint terms through `cbc2_quadratic_terms` (jet / posterior kernels + close
 `bcbf_controller_cones` and the program through `bcbf_coneqp_f64` -- no cvxpy / cvxopt / GUROBI.  `control(x, t)`
 takes one state like the reference, or a batch x[b, n] (one program per row, one launch per stage).
 
-Not mirrored: LQRController / ILQRController (they import `bdlqr` / `mpc`, absent upstream too), the matplotlib /
-tensorboard plotters (SURVEY 8f #4)."""
-import math
-import random
+Not mirrored (outside the GP / conic-program path): the nominal controllers (Zero / Greedy /
+epsilon-greedy / LQR / ILQR, controllers.py:64-285) and the plotters.  `ControlCBFLearned` keeps the reference's
+`unsafe_controller_class` / `exploration_controller_class` arguments: the caller supplies the nominal controller."""
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -52,56 +51,6 @@ class Controller(ABC):
     @abstractmethod
     def control(self, xi, t=None):
         pass
-
-
-class ZeroController(Controller):
-    def __init__(self, model, Q, R, x_goal, numSteps, dt, ctrl_range):
-        self.u_dim = R.shape[-1]
-
-    def control(self, x, t=None):
-        return x.new_zeros(*x.shape[:-1], self.u_dim)
-
-
-class GreedyController(Controller):
-    """One-step greedy tracking of x_goal (controllers.py:171-213): u = (lam R dt + (1-lam) G'PG)^-1 (1-lam) G'P(x_g - x - f dt),
-    G = g(x) dt, lam = 1/2."""
-
-    def __init__(self, model, Q, R, x_goal, numSteps, dt, ctrl_range):
-        self.x_goal, self.model, self.Q, self.R = x_goal, model, Q, R
-        self.numSteps, self.dt, self.ctrl_range = numSteps, dt, ctrl_range
-
-    def clf(self, x):
-        return (x - self.x_goal) ** 2
-
-    def grad_clf(self, x):
-        return 2 * (x - self.x_goal)
-
-    def control(self, x, t=None):
-        with torch.no_grad():
-            f = dict(dtype=x.dtype, device=x.device)
-            x_g, P, R, lam = self.x_goal.to(**f), self.Q.to(**f), self.R.to(**f) * self.dt, 0.5
-            fx = self.dt * torch.as_tensor(self.model.f_func(x), **f)
-            Gx = self.dt * torch.as_tensor(self.model.g_func(x.unsqueeze(0)), **f).squeeze(0)
-            Q = lam * R + (1 - lam) * Gx.T @ P @ Gx
-            c = (1 - lam) * Gx.T @ P @ (x_g - x - fx)
-            return torch.linalg.solve(Q.cpu(), c.unsqueeze(-1).cpu()).reshape(-1).to(x)      # m x m, host side
-
-
-class EpsilonGreedyController(ABC):
-    """Random action with probability eps(t), linearly annealed over the run (controllers.py:269-285, misc.epsilon)."""
-
-    def __init__(self, base_controller, u_dim, numSteps, egreedy_scheme, ctrl_range):
-        self.base_controller, self.u_dim, self.numSteps = base_controller, u_dim, numSteps
-        self.egreedy_scheme, self.ctrl_range = egreedy_scheme, ctrl_range
-
-    def control(self, x, t=None):
-        min_, max_ = self.ctrl_range
-        e0, e1 = self.egreedy_scheme
-        eps = e0 + (e1 - e0) * min(max((t or 0) / max(self.numSteps, 1), 0.0), 1.0)
-        u0 = self.base_controller.control(x, t=t)
-        randomact = (torch.rand(self.u_dim) * (max_ - min_) + min_).to(u0)
-        u = randomact if random.random() < eps else u0
-        return torch.max(torch.min(u, torch.as_tensor(max_).to(u)), torch.as_tensor(min_).to(u))
 
 
 class _SummedGP(GaussianProcess):
@@ -303,11 +252,15 @@ class SOCPController(Controller):
         q = G.new_zeros(b, nv)
         q[:, 0] = 1.0                                                   # linear objective [1, 0, 0..] (:575)
         y, status, _ = ops.coneqp(G.new_zeros(b, nv, nv), q, G, h, 0, qdims)
-        bad = (status != 0) | (cst != 0).any(dim=1)
+        badcone = (cst != 0).any(dim=1)
+        # solver status, with rows whose stability cone could not be factored reported as BADCONE (3)
+        self.last_status = torch.where(badcone, torch.full_like(status, 3), status)
+        bad = self.last_status != 0
         if single and bool(bad[0]):
-            raise InfeasibleProblemError("Infeasible problem: solver status %d" % int(status[0]))
-        self.last_status = status
-        uopt = y[:, extravars:].to(dtype=xi.dtype, device=xi.device)
+            raise InfeasibleProblemError("Infeasible problem: solver status %d" % int(self.last_status[0]))
+        # a batch cannot raise per row (the reference raises InfeasibleProblemError, optimizers.py:83-89): rows without
+        # a solution return the nominal control and are flagged in last_status, as ControllerCLFBayesian does
+        uopt = torch.where(bad[:, None], ub.to(y), y[:, extravars:]).to(dtype=xi.dtype, device=xi.device)
         return uopt[0] if single else uopt
 
 
@@ -342,7 +295,8 @@ class QPController(Controller):
         if single and int(status[0]) != 0:
             raise InfeasibleProblemError("Infeasible problem: solver status %d" % int(status[0]))
         self.last_status = status
-        uopt = y[:, extravars:].to(dtype=xi.dtype, device=xi.device)
+        bad = status != 0                       # batch: unsolved rows fall back to the nominal control (flagged above)
+        uopt = torch.where(bad[:, None], ub.to(y), y[:, extravars:]).to(dtype=xi.dtype, device=xi.device)
         return uopt[0] if single else uopt
 
 
@@ -353,8 +307,8 @@ class ControlCBFLearned(Controller):
 
     def __init__(self, x_dim=2, u_dim=1, model=None, train_every_n_steps=10, dt=0.001, constraint_plotter_class=None,
                  plots_dir='data/runs/', ctrl_range=(-5., 5.), x_goal=None, x_quad_goal_cost=None, u_quad_cost=None,
-                 numSteps=1000, unsafe_controller_class=GreedyController, cbfs=(), ground_truth_cbfs=(), exp_tags=(),
-                 exploration_controller_class=EpsilonGreedyController, clf_class=None, egreedy_scheme=(1, 0.1),
+                 numSteps=1000, unsafe_controller_class=None, cbfs=(), ground_truth_cbfs=(), exp_tags=(),
+                 exploration_controller_class=None, clf_class=None, egreedy_scheme=(1, 0.1),
                  summary_writer=None, x0=None, ctrl_reg=1., clf_relax_weight=100., enable_learning=False,
                  mean_dynamics_model_class=None, max_train=None, controller_class=QPController, planner_class=None,
                  training_iter=100):
@@ -368,10 +322,15 @@ class ControlCBFLearned(Controller):
         self.net_model = MeanAdjustedModel(x_dim, u_dim, mean_dynamics_model_class, model, max_train=max_train,
                                            train_every_n_steps=train_every_n_steps, enable_learning=enable_learning,
                                            dt=dt, training_iter=training_iter)
-        self.unsafe_controller = exploration_controller_class(
-            unsafe_controller_class(self.net_model, self.x_quad_goal_cost, self.u_quad_cost, self.x_goal, numSteps, dt,
-                                    self.ctrl_range),
-            u_dim, numSteps, egreedy_scheme, self.ctrl_range)
+        if unsafe_controller_class is None:
+            raise TypeError("ControlCBFLearned: pass unsafe_controller_class (the nominal controller whose output the "
+                            "safety filter corrects); the reference's Greedy / ILQR nominal controllers are not part of "
+                            "this library")
+        self.unsafe_controller = unsafe_controller_class(self.net_model, self.x_quad_goal_cost, self.u_quad_cost,
+                                                         self.x_goal, numSteps, dt, self.ctrl_range)
+        if exploration_controller_class is not None:      # e.g. an epsilon-greedy wrapper (controllers.py:269-285)
+            self.unsafe_controller = exploration_controller_class(self.unsafe_controller, u_dim, numSteps,
+                                                                  egreedy_scheme, self.ctrl_range)
         self.cbfs, self.ground_truth_cbfs = list(cbfs), list(ground_truth_cbfs)
         if clf_class is None:          # the reference calls None(...) here (:722): unconstructible upstream; allow no CLF
             self.clf = None
@@ -385,26 +344,3 @@ class ControlCBFLearned(Controller):
         uopt = self._controller.control(xi, t=t)
         self.net_model.train(xi, uopt)
         return uopt
-
-
-class NamedAffineFunc(ABC):
-    """A(x) u - b(x) with a name for plots (controllers.py:739-771)."""
-
-    @property
-    def __name__(self):
-        return self.name
-
-    @abstractmethod
-    def value(self, x):
-        pass
-
-    @abstractmethod
-    def b(self, x):
-        pass
-
-    @abstractmethod
-    def A(self, x):
-        pass
-
-    def __call__(self, x, u):
-        return self.A(x) @ u - self.b(x)

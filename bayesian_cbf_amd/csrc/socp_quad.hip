@@ -22,13 +22,6 @@ template <> struct QTol<double> {
     static __device__ inline double accept() { return 1e-7; }
     static __device__ inline double infeas() { return 1e-8; }
 };
-template <> struct QTol<float> {
-    static __device__ inline float feas() { return 2e-5f; }
-    static __device__ inline float gap() { return 1e-6f; }
-    static __device__ inline float accept() { return 2e-4f; }
-    static __device__ inline float infeas() { return 1e-5f; }
-};
-
 __device__ inline float qdv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ inline double qdv(double a, double b) { return a / b; }
 __device__ inline float qsq(float a) { return __builtin_amdgcn_sqrtf(a); }
@@ -237,7 +230,11 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
                  T* __restrict__ terms_out, T* __restrict__ cones_out, int* __restrict__ cstatus,
                  T* __restrict__ y, int* __restrict__ status, int* __restrict__ iters, int Bt, int K, int max_iters,
                  UnicycleTask<T> task) {
-    using R = T;
+    // The interior-point iterates are fp64 for BOTH entry-point precisions (T is the I/O type): with fp32 iterates the
+    // rounding floor of the scaled residuals left ~0.1 % of near-degenerate programs 2e-3 away from the optimum, above
+    // the 1e-3 the fp32 path has to hold.  The kernel is latency bound on one wave per CU either way (47 -> 65 us per
+    // 4096 programs) and runs beside the posterior stream of the other half batch in the pipelined step.
+    using R = double;
     constexpr int NV = M_ + 1, D = M_ + 2, C = M_ + 1;
     constexpr int Q = (M_ + 1) * M_ + (M_ + 1) + M_ + 1;
     constexpr int TW = M_ + 1 + M_ * M_ + M_ + 1;
@@ -658,10 +655,10 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
         for (int i = 0; i < NV; ++i) y[(size_t)b * NV + i] = (T)x[i];
         status[b] = st_code;
         if (iters) iters[b] = it;
-        if (UNI && task.dt > T(0)) {             // plant step with y = [u0, u1, relax] as stored (rounded to T), whatever
-            T* xs = task.x + (size_t)b * 3;      // the status: a caller that wants unsolved instances masked passes dt = 0
-            const T th = xs[2], u0 = (T)x[0], u1 = (T)x[1];   // and applies bcbf_unicycle_step to the controls it accepts
-            xs[0] += cos(th) * u0 * task.dt;
+        if (UNI && task.dt > T(0) && st_code == BCBF_SOCP_OPTIMAL) {   // plant step with y = [u0, u1, relax] as stored
+            T* xs = task.x + (size_t)b * 3;      // (rounded to T).  An instance whose program was not solved keeps its state:
+            const T th = xs[2], u0 = (T)x[0], u1 = (T)x[1];   // the reference raises there (unicycle_move_to_pose.py:954-964),
+            xs[0] += cos(th) * u0 * task.dt;                  // a batch freezes the instance and reports it in status[]
             xs[1] += sin(th) * u0 * task.dt;
             xs[2] += u1 / task.L_true * task.dt;
         }

@@ -208,16 +208,16 @@ struct AppendFused {
 
 template <typename T, bool FUSED>
 __global__ void __launch_bounds__(ST)
-chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const T* __restrict__ kappa,
-                   T* __restrict__ Lout, int* __restrict__ info, int N, int NpI, int NpO, AppendFused<T> f) {
+chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict__ kappa,
+                   T* Lout, int* __restrict__ info, int N, int NpI, int NpO, AppendFused<T> f) {   // Lout may alias Lin
     constexpr int V = Vec<T>::V;
     __shared__ T rbuf[NB];
     __shared__ T wbuf[NB];
     __shared__ T lrow[ST * SMAXR];      // l, all rows
     __shared__ T scratch[4 * SC];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const T* __restrict__ lin = Lin + (size_t)b * lop_elems<V>(NpI);
-    T* __restrict__ lout = Lout + (size_t)b * lop_elems<V>(NpO);
+    const T* lin = Lin + (size_t)b * lop_elems<V>(NpI);
+    T* lout = Lout + (size_t)b * lop_elems<V>(NpO);
     const int rpt = (NpI + ST - 1) / ST;
     const int nblk = NpI / NB;
 
@@ -335,10 +335,12 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
     }
     __threadfence_block();
     __syncthreads();
-    // ---- the new row N
+    // ---- the new row N.  A non-positive pivot (info = N+1) writes nothing: row N stays the identity padding row it
+    // was (in place) or has just become (re-packed), so the operator still describes the old N points exactly and
+    // the caller can retry with a larger jitter (make_psd's schedule, control_affine_model.py:905-919)
     const int Js = N / NB, col0 = Js * NB, rr = N - col0;
-    for (int j = tid; j < col0; j += ST) lout[lop_base<V>(j, NpO) + N] = lrow[j];
-    if (tid <= rr) {
+    if (ok) for (int j = tid; j < col0; j += ST) lout[lop_base<V>(j, NpO) + N] = lrow[j];
+    if (ok && tid <= rr) {
         const int jj = tid;          // column inside the diagonal block
         T val;
         if (jj == rr) val = T(1) / d;
@@ -366,13 +368,13 @@ chol_append_kernel(const T* __restrict__ Lin, const T* __restrict__ knew, const 
         if (tid < n) {
             T yv = f.xdot_new[(size_t)b * n + tid];
             for (int a = 0; a < C; ++a) yv -= f.uh_new[(size_t)b * C + a] * f.M0[((size_t)b * C + a) * n + tid];
-            f.Vw_out[((size_t)b * N1 + N) * n + tid] = (yv - vs[tid]) / d;
+            f.Vw_out[((size_t)b * N1 + N) * n + tid] = ok ? (yv - vs[tid]) / d : T(0);   // !ok: a neutral row
             f.X_out[((size_t)b * N1 + N) * n + tid] = f.x_new[(size_t)b * n + tid];
         }
         if (tid < C) {
             T sacc = T(0);
             for (int a = 0; a < C; ++a) sacc += f.uh_new[(size_t)b * C + a] * f.Bm[((size_t)b * C + a) * C + tid];
-            f.UHB_out[((size_t)b * N1 + N) * C + tid] = sacc;
+            f.UHB_out[((size_t)b * N1 + N) * C + tid] = ok ? sacc : T(0);     // !ok: Phi row 0 -> the point has no effect
         }
         // re-pack the per-refit arrays (batch stride N -> N+1)
         for (int e = tid; e < N * n; e += ST) {

@@ -451,15 +451,18 @@ def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_g
     return unicycle_control_step_prepare(gp, task, ws, x, dt, L_true, L_mean, clf_gamma, max_iters)(ev_start, ev_stop)
 
 
-def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100):
+def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,
+                                  two_stream=None):
     """Bind every argument of `unicycle_control_step` once and return `step(ev_start=None, ev_stop=None)`.
     A closed loop calls the same entry point with the same buffers thousands of times; converting ~40 tensors to
     pointers per call costs more host time than the two launches take on the device for small batches.  The tensors
-    must keep their storage (update them in place); the closure keeps them alive."""
+    must keep their storage (update them in place); the closure keeps them alive.
+    two_stream = (stream_post, stream_solve, ev_post, ev_state) (torch streams / events): the two-stream form
+    `bcbf_unicycle_control_step_2s` -- see `PipelinedControlLoop`."""
     gp, A, N, shared = _control_step_args(gp, task, ws, x)
     Bt = x.shape[0]
     Kob = task["centers"].shape[1]
-    fn = getattr(lib, "bcbf_unicycle_control_step" + _suf(x))
+    fn = getattr(lib, "bcbf_unicycle_control_step" + ("_2s" if two_stream is not None else "") + _suf(x))
     head = (_p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
             _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
             _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
@@ -468,6 +471,25 @@ def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.
             _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, 1 if shared else 0)
     keep = (dict(gp), dict(task), dict(ws), x, A)      # the pointers above are only valid while these live
     dev, y = x.device, ws["y"]
+
+    if two_stream is not None:
+        s_post, s_solve, e_post, e_state = two_stream
+        for e in (e_post, e_state):          # torch creates the hipEvent on first record: make the handles exist
+            if not e.cuda_event:
+                e.record(s_solve)
+        tail = (ctypes.c_void_p(s_post.cuda_stream), ctypes.c_void_p(e_post.cuda_event),
+                ctypes.c_void_p(e_state.cuda_event), ctypes.c_void_p(s_solve.cuda_stream))
+        keep = keep + (two_stream,)
+
+        def step(ev_start=None, ev_stop=None):
+            ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
+            ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
+            rc = fn(*head, ev0, ev1, *tail)
+            if rc:
+                check(rc, "bcbf_unicycle_control_step_2s")
+            return y
+        step.keep = keep
+        return step
 
     def step(ev_start=None, ev_stop=None):
         ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
@@ -478,6 +500,60 @@ def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.
         return y
     step.keep = keep
     return step
+
+
+class PipelinedControlLoop:
+    """The unicycle control step for a batch split into `parts` part batches on two kinds of HIP streams
+    (`bcbf_unicycle_control_step_2s`): ONE posterior stream runs the parts' posterior kernels back to back (the HBM-bound
+    stream never idles), each part's solve launch (task rows + terms + SOCP + plant step: latency bound, one wave per CU)
+    runs on the part's own solve stream beside the other parts' posterior kernels.  Instances never interact (SURVEY
+    8e), so this is the same computation as `unicycle_control_step` on the whole batch -- every instance takes one
+    control step per `step()` -- with the serialized solve launch (15 % of a single-stream step at the BASELINE config)
+    hidden.  gp / task tensors with a leading axis of Bt are sliced per part; `x` [Bt,3] is advanced in place.
+
+    step(events=None): events = [(ev_start, ev_stop)] per part brackets that part's posterior kernel.
+    Results: `y`, `status`, `iters` (views into one [Bt,...] buffer each); call `synchronize()` before reading."""
+
+    def __init__(self, gp, task, x, parts=2, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100):
+        Bt = x.shape[0]
+        if Bt % parts:
+            raise ValueError("batch %d is not divisible into %d parts" % (Bt, parts))
+        dev, Bc = x.device, Bt // parts
+        self.parts, self.x, self.device = parts, x, dev
+        Kob = task["centers"].shape[1]
+        self.ws = control_workspace(Bt, Kob, x.dtype, dev)
+        self.y, self.status, self.iters = self.ws["y"], self.ws["status"], self.ws["iters"]
+        self.stream_post = torch.cuda.Stream(device=dev)
+        self.streams_solve = [torch.cuda.Stream(device=dev) for _ in range(parts)]
+        self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(parts)]
+        self._steps = []
+        shared_model = gp.get("Lop") is not None and gp["X"].shape[0] == 1 and Bt > 1
+        for c in range(parts):
+            sl = slice(c * Bc, (c + 1) * Bc)
+            cut = lambda v, lead: v[sl] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == lead) else v
+            gpc = {k: (v if (shared_model and k != "A") else cut(v, Bt)) for k, v in gp.items()}
+            taskc = {k: cut(v, Bt) for k, v in task.items()}
+            wsc = {k: v[sl] for k, v in self.ws.items()}
+            self._steps.append(unicycle_control_step_prepare(
+                gpc, taskc, wsc, x[sl], dt=dt, L_true=L_true, L_mean=L_mean, clf_gamma=clf_gamma, max_iters=max_iters,
+                two_stream=(self.stream_post, self.streams_solve[c]) + self._events[c]))
+        # whatever produced the inputs on the current stream happens before the first step
+        cur = torch.cuda.current_stream(dev)
+        self.stream_post.wait_stream(cur)
+        for s in self.streams_solve:
+            s.wait_stream(cur)
+
+    def step(self, events=None):
+        for c, st in enumerate(self._steps):
+            if events is None:
+                st()
+            else:
+                st(events[c][0], events[c][1])
+
+    def synchronize(self):
+        self.stream_post.synchronize()
+        for s in self.streams_solve:
+            s.synchronize()
 
 
 def control_workspace(Bt, Kob, dtype, device, n=3, m=2):

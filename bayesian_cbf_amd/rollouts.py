@@ -82,9 +82,15 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
             task["dot_plan"].copy_(dplan_all[t])
         step()       # one host call, two launches (one for the fixed-kernel model): rows -> terms -> SOCP -> plant step
         # safety bookkeeping: h_k(x_t) = cst_k / gamma_k for the obstacle rows (before the step)
-        torch.minimum(min_h, (ws["cst"][:, 1:] * igam).amin(dim=1), out=min_h)
-        cost.add_((w_cost * ws["y"] * ws["y"]).sum(dim=1))
-        fails.add_(ws["status"] != 0)
+        # (a non-finite h counts as a collision: NaN -> -inf, so it can never pass for "collision-free")
+        h_now = torch.nan_to_num((ws["cst"][:, 1:] * igam).amin(dim=1), nan=-math.inf)
+        torch.minimum(min_h, h_now, out=min_h)
+        solved = ws["status"] == 0
+        # an unsolved program (MAXITER / infeasible / bad cone) is where the reference raises ValueError
+        # (unicycle_move_to_pose.py:954-964): the kernel leaves that instance's state untouched for the step, its
+        # y is not a control and does not enter the cost, and the trajectory is reported in stats['solver_failures']
+        cost.add_(torch.where(solved, (w_cost * ws["y"] * ws["y"]).sum(dim=1), torch.zeros_like(cost)))
+        fails.add_(~solved)
 
     torch.cuda.synchronize(dev)
     graph = None
@@ -116,7 +122,7 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
             traj[t + 1] = x
     torch.cuda.synchronize(dev)
     t_loop = time.perf_counter() - t_loop
-    collided = (min_h < 0)
+    collided = ~(min_h >= 0)                       # NaN-safe: anything that is not provably >= 0 is a collision
     stats = reduce_rollout_stats(collided.sum(), min_h.min(), cost.sum() / numSteps, (fails > 0).sum(), Bt)
     dist_to_goal = (x[:, :2] - xg[:2]).norm(dim=1)
     return dict(stats=stats, x_final=x, min_h=min_h, dist_to_goal=dist_to_goal, traj=traj, loop_seconds=t_loop)

@@ -75,8 +75,8 @@ def _fixed_kernel_gp(model, u, name):
     return GaussianProcess(mean=mean, knl=knl, shape=(model.state_size,), name=name, source=(model, "fu", u))
 
 
-class PolarDynamics:
-    """unicycle_move_to_pose.py:142-165 (rho, alpha, beta) kinematics."""
+class CartesianDynamics:
+    """Unit-wheelbase unicycle with the kernel (u'u + 1) I (:168-197)."""
     state_size, ctrl_size = 3, 2
 
     def __init__(self):
@@ -88,29 +88,18 @@ class PolarDynamics:
     def f_func(self, x):
         return torch.zeros_like(x)
 
-    def g_func(self, x):
-        rho, alpha, beta = x
-        assert rho > 1e-6
-        z, o = torch.zeros_like(rho), torch.ones_like(rho)
-        return torch.stack([torch.stack([-torch.cos(alpha), z]), torch.stack([-torch.sin(alpha) / rho, o]),
-                            torch.stack([-torch.sin(alpha) / rho, z])])
-
-    def step(self, u_torch, dt):
-        x = self.current_state
-        xdot = self.f_func(x) + self.g_func(x) @ u_torch
-        self.current_state = x + xdot * dt
-        return dict(xdot=xdot, x=self.current_state)
-
-
-class CartesianDynamics(PolarDynamics):
-    """Unit-wheelbase unicycle with the kernel (u'u + 1) I (:168-197)."""
-
     def g_func(self, state_in):
         state = state_in.unsqueeze(0) if state_in.dim() <= 1 else state_in
         th = state[..., 2]
         z, o = torch.zeros_like(th), torch.ones_like(th)
         gX = torch.stack([torch.stack([th.cos(), z], -1), torch.stack([th.sin(), z], -1), torch.stack([z, o], -1)], -2)
         return gX.squeeze(0) if state_in.dim() <= 1 else gX
+
+    def step(self, u_torch, dt):
+        x = self.current_state
+        xdot = self.f_func(x) + self.g_func(x) @ u_torch
+        self.current_state = x + xdot * dt
+        return dict(xdot=xdot, x=self.current_state)
 
     def fixed_kernel(self):
         return torch.eye(self.state_size, dtype=torch.float64), torch.eye(self.ctrl_size + 1, dtype=torch.float64)
@@ -295,10 +284,13 @@ class ControllerCLFBayesian:
         plan = plan.expand(Bt, 3).contiguous() if plan.dim() == 1 else plan.contiguous()
         dplan = dplan.expand(Bt, 3).contiguous() if dplan.dim() == 1 else dplan.contiguous()
         Kob = len(self.cbfs)
-        centers = torch.stack([c.center.to(**f).expand(Bt, 2) if c.center.dim() == 1 else c.center.to(**f)
-                               for c in self.cbfs], dim=1).contiguous()
-        radii = torch.stack([c.radius.to(**f).expand(Bt) if c.radius.dim() == 0 else c.radius.to(**f)
-                             for c in self.cbfs], dim=1).contiguous()
+        if Kob:
+            centers = torch.stack([c.center.to(**f).expand(Bt, 2) if c.center.dim() == 1 else c.center.to(**f)
+                                   for c in self.cbfs], dim=1).contiguous()
+            radii = torch.stack([c.radius.to(**f).expand(Bt) if c.radius.dim() == 0 else c.radius.to(**f)
+                                 for c in self.cbfs], dim=1).contiguous()
+        else:       # the reference's default cbfs=[] (:811): a pure CLF controller, the kernels take Kob = 0
+            centers, radii = torch.empty(Bt, 0, 2, **f), torch.empty(Bt, 0, **f)
         tw = torch.tensor(self.cbfs[0].term_weights if Kob else (0.5, 0.5), **f)
         return dict(plan=plan, dot_plan=dplan, Kp=self.clf.Kp.to(**f), centers=centers, radii=radii, tw=tw,
                     gammas=torch.tensor(list(self.cbf_gammas), **f),

@@ -3,7 +3,7 @@
 
 Workload = BASELINE.json configs[2]: unicycle (x in R^3, u in R^2), N_train = 512,
 batch = 4096 independent control-loop instances per GPU (regime I: every instance owns its GP),
-fp32.  One "step" = one pass of the hot path over the batch:
+fp32.  One "step" = one pass of the hot path over the batch (every instance takes one control step):
     unicycle_constraints -> posterior_step -> cbc_terms -> socp -> plant Euler step
 with all inputs resident in HBM.  Multi-GPU = more instances (weak scaling), one process per GPU,
 no collective inside the loop, one RCCL all-reduce of a small statistics vector at the end.
@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--variant", default="dense")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
-    ap.add_argument("--chunks", type=int, default=1, help="independent sub-batches, one HIP stream each")
+    ap.add_argument("--parts", type=int, default=2,
+                    help="part batches of the pipelined step (ops.PipelinedControlLoop): posterior kernels back to back on "
+                         "one stream, each part's solve launch beside the other parts' posterior kernels; 1 = the whole "
+                         "batch on one stream, posterior then solve (the round-1 schedule)")
     ap.add_argument("--regime", choices=["independent", "shared"], default="independent",
                     help="independent: every instance owns its GP (headline, HBM bound); shared: one learned model, "
                          "`batch` closed loops (Monte-Carlo rollouts, BASELINE configs[3]; matrix-core bound)")
@@ -54,7 +57,7 @@ def measured_traffic(N, Bt, dtype_name, bytes_launch):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied).  A counter run cannot
     be nested inside this process, so the number is attached only when the profiled workload is this workload."""
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         try:
             d = json.load(open(path))
@@ -63,7 +66,8 @@ def measured_traffic(N, Bt, dtype_name, bytes_launch):
         w = d.get("workload", {})
         if w.get("N_train") == N and w.get("dtype") == dtype_name and w.get("batch"):
             best = d["hbm_bytes_per_launch"] * (Bt / float(w["batch"]))    # per-instance traffic is batch independent
-    return best
+            src = "%s (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run)" % os.path.relpath(path, ROOT)
+    return best, src
 
 
 def algorithmic_bytes_per_instance(N, n, m, itemsize):
@@ -71,50 +75,104 @@ def algorithmic_bytes_per_instance(N, n, m, itemsize):
     return itemsize * (N * (N + 1) // 2 + N * n + N * n + N * (1 + m))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(p, task, sample, N, n, m):
-    """The oracle (a numpy port of the reference's arithmetic, reference-style: one instance at a
-    time, Cholesky cached) timed on this host for `sample` instances of the same workload."""
-    import scipy.linalg as sla
-    from oracle import gp_posterior as ogp, cbc as ocbc, socp as osocp, unicycle as ouni
-    h = {k: v[:sample].double().cpu().numpy() for k, v in {**p, **task}.items() if v.dim() > 0 and v.shape[0] >= sample}
-    sign, relax_mask = task["sign"].double().cpu().numpy(), task["relax_mask"].double().cpu().numpy()
-    Kp, tw, gammas = (task[k].double().cpu().numpy() for k in ("Kp", "tw", "gammas"))
-    states = []
-    for i in range(sample):     # refit state: not timed (cached in the reference between refits)
-        states.append(ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i],
-                                      h["M0"][i], h["jitter"][i][None] / 1e-5))
-    clf = ouni.CLFCartesian(Kp)
+    """The oracle (a numpy / torch-CPU port of the reference's arithmetic, Cholesky factor cached as the reference caches
+    it between refits) timed on this host on a bounded sample of the same workload, three ways:
+    (a) reference style, one instance at a time, one thread; (b) vectorised over the batch, one thread; (c) vectorised,
+    every hardware thread.  `value` is the fastest of them, `cores` the threads it used."""
     from threadpoolctl import threadpool_limits
-    limiter = threadpool_limits(limits=1)          # a scalar, single-thread port: cores = 1
-    t0 = time.perf_counter()
-    nopt = 0
-    for i in range(sample):
-        st = states[i]
-        x = h["x"][i]
-        Mk, Bk = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None],
-                                    h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], x[None])
-        fhat, ghat = ouni.ackermann_f(x), ouni.ackermann_g(x, 4.0)
-        plan, dplan = h["plan"][i], h["dot_plan"][i]
-        const = clf.grad_clf_wrt_goal(x, plan) @ dplan + 10.0 * clf.clf(x, plan)
-        terms = [ocbc.reldeg1_terms(Mk[0], Bk[0], h["A"][i], clf.grad_clf(x, plan), const, fhat, ghat, sign=-1.0)]
-        for k in range(2):
-            ob = ouni.ObstacleCBF(h["centers"][i, k], h["radii"][i, k], tuple(tw))
-            terms.append(ocbc.reldeg1_terms(Mk[0], Bk[0], h["A"][i], ob.grad_cbf(x), gammas[k] * ob.cbf(x), fhat, ghat))
-        cones = [ocbc.convert_cbc_terms_to_socp_terms(*tm, 0) for tm in terms]
-        sol = osocp.clf_cbf_socp(h["w"][i], h["r"][i], cones, h["rho"][i], relax_mask)
-        nopt += sol["status"] == "optimal"
-    el = time.perf_counter() - t0
-    limiter.restore_original_limits()
-    return dict(value=sample / el, unit="control steps/s (instance-steps)", cores=1,
-                kind="port",
-                sample="%d instances of the same N=%d,n=%d,m=%d workload, one at a time, factor cached "
-                       "(numpy/scipy oracle, BLAS limited to 1 thread: triangular solve + closed-form terms + coneqp), %.1f s; "
-                       "host has %d hardware threads" % (sample, N, n, m, el, os.cpu_count()))
+    from oracle import batched as ob, control_step as ostep, gp_posterior as ogp
+    L_mean = 4.0
+    take = lambda v, k: v[:k] if (v.dim() > 0 and v.shape[0] >= k and v.shape[0] == p["X"].shape[0]) else v
+    variants = []
+
+    # ---- (a) scalar loop, 1 thread
+    sa = min(sample, 2048)
+    h = {k: take(v, sa).double().cpu().numpy() for k, v in {**p, **task}.items()}
+    states = [ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                              h["jitter"][i][None] / 1e-5) for i in range(sa)]      # refit: not timed (cached upstream)
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        for i in range(sa):
+            st = states[i]
+            Mk, Bk = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None],
+                                        h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None],
+                                        h["x"][i][None])
+            ostep.control_step(h["x"][i], h["plan"][i], h["dot_plan"][i], Mk[0], Bk[0], h["A"][i], h["Kp"], 10.0,
+                               h["centers"][i], h["radii"][i], h["tw"], h["gammas"], L_mean, h["w"][i], h["r"][i],
+                               h["rho"][i], h["relax_mask"])
+        el = time.perf_counter() - t0
+    variants.append(dict(name="scalar loop (reference style: one instance per call)", cores=1, value=sa / el,
+                         instances=sa, seconds=el))
+    del states
+
+    # ---- (b), (c) vectorised over the batch (torch CPU: batched triangular solve + the batched cone solver)
+    sv = min(sample, 1024)
+    q = {k: take(v, sv).double().cpu() for k, v in {**p, **task}.items()}
+    Ls, Vws, UHBs = [], [], []
+    for c0 in range(0, sv, 128):                                # refit in slices: not timed
+        sl = slice(c0, min(c0 + 128, sv))
+        L_, Vw_, UHB_ = ob.refit(q["X"][sl], q["UH"][sl], q["Xdot"][sl], q["Bm"][sl], q["ell"][sl], q["s2"][sl],
+                                 q["M0"][sl], q["jitter"][sl])
+        Ls.append(L_); Vws.append(Vw_); UHBs.append(UHB_)
+    L_, Vw_, UHB_ = torch.cat(Ls), torch.cat(Vws), torch.cat(UHBs)
+    del Ls, Vws, UHBs
+    ncpu = os.cpu_count() or 1
+    for threads in (1, ncpu):
+        torch.set_num_threads(threads)
+        reps = 1 if threads == 1 else 3
+        with threadpool_limits(limits=threads):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ob.control_step(L_, Vw_, q["X"], UHB_, q["ell"], q["s2"], q["Bm"], q["M0"], q["A"], q["x"], q["plan"],
+                                q["dot_plan"], q["Kp"], 10.0, q["centers"], q["radii"], q["tw"], q["gammas"], L_mean,
+                                q["w"], q["r"], q["rho"], q["relax_mask"])
+            el = (time.perf_counter() - t0) / reps
+        variants.append(dict(name="vectorised over the batch (torch CPU)", cores=threads, value=sv / el, instances=sv,
+                             seconds=el))
+    best = max(variants, key=lambda v: v["value"])
+    return dict(value=best["value"], unit="control steps/s (instance-steps)", cores=best["cores"], kind="port",
+                sample="%s; %d instances of the same N=%d,n=%d,m=%d workload per pass, factor cached; fp64; "
+                       "host: %s, %d hardware threads" % (best["name"], best["instances"], N, n, m, cpu_model(), ncpu),
+                cpu_model=cpu_model(), host_threads=ncpu, variants=variants)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) under torch.distributed.run
+    as a CHILD process and exit with its code.  This parent never touches the GPU (no HIP call before or after)."""
+    import socket
+    import subprocess
+    if os.environ.get("BCBF_BENCH_SINGLE_DEVICE") != "1":
+        have = torch.cuda.device_count()          # counting devices does not initialise the runtime
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and "WORLD_SIZE" in os.environ:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used\n" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hooks (one-GPU boxes): BCBF_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, BCBF_BENCH_BACKEND=gloo
@@ -157,42 +215,32 @@ def main():
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
     torch.cuda.synchronize()
 
-    # ---- the batch is processed as `chunks` independent sub-batches, each on its own HIP stream:
-    # instances never interact, so sub-batch A's SOCP (latency-bound, few waves) overlaps
-    # sub-batch B's posterior kernel (HBM-bound) -- also across consecutive steps.
-    S = max(1, args.chunks)
+    # ---- one step = every instance takes one control step: posterior -> task rows + terms + SOCP -> plant step.
+    # Default schedule: the batch is split into `parts` part batches (instances never interact); ONE stream runs the
+    # parts' posterior kernels back to back, each part's solve launch runs on its own stream beside the other parts'
+    # posterior kernels (bcbf_unicycle_control_step_2s).  The HIP events bracket each posterior launch on the
+    # posterior stream, where those launches never overlap one another: a clean per-launch duration.
+    S = max(1, args.parts)
     assert Bt % S == 0
     Bc = Bt // S
     dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-
-    class Chunk:
-        def __init__(self, c):
-            sl = slice(c * Bc, (c + 1) * Bc)
-            gsl = slice(0, 1) if shared else sl
-            q = {k: v[gsl] for k, v in p.items()}
-            self.gp = dict(Lop=Lop[gsl], Vw=Vw[gsl], X=q["X"], UHB=UHB[gsl], ell=q["ell"], s2=q["s2"], Bm=q["Bm"],
-                           M0=q["M0"], A=q["A"])
-            self.task = {k: (v[sl] if v.dim() > 0 and v.shape[0] == Bt else v) for k, v in task.items()}
-            self.x = task["x"][sl].clone()
-            self.ws = ops.control_workspace(Bc, 2, dtype, dev)
-            # one host call per step: constraints -> posterior -> terms -> SOCP -> plant step, on the current stream
-            self._step = ops.unicycle_control_step_prepare(self.gp, self.task, self.ws, self.x, dt=dt_plant, L_true=L_true,
-                                                           L_mean=L_mean, clf_gamma=10.0, max_iters=20)
-
-        def step(self, ev0=None, ev1=None):
-            self._step(ev0, ev1)
-
-    chunks = [Chunk(c) for c in range(S)]
+    gsl = slice(0, 1) if shared else slice(None)
+    gp = dict(Lop=Lop[gsl], Vw=Vw[gsl], X=p["X"][gsl], UHB=UHB[gsl], ell=p["ell"][gsl], s2=p["s2"][gsl],
+              Bm=p["Bm"][gsl], M0=p["M0"][gsl], A=p["A"][gsl])
+    x = task["x"].clone()
+    if S > 1:
+        loop = ops.PipelinedControlLoop(gp, task, x, parts=S, dt=dt_plant, L_true=L_true, L_mean=L_mean, clf_gamma=10.0,
+                                        max_iters=20)
+        ev_stream = [loop.stream_post] * S
+        step, status_t, iters_t = loop.step, loop.status, loop.iters
+    else:
+        ws = ops.control_workspace(Bt, 2, dtype, dev)
+        one = ops.unicycle_control_step_prepare(gp, task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean, clf_gamma=10.0,
+                                                max_iters=20)
+        ev_stream = [torch.cuda.current_stream(dev)]
+        step = (lambda ev=None: one() if ev is None else one(ev[0][0], ev[0][1]))
+        status_t, iters_t = ws["status"], ws["iters"]
     torch.cuda.synchronize()
-
-    def step(ev=None):
-        for c, ch in enumerate(chunks):
-            with torch.cuda.stream(streams[c]):
-                if ev is None:
-                    ch.step()
-                else:
-                    ch.step(ev[c][0], ev[c][1])
 
     for _ in range(args.warmup):
         step()
@@ -208,8 +256,8 @@ def main():
           for _ in range(args.steps)]
     for row in ev:                      # instantiate the hipEvent handles (torch creates them on first record)
         for c, (e0, e1) in enumerate(row):
-            e0.record(streams[c])
-            e1.record(streams[c])
+            e0.record(ev_stream[c])
+            e1.record(ev_stream[c])
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -219,11 +267,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for row in ev for a, b in row]))
-    status = torch.cat([ch.ws["status"] for ch in chunks])
-    iters = torch.cat([ch.ws["iters"] for ch in chunks])
+    status, iters = status_t, iters_t
 
     n_opt = int((status == 0).sum())
     stats = torch.tensor([elapsed, float(n_opt), float(Bt), float(iters.float().mean())], dtype=torch.float64, device=dev)
+    rank_ms, comm_world = [elapsed / args.steps * 1e3], 1
     if multi:
         import torch.distributed as dist
         if backend != "nccl":
@@ -232,8 +280,16 @@ def main():
         sums = stats[1:3].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)            # the final (only) reduction: a few numbers over RCCL
+        comm_world = dist.get_world_size()
+        per_rank = [torch.zeros_like(stats[:1]) for _ in range(comm_world)]
+        dist.all_gather(per_rank, stats[:1].clone())           # every rank's own wall time (reporting only)
+        rank_ms = [float(t[0]) / args.steps * 1e3 for t in per_rank]
         stats[1:3] = sums
         elapsed = float(tmax[0])
+    schedule = ("%d part batches: posterior launches back to back on one stream, each part's solve launch beside the "
+                "others' posterior" % S) if S > 1 else "one stream: posterior launch, then solve launch"
+    comm = {"backend": ("rccl" if backend == "nccl" else backend) if multi else None, "world_size": comm_world,
+            "per_rank_ms_per_step": rank_ms}
     total_instances = float(stats[2])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_instances * args.steps / elapsed
@@ -252,9 +308,10 @@ def main():
             "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints + SOCP per step, "
                                    "ONE learned model queried by every closed loop (Monte-Carlo rollouts)",
                        "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
-                       "regime": "shared GP (S)", "inputs": args.variant, "streams": S,
+                       "regime": "shared GP (S)", "inputs": args.variant, "schedule": schedule,
                        "parallelism": "closed loops sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
+            "comm": comm,
             "roofline": {"bound": "mfma", "kernel": "posterior_shared_kernel" if args.dtype == "f32" and N <= 1536 else
                          "posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernel is fp32, N <= ~1600)",
                          "achieved": achieved,
@@ -265,6 +322,7 @@ def main():
         print(json.dumps(out))
     elif rank == 0:
         bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bc
+        traffic, traffic_src = measured_traffic(N, Bc, args.dtype, bytes_launch)
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; HBM GB/s vs peak" % (N, Bt),
@@ -283,10 +341,11 @@ def main():
             "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints (1 CLC + 2 obstacle "
                                    "CBCs) + SOCP per step, independent GP per instance",
                        "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
-                       "regime": "independent GPs (I)", "inputs": args.variant, "streams": S, "parallelism": "instances sharded, dp%d" % world},
+                       "regime": "independent GPs (I)", "inputs": args.variant, "schedule": schedule, "parallelism": "instances sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
+            "comm": comm,
             "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, Bc, args.dtype, bytes_launch),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
         }
         if world == 1 and args.cpu_sample > 0:

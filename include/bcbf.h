@@ -14,8 +14,9 @@
  *    of independent instances (one GP / one control loop each); the caller owns all memory and
  *    the library allocates nothing;
  *  - N = #training points per instance, n = state dim, m = control dim, C = 1+m;
- *  - `_f32` / `_f64` select the storage + arithmetic type (the fp32 conic solver keeps fp32 iterates and
- *    factors its reduced KKT system in fp64; bcbf_coneqp is fp64 only);
+ *  - `_f32` / `_f64` select the storage + arithmetic type (the conic solver keeps fp64 iterates for both -- the fp32
+ *    entry points read and write fp32 and solve the program those numbers define to fp64 accuracy; bcbf_coneqp is
+ *    fp64 only);
  *  - `stream` is a hipStream_t (pass 0 for the default stream); calls are asynchronous and
  *    re-entrant; no randomness is drawn inside the library (jitter vectors are inputs);
  *  - return value: 0 on success, <0 on a bad argument / launch failure (BCBF_E*); per-instance
@@ -30,6 +31,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libbcbf.so is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#pragma GCC visibility push(default)
 
 #define BCBF_VERSION_MAJOR 0
 #define BCBF_VERSION_MINOR 1
@@ -105,7 +108,10 @@ int bcbf_potrs_f64(const double* Lop, const double* Xdot, const double* UH, cons
 
 /* K11: append one training point to the packed operator (bordered Cholesky).  knew[Bt,N] = new
  * row of K_b against the old points, kappa[Bt] its diagonal (incl. jitter).  Lop_in has N points,
- * Lop_out N+1 (may not alias).  No reference counterpart (the reference refactorises). */
+ * Lop_out N+1 (may alias Lop_in while N+1 stays inside the same 32-row padding).  info[b] = 0, or N+1 when the new
+ * pivot is not positive: then nothing of instance b changes (row N stays an identity padding row, the operator still
+ * describes the old N points) and the caller may retry with a larger jitter.  No reference counterpart (the
+ * reference refactorises). */
 int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
                          int* info, int Bt, int N, void* stream);
 int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double* kappa, double* Lop_out,
@@ -116,7 +122,9 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
  * its diagonal (+ jitter_new[Bt], may be NULL) are formed in the kernel, the packed operator gains the row
  * (bcbf_chol_append), Vw gains (y - l'Vw)/d with y = xdot_new - M0'uh_new, X and UH*B gain their rows.
  * Inputs hold N points ([Bt,N,.]), outputs N+1 ([Bt,N+1,.], distinct buffers: the batch stride changes);
- * Lop_out may alias Lop_in while N+1 stays inside the same 32-row padding.  Equals bcbf_refit + bcbf_potrs on the
+ * Lop_out may alias Lop_in while N+1 stays inside the same 32-row padding.  info[b] = N+1 when the new pivot is not
+ * positive: instance b then gains a NEUTRAL point (identity operator row, Vw row 0, UH*B row 0: its posterior is
+ * that of the old N points) -- retry by appending again with a larger jitter_new.  Equals bcbf_refit + bcbf_potrs on the
  * N+1 points (the reference refits from scratch: unicycle_move_to_pose.py:340-386, control_affine_model.py:268-335). */
 int bcbf_gp_append_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
                        const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
@@ -333,9 +341,9 @@ int bcbf_unicycle_step_f64(double* x, const double* u, double dt, double L_true,
 /* One host call per control step of ControllerCLFBayesian.control on the unicycle
  * (unicycle_move_to_pose.py:926-995), TWO launches on `stream`: the posterior kernel (n=3, m=2), then one kernel
  * that does what bcbf_unicycle_constraints -> bcbf_cbc_terms (K = 1+Kob, sign[K]) -> bcbf_socp ->
- * x += g(x; L_true) u dt (skipped when dt <= 0; applied with y as stored whatever the status -- mask and step
- * yourself with dt = 0 + bcbf_unicycle_step if unsolved instances must not move) do separately (each lane forms its
- * own task row from the state).
+ * x += g(x; L_true) u dt (skipped when dt <= 0, and for every instance whose status != BCBF_SOCP_OPTIMAL: the
+ * reference raises ValueError(problem.status) there, :954-964, so an unsolved instance keeps its state and is
+ * reported through status[]) do separately (each lane forms its own task row from the state).
  * Arguments are those of the individual entry points; grad/cst/fhat/ghat/Mk/Bk/cones/cstatus are caller-provided
  * workspaces that also expose the intermediates; y[Bt,3] = [u, relax].
  * ev_start / ev_stop (optional hipEvent_t) are recorded around the posterior kernel for profiling.
@@ -361,6 +369,34 @@ int bcbf_unicycle_control_step_f64(
     double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
     int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream);
 
+/* Two-stream form of bcbf_unicycle_control_step, for a caller that splits its batch into (two or more) part batches:
+ * the posterior launch of this part goes to stream_post, its solve launch (task rows + terms + SOCP + plant step) to
+ * stream_solve, chained by caller-provided events -- the posterior first waits for ev_state (recorded here after the
+ * solve launch: the next posterior of THESE instances queries the state this solve advances), the solve waits for
+ * ev_post (recorded here after the posterior).  With all parts on ONE stream_post that stream runs posterior kernels
+ * back to back (HBM bound) while each part's solve (latency bound, one wave per CU) runs beside the other parts'
+ * posterior kernels: the 15 % of a step that the serialized solve launch costs disappears.  Instances never interact,
+ * so every instance still takes exactly one control step per call.  ev_start / ev_stop bracket the posterior kernel
+ * on stream_post (after the wait).  An event that was never recorded does not block (first call). */
+int bcbf_unicycle_control_step_2s_f32(
+    const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+    const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
+    const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
+    float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
+    float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
+    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
+    void* ev_start, void* ev_stop, void* stream_post, void* ev_post, void* ev_state, void* stream_solve);
+int bcbf_unicycle_control_step_2s_f64(
+    const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
+    const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
+    const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,
+    const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
+    const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
+    double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
+    int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream_post, void* ev_post,
+    void* ev_state, void* stream_solve);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

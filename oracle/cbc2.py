@@ -10,8 +10,9 @@ misc.py:268-285).  Everything is a function of the *jet* of the posterior at x:
 import numpy as np
 import scipy.linalg as sla
 
-from .gp_algebra_note import EIG_EPS
 from .gp_posterior import rbf_ard_kernel
+
+EIG_EPS = 2e-3   # gp_algebra.py:317: eigenvalues of the kernel Hessian in (-EPS, 0) are treated as rounding
 
 
 def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x):

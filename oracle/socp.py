@@ -279,7 +279,7 @@ def optimizer_qp(quadratic_objective, linear_constraints):
     return coneqp(P, q, G, h, dict(l=len(h), q=[]))
 
 
-def clf_cbf_socp(weights, u_ref, cones, rho, relax_mask):
+def clf_cbf_socp(weights, u_ref, cones, rho, relax_mask, maxiters=MAXITERS):
     """The program of ControllerCLFBayesian.control  (bayes_cbf/unicycle_move_to_pose.py:926-953).
 
     min sum_i w_i (u_i - r_i)^2 + w_relax relax^2
@@ -304,7 +304,7 @@ def clf_cbf_socp(weights, u_ref, cones, rho, relax_mask):
         Gs.append(Gk)
         hs.append(hk)
         dimsq.append(A.shape[0] + 1)
-    return coneqp(P, q, np.vstack(Gs), np.concatenate(hs), dict(l=0, q=dimsq))
+    return coneqp(P, q, np.vstack(Gs), np.concatenate(hs), dict(l=0, q=dimsq), maxiters=maxiters)
 
 
 def kkt_residuals(P, q, G, h, dims, sol):

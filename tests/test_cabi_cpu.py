@@ -25,6 +25,11 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib.lib, name), "libbcbf.so does not export %s" % name
     assert declared == set(lib.declared_symbols())
+    # ... and nothing else: the library is built with hidden visibility, internal cross-file entry points stay internal
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_version_and_layout_helpers(lib):

@@ -48,3 +48,14 @@ def test_shard_range_covers_everything():
             spans = [shard_range(total, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
+    """`python bench.py --gpus 2` on a box without 2 GPUs: the launcher parent exits 2 before any rank starts."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        return
+    assert res.returncode == 2 and "only" in res.stderr

@@ -1,0 +1,61 @@
+"""bench.py as the driver runs it: the single-GPU line, the RCCL code path, and the self-launched multi-rank path.
+
+A one-GPU box cannot hold two RCCL ranks (one communicator per device), so RCCL itself is exercised with ONE rank
+(`BCBF_BENCH_FORCE_DIST=1`: process group, barriers, the three final collectives all go through ncclComm on the
+GPU), and the N = 2 launcher path with two ranks sharing cuda:0 over gloo (`BCBF_BENCH_SINGLE_DEVICE=1`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "4", "--warmup", "2", "--batch", "256", "--ntrain", "128"]
+
+
+def _run(extra_args, extra_env, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra_args, env=env,
+                         capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    out = _run(["--cpu-sample", "8"], {})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["dtype"] == "f32" and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "GB/s" and "traffic_source" in rf
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-12
+    # kernel time <= step time; bytes/step over the step time cannot beat the kernel's own rate
+    assert rf["kernel_ms"] <= out["ms_per_step"] * 1.05
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_rccl_path_with_one_rank():
+    """ncclCommInit + barrier + all_reduce(MAX/SUM) + all_gather on the GPU box."""
+    out = _run(["--cpu-sample", "0"], {"BCBF_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                                       "MASTER_PORT": "29733"})
+    assert out["comm"]["backend"] == "rccl" and out["comm"]["world_size"] == 1 and out["n_gpus"] == 1
+    assert len(out["comm"]["per_rank_ms_per_step"]) == 1
+
+
+def test_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher): two child ranks, value = both shards over the slowest rank's time."""
+    out = _run(["--gpus", "2", "--cpu-sample", "0"], {"BCBF_BENCH_SINGLE_DEVICE": "1", "BCBF_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["comm"]["world_size"] == 2 and out["comm"]["backend"] == "gloo"
+    ms = out["comm"]["per_rank_ms_per_step"]
+    assert len(ms) == 2 and abs(max(ms) - out["ms_per_step"]) < 1e-6
+    assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-9

@@ -116,3 +116,31 @@ def test_saved_run_trajectories(name):
             np.testing.assert_allclose(xn, g["state"][t + 1], atol=5e-6)
         checked += 1
     assert checked >= 25
+
+
+@pytest.mark.parametrize("name", ["saved_run_mean_cbf_maxrisk0p5", "saved_run_bayes_cbf_maxrisk0p01"])
+def test_control_step_restatement_reproduces_saved_run(name):
+    """oracle.control_step (the end-to-end restatement the GPU tests of the fused entry point compare with) pinned on
+    the reference's committed 200-step runs: logged GUROBI control and logged next state, every 5th step."""
+    from oracle import control_step as ostep
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dt, T = float(g["dt"]), int(g["numSteps"])
+    x0, xg = g["state_start"], g["state_goal"]
+    planner = unicycle.PiecewiseLinearPlanner(x0, xg, T, dt, frac_time_to_reach_goal=0.95)
+    cbfs = unicycle.obstacles_at_mid_from_start_and_goal(x0, xg, tuple(g["term_weights"]))
+    centers, radii = np.stack([c.center for c in cbfs]), np.array([c.radius for c in cbfs])
+    rho = cbc.cbc1_safety_factor(float(g["max_risk"]))
+    for t in range(0, T - 1, 5):
+        x = g["state"][t].astype(np.float64)
+        o = ostep.control_step(x, planner.plan(t), planner.dot_plan(t), np.zeros((3, 3)), np.eye(3),
+                               np.diag(g["kernel_diag_A"]), [0.9, 1.5, 0.0], float(g["clf_gamma"]), centers, radii,
+                               g["term_weights"], g["cbf_gammas"], float(g["mean_L"]), g["cost_weights"], [0.0, 0.0], rho,
+                               dt=dt, L_true=float(g["true_L"]))
+        assert o["status"] == "optimal"
+        np.testing.assert_allclose(o["u"], g["uopt"][t], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(o["x_next"], g["state"][t + 1], atol=2e-4)     # (u is logged in fp32)
+    # an unsolved program takes no step (the reference raises, unicycle_move_to_pose.py:954-964)
+    bad = ostep.control_step(x, planner.plan(0), planner.dot_plan(0), np.zeros((3, 3)), np.eye(3), 1e3 * np.eye(3),
+                             [0.9, 1.5, 0.0], 10.0, centers, 10 * radii, g["term_weights"], g["cbf_gammas"], 1.0,
+                             g["cost_weights"], [0.0, 0.0], 2.326, dt=dt, L_true=1.0)
+    assert bad["status"] != "optimal" and np.array_equal(bad["x_next"], x)
