@@ -38,7 +38,7 @@ _TSIGS = {
     "bcbf_mll_grad_rbflin": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
-    "bcbf_posterior_jets": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_jets": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_cbc2_terms": [P] * 15 + [c_int, c_int, c_int, P],
     "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_socp": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
@@ -46,7 +46,6 @@ _TSIGS = {
     "bcbf_unicycle_constraints": [P, P, P, P, "T", P, P, P, P, "T", P, P, P, P, c_int, c_int, P],
     "bcbf_unicycle_step": [P, P, "T", "T", c_int, P],
     "bcbf_unicycle_control_step": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
-    "bcbf_unicycle_control_step_2s": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
 }
 
 

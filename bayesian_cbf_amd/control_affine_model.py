@@ -251,6 +251,43 @@ class ControlAffineRegressor:
         self.clear_cache()
         return self
 
+    def append_data(self, Xnew_in, Unew_in, XdotNew_in, cholesky_tries=10, cholesky_perturb_init=1e-5,
+                    cholesky_perturb_scale=10):
+        """Online update (no reference counterpart: the reference refits from scratch, unicycle_move_to_pose.py:340-386):
+        the k new observations enter the training set AND the cached refit state one by one through `bcbf_gp_append`
+        (bordered Cholesky on the packed factor, whitened-target row, per-refit arrays) at the current hyper-parameters
+        -- O(N^2) per observation instead of the O(N^3) refactorisation.  The result is the state `fit(..., training_iter=0)`
+        on all the points would cache, with the jitter draw of point i (make_psd's 1e-5 * rand, x10 on a failed pivot)
+        made when the point enters."""
+        Xn, Un, Yn = [self._ensure_device_dtype(X).reshape(-1, d).contiguous()
+                      for X, d in ((Xnew_in, self.x_dim), (Unew_in, self.u_dim), (XdotNew_in, self.x_dim))]
+        if Xn.shape[0] == 0:
+            return self
+        if self.Xtrain is None:
+            return self.fit(Xn, Un, Yn, training_iter=0)
+        self._require_gpu()
+        st = self._state()                                    # builds it if the cache was cleared
+        ones = torch.ones(1, 1, dtype=self.dtype, device=self.device)
+        for i in range(Xn.shape[0]):
+            x_new, uh_new, y_new = Xn[i:i + 1], torch.cat([ones, Un[i:i + 1]], dim=1), Yn[i:i + 1]
+            factor = cholesky_perturb_init
+            for ntry in range(cholesky_tries):
+                jit = (factor * self.rand_fn(1)).reshape(1).contiguous()
+                Lop, Vw, X, UHB, info = ops.gp_append(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
+                                                      st["M0"], x_new, uh_new, y_new, jit)
+                if int(info[0]) == 0:
+                    break                                      # (a failed pivot leaves st["Lop"] untouched: retry on it)
+                if ntry == cholesky_tries - 1:
+                    raise RuntimeError("cholesky: the appended point makes K_b singular after %d jitter retries" % cholesky_tries)
+                factor *= cholesky_perturb_scale
+            st.update(Lop=Lop, Vw=Vw, X=X, UHB=UHB, N=st["N"] + 1, UH=torch.cat([st["UH"], uh_new[None]], dim=1),
+                      jitter=torch.cat([st["jitter"], jit[None]], dim=1))
+            st.pop("L", None)
+        self.Xtrain = torch.cat([self.Xtrain, Xn])
+        self.Utrain = torch.cat([self.Utrain, Un])
+        self.XdotTrain = torch.cat([self.XdotTrain, Yn])
+        return self
+
     def neg_mll_backward(self, perturb_targets=False, jitter=None):
         """loss = -log p(Y) / (N n) (- log prior / (N n)) at the current hyper-parameters; its gradient is accumulated
         into the raw parameters' .grad.  Returns the loss as a float."""
@@ -640,6 +677,17 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
                 m.mean_constants.copy_(torch.as_tensor(M0).reshape(-1).to(m.mean_constants))
         self.clear_cache()
         return self
+
+    def append_data(self, Xnew_in, Unew_in, XdotNew_in, **kw):
+        """The comparator has no incremental path (its (N n)-sample system would need n bordered rows per observation and
+        it is a baseline, not the hot path): the new observations join the training set and the state is rebuilt on the
+        next query, as the reference does."""
+        Xn, Un, Yn = [self._ensure_device_dtype(X).reshape(-1, d) for X, d in
+                      ((Xnew_in, self.x_dim), (Unew_in, self.u_dim), (XdotNew_in, self.x_dim))]
+        if self.Xtrain is None:
+            return self.fit(Xn, Un, Yn, training_iter=0)
+        return self.fit(torch.cat([self.Xtrain, Xn]), torch.cat([self.Utrain, Un]), torch.cat([self.XdotTrain, Yn]),
+                        training_iter=0)
 
     # ---- expanded system
     def _hyper(self):

@@ -119,43 +119,40 @@ class SumDynamicModels:
 
 class MeanAdjustedModel(SumDynamicModels):
     """A prior mean model + a learned residual, refit every `train_every_n_steps` control steps on finite-difference
-    targets minus the prior (controllers.py:320-378; note the reference reads `self.x_dim`, `self.u_dim`, `self.dt`
-    in `_train` without ever setting them -- they are set here from the constructor)."""
+    targets minus the prior (controllers.py:320-378; the reference reads `self.x_dim`, `self.u_dim`, `self.dt` in
+    `_train` without ever setting them -- they are constructor arguments here).  The buffering / schedule / targets
+    live in `online.OnlineLearner`, shared with `LearnedShiftInvariantDynamics`; `hyper_refit_every` and
+    `online_update` switch on the incremental (`bcbf_gp_append`) updates described there."""
 
     def __init__(self, x_dim, u_dim, mean_dynamics_model_class, model, max_train=None, train_every_n_steps=None,
-                 enable_learning=None, dt=None, training_iter=100):
-        self.Xtrain, self.Utrain = [], []
+                 enable_learning=None, dt=None, training_iter=100, hyper_refit_every=1, online_update=False):
+        from .online import OnlineLearner
         self.mean_dynamics_model = mean_dynamics_model_class()
         super().__init__(model, self.mean_dynamics_model)
-        self._has_been_trained_once = False
         self.model, self.max_train, self.train_every_n_steps = model, max_train, train_every_n_steps
         self.enable_learning, self.x_dim, self.u_dim, self.dt, self.training_iter = enable_learning, x_dim, u_dim, dt, training_iter
+        self._learner = OnlineLearner(
+            model, self._residual_targets, dt, train_every_n_steps, max_train, training_iter,
+            subsample=lambda count, k: torch.randint(count, (k,)),        # :360-362: WITH replacement, as upstream
+            enable_learning=bool(enable_learning), hyper_refit_every=hyper_refit_every, online_update=online_update)
+
+    Xtrain = property(lambda self: self._learner.Xtrain)
+    Utrain = property(lambda self: self._learner.Utrain)
+    _has_been_trained_once = property(lambda self: self._learner.has_been_trained_once)
+
+    def _residual_targets(self, X, U, Xdot):
+        md = self.mean_dynamics_model
+        mean = torch.as_tensor(md.f_func(X)).to(X) + torch.as_tensor(md.g_func(X)).to(X).bmm(U.unsqueeze(-1)).squeeze(-1)
+        return Xdot - mean
 
     def _train(self):
-        if not len(self.Xtrain):
-            return
-        assert len(self.Xtrain) == len(self.Utrain), "Call train when Xtrain and Utrain are balanced"
-        Xtrain = torch.cat(self.Xtrain).reshape(-1, self.x_dim)
-        Utrain = torch.cat(self.Utrain).reshape(-1, self.u_dim)
-        XdotTrain = (Xtrain[1:, :] - Xtrain[:-1, :]) / self.dt
-        md = self.mean_dynamics_model
-        XdotMean = torch.as_tensor(md.f_func(Xtrain)).to(Xtrain) + (
-            torch.as_tensor(md.g_func(Xtrain)).to(Xtrain).bmm(Utrain.unsqueeze(-1)).squeeze(-1))
-        XdotError = XdotTrain - XdotMean[:-1, :]
-        if self.max_train is not None and XdotTrain.shape[0] > self.max_train:
-            indices = torch.randint(XdotTrain.shape[0], (self.max_train,)).to(Xtrain.device)
-            train_data = Xtrain[indices, :], Utrain[indices, :], XdotError[indices, :]
-        else:
-            train_data = Xtrain[:-1, :], Utrain[:-1, :], XdotError
-        self.model.fit(*train_data, training_iter=self.training_iter)
-        self._has_been_trained_once = True
+        """Refit on everything buffered so far (:336-369)."""
+        self._learner.dt = self.dt
+        self._learner._refit_from_scratch(self.training_iter)
 
     def train(self, xi, uopt):
-        if len(self.Xtrain) > 0 and len(self.Xtrain) % int(self.train_every_n_steps) == 0 and self.enable_learning:
-            self._train()
-        self.Xtrain.append(xi.detach())
-        self.Utrain.append(uopt.detach())
-        assert len(self.Xtrain) == len(self.Utrain)
+        self._learner.dt, self._learner.enable_learning = self.dt, bool(self.enable_learning)
+        self._learner.observe(xi, uopt)
 
 
 def _rows_to_cone(G, h):

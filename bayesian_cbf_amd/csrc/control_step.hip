@@ -14,23 +14,17 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
 
 // Two launches per step: the posterior kernel, then ONE kernel that forms the task rows (CLC + obstacle CBCs) from the
 // state, the chance-constraint terms and cones from (M_k, B_k), solves the SOCP and advances the plant.
-// Two-stream form (`_2s`): the posterior launch goes to `stream` and the solve launch to `stream_solve`, chained by
-// events -- the posterior waits for ev_state (recorded after the previous solve of THESE instances: it queries the
-// state that solve advanced), the solve waits for ev_post (recorded after the posterior).  A caller that splits its
-// batch into half batches and gives them one posterior stream keeps that stream saturated with back-to-back posterior
-// kernels (HBM bound) while each half's solve (latency bound, one wave per CU) runs beside the other half's stream.
 #define BCBF_CTRL(T, SUF)                                                                                              \
-    static int control_step_impl_##SUF(                                                                                \
+    extern "C" int bcbf_unicycle_control_step_##SUF(                                                                   \
         const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0,     \
         const T* A, T* x, const T* plan, const T* dot_plan, const T* Kp, T clf_gamma, const T* centers,               \
         const T* radii, const T* tw, const T* gammas, T L_mean, const T* w, const T* r, const T* sign,                \
         const T* relax_mask, const T* rho, T* grad, T* cst, T* fhat, T* ghat, T* Mk, T* Bk, T* cones, int* cstatus,   \
         T* y, int* status, int* iters, T dt, T L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,          \
-        void* ev_start, void* ev_stop, void* stream, void* ev_post, void* ev_state, void* stream_solve) {             \
+        void* ev_start, void* ev_stop, void* stream) {                                                                 \
         if (Bt <= 0) return BCBF_OK;                                                                                   \
         if (!x || !grad || !cst || !fhat || !ghat || Kob < 0 || Kob + 1 > BCBF_MAX_CONSTRAINTS) return BCBF_EINVAL;    \
         hipStream_t st = (hipStream_t)stream;                                                                          \
-        if (ev_state) (void)hipStreamWaitEvent(st, (hipEvent_t)ev_state, 0);                                           \
         if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);                                                  \
         /* Lop == NULL: no learned model in the loop -- (Mk, Bk) are the caller's (fixed-kernel model: 0 and I) */    \
         int rc = !Lop ? BCBF_OK : shared_gp ? bcbf_posterior_query_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, \
@@ -39,41 +33,10 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
                                                        2, stream);                                                     \
         if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);                                                    \
         if (rc) return rc;                                                                                             \
-        if (ev_post) {                                                                                                 \
-            (void)hipEventRecord((hipEvent_t)ev_post, st);                                                             \
-            (void)hipStreamWaitEvent((hipStream_t)stream_solve, (hipEvent_t)ev_post, 0);                               \
-        }                                                                                                              \
         bcbf::UnicycleTask<T> task{x, plan, dot_plan, Kp, centers, radii, tw, gammas, clf_gamma, L_mean, dt, L_true,   \
                                    grad, cst, fhat, ghat, Kob};                                                        \
-        rc = bcbf::launch_unicycle_socp<T>(Mk, Bk, A, sign, w, r, relax_mask, rho, cones, cstatus, y, status, iters,   \
-                                           Bt, max_iters, task, stream_solve);                                         \
-        if (ev_state) (void)hipEventRecord((hipEvent_t)ev_state, (hipStream_t)stream_solve);                          \
-        return rc;                                                                                                     \
-    }                                                                                                                  \
-    extern "C" int bcbf_unicycle_control_step_##SUF(                                                                   \
-        const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0,     \
-        const T* A, T* x, const T* plan, const T* dot_plan, const T* Kp, T clf_gamma, const T* centers,               \
-        const T* radii, const T* tw, const T* gammas, T L_mean, const T* w, const T* r, const T* sign,                \
-        const T* relax_mask, const T* rho, T* grad, T* cst, T* fhat, T* ghat, T* Mk, T* Bk, T* cones, int* cstatus,   \
-        T* y, int* status, int* iters, T dt, T L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,          \
-        void* ev_start, void* ev_stop, void* stream) {                                                                 \
-        return control_step_impl_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, A, x, plan, dot_plan, Kp, clf_gamma, centers, \
-                                       radii, tw, gammas, L_mean, w, r, sign, relax_mask, rho, grad, cst, fhat, ghat,  \
-                                       Mk, Bk, cones, cstatus, y, status, iters, dt, L_true, Bt, N, Kob, max_iters,    \
-                                       shared_gp, ev_start, ev_stop, stream, nullptr, nullptr, stream);                \
-    }                                                                                                                  \
-    extern "C" int bcbf_unicycle_control_step_2s_##SUF(                                                                \
-        const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0,     \
-        const T* A, T* x, const T* plan, const T* dot_plan, const T* Kp, T clf_gamma, const T* centers,               \
-        const T* radii, const T* tw, const T* gammas, T L_mean, const T* w, const T* r, const T* sign,                \
-        const T* relax_mask, const T* rho, T* grad, T* cst, T* fhat, T* ghat, T* Mk, T* Bk, T* cones, int* cstatus,   \
-        T* y, int* status, int* iters, T dt, T L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,          \
-        void* ev_start, void* ev_stop, void* stream_post, void* ev_post, void* ev_state, void* stream_solve) {        \
-        if (!ev_post || !ev_state) return BCBF_EINVAL;                                                                 \
-        return control_step_impl_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, A, x, plan, dot_plan, Kp, clf_gamma, centers, \
-                                       radii, tw, gammas, L_mean, w, r, sign, relax_mask, rho, grad, cst, fhat, ghat,  \
-                                       Mk, Bk, cones, cstatus, y, status, iters, dt, L_true, Bt, N, Kob, max_iters,    \
-                                       shared_gp, ev_start, ev_stop, stream_post, ev_post, ev_state, stream_solve);    \
+        return bcbf::launch_unicycle_socp<T>(Mk, Bk, A, sign, w, r, relax_mask, rho, cones, cstatus, y, status, iters, \
+                                             Bt, max_iters, task, stream);                                             \
     }
 BCBF_CTRL(float, f32)
 BCBF_CTRL(double, f64)

@@ -325,7 +325,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             if (dh == 0) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) wbuf[di][c] = w[c];
-                if (Wout != nullptr) {
+                if (NJ > 0 && Wout != nullptr) {        // jets: all CT columns [Phi, dPhi/dx_1 ..] of this row
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) Wout[((size_t)b * Np + row0 + di) * CT + c] = w[c];
+                } else if (Wout != nullptr) {
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi)
                         if (NQ == 1 || b * NQ + qi < nq) {
@@ -457,7 +460,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
 #define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt)
-#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, nullptr, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt)
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
         if (!Mfull || lin) return BCBF_EINVAL;
         if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
@@ -550,21 +553,23 @@ extern "C" int bcbf_posterior_query_rbflin_f64(const double* Lop, const double* 
 // Jets: value + first x-derivatives of the posterior factors at one query per instance (or per query of
 // a shared GP).  CT = (1+m)(1+n) columns [Phi, dPhi/dx_1..dPhi/dx_n]:  G[Bt,CT,CT] = Wj'Wj,
 // Mj[Bt,n,CT] = Vw'Wj (so Mk = M0' + Mj[:, :C], dMk/dx_d = Mj[:, (1+d)C:(2+d)C]).  Feeds bcbf_cbc2_terms.
+// Wj (optional, [Bt, Np, CT]) = L^-1 [Phi, dPhi/dx_d]: lets the caller form the derivative kernels between two
+// DIFFERENT states, d/dx d/dx' B_k(x, x') = d2k/dxdx' Bm - dW_d(x)'dW_e(x')  (GradientGP.knl(x, x'), gp_algebra.py:355-393).
 // Replaces autograd through custom_predict in GradientGP (gp_algebra.py:340-402).  Compiled for
 // (n,m) in {(1,1),(2,1),(2,2),(3,2)}.
 extern "C" int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
                                        const float* ell, const float* s2, const float* Bm, const float* M0,
-                                       const float* xq, float* Mk, float* Bk, float* G, float* Mj, int shared,
-                                       int Bt, int N, int n, int m, void* stream) {
+                                       const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj,
+                                       int shared, int Bt, int N, int n, int m, void* stream) {
     if (Bt <= 0) return BCBF_OK;
     if (!G || !Mj) return BCBF_EINVAL;
-    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, nullptr, shared, Bt, N, n, m, stream, G, Mj);
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, Wj, shared, Bt, N, n, m, stream, G, Mj);
 }
 extern "C" int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
                                        const double* ell, const double* s2, const double* Bm, const double* M0,
-                                       const double* xq, double* Mk, double* Bk, double* G, double* Mj, int shared,
-                                       int Bt, int N, int n, int m, void* stream) {
+                                       const double* xq, double* Mk, double* Bk, double* G, double* Mj, double* Wj,
+                                       int shared, int Bt, int N, int n, int m, void* stream) {
     if (Bt <= 0) return BCBF_OK;
     if (!G || !Mj) return BCBF_EINVAL;
-    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, nullptr, shared, Bt, N, n, m, stream, G, Mj);
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, Wj, shared, Bt, N, n, m, stream, G, Mj);
 }

@@ -13,6 +13,7 @@
 // run their update streams.  fp64 MFMA peak on MI355X is 78.6 TFLOP/s = the fp64 vector peak; as in fp32 the gain over
 // the VALU kernel is operand traffic and instruction count.
 #include "bcbf_common.h"
+#include <stdlib.h>
 
 namespace bcbf {
 
@@ -331,6 +332,10 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
     if (tid == 0) info[b] = fail;
 }
 
+int launch_refit_wave64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                        const double* jitter, const double* Kdense, double* Lop, double* UHB, double* Ldense, int* info,
+                        int Bt, int N, int Np, int n, int C, hipStream_t st);          // refit_wave64.hip
+
 }  // namespace bcbf
 
 extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const double* Bm, const double* ell,
@@ -341,6 +346,20 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
+    if (!Kdense) {
+        if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    }
+    // Batches: one wave per instance (refit_wave64.hip) -- every SIMD advances its own factorisation chain.  Few
+    // instances (less than half the chip's 1024 SIMDs; small problems earlier: their MFMA work is short either way) keep
+    // the workgroup-per-instance form below, which spreads one instance's update stream over several waves.
+    // BCBF_REFIT_WAVE=0/1 forces the choice (A/B measurements).
+    bool per_wave = Bt >= 512 || (Bt >= 64 && Np <= 256);
+    if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
+    if (per_wave) {
+        launch_refit_wave64(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);
+        return check_launch("refit_wave64");
+    }
     const bool wide = Bt < 128 && N >= 256;  // few large instances: 8 waves per workgroup (16 would cap the VGPRs at 128: spills)
 #define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
     do {                                                                                                \
@@ -351,8 +370,6 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
         BCBF_REFIT_LAUNCH(true, 0, st, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
     } else {
-        if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
-        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
         BCBF_REFIT_LAUNCH(false, 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
                            Lop, UHB, Ldense, info, N, Np, n, m + 1);
     }

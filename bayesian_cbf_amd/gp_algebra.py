@@ -11,7 +11,8 @@ tree, but evaluation LOWERS the tree onto the closed-form device kernels (SURVEY
     GradientGP(Det(grad_h).t() @ f_gp)   mean(x), knl(x, x)                        -> from the jets
 
 where `f_gp` / `fu_gp` are the leaves handed out by a `ControlAffineRegressor` (or a sum of dynamics models around
-one).  Any other shape of tree raises `NotImplementedError` -- there is no generic autograd evaluator (and no CPU path).
+one).  Any other tree -- and `knl(x, x')` / `covar(Z, x, x')` between two different states -- is evaluated node by node by
+the reference's propagation rules in `gp_eval` (jets from the device instead of autograd).  There is no CPU path.
 Leaves keep the reference's `mean / knl / covar / register_covar` behaviour (gp_algebra.py:70-106, 258-315)."""
 import torch
 
@@ -95,7 +96,10 @@ class GaussianProcess(GaussianProcessBase):
             if self.assume_independence:
                 return x.new_zeros(max(self.shape), max(Z.shape))
             raise ValueError("No covariance registered among two leaf GaussianProcesses")
-        return x.new_zeros(max(self.shape), max(Z.shape))
+        if isinstance(Z, DeterministicGP):
+            return x.new_zeros(max(self.shape), max(Z.shape))
+        c = Z.covar(self, x, xp)                        # a composed expression: its rule, transposed (gp_algebra.py:301-302)
+        return c.t() if c.dim() == 2 else c
 
     def register_covar(self, gp, covar_func):
         """One function for both directions, as the reference does (gp_algebra.py:306-309)."""
@@ -115,15 +119,32 @@ class GaussianProcessExpr(GaussianProcessBase):
     def quadratic_terms(self, x, u0):
         return self._lowered().quadratic_terms(x, u0)
 
+    def _fast(self):
+        """The fused lowering when the tree is one of the safety-condition shapes, else None (general evaluation)."""
+        if getattr(self, "_low", None) is None and not getattr(self, "_no_low", False):
+            try:
+                self._low = lower(self)
+            except NotImplementedError:
+                self._no_low = True
+        return getattr(self, "_low", None)
+
     def mean(self, x):
-        return self._lowered().mean(x)
+        low = self._fast()
+        if low is not None:
+            return low.mean(x)
+        from .gp_eval import eval_mean
+        return eval_mean(self, x)
 
     def knl(self, x, xp):
-        return self._lowered().knl(x, xp)
+        low = self._fast()
+        if low is not None and (xp is x or torch.equal(x, xp)):
+            return low.knl(x, xp)
+        from .gp_eval import eval_knl
+        return eval_knl(self, x, xp)
 
     def covar(self, Z, x, xp):
-        raise NotImplementedError("cross-covariance of a composed expression with another GP is folded into the "
-                                  "closed-form terms; evaluate the full condition instead")
+        from .gp_eval import eval_covar
+        return eval_covar(self, Z, x, xp)
 
 
 class GaussianProcessAddExpr(GaussianProcessExpr):
@@ -163,6 +184,13 @@ class GaussianProcessTranspose(GaussianProcessExpr):
     def mean(self, x):
         return self.gp.mean(x)
 
+    def knl(self, x, xp):
+        return self.gp.knl(x, xp)
+
+    def covar(self, Y, x, xp):
+        c = self.gp.covar(Y, x, xp)
+        return c.t() if c.dim() == 2 else c
+
 
 class GaussianProcessMatmulExpr(GaussianProcessExpr):
     """X @ Y with X a transposed vector GP: the inner product X'Y, a scalar GP (gp_algebra.py:133-199; the
@@ -200,17 +228,27 @@ class GradientGP(GaussianProcessExpr):
         _, (_, grad_gp, leaf) = terms[0]
         return grad_gp, leaf
 
+    def _lie1_or_none(self):
+        try:
+            return self._lie1()
+        except (NotImplementedError, AttributeError):
+            return None
+
     def mean(self, x):
         from .cbc2 import lie1_gradient
-        grad_gp, leaf = self._lie1()
-        return lie1_gradient(leaf.source[0], grad_gp, x)[0]
+        l1 = self._lie1_or_none()
+        if l1 is not None:
+            return lie1_gradient(l1[1].source[0], l1[0], x)[0]
+        from .gp_eval import eval_mean
+        return eval_mean(self, x)
 
     def knl(self, x, xp):
         from .cbc2 import lie1_gradient
-        if xp is not x and not torch.equal(x, xp):
-            raise NotImplementedError("derivative kernel between two different states is not on the hot path")
-        grad_gp, leaf = self._lie1()
-        return lie1_gradient(leaf.source[0], grad_gp, x)[1]
+        l1 = self._lie1_or_none()
+        if l1 is not None and (xp is x or torch.equal(x, xp)):
+            return lie1_gradient(l1[1].source[0], l1[0], x)[1]
+        from .gp_eval import eval_knl
+        return eval_knl(self, x, xp)
 
 
 # ------------------------------------------------------------------------------------------------ lowering

@@ -222,9 +222,10 @@ def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=
     return Mk, Bk, W
 
 
-def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False):
+def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False, want_W=False):
     """(Mk, Bk, G[b,CT,CT], Mj[b,n,CT]) with CT = (1+m)(1+n): value + first x-derivative jets
-    (replaces autograd through custom_predict in GradientGP, gp_algebra.py:340-402)."""
+    (replaces autograd through custom_predict in GradientGP, gp_algebra.py:340-402).  want_W: also
+    Wj[b,Np,CT] = L^-1 [Phi, dPhi/dx_d] (fifth return value), for derivative kernels between different states."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq)
     N, n = X.shape[1], X.shape[2]
     C = UHB.shape[2]
@@ -233,11 +234,12 @@ def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False):
     f = dict(dtype=X.dtype, device=X.device)
     Mk, Bk = torch.empty(b, n, C, **f), torch.empty(b, C, C, **f)
     G, Mj = torch.empty(b, CT, CT, **f), torch.empty(b, n, CT, **f)
+    Wj = torch.empty(b, (N + 31) // 32 * 32, CT, **f) if want_W else None
     check(getattr(lib, "bcbf_posterior_jets" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm),
-                                                        _p(M0), _p(xq), _p(Mk), _p(Bk), _p(G), _p(Mj),
+                                                        _p(M0), _p(xq), _p(Mk), _p(Bk), _p(G), _p(Mj), _p(Wj),
                                                         1 if shared else 0, b, N, n, C - 1, _stream(X)),
           "bcbf_posterior_jets")
-    return Mk, Bk, G, Mj
+    return (Mk, Bk, G, Mj, Wj) if want_W else (Mk, Bk, G, Mj)
 
 
 def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0):
@@ -452,49 +454,30 @@ def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_g
 
 
 def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,
-                                  two_stream=None):
+                                  stream=None):
     """Bind every argument of `unicycle_control_step` once and return `step(ev_start=None, ev_stop=None)`.
     A closed loop calls the same entry point with the same buffers thousands of times; converting ~40 tensors to
     pointers per call costs more host time than the two launches take on the device for small batches.  The tensors
     must keep their storage (update them in place); the closure keeps them alive.
-    two_stream = (stream_post, stream_solve, ev_post, ev_state) (torch streams / events): the two-stream form
-    `bcbf_unicycle_control_step_2s` -- see `PipelinedControlLoop`."""
+    stream: a fixed torch stream for both launches (default: the current stream at call time)."""
     gp, A, N, shared = _control_step_args(gp, task, ws, x)
     Bt = x.shape[0]
     Kob = task["centers"].shape[1]
-    fn = getattr(lib, "bcbf_unicycle_control_step" + ("_2s" if two_stream is not None else "") + _suf(x))
+    fn = getattr(lib, "bcbf_unicycle_control_step" + _suf(x))
     head = (_p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
             _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
             _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
             _p(task["r"]), _p(task["sign"]), _p(task["relax_mask"]), _p(task["rho"]), _p(ws["grad"]), _p(ws["cst"]),
             _p(ws["fhat"]), _p(ws["ghat"]), _p(ws["Mk"]), _p(ws["Bk"]), _p(ws["cones"]), _p(ws["cstatus"]), _p(ws["y"]),
             _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, 1 if shared else 0)
-    keep = (dict(gp), dict(task), dict(ws), x, A)      # the pointers above are only valid while these live
+    keep = (dict(gp), dict(task), dict(ws), x, A, stream)      # the pointers above are only valid while these live
     dev, y = x.device, ws["y"]
-
-    if two_stream is not None:
-        s_post, s_solve, e_post, e_state = two_stream
-        for e in (e_post, e_state):          # torch creates the hipEvent on first record: make the handles exist
-            if not e.cuda_event:
-                e.record(s_solve)
-        tail = (ctypes.c_void_p(s_post.cuda_stream), ctypes.c_void_p(e_post.cuda_event),
-                ctypes.c_void_p(e_state.cuda_event), ctypes.c_void_p(s_solve.cuda_stream))
-        keep = keep + (two_stream,)
-
-        def step(ev_start=None, ev_stop=None):
-            ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
-            ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
-            rc = fn(*head, ev0, ev1, *tail)
-            if rc:
-                check(rc, "bcbf_unicycle_control_step_2s")
-            return y
-        step.keep = keep
-        return step
+    fixed = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
 
     def step(ev_start=None, ev_stop=None):
         ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
         ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
-        rc = fn(*head, ev0, ev1, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        rc = fn(*head, ev0, ev1, fixed if fixed is not None else ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc:
             check(rc, "bcbf_unicycle_control_step")
         return y
@@ -502,17 +485,19 @@ def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.
     return step
 
 
-class PipelinedControlLoop:
-    """The unicycle control step for a batch split into `parts` part batches on two kinds of HIP streams
-    (`bcbf_unicycle_control_step_2s`): ONE posterior stream runs the parts' posterior kernels back to back (the HBM-bound
-    stream never idles), each part's solve launch (task rows + terms + SOCP + plant step: latency bound, one wave per CU)
-    runs on the part's own solve stream beside the other parts' posterior kernels.  Instances never interact (SURVEY
-    8e), so this is the same computation as `unicycle_control_step` on the whole batch -- every instance takes one
-    control step per `step()` -- with the serialized solve launch (15 % of a single-stream step at the BASELINE config)
-    hidden.  gp / task tensors with a leading axis of Bt are sliced per part; `x` [Bt,3] is advanced in place.
+class ConcurrentControlLoop:
+    """The unicycle control step for a batch split into `parts` part batches, each on its OWN HIP stream (posterior
+    launch, then solve launch, in stream order).  Instances never interact, so this is the same computation as
+    `unicycle_control_step` on the whole batch -- every instance takes one control step per `step()` -- but the device
+    runs one part's solve launch (task rows + terms + SOCP + plant step: latency bound, one wave per CU) beside another
+    part's posterior stream (HBM bound), and a part's posterior fills the tail of the other's.  At the BASELINE config the
+    serialized solve launch is 15-19 % of a single-stream step.  (An event-chained variant -- all posterior launches on one
+    stream, solves on side streams -- was measured and rejected: each cross-stream dependency costs ~10 us on this
+    stack, which ate the whole gain.)  gp / task tensors with a leading axis of Bt are sliced per part; `x` [Bt,3] is
+    advanced in place.
 
-    step(events=None): events = [(ev_start, ev_stop)] per part brackets that part's posterior kernel.
-    Results: `y`, `status`, `iters` (views into one [Bt,...] buffer each); call `synchronize()` before reading."""
+    step(events=None): events = [(ev_start, ev_stop)] per part brackets that part's posterior kernel on its stream.
+    Results: `y`, `status`, `iters` ([Bt,...] buffers); call `synchronize()` before reading them on another stream."""
 
     def __init__(self, gp, task, x, parts=2, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100):
         Bt = x.shape[0]
@@ -523,11 +508,10 @@ class PipelinedControlLoop:
         Kob = task["centers"].shape[1]
         self.ws = control_workspace(Bt, Kob, x.dtype, dev)
         self.y, self.status, self.iters = self.ws["y"], self.ws["status"], self.ws["iters"]
-        self.stream_post = torch.cuda.Stream(device=dev)
-        self.streams_solve = [torch.cuda.Stream(device=dev) for _ in range(parts)]
-        self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(parts)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(parts)]
         self._steps = []
         shared_model = gp.get("Lop") is not None and gp["X"].shape[0] == 1 and Bt > 1
+        cur = torch.cuda.current_stream(dev)
         for c in range(parts):
             sl = slice(c * Bc, (c + 1) * Bc)
             cut = lambda v, lead: v[sl] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == lead) else v
@@ -536,12 +520,8 @@ class PipelinedControlLoop:
             wsc = {k: v[sl] for k, v in self.ws.items()}
             self._steps.append(unicycle_control_step_prepare(
                 gpc, taskc, wsc, x[sl], dt=dt, L_true=L_true, L_mean=L_mean, clf_gamma=clf_gamma, max_iters=max_iters,
-                two_stream=(self.stream_post, self.streams_solve[c]) + self._events[c]))
-        # whatever produced the inputs on the current stream happens before the first step
-        cur = torch.cuda.current_stream(dev)
-        self.stream_post.wait_stream(cur)
-        for s in self.streams_solve:
-            s.wait_stream(cur)
+                stream=self.streams[c]))
+            self.streams[c].wait_stream(cur)       # whatever produced the inputs on the current stream happens first
 
     def step(self, events=None):
         for c, st in enumerate(self._steps):
@@ -551,8 +531,7 @@ class PipelinedControlLoop:
                 st(events[c][0], events[c][1])
 
     def synchronize(self):
-        self.stream_post.synchronize()
-        for s in self.streams_solve:
+        for s in self.streams:
             s.synchronize()
 
 

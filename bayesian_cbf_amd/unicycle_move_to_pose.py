@@ -170,8 +170,10 @@ class LearnedShiftInvariantDynamics:
 
     def __init__(self, dt=None, learned_dynamics=None, learned_dynamics_class=None, mean_dynamics=None, max_train=200,
                  training_iter=100, shift_invariant=True, train_every_n_steps=20, enable_learning=True, device="cuda",
-                 dtype=torch.float64):
+                 dtype=torch.float64, hyper_refit_every=1, online_update=False):
+        """hyper_refit_every / online_update: see `online.OnlineLearner` (defaults = the reference's schedule)."""
         from .control_affine_model import ControlAffineRegressorExactRankOne
+        from .online import OnlineLearner
         self.max_train, self.training_iter, self.dt = max_train, training_iter, dt
         self.mean_dynamics = mean_dynamics or AckermannDrive()
         cls = learned_dynamics_class or ControlAffineRegressorExactRankOne
@@ -179,13 +181,32 @@ class LearnedShiftInvariantDynamics:
             self.state_size, self.ctrl_size, device=device, dtype=dtype)
         self.shift_invariant = shift_invariant
         self.train_every_n_steps, self.enable_learning = train_every_n_steps, enable_learning
-        self.Xtrain, self.Utrain = [], []
         self.current_state = None
+
+        def subsample(count, k):                      # :377-381: numpy shuffle of all indices, first max_train kept
+            idx = np.arange(count)
+            np.random.shuffle(idx)
+            return torch.from_numpy(idx[:k])
+
+        self._learner = OnlineLearner(self.learned_dynamics, self._residual_targets, dt, train_every_n_steps, max_train,
+                                      training_iter, subsample, enable_learning=enable_learning,
+                                      hyper_refit_every=hyper_refit_every, online_update=online_update,
+                                      transform=self._trans_invariant_wrapper)
+
+    # the controller's buffers (:340-354), owned by the learner
+    Xtrain = property(lambda self: self._learner.Xtrain)
+    Utrain = property(lambda self: self._learner.Utrain)
 
     def _trans_invariant_wrapper(self, X):
         if not self.shift_invariant:
             return X
         return torch.cat([torch.zeros_like(X[..., :self.state_size - 1]), X[..., self.state_size - 1:]], dim=-1)
+
+    def _residual_targets(self, X, U, Xdot):
+        """Xdot minus the prior-mean dynamics at the shift-invariant inputs (:361-375)."""
+        x0 = self._trans_invariant_wrapper(X)
+        md = self.mean_dynamics
+        return Xdot - (md.f_func(x0) + (md.g_func(x0) @ U.unsqueeze(-1)).squeeze(-1))
 
     def f_func(self, X):
         x0 = self._trans_invariant_wrapper(X)
@@ -196,31 +217,26 @@ class LearnedShiftInvariantDynamics:
         return self.mean_dynamics.g_func(x0) + self.learned_dynamics.g_func(x0).to(x0)
 
     def train(self, xi, uopt):
-        if len(self.Xtrain) > 0 and len(self.Xtrain) % int(self.train_every_n_steps) == 0 and self.enable_learning:
-            Xtrain = torch.cat(self.Xtrain).reshape(-1, self.Xtrain[0].shape[-1])
-            Utrain = torch.cat(self.Utrain).reshape(-1, self.Utrain[0].shape[-1])
-            XdotTrain = (Xtrain[1:, :] - Xtrain[:-1, :]) / self.dt
-            self.fit(Xtrain[:-1, :], Utrain[:-1, :], XdotTrain)
-        self.Xtrain.append(xi.detach())
-        self.Utrain.append(uopt.detach())
+        """Hand one visited (state, control) to the learner: refit / append on its schedule (:340-354)."""
+        self._learner.dt, self._learner.enable_learning = self.dt, self.enable_learning
+        self._learner.observe(xi, uopt)
 
     def get_kernel_param(self, name):
         return self.learned_dynamics.get_kernel_param(name)
 
     def fit(self, Xtrain, Utrain, XdotTrain, training_iter=None):
+        """Fit the residual model on given data (:356-386): prior mean removed, shift-invariant inputs, random subsample
+        to max_train."""
         if not len(Xtrain):
             return
+        XdotError = self._residual_targets(Xtrain, Utrain, XdotTrain)
         Xtrain = self._trans_invariant_wrapper(Xtrain)
-        md = self.mean_dynamics
-        XdotMean = md.f_func(Xtrain) + (md.g_func(Xtrain) @ Utrain.unsqueeze(-1)).squeeze(-1)
-        XdotError = XdotTrain - XdotMean
         if XdotTrain.shape[0] > self.max_train:
-            idx = np.arange(XdotTrain.shape[0])
-            np.random.shuffle(idx)
-            idx = torch.from_numpy(idx[:self.max_train]).to(Xtrain.device)
+            idx = self._learner.subsample(XdotTrain.shape[0], self.max_train).to(Xtrain.device)
             Xtrain, Utrain, XdotError = Xtrain[idx], Utrain[idx], XdotError[idx]
         self.learned_dynamics.fit(Xtrain, Utrain, XdotError,
                                   training_iter=self.training_iter if training_iter is None else training_iter)
+        self._learner.has_been_trained_once, self._learner.n_in_model = True, None
 
     def fu_func_gp(self, U):
         if self.enable_learning:

@@ -31,6 +31,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (MI355X_MICROARCH.md)
+ACHIEVED_METHOD = ("algorithmic units of ALL launches of the kernel in the timed region / time during which at least one of "
+                   "them was executing (HIP events around every launch, on its stream); kernel_ms = mean duration of one "
+                   "launch, as a kernel trace reports it -- with launches_per_step > 1 the launches overlap one another")
 
 
 def parse():
@@ -44,9 +47,8 @@ def parse():
     ap.add_argument("--variant", default="dense")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
     ap.add_argument("--parts", type=int, default=2,
-                    help="part batches of the pipelined step (ops.PipelinedControlLoop): posterior kernels back to back on "
-                         "one stream, each part's solve launch beside the other parts' posterior kernels; 1 = the whole "
-                         "batch on one stream, posterior then solve (the round-1 schedule)")
+                    help="part batches, each on its own HIP stream (ops.ConcurrentControlLoop): one part's solve launch "
+                         "runs beside another part's posterior stream; 1 = the whole batch on one stream")
     ap.add_argument("--regime", choices=["independent", "shared"], default="independent",
                     help="independent: every instance owns its GP (headline, HBM bound); shared: one learned model, "
                          "`batch` closed loops (Monte-Carlo rollouts, BASELINE configs[3]; matrix-core bound)")
@@ -89,7 +91,7 @@ def cpu_baseline(p, task, sample, N, n, m):
     """The oracle (a numpy / torch-CPU port of the reference's arithmetic, Cholesky factor cached as the reference caches
     it between refits) timed on this host on a bounded sample of the same workload, three ways:
     (a) reference style, one instance at a time, one thread; (b) vectorised over the batch, one thread; (c) vectorised,
-    every hardware thread.  `value` is the fastest of them, `cores` the threads it used."""
+    16 threads (more threads are slower, see below).  `value` is the fastest of them, `cores` the threads it used."""
     from threadpoolctl import threadpool_limits
     from oracle import batched as ob, control_step as ostep, gp_posterior as ogp
     L_mean = 4.0
@@ -128,9 +130,12 @@ def cpu_baseline(p, task, sample, N, n, m):
     L_, Vw_, UHB_ = torch.cat(Ls), torch.cat(Vws), torch.cat(UHBs)
     del Ls, Vws, UHBs
     ncpu = os.cpu_count() or 1
-    for threads in (1, ncpu):
+    # torch's CPU kernels on [B, 512, 512] batches stop scaling (and collapse under oversubscription: 256 threads took
+    # 240 s for the pass one thread does in 0.4 s on the EPYC 9575F host): the multi-thread variant uses 16
+    many = min(ncpu, 16)
+    for threads in ((1, many) if many > 1 else (1,)):
         torch.set_num_threads(threads)
-        reps = 1 if threads == 1 else 3
+        reps = 1 if threads == 1 else 2
         with threadpool_limits(limits=threads):
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -216,10 +221,8 @@ def main():
     torch.cuda.synchronize()
 
     # ---- one step = every instance takes one control step: posterior -> task rows + terms + SOCP -> plant step.
-    # Default schedule: the batch is split into `parts` part batches (instances never interact); ONE stream runs the
-    # parts' posterior kernels back to back, each part's solve launch runs on its own stream beside the other parts'
-    # posterior kernels (bcbf_unicycle_control_step_2s).  The HIP events bracket each posterior launch on the
-    # posterior stream, where those launches never overlap one another: a clean per-launch duration.
+    # Default schedule: the batch is split into `parts` part batches (instances never interact), each on its own HIP
+    # stream; the device overlaps one part's latency-bound solve launch with another part's HBM-bound posterior stream.
     S = max(1, args.parts)
     assert Bt % S == 0
     Bc = Bt // S
@@ -229,9 +232,9 @@ def main():
               Bm=p["Bm"][gsl], M0=p["M0"][gsl], A=p["A"][gsl])
     x = task["x"].clone()
     if S > 1:
-        loop = ops.PipelinedControlLoop(gp, task, x, parts=S, dt=dt_plant, L_true=L_true, L_mean=L_mean, clf_gamma=10.0,
-                                        max_iters=20)
-        ev_stream = [loop.stream_post] * S
+        loop = ops.ConcurrentControlLoop(gp, task, x, parts=S, dt=dt_plant, L_true=L_true, L_mean=L_mean, clf_gamma=10.0,
+                                         max_iters=20)
+        ev_stream = loop.streams
         step, status_t, iters_t = loop.step, loop.status, loop.iters
     else:
         ws = ops.control_workspace(Bt, 2, dtype, dev)
@@ -251,22 +254,38 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    # ---- timed region: exactly `steps` steps, HIP events around the dominant kernel (on its stream)
+    # ---- timed region: exactly `steps` steps, HIP events around every launch of the dominant kernel (on its stream)
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
           for _ in range(args.steps)]
     for row in ev:                      # instantiate the hipEvent handles (torch creates them on first record)
         for c, (e0, e1) in enumerate(row):
             e0.record(ev_stream[c])
             e1.record(ev_stream[c])
+    ev_base = torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
+    ev_base.record(ev_stream[0])
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(ev[s])
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for row in ev for a, b in row]))
+    # per-launch duration (what a kernel trace reports), and the time during which AT LEAST ONE launch of the kernel
+    # was executing (with one stream the two coincide; with concurrent parts the launches overlap one another, a
+    # launch's own duration then includes the time it shared the device, and bytes / union time is the rate the
+    # kernel sustained while it ran)
+    spans = sorted((ev_base.elapsed_time(a), ev_base.elapsed_time(b)) for row in ev for a, b in row)
+    kern_ms = float(np.mean([b_ - a_ for a_, b_ in spans]))
+    busy_ms, cur_a, cur_b = 0.0, spans[0][0], spans[0][1]
+    for a_, b_ in spans[1:]:
+        if a_ > cur_b:
+            busy_ms += cur_b - cur_a
+            cur_a, cur_b = a_, b_
+        else:
+            cur_b = max(cur_b, b_)
+    busy_ms += cur_b - cur_a
+    n_launch = len(spans)
     status, iters = status_t, iters_t
 
     n_opt = int((status == 0).sum())
@@ -286,8 +305,8 @@ def main():
         rank_ms = [float(t[0]) / args.steps * 1e3 for t in per_rank]
         stats[1:3] = sums
         elapsed = float(tmax[0])
-    schedule = ("%d part batches: posterior launches back to back on one stream, each part's solve launch beside the "
-                "others' posterior" % S) if S > 1 else "one stream: posterior launch, then solve launch"
+    schedule = ("%d part batches on %d streams (posterior launch, then solve launch, per part): one part's solve runs "
+                "beside another part's posterior" % (S, S)) if S > 1 else "one stream: posterior launch, then solve launch"
     comm = {"backend": ("rccl" if backend == "nccl" else backend) if multi else None, "world_size": comm_world,
             "per_rank_ms_per_step": rank_ms}
     total_instances = float(stats[2])
@@ -298,7 +317,7 @@ def main():
         # regime S: the factor is cache resident; the kernel is a triangular solve with (1+m) right-hand sides per
         # query on the matrix cores: N^2 flop per column (N^2/2 multiply-adds) -- Gram / mean accumulation not counted
         flops_launch = float(Bc) * (1 + m) * N * N
-        achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+        achieved = flops_launch * n_launch / (busy_ms * 1e-3) / 1e12
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; shared learned model" % (N, Bt),
             "value": value, "unit": "control steps/s (instance-steps: batch x batched steps/s)",
@@ -316,14 +335,15 @@ def main():
                          "posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernel is fp32, N <= ~1600)",
                          "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops_launch,
-                         "queries_per_launch": Bc},
+                         "traffic": None, "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps,
+                         "launches_per_step": S, "achieved_method": ACHIEVED_METHOD,
+                         "algorithmic_flops_per_launch": flops_launch, "queries_per_launch": Bc},
         }
         print(json.dumps(out))
     elif rank == 0:
         bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bc
         traffic, traffic_src = measured_traffic(N, Bc, args.dtype, bytes_launch)
-        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        achieved = bytes_launch * n_launch / (busy_ms * 1e-3) / 1e9
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; HBM GB/s vs peak" % (N, Bt),
             "value": value,
@@ -346,7 +366,9 @@ def main():
             "comm": comm,
             "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
+                         "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps, "launches_per_step": S,
+                         "achieved_method": ACHIEVED_METHOD,
+                         "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(p, task, args.cpu_sample, N, n, m)

@@ -196,15 +196,18 @@ int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X,
 /* Posterior jets: value and first x-derivatives of the posterior factors (one query per instance, or per
  * query of a shared GP).  CT = (1+m)(1+n) right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] of the same stream:
  *   G[Bt,CT,CT] = Wj'Wj,  Mj[Bt,n,CT] = Vw'Wj   (Mk = M0' + Mj[:, :C]; dMk/dx_d = Mj[:, (1+d)C:(2+d)C]),
- * plus Mk, Bk as bcbf_posterior_step.  Replaces autograd through custom_predict inside GradientGP
- * (gp_algebra.py:340-402).  Compiled for (n,m) in {(1,1),(2,1),(2,2),(3,2)}. */
+ * plus Mk, Bk as bcbf_posterior_step.  Wj (optional, may be NULL): [Bt, Np, CT] = L^-1 [Phi, dPhi/dx_d] itself
+ * (Np = N rounded up to 32), from which the caller forms derivative kernels between two DIFFERENT states,
+ * d/dx_d d/dx'_e B_k(x,x') = d2k/dx_d dx'_e Bm - dW_d(x)'dW_e(x')  (GradientGP.knl(x, x'), gp_algebra.py:355-393).
+ * Replaces autograd through custom_predict inside GradientGP (gp_algebra.py:340-402).
+ * Compiled for (n,m) in {(1,1),(2,1),(2,2),(3,2)}. */
 int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
                             const float* ell, const float* s2, const float* Bm, const float* M0,
-                            const float* xq, float* Mk, float* Bk, float* G, float* Mj, int shared,
+                            const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj, int shared,
                             int Bt, int N, int n, int m, void* stream);
 int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
                             const double* ell, const double* s2, const double* Bm, const double* M0,
-                            const double* xq, double* Mk, double* Bk, double* G, double* Mj, int shared,
+                            const double* xq, double* Mk, double* Bk, double* G, double* Mj, double* Wj, int shared,
                             int Bt, int N, int n, int m, void* stream);
 
 /* K8, rel-degree 2: CBC2 = grad(L_f h)'(f + g u) + kalpha[0] h + kalpha[1] L_f h as a GP in u, closed form of
@@ -368,33 +371,6 @@ int bcbf_unicycle_control_step_f64(
     const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
     double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
     int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream);
-
-/* Two-stream form of bcbf_unicycle_control_step, for a caller that splits its batch into (two or more) part batches:
- * the posterior launch of this part goes to stream_post, its solve launch (task rows + terms + SOCP + plant step) to
- * stream_solve, chained by caller-provided events -- the posterior first waits for ev_state (recorded here after the
- * solve launch: the next posterior of THESE instances queries the state this solve advances), the solve waits for
- * ev_post (recorded here after the posterior).  With all parts on ONE stream_post that stream runs posterior kernels
- * back to back (HBM bound) while each part's solve (latency bound, one wave per CU) runs beside the other parts'
- * posterior kernels: the 15 % of a step that the serialized solve launch costs disappears.  Instances never interact,
- * so every instance still takes exactly one control step per call.  ev_start / ev_stop bracket the posterior kernel
- * on stream_post (after the wait).  An event that was never recorded does not block (first call). */
-int bcbf_unicycle_control_step_2s_f32(
-    const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
-    const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
-    const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
-    float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
-    float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
-    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
-    void* ev_start, void* ev_stop, void* stream_post, void* ev_post, void* ev_state, void* stream_solve);
-int bcbf_unicycle_control_step_2s_f64(
-    const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
-    const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
-    const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,
-    const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
-    const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
-    double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
-    int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream_post, void* ev_post,
-    void* ev_state, void* stream_solve);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

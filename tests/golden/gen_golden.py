@@ -425,8 +425,113 @@ def main_cogp():
     gen_cogp('diag_N24', N=24, b=4, seed=63, diag=True)
 
 
+# ----------------------------------------------------------------------------------------------
+# gp_algebra: the propagation rules themselves, node by node (bayes_cbf/gp_algebra.py:109-255, 319-402), on the trees
+# the reference's own tests build (tests/test_gp_algebra.py:163-239: L1h, grad L1h, L2h, cbc2_gp) and on a tree that is
+# not a safety condition (a weighted sum of two inner products with different leaves), at pairs of DIFFERENT states
+def gen_gp_algebra(tag, n, m, N, seed, kind):
+    from bayes_cbf.cbc2 import cbc2_gp
+    from bayes_cbf.gp_algebra import DeterministicGP, GradientGP
+    reg, X, U, Xdot = make_regressor(cam.ControlAffineRegressor, n, m, N, seed)
+    out = dict(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), kind=kind, **hyper(reg, n, m))
+    h, gh, hess = _h_funcs(kind, n)
+    k_alpha = [1.0, 3.0]
+    out["k_alpha"] = np.array(k_alpha)
+    torch.manual_seed(seed + 7)
+    S = 3
+    xs = 0.8 * (2 * torch.rand(S, n) - 1)
+    xps = xs + 0.3 * (2 * torch.rand(S, n) - 1)
+    us = torch.randn(S, m)
+    cvec = torch.randn(n)
+    dvec = torch.randn(n)
+    out.update(xs=t2n(xs), xps=t2n(xps), us=t2n(us), cvec=t2n(cvec), dvec=t2n(dvec))
+    recs = {}
+
+    def rec(key, val):
+        recs.setdefault(key, []).append(t2n(val).astype(np.float64))
+
+    with RandRecorder() as rr:
+        for i in range(S):
+            x, xp, u = xs[i].clone(), xps[i].clone(), us[i].clone()
+            f_gp = reg.f_func_gp()
+            fu_gp = reg.fu_func_gp(u)
+            L1h = DeterministicGP(gh, shape=(n,), name="grad h").t() @ f_gp
+            gL1h = GradientGP(L1h, x_shape=(n,))
+            L2h = gL1h.t() @ fu_gp
+            cbc2 = cbc2_gp(h, gh, reg, u, k_alpha)
+            mix = (DeterministicGP(lambda z: cvec * torch.cos(z), shape=(n,), name="c").t() @ fu_gp) * 0.7 \
+                + DeterministicGP(lambda z: dvec + z, shape=(n,), name="d").t() @ f_gp
+            for name, e in (("L1h", L1h), ("L2h", L2h), ("cbc2", cbc2), ("mix", mix)):
+                rec(name + "_mean", e.mean(x))
+                rec(name + "_knl_xx", e.knl(x, x))
+                rec(name + "_knl_xxp", e.knl(x, xp))
+                if name != "cbc2":       # cbc2_gp makes its own fu leaf: no covariance is registered with ours (:292-300)
+                    rec(name + "_covar_fu_xxp", e.covar(fu_gp, x, xp))
+                rec(name + "_covar_f_xxp", e.covar(f_gp, x, xp))
+            rec("gL1h_mean", gL1h.mean(x))
+            rec("gL1h_knl_xx", gL1h.knl(x, x))
+            rec("gL1h_knl_xxp", gL1h.knl(x, xp))
+            rec("gL1h_covar_fu_xx_same", gL1h.covar(fu_gp, x, x))        # same tensor: total derivative (:395-402)
+            rec("gL1h_covar_fu_xxp", gL1h.covar(fu_gp, x, xp))
+            rec("gL1h_covar_f_xxp", gL1h.covar(f_gp, x, xp))
+            rec("h", h(x)); rec("gh", gh(x)); rec("hess", hess(x))
+    assert len(rr.draws) == 1            # only the K_b jitter (vector-variate regressor)
+    out.update(jitter_rand=np.stack(rr.draws), L=t2n(reg._cache["perturbed_cholesky"]))
+    for k, v in recs.items():
+        out["t_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "gpalgebra_%s.npz" % tag), **out)
+    print("gpalgebra_%s: n=%d m=%d N=%d kind=%s" % (tag, n, m, N, kind))
+
+
+def handmade_trees(ga, P):
+    """Two hand-made leaf GPs (torch callables, a registered cross-covariance), a deterministic vector function and
+    trees over them that use every node type -- incl. the inner product of two RANDOM vectors.  `ga` is the algebra
+    module (the reference's here, the build's in tests/test_gp_algebra_cpu.py); P holds the parameters."""
+    n = P["W1"].shape[0]
+    W1, W2, A1, A2, C12 = (torch.as_tensor(P[k], dtype=torch.float64) for k in ("W1", "W2", "A1", "A2", "C12"))
+    rbf = lambda x, xp, l: torch.exp(-0.5 * ((x - xp) ** 2).sum() / l ** 2)
+    f = ga.GaussianProcess(lambda x: torch.sin(W1 @ x), lambda x, xp: rbf(x, xp, 0.9) * A1, (n,), name="f")
+    g = ga.GaussianProcess(lambda x: torch.cos(W2 @ x) + x, lambda x, xp: rbf(x, xp, 1.3) * A2 * (1 + 0.1 * x @ xp),
+                           (n,), name="g")
+    f.register_covar(g, lambda x, xp: rbf(x, xp, 1.1) * C12)
+    d = ga.DeterministicGP(lambda x: torch.tanh(x) + 0.5 * x.flip(0), shape=(n,), name="d")
+    L1 = d.t() @ f
+    gL1 = ga.GradientGP(L1, x_shape=(n,))
+    L2 = gL1.t() @ g
+    rr = f.t() @ g
+    mix = (L1 * 0.7 + rr) * -1.3 + d.t() @ g
+    return f, g, dict(L1=L1, gL1=gL1, L2=L2, rr=rr, mix=mix)
+
+
+def gen_gp_algebra_handmade():
+    import bayes_cbf.gp_algebra as rga
+    torch.manual_seed(0)
+    n = 3
+    A1, A2 = torch.randn(n, n), torch.randn(n, n)
+    P = dict(W1=t2n(torch.randn(n, n)), W2=t2n(torch.randn(n, n)), A1=t2n(A1 @ A1.t() + torch.eye(n)),
+             A2=t2n(A2 @ A2.t() + torch.eye(n)), C12=t2n(0.3 * torch.randn(n, n)))
+    f, g, trees = handmade_trees(rga, P)
+    xs, xps = 0.5 * torch.randn(3, n), 0.5 * torch.randn(3, n)
+    out = dict(P, xs=t2n(xs), xps=t2n(xps))
+    for name, e in trees.items():
+        for key, fn in (("mean", lambda x, xp: e.mean(x)), ("knl_xxp", lambda x, xp: e.knl(x, xp)),
+                        ("knl_xx", lambda x, xp: e.knl(x, x)), ("covar_g_xxp", lambda x, xp: e.covar(g, x, xp)),
+                        ("covar_f_xx_same", lambda x, xp: e.covar(f, x, x))):
+            out["t_%s_%s" % (name, key)] = np.stack([t2n(fn(xs[i].clone(), xps[i].clone())) for i in range(3)])
+    np.savez_compressed(os.path.join(HERE, "gpalgebra_handmade.npz"), **out)
+    print("gpalgebra_handmade: n=%d, %d values" % (n, len(out)))
+
+
+def main_gp_algebra():
+    gen_gp_algebra("pendulum_N16", n=2, m=1, N=16, seed=71, kind="radial")
+    gen_gp_algebra("n3m2_N24", n=3, m=2, N=24, seed=72, kind="generic")
+    gen_gp_algebra_handmade()
+
+
 if __name__ == '__main__':
-    if 'cogp' in sys.argv:
+    if 'gp_algebra' in sys.argv:
+        main_gp_algebra()
+    elif 'cogp' in sys.argv:
         main_cogp()
     elif 'controllers' in sys.argv:
         main_controllers()

@@ -62,5 +62,77 @@ def test_unsupported_shapes_raise():
         ga.lower(g.t() @ fu_gp + g.t() @ fu2)                 # two different models
     with pytest.raises(NotImplementedError):
         ga.lower(ga.DeterministicGP(lambda x: x[0], shape=(1,)) * 2.0)
-    with pytest.raises(NotImplementedError):
-        ga.GradientGP(g.t() @ fu_gp, x_shape=(2,)).mean(torch.zeros(2))   # gradient of F u, not of L_f h
+    # gradient of F u, not of L_f h: no fused form -- it goes to the general evaluator (gp_eval, GPU tests)
+    assert ga.GradientGP(g.t() @ fu_gp, x_shape=(2,))._lie1_or_none() is None
+    assert ga.GradientGP(g.t() @ f_gp, x_shape=(2,))._lie1_or_none() is not None
+
+
+def test_jet_product_rule_against_autograd():
+    """gp_eval's jets (value, d/dx, d/dx', d2/dx dx') through sums, products, transposes and traces equal torch.autograd
+    on the same scalar function of (x, x')."""
+    from bayesian_cbf_amd import gp_eval as ge
+    torch.manual_seed(0)
+    n = 3
+    A1, A2 = torch.randn(2, 2, n, dtype=torch.float64), torch.randn(2, 2, n, dtype=torch.float64)
+
+    def mats(x, xp):
+        Mx = torch.sin(A1 @ x) + torch.outer(x[:2], x[1:])            # [2,2] function of x
+        Mp = torch.cos(A2 @ xp) * xp[0]                               # [2,2] function of x'
+        Mxp = torch.exp(-0.5 * ((x - xp) ** 2).sum()) * (A1 @ x) @ (A2 @ xp).t()   # both
+        return Mx, Mp, Mxp
+
+    def scalar(x, xp):
+        Mx, Mp, Mxp = mats(x, xp)
+        return (Mx.t() @ Mxp @ Mp).trace() * 2.0 + (Mxp @ Mxp.t()).trace()
+
+    def jet_of(fn, x, xp, r, c):
+        v = fn(x, xp)
+        Jx, Jp = torch.autograd.functional.jacobian(lambda a, b: fn(a, b).reshape(-1), (x, xp))
+        H = torch.autograd.functional.jacobian(
+            lambda b: torch.autograd.functional.jacobian(lambda a: fn(a, b).reshape(-1), x, create_graph=True), xp)
+        return ge.Jet(v.reshape(r, c), Jx.reshape(r, c, n).permute(2, 0, 1), Jp.reshape(r, c, n).permute(2, 0, 1),
+                      H.reshape(r, c, n, n).permute(2, 3, 0, 1))
+
+    x, xp = torch.randn(n, dtype=torch.float64), torch.randn(n, dtype=torch.float64)
+    jMx = jet_of(lambda a, b: mats(a, b)[0], x, xp, 2, 2)
+    jMp = jet_of(lambda a, b: mats(a, b)[1], x, xp, 2, 2)
+    jMxp = jet_of(lambda a, b: mats(a, b)[2], x, xp, 2, 2)
+    out = ge.jadd(ge.jscale(ge.jtrace(ge.jmatmul(ge.jmatmul(ge.jT(jMx), jMxp), jMp)), 2.0),
+                  ge.jtrace(ge.jmatmul(jMxp, ge.jT(jMxp))))
+    ref = jet_of(scalar, x, xp, 1, 1)
+    for got, want in ((out.v, ref.v), (out.dx, ref.dx), (out.dp, ref.dp), (out.dxp, ref.dxp)):
+        assert torch.allclose(got, want, rtol=1e-10, atol=1e-12)
+
+
+def test_general_evaluator_on_handmade_leaves_matches_reference_golden():
+    """Every propagation rule of gp_algebra.py:109-255, 319-402 -- incl. the inner product of two RANDOM vectors and
+    GradientGP's mean / derivative kernel / cross-covariance (total derivative when x' IS x) -- on leaves made of plain
+    torch callables, against values recorded from the executed reference (tests/golden/gen_golden.py gp_algebra:
+    `handmade_trees`, restated here on this package's algebra).  Runs on the CPU: such leaves have no device source."""
+    import os
+    import numpy as np
+    from bayesian_cbf_amd import gp_algebra as ga
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpalgebra_handmade.npz"))
+    n = G["W1"].shape[0]
+    W1, W2, A1, A2, C12 = (torch.as_tensor(G[k], dtype=torch.float64) for k in ("W1", "W2", "A1", "A2", "C12"))
+    rbf = lambda x, xp, l: torch.exp(-0.5 * ((x - xp) ** 2).sum() / l ** 2)
+    f = ga.GaussianProcess(lambda x: torch.sin(W1 @ x), lambda x, xp: rbf(x, xp, 0.9) * A1, (n,), name="f")
+    g = ga.GaussianProcess(lambda x: torch.cos(W2 @ x) + x, lambda x, xp: rbf(x, xp, 1.3) * A2 * (1 + 0.1 * x @ xp),
+                           (n,), name="g")
+    f.register_covar(g, lambda x, xp: rbf(x, xp, 1.1) * C12)
+    d = ga.DeterministicGP(lambda x: torch.tanh(x) + 0.5 * x.flip(0), shape=(n,), name="d")
+    L1 = d.t() @ f
+    gL1 = ga.GradientGP(L1, x_shape=(n,))
+    L2 = gL1.t() @ g
+    rr = f.t() @ g
+    mix = (L1 * 0.7 + rr) * -1.3 + d.t() @ g
+    trees = dict(L1=L1, gL1=gL1, L2=L2, rr=rr, mix=mix)
+    for i in range(G["xs"].shape[0]):
+        x, xp = torch.as_tensor(G["xs"][i]), torch.as_tensor(G["xps"][i])
+        for name, e in trees.items():
+            for key, val in (("mean", e.mean(x)), ("knl_xxp", e.knl(x, xp)), ("knl_xx", e.knl(x, x)),
+                             ("covar_g_xxp", e.covar(g, x, xp)), ("covar_f_xx_same", e.covar(f, x, x))):
+                want = G["t_%s_%s" % (name, key)][i]
+                got = val.detach().numpy().reshape(want.shape)
+                np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(want).max()),
+                                           err_msg="%s.%s[%d]" % (name, key, i))

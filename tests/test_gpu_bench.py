@@ -39,7 +39,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "GB/s" and "traffic_source" in rf
     assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-12
     # kernel time <= step time; bytes/step over the step time cannot beat the kernel's own rate
-    assert rf["kernel_ms"] <= out["ms_per_step"] * 1.05
+    assert rf["kernel_ms"] <= out["ms_per_step"] * 1.05 and rf["kernel_busy_ms_per_step"] <= out["ms_per_step"] * 1.05
+    # achieved = all launches' bytes over the time at least one of them ran
+    total = rf["algorithmic_bytes_per_launch"] * rf["launches_per_step"]
+    assert abs(total / (rf["kernel_busy_ms_per_step"] * 1e-3) / 1e9 - rf["achieved"]) < 1e-6 * rf["achieved"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
 

@@ -317,11 +317,10 @@ def test_c1_pendulum_learn_dynamics_matrix_vector_N64(ops):
 
 @pytest.mark.parametrize("dtype,shared", [(torch.float32, False), (torch.float64, False), (torch.float32, True)],
                          ids=["f32", "f64", "f32-shared-model"])
-def test_pipelined_two_stream_loop_equals_single_stream_steps(ops, dtype, shared):
-    """ops.PipelinedControlLoop (bcbf_unicycle_control_step_2s: part batches, posterior launches on one stream, solve
-    launches on their own streams, chained by events) runs the same kernels on slices of the batch: after several
-    closed-loop steps the states, controls and statuses are bit-identical to the single-stream entry point.  (A missing
-    or misplaced event dependency shows up as a different trajectory: the posterior would query a stale state.)"""
+def test_concurrent_part_batches_equal_single_stream_steps(ops, dtype, shared):
+    """ops.ConcurrentControlLoop (part batches on their own HIP streams) runs the same two launches on slices of the
+    batch: after several closed-loop steps the states, controls and statuses are bit-identical to the single-stream
+    entry point on the whole batch."""
     from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
     Bt, N, steps = 384, 160, 6
     p = make_instances(1 if shared else Bt, N, 3, 2, dtype=dtype, device=DEV, seed=21)
@@ -339,7 +338,7 @@ def test_pipelined_two_stream_loop_equals_single_stream_steps(ops, dtype, shared
         ops.unicycle_control_step(gp, task, ws, x1, **kw)
         ys.append(ws["y"].clone())
     torch.cuda.synchronize()
-    loop = ops.PipelinedControlLoop(gp, task, x2, parts=3, **kw)
+    loop = ops.ConcurrentControlLoop(gp, task, x2, parts=3, **kw)
     for _ in range(steps):
         loop.step()
     loop.synchronize()

@@ -870,3 +870,157 @@ def test_reference_demo_entry_points(tmp_path):
                                                           dt=0.01, learned_dynamics=reg, training_iter=10, mean_L=2.0)
     assert len(run["steps"]) == 90 and np.isfinite(run["state"]).all() and np.isfinite(run["uopt"]).all()
     assert reg.Xtrain is not None and reg.Xtrain.shape[0] >= 29            # the controller fed the learner and refit
+
+
+def _closed_loop_samples(T_, seed=3):
+    rng = np.random.default_rng(seed)
+    xs = [np.array([-3.0, -1.0, -0.7])]
+    us = []
+    for k in range(T_):
+        u = np.array([1.0 + 0.5 * np.sin(0.3 * k), 0.8 * np.cos(0.2 * k)]) + 0.05 * rng.normal(size=2)
+        th = xs[-1][2]
+        xs.append(xs[-1] + 0.02 * np.array([np.cos(th) * u[0], np.sin(th) * u[0], u[1] / 1.0]))
+        us.append(u)
+    return np.array(xs[:-1]), np.array(us)
+
+
+def test_online_update_through_train_equals_oracle_refit_from_scratch():
+    """`LearnedShiftInvariantDynamics.train` with online_update -- every observation enters the regressor
+    through `bcbf_gp_append` as soon as its finite-difference target exists.  After k appends the regressor's posterior
+    equals the ORACLE's from-scratch refactorisation of the same points (what the reference computes at its next
+    scheduled refit, unicycle_move_to_pose.py:340-386), jitter draws replayed."""
+    from oracle import gp_posterior as ogp
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    from bayesian_cbf_amd.unicycle_move_to_pose import AckermannDrive, LearnedShiftInvariantDynamics
+    dt_ = 0.02
+    dyn = LearnedShiftInvariantDynamics(dt=dt_, mean_dynamics=AckermannDrive(L=12.0), training_iter=0,
+                                        train_every_n_steps=10, hyper_refit_every=1000, online_update=True, device=DEV,
+                                        learned_dynamics_class=ControlAffineRegressor)   # (no second jitter in its predict)
+    reg = dyn.learned_dynamics
+    draws = []
+    orig = reg.rand_fn
+    reg.rand_fn = lambda k: draws.append(orig(k)) or draws[-1]
+    X, U = _closed_loop_samples(48)
+    appended = []
+    orig_append = reg.append_data
+    reg.append_data = lambda *a, **k: appended.append(a[0].shape[0]) or orig_append(*a, **k)
+    for k in range(48):
+        dyn.train(t(X[k]), t(U[k]))
+        if k == 11:
+            _ = reg.custom_predict(t(X[:1]))                      # a query in between (it draws nothing in this class)
+    N = reg.Xtrain.shape[0]
+    assert N == 46 and len(dyn.Xtrain) == 48                      # samples 0..45 have their target; 46's needs x_47+1
+    assert sum(appended) == N - 9 and max(appended) <= 2          # 9 at the first scheduled refit, the rest one by one
+    # the oracle on the same points (shift-invariant inputs, prior mean removed), the same jitter
+    Xs = np.concatenate([np.zeros((N, 2)), X[:N, 2:]], axis=1)
+    Xdot = (X[1:N + 1] - X[:N]) / dt_
+    prior = np.stack([np.array([[np.cos(th), 0.0], [np.sin(th), 0.0], [0.0, 1.0 / 12.0]]) @ u for th, u in zip(X[:N, 2], U[:N])])
+    np.testing.assert_allclose(host(reg.Xtrain), Xs, atol=1e-14)
+    np.testing.assert_allclose(host(reg.XdotTrain), Xdot - prior, rtol=1e-9, atol=1e-11)
+    jit = np.concatenate([host(d) for d in draws])
+    assert jit.shape == (N,)
+    hp = {k: host(reg.get_kernel_param(k)) for k in ("A", "B", "lengthscale", "scalefactor")}
+    st = ogp.refit_state(Xs, U[:N], Xdot - prior, hp["B"], hp["lengthscale"].reshape(-1), float(hp["scalefactor"]),
+                         host(reg.model.M0), jit[None])
+    assert st["tries"] == 1
+    Xq = np.concatenate([np.zeros((5, 2)), np.linspace(-1.0, 0.5, 5)[:, None]], axis=1)
+    Uq = np.tile(np.array([[1.0, 0.3]]), (5, 1))
+    reg.rand_fn = orig
+    mean, cov = reg.custom_predict(t(Xq), t(Uq))
+    mean_o, _, cov_o = ogp.custom_predict(Xs, st["UH"], st["Y"], st["L"], hp["A"], hp["B"], hp["lengthscale"].reshape(-1),
+                                          float(hp["scalefactor"]), host(reg.model.M0), Xq, ogp.homogeneous_controls(Uq))
+    np.testing.assert_allclose(host(mean), mean_o, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(host(cov), cov_o, rtol=1e-7, atol=1e-9 * np.abs(cov_o).max())
+
+
+def host(x):
+    return x.detach().cpu().double().numpy()
+
+
+def test_learner_schedule_hyper_refit_every_and_window():
+    """OnlineLearner's schedule: scheduled points every `train_every_n_steps` calls as upstream; with hyper_refit_every = 2
+    every other one appends instead of refitting; once the buffer exceeds max_train the window is re-drawn (random
+    subsample, as upstream) and factored from scratch.  Defaults reproduce the reference: a full fit at every point."""
+    from bayesian_cbf_amd.unicycle_move_to_pose import AckermannDrive, LearnedShiftInvariantDynamics
+    X, U = _closed_loop_samples(75)
+    for kw, expect in ((dict(), ["fit9", "fit19", "fit29", "fit39", "fit40", "fit40", "fit40"]),
+                       (dict(hyper_refit_every=2), ["fit9", "app10", "fit29", "app10", "fit40", "fit40", "fit40"])):
+        dyn = LearnedShiftInvariantDynamics(dt=0.02, mean_dynamics=AckermannDrive(L=12.0), training_iter=0,
+                                            train_every_n_steps=10, max_train=40, device=DEV, **kw)
+        reg = dyn.learned_dynamics
+        log = []
+        fit0, app0 = reg.fit, reg.append_data
+        reg.fit = lambda *a, **k: log.append("fit%d" % a[0].shape[0]) or fit0(*a, **k)
+        reg.append_data = lambda *a, **k: log.append("app%d" % a[0].shape[0]) or app0(*a, **k)
+        np.random.seed(0)
+        for k in range(75):
+            dyn.train(t(X[k]), t(U[k]))
+        assert log == expect, (kw, log)
+        m, c = reg.custom_predict(t(X[:3] * np.array([0, 0, 1.0])), t(U[:3]))
+        assert torch.isfinite(m).all() and torch.isfinite(c).all() and reg.Xtrain.shape[0] == 40
+
+
+GPALG_FILES = sorted(glob.glob(os.path.join(GOLDEN, "gpalgebra_*.npz")))
+
+
+def _h_funcs_like_generator(kind, n):
+    import math
+    if kind == "radial":
+        dc, tc = math.pi / 8, math.pi / 4
+        h = lambda x: math.cos(dc) - torch.cos(x[0] - tc)
+        gh = lambda x: torch.cat([torch.sin(x[0:1] - tc), x.new_zeros(n - 1)])
+        return h, gh
+    Qm = torch.tensor([[1.0, 0.3, -0.2], [0.3, 0.7, 0.1], [-0.2, 0.1, 1.3]], dtype=torch.float64)[:n, :n]
+    wv = torch.tensor([0.5, -0.8, 0.3], dtype=torch.float64)[:n]
+    h = lambda x: 0.5 * x @ Qm.to(x) @ x + torch.sin(wv.to(x) @ x) - 0.2
+    gh = lambda x: Qm.to(x) @ x + torch.cos(wv.to(x) @ x) * wv.to(x)
+    return h, gh
+
+
+@pytest.mark.parametrize("path", GPALG_FILES, ids=os.path.basename)
+def test_gp_algebra_general_trees_match_reference(path):
+    """SURVEY 8a row gp_algebra: every propagation rule (sum, scalar multiple, inner product with the product-of-Gaussians
+    terms, transpose, GradientGP mean / derivative kernel / cross-covariance) on the trees of the reference's own tests
+    (tests/test_gp_algebra.py:163-239: L1h, grad L1h, L2h, cbc2_gp) and on a tree that is no safety condition, at pairs of
+    DIFFERENT states -- against values recorded from the executed reference (autograd through custom_predict)."""
+    from bayesian_cbf_amd.cbc2 import cbc2_gp
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    from bayesian_cbf_amd.gp_algebra import DeterministicGP, GradientGP
+    g = np.load(path)
+    reg = make(ControlAffineRegressor, g, [g["jitter_rand"][0]])
+    n = g["X"].shape[1]
+    h, gh = _h_funcs_like_generator(str(g["kind"]), n)
+    cvec, dvec = t(g["cvec"]), t(g["dvec"])
+    k_alpha = list(g["k_alpha"])
+    S = g["xs"].shape[0]
+
+    def check(key, i, val):
+        want = g["t_" + key][i]
+        got = val.detach().cpu().double().numpy().reshape(want.shape)
+        scale = max(np.abs(want).max(), 1e-3)
+        assert np.abs(got - want).max() <= 2e-7 * scale, "%s[%d]: %s vs %s" % (key, i, got, want)
+
+    for i in range(S):
+        x, xp, u = t(g["xs"][i]), t(g["xps"][i]), t(g["us"][i])
+        f_gp, fu_gp = reg.f_func_gp(), reg.fu_func_gp(u)
+        L1h = DeterministicGP(gh, shape=(n,), name="grad h").t() @ f_gp
+        gL1h = GradientGP(L1h, x_shape=(n,))
+        L2h = gL1h.t() @ fu_gp
+        cbc2 = cbc2_gp(h, gh, reg, u, k_alpha)
+        mix = (DeterministicGP(lambda z: cvec * torch.cos(z), shape=(n,), name="c").t() @ fu_gp) * 0.7 \
+            + DeterministicGP(lambda z: dvec + z, shape=(n,), name="d").t() @ f_gp
+        for name, e in (("L1h", L1h), ("L2h", L2h), ("cbc2", cbc2), ("mix", mix)):
+            check(name + "_mean", i, e.mean(x))
+            check(name + "_knl_xx", i, e.knl(x, x))
+            check(name + "_knl_xxp", i, e.knl(x, xp))
+            if name != "cbc2":
+                check(name + "_covar_fu_xxp", i, e.covar(fu_gp, x, xp))
+            check(name + "_covar_f_xxp", i, e.covar(f_gp, x, xp))
+        check("gL1h_mean", i, gL1h.mean(x))
+        check("gL1h_knl_xx", i, gL1h.knl(x, x))
+        check("gL1h_knl_xxp", i, gL1h.knl(x, xp))
+        check("gL1h_covar_fu_xx_same", i, gL1h.covar(fu_gp, x, x))
+        check("gL1h_covar_fu_xxp", i, gL1h.covar(fu_gp, x, xp))
+        check("gL1h_covar_f_xxp", i, gL1h.covar(f_gp, x, xp))
+        # the leaf also answers for a composed partner (gp_algebra.py:301-302)
+        check("L1h_covar_fu_xxp", i, fu_gp.covar(L1h, x, xp))

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""fp64 refit: the workgroup-per-instance form against the one-wave-per-instance form (BCBF_REFIT_WAVE), same inputs."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bayesian_cbf_amd import ops
+from bayesian_cbf_amd.synthetic import make_instances
+from tools.bench_configs import timeit
+
+for Bt, N, n, m in ((1024, 256, 2, 1), (4096, 256, 2, 1), (4096, 512, 3, 2), (1024, 1024, 3, 2), (512, 512, 3, 2), (256, 256, 2, 1)):
+    p = make_instances(Bt, N, n, m, dtype=torch.float64, device="cuda", seed=5)
+    row = dict(batch=Bt, N=N)
+    for form in ("0", "1"):
+        os.environ["BCBF_REFIT_WAVE"] = form
+        t = timeit(lambda: ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"]), reps=5, warm=2)
+        info = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])[2]
+        row["ms_wave" if form == "1" else "ms_workgroup"] = t
+        row["fail_" + form] = int((info != 0).sum())
+        row["TFLOPs_wave" if form == "1" else "TFLOPs_workgroup"] = Bt * N ** 3 / 3.0 / (t * 1e-3) / 1e12
+    print(json.dumps(row), flush=True)
