@@ -39,22 +39,40 @@ def _newer(a, bs):
     return all(os.path.getmtime(b) <= ta for b in bs)
 
 
+# --asan: host-side AddressSanitizer build -- the launchers, argument checks and error plumbing are
+# instrumented, the device code is not (-fno-gpu-sanitize: GPU ASan needs xnack+, not available on this pool).  A
+# separate artefact, libbcbf_asan.so, for CPU-side runs of tests/cabi_asan_driver.c under ASan; never the product library.
+ASAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"]
+ASAN = False
+
+
 def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(OBJ + ("_asan" if ASAN else ""), os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src), os.path.join(ROOT, "include", "bcbf.h"), os.path.abspath(__file__)]
     deps += [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]     # every shared header
     if not force and _newer(obj, deps):
         return obj, False
     tuning = os.environ.get("BCBF_EXTRA_HIPCC_FLAGS", "").split()        # e.g. -DBCBF_PS_UNR=2 for tuning sweeps
-    cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + tuning + ["-c", os.path.join(CSRC, src), "-o", obj]
+    flags = [f for f in FLAGS if not (ASAN and f == "-O3")] + (ASAN_FLAGS if ASAN else [])
+    cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(src, []) + tuning + ["-c", os.path.join(CSRC, src), "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
     return obj, True
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, asan=False):
+    global ASAN
+    ASAN = bool(asan)
+    try:
+        return _build(force, verbose)
+    finally:
+        ASAN = False
+
+
+def _build(force, verbose):
+    LIB = os.path.join(HERE, "libbcbf_asan.so") if ASAN else globals()["LIB"]
+    os.makedirs(OBJ + ("_asan" if ASAN else ""), exist_ok=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in results]
@@ -62,6 +80,8 @@ def build(force=False, verbose=False):
         # link to a temporary name and rename: another rank of a multi-process launch never sees a half-written library
         tmp = "%s.tmp.%d" % (LIB, os.getpid())
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
+        if ASAN:
+            cmd += ["-fsanitize=address", "-shared-libsan"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             if os.path.exists(tmp):
@@ -76,4 +96,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv)

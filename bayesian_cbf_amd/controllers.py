@@ -151,8 +151,10 @@ class MeanAdjustedModel(SumDynamicModels):
         self._learner._refit_from_scratch(self.training_iter)
 
     def train(self, xi, uopt):
-        self._learner.dt, self._learner.enable_learning = self.dt, bool(self.enable_learning)
-        self._learner.observe(xi, uopt)
+        ln = self._learner
+        ln.dt, ln.enable_learning, ln.training_iter = self.dt, bool(self.enable_learning), self.training_iter
+        ln.max_train, ln.train_every_n_steps = self.max_train, self.train_every_n_steps
+        ln.observe(xi, uopt)
 
 
 def _rows_to_cone(G, h):

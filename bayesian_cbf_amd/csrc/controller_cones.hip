@@ -168,7 +168,10 @@ extern "C" {
 int bcbf_controller_cones_rows(const int* kind, int K, int m, int objective) {
     if (K < 0 || K > bcbf::CCK || (K > 0 && !kind) || m < 1) return BCBF_EINVAL;
     int rows = objective ? m + 2 : 0;
-    for (int k = 0; k < K; ++k) rows += kind[k] == 2 ? 1 : m + 2;
+    for (int k = 0; k < K; ++k) {
+        if (kind[k] < 0 || kind[k] > 2) return BCBF_EINVAL;       // 0 stability cone, 1 safety cone, 2 linear row
+        rows += kind[k] == 2 ? 1 : m + 2;
+    }
     return rows;
 }
 int bcbf_controller_cones_f32(const float* terms, const float* u_ref, const int* kind, const double* factor,

@@ -34,6 +34,15 @@ using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 #define BCBF_RW64_KS 4           // k-steps (of 4 columns) per software-pipeline stage of the update stream
 #endif
 
+// -DBCBF_RW64_PROF (development): per-section cycle counts of every instance land in Ldense[b][0][1..7]
+#ifdef BCBF_RW64_PROF
+#define RW_T0() long long t_ = __builtin_readcyclecounter()
+#define RW_ACC(k) do { const long long n_ = __builtin_readcyclecounter(); prof[k] += n_ - t_; t_ = n_; } while (0)
+#else
+#define RW_T0() do {} while (0)
+#define RW_ACC(k) do {} while (0)
+#endif
+
 constexpr int RW_WPB = BCBF_RW64_WPB;
 constexpr int LS = NB + 1;       // padded row stride of the 32x32 LDS tile
 
@@ -106,6 +115,10 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 
     int fail = 0;
     const int nblk = Np / NB;
+#ifdef BCBF_RW64_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RW_T0();
     for (int J = 0; J < nblk && fail == 0; ++J) {
         const int col0 = J * NB;
         if (!FROM_DENSE) {
@@ -119,6 +132,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
             }
         }
         __builtin_amdgcn_wave_barrier();
+        RW_ACC(0);                                             // column staging
         double ainv[2][2][4];                                  // inv(L_JJ) as panel-solve A operands, loaded after the diagonal tile
 
         for (int I = J; I < nblk; ++I) {
@@ -161,6 +175,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                         acc[cb][ib][r] = val;
                     }
             }
+            RW_ACC(1);                                            // K_b values
             // ---- S' -= L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight)
             constexpr int KS = BCBF_RW64_KS;
             double a_nxt[KS][2], b_nxt[KS][2];
@@ -194,6 +209,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                             acc[cb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib], 0, 0, 0);
             }
 
+            RW_ACC(2);                                            // update stream
             if (I == J) {
                 // =================== the diagonal tile: factor L_JJ, invert it ===================
 #pragma unroll
@@ -284,6 +300,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                RW_ACC(3);                                        // factor
                 if (bad != 0 && bad <= N) fail = bad;
                 if (Ld && lane < NB && col0 + lane < N) {
                     for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = sh.tile[lane][c];
@@ -335,6 +352,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     for (int cb = 0; cb <= cbp; ++cb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.tile[16 * cbp + j16][16 * cb + 4 * r + g];
+                RW_ACC(4);                                        // inverse + stores
             } else {
                 // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of S' are the B operands)
 #pragma unroll
@@ -356,12 +374,17 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                         }
                     }
                 }
+                RW_ACC(5);                                        // panel solve + stores
             }
         }
         __threadfence_block();                 // this block column's panels are read back (by other lanes) from here on
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) info[b] = fail;
+#ifdef BCBF_RW64_PROF
+    if (Ld && lane == 0 && N > 8)
+        for (int k = 0; k < 6; ++k) Ld[1 + k] = (double)prof[k];
+#endif
 }
 
 // Called by bcbf_refit_mfma_f64 for batches: returns 0 after launching, or -1 when the shape is not taken here.

@@ -218,8 +218,10 @@ class LearnedShiftInvariantDynamics:
 
     def train(self, xi, uopt):
         """Hand one visited (state, control) to the learner: refit / append on its schedule (:340-354)."""
-        self._learner.dt, self._learner.enable_learning = self.dt, self.enable_learning
-        self._learner.observe(xi, uopt)
+        ln = self._learner                  # the schedule's knobs are plain attributes upstream: honour later changes
+        ln.dt, ln.enable_learning, ln.training_iter = self.dt, self.enable_learning, self.training_iter
+        ln.max_train, ln.train_every_n_steps = self.max_train, self.train_every_n_steps
+        ln.observe(xi, uopt)
 
     def get_kernel_param(self, name):
         return self.learned_dynamics.get_kernel_param(name)
