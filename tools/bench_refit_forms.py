@@ -7,7 +7,9 @@ from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
 from tools.bench_configs import timeit
 
-for Bt, N, n, m in ((1024, 256, 2, 1), (4096, 256, 2, 1), (4096, 512, 3, 2), (1024, 1024, 3, 2), (512, 512, 3, 2), (256, 256, 2, 1)):
+GRID = [(Bt, N) for N in (128, 256, 512, 1024) for Bt in (64, 128, 256, 512, 1024, 4096) if Bt * N * N * 8 * 0.6 < 24e9]
+for Bt, N in GRID:
+    n, m = (2, 1) if N <= 256 else (3, 2)
     p = make_instances(Bt, N, n, m, dtype=torch.float64, device="cuda", seed=5)
     row = dict(batch=Bt, N=N)
     for form in ("0", "1"):

@@ -12,11 +12,11 @@ CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 VARIANTS = {
     "rw_base": [],
     "rw_prof": ["-DBCBF_RW64_PROF"],
+    "rw_occ2": ["-DBCBF_RW64_OCC=2"],
     "rw_ks2": ["-DBCBF_RW64_KS=2"],
     "rw_ks8": ["-DBCBF_RW64_KS=8"],
-    "rw_wpb4": ["-DBCBF_RW64_WPB=4"],
     "rw_wpb1": ["-DBCBF_RW64_WPB=1"],
-    "rw_occ1": ["-DBCBF_RW64_OCC=1"],
+    "rw_wpb3": ["-DBCBF_RW64_WPB=3"],
 }
 
 
