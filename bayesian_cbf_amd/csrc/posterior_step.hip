@@ -81,7 +81,11 @@ template <> struct BufLoad<double> {
 // NQ > 1 (values only, shared GP): one workgroup answers NQ queries with the same stream of L -- NQ C right-hand-side
 // columns -- so the factor crosses the L2 -> CU fabric once per NQ queries (the fp64 form of regime S, which has no
 // matrix-core kernel, is bound by exactly that traffic).
-template <typename T, int C, int NS, int NJ, int NQ = 1>
+// RHS (values only, NQ = 1): the same stream as a plain triangular solve -- the right-hand sides are GIVEN rows
+// instead of kernel values: r_i = X[i][0..n) - sum_a UHB[i][a] M0[a][0..n)  (X := Xdot [N,n], UHB := UH [N,cu], M0 [cu,n]:
+// the whitened targets Vw = L^-1 (Xdot - UH M0) of bcbf_potrs, control_affine_model.py:525-545), written to Wout as
+// [N, n]; no Gram / mean.  C = number of solved columns (>= n; extra columns are zero).
+template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false>
 __global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256), (NJ > 0 ? 1 : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
@@ -90,6 +94,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                       T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
                       int n, const T* __restrict__ lin, int nq) {
     static_assert(NQ == 1 || NJ == 0, "several queries per workgroup: values only");
+    static_assert(!RHS || (NJ == 0 && NQ == 1), "right-hand-side mode: values only, one system per workgroup");
+    const int cu = RHS ? nq : 0;        // RHS mode: columns of UH (the launcher passes it in the nq slot)
     constexpr int V = Vec<T>::V;
     constexpr int CT = C * (1 + NJ) * NQ;     // right-hand-side columns
     using VecT = typename Vec<T>::type;
@@ -116,8 +122,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(lop), 0, (int)(lop_elems<V>(Np) * sizeof(T)), 0x00020000);
     const T* __restrict__ Xb = X + (size_t)gb * N * n;
-    const T* __restrict__ UHBb = UHB + (size_t)gb * N * C;
-    const T* __restrict__ Vwb = Vw + (size_t)gb * N * n;
+    const T* __restrict__ UHBb = UHB + (size_t)gb * N * (RHS ? cu : C);
+    const T* __restrict__ Vwb = RHS ? nullptr : Vw + (size_t)gb * N * n;
 
     // ---- prologue: r = Phi rows owned by this thread:  phi_i = s2 exp(-1/2 |(x_i - xq)/ell|^2) * UHB_i
     T xqr[NQ][NS], iell[NS];
@@ -126,14 +132,21 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {       // a query slot beyond the last query repeats the last one (not stored)
             const int qx = NQ == 1 ? b : min(b * NQ + qi, nq - 1);
-            xqr[qi][d] = d < n ? xq[(size_t)qx * n + d] : T(0);
+            xqr[qi][d] = (!RHS && d < n) ? xq[(size_t)qx * n + d] : T(0);
         }
-        iell[d] = d < n ? T(1) / ell[(size_t)gb * n + d] : T(0);
+        iell[d] = (!RHS && d < n) ? T(1) / ell[(size_t)gb * n + d] : T(0);
     }
-    const T s2 = s2p[gb];
+    const T s2 = RHS ? T(0) : s2p[gb];
     // optional linear part of the data kernel, k = s2 (exp(..) + lin x'x') (the CoGP comparator's RBF + Linear,
     // control_affine_model.py:1121-1122); lin == NULL -> 0
-    const T linv = lin != nullptr ? lin[gb] : T(0);
+    const T linv = (!RHS && lin != nullptr) ? lin[gb] : T(0);
+    T m0r[RHS ? BCBF_MAX_CTRL_DIM + 1 : 1][RHS ? C : 1];           // RHS mode: the prior mean M0 [cu, n]
+    if constexpr (RHS) {
+#pragma unroll
+        for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a)
+#pragma unroll
+            for (int c = 0; c < C; ++c) m0r[a][c] = (a < cu && c < n) ? M0[((size_t)gb * cu + a) * n + c] : T(0);
+    }
     // fp32 fast path: residuals held as register PAIRS over two consecutive rows, so that the update is one
     // v_pk_fma_f32 per (row pair, column) with w broadcast by op_sel -- the compiler's own packing mixes row- and
     // column-pairs and pays ~0.9 v_mov per packed multiply-add to shuffle the pairs (47 % of the loop's VALU issue).
@@ -148,10 +161,34 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(Xb), 0, (int)((size_t)N * n * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(UHBb), 0, (int)((size_t)N * C * sizeof(T)), 0x00020000);
+        const_cast<T*>(UHBb), 0, (int)((size_t)N * (RHS ? cu : C) * sizeof(T)), 0x00020000);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int rb = r == 0 ? rbA : rbB;
+        if constexpr (RHS) {
+            // given right-hand sides: r_i = Xdot_i - M0' uh_i  (rows >= N, columns >= n and idle lanes: zeros)
+            T yv[V][C], uh[V][BCBF_MAX_CTRL_DIM + 1];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int i = rb * V + v;
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    yv[v][c] = BufLoad<T>::one(rsrc_x, (live && c < n) ? (i * n + c) * (int)sizeof(T) : OOB, 0);
+#pragma unroll
+                for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a)
+                    uh[v][a] = BufLoad<T>::one(rsrc_u, (live && a < cu) ? (i * cu + a) * (int)sizeof(T) : OOB, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    T y = yv[v][c];
+#pragma unroll
+                    for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a) y -= uh[v][a] * m0r[a][c];
+                    BCBF_ACC(r, v, c) = y;
+                }
+            continue;
+        }
         T xv[V][NS], uv[V][C];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -282,9 +319,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // whitened targets of the block's 32 rows (lanes 0-31 of wave 0), fetched one block ahead with the same
     // bounds-checked loads: the diagonal step is the serial part of the block, a global load there is exposed latency
     const __amdgpu_buffer_rsrc_t rsrc_vw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(Vwb), 0, (int)((size_t)N * n * sizeof(T)), 0x00020000);
+        const_cast<T*>(RHS ? Xb : Vwb), 0, (int)((size_t)N * n * sizeof(T)), 0x00020000);
     T vwn[NS];
     auto issue_vw = [&](int J) {
+        if constexpr (RHS) return;
 #pragma unroll
         for (int d = 0; d < NS; ++d) {
             const int row = J * NB + di;
@@ -325,7 +363,12 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             if (dh == 0) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) wbuf[di][c] = w[c];
-                if (NJ > 0 && Wout != nullptr) {        // jets: all CT columns [Phi, dPhi/dx_1 ..] of this row
+                if constexpr (RHS) {                    // the solved rows ARE the output: Vw[N, n]
+                    if (row0 + di < N) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) if (c < n) Wout[((size_t)b * N + row0 + di) * n + c] = w[c];
+                    }
+                } else if (NJ > 0 && Wout != nullptr) {        // jets: all CT columns [Phi, dPhi/dx_1 ..] of this row
 #pragma unroll
                     for (int c = 0; c < CT; ++c) Wout[((size_t)b * Np + row0 + di) * CT + c] = w[c];
                 } else if (Wout != nullptr) {
@@ -337,12 +380,16 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         }
                 }
                 int g = 0;
+                if constexpr (!RHS) {
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
                     for (int a = 0; a < CQ; ++a)
 #pragma unroll
                         for (int c = a; c < CQ; ++c) gram[g++] += w[qi * CQ + a] * w[qi * CQ + c];
+                }
+                (void)g;
+                if constexpr (RHS) { /* no mean accumulation */ } else {
 #if BCBF_PS_VWPF
 #pragma unroll
                 for (int d = 0; d < NS; ++d) {            // Vw rows of this block were fetched a block ahead (zeros
@@ -361,6 +408,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         }
                 }
 #endif
+                }
             }
         }
         __syncthreads();
@@ -382,6 +430,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     }
 
     // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
+    if constexpr (RHS) return;
     if (tid < 64) {
         double gsum[NG];
 #pragma unroll
@@ -496,6 +545,29 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
 #undef BCBF_PJ_LAUNCH
     return check_launch("posterior_step");
 }
+
+// Forward solve Vw = L^-1 (Xdot - UH M0) on the streaming structure above (bcbf_potrs without alpha, n <= 4):
+// returns BCBF_OK after launching, or 1 when the shape is not taken here (the caller falls back to potrs_kernel).
+template <typename T>
+int launch_forward_stream(const T* Lop, const T* Xdot, const T* UH, const T* M0, T* Vw, int Bt, int N, int n, int cu,
+                          void* stream) {
+    constexpr int V = Vec<T>::V;
+    const int Np = round_up(N, NB);
+    const int threads = round_up(Np / V / 2, 64);
+    if (n < 1 || n > 4 || cu < 1 || cu > BCBF_MAX_CTRL_DIM + 1 || threads > (sizeof(T) == 8 ? 512 : 256)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(Bt), block(threads);
+#define BCBF_FS_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, true>), grid, block, 0, st, Lop, (const T*)nullptr, Xdot, UH, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, M0, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, Vw, (T*)nullptr, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, cu)
+    switch (n) {
+        case 1: case 2: BCBF_FS_LAUNCH(2); break;
+        case 3: BCBF_FS_LAUNCH(3); break;
+        default: BCBF_FS_LAUNCH(4); break;
+    }
+#undef BCBF_FS_LAUNCH
+    return check_launch("potrs_stream");
+}
+template int launch_forward_stream<float>(const float*, const float*, const float*, const float*, float*, int, int, int, int, void*);
+template int launch_forward_stream<double>(const double*, const double*, const double*, const double*, double*, int, int, int, int, void*);
 
 }  // namespace bcbf
 
