@@ -405,7 +405,12 @@ class ControlAffineRegressor:
         """Vector-variate prediction (control_affine_model.py:390-613): mean[b,n] and
         cov[1, b n, b' n] = kron(k_b(x,x') - v'v', A)."""
         if grad_gp:
-            raise NotImplementedError("grad_gp (derivative GP by autograd) is served by the jet kernels, not here")
+            # upstream this branch cannot run: its gradient mean has shape [b, (1+m), n, n] and `fu_mean_test + kb_star.t() @ alpha`
+            # (:547) raises "The size of tensor a (4) must match the size of tensor b (2)" for every input (executed with
+            # the golden harness; `_grad_fu_func_mean` is its only caller and is itself unused).  The derivative GP is
+            # served by GradientGP on the jet kernel (gp_algebra.GradientGP, ops.posterior_jets).
+            raise NotImplementedError("custom_predict(grad_gp=True) fails upstream too (shape error at control_affine_model.py"
+                                      ":547); use gp_algebra.GradientGP(...) / ops.posterior_jets for the derivative GP")
         Xtest = self._ensure_device_dtype(Xtest_in)
         Xtestp = self._ensure_device_dtype(Xtestp_in) if Xtestp_in is not None else Xtest
         UHtest = self._uh(Xtest, Utest_in, UHfill)
@@ -512,8 +517,11 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
                 - torch.einsum("bnc,pnd->bpcd", W, Wp))
         # make_psd(BkXX) on the [b(1+m)] x [b'(1+m)] matrix: 1e-5 * rand on its diagonal (:1089, :907-910)
         # with its retry schedule: x10 until the perturbed matrix factors, RuntimeError after 10 tries (:903-919).
-        # The factorisation is the library's (bcbf_potrf, one instance of size b(1+m) <= 2048; larger query sets keep the
-        # first draw unchecked -- the reference would spend O((b(1+m))^3) there)
+        # The factorisation is the library's (bcbf_potrf) and is run for query sets of up to one 32 x 32 tile
+        # (b(1+m) <= 32: the control loop's b = 1, where a non-positive B_k would break the cone conversion downstream;
+        # ~30 us).  Larger query sets keep the first draw unchecked: a posterior covariance plus a 1e-5 jitter fails only
+        # by rounding, and the check is a latency-bound O((b(1+m))^3) factorisation -- 2.5 ms for the speed test's
+        # 20 x 20 grid, more than the whole prediction (1.1 ms).
         if b == bp:
             idx = torch.arange(b, device=self.device)
             factor, tries = 1e-5, 10
@@ -521,7 +529,7 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
                 jit = factor * self.rand_fn(b * C)
                 out = BkXX.clone()
                 out[idx, idx] += torch.diag_embed(jit.reshape(b, C))
-                if b * C > 2048:
+                if b * C > 32:
                     break
                 _, info, _ = ops.potrf(out.permute(0, 2, 1, 3).reshape(1, b * C, b * C).contiguous())
                 if int(info[0]) == 0:

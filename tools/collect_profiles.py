@@ -1,57 +1,109 @@
 #!/usr/bin/env python3
-"""Copy the summaries of the last tools/run_prof.sh / run_pmc_mfma.sh / bench runs from gpurun_out/ into profiles/."""
-import collections, csv, glob, json, os, shutil
+"""Copy the summaries of the last `tools/run_profiles.sh <round>` run from gpurun_out/<round>/ into profiles/<round>_*.
+
+    python tools/collect_profiles.py r02
+"""
+import collections, csv, glob, json, os, shutil, sys
+
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
-latest = lambda pat: sorted(glob.glob(R + pat), key=os.path.getmtime)[-1]
-for tag, dst in (("prof_indep", "profiles/r01_bench_kernel_stats.csv"), ("prof_shared", "profiles/r01_bench_shared_kernel_stats.csv")):
-    rows = list(csv.reader(open(latest("gpurun_out/%s/*/*_kernel_stats.csv" % tag))))
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = R + "gpurun_out/%s/" % ROUND
+DST = R + "profiles/%s_" % ROUND
+
+
+def latest(pat):
+    hits = sorted(glob.glob(SRC + pat), key=os.path.getmtime)
+    return hits[-1] if hits else None
+
+
+def last_json_line(path):
+    lines = [l for l in open(path) if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+# ---- kernel-trace summaries (libbcbf kernels only; the torch kernels of the synthetic-data generator are dropped)
+for tag in ("default", "parts1", "shared"):
+    f = latest("prof_%s/*/*_kernel_stats.csv" % tag)
+    if not f:
+        continue
+    rows = list(csv.reader(open(f)))
     out = [rows[0]] + [r for r in rows[1:] if "bcbf::" in r[0]]
-    csv.writer(open(R + dst, "w")).writerows(out)
-    print(dst, [(r[0].split("(")[0][-42:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
-for a, b in (("bench_default.json", "r01_bench_default.json"), ("bench_shared_prof.json", "r01_bench_shared_under_rocprof.json"),
-             ("bench_shared.json", "r01_bench_shared.json"), ("configs.jsonl", "r01_configs_refit_potrs_posterior.jsonl"),
-             ("online_growth_f64.json", "r01_online_growth_f64.json"), ("speed_test.jsonl", "r01_speed_test_matrix_vector.jsonl"),
-             ("learn_matrix_vector.jsonl", "r01_learn_dynamics_matrix_vector.jsonl")):
-    if os.path.exists(R + "gpurun_out/" + a):
-        shutil.copy(R + "gpurun_out/" + a, R + "profiles/" + b)
-d = json.load(open(R + "profiles/r01_bench_default.json"))
-print("default", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel_ms"], d["roofline"]["traffic"], d["cpu_baseline"]["value"])
-d = json.load(open(R + "profiles/r01_bench_shared.json"))
-print("shared", d["value"], d["batched_steps_per_s"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel_ms"])
-out = {}
-for tag, pat in (("bench_shared", "gpurun_out/pmc_shared/*/*_counter_collection.csv"),
-                 ("bench_configs C2", "gpurun_out/pmc_refit_C2/*/*_counter_collection.csv"),
-                 ("bench_configs C3f64", "gpurun_out/pmc_refit_C3f64/*/*_counter_collection.csv"),
-                 ("bench_configs C3", "gpurun_out/pmc_refit_C3/*/*_counter_collection.csv"),
-                 ("bench_configs N1024f64", "gpurun_out/pmc_refit_N1024f64/*/*_counter_collection.csv")):
-    if not glob.glob(R + pat):
-        continue                       # no fresh counter pass (tools/run_pmc_mfma.sh): keep the committed numbers
+    csv.writer(open(DST + "bench_%s_kernel_stats.csv" % tag, "w")).writerows(out)
+    print(tag, [(r[0].split("(")[0][-44:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
+
+# ---- bench lines
+for a in ("bench_default", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_shared", "bench_shared_prof", "bench_f64"):
+    if os.path.exists(SRC + a + ".json") and os.path.getsize(SRC + a + ".json"):
+        d = last_json_line(SRC + a + ".json")
+        json.dump(d, open(DST + a + ".json", "w"), indent=1)
+        rf = d["roofline"]
+        print(a, round(d["value"]), round(d["ms_per_step"], 4), "frac", round(rf["frac"], 4), "kernel_ms", round(rf["kernel_ms"], 4),
+              "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
+for a in ("configs.jsonl", "refit_forms.jsonl", "online_growth_f64.json", "reldeg2.jsonl", "speed_test.jsonl",
+          "learn_matrix_vector.jsonl", "mc_rollouts.txt"):
+    if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
+        shutil.copy(SRC + a, DST + a)
+
+# ---- HBM traffic of the roofline kernel from the three counter passes per schedule
+NOTE = ("FETCH_SIZE is in KiB and, on gfx950, counts 1/2 of the bytes of wide coalesced reads: bytes = FETCH_SIZE*1024*2; "
+        "WRITE_SIZE*1024 exact.  Cross-check: TCC_MISS_sum * 128 B.  (MI355X_MICROARCH.md, HBM / rocprofv3 section)")
+for tag, sched, batch in (("default", "", 2048), ("defaultparts1", " --parts 1", 4096)):
+    raw = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
+        f = latest("pmc_traffic_%s_%s/*/*_counter_collection.csv" % (tag, c))
+        if not f:
+            continue
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "posterior_step_kernel<float, 3, 4, 0, 1, false>" in r["Kernel_Name"]:      # (not the potrs instantiation)
+                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in per.items():
+            raw[k] = dict(launches=len(v), mean=sum(v) / len(v), min=min(v), max=max(v))
+    if "FETCH_SIZE" not in raw or "WRITE_SIZE" not in raw:
+        continue
+    alg = 543744 * batch
+    fetch = raw["FETCH_SIZE"]["mean"] * 1024 * 2
+    write = raw["WRITE_SIZE"]["mean"] * 1024
+    out = dict(kernel="posterior_step_kernel<float,3,4,0,1,false>",
+               workload=dict(N_train=512, batch=batch, dtype="f32", n=3, m=2, schedule="bench.py" + sched),
+               commands=["rocprofv3 --pmc %s --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0%s"
+                         % (c, sched) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum")],
+               raw=raw, corrections=NOTE, fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
+               hbm_bytes_per_launch=fetch + write,
+               tcc_miss_bytes_per_launch=raw.get("TCC_MISS_sum", {}).get("mean", 0) * 128,
+               algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(fetch + write) / alg)
+    name = DST + ("pmc_traffic.json" if tag == "default" else "pmc_traffic_parts1.json")
+    json.dump(out, open(name, "w"), indent=1)
+    print("traffic", tag, round(out["hbm_bytes_per_launch"]), "x algorithmic", round(out["traffic_over_algorithmic"], 4),
+          "launches", raw["FETCH_SIZE"]["launches"])
+
+# ---- MFMA utilisation
+passes = {}
+for tag, sub in (("bench.py --regime shared --parts 1", "pmc_shared"), ("bench_configs C2", "pmc_refit_C2"),
+                 ("bench_configs C3f64", "pmc_refit_C3f64"), ("bench_configs C3", "pmc_refit_C3"),
+                 ("bench_configs N1024f64", "pmc_refit_N1024f64")):
+    f = latest(sub + "/*/*_counter_collection.csv")
+    if not f:
+        continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(latest(pat))):
+    for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "mfma" not in k and "posterior_shared" not in k:
+        if "refit" not in k and "posterior_shared" not in k:
             continue
         agg[(k.split("(")[0].replace("void bcbf::", ""), int(r["Grid_Size"]) // int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for (name, wgs), c in sorted(agg.items()):
         m = {k: sum(v) / len(v) for k, v in c.items()}
-        if wgs < 64:
+        if wgs < 64 or "SQ_VALU_MFMA_BUSY_CYCLES" not in m:
             continue
         util = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
         dd = dict(kernel=name, workgroups=wgs, launches=len(next(iter(c.values()))), gpu_cycles=m["GRBM_GUI_ACTIVE"] / 8,
                   mfma_busy_cycles_all_simds=m["SQ_VALU_MFMA_BUSY_CYCLES"], mfma_util=round(util, 4),
                   wait_any_frac=round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3), wait_inst_frac=round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3),
                   active_inst_frac=round(m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3))
-        out.setdefault(tag, []).append(dd)
-        print(tag, dd["kernel"], dd["workgroups"], dd["mfma_util"])
-old = json.load(open(R + "profiles/r01_pmc_mfma.json"))
-if out:
-    json.dump(dict(note=old["note"], passes=out), open(R + "profiles/r01_pmc_mfma.json", "w"), indent=1)
-for l in open(R + "profiles/r01_configs_refit_potrs_posterior.jsonl"):
-    d = json.loads(l)
-    print(d["config"], round(d["refit_ms"], 3), round(d["refit_TFLOPs"], 1), round(d["potrs_ms"], 3), round(d["posterior_ms"], 4), round(d["posterior_GBs_algorithmic"]))
-for l in open(R + "profiles/r01_speed_test_matrix_vector.jsonl"):
-    d = json.loads(l)
-    print(d["regressor"], d["N"], round(d["s_per_call"] * 1e3, 2), "ms", round(d["speedup_vs_published"], 1), round(d["fit_s"], 2), round(d["heldout_rel_rms_err"], 4))
-for l in open(R + "profiles/r01_learn_dynamics_matrix_vector.jsonl"):
-    d = json.loads(l)
-    print("learn", d["N_train"], d["seed"], round(d["seconds"], 2), "s  err matrix/vector", round(d["error_matrix"], 3), round(d["error_vector"], 3))
+        passes.setdefault(tag, []).append(dd)
+        print("mfma", tag, dd["kernel"], dd["workgroups"], dd["mfma_util"], "wait", dd["wait_any_frac"])
+if passes:
+    note = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+            "GRBM_GUI_ACTIVE --kernel-trace (own pass per command).  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs "
+            "* 1024 SIMDs): fraction of SIMD-cycles with the MFMA pipe busy, averaged over the launches of the kernel.")
+    json.dump(dict(note=note, passes=passes), open(DST + "pmc_mfma.json", "w"), indent=1)
