@@ -23,7 +23,7 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
         T* y, int* status, int* iters, T dt, T L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,          \
         void* ev_start, void* ev_stop, void* stream) {                                                                 \
         if (Bt <= 0) return BCBF_OK;                                                                                   \
-        if (!x || !grad || !cst || !fhat || !ghat || Kob < 0 || Kob + 1 > BCBF_MAX_CONSTRAINTS) return BCBF_EINVAL;    \
+        if (!x || !grad || !cst || !fhat || !ghat || Kob < 0 || Kob + 1 > BCBF_MAX_QUAD_CONSTRAINTS) return BCBF_EINVAL;    \
         hipStream_t st = (hipStream_t)stream;                                                                          \
         if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);                                                  \
         /* Lop == NULL: no learned model in the loop -- (Mk, Bk) are the caller's (fixed-kernel model: 0 and I) */    \

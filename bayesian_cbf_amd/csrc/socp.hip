@@ -11,16 +11,19 @@
 namespace bcbf {
 
 // Generic small cone QP with runtime dimensions (reference optimizers.py adapters).
-constexpr int GNV = 6, GL = 8, GNQ = 4, GD = 6;
-struct QDims { int d[GNQ]; };
+// Two instantiations: up to 4 second-order cones (the controllers' programs: registers), up to BCBF_MAX_CONSTRAINTS
+// (programs with more cones than the quad kernels take, e.g. a third obstacle: larger arrays, slower, rare)
+constexpr int GNV = 6, GL = 8, GNQ = 4, GNQ_WIDE = BCBF_MAX_CONSTRAINTS, GD = 6;
+struct QDims { int d[GNQ_WIDE]; };
 
+template <int NQMAX>
 __global__ void __launch_bounds__(64)
 coneqp_kernel(const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ G,
               const double* __restrict__ h, int nv, int l, QDims qd, int nq, double* __restrict__ x,
               int* __restrict__ status, int* __restrict__ iters, int Bt, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= Bt) return;
-    using Solver = ConeQP<double, GNV, GL, GNQ, GD, false>;
+    using Solver = ConeQP<double, GNV, GL, NQMAX, GD, false>;
     Solver S;
     S.dims_runtime(nv, l, qd.d, nq);
     const int K = S.K;
@@ -49,16 +52,20 @@ int bcbf_coneqp_f64(const double* P, const double* q, const double* G, const dou
     using namespace bcbf;
     if (Bt <= 0) return BCBF_OK;
     if (!P || !q || !G || !h || !x || !status) return BCBF_EINVAL;
-    if (nv < 1 || nv > GNV || l < 0 || l > GL || nq < 0 || nq > GNQ || (nq > 0 && !qdims)) return BCBF_EINVAL;
+    if (nv < 1 || nv > GNV || l < 0 || l > GL || nq < 0 || nq > GNQ_WIDE || (nq > 0 && !qdims)) return BCBF_EINVAL;
     QDims qd;
-    for (int k = 0; k < GNQ; ++k) {
+    for (int k = 0; k < GNQ_WIDE; ++k) {
         qd.d[k] = k < nq ? qdims[k] : 0;
         if (k < nq && (qdims[k] < 2 || qdims[k] > GD)) return BCBF_EINVAL;
     }
     if (l + nq == 0) return BCBF_EINVAL;
     if (max_iters <= 0) max_iters = 100;
-    hipLaunchKernelGGL(coneqp_kernel, dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, q, G, h, nv, l, qd,
-                       nq, x, status, iters, Bt, max_iters);
+    if (nq <= GNQ)
+        hipLaunchKernelGGL((coneqp_kernel<GNQ>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, q, G, h, nv, l,
+                           qd, nq, x, status, iters, Bt, max_iters);
+    else
+        hipLaunchKernelGGL((coneqp_kernel<GNQ_WIDE>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, q, G, h,
+                           nv, l, qd, nq, x, status, iters, Bt, max_iters);
     return check_launch("coneqp");
 }
 }

@@ -317,6 +317,8 @@ def socp(w, r, cones, relax_mask, rho, max_iters=100, out=None):
     _chk(w, r, cones, relax_mask, rho)
     Bt, K, _ = cones.shape
     m = r.shape[1]
+    if K > 4:                                  # more cones than the quad kernel's four lanes: the generic solver
+        return _socp_generic(w, r, cones, relax_mask, rho, max_iters, out)
     if out is None:
         y = torch.empty(Bt, m + 1, dtype=w.dtype, device=w.device)
         status = torch.empty(Bt, dtype=torch.int32, device=w.device)
@@ -328,11 +330,44 @@ def socp(w, r, cones, relax_mask, rho, max_iters=100, out=None):
     return y, status, iters
 
 
+def _socp_generic(w, r, cones, relax_mask, rho, max_iters=100, out=None):
+    """The CLF-CBF program with more than four cones (e.g. a third obstacle), through `bcbf_coneqp_f64`:
+    min sum w_i (u_i - r_i)^2 + w_m relax^2  s.t.  c_k'u + d_k + relax_mask_k relax >= rho |A_k u + b_k|
+    as  min 1/2 y'P y + q'y, G y + s = h, s in Q^{m+2} x ... (rows [-c', -relax_mask; -rho A, 0], h = [d; rho b]).
+    Row assembly is host-side tensor plumbing; the solve is the library's (fp64)."""
+    Bt, K, _ = cones.shape
+    m = r.shape[1]
+    f64 = dict(dtype=torch.float64, device=w.device)
+    A, b, c, d = (t.to(torch.float64) for t in unpack_cones(cones, m))
+    nv, D = m + 1, m + 2
+    rho64 = rho.to(torch.float64)
+    G = torch.zeros(Bt, K, D, nv, **f64)
+    G[:, :, 0, :m] = -c
+    G[:, :, 0, m] = -relax_mask.to(torch.float64)[None, :]
+    G[:, :, 1:, :m] = -rho64[:, None, None, None] * A
+    h = torch.cat([d[..., None], rho64[:, None, None] * b], dim=-1)
+    P = torch.diag_embed(2.0 * w.to(torch.float64)).contiguous()
+    q = torch.zeros(Bt, nv, **f64)
+    q[:, :m] = -2.0 * w[:, :m].to(torch.float64) * r.to(torch.float64)
+    x, status, iters = coneqp(P, q, G.reshape(Bt, K * D, nv).contiguous(), h.reshape(Bt, K * D).contiguous(), 0, [D] * K,
+                              max_iters=max_iters)
+    y = x.to(w.dtype)
+    if out is not None:
+        out[0].copy_(y); out[1].copy_(status); out[2].copy_(iters)
+        return out
+    return y, status, iters
+
+
 def cbc_socp(Mk, Bk, A, grad, cst, sign, fhat, ghat, w, r, relax_mask, rho, max_iters=100, want_terms=False):
     """cbc_terms + socp in one launch (four lanes per instance).  Returns (y, status, iters, cones, cstatus, terms)."""
     _chk(Mk, Bk, A, grad, cst, sign, fhat, ghat, w, r, relax_mask, rho)
     Bt, K, n = grad.shape
     m = ghat.shape[2]
+    if K > 4:                                  # two launches + the generic solver (see `socp`)
+        terms, cones, cstatus = cbc_terms(Mk, Bk, A, grad, cst, sign, fhat, ghat, want_terms=want_terms)
+        y, status, iters = _socp_generic(w, r, cones, relax_mask, rho, max_iters)
+        status = torch.where((cstatus != 0).any(dim=1), torch.full_like(status, 3), status)
+        return y, status, iters, cones, cstatus, terms
     f = dict(dtype=Mk.dtype, device=Mk.device)
     terms = torch.empty(Bt, K, terms_width(m), **f) if want_terms else None
     cones = torch.empty(Bt, K, cone_width(m), **f)
@@ -450,7 +485,34 @@ def unicycle_control_step(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_g
     status, iters) from `control_workspace`.  x[Bt,3] is advanced in place when dt > 0.  Returns ws['y'].
     GP tensors with a leading axis of 1 and Bt > 1 = one learned model shared by all instances (Monte-Carlo
     rollouts of a fixed model): the posterior runs as a shared query (fp32: the matrix-core kernel)."""
+    if task["centers"].shape[1] + 1 > 4:       # more constraints than the fused kernel's four lanes: composed path
+        return _unicycle_control_step_composed(gp, task, ws, x, dt, L_true, L_mean, clf_gamma, max_iters)
     return unicycle_control_step_prepare(gp, task, ws, x, dt, L_true, L_mean, clf_gamma, max_iters)(ev_start, ev_stop)
+
+
+def _unicycle_control_step_composed(gp, task, ws, x, dt, L_true, L_mean, clf_gamma, max_iters):
+    """The control step as separate entry points (task rows -> posterior -> terms -> generic cone solver -> plant step on
+    the solved instances): for programs with more than four constraints."""
+    gp, A, N, shared = _control_step_args(gp, task, ws, x)
+    unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], clf_gamma, task["centers"], task["radii"],
+                         task["tw"], task["gammas"], L_mean, out=(ws["grad"], ws["cst"], ws["fhat"], ws["ghat"]))
+    if gp["Lop"] is not None:
+        if shared:
+            Mk, Bk, _ = posterior_query(gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], gp["ell"], gp["s2"], gp["Bm"], gp["M0"], x,
+                                        shared=True)
+            ws["Mk"].copy_(Mk); ws["Bk"].copy_(Bk)
+        else:
+            posterior_step(gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], gp["ell"], gp["s2"], gp["Bm"], gp["M0"], x,
+                           out=(ws["Mk"], ws["Bk"]))
+    y, status, iters, cones, cstatus, _ = cbc_socp(ws["Mk"], ws["Bk"], A, ws["grad"], ws["cst"], task["sign"], ws["fhat"],
+                                                   ws["ghat"], task["w"], task["r"], task["relax_mask"], task["rho"],
+                                                   max_iters=max_iters)
+    ws["y"].copy_(y); ws["status"].copy_(status); ws["iters"].copy_(iters)
+    ws["cones"].copy_(cones); ws["cstatus"].copy_(cstatus)
+    if dt > 0:
+        u = torch.where((status == 0)[:, None], y[:, :2], torch.zeros_like(y[:, :2])).contiguous()
+        unicycle_step(x, u, dt, L_true)        # unsolved instances: zero displacement (they keep their state)
+    return ws["y"]
 
 
 def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,

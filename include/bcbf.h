@@ -46,7 +46,11 @@ extern "C" {
 /* limits of the compiled kernels */
 #define BCBF_MAX_STATE_DIM 8
 #define BCBF_MAX_CTRL_DIM 3
-#define BCBF_MAX_CONSTRAINTS 4
+#define BCBF_MAX_CONSTRAINTS 8        /* constraint rows per instance: bcbf_cbc_terms, bcbf_unicycle_constraints,
+                                         bcbf_controller_cones, bcbf_coneqp (second-order cones) */
+#define BCBF_MAX_QUAD_CONSTRAINTS 4   /* the four-lanes-per-instance solver kernels (bcbf_socp, bcbf_cbc_socp,
+                                         bcbf_unicycle_control_step): one lane of a quad per cone; programs with more
+                                         cones go through bcbf_cbc_terms + bcbf_coneqp (the host wrappers route) */
 
 /* solver status codes (per instance) */
 #define BCBF_SOCP_OPTIMAL 0
@@ -264,7 +268,8 @@ int bcbf_cbc_socp_f64(const double* Mk, const double* Bk, const double* A, const
 
 /* Generic small cone QP (the reference's optimizer_socp_* / optimizer_qp_cvxpy, optimizers.py:42-116):
  *   min 1/2 x'P x + q'x  s.t.  G x + s = h,  s in R_+^l x Q^{q_1} x ... x Q^{q_nq}
- * P[Bt,nv,nv] q[Bt,nv] G[Bt,Kt,nv] h[Bt,Kt], Kt = l + sum(qdims) <= 16, nv <= 6, nq <= 4;
+ * P[Bt,nv,nv] q[Bt,nv] G[Bt,Kt,nv] h[Bt,Kt], Kt = l + sum(qdims), l <= 8, every cone dimension <= 6, nv <= 6,
+ * nq <= BCBF_MAX_CONSTRAINTS (up to 4 cones run the register-resident instantiation, more a wider, slower one);
  * qdims is a HOST array.  -> x[Bt,nv], status[Bt], iters[Bt] (may be NULL). */
 int bcbf_coneqp_f64(const double* P, const double* q, const double* G, const double* h,
                     int nv, int l, const int* qdims, int nq,

@@ -1065,3 +1065,38 @@ def test_heterogeneous_matrix_variate_kernel_mixed_blocks():
     from bayesian_cbf_amd import ops
     Kb = ops.kb_build(t(Xtr)[None], t(UHtr)[None], t(B)[None], t(ell)[None], t(np.array([s2])))[0]
     close(torch.kron(Kb, t(A)), K11, rtol=1e-10, atol=1e-12)
+
+
+def test_controller_clf_bayesian_with_four_obstacles_and_with_none():
+    """More obstacles than the fused kernel's four lanes (K = 1 + 4 cones: the composed path with the generic cone
+    solver) and the reference's default `cbfs=[]` (a pure CLF controller, Kob = 0): batched controls against the
+    oracle's control-step restatement."""
+    from oracle import control_step as ostep
+    from oracle import cbc as ocbc
+    from bayesian_cbf_amd import unicycle_move_to_pose as ump
+    x0, xg = t([-3.0, -1.0, -np.pi / 4]), t([0.0, 0.0, np.pi / 4])
+    T, dt = 200, 0.05
+    rng = np.random.default_rng(3)
+    kdiag = [1e-2, 1e-2, 1e-2]
+    centers = np.array([[-1.5, 0.6], [-1.5, -1.6], [-0.4, 1.0], [-2.2, -2.4]])
+    radii = np.array([0.6, 0.5, 0.4, 0.5])
+    for Kob in (4, 0):
+        cbfs = [ump.ObstacleCBF(t(centers[k]), t(radii[k]), term_weights=(0.7, 0.3)) for k in range(Kob)]
+        ctrl = ump.ControllerCLFBayesian(
+            ump.PiecewiseLinearPlanner(x0, xg, T, dt, frac_time_to_reach_goal=0.95), dynamics=None,
+            mean_dynamics=ump.AckermannDrive(L=1.0, kernel_diag_A=kdiag), clf=ump.CLFCartesian(Kp=[0.9, 1.5, 0.0]),
+            cbfs=cbfs, cbf_gammas=[5.0] * Kob, max_risk=0.01, clf_gamma=10.0, cost_weights=[0.33, 0.33, 0.33],
+            device=DEV, dtype=torch.float64)
+        xs = x0.cpu().numpy() + 0.2 * rng.normal(size=(6, 3))
+        u = ctrl.control(t(xs), 3)
+        assert u.shape == (6, 2) and (ctrl.last_status == 0).all()
+        plan, dplan = ctrl.planner.plan(3).cpu().numpy(), ctrl.planner.dot_plan(3).cpu().numpy()
+        for i in range(6):
+            o = ostep.control_step(xs[i], plan, dplan, np.zeros((3, 3)), np.eye(3), np.diag(kdiag), [0.9, 1.5, 0.0], 10.0,
+                                   centers[:Kob], radii[:Kob], (0.7, 0.3), [5.0] * Kob, 1.0, [0.33, 0.33, 0.33], [0.0, 0.0],
+                                   ocbc.cbc1_safety_factor(0.01))
+            assert o["status"] == "optimal"
+            np.testing.assert_allclose(u[i].cpu().numpy(), o["u"], rtol=1e-6, atol=1e-7)
+        # single state, reference signature
+        u1 = ctrl.control(t(xs[0]), 3)
+        np.testing.assert_allclose(u1.cpu().numpy(), u[0].cpu().numpy(), rtol=1e-9, atol=1e-10)

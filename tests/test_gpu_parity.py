@@ -829,3 +829,35 @@ def test_refit_one_wave_per_instance_fp64_vs_oracle_and_workgroup_form(ops, N, n
                                         h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], host(p["xq"])[i][None])
         rel_close(host(Mk)[i], Mk_o[0], 1e-8, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
         rel_close(host(Bk)[i], Bk_o[0], 1e-8, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("K", [5, 7])
+def test_programs_with_more_than_four_cones_vs_oracle(ops, dtype, K):
+    """BCBF_MAX_QUAD_CONSTRAINTS = 4 is the quad kernel's limit, not the library's: programs with up to
+    BCBF_MAX_CONSTRAINTS = 8 cones (a third, fourth ... obstacle) go through bcbf_cbc_terms + the wide bcbf_coneqp
+    instantiation (`ops.socp` routes).  Random feasible programs + one infeasible, against the oracle."""
+    rng = np.random.default_rng(40 + K)
+    Bt, m, rho = 48, 2, 2.326
+    A, b, c, d = _random_programs(rng, Bt, m, K, rho)
+    A[7, 1] = A[7, 2] = np.eye(3)[:, 1:] * 1e-3            # instance 7: two contradictory un-relaxed half planes
+    b[7, 1] = b[7, 2] = [1.0, 0, 0]
+    c[7, 1], c[7, 2] = [1.0, 0.0], [-1.0, 0.0]
+    d[7, 1] = d[7, 2] = -1.0
+    relax_mask = np.zeros(K); relax_mask[0] = 1.0
+    w = np.full((Bt, m + 1), 0.33) * rng.uniform(0.5, 2.0, size=(Bt, m + 1))
+    r = rng.normal(size=(Bt, m)) * 0.3
+    if dtype == torch.float32:
+        A, b, c, d, w, r = (np.asarray(a, dtype=np.float32).astype(np.float64) for a in (A, b, c, d, w, r))
+    cones = ops.pack_cones(dev(A, dtype), dev(b, dtype), dev(c, dtype), dev(d, dtype))
+    y, status, iters = ops.socp(dev(w, dtype), dev(r, dtype), cones, dev(relax_mask, dtype), dev(np.full(Bt, rho), dtype))
+    st = status.cpu().numpy()
+    assert st[7] != 0 and (np.delete(st, 7) == 0).all(), st
+    yh = host(y)
+    for i in range(Bt):
+        if i == 7:
+            continue
+        sol = osocp.clf_cbf_socp(w[i], r[i], [(A[i, k], b[i, k], c[i, k], d[i, k]) for k in range(K)], rho, relax_mask)
+        assert sol["status"] == "optimal"
+        np.testing.assert_allclose(yh[i], sol["x"], rtol=1e-6 if dtype == torch.float64 else 1e-5,
+                                   atol=1e-7 if dtype == torch.float64 else 1e-5)
