@@ -79,8 +79,9 @@ class HetergeneousMatrixVariateKernel:
         R1 = X1.shape[0]
         X = torch.cat([X1, X2])[None].contiguous()
         UH = torch.cat([UH1, UH2])[None].contiguous()
-        ell = torch.as_tensor(self.lengthscale).to(mxu1).reshape(1, -1).contiguous()
-        s2 = torch.as_tensor(self.outputscale).to(mxu1).reshape(1).contiguous()
+        f = dict(dtype=mxu1.dtype, device=mxu1.device)           # (as_tensor of a Python float alone would be fp32)
+        ell = torch.as_tensor(self.lengthscale, **f).reshape(1, -1).contiguous()
+        s2 = torch.as_tensor(self.outputscale, **f).reshape(1).contiguous()
         Kb = ops.kb_build(X, UH, B[None].contiguous(), ell, s2)[0]           # k(x, x') (uh' B uh') on the stacked rows
         res = torch.kron(Kb[:R1, R1:].contiguous(), A)                      # (.) (x) A
         return res.diagonal() if diag else res

@@ -303,10 +303,15 @@ class ControllerCLFBayesian:
         dplan = dplan.expand(Bt, 3).contiguous() if dplan.dim() == 1 else dplan.contiguous()
         Kob = len(self.cbfs)
         if Kob:
-            centers = torch.stack([c.center.to(**f).expand(Bt, 2) if c.center.dim() == 1 else c.center.to(**f)
-                                   for c in self.cbfs], dim=1).contiguous()
-            radii = torch.stack([c.radius.to(**f).expand(Bt) if c.radius.dim() == 0 else c.radius.to(**f)
-                                 for c in self.cbfs], dim=1).contiguous()
+            def per_instance(v, width, what):          # one value for every loop, or one per loop: anything else is an error
+                v = v.to(**f).reshape(-1, width)
+                if v.shape[0] == 1:
+                    return v.expand(Bt, width)
+                if v.shape[0] != Bt:
+                    raise ValueError("%s: %d values for a batch of %d control loops" % (what, v.shape[0], Bt))
+                return v
+            centers = torch.stack([per_instance(c.center, 2, "obstacle center") for c in self.cbfs], dim=1).contiguous()
+            radii = torch.stack([per_instance(c.radius, 1, "obstacle radius")[:, 0] for c in self.cbfs], dim=1).contiguous()
         else:       # the reference's default cbfs=[] (:811): a pure CLF controller, the kernels take Kob = 0
             centers, radii = torch.empty(Bt, 0, 2, **f), torch.empty(Bt, 0, **f)
         tw = torch.tensor(self.cbfs[0].term_weights if Kob else (0.5, 0.5), **f)
