@@ -19,6 +19,7 @@ _SIGS = {
     "bcbf_lop_elems_f32": (c_size_t, [c_int]),
     "bcbf_lop_elems_f64": (c_size_t, [c_int]),
     "bcbf_posterior_shared_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
+    "bcbf_posterior_shared_f64": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_rows": (c_int, [ctypes.POINTER(c_int), c_int, c_int, c_int]),
     "bcbf_controller_cones_f32": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_f64": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),

@@ -48,6 +48,7 @@ __host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + 
 void set_error(const char* what, hipError_t err);
 int check_launch(const char* what);
 bool posterior_shared_fits(int N, int n, int m);   // regime-S MFMA kernel: staging + one W slab fit in LDS
+bool posterior_shared64_fits(int N, int n, int m); // its fp64 form (solution in registers): N <= 512
 
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll

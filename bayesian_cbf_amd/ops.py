@@ -202,11 +202,11 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
 
 
 def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=False):
-    """b queries against one GP on the matrix cores (fp32; GP tensors carry a leading axis of 1).
+    """b queries against one GP on the matrix cores (GP tensors carry a leading axis of 1; fp64: N <= 512).
     posterior_query(shared=True) routes here for b >= 16; this entry forces the MFMA kernel for any b."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)
-    if X.dtype != torch.float32:
-        raise ValueError("posterior_shared is fp32 only")
+    if X.dtype == torch.float64 and X.shape[1] > 512:
+        raise ValueError("posterior_shared in fp64 holds the solution in registers: N <= 512 (posterior_query streams larger models)")
     if X.shape[0] != 1:
         raise ValueError("shared query: GP tensors must have a leading axis of 1")
     N, n = X.shape[1], X.shape[2]
@@ -216,9 +216,9 @@ def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=
     Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
     Np = (N + 31) // 32 * 32
     W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
-    check(lib.bcbf_posterior_shared_f32(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq),
-                                        _p(jitter2), _p(Mk), _p(Bk), _p(W), b, N, n, C - 1, _stream(X)),
-          "bcbf_posterior_shared_f32")
+    fn = lib.bcbf_posterior_shared_f64 if X.dtype == torch.float64 else lib.bcbf_posterior_shared_f32
+    check(fn(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq),
+             _p(jitter2), _p(Mk), _p(Bk), _p(W), b, N, n, C - 1, _stream(X)), "bcbf_posterior_shared")
     return Mk, Bk, W
 
 

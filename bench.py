@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (MI355X_MICROARCH.md)
+F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64, dense (MI355X_MICROARCH.md)
 ACHIEVED_METHOD = ("algorithmic units of ALL launches of the kernel in the timed region / time during which at least one of "
                    "them was executing (HIP events around every launch, on its stream); kernel_ms = mean duration of one "
                    "launch, as a kernel trace reports it -- with launches_per_step > 1 the launches overlap one another")
@@ -317,6 +318,7 @@ def main():
         # regime S: the factor is cache resident; the kernel is a triangular solve with (1+m) right-hand sides per
         # query on the matrix cores: N^2 flop per column (N^2/2 multiply-adds) -- Gram / mean accumulation not counted
         flops_launch = float(Bc) * (1 + m) * N * N
+        mfma_peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
         achieved = flops_launch * n_launch / (busy_ms * 1e-3) / 1e12
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; shared learned model" % (N, Bt),
@@ -332,9 +334,11 @@ def main():
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
             "comm": comm,
             "roofline": {"bound": "mfma", "kernel": "posterior_shared_kernel" if args.dtype == "f32" and N <= 1536 else
-                         "posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernel is fp32, N <= ~1600)",
+                         ("posterior_shared64_kernel" if args.dtype == "f64" and N <= 512 else
+                          "posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernels hold N <= ~1600 in "
+                          "fp32 and N <= 512 in fp64)"),
                          "achieved": achieved,
-                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                         "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
                          "traffic": None, "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps,
                          "launches_per_step": S, "achieved_method": ACHIEVED_METHOD,
                          "algorithmic_flops_per_launch": flops_launch, "queries_per_launch": Bc},

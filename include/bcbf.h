@@ -196,6 +196,13 @@ int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X,
                               const float* ell, const float* s2, const float* Bm, const float* M0,
                               const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                               int Bt, int N, int n, int m, void* stream);
+/* The same in fp64 (the reference's unicycle module runs in float64, unicycle_move_to_pose.py:50), N <= 512:
+ * v_mfma_f64_16x16x4_f64, 4 queries per wavefront, the solution L^-1 Phi held in registers.
+ * bcbf_posterior_query_f64(shared=1) routes here for Bt >= 16 and N <= 512; BCBF_EINVAL for N > 512. */
+int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                              const double* ell, const double* s2, const double* Bm, const double* M0,
+                              const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                              int Bt, int N, int n, int m, void* stream);
 
 /* Posterior jets: value and first x-derivatives of the posterior factors (one query per instance, or per
  * query of a shared GP).  CT = (1+m)(1+n) right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] of the same stream:

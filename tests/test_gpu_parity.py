@@ -463,12 +463,16 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
 
 
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,n,m,b", [(512, 3, 2, 203), (100, 3, 2, 8), (256, 3, 1, 64), (1024, 3, 3, 37), (64, 3, 1, 5), (1280, 3, 2, 17)])
-def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b):
-    """Regime S (custom_predict with b test points, control_affine_model.py:536, 1051): the MFMA kernel against the
-    fp64 oracle, ragged b (not a multiple of the 8 queries a wave holds) and ragged N (padding rows)."""
+@pytest.mark.parametrize("N,n,m,b,dtype", [(512, 3, 2, 203, torch.float32), (100, 3, 2, 8, torch.float32), (256, 3, 1, 64, torch.float32),
+                                           (1024, 3, 3, 37, torch.float32), (64, 3, 1, 5, torch.float32), (1280, 3, 2, 17, torch.float32),
+                                           (512, 3, 2, 203, torch.float64), (100, 3, 2, 9, torch.float64), (256, 2, 1, 64, torch.float64),
+                                           (480, 4, 3, 37, torch.float64), (64, 1, 1, 5, torch.float64), (200, 6, 2, 17, torch.float64)])
+def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
+    """Regime S (custom_predict with b test points, control_affine_model.py:536, 1051): the MFMA kernels (fp32: W slab in
+    LDS; fp64: W in registers, N <= 512) against the fp64 oracle, ragged b (not a multiple of the queries a wave holds)
+    and ragged N (padding rows)."""
     from bayesian_cbf_amd.synthetic import make_instances
-    dtype = torch.float32
+    f64 = dtype == torch.float64
     p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=3 + N)
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     assert int(info[0]) == 0
@@ -485,16 +489,16 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b):
     Mk_o, Bk_o = ogp.posterior_step(rep(st["L"]), rep(st["alpha"]), rep(h["X"][0]), rep(st["UHB"]), rep(h["ell"][0]),
                                     rep(h["s2"][0]), rep(h["Bm"][0]), rep(h["M0"][0]), host(xq), jitter2=host(j2))
     prior = h["s2"][0] * np.abs(h["Bm"][0]).max()
-    rel_close(host(Mk), Mk_o, 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
-    rel_close(host(Bk), Bk_o, 1e-3, scale=prior, what="Bk")
+    rel_close(host(Mk), Mk_o, 1e-9 if f64 else 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+    rel_close(host(Bk), Bk_o, 1e-9 if f64 else 1e-3, scale=prior, what="Bk")
     # W'W reproduces the Gram the kernel accumulated (and the routed query entry gives the same numbers)
     Wh = host(W)
     G = np.einsum("bic,bid->bcd", Wh, Wh)
     Bk_w = prior * 0 + h["s2"][0] * h["Bm"][0][None] - G + np.stack([np.diag(r) for r in host(j2)])
-    rel_close(host(Bk), Bk_w, 1e-4, scale=prior, what="Bk from W")
+    rel_close(host(Bk), Bk_w, 1e-12 if f64 else 1e-4, scale=prior, what="Bk from W")
     Mk2, Bk2, _ = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, shared=True)
-    rel_close(host(Mk2), Mk_o, 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk(query)")
-    rel_close(host(Bk2), Bk_o, 1e-3, scale=prior, what="Bk(query)")
+    rel_close(host(Mk2), Mk_o, 1e-9 if f64 else 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk(query)")
+    rel_close(host(Bk2), Bk_o, 1e-9 if f64 else 1e-3, scale=prior, what="Bk(query)")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
