@@ -23,7 +23,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.
 # per-file extras.  posterior_shared: MFMA results are consumed by VALU code every block, so keep the accumulators
 # in VGPRs (no v_accvgpr round trips)
 EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "posterior_shared64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "posterior_shared64.hip": ["-Rpass-analysis=kernel-resource-usage"]}
+# kernels that must not touch scratch memory (posterior_shared64: an operand spilled between its explicit LDS read and
+# the explicit wait for it would be stored before it has arrived)
+NO_SCRATCH = {"posterior_shared64.hip"}
 
 
 def _hipcc():
@@ -59,6 +62,12 @@ def _compile(src, force):
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
+    if src in NO_SCRATCH and not ASAN:
+        import re
+        sizes = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res.stderr)]
+        if not sizes or any(sizes):
+            os.remove(obj)
+            raise RuntimeError("%s: kernels must not use scratch memory (ScratchSize per kernel: %s)" % (src, sizes))
     return obj, True
 
 

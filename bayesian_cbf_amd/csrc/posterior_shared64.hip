@@ -2,33 +2,66 @@
 // unicycle_move_to_pose.py:50; custom_predict with b test points, control_affine_model.py:536, 1051-1091).
 //
 // Same blocked forward substitution as posterior_shared.hip (fp32), rebuilt around what the fp64 MFMA gives:
-//   * one wave = 4 queries = 16 right-hand-side columns (4 per query, unused ones zero);
+//   * one wave = 4 queries = 16 right-hand-side columns (4 per query, unused ones zero); one wave per SIMD;
 //   * the fp64 accumulator holds row g + 4r (lane group g = lane >> 4, register r) of a 16-row tile in column
 //     j = lane & 15 -- and the B operand of the next MFMA wants B[k = g][n = j]: with k-step s = (tile u, register r)
 //     covering block rows 16u + 4r + g, an accumulator register IS a B operand, with no interleaving of rows at all;
-//   * so W = L^-1 Phi never leaves the registers: wreg[K][s] (8 doubles per 32-row block, 16 blocks = 256 VGPRs at
-//     N = 512; one wave per SIMD has 512) is written by the diagonal step of block K and read as the B operand of every
-//     later tile (I, K).  No LDS slab (it would be 64 KB per wave in fp64: one wave per CU), no LDS traffic in the loop;
-//     the loops over blocks are fully unrolled so that every wreg index is a compile-time constant;
-//   * A operands: one 8-byte buffer load per lane per (output tile, k-step) straight from the packed operator (16
-//     consecutive rows of one column per lane group: 128-byte segments), the whole next tile in flight while the
-//     current one multiplies;  diagonal step: A = the stored inverse (full-tile copy), B = Phi - acc.
-// X, UH*B and Vw are staged in LDS once per workgroup (doubles).  N <= 32 * PS64_MAXBLK; beyond that, and for few queries,
-// the streaming kernel (posterior_step.hip, two queries per workgroup) answers.
+//   * so W = L^-1 Phi never leaves the registers: wreg[K][s] (8 doubles per 32-row block, pinned to the accumulation
+//     registers, of which a wave alone on its SIMD has 256) is written by the diagonal step of block K and read as the
+//     B operand of every later tile (I, K); blocks 12-14 (6 tiles read them) sit in a per-lane LDS slab instead so that
+//     the accumulators themselves fit.  The loops over blocks are compile-time loops: every wreg index is a constant;
+//   * A operands: every 32x32 tile of the packed operator is fetched ONCE per workgroup (16-byte buffer loads, two per
+//     thread) into a ring of three LDS tiles and read by all four waves with explicit ds_read_b64, issued a whole tile
+//     ahead of the MFMAs that consume them (bank-conflict-free image: see gload);  diagonal step: A = the stored
+//     inverse (full-tile copy), B = Phi - acc.  One barrier per tile.
+//   History at N = 512, 4096 queries: streaming VALU kernel 0.27 ms -> per-wave 8-byte operand loads from L2 0.145 ->
+//   tiles shared through LDS 0.137 -> W pinned to AGPRs (no spills) + next tile's operands prefetched 0.095 ms
+//   (a bare loop of this MFMA sustains 31.4 ns per instruction with one wave per SIMD: 66 us for the 2112 of a wave).
+// The explicit prefetch (asm issue, asm wait) is only sound while the register allocator does not spill an operand
+// between the two: build.py compiles this file with -Rpass-analysis=kernel-resource-usage and refuses a build whose
+// kernels report a non-zero scratch size.  State dimensions n <= 4 (wider ones stream); N <= 32 * PS64_MAXBLK; beyond
+// that, and for few queries, the streaming kernel (posterior_step.hip, two queries per workgroup) answers.
 #include "bcbf_common.h"
+#include "diag_tile64.h"      // LdsDouble
 
 namespace bcbf {
 
 using f64x4s = __attribute__((__vector_size__(4 * sizeof(double)))) double;
-using u32x2q = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
+using u32x4q = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 
 constexpr int PS64_MAXBLK = 16;          // N <= 512
+#ifndef BCBF_PS64_REGBLK
+#define BCBF_PS64_REGBLK 12
+#endif
+constexpr int PS64_REGBLK = BCBF_PS64_REGBLK;   // W blocks 0 .. REGBLK-1 live in registers (16 each: the accumulation registers
+                                         // hold 256), blocks REGBLK .. 14 (read by 6 tiles at most) in a per-lane LDS slab;
+                                         // block 15 is never an operand
+constexpr int PS64_SLABBLK = PS64_MAXBLK - 1 - PS64_REGBLK;
 
 // compile-time loop: the body sees a constant index (every wreg[][] subscript must be one, or the array leaves the
 // register file for scratch memory -- "#pragma unroll" alone is a request the optimizer declines for 2000-MFMA bodies)
 template <int I> struct Ic { static constexpr int value = I; };
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) { f(Ic<B>{}); static_for<B + 1, E>(f); }
+}
+
+// block row of tile t in the order (0,0), (1,0), (1,1), (2,0), ...
+constexpr int tile_row(int t) { int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; return I; }
+
+// A operands of one tile: 16 explicit ds_read_b64 (a[u'][s] at byte offset OFF + 1024 s from the lane's two bases), and the
+// wait that makes their results usable
+template <int OFF> __device__ __forceinline__ void lds_get16(double (&a)[2][8], unsigned a0, unsigned a1) {
+#define BCBF_RD(u_, s_, addr) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[u_][s_]) : "v"(addr), "n"(OFF + 1024 * s_))
+    BCBF_RD(0, 0, a0); BCBF_RD(1, 0, a1); BCBF_RD(0, 1, a0); BCBF_RD(1, 1, a1);
+    BCBF_RD(0, 2, a0); BCBF_RD(1, 2, a1); BCBF_RD(0, 3, a0); BCBF_RD(1, 3, a1);
+    BCBF_RD(0, 4, a0); BCBF_RD(1, 4, a1); BCBF_RD(0, 5, a0); BCBF_RD(1, 5, a1);
+    BCBF_RD(0, 6, a0); BCBF_RD(1, 6, a1); BCBF_RD(0, 7, a0); BCBF_RD(1, 7, a1);
+#undef BCBF_RD
+}
+__device__ __forceinline__ void lds_wait16(double (&a)[2][8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[0][4]), "+v"(a[0][5]), "+v"(a[0][6]), "+v"(a[0][7]),
+                   "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(a[1][4]), "+v"(a[1][5]), "+v"(a[1][6]), "+v"(a[1][7]));
 }
 
 // quad broadcast of a double: lane c of every quad -> all four lanes (two DPP moves)
@@ -48,10 +81,12 @@ posterior_shared64_kernel(const double* __restrict__ Lop, const double* __restri
                           double* __restrict__ Wout, int nq, int N, int Np, int n) {
     constexpr int V = 2, QW = 4;
     extern __shared__ double smem64[];
-    const int nwave = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;                 // blockDim.x == 256: all four waves stage tiles
     double* Xs = smem64;                               // [Np][NS]  (state dim padded to NS with zeros)
     double* Us = Xs + (size_t)Np * NS;                 // [Np][C]   (rows >= N are zero: padded rows contribute nothing)
     double* Vs = Us + (size_t)Np * C;                  // [Np][NS]
+    double* Ts = Vs + (size_t)Np * NS;                 // three 32x32 operator tiles (ring), 16-byte aligned
+    double* Wl = Ts + 3072 + (size_t)wave * (PS64_SLABBLK * 8 * 64) + (threadIdx.x & 63);   // this lane's slots of W blocks >= REGBLK
     for (int i = threadIdx.x; i < Np * NS; i += blockDim.x) {
         const int row = i / NS, d = i - row * NS;
         const bool ok = row < N && d < n;
@@ -59,14 +94,11 @@ posterior_shared64_kernel(const double* __restrict__ Lop, const double* __restri
         Vs[i] = ok ? Vw[(size_t)row * n + d] : 0.0;
     }
     for (int i = threadIdx.x; i < Np * C; i += blockDim.x) Us[i] = i < N * C ? UHB[i] : 0.0;
-    __syncthreads();
 
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int ql = j >> 2, c = j & 3;                  // query slot in the wave, component
-    const int wq0 = (blockIdx.x * nwave + wave) * QW;
-    if (wq0 >= nq) return;                             // whole wave idle (no further barriers below)
-    const int q = wq0 + ql;
-    const bool qok = q < nq, cok = c < C;
+    const int q = (blockIdx.x * 4 + wave) * QW + ql;
+    const bool qok = q < nq, cok = c < C;              // (a wave past the end still stages tiles and meets the barriers)
     const int qq = qok ? q : nq - 1;
 
     double xqr[NS], iell[NS];
@@ -87,45 +119,98 @@ posterior_shared64_kernel(const double* __restrict__ Lop, const double* __restri
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(Lop), 0, (int)(lop_elems<V>(Np) * sizeof(double)), 0x00020000);
-    // A operands of tile (I, K), 16 values per lane: a[u'][s] = L[32I + 16u' + j][32K + 4s + g]  (K < I: the packed
-    // off-diagonal part, element (row, col) at lop_base(col) + row; K == I: the full-tile copy of inv(L_II), column
-    // stride 32).  One per-lane offset, scalar offsets per (u', s).
-    auto load_tile = [&](double (&a)[2][8], int I, int K) {
+    // Tile (I, K) of the operator, L[32I + r][32K + col] (K < I: the packed off-diagonal part, element (row, col) at
+    // lop_base(col) + row; K == I: the full-tile copy of inv(L_II), column stride 32), is fetched ONCE per workgroup:
+    // 512 16-byte pieces (column = piece / 16, rows 2 (piece % 16), +1), two per thread, 16 lanes per 256-byte column.
+    // LDS image: column-major, 256 bytes per column, the two 128-byte halves of ODD columns swapped -- an A-operand read
+    // (ds_read_b64: lanes 0-31 = lane groups g, g+1 = two adjacent columns, 16 rows each) then covers all 64 banks once.
+    const int pc0 = threadIdx.x >> 4, pp = threadIdx.x & 15;      // piece h: column pc0 + 16 h, piece pp
+    auto gload = [&](u32x4q (&r)[2], int I, int K) {
         const bool isdiag = K == I;
         const int stride = isdiag ? NB : Np - NB * (K + 1);                   // column stride inside block column K
         const int base = isdiag ? lop_dfull_block(I, Np) : lop_base<V>(K * NB, Np) + I * NB;   // element (row 0 of the tile, col 0)
-        const int voff = (g * stride + j) * (int)sizeof(double);
+        const int voff = (pc0 * stride + 2 * pp) * (int)sizeof(double);
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int up = 0; up < 2; ++up) {
-                const int soff = (base + 4 * s * stride + 16 * up) * (int)sizeof(double);
-                const u32x2q v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
-                a[up][s] = __builtin_bit_cast(double, v);
-            }
+        for (int h = 0; h < 2; ++h)
+            r[h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (base + 16 * h * stride) * (int)sizeof(double), 0);
     };
+    const int wr_off = pc0 * NB + ((pp ^ ((pc0 & 1) << 3)) << 1);             // (16 columns further: + 512 doubles)
+    auto lds_put = [&](double* tb, const u32x4q (&r)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4q*>(tb + wr_off + 512 * h) = r[h];
+    };
+    // a[u'][s] = tile[row 16u' + j][col 4s + g]
+    const int rd_off0 = g * NB + ((((j >> 1)) ^ ((g & 1) << 3)) << 1) + (j & 1);
+    const int rd_off1 = g * NB + (((8 | (j >> 1)) ^ ((g & 1) << 3)) << 1) + (j & 1);
 
-    double wreg[PS64_MAXBLK][8];                       // W_K: rows 16u + 4r + g of block K at index 4u + r, column j
-    double acur[2][8], anxt[2][8];
-    load_tile(acur, 0, 0);
+    double wreg[PS64_REGBLK][8];                       // W_K: rows 16u + 4r + g of block K at index 4u + r, column j
+    auto wget = [&](auto Kc, int s_) -> double {
+        constexpr int K_ = decltype(Kc)::value;
+        if constexpr (K_ < PS64_REGBLK) return wreg[K_][s_];
+        else return Wl[((K_ - PS64_REGBLK) * 8 + s_) * 64];
+    };
+    // Pipeline, step t = tile t (tiles in the order (0,0), (1,0), (1,1), (2,0), ...; three LDS buffers):
+    //   write tile t+2 (fetched during step t-1) into buffer (t+2) % 3  |  fetch tile t+3 into registers  |
+    //   read the A operands of tile t+1 from buffer (t+1) % 3  |  multiply tile t (operands read a step ago)  |  barrier
+    auto fetch = [&](u32x4q (&r)[2], auto tc) {
+        constexpr int t_ = decltype(tc)::value;
+        constexpr int I_ = tile_row(t_);
+        gload(r, I_, t_ - I_ * (I_ + 1) / 2);
+    };
+    // The A operands of the NEXT tile are read with explicit ds_read_b64 (issued here, at the head of the step, and waited
+    // for by lds_wait16() at its tail): written as plain loads the scheduler sinks each one to its use, a single MFMA ahead,
+    // and every MFMA pair then waits out an LDS round trip (measured: 92 cycles per MFMA instead of 64).
+    const unsigned ts_a0 = (unsigned)(size_t)(LdsDouble*)(Ts + rd_off0), ts_a1 = (unsigned)(size_t)(LdsDouble*)(Ts + rd_off1);
+    u32x4q stage[2];
+    double acur[2][8], anxt[2][8], pend[8];
+    fetch(stage, Ic<0>{});
+    lds_put(Ts, stage);
+    fetch(stage, Ic<1>{});
+    lds_put(Ts + 1024, stage);
+    fetch(stage, Ic<2>{});
+    __syncthreads();                                   // staging of X / UH B / Vw and tiles 0, 1 visible
+    lds_get16<0>(acur, ts_a0, ts_a1);
+    lds_wait16(acur);
+    // Gram row / mean column of this lane's query from the W tile of block Ib held in pend[]
+    auto epilogue = [&](int Ib) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double v = pend[e];
+            const int row = Ib * NB + 16 * (e >> 2) + 4 * (e & 3) + g;
+            const double vb[4] = {dpp_qd<0x00>(v), dpp_qd<0x55>(v), dpp_qd<0xAA>(v), dpp_qd<0xFF>(v)};
+#pragma unroll
+            for (int a_ = 0; a_ < C; ++a_) gram[a_] += v * vb[a_];             // lane c: G[c][a]
+#pragma unroll
+            for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;        // lane c: (Vw'W)[d][c]
+        }
+    };
     static_for<0, PS64_MAXBLK>([&](auto Ict) {
         constexpr int I = decltype(Ict)::value;
         if (I < nblk) {
             f64x4s acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            // ---- off-diagonal tiles (I, K), K < I: acc += L_IK W_K   (acur holds tile (I, 0) when I > 0, else the diagonal)
+            // ---- off-diagonal tiles (I, K), K < I: acc += L_IK W_K
             static_for<0, I>([&](auto Kct) {
                 constexpr int K = decltype(Kct)::value;
-                load_tile(anxt, I, K + 1);             // K + 1 == I: the diagonal tile (inverse)
+                constexpr int t = I * (I + 1) / 2 + K;
+                lds_put(Ts + 1024 * ((t + 2) % 3), stage);
+                fetch(stage, Ic<t + 3>{});
+                lds_get16<((t + 1) % 3) * 8192>(anxt, ts_a0, ts_a1);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[0][s], wreg[K][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[1][s], wreg[K][s], acc1, 0, 0, 0);
+                    const double wk = wget(Kct, s);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[0][s], wk, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[1][s], wk, acc1, 0, 0, 0);
                 }
+                if constexpr (K == 0 && I > 0) epilogue(I - 1);                // VALU work beside this row's first MFMAs
+                lds_wait16(anxt);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+                __syncthreads();
             });
-            // ---- next tile in flight: (I + 1, 0)  (past the last block the bounds check of the buffer returns zeros)
-            load_tile(anxt, I + 1, 0);
+            constexpr int t = I * (I + 1) / 2 + I;
+            lds_put(Ts + 1024 * ((t + 2) % 3), stage);
+            fetch(stage, Ic<t + 3>{});
+            lds_get16<((t + 1) % 3) * 8192>(anxt, ts_a0, ts_a1);
             // ---- Phi tile of block I: phi[4u + r] = k(x_q, X_row) (UH B)[row][c], row = 32I + 16u + 4r + g.  The exp of
             //      (query, row) is evaluated once, by the lane whose component equals r, and broadcast inside the quad
             double phi[8];
@@ -151,18 +236,20 @@ posterior_shared64_kernel(const double* __restrict__ Lop, const double* __restri
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const double v = (e >> 2) ? w1[e & 3] : w0[e & 3];
-                wreg[I][e] = v;
-                const int row = I * NB + 16 * (e >> 2) + 4 * (e & 3) + g;
-                if (Wout != nullptr && qok && cok) Wout[((size_t)q * Np + row) * C + c] = v;
-                // Gram row / mean column of this lane's query
-                const double vb[4] = {dpp_qd<0x00>(v), dpp_qd<0x55>(v), dpp_qd<0xAA>(v), dpp_qd<0xFF>(v)};
-#pragma unroll
-                for (int a_ = 0; a_ < C; ++a_) gram[a_] += v * vb[a_];             // lane c: G[c][a]
-#pragma unroll
-                for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;        // lane c: (Vw'W)[d][c]
+                pend[e] = v;
+                if constexpr (I < PS64_REGBLK) { wreg[I][e] = v; asm volatile("" : "+a"(wreg[I][e])); }   // lives in the accumulation registers
+                else if constexpr (I < PS64_MAXBLK - 1) Wl[((I - PS64_REGBLK) * 8 + e) * 64] = v;
             }
+            if (Wout != nullptr && qok && cok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    Wout[((size_t)q * Np + I * NB + 16 * (e >> 2) + 4 * (e & 3) + g) * C + c] = pend[e];
+            }
+            lds_wait16(anxt);
 #pragma unroll
             for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+            if (I == nblk - 1) epilogue(I);
+            __syncthreads();
         }
     });
 
@@ -184,12 +271,13 @@ posterior_shared64_kernel(const double* __restrict__ Lop, const double* __restri
     }
 }
 
-static int padded_state_dim64(int n) { return n <= 2 ? 2 : (n <= 4 ? n : 8); }   // instantiated widths
+static int padded_state_dim64(int n) { return n <= 2 ? 2 : n; }   // instantiated widths: 2, 3, 4
 
-// N <= 512 and the staged copies fit in LDS
+// N <= 512, n <= 4 (wider states need more registers than the explicit operand prefetch leaves: they stream) and the
+// staged copies fit in LDS
 bool posterior_shared64_fits(int N, int n, int m) {
     const size_t Np = round_up(N, NB);
-    return Np <= (size_t)NB * PS64_MAXBLK && Np * (2 * padded_state_dim64(n) + m + 1) * sizeof(double) <= 160 * 1024;
+    return n <= 4 && Np <= (size_t)NB * PS64_MAXBLK && (Np * (2 * padded_state_dim64(n) + m + 1) + 3072 + 4 * PS64_SLABBLK * 512) * sizeof(double) <= 160 * 1024;
 }
 
 template <int C, int NS>
@@ -216,10 +304,12 @@ static void launch_shared64_c(int NSp, dim3 grid, dim3 block, size_t lds, hipStr
                               double* Bk, double* W, int nq, int N, int Np, int n) {
 #define BCBF_PSH64(NSV) launch_shared64<C, NSV>(grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
     switch (NSp) {
+#ifndef BCBF_PS64_DEV          // (development: compile two instantiations only)
         case 2: BCBF_PSH64(2); break;
-        case 3: BCBF_PSH64(3); break;
         case 4: BCBF_PSH64(4); break;
-        default: BCBF_PSH64(8); break;
+#endif
+        case 3: BCBF_PSH64(3); break;
+        default: break;
     }
 #undef BCBF_PSH64
 }
@@ -236,15 +326,19 @@ extern "C" int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, co
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > 3) return BCBF_EINVAL;
     if (!posterior_shared64_fits(N, n, m)) return BCBF_EINVAL;
     const int Np = round_up(N, NB), C = m + 1, NSp = padded_state_dim64(n);
-    const size_t lds = (size_t)Np * (2 * NSp + C) * sizeof(double);
+    const size_t lds = ((size_t)Np * (2 * NSp + C) + 3072 + (Np > NB * PS64_REGBLK ? 4 * PS64_SLABBLK * 512 : 0)) * sizeof(double);
     const int waves = (nq + 3) / 4;
-    const int nwave = waves < 4 ? waves : 4;           // one wave per SIMD: the W tiles of a wave take 256 VGPRs
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((waves + nwave - 1) / nwave), block(64 * nwave);
+    dim3 grid((waves + 3) / 4), block(256);            // one wave per SIMD (the W tiles of a wave take 256 VGPRs)
     switch (m) {
+#ifdef BCBF_PS64_DEV
+        case 2: launch_shared64_c<3>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        default: break;
+#else
         case 1: launch_shared64_c<2>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
         case 2: launch_shared64_c<3>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
         default: launch_shared64_c<4>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+#endif
     }
     return check_launch("posterior_shared64");
 }

@@ -202,11 +202,11 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
 
 
 def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=False):
-    """b queries against one GP on the matrix cores (GP tensors carry a leading axis of 1; fp64: N <= 512).
+    """b queries against one GP on the matrix cores (GP tensors carry a leading axis of 1; fp64: N <= 512, n <= 4).
     posterior_query(shared=True) routes here for b >= 16; this entry forces the MFMA kernel for any b."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)
-    if X.dtype == torch.float64 and X.shape[1] > 512:
-        raise ValueError("posterior_shared in fp64 holds the solution in registers: N <= 512 (posterior_query streams larger models)")
+    if X.dtype == torch.float64 and (X.shape[1] > 512 or X.shape[2] > 4):
+        raise ValueError("posterior_shared in fp64 holds the solution in registers: N <= 512, n <= 4 (posterior_query streams the rest)")
     if X.shape[0] != 1:
         raise ValueError("shared query: GP tensors must have a leading axis of 1")
     N, n = X.shape[1], X.shape[2]

@@ -196,9 +196,9 @@ int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X,
                               const float* ell, const float* s2, const float* Bm, const float* M0,
                               const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                               int Bt, int N, int n, int m, void* stream);
-/* The same in fp64 (the reference's unicycle module runs in float64, unicycle_move_to_pose.py:50), N <= 512:
+/* The same in fp64 (the reference's unicycle module runs in float64, unicycle_move_to_pose.py:50), N <= 512, n <= 4:
  * v_mfma_f64_16x16x4_f64, 4 queries per wavefront, the solution L^-1 Phi held in registers.
- * bcbf_posterior_query_f64(shared=1) routes here for Bt >= 16 and N <= 512; BCBF_EINVAL for N > 512. */
+ * bcbf_posterior_query_f64(shared=1) routes here for Bt >= 16, N <= 512 and n <= 4; BCBF_EINVAL outside that range. */
 int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
                               const double* ell, const double* s2, const double* Bm, const double* M0,
                               const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,

@@ -466,11 +466,13 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
 @pytest.mark.parametrize("N,n,m,b,dtype", [(512, 3, 2, 203, torch.float32), (100, 3, 2, 8, torch.float32), (256, 3, 1, 64, torch.float32),
                                            (1024, 3, 3, 37, torch.float32), (64, 3, 1, 5, torch.float32), (1280, 3, 2, 17, torch.float32),
                                            (512, 3, 2, 203, torch.float64), (100, 3, 2, 9, torch.float64), (256, 2, 1, 64, torch.float64),
-                                           (480, 4, 3, 37, torch.float64), (64, 1, 1, 5, torch.float64), (200, 6, 2, 17, torch.float64)])
+                                           (480, 4, 3, 37, torch.float64), (64, 1, 1, 5, torch.float64), (416, 4, 2, 17, torch.float64),
+                                           (200, 6, 2, 17, torch.float64), (640, 3, 2, 40, torch.float64)])
 def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
     """Regime S (custom_predict with b test points, control_affine_model.py:536, 1051): the MFMA kernels (fp32: W slab in
-    LDS; fp64: W in registers, N <= 512) against the fp64 oracle, ragged b (not a multiple of the queries a wave holds)
-    and ragged N (padding rows)."""
+    LDS; fp64: W in registers, N <= 512, n <= 4) against the fp64 oracle, ragged b (not a multiple of the queries a
+    wave holds) and ragged N (padding rows).  The last two fp64 cases lie outside the matrix-core kernel's range: the
+    direct entry refuses them and the routed query streams them."""
     from bayesian_cbf_amd.synthetic import make_instances
     f64 = dtype == torch.float64
     p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=3 + N)
@@ -481,7 +483,13 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
     idx = torch.randint(0, N, (b,), generator=g)
     xq = (p["X"][0, idx.to(DEV)] + 0.3 * torch.randn(b, n, generator=g).to(DEV, dtype)).contiguous()
     j2 = (1e-5 * torch.rand(b, m + 1, generator=g)).to(DEV, dtype)
-    Mk, Bk, W = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, want_W=True)
+    direct = not f64 or (N <= 512 and n <= 4)
+    if direct:
+        Mk, Bk, W = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, want_W=True)
+    else:
+        with pytest.raises(ValueError):
+            ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, want_W=True)
+        Mk, Bk, W = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, shared=True, want_W=True)
     h = {k: host(v) for k, v in p.items()}
     st = ogp.refit_state(h["X"][0], h["U"][0], h["Xdot"][0], h["Bm"][0], h["ell"][0], h["s2"][0], h["M0"][0],
                          h["jitter"][0][None] / 1e-5)

@@ -3,7 +3,8 @@ sys.path.insert(0, "/root/repo")
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
 dev = "cuda:0"
-for dtype in (torch.float64, torch.float32):
+import os
+for dtype in ((torch.float64,) if os.environ.get('BCBF_TS_F64') else (torch.float64, torch.float32)):
     for N in (128, 256, 512):
         p = make_instances(1, N, 3, 2, dtype=dtype, device=dev, seed=1)
         Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
@@ -18,7 +19,6 @@ for dtype in (torch.float64, torch.float32):
                 e1.record(); torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / 20
             t_m = run(lambda: ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq))
-            import os
             # streaming kernel on the shared model: small-b route is the same kernel; time it through posterior_query with b<16 chunks is unfair -> use env to disable? compare with replicated per-instance step instead
             fl = b * 3 * N * N / (t_m * 1e-3) / 1e12
             print(str(dtype)[6:], "N", N, "b", b, "mfma ms %.4f" % t_m, "TF %.2f" % fl, flush=True)
