@@ -16,17 +16,17 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libbcbf.so")
 ARCH = "gfx950"
-SOURCES = ["common.hip", "posterior_step.hip", "posterior_shared.hip", "posterior_shared64.hip", "refit.hip", "refit_mfma.hip", "refit_mfma64.hip", "refit_wave64.hip", "solve.hip", "mll_grad.hip", "cbc_terms.hip", "controller_cones.hip", "socp.hip", "socp_quad.hip",
+SOURCES = ["common.hip", "posterior_step.hip", "posterior_shared.hip", "posterior_shared_reg.hip", "refit.hip", "refit_mfma.hip", "refit_mfma64.hip", "refit_wave64.hip", "solve.hip", "mll_grad.hip", "cbc_terms.hip", "controller_cones.hip", "socp.hip", "socp_quad.hip",
            "unicycle.hip", "control_step.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]
 # per-file extras.  posterior_shared: MFMA results are consumed by VALU code every block, so keep the accumulators
 # in VGPRs (no v_accvgpr round trips)
 EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "posterior_shared64.hip": ["-Rpass-analysis=kernel-resource-usage"]}
-# kernels that must not touch scratch memory (posterior_shared64: an operand spilled between its explicit LDS read and
+               "posterior_shared_reg.hip": ["-Rpass-analysis=kernel-resource-usage"]}
+# kernels that must not touch scratch memory (posterior_shared_reg: an operand spilled between its explicit LDS read and
 # the explicit wait for it would be stored before it has arrived)
-NO_SCRATCH = {"posterior_shared64.hip"}
+NO_SCRATCH = {"posterior_shared_reg.hip"}
 
 
 def _hipcc():

@@ -48,7 +48,12 @@ __host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + 
 void set_error(const char* what, hipError_t err);
 int check_launch(const char* what);
 bool posterior_shared_fits(int N, int n, int m);   // regime-S MFMA kernel: staging + one W slab fit in LDS
-bool posterior_shared64_fits(int N, int n, int m); // its fp64 form (solution in registers): N <= 512
+bool posterior_shared64_fits(int N, int n, int m); // solution in registers (posterior_shared_reg.hip), fp64: N <= 512, n <= 4
+bool posterior_shared_reg32_fits(int N, int n, int m);   // the same form in fp32
+template <typename T>
+int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
+                                const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk, T* W, int nq,
+                                int N, int n, int m, void* stream);
 
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll

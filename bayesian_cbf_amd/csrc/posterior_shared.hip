@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "bcbf_common.h"
+#include <stdlib.h>
 
 namespace bcbf {
 
@@ -345,6 +346,11 @@ extern "C" int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, cons
     if (nq <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > 3) return BCBF_EINVAL;
+    // N <= 512, n <= 4: the form that keeps W in registers (posterior_shared_reg.hip).  BCBF_SHARED_REG=0 keeps this
+    // file's kernel (W slab in LDS) for comparisons
+    static const int use_reg = [] { const char* e = getenv("BCBF_SHARED_REG"); return e ? atoi(e) : 1; }();
+    if (use_reg && posterior_shared_reg32_fits(N, n, m))
+        return launch_posterior_shared_reg<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream);
     const int Np = round_up(N, NB), C = m + 1, NSp = padded_state_dim(n);
     if (!posterior_shared_fits(N, n, m)) return BCBF_EINVAL;      // the W slab of a wave lives in LDS
     const size_t stage = (size_t)Np * (2 * NSp + C) * sizeof(float), slab = (size_t)Np * 16 * sizeof(float);

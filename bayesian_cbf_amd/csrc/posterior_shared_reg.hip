@@ -1,0 +1,398 @@
+// Regime S with the solution held in registers: many queries against ONE GP on the matrix cores, fp64
+// (v_mfma_f64_16x16x4_f64; the reference's unicycle module is fp64, unicycle_move_to_pose.py:50) and fp32
+// (v_mfma_f32_16x16x4_f32).  Replaces custom_predict with b test points (control_affine_model.py:536-602, 1051-1091).
+//
+// Blocked forward substitution W = L^-1 Phi with 32-row blocks, one wave = 4 queries = 16 right-hand-side columns (4 per
+// query, unused ones zero), one wave per SIMD, four waves per workgroup:
+//   * the accumulator of a 16x16x4 MFMA holds, in lane (j = lane & 15, g = lane >> 4), register r, the element
+//     (row g + 4r [fp64] | 4g + r [fp32], column j) of a 16-row tile -- and the B operand of the next MFMA wants
+//     B[k = g][n = j].  With k-step s = (tile u, register r) covering the block rows blkrow(s, g) = 16u + 4r + g [fp64] |
+//     16u + 4g + r [fp32], an accumulator register IS a B operand: no shuffle, no LDS round trip;
+//   * so W never leaves the registers: wreg[K][s] (8 values per 32-row block, pinned to the accumulation registers, of
+//     which a wave alone on its SIMD has 256) is written by the diagonal step of block K and read as the B operand of
+//     every later tile (I, K).  fp64 at N = 512 would need all 256: blocks 12-14 (6 tiles read them) sit in a per-lane
+//     LDS slab instead.  The loops over blocks are compile-time loops: every wreg index is a constant;
+//   * A operands: every 32x32 tile of the packed operator is fetched ONCE per workgroup (16-byte buffer loads) into a
+//     ring of three LDS tiles and read by all four waves with explicit ds_read, issued a whole tile ahead of the MFMAs
+//     that consume them (bank-conflict-free image: see gload);  diagonal step: A = the stored inverse (full-tile copy),
+//     B = Phi - acc.  One barrier per tile.
+//   History, fp64, N = 512, 4096 queries: streaming VALU kernel 0.27 ms -> per-wave 8-byte operand loads from L2 0.145
+//   -> tiles shared through LDS 0.137 -> W pinned to AGPRs (no spills) + next tile's operands prefetched 0.095 ms
+//   (a bare loop of the fp64 MFMA sustains 31.4 ns per instruction with one wave per SIMD: 66 us for the 2112 of a wave).
+// The explicit prefetch (asm issue, asm wait) is only sound while the register allocator does not spill an operand
+// between the two: build.py compiles this file with -Rpass-analysis=kernel-resource-usage and refuses a build whose
+// kernels report a non-zero scratch size.  State dimensions n <= 4 (wider ones stream); N <= 512; beyond that, and for
+// few queries, posterior_shared.hip (fp32, W slab in LDS) or the streaming kernel (posterior_step.hip) answer.
+#include "bcbf_common.h"
+#include "diag_tile64.h"      // LdsDouble
+
+namespace bcbf {
+
+using f64x4r = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+using f32x4r = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+using u32x4r = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
+
+constexpr int PSR_MAXBLK = 16;           // N <= 512
+
+// compile-time loop: the body sees a constant index (every wreg[][] subscript must be one, or the array leaves the
+// register file for scratch memory -- "#pragma unroll" alone is a request the optimizer declines for 2000-MFMA bodies)
+template <int I> struct Ic { static constexpr int value = I; };
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(Ic<B>{}); static_for<B + 1, E>(f); }
+}
+
+// block row of tile t in the order (0,0), (1,0), (1,1), (2,0), ...
+constexpr int tile_row(int t) { int I = 0; while ((I + 1) * (I + 2) / 2 <= t) ++I; return I; }
+
+template <typename T> struct PSR;
+template <> struct PSR<double> {
+    using acc_t = f64x4r;
+    static constexpr int REGBLK = 12;                 // W blocks in registers (16 VGPRs each); 12..14 in the LDS slab
+    static constexpr int PIECES = 2;                  // 16-byte pieces of a tile per thread
+    static constexpr int PPC = 16;                    // pieces per tile column
+    static constexpr int TILE_BYTES = NB * NB * 8;
+    // column of the tile that k-step s reads in lane group g (= block row of the W value in register s): colstep(s) + lanecol * g
+    __host__ __device__ static constexpr int colstep(int s) { return 4 * s; }
+    static constexpr int LANECOL = 1;
+    __device__ static acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static double exp_(double x) { return exp(x); }
+};
+template <> struct PSR<float> {
+    using acc_t = f32x4r;
+    static constexpr int REGBLK = PSR_MAXBLK - 1;     // all of them (8 VGPRs each)
+    static constexpr int PIECES = 1;
+    static constexpr int PPC = 8;
+    static constexpr int TILE_BYTES = NB * NB * 4;
+    __host__ __device__ static constexpr int colstep(int s) { return 16 * (s >> 2) + (s & 3); }
+    static constexpr int LANECOL = 4;
+    __device__ static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static float exp_(float x) { return __expf(x); }
+};
+
+// A operands of one tile: 16 explicit LDS reads (a[u'][s] at byte offset OFF + column colstep(s) from the lane's two
+// bases), and the wait that makes their results usable
+template <int OFF> __device__ __forceinline__ void lds_get16(double (&a)[2][8], unsigned a0, unsigned a1) {
+#define BCBF_RD(u_, s_, addr) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[u_][s_]) : "v"(addr), "n"(OFF + NB * 8 * PSR<double>::colstep(s_)))
+    BCBF_RD(0, 0, a0); BCBF_RD(1, 0, a1); BCBF_RD(0, 1, a0); BCBF_RD(1, 1, a1);
+    BCBF_RD(0, 2, a0); BCBF_RD(1, 2, a1); BCBF_RD(0, 3, a0); BCBF_RD(1, 3, a1);
+    BCBF_RD(0, 4, a0); BCBF_RD(1, 4, a1); BCBF_RD(0, 5, a0); BCBF_RD(1, 5, a1);
+    BCBF_RD(0, 6, a0); BCBF_RD(1, 6, a1); BCBF_RD(0, 7, a0); BCBF_RD(1, 7, a1);
+#undef BCBF_RD
+}
+template <int OFF> __device__ __forceinline__ void lds_get16(float (&a)[2][8], unsigned a0, unsigned a1) {
+#define BCBF_RD(u_, s_, addr) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[u_][s_]) : "v"(addr), "n"(OFF + NB * 4 * PSR<float>::colstep(s_)))
+    BCBF_RD(0, 0, a0); BCBF_RD(1, 0, a1); BCBF_RD(0, 1, a0); BCBF_RD(1, 1, a1);
+    BCBF_RD(0, 2, a0); BCBF_RD(1, 2, a1); BCBF_RD(0, 3, a0); BCBF_RD(1, 3, a1);
+    BCBF_RD(0, 4, a0); BCBF_RD(1, 4, a1); BCBF_RD(0, 5, a0); BCBF_RD(1, 5, a1);
+    BCBF_RD(0, 6, a0); BCBF_RD(1, 6, a1); BCBF_RD(0, 7, a0); BCBF_RD(1, 7, a1);
+#undef BCBF_RD
+}
+template <typename T> __device__ __forceinline__ void lds_wait16(T (&a)[2][8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[0][4]), "+v"(a[0][5]), "+v"(a[0][6]), "+v"(a[0][7]),
+                   "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(a[1][4]), "+v"(a[1][5]), "+v"(a[1][6]), "+v"(a[1][7]));
+}
+
+// quad broadcast: lane c of every quad -> all four lanes (one DPP move per 32 bits)
+template <int CTRL> __device__ inline float dpp_bc(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ inline double dpp_bc(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFLL), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+template <typename T, int C, int NS>
+__global__ void __launch_bounds__(256, 1)
+posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
+                            const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
+                            const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
+                            const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
+                            T* __restrict__ Wout, int nq, int N, int Np, int n) {
+    using P = PSR<T>;
+    using acc_t = typename P::acc_t;
+    constexpr int V = Vec<T>::V, QW = 4, ES = (int)sizeof(T);
+    constexpr int REGBLK = P::REGBLK, SLABBLK = PSR_MAXBLK - 1 - REGBLK;
+    constexpr int TILE = NB * NB;                      // elements per tile buffer
+    extern __shared__ double smem_psr[];
+    const int wave = threadIdx.x >> 6;                 // blockDim.x == 256: all four waves stage tiles
+    T* Ts = reinterpret_cast<T*>(smem_psr);            // three 32x32 operator tiles (ring) first: 16-byte aligned
+    T* Xs = Ts + 3 * TILE;                             // [Np][NS]  (state dim padded to NS with zeros)
+    T* Us = Xs + (size_t)Np * NS;                      // [Np][C]   (rows >= N are zero: padded rows contribute nothing)
+    T* Vs = Us + (size_t)Np * C;                       // [Np][NS]
+    T* Wl = Vs + (size_t)Np * NS + (size_t)wave * (SLABBLK * 8 * 64) + (threadIdx.x & 63);   // this lane's slots of W blocks >= REGBLK
+    for (int i = threadIdx.x; i < Np * NS; i += blockDim.x) {
+        const int row = i / NS, d = i - row * NS;
+        const bool ok = row < N && d < n;
+        Xs[i] = ok ? X[(size_t)row * n + d] : T(0);
+        Vs[i] = ok ? Vw[(size_t)row * n + d] : T(0);
+    }
+    for (int i = threadIdx.x; i < Np * C; i += blockDim.x) Us[i] = i < N * C ? UHB[i] : T(0);
+
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int ql = j >> 2, c = j & 3;                  // query slot in the wave, component
+    const int q = (blockIdx.x * 4 + wave) * QW + ql;
+    const bool qok = q < nq, cok = c < C;              // (a wave past the end still stages tiles and meets the barriers)
+    const int qq = qok ? q : nq - 1;
+
+    T xqr[NS], iell[NS];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) {
+        xqr[d] = d < n ? xq[(size_t)qq * n + d] : T(0);
+        iell[d] = d < n ? T(1) / ell[d] : T(0);
+    }
+    const T s2 = s2p[0];
+    T gram[C], mk[NS];
+#pragma unroll
+    for (int a = 0; a < C; ++a) gram[a] = T(0);
+#pragma unroll
+    for (int d = 0; d < NS; ++d) mk[d] = T(0);
+    const int cc = cok ? c : 0;
+    const T cmask = cok ? T(1) : T(0);
+    const int nblk = Np / NB;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(Lop), 0, (int)(lop_elems<V>(Np) * sizeof(T)), 0x00020000);
+    // Tile (I, K) of the operator, L[32I + r][32K + col] (K < I: the packed off-diagonal part, element (row, col) at
+    // lop_base(col) + row; K == I: the full-tile copy of inv(L_II), column stride 32), is fetched ONCE per workgroup in
+    // 16-byte pieces (PPC per column; thread -> column tid / PPC (+ 16 for its second piece in fp64), piece tid % PPC).
+    // LDS image: column-major, 32 elements per column, with the two 16-row halves of a column swapped when the lane
+    // group that reads it is odd -- the 32 lanes an LDS read serves in one cycle (lane groups g, g+1: two columns, 16
+    // rows each) then cover every bank exactly once (ds_read_b64: 64 banks; ds_read_b32: 32).
+    constexpr int PPC = P::PPC, EPP = 16 / ES;        // elements per piece
+    const int pc0 = threadIdx.x / PPC, pp = threadIdx.x % PPC;
+    auto gload = [&](u32x4r (&r)[P::PIECES], int I, int K) {
+        const bool isdiag = K == I;
+        const int stride = isdiag ? NB : Np - NB * (K + 1);                   // column stride inside block column K
+        const int base = isdiag ? lop_dfull_block(I, Np) : lop_base<V>(K * NB, Np) + I * NB;   // element (row 0 of the tile, col 0)
+        const int voff = (pc0 * stride + EPP * pp) * ES;
+#pragma unroll
+        for (int h = 0; h < P::PIECES; ++h)
+            r[h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (base + 16 * h * stride) * ES, 0);
+    };
+    // the group that reads column col is (col / LANECOL) & 3; its parity selects the half swap
+    const int wr_off = pc0 * NB + ((pp ^ (((pc0 / P::LANECOL) & 1) * (PPC / 2))) * EPP);   // (second piece: 16 columns further)
+    auto lds_put = [&](T* tb, const u32x4r (&r)[P::PIECES]) {
+#pragma unroll
+        for (int h = 0; h < P::PIECES; ++h) *reinterpret_cast<u32x4r*>(tb + wr_off + 16 * NB * h) = r[h];
+    };
+    // a[u'][s] = tile[row 16u' + j][col colstep(s) + LANECOL g]
+    const int rd_off0 = P::LANECOL * g * NB + (j ^ ((g & 1) << 4));
+    const int rd_off1 = P::LANECOL * g * NB + ((16 | j) ^ ((g & 1) << 4));
+    const unsigned ts_a0 = (unsigned)(size_t)(__attribute__((address_space(3))) T*)(Ts + rd_off0);
+    const unsigned ts_a1 = (unsigned)(size_t)(__attribute__((address_space(3))) T*)(Ts + rd_off1);
+
+    T wreg[REGBLK][8];                                 // W_K: block rows colstep(s) + LANECOL g at index s, column j
+    auto wget = [&](auto Kc, int s_) -> T {
+        constexpr int K_ = decltype(Kc)::value;
+        if constexpr (K_ < REGBLK) return wreg[K_][s_];
+        else return Wl[((K_ - REGBLK) * 8 + s_) * 64];
+    };
+    // Pipeline, step t = tile t (tiles in the order (0,0), (1,0), (1,1), (2,0), ...; three LDS buffers):
+    //   write tile t+2 (fetched during step t-1) into buffer (t+2) % 3  |  fetch tile t+3 into registers  |
+    //   read the A operands of tile t+1 from buffer (t+1) % 3  |  multiply tile t (operands read a step ago)  |  barrier
+    auto fetch = [&](u32x4r (&r)[P::PIECES], auto tc) {
+        constexpr int t_ = decltype(tc)::value;
+        constexpr int I_ = tile_row(t_);
+        gload(r, I_, t_ - I_ * (I_ + 1) / 2);
+    };
+    u32x4r stage[P::PIECES];
+    T acur[2][8], anxt[2][8], pend[8];
+    fetch(stage, Ic<0>{});
+    lds_put(Ts, stage);
+    fetch(stage, Ic<1>{});
+    lds_put(Ts + TILE, stage);
+    fetch(stage, Ic<2>{});
+    __syncthreads();                                   // staging of X / UH B / Vw and tiles 0, 1 visible
+    lds_get16<0>(acur, ts_a0, ts_a1);
+    lds_wait16(acur);
+    // Gram row / mean column of this lane's query from the W tile of block Ib held in pend[]
+    auto epilogue = [&](int Ib) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const T v = pend[e];
+            const int row = Ib * NB + P::colstep(e) + P::LANECOL * g;
+            const T vb[4] = {dpp_bc<0x00>(v), dpp_bc<0x55>(v), dpp_bc<0xAA>(v), dpp_bc<0xFF>(v)};
+#pragma unroll
+            for (int a_ = 0; a_ < C; ++a_) gram[a_] += v * vb[a_];             // lane c: G[c][a]
+#pragma unroll
+            for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;        // lane c: (Vw'W)[d][c]
+        }
+    };
+    static_for<0, PSR_MAXBLK>([&](auto Ict) {
+        constexpr int I = decltype(Ict)::value;
+        if (I < nblk) {
+            acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            // ---- off-diagonal tiles (I, K), K < I: acc += L_IK W_K
+            static_for<0, I>([&](auto Kct) {
+                constexpr int K = decltype(Kct)::value;
+                constexpr int t = I * (I + 1) / 2 + K;
+                lds_put(Ts + TILE * ((t + 2) % 3), stage);
+                fetch(stage, Ic<t + 3>{});
+                lds_get16<((t + 1) % 3) * P::TILE_BYTES>(anxt, ts_a0, ts_a1);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const T wk = wget(Kct, s);
+                    acc0 = P::mfma(acur[0][s], wk, acc0);
+                    acc1 = P::mfma(acur[1][s], wk, acc1);
+                }
+                if constexpr (K == 0 && I > 0) epilogue(I - 1);                // VALU work beside this row's first MFMAs
+                lds_wait16(anxt);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+                __syncthreads();
+            });
+            constexpr int t = I * (I + 1) / 2 + I;
+            lds_put(Ts + TILE * ((t + 2) % 3), stage);
+            fetch(stage, Ic<t + 3>{});
+            lds_get16<((t + 1) % 3) * P::TILE_BYTES>(anxt, ts_a0, ts_a1);
+            // ---- Phi tile of block I: phi[s] = k(x_q, X_row) (UH B)[row][c], row = 32I + blkrow(s, g).  The exp of
+            //      (query, row) is evaluated once, by the lane whose component equals the register index, and broadcast
+            //      inside the quad: lane c evaluates the row that register 4u + c holds
+            T phi[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row_m = I * NB + P::colstep(4 * u) + P::LANECOL * g + (P::colstep(1) - P::colstep(0)) * c;
+                T d2 = T(0);
+#pragma unroll
+                for (int d = 0; d < NS; ++d) { const T z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
+                const T kmine = s2 * P::exp_(T(-0.5) * d2);
+                const T kk[4] = {dpp_bc<0x00>(kmine), dpp_bc<0x55>(kmine), dpp_bc<0xAA>(kmine), dpp_bc<0xFF>(kmine)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    phi[4 * u + r] = kk[r] * Us[(I * NB + P::colstep(4 * u + r) + P::LANECOL * g) * C + cc] * cmask;
+            }
+            // ---- diagonal step: W_I = inv(L_II) (Phi_I - acc)   (inv(L_II) is lower triangular: tile 0 needs k < 16 only)
+            acc_t w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const T b_ = phi[s] - ((s >> 2) ? acc1[s & 3] : acc0[s & 3]);
+                if (s < 4) w0 = P::mfma(acur[0][s], b_, w0);
+                w1 = P::mfma(acur[1][s], b_, w1);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const T v = (e >> 2) ? w1[e & 3] : w0[e & 3];
+                pend[e] = v;
+                if constexpr (I < REGBLK) { wreg[I][e] = v; asm volatile("" : "+a"(wreg[I][e])); }   // lives in the accumulation registers
+                else if constexpr (I < PSR_MAXBLK - 1) Wl[((I - REGBLK) * 8 + e) * 64] = v;
+            }
+            if (Wout != nullptr && qok && cok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    Wout[((size_t)q * Np + I * NB + P::colstep(e) + P::LANECOL * g) * C + c] = pend[e];
+            }
+            lds_wait16(anxt);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+            if (I == nblk - 1) epilogue(I);
+            __syncthreads();
+        }
+    });
+
+    // ---- the four lane groups hold different rows: combine, then write Mk[q][d][c], Bk[q][c][a]
+#pragma unroll
+    for (int a = 0; a < C; ++a) { gram[a] += __shfl_xor(gram[a], 16, 64); gram[a] += __shfl_xor(gram[a], 32, 64); }
+#pragma unroll
+    for (int d = 0; d < NS; ++d) { mk[d] += __shfl_xor(mk[d], 16, 64); mk[d] += __shfl_xor(mk[d], 32, 64); }
+    if (g == 0 && qok && cok) {
+#pragma unroll
+        for (int d = 0; d < NS; ++d)
+            if (d < n) Mk[((size_t)q * n + d) * C + c] = M0[c * n + d] + mk[d];
+#pragma unroll
+        for (int a = 0; a < C; ++a) {
+            T v = s2 * Bm[c * C + a] - gram[a];
+            if (a == c && jitter2 != nullptr) v += jitter2[(size_t)q * C + c];
+            Bk[((size_t)q * C + c) * C + a] = v;
+        }
+    }
+}
+
+static int psr_state_dim(int n) { return n <= 2 ? 2 : n; }   // instantiated widths: 2, 3, 4
+
+template <typename T> static size_t psr_lds_bytes(int Np, int n, int m) {
+    constexpr int SLABBLK = PSR_MAXBLK - 1 - PSR<T>::REGBLK;
+    return ((size_t)3 * NB * NB + (size_t)Np * (2 * psr_state_dim(n) + m + 1) +
+            (Np > NB * PSR<T>::REGBLK ? (size_t)4 * SLABBLK * 512 : 0)) * sizeof(T);
+}
+
+// N <= 512, n <= 4 (wider states need more registers than the explicit operand prefetch leaves) and the staged copies
+// fit in LDS
+template <typename T> static bool psr_fits(int N, int n, int m) {
+    const int Np = round_up(N, NB);
+    return n <= 4 && Np <= NB * PSR_MAXBLK && psr_lds_bytes<T>(Np, n, m) <= 160 * 1024;
+}
+bool posterior_shared64_fits(int N, int n, int m) { return psr_fits<double>(N, n, m); }
+bool posterior_shared_reg32_fits(int N, int n, int m) { return psr_fits<float>(N, n, m); }
+
+template <typename T, int C, int NS>
+static void launch_psr(dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X, const T* UHB,
+                       const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
+                       T* W, int nq, int N, int Np, int n) {
+    static int opt_in[64] = {0};               // largest dynamic LDS size opted into, per device
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    int& lds_opt_in = opt_in[dev_ & 63];
+    if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
+        (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_opt_in = (int)lds;
+    }
+    hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq,
+                       jitter2, Mk, Bk, W, nq, N, Np, n);
+}
+
+template <typename T, int C>
+static void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
+                         const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
+                         T* Mk, T* Bk, T* W, int nq, int N, int Np, int n) {
+#define BCBF_PSR(NSV) launch_psr<T, C, NSV>(grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
+    switch (NSp) {
+#ifndef BCBF_PSR_DEV              // (development: the C = 3, NS = 3 instantiations only)
+        case 2: BCBF_PSR(2); break;
+        case 4: BCBF_PSR(4); break;
+#endif
+        case 3: BCBF_PSR(3); break;
+        default: break;
+    }
+#undef BCBF_PSR
+}
+
+template <typename T>
+int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
+                                const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk, T* W, int nq,
+                                int N, int n, int m, void* stream) {
+    if (nq <= 0) return BCBF_OK;
+    if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > 3) return BCBF_EINVAL;
+    if (!psr_fits<T>(N, n, m)) return BCBF_EINVAL;
+    const int Np = round_up(N, NB), NSp = psr_state_dim(n);
+    const size_t lds = psr_lds_bytes<T>(Np, n, m);
+    const int waves = (nq + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((waves + 3) / 4);                        // 256 threads: one wave per SIMD (W takes the accumulation registers)
+    switch (m) {
+#ifdef BCBF_PSR_DEV
+        case 2: launch_psr_c<T, 3>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        default: break;
+#else
+        case 1: launch_psr_c<T, 2>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 2: launch_psr_c<T, 3>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        default: launch_psr_c<T, 4>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+#endif
+    }
+    return check_launch("posterior_shared_reg");
+}
+template int launch_posterior_shared_reg<float>(const float*, const float*, const float*, const float*, const float*, const float*,
+                                                const float*, const float*, const float*, const float*, float*, float*, float*,
+                                                int, int, int, int, void*);
+
+}  // namespace bcbf
+
+extern "C" int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                         const double* ell, const double* s2, const double* Bm, const double* M0,
+                                         const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                         int nq, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream);
+}

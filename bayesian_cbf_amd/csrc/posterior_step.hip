@@ -601,7 +601,7 @@ extern "C" int bcbf_posterior_query_f64(const double* Lop, const double* Vw, con
                                         const double* ell, const double* s2, const double* Bm, const double* M0,
                                         const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                         int shared, int Bt, int N, int n, int m, void* stream) {
-    // fp64 matrix cores with the solution kept in registers (posterior_shared64.hip): N <= 512
+    // fp64 matrix cores with the solution kept in registers (posterior_shared_reg.hip): N <= 512, n <= 4
     if (shared && Bt >= 16 && bcbf::posterior_shared64_fits(N, n, m))
         return bcbf_posterior_shared_f64(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, Bt, N, n, m, stream);
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream);

@@ -319,6 +319,13 @@ def main():
         # query on the matrix cores: N^2 flop per column (N^2/2 multiply-adds) -- Gram / mean accumulation not counted
         flops_launch = float(Bc) * (1 + m) * N * N
         mfma_peak = F64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else F32_MFMA_PEAK_TFLOPS
+        if N <= 512 and n <= 4:
+            shared_kernel = "posterior_shared_reg_kernel<%s>" % ("double" if args.dtype == "f64" else "float")
+        elif args.dtype == "f32" and N <= 1536:
+            shared_kernel = "posterior_shared_kernel"
+        else:
+            shared_kernel = ("posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernels hold N <= 512 with the "
+                             "solution in registers, N <= ~1600 in fp32 with it in LDS)")
         achieved = flops_launch * n_launch / (busy_ms * 1e-3) / 1e12
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; shared learned model" % (N, Bt),
@@ -333,10 +340,7 @@ def main():
                        "parallelism": "closed loops sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
             "comm": comm,
-            "roofline": {"bound": "mfma", "kernel": "posterior_shared_kernel" if args.dtype == "f32" and N <= 1536 else
-                         ("posterior_shared64_kernel" if args.dtype == "f64" and N <= 512 else
-                          "posterior_step_kernel (cache-resident factor, VALU; the matrix-core kernels hold N <= ~1600 in "
-                          "fp32 and N <= 512 in fp64)"),
+            "roofline": {"bound": "mfma", "kernel": shared_kernel,
                          "achieved": achieved,
                          "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
                          "traffic": None, "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps,

@@ -190,7 +190,8 @@ int bcbf_posterior_query_f64(const double* Lop, const double* Vw, const double* 
 
 /* Regime S on the matrix cores (fp32; N up to ~1600, while Np*(2n+m+17)*4 bytes fit the 160 KB LDS): Bt queries
  * against ONE GP (instance 0 of the GP tensors), 4 queries per wavefront, blocked forward substitution with
- * v_mfma_f32_16x16x4_f32 against the cache-resident factor.  Same outputs as bcbf_posterior_query_f32(shared=1), which routes here for Bt >= 16.  Replaces
+ * v_mfma_f32_16x16x4_f32 against the cache-resident factor (N <= 512 and n <= 4: the solution stays in registers,
+ * as in the fp64 entry below; larger models keep it in LDS).  Same outputs as bcbf_posterior_query_f32(shared=1), which routes here for Bt >= 16.  Replaces
  * custom_predict with b test points (control_affine_model.py:536-602, 1051-1091). */
 int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
                               const float* ell, const float* s2, const float* Bm, const float* M0,
