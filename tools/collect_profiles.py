@@ -22,7 +22,7 @@ def last_json_line(path):
 
 
 # ---- kernel-trace summaries (libbcbf kernels only; the torch kernels of the synthetic-data generator are dropped)
-for tag in ("default", "parts1", "shared"):
+for tag in ("default", "parts1", "shared", "shared_f64"):
     f = latest("prof_%s/*/*_kernel_stats.csv" % tag)
     if not f:
         continue
@@ -32,7 +32,7 @@ for tag in ("default", "parts1", "shared"):
     print(tag, [(r[0].split("(")[0][-44:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
 
 # ---- bench lines
-for a in ("bench_default", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_shared", "bench_shared_prof", "bench_f64"):
+for a in ("bench_default", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_shared", "bench_shared_prof", "bench_shared_f64", "bench_shared_f64_prof", "bench_f64"):
     if os.path.exists(SRC + a + ".json") and os.path.getsize(SRC + a + ".json"):
         d = last_json_line(SRC + a + ".json")
         json.dump(d, open(DST + a + ".json", "w"), indent=1)
@@ -40,7 +40,7 @@ for a in ("bench_default", "bench_default_prof", "bench_parts1", "bench_parts1_p
         print(a, round(d["value"]), round(d["ms_per_step"], 4), "frac", round(rf["frac"], 4), "kernel_ms", round(rf["kernel_ms"], 4),
               "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
 for a in ("configs.jsonl", "refit_forms.jsonl", "online_growth_f64.json", "reldeg2.jsonl", "speed_test.jsonl",
-          "learn_matrix_vector.jsonl", "mc_rollouts.txt"):
+          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
         shutil.copy(SRC + a, DST + a)
 
@@ -79,7 +79,7 @@ for tag, sched, batch in (("default", "", 2048), ("defaultparts1", " --parts 1",
 
 # ---- MFMA utilisation
 passes = {}
-for tag, sub in (("bench.py --regime shared --parts 1", "pmc_shared"), ("bench_configs C2", "pmc_refit_C2"),
+for tag, sub in (("bench.py --regime shared --parts 1", "pmc_shared"), ("bench.py --regime shared --dtype f64 --parts 1", "pmc_shared_f64"), ("bench_configs C2", "pmc_refit_C2"),
                  ("bench_configs C3f64", "pmc_refit_C3f64"), ("bench_configs C3", "pmc_refit_C3"),
                  ("bench_configs N1024f64", "pmc_refit_N1024f64")):
     f = latest(sub + "/*/*_counter_collection.csv")

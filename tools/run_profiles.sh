@@ -11,6 +11,8 @@ python bench.py --steps 200 --warmup 10 --parts 1 --cpu-sample 0 > $O/bench_part
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_parts1 -- python3 bench.py --parts 1 --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_parts1_prof.json 2> $O/bench_parts1_prof.err
 python bench.py --steps 200 --warmup 10 --regime shared --cpu-sample 0 > $O/bench_shared.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared -- python3 bench.py --regime shared --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_shared_prof.json 2> $O/bench_shared_prof.err
+python bench.py --steps 200 --warmup 10 --regime shared --dtype f64 --cpu-sample 0 > $O/bench_shared_f64.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared_f64 -- python3 bench.py --regime shared --dtype f64 --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_shared_f64_prof.json 2> $O/bench_shared_f64_prof.err
 python bench.py --steps 200 --warmup 10 --dtype f64 --cpu-sample 0 > $O/bench_f64.json 2>/dev/null
 # HBM traffic of the roofline kernel (default schedule AND the one-stream schedule): three passes each
 for sched in "" "--parts 1"; do
@@ -23,10 +25,12 @@ done
 # MFMA utilisation of the matrix-core kernels
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc_shared -- python3 bench.py --regime shared --parts 1 --steps 10 --warmup 2 --cpu-sample 0 > $O/pmc_shared.log 2>&1
+rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc_shared_f64 -- python3 bench.py --regime shared --dtype f64 --parts 1 --steps 10 --warmup 2 --cpu-sample 0 > $O/pmc_shared_f64.log 2>&1
 for cfg in C2 C3f64 C3 N1024f64; do
   rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc_refit_$cfg -- python3 tools/bench_configs.py $cfg > $O/pmc_refit_$cfg.log 2>&1
 done
 python tools/bench_configs.py 2>/dev/null > $O/configs.jsonl
+python tools/time_shared.py 2>/dev/null > $O/shared_queries.txt
 python tools/bench_refit_forms.py 2>/dev/null > $O/refit_forms.jsonl
 python tools/bench_online.py 2>/dev/null > $O/online_growth_f64.json
 python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
