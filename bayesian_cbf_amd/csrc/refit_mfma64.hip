@@ -351,12 +351,13 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     }
     // Batches: one wave per instance (refit_wave64.hip) -- every SIMD advances its own factorisation chain.
-    // Measured (tools/bench_refit_forms.py, MI355X): the per-wave form wins from ~1024 instances at N <= 512 (N = 256:
-    // 0.52 vs 0.83 ms at 1024, 2.0 vs 3.3 ms at 4096; N = 128 already at 512), the workgroup form below that and at
-    // N >= 1024, where one instance's update stream is long enough to feed four waves.  (The 4-column-blocked diagonal
-    // tile of the per-wave form was also tried here for wave 0: it needs ~100 more registers than this kernel's 256
-    // budget leaves, spills, and is 7 % slower than the 32-step form below.)
-    bool per_wave = (Bt >= 1024 && Np <= 512) || (Bt >= 512 && Np <= 128);
+    // Measured (tools/bench_refit_forms.py, MI355X): the per-wave form wins from 1024 instances on at every N (N = 256:
+    // 0.45 vs 0.82 ms at 1024, 1.75 vs 3.2 ms at 4096; N = 512: 2.1 vs 3.1 and 8.2 vs 12.0; N = 1024: 15.0 vs 15.7),
+    // from 512 at N <= 256 and from 64 at N <= 128; below that the workgroup form, whose four waves share one
+    // instance's update stream.  (The 4-column-blocked diagonal tile of the per-wave form was also tried here for wave 0:
+    // it needs ~100 more registers than this kernel's 256 budget leaves, spills, and is 7 % slower than the 32-step
+    // form below.)
+    bool per_wave = Bt >= 1024 || (Bt >= 512 && Np <= 256) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
     if (per_wave) {
         launch_refit_wave64(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);

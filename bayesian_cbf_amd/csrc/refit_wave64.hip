@@ -15,9 +15,20 @@
 //     step and swap them (v_permlane32_swap), then multiply by the 4x4 inverse kept from the factor.
 //   ~13 k cycles per tile instead of ~65 k.
 //
-// The rank-32 updates (v_mfma_f64_16x16x4_f64 on transposed tiles, operands one f64 per lane straight from the packed
-// operator) and the panel solve (accumulator registers as B operands) are those of refit_mfma64.hip, run tile after tile
-// by the owning wave.  Same outputs, same packed layout (bcbf_common.h), same info convention.
+// The rank-32 updates (v_mfma_f64_16x16x4_f64 on transposed tiles, operands straight from the packed operator: the
+// two 16-row halves of a tile are interleaved, MFMA index mu of half h = tile row 2 mu + h, so that a lane's two operand
+// values are adjacent rows and arrive in one 16-byte load) and the panel solve (accumulator registers as B operands)
+// are those of refit_mfma64.hip, run tile after tile by the owning wave.  Same outputs, same packed layout
+// (bcbf_common.h), same info convention.
+//
+// A wave alone on its SIMD hides nothing: every wait is paid in full.  What that meant here (cycle counters,
+// -DBCBF_RW64_PROF, N = 256): the K_b value pass was 44 % of the kernel -- not its arithmetic, but `if (d < n)` around
+// each row load and each LDS read: every access became a basic block with a complete wait behind it (ten serialized
+// memory round trips and 120 LDS round trips per tile).  Zero-filled fixed-width rows + out-of-range buffer offsets
+// (straight-line code, all accesses in flight together) took that pass from 18 k to 4 k cycles per tile:
+// 0.63 -> 0.45 ms at 1024 x 256, 10.7 -> 8.2 ms at 4096 x 512 (same box).  (The same rewrite LOSES in the
+// workgroup-form kernels, refit_mfma*.hip: they run four waves per SIMD against a 128 / 256-register cap, waits are
+// hidden by the other waves and the extra values in flight spill.)
 #include "bcbf_common.h"
 #include "diag_tile64.h"
 
@@ -55,7 +66,7 @@ struct RWShared {
 
 // exp(-x) for x >= 0 in full double precision: k = rint(x log2 e), r = k ln2 - x in [-ln2/2, ln2/2] (two-part ln2),
 // degree-12 Taylor polynomial (truncation 1.7e-16), scaled by 2^-k.  Half the instructions of the library exp (no
-// special cases: the argument is a squared distance); the kernel-value pass is 38 % of this kernel.
+// special cases: the argument is a squared distance).
 __device__ inline double exp_neg(double x) {
     const double kf = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(kf, 0.6931471803691238, -x);
@@ -119,6 +130,11 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 
     int fail = 0;
     const int nblk = Np / NB;
+    // row inputs through buffer descriptors (zero-filled out-of-range reads; jitter may be absent: an empty buffer)
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Xb), 0, FROM_DENSE ? 0 : N * n * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(UHBb), 0, FROM_DENSE ? 0 : N * C * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : X), 0, (!FROM_DENSE && jitter) ? N * 8 : 0, 0x00020000);
 #ifdef BCBF_RW64_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -126,13 +142,14 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
     for (int J = 0; J < nblk && fail == 0; ++J) {
         const int col0 = J * NB;
         if (!FROM_DENSE) {
-            for (int e = lane; e < NB * n; e += 64) {
-                const int c = e / n, d = e - c * n;
-                sh.colX[c][d] = (col0 + c < N) ? Xb[(size_t)(col0 + c) * n + d] : 0.0;
+            // (zero-filled to the full widths: the value pass below reads fixed-width rows without a branch)
+            for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
+                const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+                sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : 0.0;
             }
-            for (int e = lane; e < NB * C; e += 64) {
-                const int c = e / C, a = e - c * C;
-                sh.colUH[c][a] = (col0 + c < N) ? UHb[(size_t)(col0 + c) * C + a] : 0.0;
+            for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
+                const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+                sh.colUH[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : 0.0;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -142,61 +159,87 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
         // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one tile ahead, so that the loads are in
         // flight during the previous tile's update stream instead of queueing behind its panel stores
         double rx[2][BCBF_MAX_STATE_DIM], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+        // Branch-free: every load is issued, a component the model does not have (d >= n, c >= C) or a row past the end
+        // is an out-of-range buffer offset and reads as zero.  (Written with `if (d < n)` around plain loads each one
+        // became its own basic block with a full wait behind it: ten serialized memory round trips per tile, 44 % of
+        // the kernel at N = 256.)
         auto load_rows = [&](int I_) {
             if (FROM_DENSE) return;
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) {
-                const int i = I_ * NB + j16 + 16 * ib;
+                const int i = I_ * NB + 2 * j16 + ib;
                 const bool in = I_ < nblk && i < N;
 #pragma unroll
-                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) rx[ib][d] = (in && d < n) ? Xb[(size_t)i * n + d] : 0.0;
+                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                    rx[ib][d] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsX, (in && d < n) ? (i * n + d) * 8 : -8, 0, 0));
 #pragma unroll
-                for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) ru[ib][c] = (in && c < C) ? UHBb[(size_t)i * C + c] : 0.0;
-                rj[ib] = (in && jitter) ? jitter[(size_t)b * N + i] : 0.0;
+                for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
+                    ru[ib][c] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsU, (in && c < C) ? (i * C + c) * 8 : -8, 0, 0));
+                rj[ib] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsJ, in ? i * 8 : -8, 0, 0));
             }
         };
         load_rows(J);
         for (int I = J; I < nblk; ++I) {
-            const int irow = I * NB + j16;                        // + 16 ib
-            f64x4 acc[2][2];                                      // [cb][ib]:  S'[c = 16cb + 4r + g][i = 16ib + j16]
-            // ---- initial value K_b'(c, i)
+            const int irow = I * NB + 2 * j16;                    // + ib
+            f64x4 acc[2][2];                                      // [cb][ib]:  S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
+                                                                  // the two halves of an operand are adjacent rows, one 16-byte load)
+            // ---- initial value K_b'(c, i).  Straight-line: the column's inputs come from LDS as fixed-width rows (4 state
+            //      components, 4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE
+            //      read per column for both rows of the lane.  (With `if (d < n)` around each LDS read every read sat in a
+            //      basic block of its own with a full wait behind it: 120 serialized LDS round trips per tile.)
+            if (FROM_DENSE) {
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const int i = irow + 16 * ib;
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = irow + ib;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 2 * (4 * r + g) + cb, j = col0 + c;
+                            double val;
+                            if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;      // padding: identity
+                            else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
+                            acc[cb][ib][r] = val;
+                        }
+                }
+            } else {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * cb + 4 * r + g, j = col0 + c;
-                        double val;
-                        if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;          // padding: identity
-                        else if (FROM_DENSE) val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
-                        else {
+                        const int c = 2 * (4 * r + g) + cb, j = col0 + c;
+                        double cx[4], cu[4];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) {
+                            const int i = irow + ib;
                             double d2 = 0.0, uu = 0.0;
 #pragma unroll
-                            for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
-                                if (d < n) { const double z = (rx[ib][d] - sh.colX[c][d]) * iell[d]; d2 += z * z; }
+                            for (int d = 0; d < 4; ++d) { const double z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                            if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
 #pragma unroll
-                            for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a)
-                                if (a < C) uu += ru[ib][a] * sh.colUH[c][a];
-                            val = s2 * exp_neg(0.5 * d2) * uu + (i == j ? rj[ib] : 0.0);
+                                for (int d = 4; d < BCBF_MAX_STATE_DIM; ++d) { const double z = (rx[ib][d] - sh.colX[c][d]) * iell[d]; d2 += z * z; }
+                            }
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                            double val = s2 * exp_neg(0.5 * d2) * uu + (i == j ? rj[ib] : 0.0);
+                            val = (i >= N || j >= N) ? ((i == j) ? 1.0 : 0.0) : val;   // padding: identity
+                            acc[cb][ib][r] = val;
                         }
-                        acc[cb][ib][r] = val;
                     }
             }
             load_rows(I + 1);
             RW_ACC(1);                                            // K_b values
             // ---- S' -= L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight)
             constexpr int KS = BCBF_RW64_KS;
-            double a_nxt[KS][2], b_nxt[KS][2];
+            double2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
             auto fetch = [&](int kk) {
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) {
                     const int base = lop_base<V>(kk + 4 * s_ + g, Np);
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) a_nxt[s_][cb] = lop[base + col0 + 16 * cb + j16];
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) b_nxt[s_][ib] = lop[base + irow + 16 * ib];
+                    a_nxt[s_] = *reinterpret_cast<const double2*>(lop + base + col0 + 2 * j16);
+                    b_nxt[s_] = *reinterpret_cast<const double2*>(lop + base + irow);
                 }
             };
             if (col0 > 0) fetch(0);
@@ -204,10 +247,8 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                 double a_cur[KS][2], b_cur[KS][2];
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) {
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) a_cur[s_][cb] = -a_nxt[s_][cb];            // D = (-A) B + C
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) b_cur[s_][ib] = b_nxt[s_][ib];
+                    a_cur[s_][0] = -a_nxt[s_].x; a_cur[s_][1] = -a_nxt[s_].y;                // D = (-A) B + C
+                    b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
                 }
                 if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
 #pragma unroll
@@ -227,7 +268,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sh.d.tile[16 * cb + 4 * r + g][16 * ib + j16] = acc[cb][ib][r];
+                        for (int r = 0; r < 4; ++r) sh.d.tile[2 * (4 * r + g) + cb][2 * j16 + ib] = acc[cb][ib][r];
                 __builtin_amdgcn_wave_barrier();
                 const int bad = diag_factor_invert64(BCBF_LDS_TILE(sh.d), lane);          // diag_tile64.h: tile -> L, xinv -> inv(L)
                 RW_ACC(3);                                        // factor + inverse
@@ -251,25 +292,28 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     }
                 }
                 if (fail != 0) break;
+                // A operands of the panel solve: output row c' = 16 cbp + j16, contraction index c = 2 (4r + g) + cb (the
+                // column an accumulator register of S' holds).  inv(L_JJ) is lower triangular: c' < 16 meets c < 16 only,
+                // that is r < 2
 #pragma unroll
                 for (int cbp = 0; cbp < 2; ++cbp)
 #pragma unroll
-                    for (int cb = 0; cb <= cbp; ++cb)
+                    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][16 * cb + 4 * r + g];
+                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * (4 * r + g) + cb];
                 RW_ACC(4);                                        // stores of the inverse
             } else {
                 // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of S' are the B operands)
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {
-                    const int i = irow + 16 * ib;
+                    const int i = irow + ib;
 #pragma unroll
                     for (int cbp = 0; cbp < 2; ++cbp) {
                         f64x4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int cb = 0; cb <= cbp; ++cb)
+                        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
+                            for (int r = 0; r < (cbp == 0 ? 2 : 4); ++r)
                                 y = __builtin_amdgcn_mfma_f64_16x16x4f64(ainv[cbp][cb][r], acc[cb][ib][r], y, 0, 0, 0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {

@@ -12,12 +12,10 @@ CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 VARIANTS = {
     "rw_base": [],
     "rw_prof": ["-DBCBF_RW64_PROF"],
-    "rw_occ2": ["-DBCBF_RW64_OCC=2"],
-    "rw_ks2": ["-DBCBF_RW64_KS=2"],
-    "rw_ks8": ["-DBCBF_RW64_KS=8"],
-    "rw_wpb1": ["-DBCBF_RW64_WPB=1"],
-    "rw_wpb3": ["-DBCBF_RW64_WPB=3"],
 }
+if os.environ.get("BCBF_RW_SWEEP"):
+    VARIANTS.update({"rw_occ2_ks4": ["-DBCBF_RW64_OCC=2", "-DBCBF_RW64_KS=4"], "rw_occ2_ks2": ["-DBCBF_RW64_OCC=2", "-DBCBF_RW64_KS=2"], "rw_ks4": ["-DBCBF_RW64_KS=4"],
+                     "rw_wpb2": ["-DBCBF_RW64_WPB=2"], "rw_wpb4": ["-DBCBF_RW64_WPB=4"]})
 
 
 def build():
