@@ -1,4 +1,4 @@
-// The 32x32 diagonal tile of the fp64 blocked Cholesky (refit_wave64.hip, refit_mfma64.hip): factor S = L L' and
+// The 32x32 diagonal tile of the blocked Cholesky (refit_wave64.hip; fp64 and fp32): factor S = L L' and
 // invert L, by ONE wave, out of LDS -- built around 4-column blocks so that the serial part of a step is four rsqrt
 // chains instead of 32 dependent dot products:
 //
@@ -17,20 +17,23 @@ namespace bcbf {
 
 constexpr int DT_LS = NB + 1;            // padded row stride of the LDS tiles
 
-struct DiagTile64 {
-    double tile[NB][DT_LS];                   // in: S' (tile[c][i] = S[i][c]);  out: L, row-major [r][c], zeros above
-    double xinv[NB][DT_LS];                   // out: X = inv(L) [row][col], zeros above the diagonal
-    double P[NB][4];                          // raw panel columns of the current 4-column step
-    double Lp[NB][4];                         // solved panel rows l[r][0..3]
-    double I4[NB / 4][12];                    // the eight 4x4 inverses (10 used)
+template <typename T> struct DiagTile {
+    T tile[NB][DT_LS];                        // in: S' (tile[c][i] = S[i][c]);  out: L, row-major [r][c], zeros above
+    T xinv[NB][DT_LS];                        // out: X = inv(L) [row][col], zeros above the diagonal
+    T P[NB][4];                               // raw panel columns of the current 4-column step
+    T Lp[NB][4];                              // solved panel rows l[r][0..3]
+    T I4[NB / 4][12];                         // the eight 4x4 inverses (10 used)
 };
+using DiagTile64 = DiagTile<double>;
 
 // both halves' values of v: .x = the value held by lane (l & 31), .y = by lane (l & 31) + 32
 __device__ inline double2 halves64(double v) {
     const long long b = __builtin_bit_cast(long long, v);
     const unsigned lo = (unsigned)(b & 0xffffffffLL), hi = (unsigned)(b >> 32);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    unsigned lo2 = lo, hi2 = hi;
+    asm volatile("" : "+v"(lo2), "+v"(hi2));  // distinct registers for the two in-place operands (see the float form)
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo2, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi2, false, false);
     double2 o;
     o.x = __builtin_bit_cast(double, ((long long)r1[0] << 32) | (long long)r0[0]);
     o.y = __builtin_bit_cast(double, ((long long)r1[1] << 32) | (long long)r0[1]);
@@ -42,19 +45,42 @@ __device__ inline double rsqrt_nr2(double p) {      // hardware estimate + two N
     y = y * (1.5 - 0.5 * p * y * y);
     return y;
 }
+__device__ inline float rsqrt_nr2(float p) {        // hardware estimate (1 ulp) + one Newton step
+    float y = __builtin_amdgcn_rsqf(p);
+    y = y * (1.5f - 0.5f * p * y * y);
+    return y;
+}
+__device__ inline float2 halves64(float v) {
+    // (the builtin form of this swap, fine in the double overload above, came back with BOTH results equal to the lower
+    // half's value here -- ROCm 7.2 clang, tools/micro/halves_test.hip -- so the instruction is written out; the s_nop
+    // covers the VALU-write -> permlane read hazard the compiler cannot see inside the asm)
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float2 o;
+    o.x = __builtin_bit_cast(float, a);      // lanes 0-31 keep theirs, lanes 32-63 receive the lower half's
+    o.y = __builtin_bit_cast(float, b);      // lanes 0-31 receive the upper half's, lanes 32-63 keep theirs
+    return o;
+}
 
 // LDS-qualified views: a plain pointer to a __shared__ object is a GENERIC pointer once it crosses a function boundary
 // or a dynamic index, and the accesses compile to flat_load / flat_store instead of ds_read / ds_write (measured:
 // +27 % kernel time)
-using DiagTile64Lds = __attribute__((address_space(3))) DiagTile64;
-using LdsDouble = __attribute__((address_space(3))) double;
-#define BCBF_LDS_TILE(obj) ((bcbf::DiagTile64Lds*)&(obj))
+template <typename T> using DiagTileLds = __attribute__((address_space(3))) DiagTile<T>;
+template <typename T> using LdsElem = __attribute__((address_space(3))) T;
+using DiagTile64Lds = DiagTileLds<double>;
+using LdsDouble = LdsElem<double>;
+#define BCBF_LDS_TILE(T, obj) ((bcbf::DiagTileLds<T>*)&(obj))
 
 // Whole wave (64 lanes) calls this with the tile's S' already in sh->tile (and visible: wave barrier done by the
 // caller).  Returns 0, or 1 + the index (0..31) of the first non-positive pivot (the outputs are then garbage).
-__device__ inline int diag_factor_invert64(DiagTile64Lds* sh, int lane) {
+template <typename T> struct Vec2Of;
+template <> struct Vec2Of<double> { using type = double2; };
+template <> struct Vec2Of<float> { using type = float2; };
+
+template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* sh, int lane) {
+    using T2 = typename Vec2Of<T>::type;
     const int rr = lane & 31, hb = lane >> 5;
-    double S[16];                                      // S[rr][16 hb + q]  (= S'[16 hb + q][rr])
+    T S[16];                                      // S[rr][16 hb + q]  (= S'[16 hb + q][rr])
 #pragma unroll
     for (int q = 0; q < 16; ++q) S[q] = sh->tile[16 * hb + q][rr];
     __builtin_amdgcn_wave_barrier();                   // the tile buffer is free again (it becomes L)
@@ -70,49 +96,49 @@ __device__ inline int diag_factor_invert64(DiagTile64Lds* sh, int lane) {
         }
         __builtin_amdgcn_wave_barrier();
         // (2) 4x4 diagonal block: Cholesky factor and inverse, redundantly in every lane
-        const double d00 = sh->P[c0][0];
-        const double d10 = sh->P[c0 + 1][0], d11 = sh->P[c0 + 1][1];
-        const double d20 = sh->P[c0 + 2][0], d21 = sh->P[c0 + 2][1], d22 = sh->P[c0 + 2][2];
-        const double d30 = sh->P[c0 + 3][0], d31 = sh->P[c0 + 3][1], d32 = sh->P[c0 + 3][2], d33 = sh->P[c0 + 3][3];
-        const double p0 = d00;
-        if (!(p0 > 0.0) && bad == 0) bad = c0 + 1;
-        const double r0 = rsqrt_nr2(p0 > 0.0 ? p0 : 1.0);
-        const double l00 = p0 * r0, l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
-        const double p1 = d11 - l10 * l10;
-        if (!(p1 > 0.0) && bad == 0) bad = c0 + 2;
-        const double r1 = rsqrt_nr2(p1 > 0.0 ? p1 : 1.0);
-        const double l11 = p1 * r1, l21 = (d21 - l20 * l10) * r1, l31 = (d31 - l30 * l10) * r1;
-        const double p2 = d22 - l20 * l20 - l21 * l21;
-        if (!(p2 > 0.0) && bad == 0) bad = c0 + 3;
-        const double r2 = rsqrt_nr2(p2 > 0.0 ? p2 : 1.0);
-        const double l22 = p2 * r2, l32 = (d32 - l30 * l20 - l31 * l21) * r2;
-        const double p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
-        if (!(p3 > 0.0) && bad == 0) bad = c0 + 4;
-        const double r3 = rsqrt_nr2(p3 > 0.0 ? p3 : 1.0);
-        const double l33 = p3 * r3;
+        const T d00 = sh->P[c0][0];
+        const T d10 = sh->P[c0 + 1][0], d11 = sh->P[c0 + 1][1];
+        const T d20 = sh->P[c0 + 2][0], d21 = sh->P[c0 + 2][1], d22 = sh->P[c0 + 2][2];
+        const T d30 = sh->P[c0 + 3][0], d31 = sh->P[c0 + 3][1], d32 = sh->P[c0 + 3][2], d33 = sh->P[c0 + 3][3];
+        const T p0 = d00;
+        if (!(p0 > T(0.0)) && bad == 0) bad = c0 + 1;
+        const T r0 = rsqrt_nr2(p0 > T(0.0) ? p0 : T(1.0));
+        const T l00 = p0 * r0, l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+        const T p1 = d11 - l10 * l10;
+        if (!(p1 > T(0.0)) && bad == 0) bad = c0 + 2;
+        const T r1 = rsqrt_nr2(p1 > T(0.0) ? p1 : T(1.0));
+        const T l11 = p1 * r1, l21 = (d21 - l20 * l10) * r1, l31 = (d31 - l30 * l10) * r1;
+        const T p2 = d22 - l20 * l20 - l21 * l21;
+        if (!(p2 > T(0.0)) && bad == 0) bad = c0 + 3;
+        const T r2 = rsqrt_nr2(p2 > T(0.0) ? p2 : T(1.0));
+        const T l22 = p2 * r2, l32 = (d32 - l30 * l20 - l31 * l21) * r2;
+        const T p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+        if (!(p3 > T(0.0)) && bad == 0) bad = c0 + 4;
+        const T r3 = rsqrt_nr2(p3 > T(0.0) ? p3 : T(1.0));
+        const T l33 = p3 * r3;
         // inverse of the 4x4 factor (lower): i_aa = 1 / l_aa
-        const double i00 = r0, i11 = r1, i22 = r2, i33 = r3;
-        const double i10 = -(l10 * i00) * r1;
-        const double i20 = -(l20 * i00 + l21 * i10) * r2, i21 = -(l21 * i11) * r2;
-        const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * r3, i31 = -(l31 * i11 + l32 * i21) * r3,
+        const T i00 = r0, i11 = r1, i22 = r2, i33 = r3;
+        const T i10 = -(l10 * i00) * r1;
+        const T i20 = -(l20 * i00 + l21 * i10) * r2, i21 = -(l21 * i11) * r2;
+        const T i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * r3, i31 = -(l31 * i11 + l32 * i21) * r3,
                      i32 = -(l32 * i22) * r3;
         if (lane == 0) {
-            LdsDouble* I4 = sh->I4[s];
+            LdsElem<T>* I4 = sh->I4[s];
             I4[0] = i00; I4[1] = i10; I4[2] = i11; I4[3] = i20; I4[4] = i21; I4[5] = i22;
             I4[6] = i30; I4[7] = i31; I4[8] = i32; I4[9] = i33;
         }
         // (3) this lane's row of the panel: l = P[rr][:] inv(L4)'   (rows of the block itself: L4; rows above: 0)
-        const double pr0 = sh->P[rr][0], pr1 = sh->P[rr][1], pr2 = sh->P[rr][2], pr3 = sh->P[rr][3];
-        double l0 = pr0 * i00;
-        double l1 = pr0 * i10 + pr1 * i11;
-        double l2 = pr0 * i20 + pr1 * i21 + pr2 * i22;
-        double l3 = pr0 * i30 + pr1 * i31 + pr2 * i32 + pr3 * i33;
+        const T pr0 = sh->P[rr][0], pr1 = sh->P[rr][1], pr2 = sh->P[rr][2], pr3 = sh->P[rr][3];
+        T l0 = pr0 * i00;
+        T l1 = pr0 * i10 + pr1 * i11;
+        T l2 = pr0 * i20 + pr1 * i21 + pr2 * i22;
+        T l3 = pr0 * i30 + pr1 * i31 + pr2 * i32 + pr3 * i33;
         const int ra = rr - c0;                          // row inside the block (0..3), negative above
-        if (ra == 0) { l0 = l00; l1 = 0.0; l2 = 0.0; l3 = 0.0; }
-        if (ra == 1) { l0 = l10; l1 = l11; l2 = 0.0; l3 = 0.0; }
-        if (ra == 2) { l0 = l20; l1 = l21; l2 = l22; l3 = 0.0; }
+        if (ra == 0) { l0 = l00; l1 = T(0.0); l2 = T(0.0); l3 = T(0.0); }
+        if (ra == 1) { l0 = l10; l1 = l11; l2 = T(0.0); l3 = T(0.0); }
+        if (ra == 2) { l0 = l20; l1 = l21; l2 = l22; l3 = T(0.0); }
         if (ra == 3) { l0 = l30; l1 = l31; l2 = l32; l3 = l33; }
-        if (ra < 0) { l0 = 0.0; l1 = 0.0; l2 = 0.0; l3 = 0.0; }
+        if (ra < 0) { l0 = T(0.0); l1 = T(0.0); l2 = T(0.0); l3 = T(0.0); }
         if (hb == 0) {
             sh->Lp[rr][0] = l0; sh->Lp[rr][1] = l1; sh->Lp[rr][2] = l2; sh->Lp[rr][3] = l3;
             sh->tile[rr][c0] = l0; sh->tile[rr][c0 + 1] = l1; sh->tile[rr][c0 + 2] = l2; sh->tile[rr][c0 + 3] = l3;
@@ -124,7 +150,7 @@ __device__ inline int diag_factor_invert64(DiagTile64Lds* sh, int lane) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 if (16 + q <= c0 + 3) continue;          // dead for both halves (compile time)
-                const LdsDouble* lj = sh->Lp[16 * hb + q];
+                const LdsElem<T>* lj = sh->Lp[16 * hb + q];
                 S[q] -= l0 * lj[0] + l1 * lj[1] + l2 * lj[2] + l3 * lj[3];
                 // pin the update HERE: LLVM otherwise sinks the multiply-adds to the step that publishes
                 // this column and keeps the four loaded operands alive instead of the one result (500+
@@ -142,24 +168,24 @@ __device__ inline int diag_factor_invert64(DiagTile64Lds* sh, int lane) {
 #pragma unroll 1
         for (int s = 0; s < NB / 4; ++s) {
             const int c0 = 4 * s;
-            double pa = 0.0, pb = 0.0;                   // rows c0 + 2hb, c0 + 2hb + 1
-            const LdsDouble* La = &sh->tile[c0 + 2 * hb][0];
-            const LdsDouble* Lb = La + DT_LS;
+            T pa = T(0.0), pb = T(0.0);                   // rows c0 + 2hb, c0 + 2hb + 1
+            const LdsElem<T>* La = &sh->tile[c0 + 2 * hb][0];
+            const LdsElem<T>* Lb = La + DT_LS;
 #pragma unroll 4
             for (int k = 0; k < c0; ++k) {
-                const double xk = sh->xinv[k][rr];
+                const T xk = sh->xinv[k][rr];
                 pa -= La[k] * xk;
                 pb -= Lb[k] * xk;
             }
-            const double2 ha = halves64(pa), hbv = halves64(pb);
-            const double e0 = (rr == c0 ? 1.0 : 0.0) + ha.x, e1 = (rr == c0 + 1 ? 1.0 : 0.0) + hbv.x;
-            const double e2 = (rr == c0 + 2 ? 1.0 : 0.0) + ha.y, e3 = (rr == c0 + 3 ? 1.0 : 0.0) + hbv.y;
-            const LdsDouble* I4 = sh->I4[s];
+            const T2 ha = halves64(pa), hbv = halves64(pb);
+            const T e0 = (rr == c0 ? T(1.0) : T(0.0)) + ha.x, e1 = (rr == c0 + 1 ? T(1.0) : T(0.0)) + hbv.x;
+            const T e2 = (rr == c0 + 2 ? T(1.0) : T(0.0)) + ha.y, e3 = (rr == c0 + 3 ? T(1.0) : T(0.0)) + hbv.y;
+            const LdsElem<T>* I4 = sh->I4[s];
             if (hb == 0) {                                // exact zeros above the diagonal (rows < column)
-                sh->xinv[c0][rr] = c0 >= rr ? I4[0] * e0 : 0.0;
-                sh->xinv[c0 + 1][rr] = c0 + 1 >= rr ? I4[1] * e0 + I4[2] * e1 : 0.0;
-                sh->xinv[c0 + 2][rr] = c0 + 2 >= rr ? I4[3] * e0 + I4[4] * e1 + I4[5] * e2 : 0.0;
-                sh->xinv[c0 + 3][rr] = c0 + 3 >= rr ? I4[6] * e0 + I4[7] * e1 + I4[8] * e2 + I4[9] * e3 : 0.0;
+                sh->xinv[c0][rr] = c0 >= rr ? I4[0] * e0 : T(0.0);
+                sh->xinv[c0 + 1][rr] = c0 + 1 >= rr ? I4[1] * e0 + I4[2] * e1 : T(0.0);
+                sh->xinv[c0 + 2][rr] = c0 + 2 >= rr ? I4[3] * e0 + I4[4] * e1 + I4[5] * e2 : T(0.0);
+                sh->xinv[c0 + 3][rr] = c0 + 3 >= rr ? I4[6] * e0 + I4[7] * e1 + I4[8] * e2 + I4[9] * e3 : T(0.0);
             }
             __builtin_amdgcn_wave_barrier();
         }

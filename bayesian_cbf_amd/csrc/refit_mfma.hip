@@ -13,7 +13,11 @@
 // fp32 MFMA runs at the fp32 vector rate on gfx950: the gain is operand traffic / instruction count
 // (2 loads + 1 MFMA per 2048 MACs instead of LDS broadcasts), not peak.
 #include "bcbf_common.h"
+#include <stdlib.h>
 
+#ifndef BCBF_R32_WAVE_MIN_BATCH
+#define BCBF_R32_WAVE_MIN_BATCH 1024
+#endif
 namespace bcbf {
 
 // v(lane) + v(lane ^ 32) in every lane on the VALU (gfx950 v_permlane32_swap; a __shfl_xor is an LDS round trip)
@@ -315,6 +319,10 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
     if (tid == 0) info[b] = fail;
 }
 
+int launch_refit_wave32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                        const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info,
+                        int Bt, int N, int Np, int n, int C, hipStream_t st);          // refit_wave64.hip
+
 }  // namespace bcbf
 
 extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
@@ -325,6 +333,17 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     if (!Lop || !info || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
+    // Batches: one wave per instance (refit_wave64.hip, also compiled for fp32); BCBF_REFIT_WAVE=0/1 forces a form
+    bool per_wave = Bt >= BCBF_R32_WAVE_MIN_BATCH || (Bt >= 512 && Np <= 512) || (Bt >= 128 && Np <= 256) || (Bt >= 64 && Np <= 128);
+    if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
+    if (per_wave) {
+        if (!Kdense) {
+            if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+            if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+        }
+        launch_refit_wave32(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);
+        return check_launch("refit_wave32");
+    }
     const bool wide = Bt < 128 && N >= 128;   // few instances: 16 waves per workgroup and the unrolled diagonal-tile code (Bt=1: 145 -> 117 us at N=128, 346 -> 273 at 256, 869 -> 725 at 512, 2115 -> 1990 at 1024)
 #define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
     do {                                                                                                \

@@ -35,6 +35,7 @@
 namespace bcbf {
 
 using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 
 #ifndef BCBF_RW64_WPB
 #define BCBF_RW64_WPB 1          // waves (= instances) per workgroup (measured: 1 beats 2 by 5 %, 3 loses 80 %: LDS)
@@ -42,6 +43,12 @@ using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 #ifndef BCBF_RW64_OCC
 #define BCBF_RW64_OCC 1          // waves per SIMD the register allocation aims at (2 = 256 VGPRs spills ~100 registers
                                  // and is 1.6x slower at N = 256, batch 1024: 0.94 vs 0.57 ms)
+#endif
+// fp32: both allocations are compiled; two waves per SIMD (256 registers each, ~40 spilled) win once the batch gives every
+// SIMD more than one instance (4096 x 512: 5.4 -> 4.8 ms, 4096 x 256: 1.33 -> 1.12), one wave per SIMD below that
+// (1024 x 256: 0.35 vs 0.44 ms)
+#ifndef BCBF_RW32_KS
+#define BCBF_RW32_KS 8
 #endif
 #ifndef BCBF_RW64_KS
 #define BCBF_RW64_KS 8           // k-steps (of 4 columns) per software-pipeline stage of the update stream (8 beats 4 by 4 %)
@@ -58,16 +65,16 @@ using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 
 constexpr int RW_WPB = BCBF_RW64_WPB;
 
-struct RWShared {
-    DiagTile64 d;                             // the diagonal tile's working set (diag_tile64.h)
-    double colX[NB][BCBF_MAX_STATE_DIM];
-    double colUH[NB][BCBF_MAX_CTRL_DIM + 1];
+template <typename T> struct RWShared {
+    DiagTile<T> d;                            // the diagonal tile's working set (diag_tile64.h)
+    T colX[NB][BCBF_MAX_STATE_DIM];
+    T colUH[NB][BCBF_MAX_CTRL_DIM + 1];
 };
 
 // exp(-x) for x >= 0 in full double precision: k = rint(x log2 e), r = k ln2 - x in [-ln2/2, ln2/2] (two-part ln2),
 // degree-12 Taylor polynomial (truncation 1.7e-16), scaled by 2^-k.  Half the instructions of the library exp (no
 // special cases: the argument is a squared distance).
-__device__ inline double exp_neg(double x) {
+__device__ inline double exp_neg64(double x) {
     const double kf = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(kf, 0.6931471803691238, -x);
     r = __builtin_fma(kf, 1.9082149292705877e-10, r);
@@ -86,55 +93,81 @@ __device__ inline double exp_neg(double x) {
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, -(int)kf);
 }
-template <bool FROM_DENSE>
-__global__ void __launch_bounds__(64 * RW_WPB, BCBF_RW64_OCC)
-refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH, const double* __restrict__ Bm,
-                    const double* __restrict__ ell, const double* __restrict__ s2p, const double* __restrict__ jitter,
-                    const double* __restrict__ Kdense, double* __restrict__ Lop, double* __restrict__ UHBout,
-                    double* __restrict__ Ldense, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
-    constexpr int V = 2;
-    __shared__ RWShared shm[RW_WPB];
+// what differs between the two precisions: the MFMA, the row its accumulator register r holds in lane group g (the
+// M index: g + 4r in fp64, 4g + r in fp32 -- the same value is the contraction index of k-step r when an accumulator is
+// fed back as a B operand), the exponential and the load width
+template <typename T> struct RW;
+template <> struct RW<double> {
+    using acc_t = f64x4;
+    using vec2 = double2;
+    __device__ static int midx(int r, int g) { return 4 * r + g; }
+    static constexpr int PANEL_R0 = 2;                // k-steps that meet the upper 16 rows of inv(L_JJ): midx < 8 <=> r < 2
+    __device__ static acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static double exp_neg(double x) { return exp_neg64(x); }
+    __device__ static double bload(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+};
+template <> struct RW<float> {
+    using acc_t = f32x4w;
+    using vec2 = float2;
+    __device__ static int midx(int r, int g) { return 4 * g + r; }
+    static constexpr int PANEL_R0 = 4;                // midx < 8 <=> g < 2: a property of the lane, every k-step runs
+    __device__ static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static float exp_neg(float x) { return __expf(-x); }
+    __device__ static float bload(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+};
+
+template <typename T, bool FROM_DENSE, int OCC>
+__global__ void __launch_bounds__(64 * RW_WPB, OCC)
+refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
+                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
+                    const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout,
+                    T* __restrict__ Ldense, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+    constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
+    using P = RW<T>;
+    using acc_t = typename P::acc_t;
+    using T2 = typename P::vec2;
+    __shared__ RWShared<T> shm[RW_WPB];
     // wave-uniform instance index: the per-instance pointers and hyper-parameters then live in SGPRs (scalar loads)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x * RW_WPB + wave;
     if (b >= Bt) return;                                      // whole wave: no workgroup barrier anywhere below
-    __attribute__((address_space(3))) RWShared& sh = *(__attribute__((address_space(3))) RWShared*)&shm[wave];   // keep ds_* ops
+    __attribute__((address_space(3))) RWShared<T>& sh = *(__attribute__((address_space(3))) RWShared<T>*)&shm[wave];   // keep ds_* ops
     const int j16 = lane & 15, g = lane >> 4;                 // MFMA roles
 
-    double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
-    const double* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
-    const double* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
-    const double* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
-    double* Ld = Ldense ? Ldense + (size_t)b * N * N : nullptr;
-    double iell[BCBF_MAX_STATE_DIM], Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
-    double s2 = 0.0;
+    T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const T* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
+    const T* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
+    const T* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
+    T* Ld = Ldense ? Ldense + (size_t)b * N * N : nullptr;
+    T iell[BCBF_MAX_STATE_DIM], Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+    T s2 = T(0.0);
     if (!FROM_DENSE) {
         s2 = s2p[b];
 #pragma unroll
-        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) iell[d] = d < n ? 1.0 / ell[(size_t)b * n + d] : 0.0;
+        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
 #pragma unroll
         for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a)
-            Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : 0.0;
+            Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : T(0.0);
         for (int i = lane; i < N; i += 64)
             for (int c = 0; c < C; ++c) {
-                double s = 0.0;
+                T s = T(0.0);
                 for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
                 UHBout[((size_t)b * N + i) * C + c] = s;
             }
     }
     if (Ld)
-        for (int e = lane; e < N * N; e += 64) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = 0.0; }
-    const double* UHBb = FROM_DENSE ? nullptr : UHBout + (size_t)b * N * C;      // rows of UH B, read back per tile
+        for (int e = lane; e < N * N; e += 64) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = T(0.0); }
+    const T* UHBb = FROM_DENSE ? nullptr : UHBout + (size_t)b * N * C;      // rows of UH B, read back per tile
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
 
     int fail = 0;
     const int nblk = Np / NB;
     // row inputs through buffer descriptors (zero-filled out-of-range reads; jitter may be absent: an empty buffer)
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Xb), 0, FROM_DENSE ? 0 : N * n * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(UHBb), 0, FROM_DENSE ? 0 : N * C * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xb), 0, FROM_DENSE ? 0 : N * n * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, FROM_DENSE ? 0 : N * C * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : X), 0, (!FROM_DENSE && jitter) ? N * 8 : 0, 0x00020000);
+        const_cast<T*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : X), 0, (!FROM_DENSE && jitter) ? N * ES : 0, 0x00020000);
 #ifdef BCBF_RW64_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -145,20 +178,20 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
             // (zero-filled to the full widths: the value pass below reads fixed-width rows without a branch)
             for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
                 const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
-                sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : 0.0;
+                sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
             }
             for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
                 const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
-                sh.colUH[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : 0.0;
+                sh.colUH[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : T(0.0);
             }
         }
         __builtin_amdgcn_wave_barrier();
         RW_ACC(0);                                             // column staging
-        double ainv[2][2][4];                                  // inv(L_JJ) as panel-solve A operands, loaded after the diagonal tile
+        T ainv[2][2][4];                                  // inv(L_JJ) as panel-solve A operands, loaded after the diagonal tile
 
         // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one tile ahead, so that the loads are in
         // flight during the previous tile's update stream instead of queueing behind its panel stores
-        double rx[2][BCBF_MAX_STATE_DIM], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+        T rx[2][BCBF_MAX_STATE_DIM], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
         // Branch-free: every load is issued, a component the model does not have (d >= n, c >= C) or a row past the end
         // is an out-of-range buffer offset and reads as zero.  (Written with `if (d < n)` around plain loads each one
         // became its own basic block with a full wait behind it: ten serialized memory round trips per tile, 44 % of
@@ -171,17 +204,17 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                 const bool in = I_ < nblk && i < N;
 #pragma unroll
                 for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
-                    rx[ib][d] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsX, (in && d < n) ? (i * n + d) * 8 : -8, 0, 0));
+                    rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
 #pragma unroll
                 for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
-                    ru[ib][c] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsU, (in && c < C) ? (i * C + c) * 8 : -8, 0, 0));
-                rj[ib] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsJ, in ? i * 8 : -8, 0, 0));
+                    ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
+                rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
             }
         };
         load_rows(J);
         for (int I = J; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;                    // + ib
-            f64x4 acc[2][2];                                      // [cb][ib]:  S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
+            acc_t acc[2][2];                                      // [cb][ib]:  S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
                                                                   // the two halves of an operand are adjacent rows, one 16-byte load)
             // ---- initial value K_b'(c, i).  Straight-line: the column's inputs come from LDS as fixed-width rows (4 state
             //      components, 4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE
@@ -195,9 +228,9 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int c = 2 * (4 * r + g) + cb, j = col0 + c;
-                            double val;
-                            if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;      // padding: identity
+                            const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                            T val;
+                            if (i >= N || j >= N) val = (i == j) ? T(1.0) : T(0.0);      // padding: identity
                             else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
                             acc[cb][ib][r] = val;
                         }
@@ -207,24 +240,24 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int c = 2 * (4 * r + g) + cb, j = col0 + c;
-                        double cx[4], cu[4];
+                        const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                        T cx[4], cu[4];
 #pragma unroll
                         for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib) {
                             const int i = irow + ib;
-                            double d2 = 0.0, uu = 0.0;
+                            T d2 = T(0.0), uu = T(0.0);
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) { const double z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                            for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
                             if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
 #pragma unroll
-                                for (int d = 4; d < BCBF_MAX_STATE_DIM; ++d) { const double z = (rx[ib][d] - sh.colX[c][d]) * iell[d]; d2 += z * z; }
+                                for (int d = 4; d < BCBF_MAX_STATE_DIM; ++d) { const T z = (rx[ib][d] - sh.colX[c][d]) * iell[d]; d2 += z * z; }
                             }
 #pragma unroll
                             for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
-                            double val = s2 * exp_neg(0.5 * d2) * uu + (i == j ? rj[ib] : 0.0);
-                            val = (i >= N || j >= N) ? ((i == j) ? 1.0 : 0.0) : val;   // padding: identity
+                            T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
+                            val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;   // padding: identity
                             acc[cb][ib][r] = val;
                         }
                     }
@@ -232,19 +265,19 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
             load_rows(I + 1);
             RW_ACC(1);                                            // K_b values
             // ---- S' -= L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight)
-            constexpr int KS = BCBF_RW64_KS;
-            double2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
+            constexpr int KS = sizeof(T) == 4 ? BCBF_RW32_KS : BCBF_RW64_KS;
+            T2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
             auto fetch = [&](int kk) {
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) {
                     const int base = lop_base<V>(kk + 4 * s_ + g, Np);
-                    a_nxt[s_] = *reinterpret_cast<const double2*>(lop + base + col0 + 2 * j16);
-                    b_nxt[s_] = *reinterpret_cast<const double2*>(lop + base + irow);
+                    a_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + col0 + 2 * j16);
+                    b_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + irow);
                 }
             };
             if (col0 > 0) fetch(0);
             for (int kk = 0; kk < col0; kk += 4 * KS) {
-                double a_cur[KS][2], b_cur[KS][2];
+                T a_cur[KS][2], b_cur[KS][2];
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) {
                     a_cur[s_][0] = -a_nxt[s_].x; a_cur[s_][1] = -a_nxt[s_].y;                // D = (-A) B + C
@@ -257,7 +290,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib)
-                            acc[cb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib], 0, 0, 0);
+                            acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
             }
 
             RW_ACC(2);                                            // update stream
@@ -268,9 +301,9 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sh.d.tile[2 * (4 * r + g) + cb][2 * j16 + ib] = acc[cb][ib][r];
+                        for (int r = 0; r < 4; ++r) sh.d.tile[2 * P::midx(r, g) + cb][2 * j16 + ib] = acc[cb][ib][r];
                 __builtin_amdgcn_wave_barrier();
-                const int bad = diag_factor_invert64(BCBF_LDS_TILE(sh.d), lane);          // diag_tile64.h: tile -> L, xinv -> inv(L)
+                const int bad = diag_factor_invert<T>(BCBF_LDS_TILE(T, sh.d), lane);          // diag_tile64.h: tile -> L, xinv -> inv(L)
                 RW_ACC(3);                                        // factor + inverse
                 if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
                 if (Ld && lane < NB && col0 + lane < N) {
@@ -284,11 +317,11 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 #pragma unroll
                         for (int t = 0; t < NB * NB / 64; ++t) {
                             const int e = lane + 64 * t, c = e >> 5, r = e & 31;
-                            const double xv = sh.d.xinv[r][c];
+                            const T xv = sh.d.xinv[r][c];
                             lop[bfull + e] = xv;
                             if (r >= c) lop[bpack + lop_dinv_col(c) + r] = xv;
                         }
-                        if (lane < LOP_DB - 528) lop[bpack + 528 + lane] = 0.0;                  // the block's padding
+                        if (lane < LOP_DB - 528) lop[bpack + 528 + lane] = T(0.0);                  // the block's padding
                     }
                 }
                 if (fail != 0) break;
@@ -300,7 +333,7 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * (4 * r + g) + cb];
+                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];
                 RW_ACC(4);                                        // stores of the inverse
             } else {
                 // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of S' are the B operands)
@@ -309,15 +342,15 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
                     const int i = irow + ib;
 #pragma unroll
                     for (int cbp = 0; cbp < 2; ++cbp) {
-                        f64x4 y = {0.0, 0.0, 0.0, 0.0};
+                        acc_t y = {0, 0, 0, 0};
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                            for (int r = 0; r < (cbp == 0 ? 2 : 4); ++r)
-                                y = __builtin_amdgcn_mfma_f64_16x16x4f64(ainv[cbp][cb][r], acc[cb][ib][r], y, 0, 0, 0);
+                            for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
+                                y = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], y);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int c = 16 * cbp + 4 * r + g;
+                            const int c = 16 * cbp + P::midx(r, g);
                             lop[lop_base<V>(col0 + c, Np) + i] = y[r];
                             if (Ld && i < N && col0 + c < N) Ld[(size_t)i * N + col0 + c] = y[r];
                         }
@@ -332,22 +365,46 @@ refit_wave64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
     if (lane == 0) info[b] = fail;
 #ifdef BCBF_RW64_PROF
     if (Ld && lane == 0 && N > 8)
-        for (int k = 0; k < 6; ++k) Ld[1 + k] = (double)prof[k];
+        for (int k = 0; k < 6; ++k) Ld[1 + k] = (T)prof[k];
 #endif
 }
 
-// Called by bcbf_refit_mfma_f64 for batches: returns 0 after launching, or -1 when the shape is not taken here.
+// Called by bcbf_refit_mfma_f64 / _f32 for batches.
+template <typename T>
+static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,
+                             const T* Kdense, T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C,
+                             hipStream_t st) {
+    const dim3 grid((Bt + RW_WPB - 1) / RW_WPB), block(64 * RW_WPB);
+    int dev_ = 0, cus = 256;
+    (void)hipGetDevice(&dev_);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
+    const bool two = sizeof(T) == 4 && Bt >= 8 * cus;          // more than one instance per SIMD
+#define BCBF_RW_LAUNCH(OCC_)                                                                                              \
+    do {                                                                                                                  \
+        if (Kdense)                                                                                                       \
+            hipLaunchKernelGGL((refit_wave_kernel<T, true, OCC_>), grid, block, 0, st, nullptr, nullptr, nullptr, nullptr,  \
+                               nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, Bt, N, Np, 0, 0);                    \
+        else                                                                                                              \
+            hipLaunchKernelGGL((refit_wave_kernel<T, false, OCC_>), grid, block, 0, st, X, UH, Bm, ell, s2, jitter,        \
+                               nullptr, Lop, UHB, Ldense, info, Bt, N, Np, n, C);                                         \
+    } while (0)
+    if constexpr (sizeof(T) == 4) {
+        if (two) BCBF_RW_LAUNCH(2); else BCBF_RW_LAUNCH(1);
+    } else {
+        BCBF_RW_LAUNCH(BCBF_RW64_OCC);
+    }
+#undef BCBF_RW_LAUNCH
+    return 0;
+}
 int launch_refit_wave64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                         const double* jitter, const double* Kdense, double* Lop, double* UHB, double* Ldense, int* info,
                         int Bt, int N, int Np, int n, int C, hipStream_t st) {
-    const dim3 grid((Bt + RW_WPB - 1) / RW_WPB), block(64 * RW_WPB);
-    if (Kdense)
-        hipLaunchKernelGGL((refit_wave64_kernel<true>), grid, block, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, Kdense, Lop, nullptr, Ldense, info, Bt, N, Np, 0, 0);
-    else
-        hipLaunchKernelGGL((refit_wave64_kernel<false>), grid, block, 0, st, X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB,
-                           Ldense, info, Bt, N, Np, n, C);
-    return 0;
+    return launch_refit_wave<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, st);
+}
+int launch_refit_wave32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                        const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info,
+                        int Bt, int N, int Np, int n, int C, hipStream_t st) {
+    return launch_refit_wave<float>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, st);
 }
 
 }  // namespace bcbf
