@@ -32,6 +32,7 @@ done
 python tools/bench_configs.py 2>/dev/null > $O/configs.jsonl
 python tools/time_shared.py 2>/dev/null > $O/shared_queries.txt
 python tools/bench_refit_forms.py 2>/dev/null > $O/refit_forms.jsonl
+python tools/bench_refit_forms.py f32 2>/dev/null > $O/refit_forms_f32.jsonl
 python tools/bench_online.py 2>/dev/null > $O/online_growth_f64.json
 python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
 python tools/bench_speed_test.py 2>/dev/null > $O/speed_test.jsonl
