@@ -788,15 +788,18 @@ def test_fp64_shared_queries_two_per_workgroup(ops, m):
         rel_close(host(Bk[i]), Bk_o[0], 1e-8, scale=h["s2"][0] * np.abs(h["Bm"][0]).max(), what="Bk vs oracle")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("N,n,m", [(1, 2, 1), (31, 3, 2), (33, 3, 2), (100, 2, 1), (256, 2, 1), (512, 3, 2), (700, 3, 3)])
-def test_refit_one_wave_per_instance_fp64_vs_oracle_and_workgroup_form(ops, N, n, m, monkeypatch):
-    """The batch form of the fp64 refit (refit_wave64.hip: one wave per instance, 4-column-blocked diagonal tiles) against
-    the oracle's factor and against the workgroup-per-instance form (refit_mfma64.hip) on the same inputs: dense L,
+def test_refit_one_wave_per_instance_vs_oracle_and_workgroup_form(ops, N, n, m, dtype, monkeypatch):
+    """The batch form of the refit (refit_wave64.hip: one wave per instance, 4-column-blocked diagonal tiles; fp64 and fp32;
+    a batch of 70 runs one wave per SIMD, the two-waves-per-SIMD fp32 allocation is covered by the C3 test) against
+    the oracle's factor and against the workgroup-per-instance form (refit_mfma64.hip / refit_mfma.hip) on the same inputs: dense L,
     packed operator (incl. the inverted diagonal blocks), UH*B, per-instance failure index.  BCBF_REFIT_WAVE forces the
     form (the library picks by batch size)."""
     from bayesian_cbf_amd.synthetic import make_instances
     Bt = 70                                    # odd number of workgroups' worth of waves + a ragged tail
-    dtype = torch.float64
+    f64 = dtype == torch.float64
+    tL, tW, tP = (1e-8, 1e-9, 1e-8) if f64 else (1e-3, 1e-3, 2e-3)     # (fp32: two factorizations of K_b with cond ~1e5)
     p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=100 + N)
     p["X"] = (p["X"] * 2.0).contiguous()
     jit = p["jitter"].clone()
@@ -804,7 +807,7 @@ def test_refit_one_wave_per_instance_fp64_vs_oracle_and_workgroup_form(ops, N, n
     if N >= 31:                                # instance 5: a duplicated point with a negative shift -> pivot 21 fails
         X[5, 20], UH[5, 20] = X[5, 3], UH[5, 3]
         jit[5] = 0.0
-        jit[5, 20] = -1e-3
+        jit[5, 20] = -1e-3 if f64 else -1e-2
     args = (X, UH, p["Bm"], p["ell"], p["s2"], jit)
     monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
     Lop_w, UHB_w, info_w, Ld_w = ops.refit(*args, want_dense=True)
@@ -817,20 +820,20 @@ def test_refit_one_wave_per_instance_fp64_vs_oracle_and_workgroup_form(ops, N, n
     assert np.array_equal(iw, info_g.cpu().numpy()) and np.array_equal(iw, info_p.cpu().numpy())
     good = iw == 0
     assert good.sum() == (Bt - 1 if N >= 31 else Bt) and (N < 31 or iw[5] == 21)
-    rel_close(host(UHB_w), host(UHB_g), 1e-14, what="UHB")
+    rel_close(host(UHB_w), host(UHB_g), 1e-14 if f64 else 1e-6, what="UHB")
     h = {k: host(v) for k, v in dict(X=X, U=p["U"], Xdot=p["Xdot"], Bm=p["Bm"], ell=p["ell"], s2=p["s2"], M0=p["M0"], jit=jit).items()}
     for i in (0, 1, 37, Bt - 1):
         st = ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
                              h["jit"][i][None] / 1e-5)
-        rel_close(host(Ld_w[i]), st["L"], 1e-8, what="L vs oracle [%d]" % i)
-        rel_close(host(Ld_p[i]), st["L"], 1e-8, what="L(potrf) vs oracle [%d]" % i)
+        rel_close(host(Ld_w[i]), st["L"], tL, what="L vs oracle [%d]" % i)
+        rel_close(host(Ld_p[i]), st["L"], tL, what="L(potrf) vs oracle [%d]" % i)
     g = torch.as_tensor(good, device=DEV)
-    rel_close(host(Ld_w[g]), host(Ld_g[g]), 1e-9, what="L vs workgroup form")
+    rel_close(host(Ld_w[g]), host(Ld_g[g]), tW, what="L vs workgroup form")
     # packed operator: off-diagonal panels and inverted diagonal blocks (inverses of ill-conditioned blocks: relative to
     # the largest entry of the operator, per instance)
     for i in np.nonzero(good)[0][:8]:
-        rel_close(host(Lop_w[i]), host(Lop_g[i]), 1e-8, what="Lop vs workgroup form [%d]" % i)
-        rel_close(host(Lop_p[i]), host(Lop_g[i]), 1e-8, what="Lop(potrf) vs workgroup form [%d]" % i)
+        rel_close(host(Lop_w[i]), host(Lop_g[i]), tP, what="Lop vs workgroup form [%d]" % i)
+        rel_close(host(Lop_p[i]), host(Lop_g[i]), tP, what="Lop(potrf) vs workgroup form [%d]" % i)
     # and the posterior through the new operator
     Vw, _ = ops.potrs(Lop_w, p["Xdot"], UH, p["M0"], want_alpha=False)
     Mk, Bk = ops.posterior_step(Lop_w, Vw, X, UHB_w, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
@@ -839,8 +842,8 @@ def test_refit_one_wave_per_instance_fp64_vs_oracle_and_workgroup_form(ops, N, n
                              h["jit"][i][None] / 1e-5)
         Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None], h["ell"][i][None],
                                         h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], host(p["xq"])[i][None])
-        rel_close(host(Mk)[i], Mk_o[0], 1e-8, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
-        rel_close(host(Bk)[i], Bk_o[0], 1e-8, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
+        rel_close(host(Mk)[i], Mk_o[0], 1e-8 if f64 else 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+        rel_close(host(Bk)[i], Bk_o[0], 1e-8 if f64 else 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
