@@ -641,15 +641,18 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
     """Vector-variate ("CoGP") comparator: vec(F) ~ GP(vec(M), Sigma k(x,x')), an (N n) x (N n) system
     (:1128-1330).  On the device it is the matrix-variate structure with expanded inputs -- sample (i,a) carries x_i
     and the row UH'[(i,a), (p,a')] = uh_i[p] delta_aa' -- so the same factorisation / solve / query kernels run it
-    (K_b build and query with the `rbflin` data kernel).  Compiled for (1+m) n <= 4 outputs (the pendulum of the
-    published speed test)."""
+    (K_b build and query with the `rbflin` data kernel).  Up to (1+m) n = BCBF_MAX_TASK_DIM = 12 task outputs (the
+    pendulum's 4 of the published speed test, the unicycle's 9 of unicycle_speed_test_matrix_vector_exp): the K_b build
+    and the likelihood-gradient sums take that many columns; the query kernels hold 4 right-hand-side columns per
+    query, so more task outputs are queried 4 columns at a time (the posterior is linear in the columns of Phi; the
+    covariance needs W = L^-1 Phi of all of them, not the kernels' per-call Gram)."""
 
     def __init__(self, x_dim, u_dim, device=None, default_device=default_device, gamma_length_scale_prior=None,
                  model_class=None, rank=None, dtype=None, generator=None):
         super().__init__(x_dim, u_dim, device=device, default_device=default_device,
                          gamma_length_scale_prior=gamma_length_scale_prior, rank=rank, dtype=dtype, generator=generator)
-        if (1 + u_dim) * x_dim > 4:
-            raise NotImplementedError("the CoGP comparator is compiled for (1+m) n <= 4 task outputs (pendulum)")
+        if (1 + u_dim) * x_dim > 12:
+            raise NotImplementedError("the CoGP comparator takes (1+m) n <= 12 task outputs (BCBF_MAX_TASK_DIM)")
         self.model = VectorKernelParams(x_dim, u_dim, rank=rank, dtype=dtype).to(self.device)
 
     def get_kernel_param(self, name):
@@ -733,8 +736,8 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
                 raise RuntimeError("cholesky: pivot %d is not positive after %d jitter retries" % (int(info[0]), cholesky_tries))
             factor = factor * cholesky_perturb_scale
         Ce = UHe.shape[1]
-        zeroM = Xe.new_zeros(1, Ce, 1)
-        Vw1, alpha = ops.potrs(Lop, Ye, UHe[None], zeroM)
+        # (the targets are already mean-free: the solve's own `Y - UH M0` step gets a zero two-column factor, whatever Ce)
+        Vw1, alpha = ops.potrs(Lop, Ye, Xe.new_zeros(1, Ne, 2), Xe.new_zeros(1, 2, 1))
         Vw = Xe.new_zeros(1, Ne, n)                      # the query kernel reads n target columns; only the first is used
         Vw[..., 0] = Vw1[..., 0]
         st = dict(hp, X=Xe[None], UH=UHe[None], UHB=(UHe @ hp["Bm"][0])[None].contiguous(), Lop=Lop, Vw=Vw, alpha=alpha,
@@ -761,8 +764,7 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         if self.Xtrain is None:
             return fX_mean_test, Sigma * self._data_knl(Xtest, Xtestp)[:, :, None, None]
         st = self._state()
-        Mk, Bk, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"], st["M0e"],
-                                        Xtest.contiguous(), shared=True, want_W=compute_cov, lin=st["lin"])
+        Mk, W = self._query_columns(st, Xtest.contiguous(), compute_cov)
         mean_k = fX_mean_test + Mk[:, 0, :].reshape(b, C, n).transpose(-2, -1)
         if not compute_cov:
             return mean_k, Xtest.new_zeros(b, Xtestp.shape[0], Ce, Ce)
@@ -770,6 +772,30 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         KkXX = torch_kron(self._data_knl(Xtest, Xtestp), Sigma) - vb.t() @ vb             # (:1313-1317; v of Xtest on both sides)
         KkXX = KkXX + torch.diag(1e-5 * self.rand_fn(b * Ce))                             # make_psd (:1318)
         return mean_k, KkXX.reshape(b, Ce, b, Ce).transpose(2, 1)
+
+    @staticmethod
+    def _query_columns(st, xq, want_W):
+        """Mk[b, n, Ce] and W[b, Np, Ce] = L^-1 Phi(x_b) of the expanded system, the Ce task columns taken through the
+        query kernel at most 4 at a time (a lone last column rides with a zero one)."""
+        Ce = st["UHB"].shape[2]
+        if Ce <= 4:
+            Mk, _, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"], st["M0e"],
+                                           xq, shared=True, want_W=want_W, lin=st["lin"])
+            return Mk, W
+        Mks, Ws = [], []
+        for c0 in range(0, Ce, 4):
+            c1 = min(c0 + 4, Ce)
+            U = st["UHB"][:, :, c0:c1]
+            if c1 - c0 == 1:
+                U = torch.cat([U, torch.zeros_like(U)], dim=2)
+            Cc = U.shape[2]
+            eye = torch.eye(Cc, dtype=U.dtype, device=U.device)[None].contiguous()       # (the per-call B_k is not used)
+            Mk, _, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], U.contiguous(), st["ell"], st["s2"], eye,
+                                           st["M0e"][:, :Cc].contiguous(), xq, shared=True, want_W=want_W, lin=st["lin"])
+            Mks.append(Mk[:, :, :c1 - c0])
+            if want_W:
+                Ws.append(W[:, :, :c1 - c0])
+        return torch.cat(Mks, dim=2), (torch.cat(Ws, dim=2) if want_W else None)
 
     def custom_predict(self, Xtest_in, Utest_in=None, UHfill=1, Xtestp_in=None, Utestp_in=None, UHfillp=1,
                        compute_cov=True):
@@ -824,7 +850,7 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
             if ntry == 9 or jitter is not None:
                 raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
             factor *= 10
-        _, alpha = ops.potrs(Lop, Ye, UHe[None], Xe.new_zeros(1, Ce, 1))
+        _, alpha = ops.potrs(Lop, Ye, Xe.new_zeros(1, Ne, 2), Xe.new_zeros(1, 2, 1))
         Kinv = ops.kb_inverse(Lop, Ne)
         one = Xe.new_ones(1, 1, 1)
         g_ell, g_s2, g_B, logdetK, RtA, UHtA, g_lin = ops.mll_grad(Lop, alpha, Kinv, Xe[None], UHe[None], Ye, one, hp["Bm"],

@@ -12,9 +12,10 @@
 namespace bcbf {
 
 constexpr int MG_T = 256;
-constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 2 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
+// CM = compile-time bound on the columns of UH: BCBF_MAX_CTRL_DIM + 1 for the matrix-variate model, BCBF_MAX_TASK_DIM
+// for the expanded CoGP system with more than four task outputs (a comparator: one workgroup, registers to spare)
 
-template <typename T>
+template <typename T, int CM>
 __global__ void __launch_bounds__(MG_T)
 mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T* __restrict__ Kinv,
                 const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ R, const T* __restrict__ Ainv,
@@ -25,6 +26,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     // nt = number of target columns of R / alpha / A (== n for the matrix-variate model; 1 for the expanded
     // CoGP system); lin (optional) = weight of the linear part of the data kernel, k = exp(..) + lin x'x'.
     constexpr int V = Vec<T>::V;
+    constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 2 + CM * CM;
     __shared__ double red[4][MG_MAXOUT];
     const int b = blockIdx.x, tid = threadIdx.x;
     const T* Xb = X + (size_t)b * N * n;
@@ -34,22 +36,22 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     const T* Kib = Kinv + (size_t)b * N * N;
     const T* lop = Lop + (size_t)b * lop_elems<V>(Np);
     double iell[BCBF_MAX_STATE_DIM], Ai[BCBF_MAX_STATE_DIM][BCBF_MAX_STATE_DIM];
-    double Bl[BCBF_MAX_CTRL_DIM + 1][BCBF_MAX_CTRL_DIM + 1];
+    double Bl[CM][CM];
     const double s2 = (double)s2p[b];
     const double linv = lin != nullptr ? (double)lin[b] : 0.0;
     for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) {
         iell[d] = d < n ? 1.0 / (double)ell[(size_t)b * n + d] : 0.0;
         for (int e = 0; e < BCBF_MAX_STATE_DIM; ++e) Ai[d][e] = (d < nt && e < nt) ? (double)Ainv[((size_t)b * nt + d) * nt + e] : 0.0;
     }
-    for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a)
-        for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) Bl[a][c] = (a < C && c < C) ? (double)Bm[((size_t)b * C + a) * C + c] : 0.0;
+    for (int a = 0; a < CM; ++a)
+        for (int c = 0; c < CM; ++c) Bl[a][c] = (a < C && c < C) ? (double)Bm[((size_t)b * C + a) * C + c] : 0.0;
 
     // ---- phase 1: the N^2 pair terms (register accumulators, fully unrolled over the compile-time maxima)
-    double gl[BCBF_MAX_STATE_DIM], gB[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)], gs = 0.0, glin = 0.0;
+    double gl[BCBF_MAX_STATE_DIM], gB[CM * CM], gs = 0.0, glin = 0.0;
 #pragma unroll
     for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] = 0.0;
 #pragma unroll
-    for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) gB[a] = 0.0;
+    for (int a = 0; a < CM * CM; ++a) gB[a] = 0.0;
     for (long long idx = tid; idx < (long long)N * N; idx += MG_T) {
         const int i = (int)(idx / N), j = (int)(idx - (long long)i * N);
         double d2 = 0.0, dz2[BCBF_MAX_STATE_DIM], dot = 0.0;
@@ -63,17 +65,17 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
         }
         const double krbf = exp(-0.5 * d2);
         const double kij = krbf + linv * dot;
-        double ui[BCBF_MAX_CTRL_DIM + 1], uj[BCBF_MAX_CTRL_DIM + 1], uij = 0.0;
+        double ui[CM], uj[CM], uij = 0.0;
 #pragma unroll
-        for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a) {
+        for (int a = 0; a < CM; ++a) {
             ui[a] = a < C ? (double)UHb[(size_t)i * C + a] : 0.0;
             uj[a] = a < C ? (double)UHb[(size_t)j * C + a] : 0.0;
         }
 #pragma unroll
-        for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a) {
+        for (int a = 0; a < CM; ++a) {
             double t = 0.0;
 #pragma unroll
-            for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) t += Bl[a][c] * uj[c];
+            for (int c = 0; c < CM; ++c) t += Bl[a][c] * uj[c];
             uij += ui[a] * t;
         }
         double q = 0.0;                                      // alpha_i' A^-1 alpha_j
@@ -95,23 +97,20 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
 #pragma unroll
         for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] += GK * dz2[d] * iell[d];       // z^2 / ell = dx^2 / ell^3
 #pragma unroll
-        for (int a = 0; a <= BCBF_MAX_CTRL_DIM; ++a)
+        for (int a = 0; a < CM; ++a)
 #pragma unroll
-            for (int c = 0; c <= BCBF_MAX_CTRL_DIM; ++c) gB[a * (BCBF_MAX_CTRL_DIM + 1) + c] += Gk * s2 * ui[a] * uj[c];
+            for (int c = 0; c < CM; ++c) gB[a * CM + c] += Gk * s2 * ui[a] * uj[c];
     }
-    // workgroup reduction of the 8 + 1 + 16 sums
-    constexpr int NR = BCBF_MAX_STATE_DIM + 2 + (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1);
-    double vals[NR];
-    vals[NR - 1] = wave_sum(glin);
+    // workgroup reduction of the 8 + 1 + CM^2 + 1 sums (each wave's total goes straight to LDS)
+    constexpr int NR = MG_MAXOUT;
+    const bool lead = (tid & 63) == 0;
+    auto put = [&](int o, double v) { v = wave_sum(v); if (lead) red[tid >> 6][o] = v; };
+    put(NR - 1, glin);
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) vals[d] = wave_sum(gl[d]);
-    vals[BCBF_MAX_STATE_DIM] = wave_sum(gs);
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) put(d, gl[d]);
+    put(BCBF_MAX_STATE_DIM, gs);
 #pragma unroll
-    for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) vals[BCBF_MAX_STATE_DIM + 1 + a] = wave_sum(gB[a]);
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int o = 0; o < NR; ++o) red[tid >> 6][o] = vals[o];
-    }
+    for (int a = 0; a < CM * CM; ++a) put(BCBF_MAX_STATE_DIM + 1 + a, gB[a]);
     __syncthreads();
     if (tid < NR) {
         const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
@@ -119,7 +118,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
         else if (tid == BCBF_MAX_STATE_DIM) g_s2[b] = (T)v;
         else if (tid == NR - 1) { if (g_lin != nullptr) g_lin[b] = (T)v; }
         else {
-            const int o = tid - BCBF_MAX_STATE_DIM - 1, a = o / (BCBF_MAX_CTRL_DIM + 1), c = o % (BCBF_MAX_CTRL_DIM + 1);
+            const int o = tid - BCBF_MAX_STATE_DIM - 1, a = o / CM, c = o % CM;
             if (a < C && c < C) g_B[((size_t)b * C + a) * C + c] = (T)v;
         }
     }
@@ -152,11 +151,17 @@ static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T*
     if (!Lop || !alpha || !Kinv || !X || !UH || !R || !Ainv || !Bm || !ell || !s2 || !g_ell || !g_s2 || !g_B || !logdetK ||
         !RtA || !UHtA)
         return BCBF_EINVAL;
-    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM || nt < 1 || nt > BCBF_MAX_STATE_DIM)
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m + 1 > BCBF_MAX_TASK_DIM || nt < 1 || nt > BCBF_MAX_STATE_DIM)
         return BCBF_EINVAL;
-    hipLaunchKernelGGL((mll_grad_kernel<T>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv, X, UH, R,
-                       Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin,
-                       g_lin);
+    if ((m + 1) * nt > 128) return BCBF_EINVAL;                    // phase 2: one thread per entry of UH' alpha
+    if (m <= BCBF_MAX_CTRL_DIM)
+        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_CTRL_DIM + 1>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
+                           X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt,
+                           lin, g_lin);
+    else
+        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_TASK_DIM>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
+                           X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt,
+                           lin, g_lin);
     return check_launch("mll_grad");
 }
 

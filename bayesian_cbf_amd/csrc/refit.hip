@@ -22,10 +22,11 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
     const T* Xb = X + (size_t)b * N * n;
     const T* UHb = UH + (size_t)b * N * C;
     const T* Bmb = Bm + (size_t)b * C * C;
-    T ub[BCBF_MAX_CTRL_DIM + 1];
-    for (int c = 0; c < C; ++c) {
+    T ub[BCBF_MAX_TASK_DIM];                           // (1+m) columns, or the (1+m) n of the expanded CoGP system
+#pragma unroll
+    for (int c = 0; c < BCBF_MAX_TASK_DIM; ++c) {
         T s = T(0);
-        for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmb[a * C + c];
+        if (c < C) for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmb[a * C + c];
         ub[c] = s;
     }
     const T s2 = s2p[b];
@@ -37,7 +38,9 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
             d2 += z * z;
             dot += Xb[(size_t)i * n + d] * Xb[(size_t)j * n + d];
         }
-        for (int a = 0; a < C; ++a) uu += ub[a] * UHb[(size_t)j * C + a];
+#pragma unroll
+        for (int a = 0; a < BCBF_MAX_TASK_DIM; ++a)
+            if (a < C) uu += ub[a] * UHb[(size_t)j * C + a];
         T val = s2 * (texp2<T>(T(-0.5) * d2) + linv * dot) * uu;
         if (i == j && jitter) val += jitter[(size_t)b * N + i];
         Kb[((size_t)b * N + i) * N + j] = val;
@@ -49,7 +52,7 @@ static int launch_kb_build(const T* X, const T* UH, const T* Bm, const T* ell, c
                            T* Kb, int Bt, int N, int n, int m, void* stream, const T* lin = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!X || !UH || !Bm || !ell || !s2 || !Kb) return BCBF_EINVAL;
-    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m + 1 > BCBF_MAX_TASK_DIM) return BCBF_EINVAL;
     hipLaunchKernelGGL((kb_build_kernel<T>), dim3(N, Bt), dim3(256), 0, (hipStream_t)stream, X, UH, Bm, ell, s2,
                        jitter, Kb, N, n, m + 1, lin);
     return check_launch("kb_build");

@@ -520,6 +520,107 @@ unicycle_no_learning_gets_stuck_exp = _obstacle_recipe(
     train_every_n_steps=2000)
 
 
+class NoPlanner:
+    """unicycle_move_to_pose.py:1522-1530: the goal itself at every step."""
+
+    def __init__(self, x_goal):
+        self.x_goal = x_goal
+
+    def plan(self, t):
+        return self.x_goal
+
+    def dot_plan(self, t):
+        return torch.zeros_like(self.x_goal)
+
+
+def unicycle_speed_test_matrix_vector_exp(max_train_variations=(64, 64 + 16, 64 + 32, 128), ntimes=10, repeat=50,
+                                          errorbartries=20, state_start=(-3.0, -1.0, -math.pi / 4),
+                                          state_goal=(0.0, 0.0, math.pi / 4), numSteps=512, dt=0.01,
+                                          true_dynamics_gen=None, mean_dynamics_gen=None, logger=None, exps=None,
+                                          training_iter=50, device="cuda", dtype=torch.float64):
+    """unicycle_move_to_pose.py:2031-2152: inference time and learning error of the four regressors (matrix-variate
+    full / diag, vector-variate full / diag; the vector ones carry (1+m) n = 9 task outputs) wrapped in
+    LearnedShiftInvariantDynamics, on one closed-loop trajectory of the true unicycle under the mean CLF controller;
+    `custom_predict_fullmat(Xtest); clear_cache()` on 20 headings spanning the training set, min over `repeat` of
+    `ntimes` calls (device synchronised after every call: the reference's timing is host side).
+    Returns {name: {max_train: dict(elapsed, errors)}}; logged under the reference's tags when a logger is given."""
+    import timeit
+    from functools import partial
+    from .control_affine_model import (ControlAffineRegressorExact, ControlAffineRegMatrixDiag,
+                                       ControlAffineRegressorVector, ControlAffineRegVectorDiag)
+    from .pendulum import measure_batch_error
+    from .sampling import sample_generator_trajectory
+    f = dict(device=device, dtype=dtype)
+    true_dynamics_gen = true_dynamics_gen or partial(AckermannDrive, L=1.0)
+    mean_dynamics_gen = mean_dynamics_gen or partial(AckermannDrive, L=12.0)
+    exps = exps or dict(matrix=ControlAffineRegressorExact, vector=ControlAffineRegressorVector,
+                        vectordiag=ControlAffineRegVectorDiag, matrixdiag=ControlAffineRegMatrixDiag)
+    true_model = true_dynamics_gen()
+    goal = torch.tensor(state_goal, **f)
+
+    def trajectory():
+        ctrl = ControllerCLF(NoPlanner(goal), coordinate_converter=lambda x, x_g: x, dynamics=CartesianDynamics(),
+                             clf=CLFCartesian(), device=device, dtype=dtype)
+        _, X, U = sample_generator_trajectory(true_model, numSteps, dt=dt, x0=torch.tensor([state_start], **f),
+                                              controller=ctrl.control)
+        X, U = X[:, 0], U[:, 0]
+        Xdot = true_model.f_func(X[:-1]) + (true_model.g_func(X[:-1]) @ U.unsqueeze(-1)).squeeze(-1)
+        return Xdot, X, U
+
+    def true_F(Xt):                                               # [b, 1+m, n]
+        return torch.cat([true_model.f_func(Xt).unsqueeze(-1), true_model.g_func(Xt)], dim=-1).transpose(-2, -1)
+
+    def heading_grid(Xtrain):                                     # (:2099-2110) mgrid with 1 x 1 x 20 cells
+        lo, hi = Xtrain.min(dim=0).values, Xtrain.max(dim=0).values
+        th = lo[2] + (hi[2] - lo[2]) / 20 * torch.arange(20, **f)
+        return torch.stack([lo[0].expand(20), lo[1].expand(20), th], dim=-1).contiguous()
+
+    def make(cls, max_train):
+        return LearnedShiftInvariantDynamics(dt=dt, learned_dynamics_class=cls, mean_dynamics=mean_dynamics_gen(),
+                                             max_train=max_train, device=device, dtype=dtype)
+
+    Xdot, X, U = trajectory()
+    if logger is not None:
+        for t, (dx, x, u) in enumerate(zip(Xdot, X, U)):
+            logger.add_tensors("traj", dict(dx=dx, x=x, u=u), t)
+    order = np.arange(X.shape[0] - 1)
+    out = {name: {} for name in exps}
+    for max_train in max_train_variations:
+        np.random.shuffle(order)
+        idx = torch.from_numpy(order[:max_train].copy()).to(device)
+        Xtrain, Utrain, XdotTrain = X[idx], U[idx], Xdot[idx]
+        Xtest = heading_grid(Xtrain)
+        for name, cls in exps.items():
+            model = make(cls, max_train)
+            model.fit(Xtrain, Utrain, XdotTrain, training_iter=training_iter)
+
+            def call():
+                model.custom_predict_fullmat(Xtest)
+                model.clear_cache()
+                torch.cuda.synchronize()
+            call()
+            elapsed = min(timeit.repeat(call, repeat=repeat, number=ntimes)) / ntimes
+            errors = []
+            for _ in range(errorbartries):
+                # compute_errors (:2156-2221).  As upstream, the regressor of an error sample is constructed and queried
+                # WITHOUT being fitted (no fit call there): the figure is the variance-weighted error of the prior model
+                # (mean dynamics, prior covariance) on 400 states of a fresh trajectory
+                dX2, X2, U2 = trajectory()
+                np.random.shuffle(order)
+                tdx = torch.from_numpy(order[-400:].copy()).to(device)
+                mdl = make(cls, max_train)
+                Xt = X2[tdx]
+                mean, var = mdl.custom_predict_fullmat(Xt)
+                b, D = Xt.shape[0], mean.numel() // Xt.shape[0]
+                blocks = var.reshape(b, D, b, D)[torch.arange(b), :, torch.arange(b), :]
+                errors.append(float(measure_batch_error(mean.reshape(b, D), blocks, true_F(Xt).reshape(b, D).to(mean))))
+            out[name][max_train] = dict(elapsed=elapsed, errors=errors)
+            if logger is not None:
+                logger.add_scalars(name, dict(elapsed=elapsed), max_train)
+                logger.add_tensors(name, dict(errors=np.asarray(errors)), max_train)
+    return out
+
+
 def _with_playback(exp):
     def run(**kw):
         from . import tblog

@@ -46,6 +46,10 @@ extern "C" {
 /* limits of the compiled kernels */
 #define BCBF_MAX_STATE_DIM 8
 #define BCBF_MAX_CTRL_DIM 3
+/* Columns of the control / task factor accepted by the entry points the vector-variate (CoGP) comparator runs on with
+ * expanded inputs -- bcbf_kb_build[_rbflin], bcbf_mll_grad_rbflin: (1+m) n task outputs, 9 for the unicycle
+ * (control_affine_model.py:1106-1357).  The per-step kernels keep BCBF_MAX_CTRL_DIM. */
+#define BCBF_MAX_TASK_DIM 12
 #define BCBF_MAX_CONSTRAINTS 8        /* constraint rows per instance: bcbf_cbc_terms, bcbf_unicycle_constraints,
                                          bcbf_controller_cones, bcbf_coneqp (second-order cones) */
 #define BCBF_MAX_QUAD_CONSTRAINTS 4   /* the four-lanes-per-instance solver kernels (bcbf_socp, bcbf_cbc_socp,
@@ -79,7 +83,8 @@ size_t bcbf_lop_elems_f64(int N);
 
 /* K1: K_b[i][j] = s2*exp(-1/2 |(x_i-x_j)/ell|^2) * uh_i' Bm uh_j  (+ jitter[i] on the diagonal).
  * Replaces control_affine_model.py:370-372 (+ the diagonal perturbation of make_psd :907-910).
- * X[Bt,N,n] UH[Bt,N,C] Bm[Bt,C,C] ell[Bt,n] s2[Bt] jitter[Bt,N] (may be NULL) -> Kb[Bt,N,N] (full, symmetric). */
+ * X[Bt,N,n] UH[Bt,N,C] Bm[Bt,C,C] ell[Bt,n] s2[Bt] jitter[Bt,N] (may be NULL) -> Kb[Bt,N,N] (full, symmetric).
+ * C = m + 1 up to BCBF_MAX_TASK_DIM here (the expanded CoGP system), also in the _rbflin form. */
 int bcbf_kb_build_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                       const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream);
 int bcbf_kb_build_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
@@ -305,7 +310,7 @@ int bcbf_posterior_query_rbflin_f64(const double* Lop, const double* Vw, const d
                                     const double* M0, const double* xq, const double* jitter2, double* Mk,
                                     double* Bk, double* W, int shared, int Bt, int N, int n, int m, void* stream);
 /* bcbf_mll_grad with nt target columns (R, alpha [Bt,N,nt]; Ainv, RtA [Bt,nt,nt]; UHtA [Bt,C,nt]) and the extra
- * output g_lin[Bt] = d log p / d lin. */
+ * output g_lin[Bt] = d log p / d lin.  C = m + 1 up to BCBF_MAX_TASK_DIM (C nt <= 128). */
 int bcbf_mll_grad_rbflin_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
                              const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2,
                              const float* lin, float* g_ell, float* g_s2, float* g_lin, float* g_B, float* logdetK,

@@ -379,10 +379,10 @@ def main_controllers():
 
 
 
-def gen_cogp(tag, N, b, seed, diag):
-    """ControlAffineRegressorVector / ControlAffineRegVectorDiag on the pendulum shapes (n=2, m=1):
-    _custom_predict_matrix, custom_predict, custom_predict_fullmat (control_affine_model.py:1128-1330)."""
-    n, m = 2, 1
+def gen_cogp(tag, N, b, seed, diag, n=2, m=1):
+    """ControlAffineRegressorVector / ControlAffineRegVectorDiag on the pendulum shapes (n=2, m=1) and the unicycle's
+    (n=3, m=2: nine task outputs): _custom_predict_matrix, custom_predict, custom_predict_fullmat
+    (control_affine_model.py:1128-1330)."""
     cls = cam.ControlAffineRegVectorDiag if diag else cam.ControlAffineRegressorVector
     torch.manual_seed(seed)
     reg = cls(n, m, device='cpu')
@@ -396,7 +396,10 @@ def gen_cogp(tag, N, b, seed, diag):
             bm.constant.copy_(0.2 * torch.randn(1))
     X = 1.5 * (2 * torch.rand(N, n) - 1)
     U = torch.randn(N, m)
-    Xdot = torch.sin(X @ torch.randn(n, n).t()) + 0.5 * torch.cos(X) * U + 1e-3 * torch.randn(N, n)
+    if m == 1:
+        Xdot = torch.sin(X @ torch.randn(n, n).t()) + 0.5 * torch.cos(X) * U + 1e-3 * torch.randn(N, n)
+    else:
+        Xdot = torch.sin(X @ torch.randn(n, n).t()) + 0.5 * torch.cos(X) * (U @ torch.randn(m, n)) + 1e-3 * torch.randn(N, n)
     model.set_train_data(X, U, Xdot)
     Sigma = t2n(model.covar_module.task_covar_module.covar_matrix.evaluate())
     out = dict(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), Sigma=Sigma, ell=t2n(rbf.lengthscale).reshape(-1),
@@ -423,6 +426,8 @@ def main_cogp():
     gen_cogp('full_N12', N=12, b=3, seed=61, diag=False)
     gen_cogp('full_N48', N=48, b=5, seed=62, diag=False)
     gen_cogp('diag_N24', N=24, b=4, seed=63, diag=True)
+    gen_cogp('full_n3m2_N10', N=10, b=3, seed=64, diag=False, n=3, m=2)
+    gen_cogp('diag_n3m2_N20', N=20, b=4, seed=65, diag=True, n=3, m=2)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -705,7 +705,7 @@ COGP_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cogp_*.npz")))
 def make_cogp(g, draws, dtype=torch.float64):
     from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorVector, ControlAffineRegVectorDiag
     cls = ControlAffineRegVectorDiag if int(g["diag"]) else ControlAffineRegressorVector
-    reg = cls(2, 1, device=DEV, dtype=dtype)
+    reg = cls(g["X"].shape[1], g["U"].shape[1], device=DEV, dtype=dtype)      # pendulum (2, 1): 4 task outputs; unicycle (3, 2): 9
     reg.set_kernel_params(Sigma=g["Sigma"], lengthscale=float(g["ell"][0]), variance=float(g["lin"]),
                           scalefactor=float(g["s2"]), M0=g["M0"])
     f = dict(dtype=dtype, device=DEV)
@@ -739,11 +739,13 @@ def test_cogp_regressor_matches_reference(path):
     np.testing.assert_allclose(K32.cpu().double().numpy(), g["KkXX"], rtol=0, atol=2e-3 * scale)
 
 
-def test_cogp_fit_gradient_matches_finite_differences_of_the_oracle_likelihood():
+@pytest.mark.parametrize("path", [f for f in COGP_FILES if "full_N48" in f or "full_n3m2" in f], ids=os.path.basename)
+def test_cogp_fit_gradient_matches_finite_differences_of_the_oracle_likelihood(path):
     """fit() of the vector-variate comparator: device gradient of -log p / (N n) w.r.t. every raw parameter (single
-    lengthscale, linear variance, output scale, Sigma factors, mean) vs central differences of the oracle."""
+    lengthscale, linear variance, output scale, Sigma factors, mean) vs central differences of the oracle; 4 task
+    outputs (pendulum) and 9 (unicycle: the wide instantiation of the gradient sums)."""
     from oracle import gp_posterior as ogp
-    g = np.load(COGP_FILES[-1])
+    g = np.load(path)
     reg = make_cogp(g, [])
     N, n = g["X"].shape
     UH = ogp.homogeneous_controls(g["U"])
@@ -775,6 +777,38 @@ def test_cogp_fit_gradient_matches_finite_differences_of_the_oracle_likelihood()
     reg.rand_fn = lambda k: torch.rand(k, **T64)
     reg.fit(t(g["X"]), t(g["U"]), t(g["Xdot"]), training_iter=20, lr=0.1)
     assert reg.fit_losses[-1] < reg.fit_losses[0]
+
+
+def test_unicycle_speed_test_recipe_runs_all_four_regressors():
+    """unicycle_speed_test_matrix_vector_exp (unicycle_move_to_pose.py:2031-2152): the four regressors -- the
+    vector-variate ones with the unicycle's nine task outputs -- fit, answer `custom_predict_fullmat` on the heading grid
+    and report finite times / errors; the learned models reproduce the true residual dynamics on the training range."""
+    from bayesian_cbf_amd import unicycle_move_to_pose as ump
+    np.random.seed(3)
+    torch.manual_seed(3)
+    out = ump.unicycle_speed_test_matrix_vector_exp(max_train_variations=(48,), ntimes=1, repeat=1, errorbartries=1,
+                                                    numSteps=160, training_iter=15)
+    assert set(out) == {"matrix", "vector", "vectordiag", "matrixdiag"}
+    for name, rows in out.items():
+        d = rows[48]
+        assert 0 < d["elapsed"] < 1.0 and len(d["errors"]) == 1 and np.isfinite(d["errors"]).all(), name
+    # a fitted vector-variate model (9 outputs) on the same kind of data: mean of F within a few percent of the truth
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorVector
+    true, prior = ump.AckermannDrive(L=1.0), ump.AckermannDrive(L=12.0)
+    g = torch.Generator().manual_seed(5)
+    X = torch.cat([torch.zeros(96, 2), 2.0 * torch.rand(96, 1, generator=g) - 1.0], dim=1).to(**T64)
+    U = (torch.rand(96, 2, generator=g) * torch.tensor([2.0, 1.0])).to(**T64)
+    model = ump.LearnedShiftInvariantDynamics(dt=0.01, learned_dynamics_class=ControlAffineRegressorVector,
+                                              mean_dynamics=prior, max_train=96, device=DEV, dtype=torch.float64)
+    Xdot = true.f_func(X) + (true.g_func(X) @ U.unsqueeze(-1)).squeeze(-1)
+    model.fit(X, U, Xdot, training_iter=40)
+    Xt = torch.cat([torch.zeros(9, 2), torch.linspace(-0.8, 0.8, 9)[:, None]], dim=1).to(**T64)
+    mean, var = model.custom_predict_fullmat(Xt)
+    F_true = torch.cat([true.f_func(Xt).unsqueeze(-1), true.g_func(Xt)], dim=-1).transpose(-2, -1).reshape(-1)
+    F_prior = torch.cat([prior.f_func(Xt).unsqueeze(-1), prior.g_func(Xt)], dim=-1).transpose(-2, -1).reshape(-1)
+    err, err0 = float((mean - F_true).abs().max()), float((F_prior - F_true).abs().max())
+    assert err < 0.15 * err0, (err, err0)
+    assert var.shape == (81, 81) and bool(torch.isfinite(var).all())
 
 
 def test_closed_loop_logged_in_the_reference_format_and_played_back(tmp_path):
