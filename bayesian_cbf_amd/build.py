@@ -58,7 +58,11 @@ def _compile(src, force):
         return obj, False
     tuning = os.environ.get("BCBF_EXTRA_HIPCC_FLAGS", "").split()        # e.g. -DBCBF_PS_UNR=2 for tuning sweeps
     flags = [f for f in FLAGS if not (ASAN and f == "-O3")] + (ASAN_FLAGS if ASAN else [])
-    cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(src, []) + tuning + ["-c", os.path.join(CSRC, src), "-o", obj]
+    extra = list(EXTRA_FLAGS.get(src, []))
+    if ASAN and src == "posterior_shared_reg.hip":
+        extra.append("-DBCBF_PSR_DEV")        # host-side instrumentation only: one device instantiation per precision is
+                                              # enough there (the 18 of the product build take minutes to compile)
+    cmd = [_hipcc()] + flags + extra + tuning + ["-c", os.path.join(CSRC, src), "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
