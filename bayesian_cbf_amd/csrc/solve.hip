@@ -215,6 +215,8 @@ struct AppendFused {
     const T *Vw_in, *X_in, *UHB_in, *ell, *s2, *Bm, *M0, *x_new, *uh_new, *xdot_new, *jitter_new;
     T *Vw_out, *X_out, *UHB_out;
     int n, C;
+    const T* Wgiven;     // optional: W = L^-1 Phi(x_new) [Bt, NpI, C] from the streaming posterior kernel (bcbf_gp_append_stream):
+                         // l = W uh_new, the forward solve below is skipped
 };
 
 template <typename T, bool FUSED>
@@ -256,7 +258,15 @@ chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict
         for (int r = 0; r < SMAXR; ++r) {
             const int i = tid + r * ST;
             T v = T(0);
-            if (r < rpt && i < N) {
+            if (f.Wgiven != nullptr) {
+                // l_i = sum_c W[i][c] uh_new[c]:  Phi(x) uh = k(X, x) o (UH B uh) is the new kernel column, so L^-1 of it is W uh
+                if (r < rpt && i < NpI) {
+#pragma unroll
+                    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
+                        if (c < C) v += f.Wgiven[((size_t)b * NpI + i) * C + c] * f.uh_new[(size_t)b * C + c];
+                    lrow[i] = i < N ? v : T(0);
+                }
+            } else if (r < rpt && i < N) {
                 T d2 = T(0), uu = T(0);
 #pragma unroll
                 for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
@@ -277,7 +287,9 @@ chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict
             y[r] = (r < rpt && i < N) ? knew[(size_t)b * N + i] : T(0);
         }
     }
-    for (int J = 0; J < nblk; ++J) {
+    const bool solved = FUSED && f.Wgiven != nullptr;
+    if (solved) __syncthreads();
+    for (int J = 0; J < (solved ? 0 : nblk); ++J) {
         const int col0 = J * NB;
 #pragma unroll
         for (int r = 0; r < SMAXR; ++r) {
@@ -413,7 +425,7 @@ template <typename T>
 static int launch_gp_append(const T* Lin, const T* Vw_in, const T* X_in, const T* UHB_in, const T* ell, const T* s2,
                             const T* Bm, const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,
                             const T* jitter_new, T* Lout, T* Vw_out, T* X_out, T* UHB_out, int* info, int Bt, int N,
-                            int n, int m, void* stream) {
+                            int n, int m, void* stream, const T* Wgiven = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lin || !Vw_in || !X_in || !UHB_in || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !Lout ||
         !Vw_out || !X_out || !UHB_out || !info || N < 1)
@@ -424,7 +436,7 @@ static int launch_gp_append(const T* Lin, const T* Vw_in, const T* X_in, const T
     if (NpO > ST * SMAXR) return BCBF_EINVAL;
     if (Lin == Lout && NpI != NpO) return BCBF_EINVAL;
     AppendFused<T> f{Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, Vw_out, X_out, UHB_out,
-                     n, m + 1};
+                     n, m + 1, Wgiven};
     hipLaunchKernelGGL((chol_append_kernel<T, true>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, nullptr, nullptr,
                        Lout, info, N, NpI, NpO, f);
     return check_launch("gp_append");
@@ -461,6 +473,34 @@ int bcbf_gp_append_f64(const double* Lop_in, const double* Vw_in, const double* 
                        void* stream) {
     return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
                                           jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream);
+}
+// The same update with the forward solve on the streaming posterior kernel: W = L^-1 Phi(x_new) (bcbf_posterior_query,
+// one query per instance, at the HBM roofline) and l = W uh_new; the append kernel then only copies / re-packs and writes
+// the new rows.  Work buffers from the caller (the library allocates nothing): Wwork[Bt, Np, 1+m] (Np = N rounded up to
+// 32), Mk_work[Bt, n, 1+m], Bk_work[Bt, 1+m, 1+m].
+int bcbf_gp_append_stream_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                              const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                              const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                              float* Vw_out, float* X_out, float* UHB_out, int* info, float* Wwork, float* Mk_work,
+                              float* Bk_work, int Bt, int N, int n, int m, void* stream) {
+    if (!Wwork || !Mk_work || !Bk_work) return BCBF_EINVAL;
+    const int rc = bcbf_posterior_query_f32(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, nullptr, Mk_work, Bk_work,
+                                            Wwork, 0, Bt, N, n, m, stream);
+    if (rc != BCBF_OK) return rc;
+    return bcbf::launch_gp_append<float>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                         jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, Wwork);
+}
+int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                              const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                              const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                              double* Vw_out, double* X_out, double* UHB_out, int* info, double* Wwork, double* Mk_work,
+                              double* Bk_work, int Bt, int N, int n, int m, void* stream) {
+    if (!Wwork || !Mk_work || !Bk_work) return BCBF_EINVAL;
+    const int rc = bcbf_posterior_query_f64(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, nullptr, Mk_work, Bk_work,
+                                            Wwork, 0, Bt, N, n, m, stream);
+    if (rc != BCBF_OK) return rc;
+    return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                          jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, Wwork);
 }
 int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
                          int* info, int Bt, int N, void* stream) {

@@ -2,6 +2,8 @@
 stream.  PyTorch is only the allocator / stream provider here; all arithmetic is in libbcbf."""
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -107,10 +109,15 @@ def chol_append(Lop, knew, kappa, N):
     return out, info
 
 
+GP_APPEND_STREAM_MIN_N = int(os.environ.get("BCBF_APPEND_STREAM_MIN_N", "384"))
+
+
 def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new=None):
     """Online update: one observation per instance enters the GP without refactorisation.
     Returns (Lop', Vw'[Bt,N+1,n], X'[Bt,N+1,n], UHB'[Bt,N+1,C], info).  The operator is updated in place
-    (the returned Lop' IS Lop) while N+1 stays inside the same 32-row padding, re-packed otherwise."""
+    (the returned Lop' IS Lop) while N+1 stays inside the same 32-row padding, re-packed otherwise.
+    From N = GP_APPEND_STREAM_MIN_N on the forward solve l = L^-1 k runs on the streaming posterior kernel
+    (bcbf_gp_append_stream: W = L^-1 Phi(x_new) at the HBM roofline, l = W uh_new)."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new)
     Bt, N, n = X.shape
     C = UHB.shape[2]
@@ -119,6 +126,14 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
     Lout = Lop if same_pad else torch.empty(Bt, lop_elems(N + 1, X.dtype), **f)
     Vw2, X2, UHB2 = torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, C, **f)
     info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+    if N >= GP_APPEND_STREAM_MIN_N:
+        Np = (N + 31) // 32 * 32
+        Ww, Mkw, Bkw = torch.empty(Bt, Np, C, **f), torch.empty(Bt, n, C, **f), torch.empty(Bt, C, C, **f)
+        check(getattr(lib, "bcbf_gp_append_stream" + _suf(X))(
+            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(x_new), _p(uh_new), _p(xdot_new),
+            _p(jitter_new), _p(Lout), _p(Vw2), _p(X2), _p(UHB2), _p(info), _p(Ww), _p(Mkw), _p(Bkw), Bt, N, n, C - 1,
+            _stream(X)), "bcbf_gp_append_stream")
+        return Lout, Vw2, X2, UHB2, info
     check(getattr(lib, "bcbf_gp_append" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0),
                                                    _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(Lout),
                                                    _p(Vw2), _p(X2), _p(UHB2), _p(info), Bt, N, n, C - 1, _stream(X)),

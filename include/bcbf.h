@@ -144,6 +144,20 @@ int bcbf_gp_append_f64(const double* Lop_in, const double* Vw_in, const double* 
                        const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
                        double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
                        void* stream);
+/* The same update with the forward solve on the streaming posterior kernel (one query per instance at x_new, at the HBM
+ * roofline: W = L^-1 Phi(x_new), l = W uh_new) -- the form for large N (at N = 1500 the simple solve of bcbf_gp_append
+ * reads the factor at 40 % of the HBM rate).  Work buffers from the caller: Wwork[Bt, Np, 1+m] (Np = N rounded up to 32),
+ * Mk_work[Bt, n, 1+m], Bk_work[Bt, 1+m, 1+m].  Same outputs and info convention. */
+int bcbf_gp_append_stream_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                              const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                              const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                              float* Vw_out, float* X_out, float* UHB_out, int* info, float* Wwork, float* Mk_work,
+                              float* Bk_work, int Bt, int N, int n, int m, void* stream);
+int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                              const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                              const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                              double* Vw_out, double* X_out, double* UHB_out, int* info, double* Wwork, double* Mk_work,
+                              double* Bk_work, int Bt, int N, int n, int m, void* stream);
 
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */
