@@ -36,6 +36,7 @@ python tools/bench_refit_forms.py f32 2>/dev/null > $O/refit_forms_f32.jsonl
 python tools/bench_online.py 2>/dev/null > $O/online_growth_f64.json
 python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
 python tools/bench_speed_test.py 2>/dev/null > $O/speed_test.jsonl
+python tools/bench_speed_test_unicycle.py --quick 2>/dev/null > $O/speed_test_unicycle.jsonl
 python tools/learn_dynamics_matrix_vector.py /tmp/learn_matrix_vector > /dev/null 2>&1; cp gpurun_out/learn_matrix_vector.jsonl $O/ 2>/dev/null
 python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -3 > $O/mc_rollouts.txt
 du -sh $O; ls $O | head -50
