@@ -17,7 +17,8 @@
 //     that consume them (bank-conflict-free image: see gload);  diagonal step: A = the stored inverse (full-tile copy),
 //     B = Phi - acc.  One barrier per tile.
 //   History, fp64, N = 512, 4096 queries: streaming VALU kernel 0.27 ms -> per-wave 8-byte operand loads from L2 0.145
-//   -> tiles shared through LDS 0.137 -> W pinned to AGPRs (no spills) + next tile's operands prefetched 0.095 ms
+//   -> tiles shared through LDS 0.137 -> W pinned to AGPRs (no spills) + next tile's operands prefetched 0.095 -> reads
+//   chained between the MFMAs, Phi tile beside the previous tile's MFMAs 0.092 ms
 //   (a bare loop of the fp64 MFMA sustains 31.4 ns per instruction with one wave per SIMD: 66 us for the 2112 of a wave).
 // The explicit prefetch (asm issue, asm wait) is only sound while the register allocator does not spill an operand
 // between the two: build.py compiles this file with -Rpass-analysis=kernel-resource-usage and refuses a build whose
@@ -86,6 +87,31 @@ template <int OFF> __device__ __forceinline__ void lds_get16(float (&a)[2][8], u
     BCBF_RD(0, 4, a0); BCBF_RD(1, 4, a1); BCBF_RD(0, 5, a0); BCBF_RD(1, 5, a1);
     BCBF_RD(0, 6, a0); BCBF_RD(1, 6, a1); BCBF_RD(0, 7, a0); BCBF_RD(1, 7, a1);
 #undef BCBF_RD
+}
+// ... the same reads a quarter at a time (k-steps 2G, 2G+1 of both tiles), CHAINED to an accumulator: the first read
+// names `acc` as an in/out operand (an accumulation register tuple, "+a"), so it is ordered after the MFMA that last
+// wrote that accumulator and before the next one that reads it -- the source order of reads and MFMAs below is the issue
+// order.  (Volatile asm statements keep their order among themselves only: left unchained, the scheduler runs a tile's 16
+// MFMAs first and sinks all 16 reads of the next tile to the end of the step, against the wait.  sched_barrier does pin
+// them but splits the scheduling region: 1500 spills in fp64.  Measured gain of the chaining: 3 % fp32, 1 % fp64.)
+template <int OFF, int G, typename A> __device__ __forceinline__ void lds_get4(double (&a)[2][8], unsigned a0, unsigned a1, A& acc) {
+#define BCBF_RD(u_, s_, addr) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[u_][s_]) : "v"(addr), "n"(OFF + NB * 8 * PSR<double>::colstep(s_)))
+    asm volatile("ds_read_b64 %0, %2 offset:%3" : "=v"(a[0][2 * G]), "+a"(acc) : "v"(a0), "n"(OFF + NB * 8 * PSR<double>::colstep(2 * G)));
+    BCBF_RD(1, 2 * G, a1); BCBF_RD(0, 2 * G + 1, a0); BCBF_RD(1, 2 * G + 1, a1);
+#undef BCBF_RD
+}
+template <int OFF, int G, typename A> __device__ __forceinline__ void lds_get4(float (&a)[2][8], unsigned a0, unsigned a1, A& acc) {
+#define BCBF_RD(u_, s_, addr) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[u_][s_]) : "v"(addr), "n"(OFF + NB * 4 * PSR<float>::colstep(s_)))
+    asm volatile("ds_read_b32 %0, %2 offset:%3" : "=v"(a[0][2 * G]), "+a"(acc) : "v"(a0), "n"(OFF + NB * 4 * PSR<float>::colstep(2 * G)));
+    BCBF_RD(1, 2 * G, a1); BCBF_RD(0, 2 * G + 1, a0); BCBF_RD(1, 2 * G + 1, a1);
+#undef BCBF_RD
+}
+template <typename A> __device__ __forceinline__ void chain(A& acc) { asm volatile("" : "+a"(acc)); }
+template <typename T, typename A> __device__ __forceinline__ void lds_wait16(T (&a)[2][8], A& acc) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[0][4]), "+v"(a[0][5]), "+v"(a[0][6]), "+v"(a[0][7]),
+                   "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(a[1][4]), "+v"(a[1][5]), "+v"(a[1][6]), "+v"(a[1][7]),
+                   "+a"(acc));
 }
 template <typename T> __device__ __forceinline__ void lds_wait16(T (&a)[2][8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -221,6 +247,26 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
             for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;        // lane c: (Vw'W)[d][c]
         }
     };
+    // Phi tile of block I: phi[s] = k(x_q, X_row) (UH B)[row][c], row = 32I + blkrow(s, g).  The exp of (query, row) is
+    // evaluated once, by the lane whose component equals the register index, and broadcast inside the quad: lane c
+    // evaluates the row that register 4u + c holds.  It does not depend on the accumulation, so it is formed during the
+    // LAST off-diagonal tile of the row, beside that tile's MFMAs (in the diagonal step every MFMA waits for it)
+    T phi[8];
+    auto phi_tile = [&](auto Ic_) {
+        constexpr int I = decltype(Ic_)::value;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row_m = I * NB + P::colstep(4 * u) + P::LANECOL * g + (P::colstep(1) - P::colstep(0)) * c;
+            T d2 = T(0);
+#pragma unroll
+            for (int d = 0; d < NS; ++d) { const T z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
+            const T kmine = s2 * P::exp_(T(-0.5) * d2);
+            const T kk[4] = {dpp_bc<0x00>(kmine), dpp_bc<0x55>(kmine), dpp_bc<0xAA>(kmine), dpp_bc<0xFF>(kmine)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                phi[4 * u + r] = kk[r] * Us[(I * NB + P::colstep(4 * u + r) + P::LANECOL * g) * C + cc] * cmask;
+        }
+    };
     static_for<0, PSR_MAXBLK>([&](auto Ict) {
         constexpr int I = decltype(Ict)::value;
         if (I < nblk) {
@@ -231,15 +277,18 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
                 constexpr int t = I * (I + 1) / 2 + K;
                 lds_put(Ts + TILE * ((t + 2) % 3), stage);
                 fetch(stage, Ic<t + 3>{});
-                lds_get16<((t + 1) % 3) * P::TILE_BYTES>(anxt, ts_a0, ts_a1);
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                // the next tile's operand reads ride behind this tile's first four MFMAs on acc0, four reads each
+                static_for<0, 8>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
                     const T wk = wget(Kct, s);
                     acc0 = P::mfma(acur[0][s], wk, acc0);
+                    if constexpr (s < 4) lds_get4<((t + 1) % 3) * P::TILE_BYTES, s>(anxt, ts_a0, ts_a1, acc0);
+                    if constexpr (s == 4) chain(acc0);                        // (bounds how far the last reads can sink)
                     acc1 = P::mfma(acur[1][s], wk, acc1);
-                }
+                });
                 if constexpr (K == 0 && I > 0) epilogue(I - 1);                // VALU work beside this row's first MFMAs
-                lds_wait16(anxt);
+                if constexpr (K == I - 1) phi_tile(Ict);                       // ... and beside its last ones
+                lds_wait16(anxt, acc0);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
                 __syncthreads();
@@ -248,22 +297,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
             lds_put(Ts + TILE * ((t + 2) % 3), stage);
             fetch(stage, Ic<t + 3>{});
             lds_get16<((t + 1) % 3) * P::TILE_BYTES>(anxt, ts_a0, ts_a1);
-            // ---- Phi tile of block I: phi[s] = k(x_q, X_row) (UH B)[row][c], row = 32I + blkrow(s, g).  The exp of
-            //      (query, row) is evaluated once, by the lane whose component equals the register index, and broadcast
-            //      inside the quad: lane c evaluates the row that register 4u + c holds
-            T phi[8];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int row_m = I * NB + P::colstep(4 * u) + P::LANECOL * g + (P::colstep(1) - P::colstep(0)) * c;
-                T d2 = T(0);
-#pragma unroll
-                for (int d = 0; d < NS; ++d) { const T z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
-                const T kmine = s2 * P::exp_(T(-0.5) * d2);
-                const T kk[4] = {dpp_bc<0x00>(kmine), dpp_bc<0x55>(kmine), dpp_bc<0xAA>(kmine), dpp_bc<0xFF>(kmine)};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    phi[4 * u + r] = kk[r] * Us[(I * NB + P::colstep(4 * u + r) + P::LANECOL * g) * C + cc] * cmask;
-            }
+            if constexpr (I == 0) phi_tile(Ict);           // (later blocks: formed beside the MFMAs of tile (I, I-1))
             // ---- diagonal step: W_I = inv(L_II) (Phi_I - acc)   (inv(L_II) is lower triangular: tile 0 needs k < 16 only)
             acc_t w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
 #pragma unroll
