@@ -22,7 +22,9 @@ def main():
     ap.add_argument("--learned", type=int, default=0, help="N_train of a per-trajectory learned GP (0 = fixed kernel)")
     ap.add_argument("--graph", action="store_true", help="replay the closed-loop step from a captured HIP graph")
     ap.add_argument("--shared-learned", type=int, default=0,
-                    help="N_train of ONE learned GP queried by every trajectory (fp32: matrix-core posterior)")
+                    help="N_train of ONE learned GP queried by every trajectory (matrix-core posterior; N <= 512 in fp64)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default=None,
+                    help="precision of the shared learned model (default: f64 as the reference's module for N <= 512, else f32)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
     torch.cuda.set_device(local)
@@ -43,7 +45,8 @@ def main():
     if args.shared_learned:
         from bayesian_cbf_amd.control_affine_model import BatchedControlAffineGP
         from bayesian_cbf_amd.synthetic import make_instances
-        dtype = torch.float32
+        f64 = args.dtype == "f64" or (args.dtype is None and args.shared_learned <= 512)
+        dtype = torch.float64 if f64 else torch.float32
         p = make_instances(1, args.shared_learned, 3, 2, dtype=dtype, device="cuda", seed=100)     # same model on every rank
         gp = BatchedControlAffineGP(p["X"], p["U"], 0.05 * p["Xdot"], 1e-2 * p["A"], 1e-2 * p["Bm"], p["ell"], p["s2"],
                                     p["M0"]).as_dict()
