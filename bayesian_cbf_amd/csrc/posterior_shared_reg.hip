@@ -22,7 +22,9 @@
 //   (a bare loop of the fp64 MFMA sustains 31.4 ns per instruction with one wave per SIMD: 66 us for the 2112 of a wave).
 // The explicit prefetch (asm issue, asm wait) is only sound while the register allocator does not spill an operand
 // between the two: build.py compiles this file with -Rpass-analysis=kernel-resource-usage and refuses a build whose
-// kernels report a non-zero scratch size.  State dimensions n <= 4 (wider ones stream); N <= 512; beyond that, and for
+// one-wave kernels report a non-zero scratch size.  fp32 with more queries than one wave per SIMD holds takes a second
+// instantiation (OCC = 2: 252 registers, plain operand loads at their use, two workgroups per CU): 63 -> 74 TFLOP/s at
+// 16384 queries.  State dimensions n <= 4 (wider ones stream); N <= 512; beyond that, and for
 // few queries, posterior_shared.hip (fp32, W slab in LDS) or the streaming kernel (posterior_step.hip) answer.
 #include "bcbf_common.h"
 #include "diag_tile64.h"      // LdsDouble
@@ -33,6 +35,9 @@ using f64x4r = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 using f32x4r = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 using u32x4r = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 
+#ifndef BCBF_PSR_OCC2
+#define BCBF_PSR_OCC2 1
+#endif
 constexpr int PSR_MAXBLK = 16;           // N <= 512
 
 // compile-time loop: the body sees a constant index (every wreg[][] subscript must be one, or the array leaves the
@@ -130,8 +135,8 @@ template <int CTRL> __device__ inline double dpp_bc(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
-template <typename T, int C, int NS>
-__global__ void __launch_bounds__(256, 1)
+template <typename T, int C, int NS, int OCC>
+__global__ void __launch_bounds__(256, OCC)
 posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                             const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                             const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
@@ -232,8 +237,10 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     lds_put(Ts + TILE, stage);
     fetch(stage, Ic<2>{});
     __syncthreads();                                   // staging of X / UH B / Vw and tiles 0, 1 visible
-    lds_get16<0>(acur, ts_a0, ts_a1);
-    lds_wait16(acur);
+    if constexpr (OCC == 1) {
+        lds_get16<0>(acur, ts_a0, ts_a1);
+        lds_wait16(acur);
+    }
     // Gram row / mean column of this lane's query from the W tile of block Ib held in pend[]
     auto epilogue = [&](int Ib) {
 #pragma unroll
@@ -277,27 +284,45 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
                 constexpr int t = I * (I + 1) / 2 + K;
                 lds_put(Ts + TILE * ((t + 2) % 3), stage);
                 fetch(stage, Ic<t + 3>{});
-                // the next tile's operand reads ride behind this tile's first four MFMAs on acc0, four reads each
-                static_for<0, 8>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    const T wk = wget(Kct, s);
-                    acc0 = P::mfma(acur[0][s], wk, acc0);
-                    if constexpr (s < 4) lds_get4<((t + 1) % 3) * P::TILE_BYTES, s>(anxt, ts_a0, ts_a1, acc0);
-                    if constexpr (s == 4) chain(acc0);                        // (bounds how far the last reads can sink)
-                    acc1 = P::mfma(acur[1][s], wk, acc1);
-                });
-                if constexpr (K == 0 && I > 0) epilogue(I - 1);                // VALU work beside this row's first MFMAs
-                if constexpr (K == I - 1) phi_tile(Ict);                       // ... and beside its last ones
-                lds_wait16(anxt, acc0);
+                if constexpr (OCC == 1) {
+                    // the next tile's operand reads ride behind this tile's first four MFMAs on acc0, four reads each
+                    static_for<0, 8>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        const T wk = wget(Kct, s);
+                        acc0 = P::mfma(acur[0][s], wk, acc0);
+                        if constexpr (s < 4) lds_get4<((t + 1) % 3) * P::TILE_BYTES, s>(anxt, ts_a0, ts_a1, acc0);
+                        if constexpr (s == 4) chain(acc0);                    // (bounds how far the last reads can sink)
+                        acc1 = P::mfma(acur[1][s], wk, acc1);
+                    });
+                    if constexpr (K == 0 && I > 0) epilogue(I - 1);            // VALU work beside this row's first MFMAs
+                    if constexpr (K == I - 1) phi_tile(Ict);                   // ... and beside its last ones
+                    lds_wait16(anxt, acc0);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+                    for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+                } else {
+                    // two waves per SIMD: plain operand loads at their use (the other wave's MFMAs cover the round trip),
+                    // 16 registers fewer and nothing for the register allocator to get wrong
+                    const T* tb = Ts + TILE * (t % 3);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const T wk = wget(Kct, s);
+                        acc0 = P::mfma(tb[rd_off0 + NB * P::colstep(s)], wk, acc0);
+                        acc1 = P::mfma(tb[rd_off1 + NB * P::colstep(s)], wk, acc1);
+                    }
+                    if constexpr (K == 0 && I > 0) epilogue(I - 1);
+                }
                 __syncthreads();
             });
             constexpr int t = I * (I + 1) / 2 + I;
             lds_put(Ts + TILE * ((t + 2) % 3), stage);
             fetch(stage, Ic<t + 3>{});
-            lds_get16<((t + 1) % 3) * P::TILE_BYTES>(anxt, ts_a0, ts_a1);
-            if constexpr (I == 0) phi_tile(Ict);           // (later blocks: formed beside the MFMAs of tile (I, I-1))
+            if constexpr (OCC == 1) lds_get16<((t + 1) % 3) * P::TILE_BYTES>(anxt, ts_a0, ts_a1);
+            if constexpr (I == 0 || OCC == 2) phi_tile(Ict);   // (one wave per SIMD, later blocks: formed beside the MFMAs of tile (I, I-1))
+            if constexpr (OCC == 2) {
+                const T* tb = Ts + TILE * (t % 3);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { acur[0][s] = tb[rd_off0 + NB * P::colstep(s)]; acur[1][s] = tb[rd_off1 + NB * P::colstep(s)]; }
+            }
             // ---- diagonal step: W_I = inv(L_II) (Phi_I - acc)   (inv(L_II) is lower triangular: tile 0 needs k < 16 only)
             acc_t w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
 #pragma unroll
@@ -318,9 +343,11 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
                 for (int e = 0; e < 8; ++e)
                     Wout[((size_t)q * Np + I * NB + P::colstep(e) + P::LANECOL * g) * C + c] = pend[e];
             }
-            lds_wait16(anxt);
+            if constexpr (OCC == 1) {
+                lds_wait16(anxt);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+                for (int s = 0; s < 8; ++s) { acur[0][s] = anxt[0][s]; acur[1][s] = anxt[1][s]; }
+            }
             if (I == nblk - 1) epilogue(I);
             __syncthreads();
         }
@@ -358,29 +385,47 @@ template <typename T> static bool psr_fits(int N, int n, int m) {
     const int Np = round_up(N, NB);
     return n <= 4 && Np <= NB * PSR_MAXBLK && psr_lds_bytes<T>(Np, n, m) <= 160 * 1024;
 }
-bool posterior_shared64_fits(int N, int n, int m) { return psr_fits<double>(N, n, m); }
-bool posterior_shared_reg32_fits(int N, int n, int m) { return psr_fits<float>(N, n, m); }
-
 template <typename T, int C, int NS>
 static void launch_psr(dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X, const T* UHB,
                        const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
                        T* W, int nq, int N, int Np, int n) {
-    static int opt_in[64] = {0};               // largest dynamic LDS size opted into, per device
-    int dev_ = 0;
+    // fp32 with enough queries for two waves per SIMD (more than 16 per CU-SIMD: > 4096 on 256 CUs): the 256-register
+    // allocation, two workgroups per CU, each wave's stalls under the other's MFMAs.  fp64 needs the full file.
+    int dev_ = 0, cus = 256;
     (void)hipGetDevice(&dev_);
-    int& lds_opt_in = opt_in[dev_ & 63];
-    if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
-        (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_opt_in = (int)lds;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
+    const bool two = sizeof(T) == 4 && BCBF_PSR_OCC2 && nq > 16 * cus && lds <= 64 * 1024;
+    auto go = [&](auto occ) {
+        constexpr int OCC = decltype(occ)::value;
+        static int opt_in[64] = {0};           // largest dynamic LDS size opted into, per device
+        int& lds_opt_in = opt_in[dev_ & 63];
+        if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
+            (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_opt_in = (int)lds;
+        }
+        hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, OCC>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
+                           xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+    };
+    if constexpr (sizeof(T) == 4 && BCBF_PSR_OCC2) {
+        if (two) go(Ic<2>{}); else go(Ic<1>{});
+    } else {
+        go(Ic<1>{});
     }
-    hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq,
-                       jitter2, Mk, Bk, W, nq, N, Np, n);
 }
 
+// The 27 kernel instantiations take minutes to compile in one translation unit: build.py compiles this file once per
+// (precision, component count) with -DBCBF_PSR_PART_T=<0 double | 1 float> -DBCBF_PSR_PART_C=<2|3|4> -- each part
+// instantiates launch_psr_c<T, C> and its kernels -- and once with -DBCBF_PSR_PART_BASE for the dispatchers and C entry
+// points, which only see the declaration below.  No part macro: everything in one unit.
 template <typename T, int C>
-static void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
-                         const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
-                         T* Mk, T* Bk, T* W, int nq, int N, int Np, int n) {
+void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
+                  const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
+                  T* Mk, T* Bk, T* W, int nq, int N, int Np, int n);
+#ifndef BCBF_PSR_PART_BASE
+template <typename T, int C>
+void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
+                  const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
+                  T* Mk, T* Bk, T* W, int nq, int N, int Np, int n) {
 #define BCBF_PSR(NSV) launch_psr<T, C, NSV>(grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
     switch (NSp) {
 #ifndef BCBF_PSR_DEV              // (development: the C = 3, NS = 3 instantiations only)
@@ -392,6 +437,22 @@ static void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T
     }
 #undef BCBF_PSR
 }
+#endif
+#if defined(BCBF_PSR_PART_T) && defined(BCBF_PSR_PART_C)
+#if BCBF_PSR_PART_T == 0
+#define BCBF_PSR_PT double
+#else
+#define BCBF_PSR_PT float
+#endif
+template void launch_psr_c<BCBF_PSR_PT, BCBF_PSR_PART_C>(int, dim3, size_t, hipStream_t, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
+                                                         const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
+                                                         const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
+                                                         BCBF_PSR_PT*, BCBF_PSR_PT*, BCBF_PSR_PT*, int, int, int, int);
+#endif
+
+#if !(defined(BCBF_PSR_PART_T) && defined(BCBF_PSR_PART_C))
+bool posterior_shared64_fits(int N, int n, int m) { return psr_fits<double>(N, n, m); }
+bool posterior_shared_reg32_fits(int N, int n, int m) { return psr_fits<float>(N, n, m); }
 
 template <typename T>
 int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
@@ -422,11 +483,14 @@ template int launch_posterior_shared_reg<float>(const float*, const float*, cons
                                                 const float*, const float*, const float*, const float*, float*, float*, float*,
                                                 int, int, int, int, void*);
 
+#endif
 }  // namespace bcbf
 
+#if !(defined(BCBF_PSR_PART_T) && defined(BCBF_PSR_PART_C))
 extern "C" int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
                                          const double* ell, const double* s2, const double* Bm, const double* M0,
                                          const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                          int nq, int N, int n, int m, void* stream) {
     return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream);
 }
+#endif

@@ -509,6 +509,28 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
     rel_close(host(Bk2), Bk_o, 1e-9 if f64 else 1e-3, scale=prior, what="Bk(query)")
 
 
+def test_shared_gp_two_waves_per_simd_form_equals_one_wave_form(ops):
+    """fp32, more queries than one wave per SIMD holds (> 16 per compute unit): the launcher takes the 256-register
+    instantiation of the register-resident kernel (two workgroups per CU, plain operand loads).  Same arithmetic in the
+    same order as the one-wave form: the same answers as the batch cut into pieces that take the one-wave form."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    dtype, N, n, m = torch.float32, 512, 3, 2
+    p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=77)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    b = 16 * cus + 1237                                       # ragged, beyond the switch-over
+    g = torch.Generator(device="cpu").manual_seed(5)
+    xq = (p["X"][0, torch.randint(0, N, (b,), generator=g).to(DEV)] + 0.3 * torch.randn(b, n, generator=g).to(DEV, dtype)).contiguous()
+    Mk, Bk, W = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, want_W=True)
+    for a in range(0, b, 2048):
+        Mk1, Bk1, W1 = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq[a:a + 2048].contiguous(), want_W=True)
+        scale = float(p["s2"][0]) * float(p["Bm"][0].abs().max())
+        rel_close(host(Mk[a:a + 2048]), host(Mk1), 1e-6, scale=max(1.0, float(Mk1.abs().max())), what="Mk")
+        rel_close(host(Bk[a:a + 2048]), host(Bk1), 1e-6, scale=scale, what="Bk")
+        rel_close(host(W[a:a + 2048]), host(W1), 1e-6, scale=max(1e-3, float(W1.abs().max())), what="W")
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_control_step_shared_model_equals_replicated_model(ops, dtype):
     """bcbf_unicycle_control_step with shared_gp=1 (one learned model, Bt closed loops: BASELINE config 4) gives the
