@@ -352,6 +352,25 @@ def main():
         bytes_launch = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bc
         traffic, traffic_src = measured_traffic(N, Bc, args.dtype, bytes_launch)
         achieved = bytes_launch * n_launch / (busy_ms * 1e-3) / 1e9
+        # the same kernel on the same part batch with the device to itself (after the timed region): one launch per event
+        # pair, nothing else running -- bytes per launch / its own duration, the figure a kernel trace of a one-stream run gives
+        alone = {}
+        if S > 1:
+            for tag, cnt in (("part_batch", Bc), ("full_batch", Bt)):
+                sl = slice(0, cnt)
+                pa = [gp[k][sl] for k in ("Lop", "Vw", "X", "UHB", "ell", "s2", "Bm", "M0")] + [x[sl].contiguous()]
+                for _ in range(3):
+                    ops.posterior_step(*pa)
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+                torch.cuda.synchronize()
+                for e0, e1 in evs:
+                    e0.record()
+                    ops.posterior_step(*pa)
+                    e1.record()
+                torch.cuda.synchronize()
+                ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+                gbs = algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * cnt / (ms * 1e-3) / 1e9
+                alone[tag] = {"instances": cnt, "kernel_ms": ms, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; HBM GB/s vs peak" % (N, Bt),
             "value": value,
@@ -378,6 +397,11 @@ def main():
                          "achieved_method": ACHIEVED_METHOD,
                          "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
         }
+        if alone:
+            alone["note"] = ("the same kernel with the device to itself, one launch per HIP-event pair, after the timed region: "
+                             "algorithmic bytes per launch / that launch's duration (what a kernel trace of a one-stream run "
+                             "reports: profiles/*_bench_parts1_kernel_stats.csv)")
+            out["roofline"]["unoverlapped"] = alone
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(p, task, args.cpu_sample, N, n, m)
         print(json.dumps(out))
