@@ -310,9 +310,10 @@ class ControlAffineRegressor:
             if ntry == 9 or jitter is not None:
                 raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
             factor *= 10
-        _, alpha = ops.potrs(Lop, Y, UH, hp["M0"])
         R = (Y - UH @ hp["M0"]).contiguous()
         Kinv = ops.kb_inverse(Lop, N)
+        alpha = (Kinv @ R).contiguous()          # K_b^-1 R from the inverse the gradient needs anyway (the two triangular
+                                                 # solves of bcbf_potrs on one workgroup were a third of an iteration)
         Ad = hp["A"][0]
         # n x n (n <= 8) inverse and log-determinant on the host: not worth pulling the device solver library in
         Ad_h = Ad.double().cpu()
@@ -850,8 +851,8 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
             if ntry == 9 or jitter is not None:
                 raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
             factor *= 10
-        _, alpha = ops.potrs(Lop, Ye, Xe.new_zeros(1, Ne, 2), Xe.new_zeros(1, 2, 1))
         Kinv = ops.kb_inverse(Lop, Ne)
+        alpha = (Kinv @ Ye).contiguous()
         one = Xe.new_ones(1, 1, 1)
         g_ell, g_s2, g_B, logdetK, RtA, UHtA, g_lin = ops.mll_grad(Lop, alpha, Kinv, Xe[None], UHe[None], Ye, one, hp["Bm"],
                                                                     hp["ell"], hp["s2"], lin=hp["lin"])

@@ -28,7 +28,9 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     constexpr int V = Vec<T>::V;
     constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 2 + CM * CM;
     __shared__ double red[4][MG_MAXOUT];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // grid (Bt, G): the N^2 pair terms of one GP are split over G workgroups (a fit is ONE model: a single workgroup
+    // left 255 CUs idle for 2 ms at N = 512); partial sums are added atomically into outputs the launcher has zeroed
+    const int b = blockIdx.x, tid = threadIdx.x, part = blockIdx.y, G = gridDim.y;
     const T* Xb = X + (size_t)b * N * n;
     const T* UHb = UH + (size_t)b * N * C;
     const T* Rb = R + (size_t)b * N * nt;
@@ -52,7 +54,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] = 0.0;
 #pragma unroll
     for (int a = 0; a < CM * CM; ++a) gB[a] = 0.0;
-    for (long long idx = tid; idx < (long long)N * N; idx += MG_T) {
+    for (long long idx = (long long)part * MG_T + tid; idx < (long long)N * N; idx += (long long)G * MG_T) {
         const int i = (int)(idx / N), j = (int)(idx - (long long)i * N);
         double d2 = 0.0, dz2[BCBF_MAX_STATE_DIM], dot = 0.0;
 #pragma unroll
@@ -114,14 +116,20 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     __syncthreads();
     if (tid < NR) {
         const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        if (tid < BCBF_MAX_STATE_DIM) { if (tid < n) g_ell[(size_t)b * n + tid] = (T)v; }
-        else if (tid == BCBF_MAX_STATE_DIM) g_s2[b] = (T)v;
-        else if (tid == NR - 1) { if (g_lin != nullptr) g_lin[b] = (T)v; }
+        T* dst = nullptr;
+        if (tid < BCBF_MAX_STATE_DIM) { if (tid < n) dst = g_ell + (size_t)b * n + tid; }
+        else if (tid == BCBF_MAX_STATE_DIM) dst = g_s2 + b;
+        else if (tid == NR - 1) { if (g_lin != nullptr) dst = g_lin + b; }
         else {
             const int o = tid - BCBF_MAX_STATE_DIM - 1, a = o / CM, c = o % CM;
-            if (a < C && c < C) g_B[((size_t)b * C + a) * C + c] = (T)v;
+            if (a < C && c < C) dst = g_B + ((size_t)b * C + a) * C + c;
+        }
+        if (dst != nullptr) {
+            if (G == 1) *dst = (T)v;
+            else atomicAdd(dst, (T)v);
         }
     }
+    if (part != 0) return;
     // ---- phase 2: the small products (one output per thread, a loop over the N rows) and logdet (last wave)
     if (tid < nt * nt) {
         const int d = tid / nt, e = tid - d * nt;
@@ -154,12 +162,27 @@ static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T*
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m + 1 > BCBF_MAX_TASK_DIM || nt < 1 || nt > BCBF_MAX_STATE_DIM)
         return BCBF_EINVAL;
     if ((m + 1) * nt > 128) return BCBF_EINVAL;                    // phase 2: one thread per entry of UH' alpha
+    // few models: spread each one's pair terms over G workgroups (partials meet in zeroed outputs by atomic adds)
+    int G = 1;
+    if (Bt < 64) {
+        const long long per_wg = (long long)MG_T * 32;             // ~32 pairs per thread
+        G = (int)(((long long)N * N + per_wg - 1) / per_wg);
+        if (G > 128) G = 128;
+        if (G < 1) G = 1;
+    }
+    if (G > 1) {
+        const int C = m + 1;
+        (void)hipMemsetAsync(g_ell, 0, sizeof(T) * (size_t)Bt * n, (hipStream_t)stream);
+        (void)hipMemsetAsync(g_s2, 0, sizeof(T) * (size_t)Bt, (hipStream_t)stream);
+        (void)hipMemsetAsync(g_B, 0, sizeof(T) * (size_t)Bt * C * C, (hipStream_t)stream);
+        if (g_lin) (void)hipMemsetAsync(g_lin, 0, sizeof(T) * (size_t)Bt, (hipStream_t)stream);
+    }
     if (m <= BCBF_MAX_CTRL_DIM)
-        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_CTRL_DIM + 1>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
+        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_CTRL_DIM + 1>), dim3(Bt, G), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
                            X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt,
                            lin, g_lin);
     else
-        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_TASK_DIM>), dim3(Bt), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
+        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_TASK_DIM>), dim3(Bt, G), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
                            X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt,
                            lin, g_lin);
     return check_launch("mll_grad");
