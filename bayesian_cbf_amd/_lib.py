@@ -34,6 +34,7 @@ _TSIGS = {
     "bcbf_gp_append": [P] * 17 + [c_int, c_int, c_int, c_int, P],
     "bcbf_gp_append_stream": [P] * 20 + [c_int, c_int, c_int, c_int, P],
     "bcbf_potri": [P, P, c_int, c_int, P],
+    "bcbf_trtri": [P, P, c_int, c_int, P],
     "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P],
     "bcbf_kb_build_rbflin": [P] * 8 + [c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query_rbflin": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],

@@ -104,6 +104,16 @@ potrs_kernel(const T* __restrict__ Lop, const T* __restrict__ Xdot, const T* __r
         __syncthreads();
     }
     if (alpha == nullptr) return;
+    if (IDENT && C == 1) {
+        // forward only (bcbf_trtri): the solved rows are 8 columns of L^-1
+#pragma unroll
+        for (int r = 0; r < SMAXR; ++r) {
+            const int i = tid + r * ST;
+            if (r < rpt && i < N)
+                for (int c = 0; c < n; ++c) alpha[((size_t)b * N + i) * ostride + j0 + c] = y[r][c];
+        }
+        return;
+    }
 
     // ---- backward substitution: y holds Vw rows; solved rows are overwritten with alpha
     for (int J = nblk - 1; J >= 0; --J) {
@@ -190,13 +200,13 @@ static int launch_potrs(const T* Lop, const T* Xdot, const T* UH, const T* M0, T
 }
 
 template <typename T>
-static int launch_potri(const T* Lop, T* Kinv, int Bt, int N, void* stream) {
+static int launch_potri(const T* Lop, T* Kinv, int Bt, int N, void* stream, int forward_only = 0) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !Kinv || N < 1) return BCBF_EINVAL;
     const int Np = round_up(N, NB);
     if (Np > ST * SMAXR) return BCBF_EINVAL;
     hipLaunchKernelGGL((potrs_kernel<T, true>), dim3((N + SC - 1) / SC, Bt), dim3(ST), 0, (hipStream_t)stream, Lop,
-                       nullptr, nullptr, nullptr, nullptr, Kinv, N, Np, SC, 0);
+                       nullptr, nullptr, nullptr, nullptr, Kinv, N, Np, SC, forward_only);
     return check_launch("potri");
 }
 
@@ -458,6 +468,14 @@ int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream) {
 }
 int bcbf_potri_f64(const double* Lop, double* Kinv, int Bt, int N, void* stream) {
     return bcbf::launch_potri<double>(Lop, Kinv, Bt, N, stream);
+}
+// Dense inverse of the factor itself, Linv[Bt,N,N] = L^-1 (lower triangular): the forward half of bcbf_potri (whose
+// backward half is 32 workgroup reductions per block: 2 ms at N = 512).  K_b^-1 = Linv' Linv is then one GEMM.
+int bcbf_trtri_f32(const float* Lop, float* Linv, int Bt, int N, void* stream) {
+    return bcbf::launch_potri<float>(Lop, Linv, Bt, N, stream, 1);
+}
+int bcbf_trtri_f64(const double* Lop, double* Linv, int Bt, int N, void* stream) {
+    return bcbf::launch_potri<double>(Lop, Linv, Bt, N, stream, 1);
 }
 int bcbf_gp_append_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
                        const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,

@@ -141,11 +141,16 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
     return Lout, Vw2, X2, UHB2, info
 
 
-def kb_inverse(Lop, N):
-    """Dense K_b^-1 [Bt,N,N] from the packed factor (bcbf_potri; fit path only)."""
+def kb_inverse(Lop, N, gemm=True):
+    """Dense K_b^-1 [Bt,N,N] from the packed factor (fit path only).  gemm=True: L^-1 from bcbf_trtri (the forward half
+    of the solve) and K_b^-1 = L^-T L^-1 as one library GEMM; gemm=False: bcbf_potri (forward + backward solves of the
+    identity: its backward half is latency bound, 2 ms at N = 512 for one model against 0.3 ms this way)."""
     _chk(Lop)
     Bt = Lop.shape[0]
     Kinv = torch.empty(Bt, N, N, dtype=Lop.dtype, device=Lop.device)
+    if gemm:
+        check(getattr(lib, "bcbf_trtri" + _suf(Lop))(_p(Lop), _p(Kinv), Bt, N, _stream(Lop)), "bcbf_trtri")
+        return torch.matmul(Kinv.transpose(1, 2), Kinv)
     check(getattr(lib, "bcbf_potri" + _suf(Lop))(_p(Lop), _p(Kinv), Bt, N, _stream(Lop)), "bcbf_potri")
     return Kinv
 

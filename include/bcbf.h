@@ -163,6 +163,11 @@ int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const d
  * 8 columns. */
 int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream);
 int bcbf_potri_f64(const double* Lop, double* Kinv, int Bt, int N, void* stream);
+/* Dense inverse of the Cholesky factor, Linv[Bt,N,N] = L^-1 (lower triangular, zeros above): the forward half of
+ * bcbf_potri.  K_b^-1 = Linv' Linv is one plain GEMM on the caller's side (the fit path does that: the backward half of
+ * bcbf_potri is latency bound, 2 ms at N = 512 for ONE model). */
+int bcbf_trtri_f32(const float* Lop, float* Linv, int Bt, int N, void* stream);
+int bcbf_trtri_f64(const double* Lop, double* Linv, int Bt, int N, void* stream);
 
 /* K12 -- hyper-parameter fit support (ControlAffineRegressor.fit, control_affine_model.py:268-335):
  * the O(N^2) sums of the gradient of  log p(Y) = -1/2 tr(A^-1 R'K_b^-1 R) - n/2 logdet K_b - N/2 logdet A - Nn/2 log 2pi

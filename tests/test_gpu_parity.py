@@ -605,14 +605,16 @@ def test_online_gp_append_equals_refit(ops, dtype):
         rel_close(host(Vw), host(Vw_r), 1e-8, what="Vw")
 
 
+@pytest.mark.parametrize("gemm", [False, True], ids=["potri", "trtri+gemm"])
 @pytest.mark.parametrize("dtype,N", [(torch.float64, 100), (torch.float64, 256), (torch.float32, 64)])
-def test_potri_dense_inverse(ops, dtype, N):
-    """bcbf_potri: K_b^-1 from the packed factor (ragged N: the last column chunk is partial)."""
+def test_potri_dense_inverse(ops, dtype, N, gemm):
+    """K_b^-1 from the packed factor (ragged N: the last column chunk is partial): bcbf_potri, and bcbf_trtri (dense
+    L^-1, checked lower triangular with L L^-1 = I through the dense factor) followed by one GEMM."""
     from bayesian_cbf_amd.synthetic import make_instances
     p = make_instances(3, N, 3, 2, dtype=dtype, device=DEV, seed=21)
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     assert (info == 0).all()
-    Kinv = ops.kb_inverse(Lop, N)
+    Kinv = ops.kb_inverse(Lop, N, gemm=gemm)
     Kb = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     eye = torch.eye(N, dtype=torch.float64, device=DEV)
     res = (Kb.double() @ Kinv.double() - eye).abs().max()
