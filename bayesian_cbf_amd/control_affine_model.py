@@ -738,10 +738,10 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
             factor = factor * cholesky_perturb_scale
         Ce = UHe.shape[1]
         # (the targets are already mean-free: the solve's own `Y - UH M0` step gets a zero two-column factor, whatever Ce)
-        Vw1, alpha = ops.potrs(Lop, Ye, Xe.new_zeros(1, Ne, 2), Xe.new_zeros(1, 2, 1))
+        Vw1, _ = ops.potrs(Lop, Ye, Xe.new_zeros(1, Ne, 2), Xe.new_zeros(1, 2, 1), want_alpha=False)   # (streaming forward solve)
         Vw = Xe.new_zeros(1, Ne, n)                      # the query kernel reads n target columns; only the first is used
         Vw[..., 0] = Vw1[..., 0]
-        st = dict(hp, X=Xe[None], UH=UHe[None], UHB=(UHe @ hp["Bm"][0])[None].contiguous(), Lop=Lop, Vw=Vw, alpha=alpha,
+        st = dict(hp, X=Xe[None], UH=UHe[None], UHB=(UHe @ hp["Bm"][0])[None].contiguous(), Lop=Lop, Vw=Vw,
                   Y=Ye, N=Ne, jitter=jitter[None].contiguous(), M0e=Xe.new_zeros(1, Ce, n))
         self._cache["state"] = st
         return st
