@@ -55,7 +55,10 @@ for tag, sched, batch in (("default", "", 2048), ("defaultparts1", " --parts 1",
             continue
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "posterior_step_kernel<float, 3, 4, 0, 1, false>" in r["Kernel_Name"]:      # (not the potrs instantiation)
+            # (not the potrs instantiation; only launches of this schedule's size: the bench line's un-overlapped
+            #  measurements launch the same kernel on the part batch AND on the full batch)
+            if "posterior_step_kernel<float, 3, 4, 0, 1, false>" in r["Kernel_Name"] and \
+                    int(r["Grid_Size"]) // int(r["Workgroup_Size"]) == batch:
                 per[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in per.items():
             raw[k] = dict(launches=len(v), mean=sum(v) / len(v), min=min(v), max=max(v))
