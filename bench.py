@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+PREWARM_MIN = 60               # untimed steps before the timed region (>= --warmup): 5 left a 20-step run 5 % slow
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (MI355X_MICROARCH.md)
 F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64, dense (MI355X_MICROARCH.md)
 ACHIEVED_METHOD = ("algorithmic units of ALL launches of the kernel in the timed region / time during which at least one of "
@@ -246,7 +247,10 @@ def main():
         status_t, iters_t = ws["status"], ws["iters"]
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # untimed: the W warm-up steps asked for, preceded by enough further steps to reach the steady state the timed region
+    # is meant to measure (clocks, caches, the two streams' pipeline): at least PREWARM_MIN untimed steps in all
+    prewarm = max(0, PREWARM_MIN - args.warmup)
+    for _ in range(prewarm + args.warmup):
         step()
     torch.cuda.synchronize()
 
@@ -330,7 +334,7 @@ def main():
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; shared learned model" % (N, Bt),
             "value": value, "unit": "control steps/s (instance-steps: batch x batched steps/s)",
-            "batched_steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "batched_steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints + SOCP per step, "
@@ -379,6 +383,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": prewarm,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
