@@ -3,8 +3,11 @@
 These complement tests/test_gpu_parity.py (entry point by entry point, goldens) with the exact shapes, seeds and
 fused entry points that `bench.py` and the tools time: the two launches of `bcbf_unicycle_control_step` at
 N=512, n=3, m=2 (C3), the batched kernel build + Cholesky + posterior at N=256, batch 1024, fp64 (C2), the online
-growth 128 -> 2048 through `bcbf_gp_append` (C5) and the pendulum learning experiment at N=64 (C1).
+growth 128 -> 2048 through `bcbf_gp_append` (C5), the pendulum learning experiment at N=64 (C1) and the Monte-Carlo
+rollouts at their full size of 32 768 trajectories (C4).
 Tolerances: BASELINE.json north_star -- 1e-5 relative in fp64 (held at 1e-8), 1e-3 relative in fp32."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -347,3 +350,25 @@ def test_concurrent_part_batches_equal_single_stream_steps(ops, dtype, shared):
     ok = ws["status"] == 0
     assert int(ok.sum()) > Bt // 2 and torch.equal(ys[-1][ok], loop.y[ok])
     assert float((x1 - task["x"]).abs().max()) > 1e-3            # the loops did move
+
+
+def test_c4_full_size_monte_carlo_rollouts_properties():
+    """BASELINE configs[3] at its full size on one GPU: 32 768 trajectories x 200 steps of the
+    unicycle_bayes_cbf_safe_obstacle recipe (max_risk 0.01, true L = 12), replayed from a captured HIP graph.  Size-independent
+    properties: every program solved, no trajectory enters an obstacle, finite statistics, the run is deterministic
+    (same seed -> identical statistics), and trajectory 0 of a zero-noise run is the reference's committed run."""
+    from bayesian_cbf_amd.rollouts import monte_carlo_safety_rollouts
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "saved_run_bayes_cbf_maxrisk0p01.npz"))
+    kw = dict(numSteps=int(g["numSteps"]), dt=float(g["dt"]), kernel_diag_A=tuple(g["kernel_diag_A"]), L_mean=float(g["mean_L"]),
+              L_true=float(g["true_L"]), max_risk=float(g["max_risk"]))
+    a = monte_carlo_safety_rollouts(32768, start_noise=0.05, seed=11, use_graph=True, **kw)
+    b = monte_carlo_safety_rollouts(32768, start_noise=0.05, seed=11, use_graph=True, **kw)
+    st = a["stats"]
+    assert st["count"] == 32768 and st["solver_failures"] == 0 and st["collisions"] == 0, st
+    assert np.isfinite(st["min_h"]) and st["min_h"] > 0.0 and np.isfinite(st["mean_cost"]), st
+    assert st == b["stats"]
+    assert a["loop_seconds"] < 1.0                                # (27 ms on an MI355X: launch bound without the graph)
+    z = monte_carlo_safety_rollouts(64, start_noise=0.0, record=True, **kw)
+    err = np.abs(z["traj"].cpu().numpy()[:int(g["numSteps"]), 0] - g["state"]).max(axis=1)
+    assert err[:50].max() < 5e-3 and err.max() < 5e-2
+
