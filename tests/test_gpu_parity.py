@@ -465,6 +465,7 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,n,m,b,dtype", [(512, 3, 2, 203, torch.float32), (100, 3, 2, 8, torch.float32), (256, 3, 1, 64, torch.float32),
                                            (1024, 3, 3, 37, torch.float32), (64, 3, 1, 5, torch.float32), (1280, 3, 2, 17, torch.float32),
+                                           (480, 4, 3, 37, torch.float32), (96, 2, 3, 5, torch.float32), (64, 2, 1, 40, torch.float32), (416, 4, 2, 17, torch.float32),
                                            (512, 3, 2, 203, torch.float64), (100, 3, 2, 9, torch.float64), (256, 2, 1, 64, torch.float64),
                                            (480, 4, 3, 37, torch.float64), (64, 1, 1, 5, torch.float64), (416, 4, 2, 17, torch.float64),
                                            (200, 6, 2, 17, torch.float64), (640, 3, 2, 40, torch.float64)])
