@@ -248,12 +248,14 @@ def test_c5_online_growth_128_to_2048_vs_oracle(ops):
     assert X.shape[1] == N1 and torch.equal(X, p["X"])
 
 
-def test_gp_append_failed_pivot_leaves_the_instance_unchanged(ops):
+@pytest.mark.parametrize("N", [40, 400], ids=["simple-solve", "streaming-solve"])
+def test_gp_append_failed_pivot_leaves_the_instance_unchanged(ops, N):
     """A duplicated observation without jitter has a zero pivot: info = N+1, the instance's posterior stays that of
     its N points (the appended row is neutral), healthy instances of the batch take their point; appending again with
-    a jitter (make_psd's retry) then succeeds."""
+    a jitter (make_psd's retry) then succeeds.  N = 400 takes the form whose forward solve runs on the streaming
+    posterior kernel (bcbf_gp_append_stream)."""
     from bayesian_cbf_amd.synthetic import make_instances
-    Bt, N, n, m = 3, 40, 3, 2
+    Bt, n, m = 3, 3, 2
     dtype = torch.float64
     p = make_instances(Bt, N + 1, n, m, dtype=dtype, device=DEV, seed=9)
     cut = lambda t, k: t[:, :k].contiguous()
