@@ -243,11 +243,15 @@ class ControlAffineRegressor:
         scheduler = torch.optim.lr_scheduler.MultiStepLR(
             optimizer, milestones=[int(round(f * training_iter)) for f in (0.3, 0.6, 0.8, 0.9)])
         self.fit_losses = []
-        for _ in range(training_iter):
-            optimizer.zero_grad()
-            self.fit_losses.append(self.neg_mll_backward(perturb_targets=True))
-            optimizer.step()
-            scheduler.step()
+        self._fit_jitter = 1e-5                         # sticky jitter level for the iterations of this fit (neg_mll_backward)
+        try:
+            for _ in range(training_iter):
+                optimizer.zero_grad()
+                self.fit_losses.append(self.neg_mll_backward(perturb_targets=True))
+                optimizer.step()
+                scheduler.step()
+        finally:
+            self._fit_jitter = None
         self.clear_cache()
         return self
 
@@ -301,7 +305,10 @@ class ControlAffineRegressor:
         if perturb_targets:
             Y = Y * (1 + 1e-6 * torch.rand_like(Y))                                # :318-321
         Y = Y[None].contiguous()
-        factor = 1e-5
+        # jitter schedule of make_psd (1e-5 rand, x10 on a failed pivot).  Inside one fit() the level that last worked is
+        # where the next iteration starts (`_fit_jitter`): in fp32 the first level fails at every iteration of a
+        # well-fitted model, and each failed attempt is a whole factorisation (2.9 -> 1 per iteration)
+        factor = getattr(self, "_fit_jitter", None) or 1e-5
         for ntry in range(10):
             jit = (factor * self.rand_fn(N))[None].contiguous() if jitter is None else jitter
             Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit)
@@ -310,6 +317,8 @@ class ControlAffineRegressor:
             if ntry == 9 or jitter is not None:
                 raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
             factor *= 10
+        if getattr(self, "_fit_jitter", None) is not None:
+            self._fit_jitter = factor
         R = (Y - UH @ hp["M0"]).contiguous()
         Kinv = ops.kb_inverse(Lop, N)
         alpha = (Kinv @ R).contiguous()          # K_b^-1 R from the inverse the gradient needs anyway (the two triangular
@@ -841,7 +850,7 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         if perturb_targets:
             Y = Y * (1 + 1e-6 * torch.rand_like(Y))
         Ye = (Y - UH @ hp["M0"]).reshape(1, Ne, 1).contiguous()
-        factor = 1e-5
+        factor = getattr(self, "_fit_jitter", None) or 1e-5         # (sticky inside one fit(): see the matrix-variate class)
         for ntry in range(10):
             jit = (factor * self.rand_fn(Ne))[None].contiguous() if jitter is None else jitter
             Kb = ops.kb_build(Xe[None], UHe[None], hp["Bm"], hp["ell"], hp["s2"], jit, lin=hp["lin"])
@@ -851,6 +860,8 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
             if ntry == 9 or jitter is not None:
                 raise RuntimeError("cholesky: pivot %d is not positive" % int(info[0]))
             factor *= 10
+        if getattr(self, "_fit_jitter", None) is not None:
+            self._fit_jitter = factor
         Kinv = ops.kb_inverse(Lop, Ne)
         alpha = (Kinv @ Ye).contiguous()
         one = Xe.new_ones(1, 1, 1)
