@@ -13,6 +13,7 @@
 // fp32 MFMA runs at the fp32 vector rate on gfx950: the gain is operand traffic / instruction count
 // (2 loads + 1 MFMA per 2048 MACs instead of LDS broadcasts), not peak.
 #include "bcbf_common.h"
+#include "diag_tile64.h"
 #include <stdlib.h>
 
 #ifndef BCBF_R32_WAVE_MIN_BATCH
@@ -54,8 +55,9 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                   const float* __restrict__ Kdense, float* __restrict__ Lop, float* __restrict__ UHBout,
                   float* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C) {
     constexpr int V = 4;
-    __shared__ float dS[NB][NB + 1];                         // diagonal tile S_JJ (row c, col i)
-    __shared__ float dinv[NB][NB + 1];                       // inv(L_JJ)[c][c']
+    __shared__ DiagTile<float> dt;                           // the diagonal tile's working set (diag_tile64.h)
+    float (&dS)[NB][NB + 1] = dt.tile;                       // diagonal tile S_JJ (row c, col i); after the factorisation: L
+    float (&dinv)[NB][NB + 1] = dt.xinv;                     // inv(L_JJ)[c][c']
     __shared__ float colX[NB][BCBF_MAX_STATE_DIM];
     __shared__ float colUH[NB][BCBF_MAX_CTRL_DIM + 1];
     __shared__ float idg[NB];                                // 1 / L_JJ[c][c]
@@ -209,6 +211,24 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
                     for (int i = 0; i < NB; ++i) { const float xi = lane == i ? 1.f : 1e-6f * dS[i][lane]; dinv[i][lane] = xi; if (i >= lane) lop[base + i] = xi; lop[lop_dfull(J, i, lane, Np)] = xi; }
                 }
 #else
+                if constexpr (NW == 8) {      // few instances in flight, 256-register budget: the 4-column-blocked tile routine
+                bad = diag_factor_invert<float>(BCBF_LDS_TILE(float, dt), lane);
+                if (bad != 0) bad += col0;
+                __builtin_amdgcn_wave_barrier();
+                if (Ld && lane < NB && col0 + lane < N) {
+                    for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = dt.tile[lane][c];
+                }
+                {
+                    const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
+#pragma unroll
+                    for (int t = 0; t < NB * NB / 64; ++t) {
+                        const int e = lane + 64 * t, c = e >> 5, r = e & 31;
+                        const float xv = dt.xinv[r][c];
+                        lop[bfull + e] = xv;
+                        if (r >= c) lop[bpack + lop_dinv_col(c) + r] = xv;
+                    }
+                }
+                } else
                 if constexpr (NW != 4) {      // few instances in flight: latency of one GP counts; the batch form (NW = 4, 128 VGPRs) would spill
                 // Fully unrolled (see refit_mfma64.hip): constant LDS offsets, the half-wave sums on the VALU
                 // (v_permlane32_swap), two partial sums per dot product.
@@ -344,10 +364,15 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
         launch_refit_wave32(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);
         return check_launch("refit_wave32");
     }
+    // few instances: 8 waves per workgroup with the 4-column-blocked diagonal tile (256-register budget) beat 16 waves with
+    // the unrolled 32-step tile (128 registers: the blocked routine spills there) -- ONE model, fp32: 126 -> 107 us at N = 128,
+    // 288 -> 235 at 256, 754 -> 702 at 512, 2991 -> 2815 at 1024.  BCBF_REFIT_WIDE8=0 keeps the 16-wave form
+    static const int wide8 = [] { const char* e = getenv("BCBF_REFIT_WIDE8"); return e ? atoi(e) : 1; }();
     const bool wide = Bt < 128 && N >= 128;   // few instances: 16 waves per workgroup and the unrolled diagonal-tile code (Bt=1: 145 -> 117 us at N=128, 346 -> 273 at 256, 869 -> 725 at 512, 2115 -> 1990 at 1024)
 #define BCBF_REFIT_LAUNCH(DENSE, ...)                                                                   \
     do {                                                                                                \
-        if (wide) hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 16>), dim3(Bt), dim3(1024), __VA_ARGS__);              \
+        if (wide && wide8) hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 8>), dim3(Bt), dim3(512), __VA_ARGS__);       \
+        else if (wide) hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 16>), dim3(Bt), dim3(1024), __VA_ARGS__);         \
         else hipLaunchKernelGGL((refit_mfma_kernel<DENSE, 4>), dim3(Bt), dim3(256), __VA_ARGS__);                     \
     } while (0)
     if (Kdense) {
