@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .gp_algebra import GaussianProcess
+from .matrix_variate_multitask_model import HetergeneousMatrixVariateMean, SharedConstantMeans
 
 
 def default_device():
@@ -125,6 +126,13 @@ class ControlAffineRegressor:
         self._cache = dict()
         self._f_func_gp = GaussianProcess(self.f_func_mean, self.f_func_knl, (self.x_dim,), name="f",
                                           source=(self, "f", None))
+        # the reference model's row container and prior-mean module (ControlAffineExactGP.__init__, :146-156); the mean
+        # module reads the same (1+m) n constants the device path receives as M0
+        self.matshape = (1 + u_dim, x_dim)
+        self.decoder = CatEncoder(1, x_dim, 1 + u_dim)
+        if hasattr(self.model, "mean_constants"):
+            self.mean_module = HetergeneousMatrixVariateMean(
+                SharedConstantMeans(lambda: self.model.mean_constants, (1 + u_dim) * x_dim), self.decoder, self.matshape)
 
     # ---------------------------------------------------------------- bookkeeping
     @property
@@ -223,6 +231,40 @@ class ControlAffineRegressor:
         self.load_state_dict(torch.load(path))
 
     # ---------------------------------------------------------------- training data
+    def encode_from_XU(self, Xtrain, Utrain=None, M=0):
+        """(encoder, MXU rows [mask, x, uh]): observation rows (M=1, uh = [1, u]) or matrix rows (M=0, uh = 0)
+        (ControlAffineExactGP.encode_from_XU, :186-193)."""
+        Mtrain = Xtrain.new_full([Xtrain.size(0), 1], M)
+        if M:
+            assert Utrain is not None
+            UHtrain = torch.cat([Mtrain, Utrain], dim=1)
+        else:
+            UHtrain = Xtrain.new_zeros((Xtrain.size(0), self.matshape[0]))
+        return CatEncoder.from_data(Mtrain, Xtrain, UHtrain)
+
+    def set_train_data(self, Xtrain, Utrain, XdotTrain):
+        """ControlAffineExactGP.set_train_data (:179-184): store the training set (no optimisation)."""
+        assert self.matshape == (1 + Utrain.shape[-1], Xtrain.shape[-1])
+        assert Xtrain.shape[-1] == XdotTrain.shape[-1]
+        return self.fit(Xtrain, Utrain, XdotTrain, training_iter=0)
+
+    @property
+    def train_inputs(self):
+        """(MXU,) as the reference's model keeps it, or None without data."""
+        if self.Xtrain is None:
+            return None
+        return (self.encode_from_XU(self.Xtrain, self.Utrain, 1)[1],)
+
+    @property
+    def train_targets(self):
+        return None if self.XdotTrain is None else self.XdotTrain.reshape(-1)
+
+    def zero_grad(self):
+        for p in self.model.parameters():
+            if p.grad is not None:
+                p.grad.detach_()
+                p.grad.zero_()
+
     def fit(self, Xtrain_in, Utrain_in, XdotTrain_in, training_iter=50, lr=0.1, **kw):
         """Store the training set and optimise the hyper-parameters (control_affine_model.py:268-335):
         `training_iter` Adam steps (lr, MultiStepLR at 30/60/80/90 %) on -log p(Y)/(N n), targets perturbed by
@@ -243,7 +285,7 @@ class ControlAffineRegressor:
         scheduler = torch.optim.lr_scheduler.MultiStepLR(
             optimizer, milestones=[int(round(f * training_iter)) for f in (0.3, 0.6, 0.8, 0.9)])
         self.fit_losses = []
-        self._fit_jitter = 1e-5                         # sticky jitter level for the iterations of this fit (neg_mll_backward)
+        self._fit_jitter = 1e-5                         # jitter level the iterations of this fit hand on (neg_mll_backward)
         try:
             for _ in range(training_iter):
                 optimizer.zero_grad()
@@ -251,6 +293,7 @@ class ControlAffineRegressor:
                 optimizer.step()
                 scheduler.step()
         finally:
+            self.fit_jitter_level = self._fit_jitter    # the level the last iteration's likelihood was evaluated at (info)
             self._fit_jitter = None
         self.clear_cache()
         return self
@@ -305,10 +348,12 @@ class ControlAffineRegressor:
         if perturb_targets:
             Y = Y * (1 + 1e-6 * torch.rand_like(Y))                                # :318-321
         Y = Y[None].contiguous()
-        # jitter schedule of make_psd (1e-5 rand, x10 on a failed pivot).  Inside one fit() the level that last worked is
-        # where the next iteration starts (`_fit_jitter`): in fp32 the first level fails at every iteration of a
-        # well-fitted model, and each failed attempt is a whole factorisation (2.9 -> 1 per iteration)
-        factor = getattr(self, "_fit_jitter", None) or 1e-5
+        # jitter schedule of make_psd (1e-5 rand, x10 on a failed pivot).  Inside one fit() an iteration starts ONE level
+        # below the level that last worked, never below 1e-5 (`_fit_jitter`): in fp32 the first level fails at every
+        # iteration of a well-fitted model and each failed attempt is a whole factorisation, but a level raised at a
+        # transiently bad hyper-parameter point must decay again -- otherwise the rest of the fit optimises K_b plus an
+        # inflated jitter while `_state()` (make_psd's own schedule, from 1e-5) predicts with a smaller one
+        factor = max(1e-5, (getattr(self, "_fit_jitter", None) or 1e-5) / 10)
         for ntry in range(10):
             jit = (factor * self.rand_fn(N))[None].contiguous() if jitter is None else jitter
             Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit)
@@ -442,6 +487,54 @@ class ControlAffineRegressor:
         vp = torch.einsum("bnc,bc->bn", Wp, UHtestp)
         sv = self._prior_knl(Xtest, Xtestp) * (UHtest @ B @ UHtestp.t()) - v @ vp.t()
         return mean, (sv if scalar_var_only else torch_kron(sv, A)[None])
+
+    def predict(self, Xtest_in, return_cov=True):
+        """Posterior of the MATRIX F(x)' at the test states (:337-363: the reference evaluates its gpytorch model on
+        matrix rows, mask 0): mean [b, 1+m, n] and the full covariance [b(1+m)n, b(1+m)n] = kron(B_k(X, X), A), entry order
+        (test point, row of F', state dimension).  The arithmetic is the matrix-variate posterior of
+        `_custom_predict_matrix` WITHOUT its second make_psd jitter (gpytorch's exact prediction adds none; parity with
+        gpytorch itself is unpinned)."""
+        Xtest = self._ensure_device_dtype(Xtest_in)
+        b, C, n = Xtest.shape[0], 1 + self.u_dim, self.x_dim
+        A, B = self.model.A.detach(), self.model.B.detach()
+        if self.Xtrain is None:
+            mean = self.model.M0.detach()[None].expand(b, -1, -1)
+            Bk = B * self._prior_knl(Xtest, Xtest)[:, :, None, None]
+        else:
+            _, Mk, _, W = self._query(Xtest, want_W=return_cov)
+            mean = Mk.transpose(-2, -1)
+            if return_cov:
+                Bk = self._prior_knl(Xtest, Xtest)[:, :, None, None] * B - torch.einsum("bnc,pnd->bpcd", W, W)
+        mean = mean.to(device=Xtest_in.device, dtype=Xtest_in.dtype) if isinstance(Xtest_in, torch.Tensor) else mean
+        if not return_cov:
+            return mean
+        cov = torch_kron(Bk.transpose(2, 1).reshape(b * C, b * C), A)
+        if isinstance(Xtest_in, torch.Tensor):
+            cov = cov.to(device=Xtest_in.device, dtype=Xtest_in.dtype)
+        return mean, cov
+
+    def _predict_flatten(self, Xtest_in, Utest_in):
+        """f(x) + g(x) u predicted directly on observation rows (mask 1) (:645-682): mean [b, n] and the [b n, b n]
+        covariance kron(k_b(x, x') - v'v', A) in the reference's raw reshape (b, n, n, b).  Put Utest = 0 for f only."""
+        mean, cov = ControlAffineRegressor.custom_predict(self, Xtest_in, Utest_in, compute_cov=True)
+        b = mean.shape[0]
+        cov = cov.reshape(b, mean.shape[-1], mean.shape[-1], b)
+        if isinstance(Xtest_in, torch.Tensor):
+            mean, cov = (t.to(device=Xtest_in.device, dtype=Xtest_in.dtype) for t in (mean, cov))
+        return mean, cov
+
+    def _A_mat(self):
+        return self.model.A
+
+    def _B_mat(self):
+        return self.model.B
+
+    def _cbf_func(self, Xtest, grad_htest, return_cov=False):
+        """grad_h' F(x)' and its covariance (:853-860)."""
+        if return_cov:
+            mean_Fx, cov_Fx = self.predict(Xtest, return_cov=True)
+            return grad_htest @ mean_Fx, grad_htest.T @ cov_Fx @ grad_htest
+        return grad_htest @ self.predict(Xtest, return_cov=False), None
 
     # ---------------------------------------------------------------- GP views (:707-818)
     @staticmethod
@@ -850,7 +943,7 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         if perturb_targets:
             Y = Y * (1 + 1e-6 * torch.rand_like(Y))
         Ye = (Y - UH @ hp["M0"]).reshape(1, Ne, 1).contiguous()
-        factor = getattr(self, "_fit_jitter", None) or 1e-5         # (sticky inside one fit(): see the matrix-variate class)
+        factor = max(1e-5, (getattr(self, "_fit_jitter", None) or 1e-5) / 10)   # (decaying level: see the matrix-variate class)
         for ntry in range(10):
             jit = (factor * self.rand_fn(Ne))[None].contiguous() if jitter is None else jitter
             Kb = ops.kb_build(Xe[None], UHe[None], hp["Bm"], hp["ell"], hp["s2"], jit, lin=hp["lin"])

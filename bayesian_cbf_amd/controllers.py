@@ -5,9 +5,12 @@ constraint terms through `cbc2_quadratic_terms` (jet / posterior kernels + close
 `bcbf_controller_cones` and the program through `bcbf_coneqp_f64` -- no cvxpy / cvxopt / GUROBI.  `control(x, t)`
 takes one state like the reference, or a batch x[b, n] (one program per row, one launch per stage).
 
-Not mirrored (outside the GP / conic-program path): the nominal controllers (Zero / Greedy /
-epsilon-greedy / LQR / ILQR, controllers.py:64-285) and the plotters.  `ControlCBFLearned` keeps the reference's
-`unsafe_controller_class` / `exploration_controller_class` arguments: the caller supplies the nominal controller."""
+The small host-side nominal controllers (Zero / Greedy / epsilon-greedy, controllers.py:166-213, 269-285) and
+`NamedAffineFunc` (:739-771) are here as upstream has them; `ControlCBFLearned()` is constructible with its defaults
+(nominal controller = the greedy one-step tracker inside the epsilon-greedy explorer).  Not mirrored (SURVEY 2.1 #8:
+outside the GP / conic-program path): LQR / ILQR (they need the external `lqr` / `mpc` packages) and the plotters."""
+import math
+import random
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -51,6 +54,96 @@ class Controller(ABC):
     @abstractmethod
     def control(self, xi, t=None):
         pass
+
+
+def epsilon(i, interpolate={0: 1, 1000: 0.01}):
+    """Log-linear interpolation between two (step, value) pairs (misc.py:261-265)."""
+    (si, sv), (ei, ev) = list(interpolate.items())
+    return math.exp((i - si) / (ei - si) * (math.log(ev) - math.log(sv)) + math.log(sv))
+
+
+def clip(x, min_, max_):
+    """misc.py:287-288."""
+    return torch.max(torch.min(x, max_), min_)
+
+
+class ZeroController(Controller):
+    """u = 0 (controllers.py:166-171)."""
+
+    def __init__(self, model, Q, R, x_goal, numSteps, dt, ctrl_range):
+        self.u_dim = R.shape[-1]
+
+    def control(self, x, t=None):
+        return x.new_zeros(*x.shape[:-1], self.u_dim)
+
+
+class GreedyController(Controller):
+    """One-step greedy tracking of x_goal (controllers.py:174-213): with G = g(x) dt, lam = 1/2,
+    u = (lam R dt + (1 - lam) G'P G)^-1 (1 - lam) G'P (x_g - x - f(x) dt).  One state or a batch of states."""
+
+    def __init__(self, model, Q, R, x_goal, numSteps, dt, ctrl_range):
+        self.x_goal, self.model, self.Q, self.R = x_goal, model, Q, R
+        self.numSteps, self.dt, self.ctrl_range = numSteps, dt, ctrl_range
+
+    def clf(self, x):
+        return (x - self.x_goal) ** 2
+
+    def grad_clf(self, x):
+        return 2 * (x - self.x_goal)
+
+    def control(self, x, t=None):
+        with torch.no_grad():
+            f = dict(dtype=x.dtype, device=x.device)
+            x_g, P, R, lam = self.x_goal.to(**f), self.Q.to(**f), self.R.to(**f) * self.dt, 0.5
+            xb = x.reshape(-1, x.shape[-1])
+            fx = self.dt * torch.as_tensor(self.model.f_func(xb), **f)
+            Gx = self.dt * torch.as_tensor(self.model.g_func(xb), **f)              # [b, n, m]
+            Q = lam * R + (1 - lam) * Gx.transpose(-2, -1) @ P @ Gx
+            c = (1 - lam) * Gx.transpose(-2, -1) @ (P @ (x_g - xb - fx).unsqueeze(-1))
+            u = torch.linalg.solve(Q, c).squeeze(-1)
+            assert u.shape[-1] == self.R.shape[-1]
+            return u[0] if x.dim() == 1 else u
+
+
+class EpsilonGreedyController(ABC):
+    """A uniformly random action with probability eps(t), eps annealed log-linearly from egreedy_scheme[0] at t = 0 to
+    egreedy_scheme[1] at t = numSteps; clipped to ctrl_range (controllers.py:269-285)."""
+
+    def __init__(self, base_controller, u_dim, numSteps, egreedy_scheme, ctrl_range):
+        self.base_controller, self.u_dim, self.numSteps = base_controller, u_dim, numSteps
+        self.egreedy_scheme, self.ctrl_range = egreedy_scheme, ctrl_range
+
+    def control(self, x, t=None):
+        min_, max_ = self.ctrl_range
+        eps = epsilon(t, interpolate={0: self.egreedy_scheme[0], self.numSteps: self.egreedy_scheme[1]})
+        u0 = self.base_controller.control(x, t=t)
+        randomact = (torch.rand(self.u_dim) * (max_ - min_) + min_).to(u0)
+        uegreedy = randomact.expand_as(u0) if random.random() < eps else u0
+        return clip(uegreedy, torch.as_tensor(min_).to(u0), torch.as_tensor(max_).to(u0))
+
+
+class NamedAffineFunc(ABC):
+    """A(x) u - b(x) with a name for plots (controllers.py:739-771); the pendulum / car barrier and Lyapunov classes of
+    the reference derive from it."""
+
+    @property
+    def __name__(self):
+        return self.name
+
+    @abstractmethod
+    def value(self, x):
+        """Scalar value function."""
+
+    @abstractmethod
+    def b(self, x):
+        """A(x) @ u - b(x)"""
+
+    @abstractmethod
+    def A(self, x):
+        """A(x) @ u - b(x)"""
+
+    def __call__(self, x, u):
+        return self.A(x) @ u - self.b(x)
 
 
 class _SummedGP(GaussianProcess):
@@ -306,28 +399,36 @@ class ControlCBFLearned(Controller):
 
     def __init__(self, x_dim=2, u_dim=1, model=None, train_every_n_steps=10, dt=0.001, constraint_plotter_class=None,
                  plots_dir='data/runs/', ctrl_range=(-5., 5.), x_goal=None, x_quad_goal_cost=None, u_quad_cost=None,
-                 numSteps=1000, unsafe_controller_class=None, cbfs=(), ground_truth_cbfs=(), exp_tags=(),
-                 exploration_controller_class=None, clf_class=None, egreedy_scheme=(1, 0.1),
+                 numSteps=1000, unsafe_controller_class=GreedyController, cbfs=(), ground_truth_cbfs=(), exp_tags=(),
+                 exploration_controller_class=EpsilonGreedyController, clf_class=None, egreedy_scheme=(1, 0.1),
                  summary_writer=None, x0=None, ctrl_reg=1., clf_relax_weight=100., enable_learning=False,
                  mean_dynamics_model_class=None, max_train=None, controller_class=QPController, planner_class=None,
                  training_iter=100):
+        """Defaults as upstream, except: the nominal controller defaults to `GreedyController` (upstream: `LQRController`,
+        which needs the external `lqr` package), goal and costs default to the origin / identity when not given (upstream:
+        `torch.tensor(None)` raises), `model=None` builds a `ControlAffineRegressorExact`, `mean_dynamics_model_class=None` a
+        zero prior mean, and `exploration_controller_class=None` means "no exploration wrapper"."""
         self.x_dim, self.u_dim, self.model, self.dt, self.numSteps = x_dim, u_dim, model, dt, numSteps
         self.ctrl_reg, self.clf_relax_weight, self.summary_writer = ctrl_reg, clf_relax_weight, summary_writer
+        if model is None:                         # upstream passes None on to the model sum, which fails at the first query
+            from .control_affine_model import ControlAffineRegressorExact
+            model = self.model = ControlAffineRegressorExact(x_dim, u_dim)
+        if mean_dynamics_model_class is None:     # upstream: None() raises; a zero prior mean is the neutral choice
+            from .unicycle_move_to_pose import ZeroDynamicsModel
+            mean_dynamics_model_class = lambda: ZeroDynamicsModel(m=u_dim, n=x_dim)
         dev = getattr(model, "device", "cpu")
         self.ctrl_range = torch.tensor(ctrl_range)
-        self.x_goal = torch.tensor(x_goal, device=dev)
-        self.x_quad_goal_cost = torch.tensor(x_quad_goal_cost, device=dev)
-        self.u_quad_cost = torch.tensor(u_quad_cost, device=dev)
+        self.x_goal = torch.as_tensor([0.0] * x_dim if x_goal is None else x_goal, device=dev)
+        self.x_quad_goal_cost = torch.as_tensor(np.eye(x_dim) if x_quad_goal_cost is None else x_quad_goal_cost,
+                                                device=dev).to(self.x_goal.dtype)
+        self.u_quad_cost = torch.as_tensor(np.eye(u_dim) if u_quad_cost is None else u_quad_cost,
+                                           device=dev).to(self.x_goal.dtype)
         self.net_model = MeanAdjustedModel(x_dim, u_dim, mean_dynamics_model_class, model, max_train=max_train,
                                            train_every_n_steps=train_every_n_steps, enable_learning=enable_learning,
                                            dt=dt, training_iter=training_iter)
-        if unsafe_controller_class is None:
-            raise TypeError("ControlCBFLearned: pass unsafe_controller_class (the nominal controller whose output the "
-                            "safety filter corrects); the reference's Greedy / ILQR nominal controllers are not part of "
-                            "this library")
         self.unsafe_controller = unsafe_controller_class(self.net_model, self.x_quad_goal_cost, self.u_quad_cost,
                                                          self.x_goal, numSteps, dt, self.ctrl_range)
-        if exploration_controller_class is not None:      # e.g. an epsilon-greedy wrapper (controllers.py:269-285)
+        if exploration_controller_class is not None:      # the epsilon-greedy wrapper (controllers.py:269-285)
             self.unsafe_controller = exploration_controller_class(self.unsafe_controller, u_dim, numSteps,
                                                                   egreedy_scheme, self.ctrl_range)
         self.cbfs, self.ground_truth_cbfs = list(cbfs), list(ground_truth_cbfs)

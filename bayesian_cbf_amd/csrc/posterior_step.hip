@@ -38,6 +38,21 @@
 #ifndef BCBF_PS_UNR
 #define BCBF_PS_UNR 4      // columns per software-pipeline stage of the streaming loop
 #endif
+// jets instantiations (NJ > 0: the rel-degree-2 path, up to 12 right-hand-side columns): columns per pipeline stage and
+// occupancy target per element type.  Their Gram / mean sums live in ONE matrix-core accumulator (see step 2b) instead
+// of 126 VALU accumulators per lane, which is what lets two waves share a SIMD with 4 columns per stage in flight.
+#ifndef BCBF_PJ_UNR32
+#define BCBF_PJ_UNR32 4
+#endif
+#ifndef BCBF_PJ_UNR64
+#define BCBF_PJ_UNR64 2
+#endif
+#ifndef BCBF_PJ_WAVES32
+#define BCBF_PJ_WAVES32 2
+#endif
+#ifndef BCBF_PJ_WAVES64
+#define BCBF_PJ_WAVES64 1
+#endif
 
 namespace bcbf {
 
@@ -75,6 +90,21 @@ template <> struct BufLoad<double> {
     }
 };
 
+// One 16x16 matrix-core accumulator: acc += a(16x4) b(4x16); lane l supplies a[l % 16][l / 16] and b[l / 16][l % 16]
+// and holds acc[row(l / 16, r)][l % 16], r = 0..3, with row(g, r) = 4 g + r in fp32 and g + 4 r in fp64
+// (tools/probe/mfma64_layout.hip).  Exact IEEE arithmetic in both precisions.
+template <typename T> struct Mfma16;
+template <> struct Mfma16<float> {
+    using acc_t = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+    static __device__ inline acc_t mac(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ inline int row(int g, int r) { return 4 * g + r; }
+};
+template <> struct Mfma16<double> {
+    using acc_t = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    static __device__ inline acc_t mac(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ inline int row(int g, int r) { return g + 4 * r; }
+};
+
 // NJ = 0: values only (the control-step kernel).  NJ = n > 0: also the first x-derivative jets --
 // right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] (CT = C (1+n) columns of the same stream); outputs the full
 // Gram Wj'Wj [CT,CT] and Vw'Wj [n,CT], from which the rel-degree-2 terms are formed.
@@ -86,7 +116,8 @@ template <> struct BufLoad<double> {
 // the whitened targets Vw = L^-1 (Xdot - UH M0) of bcbf_potrs, control_affine_model.py:525-545), written to Wout as
 // [N, n]; no Gram / mean.  C = number of solved columns (>= n; extra columns are zero).
 template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false>
-__global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256), (NJ > 0 ? 1 : BCBF_PS_WAVES))
+__global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256),
+                                   (NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
@@ -108,8 +139,13 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         const int qi = a / CQ, a_ = a - qi * CQ, c_ = c - qi * CQ;
         return qi * (CQ * (CQ + 1) / 2) + a_ * CQ - a_ * (a_ - 1) / 2 + (c_ - a_);
     };
+    // jets: a w_J row is widened to 16 entries [w (CT), Vw row (n), zeros]: the 32 x 16 tile is both operands of the
+    // matrix-core product of step 2b
+    constexpr bool MG = NJ > 0;                                // Gram / mean sums on the matrix cores
+    constexpr int CW = MG ? 16 : CP;
+    static_assert(!MG || CT + NS <= 16 || CT + NJ <= 16, "jets: [W, Vw] must fit the 16 rows of one MFMA tile");
     __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
-    __shared__ __attribute__((aligned(16))) T wbuf[NB][CP];
+    __shared__ __attribute__((aligned(16))) T wbuf[NB][CW];
 
     const int b = blockIdx.x;
     const int gb = shared ? 0 : b;      // regime S: every query reads the one shared GP (instance 0)
@@ -227,21 +263,26 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     }
 
     // Gram W'W: per-lane partial sums in T (32 rows x nblk terms each), reduced and subtracted in fp64
-    T gram[NG];
+    T gram[MG ? 1 : NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) gram[g] = T(0);
-    T mk[NS][CT];
+    for (int g = 0; g < (MG ? 1 : NG); ++g) gram[g] = T(0);
+    T mk[MG ? 1 : NS][MG ? 1 : CT];
 #pragma unroll
-    for (int d = 0; d < NS; ++d)
+    for (int d = 0; d < (MG ? 1 : NS); ++d)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) mk[d][c] = T(0);
+        for (int c = 0; c < (MG ? 1 : CT); ++c) mk[d][c] = T(0);
+    typename Mfma16<T>::acc_t gacc = {T(0), T(0), T(0), T(0)};      // jets: [W, Vw]' [W, Vw] summed over all rows
+    if constexpr (MG) {                                             // columns CT + n .. 15 of the tile stay zero
+        for (int i = tid; i < NB * CW; i += blockDim.x) wbuf[i / CW][i % CW] = T(0);
+    }
 
     const int nblk = Np / NB;
     // Streaming pipeline state.  Column groups of UNR columns form ONE stream over all blocks: the
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
-    constexpr int UNR = (NJ > 0 || NQ > 1) ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR), NGRP = NB / UNR, HALF = NB / 2;
+    constexpr int UNR = NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_UNR64 : BCBF_PJ_UNR32)
+                               : (NQ > 1 ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
@@ -380,7 +421,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         }
                 }
                 int g = 0;
-                if constexpr (!RHS) {
+                if constexpr (!RHS && !MG) {
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
@@ -389,7 +430,17 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         for (int c = a; c < CQ; ++c) gram[g++] += w[qi * CQ + a] * w[qi * CQ + c];
                 }
                 (void)g;
-                if constexpr (RHS) { /* no mean accumulation */ } else {
+                if constexpr (MG) {
+#if BCBF_PS_VWPF
+                    // the Vw rows of this block (fetched a block ahead; zeros beyond row N / state dimension n) complete
+                    // the tile: columns CT .. CT + n - 1
+#pragma unroll
+                    for (int d = 0; d < NS; ++d)
+                        if (CT + d < CW) wbuf[di][CT + d] = vwn[d];
+#else
+                    static_assert(!MG, "jets need the prefetched Vw rows (BCBF_PS_VWPF)");
+#endif
+                } else if constexpr (RHS) { /* no mean accumulation */ } else {
 #if BCBF_PS_VWPF
 #pragma unroll
                 for (int d = 0; d < NS; ++d) {            // Vw rows of this block were fetched a block ahead (zeros
@@ -408,6 +459,18 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         }
                 }
 #endif
+                }
+            }
+            if constexpr (MG) {
+                // 2b. Gram and mean sums of the block on the matrix cores: with T_J = [w_J, Vw_J, 0] (32 x 16, in wbuf),
+                // gacc += T_J' T_J -- rows / columns < CT: the Gram Wj'Wj, rows CT .. CT+n-1: Vw'Wj.  A and B operand of
+                // a k-step are the SAME register (a[i][k] = T_J[k][i] = b[k][i]); 8 k-steps of 4 rows; the reads are
+                // 64 consecutive words each.  One accumulator (4 registers) replaces CT (CT+1) / 2 + n CT VALU sums.
+                const int kq = tid >> 4, ci = tid & 15;
+#pragma unroll
+                for (int s8 = 0; s8 < NB / 4; ++s8) {
+                    const T a = wbuf[4 * s8 + kq][ci];
+                    gacc = Mfma16<T>::mac(a, a, gacc);
                 }
             }
         }
@@ -431,6 +494,34 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 
     // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
     if constexpr (RHS) return;
+    if constexpr (MG) {
+        // jets: every lane of wave 0 writes its four entries (i = row(l / 16, r), j = l % 16) of [W, Vw]'[W, Vw]
+        if (tid < 64) {
+            const int j = tid & 15, grp = tid >> 4;
+            T* Gb = Gfull + (size_t)b * CT * CT;
+            T* Mb = Mfull + (size_t)b * n * CT;
+            const T* M0b = M0 + (size_t)gb * C * n;
+            const T* Bmb = Bm + (size_t)gb * C * C;
+            T* Mkb = Mk + (size_t)b * n * C;
+            T* Bkb = Bk + (size_t)b * C * C;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = Mfma16<T>::row(grp, r);
+                const T val = gacc[r];
+                if (j < CT) {
+                    if (i < CT) {
+                        Gb[i * CT + j] = val;
+                        if (i < C && j < C) Bkb[i * C + j] = (T)((double)s2 * (double)Bmb[i * C + j] - (double)val);
+                    } else if (i < CT + n) {
+                        const int d = i - CT;
+                        Mb[d * CT + j] = val;
+                        if (j < C) Mkb[d * C + j] = M0b[j * n + d] + val;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (tid < 64) {
         double gsum[NG];
 #pragma unroll

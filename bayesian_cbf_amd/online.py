@@ -13,7 +13,8 @@ What this class adds on the same schedule (both off by default = the reference's
   `append_data` (`bcbf_gp_append`: bordered Cholesky, O(N^2) per observation).  With unchanged hyper-parameters
   that IS the refactorisation on the same points (tests compare it with the oracle's from-scratch refit).
 * ``online_update = True``: every observation enters as soon as its finite-difference target exists (the call after
-  it was visited), so the model the controller queries is never stale.
+  it was visited), so the model the controller queries is never stale -- until the buffer outgrows `max_train`: from
+  then on the regressor holds a random subsample, which is only re-drawn at the scheduled points.
 
 When the training set would exceed `max_train` the window is re-drawn as the reference draws it (random subsample of
 the whole buffer, `subsample`) and factored from scratch -- a bordered factor cannot drop rows.
@@ -80,8 +81,11 @@ class OnlineLearner:
             self.n_scheduled += 1
             if hyper or not self._append_new():
                 self._refit_from_scratch(self.training_iter if hyper else 0)
-        elif self.online_update and self.enable_learning and self.has_been_trained_once:
+        elif self.online_update and self.enable_learning and self.has_been_trained_once and self.n_in_model is not None:
+            # (n_in_model None: the regressor holds a random subsample of a buffer beyond max_train -- new points then wait
+            #  for the next SCHEDULED re-draw; re-drawing and refactorising at every control step would be a full O(N^3)
+            #  refit per step on a window that changes at random)
             if not self._append_new():
-                self._refit_from_scratch(0)
+                self._refit_from_scratch(0)        # the window overflowed just now: one re-draw
         self.Xtrain.append(xi.detach())
         self.Utrain.append(uopt.detach())

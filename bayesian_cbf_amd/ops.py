@@ -581,6 +581,9 @@ class ConcurrentControlLoop:
     step(events=None): events = [(ev_start, ev_stop)] per part brackets that part's posterior kernel on its stream.
     Results: `y`, `status`, `iters` ([Bt,...] buffers); call `synchronize()` before reading them on another stream."""
 
+    GP_INSTANCE_KEYS = ("Lop", "Vw", "X", "UHB", "ell", "s2", "Bm", "M0")       # + "A" when it carries the batch axis
+    TASK_INSTANCE_KEYS = ("x", "x0", "xg", "plan", "dot_plan", "centers", "radii", "w", "r", "rho")
+
     def __init__(self, gp, task, x, parts=2, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100):
         Bt = x.shape[0]
         if Bt % parts:
@@ -594,11 +597,21 @@ class ConcurrentControlLoop:
         self._steps = []
         shared_model = gp.get("Lop") is not None and gp["X"].shape[0] == 1 and Bt > 1
         cur = torch.cuda.current_stream(dev)
+        A = gp["A"]                                  # [Bt,n,n], or [1,n,n] = one kernel matrix for every instance
+        a_key = ("A",) if (A.dim() == 3 and A.shape[0] == Bt and Bt > 1) else ()
+        gp_keys = a_key if shared_model else self.GP_INSTANCE_KEYS + a_key
         for c in range(parts):
             sl = slice(c * Bc, (c + 1) * Bc)
-            cut = lambda v, lead: v[sl] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == lead) else v
-            gpc = {k: (v if (shared_model and k != "A") else cut(v, Bt)) for k, v in gp.items()}
-            taskc = {k: cut(v, Bt) for k, v in task.items()}
+            # per-instance tensors are named, not inferred from their shape (with a small batch a global task tensor --
+            # Kp[3], sign[3], tw[Kob], gammas[Kob], relax_mask[3] -- can have a leading dimension equal to Bt)
+            def cut(k, v, keys):
+                if not (torch.is_tensor(v) and k in keys):
+                    return v
+                if v.dim() == 0 or v.shape[0] != Bt:
+                    raise ValueError("%s: expected a per-instance tensor with leading dimension %d, got %s" % (k, Bt, tuple(v.shape)))
+                return v[sl]
+            gpc = {k: cut(k, v, gp_keys) for k, v in gp.items()}
+            taskc = {k: cut(k, v, self.TASK_INSTANCE_KEYS) for k, v in task.items()}
             wsc = {k: v[sl] for k, v in self.ws.items()}
             self._steps.append(unicycle_control_step_prepare(
                 gpc, taskc, wsc, x[sl], dt=dt, L_true=L_true, L_mean=L_mean, clf_gamma=clf_gamma, max_iters=max_iters,

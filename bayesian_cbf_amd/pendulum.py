@@ -38,6 +38,19 @@ class PendulumDynamicsModel:
     def F_func(self, X):
         return torch.cat([self.f_func(X).unsqueeze(-1), self.g_func(X)], dim=-1)
 
+    # the plant protocol of sampling.DynamicsModel (sampling.py:32-47); the reference's pendulum loop
+    # (`sampling_pendulum`, :164-233) inlines the same Euler update and theta wrap
+    def set_init_state(self, x0):
+        self.current_state = x0.clone()
+
+    def step(self, u, dt):
+        x = self.current_state
+        xdot = self.f_func(x) + (self.g_func(x) @ u.to(x).unsqueeze(-1)).squeeze(-1)
+        xn = x + xdot * dt
+        xn[..., 0] = ((xn[..., 0] + math.pi) % (2 * math.pi)) - math.pi
+        self.current_state = xn
+        return dict(xdot=xdot, x=xn)
+
 
 class RadialCBFRelDegree2(RelDeg2Safety):
     """h(x) = cos(delta_col) - cos(theta - theta_c)  (:675-696): keep the pendulum out of a cone around theta_c."""
@@ -96,20 +109,29 @@ class ControlRandom:
         return self.control_trivial.control(xi, t=t) * (torch.rand(1) * 0.8 + 0.60).to(xi)
 
 
-def sampling_pendulum_data(dynamics_model, D=100, dt=0.01, x0=None, controller=None, **_ignored):
-    """One explicit-Euler trajectory of D+1 states (theta wrapped to [-pi, pi)); returns (dX[D,2], X[D+1,2], U[D+1,1]) with
-    dX the finite differences, as pendulum.py:164-252 (host loop: one short trajectory, not a hot path)."""
-    assert controller is not None
-    x = torch.as_tensor(x0, dtype=torch.float64).clone()
-    X = torch.empty(D + 1, 2, dtype=torch.float64)
-    U = torch.empty(D + 1, 1, dtype=torch.float64)
-    for t in range(D + 1):
-        X[t] = x
-        u = controller(x, t=t).to(torch.float64)
-        U[t] = u
-        xdot = dynamics_model.f_func(x[None])[0] + dynamics_model.g_func(x) @ u
-        x = x + xdot * dt
-        x[0] = ((x[0] + math.pi) % (2 * math.pi)) - math.pi
+def sampling_pendulum(dynamics_model, numSteps, controller=None, x0=None, dt=0.01, plot_every_n_steps=20, axs=None,
+                      visualizer=None, visualizer_class=None, plotfile=None):
+    """pendulum.py:164-233: numSteps controller calls along one explicit-Euler trajectory (theta wrapped to [-pi, pi) by
+    the plant's `step`), through the rollout harness of `sampling.sample_generator_trajectory`.  Returns
+    (damage %, time[numSteps], theta[numSteps], omega[numSteps], u[numSteps]); damage = share of steps with
+    0 < theta < pi/4.  Plotting visualizers are out of scope: the default shows nothing."""
+    from .sampling import sample_generator_trajectory, VisualizerZ
+    assert controller is not None, "Surprise !! Changed interface to make controller a required argument"
+    if visualizer is None:
+        visualizer = visualizer_class(plotfile=plotfile, plot_every_n_steps=plot_every_n_steps) if visualizer_class else VisualizerZ()
+    x0 = torch.as_tensor(x0, dtype=torch.float64)
+    _, X, U = sample_generator_trajectory(dynamics_model, numSteps, dt=dt, x0=x0, controller=controller, visualizer=visualizer)
+    theta_vec, omega_vec, u_vec = X[:numSteps, 0], X[:numSteps, 1], U[:, 0]
+    assert torch.all((theta_vec <= math.pi) & (-math.pi <= theta_vec))
+    damage = ((0 < theta_vec) & (theta_vec < math.pi / 4)).double().sum() * 100 / numSteps
+    return damage, dt * torch.arange(numSteps, dtype=torch.float64), theta_vec, omega_vec, u_vec
+
+
+def sampling_pendulum_data(dynamics_model, D=100, dt=0.01, **kwargs):
+    """(dX[D,2], X[D+1,2], U[D+1,1]) with dX the finite differences of the (wrapped) states, pendulum.py:236-252."""
+    _, _, theta_vec, omega_vec, u_vec = sampling_pendulum(dynamics_model, numSteps=D + 1, dt=dt, **kwargs)
+    X = torch.stack((theta_vec, omega_vec), dim=1)
+    U = u_vec.reshape(-1, 1)
     dX = (X[1:] - X[:-1]) / dt
     return dX, X, U
 
@@ -198,4 +220,95 @@ def learn_dynamics_matrix_vector_exp(exps=None, theta0=5 * math.pi / 6, omega0=-
         dgp, logged = learn_dynamics_from_data(dX, X, U, pend_env, kw["regressor_class"], logger, max_train=max_train,
                                                tags=[name], training_iter=training_iter, device=device, dtype=dtype)
         out[name] = (dgp, logged, learned_model_error(logged))
+    return out
+
+
+def compute_errors(regressor_class, sampling_callable, pend_env, ntries=5, max_train=200, test_on_grid=False, ntest=400,
+                   device="cuda", dtype=torch.float32):
+    """pendulum.py:1248-1303: `ntries` variance-weighted errors (`measure_batch_error`) of `regressor_class` on fresh
+    trajectories.  As upstream, the regressor of a sample is constructed and queried WITHOUT being fitted (there is no
+    fit call between `regressor_class(...)` and `custom_predict_fullmat`, :1279-1283): the figure is the error of the
+    prior model."""
+    import numpy as np
+    errors = []
+    for _ in range(ntries):
+        dX, X, U = sampling_callable()
+        order = np.arange(X.shape[0] - 1)
+        np.random.shuffle(order)
+        order_t = torch.from_numpy(order)
+        Xtrain = X[order_t[:max_train]]
+        if test_on_grid:
+            grid = get_grid_from_Xtrain(Xtrain.cpu().numpy())
+            Xtest = torch.from_numpy(grid.reshape(-1, Xtrain.shape[-1]))
+        else:
+            Xtest = X[order_t[-ntest:]]
+        Xtest = Xtest.to(device=device, dtype=dtype)
+        FX_true = pend_env.F_func(Xtest).transpose(-2, -1)                       # (b, 1+m, n)
+        dgp = regressor_class(Xtrain.shape[-1], U.shape[-1], device=device, dtype=dtype)
+        FX_learned, var_FX = dgp.custom_predict_fullmat(Xtest.reshape(-1, Xtest.shape[-1]))
+        b, T_ = Xtest.shape[0], (1 + pend_env.ctrl_size) * pend_env.state_size
+        idx = torch.arange(b, device=var_FX.device)
+        blocks = var_FX.reshape(b, T_, b, T_)[idx, :, idx, :]
+        errors.append(measure_batch_error(FX_learned.reshape(-1, T_), blocks, FX_true.reshape(-1, T_).to(FX_learned)))
+    return errors
+
+
+def speed_test_matrix_vector_exp(max_train_variations=(256, 256 + 64, 256 + 128, 256 + 256), ntimes=50, repeat=5,
+                                 errorbartries=30, logger=None, exps=None, theta0=5 * math.pi / 6, omega0=-0.01, tau=0.01,
+                                 mass=1, gravity=10, length=1, numSteps=2000, pendulum_dynamics_class=PendulumDynamicsModel,
+                                 training_iter=50, device="cuda", dtype=torch.float32):
+    """The reference's published speed test (pendulum.py:1305-1394, the only path of the repository with published
+    numbers): one randomised pendulum trajectory; per training-set size a random subset, and per regressor
+    (MVGP full / diag, CoGP full / diag) `fit(training_iter=50)`, then
+    min(timeit.repeat('dgp.custom_predict_fullmat(Xtest); dgp.clear_cache()', repeat, number=ntimes)) on the 20 x 20
+    (theta, omega) grid of the training range, and `errorbartries` prior-model errors (`compute_errors`).  Every timed call
+    ends with a device synchronize (the reference's timing is host side).  Logged under the reference's tags when a
+    logger is given (`<name>/elapsed` is seconds PER CALL, as upstream logs it); returns
+    {name: {max_train: dict(elapsed=s per call, errors=[...], fit_s=...)}}."""
+    import time
+    import timeit
+    from functools import partial
+    import numpy as np
+    from .control_affine_model import (ControlAffineRegressorExact, ControlAffineRegMatrixDiag,
+                                       ControlAffineRegressorVector, ControlAffineRegVectorDiag)
+    exps = exps or dict(matrix=dict(regressor_class=ControlAffineRegressorExact),
+                        vector=dict(regressor_class=ControlAffineRegressorVector),
+                        matrixdiag=dict(regressor_class=ControlAffineRegMatrixDiag),
+                        vectordiag=dict(regressor_class=ControlAffineRegVectorDiag))
+    pend_env = pendulum_dynamics_class(m=1, n=2, mass=mass, gravity=gravity, length=length)
+    sample = partial(sampling_pendulum_data, dynamics_model=pend_env, D=numSteps, x0=torch.tensor([theta0, omega0]), dt=tau,
+                     controller=ControlRandom(mass=mass, gravity=gravity, length=length).control)
+    dX, X, U = sample()
+    if logger is not None:
+        for t, (dx, x, u) in enumerate(zip(dX, X, U)):
+            logger.add_tensors("traj", dict(dx=dx, x=x, u=u), t)
+    order = np.arange(X.shape[0] - 1)
+    f = dict(device=device, dtype=dtype)
+    out = {name: {} for name in exps}
+    for max_train in max_train_variations:
+        np.random.shuffle(order)
+        idx = torch.from_numpy(order[:max_train].copy())
+        Xtrain, Utrain, XdotTrain = X[idx].to(**f), U[idx].to(**f), dX[idx].to(**f)
+        grid = get_grid_from_Xtrain(X[idx].numpy())
+        Xtest = torch.from_numpy(grid.reshape(-1, 2)).to(**f)           # raw reshape of the [2, 20, 20] mgrid, as upstream (:1351-1355)
+        for name, kw in exps.items():
+            dgp = kw["regressor_class"](2, 1, device=device, dtype=dtype)
+            t0 = time.perf_counter()
+            dgp.fit(Xtrain, Utrain, XdotTrain, training_iter=training_iter)
+            torch.cuda.synchronize()
+            fit_s = time.perf_counter() - t0
+
+            def call():
+                dgp.custom_predict_fullmat(Xtest)
+                dgp.clear_cache()
+                torch.cuda.synchronize()
+            call()
+            elapsed = min(timeit.repeat(call, repeat=repeat, number=ntimes)) / ntimes
+            errors = compute_errors(kw["regressor_class"], sample, pend_env, max_train=max_train, ntries=errorbartries,
+                                    device=device, dtype=dtype)
+            out[name][max_train] = dict(elapsed=elapsed, errors=errors, fit_s=fit_s,
+                                        fit_loss_first_last=[dgp.fit_losses[0], dgp.fit_losses[-1]] if training_iter else None)
+            if logger is not None:
+                logger.add_scalars(name, dict(elapsed=elapsed), max_train)
+                logger.add_tensors(name, dict(errors=np.asarray(errors)), max_train)
     return out

@@ -49,14 +49,19 @@ class AckermannDrive:
         return _fixed_kernel_gp(self, u, "AckermannDrive")
 
     def step(self, u, dt):
-        """Explicit Euler (:277-282); device batches go through the HIP kernel."""
-        x = self.current_state
-        if x.is_cuda and x.dim() == 2:
-            ops.unicycle_step(x, u.contiguous(), float(dt), float(self.L))
-            return dict(x=x, xdot=None)
-        xdot = self.f_func(x) + (self.g_func(x) @ u.unsqueeze(-1)).squeeze(-1)
-        self.current_state = x + xdot * dt
-        return dict(xdot=xdot, x=self.current_state)
+        """Explicit Euler (:277-282): returns dict(xdot, x).  A device batch of states [Bt, 3] advances in ONE launch of
+        the HIP plant kernel (`bcbf_unicycle_step`, in place on `current_state`)."""
+        return _euler_step(self, u, dt, float(self.L))
+
+
+def _euler_step(model, u, dt, L):
+    x = model.current_state
+    xdot = model.f_func(x) + (model.g_func(x) @ u.unsqueeze(-1)).squeeze(-1)
+    if x.is_cuda and x.dim() == 2:
+        ops.unicycle_step(x, u.to(x).contiguous(), float(dt), L)
+    else:
+        model.current_state = x + xdot * dt
+    return dict(xdot=xdot, x=model.current_state)
 
 
 def _fixed_kernel_gp(model, u, name):
@@ -75,6 +80,34 @@ def _fixed_kernel_gp(model, u, name):
     return GaussianProcess(mean=mean, knl=knl, shape=(model.state_size,), name=name, source=(model, "fu", u))
 
 
+class PolarDynamics:
+    """The unicycle in polar coordinates relative to the goal, x = (rho, alpha, beta), u = (v, omega)
+    (unicycle_move_to_pose.py:143-167): f = 0, g = [[-cos a, 0], [-sin a / rho, 1], [-sin a / rho, 0]]."""
+    state_size, ctrl_size = 3, 2
+
+    def __init__(self):
+        self.current_state = None
+
+    def set_init_state(self, x0):
+        self.current_state = x0
+
+    def f_func(self, x):
+        return torch.zeros_like(x)
+
+    def g_func(self, x):
+        rho, alpha = x[..., 0], x[..., 1]
+        assert bool((rho > 1e-6).all())
+        z, o = torch.zeros_like(rho), torch.ones_like(rho)
+        s = -torch.sin(alpha) / rho
+        return torch.stack([torch.stack([-torch.cos(alpha), z], -1), torch.stack([s, o], -1), torch.stack([s, z], -1)], -2)
+
+    def step(self, u_torch, dt):
+        x = self.current_state
+        xdot = self.f_func(x) + (self.g_func(x) @ u_torch.unsqueeze(-1)).squeeze(-1)
+        self.current_state = x + xdot * dt
+        return dict(xdot=xdot, x=self.current_state)
+
+
 class CartesianDynamics:
     """Unit-wheelbase unicycle with the kernel (u'u + 1) I (:168-197)."""
     state_size, ctrl_size = 3, 2
@@ -83,7 +116,7 @@ class CartesianDynamics:
         self.current_state = None
 
     def set_init_state(self, x0):
-        self.current_state = x0
+        self.current_state = x0.clone()
 
     def f_func(self, x):
         return torch.zeros_like(x)
@@ -96,10 +129,7 @@ class CartesianDynamics:
         return gX.squeeze(0) if state_in.dim() <= 1 else gX
 
     def step(self, u_torch, dt):
-        x = self.current_state
-        xdot = self.f_func(x) + self.g_func(x) @ u_torch
-        self.current_state = x + xdot * dt
-        return dict(xdot=xdot, x=self.current_state)
+        return _euler_step(self, u_torch, dt, 1.0)
 
     def fixed_kernel(self):
         return torch.eye(self.state_size, dtype=torch.float64), torch.eye(self.ctrl_size + 1, dtype=torch.float64)
@@ -561,11 +591,9 @@ def unicycle_speed_test_matrix_vector_exp(max_train_variations=(64, 64 + 16, 64 
     def trajectory():
         ctrl = ControllerCLF(NoPlanner(goal), coordinate_converter=lambda x, x_g: x, dynamics=CartesianDynamics(),
                              clf=CLFCartesian(), device=device, dtype=dtype)
-        _, X, U = sample_generator_trajectory(true_model, numSteps, dt=dt, x0=torch.tensor([state_start], **f),
-                                              controller=ctrl.control)
-        X, U = X[:, 0], U[:, 0]
-        Xdot = true_model.f_func(X[:-1]) + (true_model.g_func(X[:-1]) @ U.unsqueeze(-1)).squeeze(-1)
-        return Xdot, X, U
+        Xdot, X, U = sample_generator_trajectory(true_model, numSteps, dt=dt, x0=torch.tensor([state_start], **f),
+                                                 controller=ctrl.control)
+        return Xdot[:, 0], X[:, 0], U[:, 0]
 
     def true_F(Xt):                                               # [b, 1+m, n]
         return torch.cat([true_model.f_func(Xt).unsqueeze(-1), true_model.g_func(Xt)], dim=-1).transpose(-2, -1)

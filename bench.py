@@ -30,7 +30,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-PREWARM_MIN = 60               # untimed steps before the timed region (>= --warmup): 5 left a 20-step run 5 % slow
+DEFAULT_STEPS, DEFAULT_WARMUP = 200, 60   # no flags: long enough that clocks / caches / the two streams' pipeline are in
+                                          # their steady state (with 5 untimed steps a 20-step run measures ~5 % slower);
+                                          # EXACTLY --warmup untimed steps run before the timed region, never more
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (MI355X_MICROARCH.md)
 F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64, dense (MI355X_MICROARCH.md)
 ACHIEVED_METHOD = ("algorithmic units of ALL launches of the kernel in the timed region / time during which at least one of "
@@ -41,8 +43,8 @@ ACHIEVED_METHOD = ("algorithmic units of ALL launches of the kernel in the timed
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=DEFAULT_STEPS)
+    ap.add_argument("--warmup", type=int, default=DEFAULT_WARMUP)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--ntrain", type=int, default=512)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
@@ -247,19 +249,13 @@ def main():
         status_t, iters_t = ws["status"], ws["iters"]
     torch.cuda.synchronize()
 
-    # untimed: the W warm-up steps asked for, preceded by enough further steps to reach the steady state the timed region
-    # is meant to measure (clocks, caches, the two streams' pipeline): at least PREWARM_MIN untimed steps in all
-    prewarm = max(0, PREWARM_MIN - args.warmup)
-    for _ in range(prewarm + args.warmup):
-        step()
-    torch.cuda.synchronize()
-
     def barrier():
         if multi:
             import torch.distributed as dist
             dist.barrier()
 
-    # ---- timed region: exactly `steps` steps, HIP events around every launch of the dominant kernel (on its stream)
+    # HIP events around every launch of the dominant kernel (on its stream), created and instantiated BEFORE the warm-up
+    # so that nothing but the barrier sits between the last untimed step and the first timed one
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
           for _ in range(args.steps)]
     for row in ev:                      # instantiate the hipEvent handles (torch creates them on first record)
@@ -267,6 +263,11 @@ def main():
             e0.record(ev_stream[c])
             e1.record(ev_stream[c])
     ev_base = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    # ---- untimed: exactly the W warm-up steps asked for
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly `steps` steps, bracketed by barrier + synchronize on both sides
     barrier()
     torch.cuda.synchronize()
     ev_base.record(ev_stream[0])
@@ -292,6 +293,12 @@ def main():
     busy_ms += cur_b - cur_a
     n_launch = len(spans)
     status, iters = status_t, iters_t
+    # where inside the timed region the time went (device time stamps of the step ends): a short run that starts from few
+    # untimed steps still contains the ramp of the clocks -- reported, never removed from `value`
+    ends = [max(ev_base.elapsed_time(b_) for _, b_ in row) for row in ev]
+    per = np.diff(np.array([0.0] + ends))
+    k5 = max(1, min(5, len(per) // 2))
+    region = {"first_steps_ms": float(np.mean(per[:k5])), "last_steps_ms": float(np.mean(per[-k5:])), "averaged_over": k5}
 
     n_opt = int((status == 0).sum())
     stats = torch.tensor([elapsed, float(n_opt), float(Bt), float(iters.float().mean())], dtype=torch.float64, device=dev)
@@ -334,7 +341,7 @@ def main():
         out = {
             "metric": "control steps/sec (GP posterior + CBF-QP) at N_train=%d, batch=%d; shared learned model" % (N, Bt),
             "value": value, "unit": "control steps/s (instance-steps: batch x batched steps/s)",
-            "batched_steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm,
+            "batched_steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "unicycle x in R^3, u in R^2: GP posterior + 3 chance constraints + SOCP per step, "
@@ -344,6 +351,7 @@ def main():
                        "parallelism": "closed loops sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
             "comm": comm,
+            "timed_region": region,
             "roofline": {"bound": "mfma", "kernel": shared_kernel,
                          "achieved": achieved,
                          "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
@@ -383,7 +391,6 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm_steps": prewarm,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -396,6 +403,7 @@ def main():
                        "regime": "independent GPs (I)", "inputs": args.variant, "schedule": schedule, "parallelism": "instances sharded, dp%d" % world},
             "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
             "comm": comm,
+            "timed_region": region,
             "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps, "launches_per_step": S,

@@ -533,8 +533,61 @@ def main_gp_algebra():
     gen_gp_algebra_handmade()
 
 
+
+def gen_facade():
+    """Small host-side surfaces of the path, recorded from the executed reference:
+    HetergeneousMatrixVariateMean.forward (matrix_variate_multitask_model.py:44-66) on observation rows, matrix rows, a
+    sorted mix and raw states without a mask column; sample_generator_trajectory (sampling.py:49-75) on the Ackermann
+    plant with a deterministic controller and with a controller_class; sampling_pendulum_data (pendulum.py:164-252)."""
+    import math
+    import bayes_cbf.sampling as rs
+    import bayes_cbf.pendulum as rp
+    out = {}
+    n, m = 3, 2
+    torch.manual_seed(77)
+    reg = cam.ControlAffineRegressor(n, m, device='cpu')
+    with torch.no_grad():
+        for bm in reg.model.mean_module.base_means:
+            bm.constant.copy_(0.5 * torch.randn(1))
+    out['mean_constants'] = np.array([float(bm.constant.detach()) for bm in reg.model.mean_module.base_means])
+    X5, U5 = torch.randn(5, n), torch.randn(5, m)
+    _, mxu1 = reg.model.encode_from_XU(X5, U5, 1)
+    _, mxu0 = reg.model.encode_from_XU(X5[:4])
+    mix = torch.cat([mxu1[:3], mxu0[:2]])
+    raw = torch.randn(4, n)
+    mm = reg.model.mean_module
+    out.update(mean_mxu1=t2n(mxu1), mean_out1=t2n(mm(mxu1)), mean_mxu0=t2n(mxu0), mean_out0=t2n(mm(mxu0)),
+               mean_mix=t2n(mix), mean_outmix=t2n(mm(mix)), mean_raw=t2n(raw), mean_outraw=t2n(mm(raw)))
+    # ---- rollout harness on the Ackermann plant
+    ctl = lambda x, t=0: torch.stack([1.0 + 0.1 * torch.sin(x[2] + 0.05 * t), 0.3 * torch.cos(x[0]) - 0.02 * t])
+    x0 = torch.tensor([-1.0, 0.4, 0.7])
+    Xdot, X, U = rs.sample_generator_trajectory(ump.AckermannDrive(L=1.3), 12, dt=0.02, x0=x0, controller=ctl)
+    out.update(traj_x0=t2n(x0), traj_Xdot=t2n(Xdot), traj_X=t2n(X), traj_U=t2n(U), traj_L=1.3, traj_dt=0.02)
+
+    class Ctl:
+        def __init__(self, dt=None, true_model=None):
+            self.gain = 2.0 * dt * true_model.L
+
+        def control(self, x, t=0):
+            return torch.stack([self.gain * (1 + x[0] * 0), 0.1 * x[1] + 0.01 * t])
+    plant = ump.AckermannDrive(L=0.7)
+    Xdot, X, U = rs.sample_generator_trajectory(plant, 6, dt=0.05, x0=[0.1, -0.2, 0.3], true_model=plant, controller_class=Ctl)
+    out.update(trajc_Xdot=t2n(Xdot), trajc_X=t2n(X), trajc_U=t2n(U))
+    # ---- pendulum trajectory (deterministic controller: the randomised one draws torch.rand per step)
+    env = rp.PendulumDynamicsModel(m=1, n=2, mass=1, gravity=10, length=1)
+    pctl = lambda x, t=0: (12.0 + 2.0 * torch.sin(x[0]) + 0.5 * math.cos(0.1 * t)).reshape(1)
+    dX, X, U = rp.sampling_pendulum_data(env, D=60, dt=0.05, x0=torch.tensor([5 * math.pi / 6, -0.01]), controller=pctl,
+                                         visualizer=rs.VisualizerZ())
+    assert float((X[1:, 0] - X[:-1, 0]).abs().max()) > 3.0             # the trajectory wraps around +-pi at least once
+    out.update(pend_dX=t2n(dX), pend_X=t2n(X), pend_U=t2n(U))
+    np.savez_compressed(os.path.join(HERE, 'facade_surfaces.npz'), **out)
+    print('facade_surfaces:', {k: v.shape for k, v in out.items() if hasattr(v, 'shape')})
+
+
 if __name__ == '__main__':
-    if 'gp_algebra' in sys.argv:
+    if 'facade' in sys.argv:
+        gen_facade()
+    elif 'gp_algebra' in sys.argv:
         main_gp_algebra()
     elif 'cogp' in sys.argv:
         main_cogp()

@@ -1,0 +1,164 @@
+"""Host-side surfaces of the path that need no GPU, against vectors recorded from the executed reference
+(tests/golden/facade_surfaces.npz, generator: tests/golden/gen_golden.py facade):
+`HetergeneousMatrixVariateMean.forward` (matrix_variate_multitask_model.py:44-66), `sample_generator_trajectory`
+(sampling.py:49-75) and the pendulum trajectory (`sampling_pendulum_data`, pendulum.py:164-252)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "facade_surfaces.npz"))
+T64 = dict(dtype=torch.float64)
+
+
+def t(a):
+    return torch.as_tensor(np.asarray(a), **T64)
+
+
+def test_matrix_variate_mean_forward_matches_reference_on_all_row_kinds():
+    from bayesian_cbf_amd.control_affine_model import CatEncoder
+    from bayesian_cbf_amd.matrix_variate_multitask_model import (ConstantMean, HetergeneousMatrixVariateMean,
+                                                                 SharedConstantMeans)
+    n, m = 3, 2
+    consts = t(G["mean_constants"])
+    shared = HetergeneousMatrixVariateMean(SharedConstantMeans(lambda: consts, (1 + m) * n), CatEncoder(1, n, 1 + m), (1 + m, n))
+    own = HetergeneousMatrixVariateMean(ConstantMean(dtype=torch.float64), CatEncoder(1, n, 1 + m), (1 + m, n))
+    with torch.no_grad():
+        for bm, c in zip(own.base_means, consts):
+            bm.constant.fill_(float(c))
+    for mod in (shared, own):
+        for inp, out in (("mean_mxu1", "mean_out1"), ("mean_mxu0", "mean_out0"), ("mean_mix", "mean_outmix"),
+                         ("mean_raw", "mean_outraw")):
+            np.testing.assert_allclose(mod(t(G[inp])).detach().numpy(), G[out], rtol=0, atol=1e-14, err_msg=inp)
+    # observation rows: uh' M0; matrix rows: vec(M0)
+    M0 = consts.reshape(1 + m, n)
+    mxu1 = t(G["mean_mxu1"])
+    np.testing.assert_allclose(shared(mxu1).reshape(-1, n).numpy(), (mxu1[:, 1 + n:] @ M0).numpy(), atol=1e-14)
+    assert shared.state_dict() == dict(matshape=(1 + m, n), decoder=dict(sizes=[1, n, 1 + m]))
+    # unsorted masks are refused, as upstream
+    bad = torch.cat([t(G["mean_mxu0"])[:1], mxu1[:2]])
+    with pytest.raises(AssertionError):
+        shared(torch.cat([mxu1[:1], bad]))
+    # the edge of the raw-state call: a first row with x[0] == 1.0 exactly is taken for an observation row
+    raw = t(G["mean_raw"]).clone()
+    raw[0, 0] = 1.0
+    with pytest.raises(AssertionError):
+        shared(raw)
+
+
+def test_regressor_mean_module_reads_the_device_paths_constants():
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    reg = ControlAffineRegressor(3, 2, device="cpu", dtype=torch.float64)
+    with torch.no_grad():
+        reg.model.mean_constants.copy_(t(G["mean_constants"]))
+    np.testing.assert_allclose(reg.mean_module(t(G["mean_mix"])).detach().numpy(), G["mean_outmix"], atol=1e-14)
+    _, mxu = reg.encode_from_XU(t(G["mean_raw"]))
+    assert mxu.shape == (4, 1 + 3 + 3) and float(mxu[:, 0].abs().max()) == 0 and float(mxu[:, 4:].abs().max()) == 0
+    reg.set_train_data(t(G["mean_mxu1"])[:, 1:4], t(G["mean_mxu1"])[:, 5:], t(G["mean_mxu1"])[:, 1:4])
+    np.testing.assert_array_equal(reg.train_inputs[0].numpy(), G["mean_mxu1"])
+
+
+def test_sample_generator_trajectory_reference_surface_single_trajectory():
+    from bayesian_cbf_amd.sampling import sample_generator_trajectory, Visualizer
+    from bayesian_cbf_amd.unicycle_move_to_pose import AckermannDrive
+    ctl = lambda x, t=0: torch.stack([1.0 + 0.1 * torch.sin(x[2] + 0.05 * t), 0.3 * torch.cos(x[0]) - 0.02 * t])
+    Xdot, X, U = sample_generator_trajectory(AckermannDrive(L=float(G["traj_L"])), 12, dt=float(G["traj_dt"]),
+                                             x0=t(G["traj_x0"]), controller=ctl)
+    for got, key in ((Xdot, "traj_Xdot"), (X, "traj_X"), (U, "traj_U")):
+        np.testing.assert_allclose(got.numpy(), G[key], rtol=0, atol=1e-6)      # the reference ran in its float32 default
+
+    class Ctl:
+        def __init__(self, dt=None, true_model=None):
+            self.gain = 2.0 * dt * true_model.L
+
+        def control(self, x, t=0):
+            return torch.stack([self.gain * (1 + x[0] * 0), 0.1 * x[1] + 0.01 * t])
+
+    seen = []
+
+    class Rec(Visualizer):
+        def setStateCtrl(self, x, u, t=0, **kw):
+            seen.append((t, x.clone(), u.clone(), sorted(kw)))
+
+    plant = AckermannDrive(L=0.7)
+    Xdot, X, U = sample_generator_trajectory(plant, 6, dt=0.05, x0=[0.1, -0.2, 0.3], true_model=plant, controller_class=Ctl,
+                                             visualizer=Rec())
+    for got, key in ((Xdot, "trajc_Xdot"), (X, "trajc_X"), (U, "trajc_U")):
+        np.testing.assert_allclose(got.numpy(), G[key], rtol=0, atol=1e-6)
+    assert [s[0] for s in seen] == list(range(6)) and all(torch.equal(s[1], X[s[0]]) and torch.equal(s[2], U[s[0]]) for s in seen)
+    assert seen[0][3] == []                          # a plain controller has no Bayesian model to visualise
+
+
+def test_sample_generator_trajectory_batch_rows_equal_single_trajectories_cpu():
+    from bayesian_cbf_amd.sampling import sample_generator_trajectory
+    from bayesian_cbf_amd.unicycle_move_to_pose import AckermannDrive, CartesianDynamics
+    x0 = torch.tensor([[-1.0, 0.4, 0.7], [0.3, -0.2, -1.1], [2.0, 1.0, 0.1]], **T64)
+    ctl = lambda x, t=0: torch.stack([1.0 + 0.1 * torch.sin(x[..., 2] + 0.05 * t), 0.3 * torch.cos(x[..., 0]) - 0.02 * t], -1)
+    for plant_cls in (lambda: AckermannDrive(L=1.3), CartesianDynamics):
+        Xd, X, U = sample_generator_trajectory(plant_cls(), 9, dt=0.02, x0=x0, controller=ctl)
+        assert Xd.shape == (9, 3, 3) and X.shape == (10, 3, 3) and U.shape == (9, 3, 2)
+        for i in range(3):
+            Xd1, X1, U1 = sample_generator_trajectory(plant_cls(), 9, dt=0.02, x0=x0[i], controller=ctl)
+            np.testing.assert_allclose(X[:, i].numpy(), X1.numpy(), atol=1e-14)
+            np.testing.assert_allclose(Xd[:, i].numpy(), Xd1.numpy(), atol=1e-14)
+            np.testing.assert_allclose(U[:, i].numpy(), U1.numpy(), atol=1e-14)
+
+
+def test_pendulum_trajectory_through_the_rollout_harness_matches_reference():
+    from bayesian_cbf_amd.pendulum import PendulumDynamicsModel, sampling_pendulum, sampling_pendulum_data
+    env = PendulumDynamicsModel(m=1, n=2, mass=1, gravity=10, length=1)
+    pctl = lambda x, t=0: (12.0 + 2.0 * torch.sin(x[0]) + 0.5 * math.cos(0.1 * t)).reshape(1)
+    x0 = torch.tensor([5 * math.pi / 6, -0.01])
+    dX, X, U = sampling_pendulum_data(env, D=60, dt=0.05, x0=x0, controller=pctl)
+    # (the reference integrates in float32: the wrap points coincide, values agree to float32 rounding accumulated over 60 steps)
+    assert np.array_equal(np.abs(np.diff(G["pend_X"][:, 0])) > 3, np.abs(np.diff(X[:, 0].numpy())) > 3)
+    np.testing.assert_allclose(X.numpy(), G["pend_X"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(U.numpy(), G["pend_U"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(dX.numpy(), G["pend_dX"], rtol=0, atol=2e-2)
+    dmg, tv, th, om, uv = sampling_pendulum(env, 61, controller=pctl, x0=x0, dt=0.05)
+    assert th.shape == (61,) and torch.equal(th, X[:, 0]) and 0 <= float(dmg) <= 100 and float(tv[-1]) == pytest.approx(3.0)
+
+
+def test_nominal_controllers_restored_and_control_cbf_learned_default_constructible():
+    """controllers.py:166-213, 269-285, 739-771: Zero / Greedy / EpsilonGreedy / NamedAffineFunc exist, and
+    ControlCBFLearned() builds with its default arguments (greedy nominal controller inside the epsilon-greedy explorer)."""
+    import random
+    from bayesian_cbf_amd.controllers import (ControlCBFLearned, EpsilonGreedyController, GreedyController, NamedAffineFunc,
+                                              ZeroController, epsilon)
+    from bayesian_cbf_amd.pendulum import PendulumDynamicsModel
+    from bayesian_cbf_amd.unicycle_move_to_pose import PolarDynamics
+    c = ControlCBFLearned()
+    assert isinstance(c.unsafe_controller, EpsilonGreedyController) and isinstance(c.unsafe_controller.base_controller, GreedyController)
+    assert epsilon(0, {0: 1, 100: 0.1}) == pytest.approx(1.0) and epsilon(100, {0: 1, 100: 0.1}) == pytest.approx(0.1)
+    assert epsilon(50, {0: 1, 100: 0.1}) == pytest.approx(math.sqrt(0.1))
+    env = PendulumDynamicsModel()
+    P, R, xg, dt = torch.tensor([[2.0, 0.3], [0.3, 1.0]], **T64), torch.tensor([[0.7]], **T64), torch.tensor([0.2, -0.1], **T64), 0.05
+    g = GreedyController(env, P, R, xg, 100, dt, torch.tensor([-5.0, 5.0]))
+    x = torch.tensor([1.0, 0.2], **T64)
+    u = g.control(x)
+    # u minimises  (1-lam) |x + f dt + G u - x_g|_P^2 + lam u' R dt u,  lam = 1/2: zero gradient
+    uu = u.clone().requires_grad_(True)
+    xp = x + dt * env.f_func(x[None])[0] + dt * env.g_func(x) @ uu
+    cost = 0.5 * (xp - xg) @ P @ (xp - xg) + 0.5 * uu @ (R * dt) @ uu
+    cost.backward()
+    assert float(uu.grad.abs().max()) < 1e-12
+    ub = g.control(torch.stack([x, x + 0.1]))
+    assert ub.shape == (2, 1) and torch.allclose(ub[0], u)
+    assert torch.equal(ZeroController(env, P, R, xg, 100, dt, None).control(x), torch.zeros(1, **T64))
+    e = EpsilonGreedyController(g, 1, 100, [1, 0.1], torch.tensor([-0.05, 0.05], **T64))
+    random.seed(0)
+    out = torch.stack([e.control(x, t=99) for _ in range(50)])
+    assert float(out.abs().max()) <= 0.05 + 1e-15                         # clipped to the control range
+
+    class H(NamedAffineFunc):
+        name = "h"
+        value = lambda self, x: x[0]
+        A = lambda self, x: torch.tensor([[1.0, 2.0]])
+        b = lambda self, x: torch.tensor([0.5])
+    assert H().__name__ == "h" and float(H()(None, torch.tensor([1.0, 1.0]))) == 2.5
+    pd = PolarDynamics()
+    pd.set_init_state(torch.tensor([1.0, 0.3, 0.2], **T64))
+    obs = pd.step(torch.tensor([1.0, 0.5], **T64), 0.1)
+    np.testing.assert_allclose(obs["xdot"].numpy(), [-math.cos(0.3), -math.sin(0.3) + 0.5, -math.sin(0.3)], atol=1e-14)

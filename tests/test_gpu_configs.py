@@ -354,6 +354,127 @@ def test_concurrent_part_batches_equal_single_stream_steps(ops, dtype, shared):
     assert float((x1 - task["x"]).abs().max()) > 1e-3            # the loops did move
 
 
+def test_c3_timed_schedule_two_streams_full_batch_vs_oracle(ops):
+    """The schedule `bench.py` actually times -- `ops.ConcurrentControlLoop(parts=2)` at N=512, batch 4096, fp32 with the
+    bench's seeds and arguments -- compared with the ORACLE directly (not through the single-stream entry point): 64
+    instances spread over both part batches, posterior, control, solver status in both directions and the next state.
+    Also measures what the loose fp32 bound on B_k hides: the worst |dB_k| relative to |B_k| ITSELF (the tolerance of
+    DESIGN.md section 4 is 1e-3 of the prior scale s2 |B|; near training data B_k = s2 B - W'W cancels)."""
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+    Bt, N, n, m = 4096, 512, 3, 2
+    dtype = torch.float32
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=1234)
+    task = make_unicycle_task(Bt, dtype=dtype, device=DEV, seed=99)
+    Lop, UHB, jit = _refit_with_retry(ops, p)
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    gp = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=p["A"])
+    x = task["x"].clone()
+    dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
+    loop = ops.ConcurrentControlLoop(gp, task, x, parts=2, dt=dt_plant, L_true=L_true, L_mean=L_mean, clf_gamma=10.0,
+                                     max_iters=20)
+    loop.step()
+    loop.synchronize()
+    idx = np.concatenate([np.linspace(0, Bt // 2 - 1, 32), np.linspace(Bt // 2, Bt - 1, 32)]).astype(int)
+    hsel = {k: host(v[idx]) if (v.dim() > 0 and v.shape[0] == Bt) else host(v) for k, v in {**p, **task}.items()}
+    hj = host(jit[idx])
+    y, st, xn = host(loop.y[idx]), loop.status[idx].cpu().numpy(), host(x[idx])
+    Mk_d, Bk_d = host(loop.ws["Mk"][idx]), host(loop.ws["Bk"][idx])
+    n_checked, worst_u, worst_bk_own = 0, 0.0, 0.0
+    for j in range(len(idx)):
+        stt = ogp.refit_state(hsel["X"][j], hsel["U"][j], hsel["Xdot"][j], hsel["Bm"][j], hsel["ell"][j], hsel["s2"][j],
+                              hsel["M0"][j], hj[j][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(stt["L"][None], stt["alpha"][None], hsel["X"][j][None], stt["UHB"][None],
+                                        hsel["ell"][j][None], hsel["s2"][j][None], hsel["Bm"][j][None], hsel["M0"][j][None],
+                                        hsel["x"][j][None])
+        rel_close(Mk_d[j], Mk_o[0], 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+        rel_close(Bk_d[j], Bk_o[0], 1e-3, scale=float(hsel["s2"][j] * np.abs(hsel["Bm"][j]).max()), what="Bk")
+        worst_bk_own = max(worst_bk_own, float(np.abs(Bk_d[j] - Bk_o[0]).max() / np.abs(Bk_o[0]).max()))
+        o = ostep.control_step(hsel["x"][j], hsel["plan"][j], hsel["dot_plan"][j], Mk_o[0], Bk_o[0], hsel["A"][j],
+                               hsel["Kp"], 10.0, hsel["centers"][j], hsel["radii"][j], hsel["tw"], hsel["gammas"], L_mean,
+                               hsel["w"][j], hsel["r"][j], hsel["rho"][j], hsel["relax_mask"], dt=dt_plant, L_true=L_true)
+        dev_ok, ora_ok = st[j] == 0, o["status"] == "optimal"
+        if dev_ok != ora_ok:
+            loose, tight = ostep.shifted_status(o, hsel["w"][j], hsel["r"][j], hsel["rho"][j], hsel["relax_mask"], 2e-3)
+            assert (loose == "optimal") != (tight == "optimal"), (int(idx[j]), int(st[j]), o["status"])
+            continue
+        if not ora_ok:
+            np.testing.assert_array_equal(xn[j], hsel["x"][j].astype(np.float32))
+            continue
+        n_checked += 1
+        scale = max(1.0, np.abs(o["sol"]["x"]).max())
+        err = np.abs(y[j] - o["sol"]["x"]).max() / scale
+        worst_u = max(worst_u, err)
+        assert err <= 1e-3, "instance %d: |y - y_oracle| = %.3e of scale %.2f" % (idx[j], err, scale)
+        np.testing.assert_allclose(xn[j], o["x_next"], rtol=0, atol=4e-6 * max(1.0, np.abs(o["x_next"]).max()))
+    assert n_checked >= 56, n_checked
+    # fp32 B_k relative to its OWN magnitude (informational bound: the control holds 1e-3 above)
+    assert worst_bk_own < 2e-2, worst_bk_own
+    print("C3 two-stream schedule: %d of 64 sampled instances solved on both sides, max |du| %.2e, worst |dBk|/|Bk| %.2e"
+          % (n_checked, worst_u, worst_bk_own))
+
+
+def test_concurrent_part_batches_do_overlap_on_the_device(ops):
+    """The two-stream schedule is only worth anything while the device really co-runs the part batches: HIP events around
+    each part's posterior launch (as bench.py places them) must show the launches of a step overlapping one another --
+    the union of their intervals clearly below the sum of their durations.  (Serial execution: union == sum.)"""
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+    Bt, N = 4096, 512
+    dtype = torch.float32
+    p = make_instances(Bt, N, 3, 2, dtype=dtype, device=DEV, seed=1234)
+    task = make_unicycle_task(Bt, dtype=dtype, device=DEV, seed=99)
+    Lop, UHB, _ = _refit_with_retry(ops, p)
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    gp = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=p["A"])
+    x = task["x"].clone()
+    loop = ops.ConcurrentControlLoop(gp, task, x, parts=2, dt=1e-3, L_true=1.0, L_mean=4.0, clf_gamma=10.0, max_iters=20)
+    steps = 30
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)] for _ in range(steps)]
+    for row in ev:
+        for c, (e0, e1) in enumerate(row):
+            e0.record(loop.streams[c]); e1.record(loop.streams[c])
+    base = torch.cuda.Event(enable_timing=True)
+    for _ in range(20):
+        loop.step()
+    loop.synchronize()
+    base.record(loop.streams[0])
+    for s in range(steps):
+        loop.step(ev[s])
+    loop.synchronize()
+    spans = sorted((base.elapsed_time(a), base.elapsed_time(b)) for row in ev for a, b in row)
+    total = sum(b - a for a, b in spans)
+    union, ca, cb = 0.0, spans[0][0], spans[0][1]
+    for a, b in spans[1:]:
+        if a > cb:
+            union += cb - ca
+            ca, cb = a, b
+        else:
+            cb = max(cb, b)
+    union += cb - ca
+    assert union < 0.85 * total, "posterior launches of the two part batches no longer overlap: union %.3f ms of %.3f ms" % (union, total)
+
+
+def test_concurrent_loop_small_batches_slice_only_per_instance_tensors(ops):
+    """A batch as small as a global task tensor's length (Bt = 2 = len(tw); Bt = 3 = len(Kp)) must not have those tensors
+    sliced per part: results equal the single-stream entry point."""
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+    for Bt, parts in ((2, 2), (3, 3)):
+        p = make_instances(Bt, 64, 3, 2, dtype=torch.float64, device=DEV, seed=31)
+        task = make_unicycle_task(Bt, dtype=torch.float64, device=DEV, seed=32)
+        Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+        Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+        gp = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=p["A"])
+        kw = dict(dt=0.01, L_true=1.0, L_mean=4.0, clf_gamma=10.0, max_iters=30)
+        x1, x2 = task["x"].clone(), task["x"].clone()
+        ws = ops.control_workspace(Bt, 2, torch.float64, DEV)
+        ops.unicycle_control_step(gp, task, ws, x1, **kw)
+        loop = ops.ConcurrentControlLoop(gp, task, x2, parts=parts, **kw)
+        loop.step()
+        loop.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(ws["status"], loop.status) and torch.equal(x1, x2)
+        assert torch.equal(ws["y"][ws["status"] == 0], loop.y[loop.status == 0])
+
+
 def test_c4_full_size_monte_carlo_rollouts_properties():
     """BASELINE configs[3] at its full size on one GPU: 32 768 trajectories x 200 steps of the
     unicycle_bayes_cbf_safe_obstacle recipe (max_risk 0.01, true L = 12), replayed from a captured HIP graph.  Size-independent

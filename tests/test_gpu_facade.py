@@ -1134,3 +1134,80 @@ def test_controller_clf_bayesian_with_four_obstacles_and_with_none():
         # single state, reference signature
         u1 = ctrl.control(t(xs[0]), 3)
         np.testing.assert_allclose(u1.cpu().numpy(), u[0].cpu().numpy(), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("path", POSTERIOR_FILES, ids=os.path.basename)
+def test_predict_and_predict_flatten_against_reference_vectors(path):
+    """`predict` (control_affine_model.py:337-363) = the posterior of the matrix F(x)' on matrix rows: the recorded
+    `custom_predict_fullmat` output of the reference minus the make_psd jitter it adds (kron(diag(1e-5 rand), A), :1089);
+    `_predict_flatten` (:645-682) = the vector-variate posterior on observation rows in its raw (b, n, n, b) reshape;
+    the prior-mean module of the regressor evaluates to the M0 the device path uses."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor, ControlAffineRegressorExact
+    g = np.load(path)
+    reg = make(ControlAffineRegressorExact, g, [g["jitter_rand"][0]])
+    Xt, Ut = t(g["Xtest"]), t(g["Utest"])
+    b, n, C = Xt.shape[0], g["X"].shape[1], g["U"].shape[1] + 1
+    mean, cov = reg.predict(Xt)
+    assert mean.shape == (b, C, n) and cov.shape == (b * C * n, b * C * n)
+    close(mean.reshape(-1), g["full_mean"])
+    jit = np.kron(np.diag(1e-5 * g["full_jitter2"]), g["A"])
+    close(cov, g["full_var"] - jit, rtol=1e-7, atol=1e-9)
+    close(reg.predict(Xt, return_cov=False), g["full_mean"].reshape(b, C, n))
+    gx = reg.g_func(Xt)                                               # (:820-830: g = predict()[:, 1:, :] transposed)
+    close(gx, g["full_mean"].reshape(b, C, n)[:, 1:, :].transpose(0, 2, 1))
+    regv = make(ControlAffineRegressor, g, [g["jitter_rand"][0]])
+    mflat, cflat = regv._predict_flatten(Xt, Ut)
+    close(mflat, g["vec_mean"])
+    close(cflat, g["vec_cov"].reshape(b, n, n, b))
+    # the mean module on the training rows = UH M0, on test states = vec(M0) per row
+    _, mxu = reg.encode_from_XU(reg.Xtrain, reg.Utrain, 1)
+    UH = torch.cat([torch.ones_like(reg.Utrain[:, :1]), reg.Utrain], dim=1)
+    close(reg.mean_module(mxu).reshape(-1, n), (UH @ t(g["M0"])).cpu().numpy())
+    close(reg.mean_module(Xt).reshape(b, C, n), np.broadcast_to(g["M0"], (b, C, n)))
+
+
+def test_sample_generator_trajectory_device_batch_through_plant_kernel():
+    """The rollout harness with the reference's surface on a DEVICE batch: `dynamics_model.step` advances all rows in one
+    `bcbf_unicycle_step` launch; every row equals the single-trajectory run of the same start state (host arithmetic),
+    and Xdot is returned (sampling.py:49-75)."""
+    from bayesian_cbf_amd.sampling import sample_generator_trajectory
+    from bayesian_cbf_amd.unicycle_move_to_pose import AckermannDrive
+    Bt, D = 37, 15
+    gen = torch.Generator().manual_seed(3)
+    x0 = (torch.randn(Bt, 3, generator=gen, dtype=torch.float64) * torch.tensor([2.0, 2.0, 1.5], dtype=torch.float64))
+    ctl = lambda x, t=0: torch.stack([1.0 + 0.1 * torch.sin(x[..., 2] + 0.05 * t), 0.3 * torch.cos(x[..., 0]) - 0.02 * t], -1)
+    plant = AckermannDrive(L=1.7)
+    Xd, X, U = sample_generator_trajectory(plant, D, dt=0.03, x0=x0.to(DEV), controller=ctl)
+    assert Xd.shape == (D, Bt, 3) and X.shape == (D + 1, Bt, 3) and U.shape == (D, Bt, 2) and X.is_cuda
+    for i in (0, 11, Bt - 1):
+        Xd1, X1, U1 = sample_generator_trajectory(AckermannDrive(L=1.7), D, dt=0.03, x0=x0[i], controller=ctl)
+        close(X[:, i], X1.numpy(), rtol=1e-12, atol=1e-12)
+        close(Xd[:, i], Xd1.numpy(), rtol=1e-12, atol=1e-12)
+        close(U[:, i], U1.numpy(), rtol=1e-12, atol=1e-12)
+    close((X[1:] - X[:-1]) / 0.03, Xd.cpu().numpy(), rtol=1e-9, atol=1e-9)      # explicit Euler: X[t+1] = X[t] + Xdot[t] dt
+
+
+def test_speed_test_matrix_vector_exp_facade_recipe_small():
+    """pendulum.speed_test_matrix_vector_exp (pendulum.py:1305-1394) under its reference name: all four regressors,
+    two small training sizes, the reference's log tags; timings positive, prior-model errors finite."""
+    from bayesian_cbf_amd import pendulum, tblog
+    torch.manual_seed(0)
+    np.random.seed(0)
+    logged = []
+
+    class L:
+        def add_tensors(self, tag, d, step):
+            logged.append((tag, sorted(d), step))
+
+        def add_scalars(self, tag, d, step):
+            logged.append((tag, sorted(d), step))
+    res = pendulum.speed_test_matrix_vector_exp(max_train_variations=(24, 40), ntimes=2, repeat=2, errorbartries=2, numSteps=120,
+                                                logger=L(), training_iter=5, dtype=torch.float64)
+    assert sorted(res) == ["matrix", "matrixdiag", "vector", "vectordiag"]
+    for name, per in res.items():
+        assert sorted(per) == [24, 40]
+        for r in per.values():
+            assert 0 < r["elapsed"] < 1.0 and len(r["errors"]) == 2 and all(np.isfinite(e) and e > 0 for e in r["errors"])
+    tags = {tg for tg, _, _ in logged}
+    assert {"traj", "matrix", "vector", "matrixdiag", "vectordiag"} <= tags
+    assert ("matrix", ["elapsed"], 24) in logged and ("vectordiag", ["errors"], 40) in logged
