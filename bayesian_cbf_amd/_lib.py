@@ -33,6 +33,9 @@ _TSIGS = {
     "bcbf_chol_append": [P, P, P, P, P, c_int, c_int, P],
     "bcbf_gp_append": [P] * 17 + [c_int, c_int, c_int, c_int, P],
     "bcbf_gp_append_stream": [P] * 20 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_gp_reserve": [P] * 8 + [c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_query_reserved": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_gp_append_reserved": [P] * 16 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_potri": [P, P, c_int, c_int, P],
     "bcbf_trtri": [P, P, c_int, c_int, P],
     "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P],

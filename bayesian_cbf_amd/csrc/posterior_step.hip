@@ -42,10 +42,14 @@
 // occupancy target per element type.  Their Gram / mean sums live in ONE matrix-core accumulator (see step 2b) instead
 // of 126 VALU accumulators per lane, which is what lets two waves share a SIMD with 4 columns per stage in flight.
 #ifndef BCBF_PJ_UNR32
-#define BCBF_PJ_UNR32 4
+#define BCBF_PJ_UNR32 4      // fp32, more than 6 right-hand-side columns (unicycle shape: 12); measured 4096 x 512, n=3, m=2:
+                             // (UNR, waves/SIMD) = (2,1) 663 us, (2,2) 520, (4,1) 539, (4,2) 419, (8,1) 528
+#endif
+#ifndef BCBF_PJ_UNR32_NARROW
+#define BCBF_PJ_UNR32_NARROW 8   // fp32, up to 6 columns (pendulum shape): 8 columns per stage still fit 2 waves/SIMD: 353 -> 344 us
 #endif
 #ifndef BCBF_PJ_UNR64
-#define BCBF_PJ_UNR64 2
+#define BCBF_PJ_UNR64 4      // fp64: (2,1) 633 us, (4,1) 567 (2048 x 512, n=3, m=2); 1024 x 256, n=2, m=1: 70 -> 58 us
 #endif
 #ifndef BCBF_PJ_WAVES32
 #define BCBF_PJ_WAVES32 2
@@ -123,7 +127,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
                       T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
-                      int n, const T* __restrict__ lin, int nq) {
+                      int n, const T* __restrict__ lin, int nq, int Nl, int ldN) {
+    // Nl: the padded size the operator is LAID OUT for (>= Np; column lengths, block offsets, batch stride), ldN: rows
+    // per instance of X / UH B / Vw.  Nl == Np, ldN == N: the packed layout of exactly N points; larger: capacity-
+    // reserving storage of the online path (bcbf_gp_reserve), of which the first N points are live.
     static_assert(NQ == 1 || NJ == 0, "several queries per workgroup: values only");
     static_assert(!RHS || (NJ == 0 && NQ == 1), "right-hand-side mode: values only, one system per workgroup");
     const int cu = RHS ? nq : 0;        // RHS mode: columns of UH (the launcher passes it in the nq slot)
@@ -154,12 +161,12 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const int npairs = nrb / 2;
     const bool live = tid < npairs;
     const int rbA = tid, rbB = nrb - 1 - tid;
-    const T* __restrict__ lop = Lop + (size_t)gb * lop_elems<V>(Np);
+    const T* __restrict__ lop = Lop + (size_t)gb * lop_elems<V>(Nl);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(lop), 0, (int)(lop_elems<V>(Np) * sizeof(T)), 0x00020000);
-    const T* __restrict__ Xb = X + (size_t)gb * N * n;
-    const T* __restrict__ UHBb = UHB + (size_t)gb * N * (RHS ? cu : C);
-    const T* __restrict__ Vwb = RHS ? nullptr : Vw + (size_t)gb * N * n;
+        const_cast<T*>(lop), 0, (int)(lop_elems<V>(Nl) * sizeof(T)), 0x00020000);
+    const T* __restrict__ Xb = X + (size_t)gb * ldN * n;
+    const T* __restrict__ UHBb = UHB + (size_t)gb * ldN * (RHS ? cu : C);
+    const T* __restrict__ Vwb = RHS ? nullptr : Vw + (size_t)gb * ldN * n;
 
     // ---- prologue: r = Phi rows owned by this thread:  phi_i = s2 exp(-1/2 |(x_i - xq)/ell|^2) * UHB_i
     T xqr[NQ][NS], iell[NS];
@@ -281,7 +288,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
-    constexpr int UNR = NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_UNR64 : BCBF_PJ_UNR32)
+    constexpr int UNR = NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
                                : (NQ > 1 ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
@@ -295,7 +302,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         const int voffB = (live && rbB >= rbmin) ? (rbB - rbmin) * V * (int)sizeof(T) : OOB;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int soff = (lop_base<V>(J * NB + g * UNR + u, Np) + (J + 1) * NB) * (int)sizeof(T);
+            const int soff = (lop_base<V>(J * NB + g * UNR + u, Nl) + (J + 1) * NB) * (int)sizeof(T);
             la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
             lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
         }
@@ -353,7 +360,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         for (int q = 0; q < HALF; ++q) {
             const int jj = dh * HALF + q;
             const int voff = (tid < 64 && di >= jj) ? (lop_dinv_col(jj) + di) * (int)sizeof(T) : OOB;
-            dval[q] = BufLoad<T>::one(rsrc, voff, lop_dinv_block(J, Np) * (int)sizeof(T));
+            dval[q] = BufLoad<T>::one(rsrc, voff, lop_dinv_block(J, Nl) * (int)sizeof(T));
         }
     };
 #if BCBF_PS_VWPF
@@ -407,7 +414,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 if constexpr (RHS) {                    // the solved rows ARE the output: Vw[N, n]
                     if (row0 + di < N) {
 #pragma unroll
-                        for (int c = 0; c < C; ++c) if (c < n) Wout[((size_t)b * N + row0 + di) * n + c] = w[c];
+                        for (int c = 0; c < C; ++c) if (c < n) Wout[((size_t)b * ldN + row0 + di) * n + c] = w[c];
                     }
                 } else if (NJ > 0 && Wout != nullptr) {        // jets: all CT columns [Phi, dPhi/dx_1 ..] of this row
 #pragma unroll
@@ -588,19 +595,21 @@ template <typename T>
 static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                  const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
                                  T* Wout, int shared, int Bt, int N, int n, int m, void* stream,
-                                 T* Gfull = nullptr, T* Mfull = nullptr, const T* lin = nullptr) {
+                                 T* Gfull = nullptr, T* Mfull = nullptr, const T* lin = nullptr, int Ncap = 0) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     constexpr int V = Vec<T>::V;
     const int Np = round_up(N, NB);
+    if (Ncap != 0 && Ncap < N) return BCBF_EINVAL;
+    const int Nl = Ncap ? round_up(Ncap, NB) : Np, ldN = Ncap ? Ncap : N;     // capacity-reserving storage (bcbf_gp_reserve)
     const int npairs = Np / V / 2;
     const int threads = round_up(npairs, 64);
     if (threads > (sizeof(T) == 8 && Gfull == nullptr ? 512 : 256)) return BCBF_EINVAL;   // N <= 2048 (fp64 jets: 1024)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt)
-#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt)
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt, Nl, ldN)
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
         if (!Mfull || lin) return BCBF_EINVAL;
         if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
@@ -612,7 +621,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
       if constexpr (sizeof(T) == 8) {
         // fp64, one model, many queries: BCBF_PS_NQ queries per workgroup share the stream of L
         const dim3 gridq((Bt + BCBF_PS_NQ - 1) / BCBF_PS_NQ);
-#define BCBF_PQ_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, BCBF_PS_NQ>), gridq, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt)
+#define BCBF_PQ_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, BCBF_PS_NQ>), gridq, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN)
         if (m == 1) BCBF_PQ_LAUNCH(2);
         else BCBF_PQ_LAUNCH(3);
 #undef BCBF_PQ_LAUNCH
@@ -648,7 +657,7 @@ int launch_forward_stream(const T* Lop, const T* Xdot, const T* UH, const T* M0,
     if (n < 1 || n > 4 || cu < 1 || cu > BCBF_MAX_CTRL_DIM + 1 || threads > (sizeof(T) == 8 ? 512 : 256)) return 1;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_FS_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, true>), grid, block, 0, st, Lop, (const T*)nullptr, Xdot, UH, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, M0, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, Vw, (T*)nullptr, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, cu)
+#define BCBF_FS_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, true>), grid, block, 0, st, Lop, (const T*)nullptr, Xdot, UH, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, M0, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, Vw, (T*)nullptr, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, cu, Np, N)
     switch (n) {
         case 1: case 2: BCBF_FS_LAUNCH(2); break;
         case 3: BCBF_FS_LAUNCH(3); break;
@@ -738,4 +747,24 @@ extern "C" int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, cons
     if (Bt <= 0) return BCBF_OK;
     if (!G || !Mj) return BCBF_EINVAL;
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, Wj, shared, Bt, N, n, m, stream, G, Mj);
+}
+
+// Queries on capacity-reserving storage (bcbf_gp_reserve: the operator laid out for Ncap points, X / UH B / Vw with Ncap
+// rows per instance, the first N live): one query per instance, the streaming kernel.  W (optional) [Bt, Np, 1+m] with
+// Np = N rounded up to 32.  The online path's forward solve and its control-step posterior.
+extern "C" int bcbf_posterior_query_reserved_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                                 const float* ell, const float* s2, const float* Bm, const float* M0,
+                                                 const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                                 int Bt, int N, int Ncap, int n, int m, void* stream) {
+    if (Ncap < N) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, 0, Bt, N, n, m, stream,
+                                              nullptr, nullptr, nullptr, Ncap);
+}
+extern "C" int bcbf_posterior_query_reserved_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                                 const double* ell, const double* s2, const double* Bm, const double* M0,
+                                                 const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                                 int Bt, int N, int Ncap, int n, int m, void* stream) {
+    if (Ncap < N) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, 0, Bt, N, n, m, stream,
+                                               nullptr, nullptr, nullptr, Ncap);
 }

@@ -229,6 +229,42 @@ struct AppendFused {
                          // l = W uh_new, the forward solve below is skipped
 };
 
+// The packed operator of NpI (padded) points re-laid out for NpO >= NpI points: every stored element keeps its (row,
+// column); rows / columns of the new padding are those of the identity.  (The layout's column lengths and block offsets
+// depend on the padded size: bcbf_common.h.)
+template <typename T>
+__device__ inline void relayout_operator(const T* __restrict__ lin, T* __restrict__ lout, int NpI, int NpO, int tid) {
+    constexpr int V = Vec<T>::V;
+    // off-diagonal part: column j keeps its rows below its diagonal block; rows / columns of the new padding are zero
+    for (int j = 0; j < NpO; ++j) {
+        const int first = (j / NB + 1) * NB;
+        const int bo = lop_base<V>(j, NpO);
+        if (j < NpI) {
+            const int bi = lop_base<V>(j, NpI);
+            for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i < NpI ? lin[bi + i] : T(0);
+        } else {
+            for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = T(0);
+        }
+    }
+    // inverted diagonal blocks: copied; a new padding block is the identity
+    const int nbI = NpI / NB, nbO = NpO / NB;
+    for (int e = tid; e < nbO * LOP_DB; e += ST) {
+        const int Jb = e / LOP_DB, o = e - Jb * LOP_DB;
+        T v;
+        if (Jb < nbI) v = lin[lop_dinv_block(Jb, NpI) + o];
+        else {                       // identity: o is a diagonal position iff o == lop_dinv_col(c) + c for some c
+            v = T(0);
+            for (int c = 0; c < NB; ++c) if (o == lop_dinv_col(c) + c) v = T(1);
+        }
+        lout[lop_dinv_block(Jb, NpO) + o] = v;
+    }
+    // ... and their full-tile copies (read by the shared-model kernel)
+    for (int e = tid; e < nbO * NB * NB; e += ST) {
+        const int Jb = e / (NB * NB), o = e - Jb * NB * NB;
+        lout[lop_dfull_block(Jb, NpO) + o] = Jb < nbI ? lin[lop_dfull_block(Jb, NpI) + o] : ((o / NB == o % NB) ? T(1) : T(0));
+    }
+}
+
 template <typename T, bool FUSED>
 __global__ void __launch_bounds__(ST)
 chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict__ kappa,
@@ -336,36 +372,7 @@ chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict
     if (tid == 0) info[b] = ok ? 0 : N + 1;
 
     // ---- copy / re-layout the old operator
-    if (lout != lin) {
-        // off-diagonal part: column j keeps its rows below its diagonal block; rows / columns of the new padding are zero
-        for (int j = 0; j < NpO; ++j) {
-            const int first = (j / NB + 1) * NB;
-            const int bo = lop_base<V>(j, NpO);
-            if (j < NpI) {
-                const int bi = lop_base<V>(j, NpI);
-                for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i < NpI ? lin[bi + i] : T(0);
-            } else {
-                for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = T(0);
-            }
-        }
-        // inverted diagonal blocks: copied; a new padding block is the identity
-        const int nbI = NpI / NB, nbO = NpO / NB;
-        for (int e = tid; e < nbO * LOP_DB; e += ST) {
-            const int Jb = e / LOP_DB, o = e - Jb * LOP_DB;
-            T v;
-            if (Jb < nbI) v = lin[lop_dinv_block(Jb, NpI) + o];
-            else {                       // identity: o is a diagonal position iff o == lop_dinv_col(c) + c for some c
-                v = T(0);
-                for (int c = 0; c < NB; ++c) if (o == lop_dinv_col(c) + c) v = T(1);
-            }
-            lout[lop_dinv_block(Jb, NpO) + o] = v;
-        }
-        // ... and their full-tile copies (read by the shared-model kernel)
-        for (int e = tid; e < nbO * NB * NB; e += ST) {
-            const int Jb = e / (NB * NB), o = e - Jb * NB * NB;
-            lout[lop_dfull_block(Jb, NpO) + o] = Jb < nbI ? lin[lop_dfull_block(Jb, NpI) + o] : ((o / NB == o % NB) ? T(1) : T(0));
-        }
-    }
+    if (lout != lin) relayout_operator<T>(lin, lout, NpI, NpO, tid);
     __threadfence_block();
     __syncthreads();
     // ---- the new row N.  A non-positive pivot (info = N+1) writes nothing: row N stays the identity padding row it
@@ -452,6 +459,137 @@ static int launch_gp_append(const T* Lin, const T* Vw_in, const T* X_in, const T
     return check_launch("gp_append");
 }
 
+
+// --------------------------------------------------------------------------------------------
+// Capacity-reserving GP storage (online path, BASELINE configs[4]).  The packed layout depends on the padded size, and
+// X / UH B / Vw are [Bt, N, .] arrays, so bcbf_gp_append must copy every per-instance array on every append and re-pack
+// the whole operator whenever N crosses a multiple of 32.  Reserved storage lays the operator out ONCE for Ncap points
+// (rows / columns beyond the live N are identity padding) and gives the arrays Ncap rows per instance: an append then
+// writes one operator row, one inverted-diagonal-block row and one row of each array IN PLACE -- O(N) bytes instead of
+// O(N^2), no allocation, nothing copied.  The kernels that read it take (N, Ncap): bcbf_posterior_query_reserved.
+template <typename T>
+__global__ void __launch_bounds__(ST)
+gp_reserve_kernel(const T* __restrict__ Lin, const T* __restrict__ Vw_in, const T* __restrict__ X_in,
+                  const T* __restrict__ UHB_in, T* __restrict__ Lout, T* __restrict__ Vw_out, T* __restrict__ X_out,
+                  T* __restrict__ UHB_out, int N, int NcapIn, int Ncap, int n, int C) {
+    // NcapIn = 0: the inputs are the packed state of exactly N points; > 0: reserved storage of that capacity (growing)
+    constexpr int V = Vec<T>::V;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ldI = NcapIn ? NcapIn : N;
+    const int NpI = round_up(ldI, NB), NpO = round_up(Ncap, NB);
+    relayout_operator<T>(Lin + (size_t)b * lop_elems<V>(NpI), Lout + (size_t)b * lop_elems<V>(NpO), NpI, NpO, tid);
+    for (int e = tid; e < Ncap * n; e += ST) {
+        const bool live = e < N * n;
+        Vw_out[(size_t)b * Ncap * n + e] = live ? Vw_in[(size_t)b * ldI * n + e] : T(0);
+        X_out[(size_t)b * Ncap * n + e] = live ? X_in[(size_t)b * ldI * n + e] : T(0);
+    }
+    for (int e = tid; e < Ncap * C; e += ST) UHB_out[(size_t)b * Ncap * C + e] = e < N * C ? UHB_in[(size_t)b * ldI * C + e] : T(0);
+}
+
+// One observation per instance enters reserved storage in place.  W = L^-1 Phi(x_new) [Bt, Np, C] comes from the
+// streaming posterior kernel (one pass over the factor at the HBM rate); l = W uh_new is the new operator row,
+// d = sqrt(kappa - l'l) its pivot.  A non-positive pivot (info = N+1) leaves the operator as it was (row N is still an
+// identity padding row) and enters a NEUTRAL point (Vw row 0, UH B row 0), as bcbf_gp_append does.
+template <typename T>
+__global__ void __launch_bounds__(ST)
+gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict__ X, T* __restrict__ UHB,
+                         const T* __restrict__ s2, const T* __restrict__ Bm, const T* __restrict__ M0,
+                         const T* __restrict__ x_new, const T* __restrict__ uh_new, const T* __restrict__ xdot_new,
+                         const T* __restrict__ jitter_new, const T* __restrict__ W, int* __restrict__ info,
+                         int N, int Ncap, int n, int C) {
+    constexpr int V = Vec<T>::V;
+    __shared__ T lrow[ST * SMAXR];
+    __shared__ T scratch[4 * SC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Np = round_up(N, NB), Nl = round_up(Ncap, NB);
+    T* lop = Lop + (size_t)b * lop_elems<V>(Nl);
+    T* Vwb = Vw + (size_t)b * Ncap * n;
+    T uh[BCBF_MAX_CTRL_DIM + 1];
+#pragma unroll
+    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) uh[c] = c < C ? uh_new[(size_t)b * C + c] : T(0);
+    // l = W uh_new; l'l and l'Vw in the same pass
+    T acc[SC + 1];
+#pragma unroll
+    for (int c = 0; c < SC + 1; ++c) acc[c] = T(0);
+    for (int i = tid; i < N; i += ST) {
+        T v = T(0);
+#pragma unroll
+        for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
+            if (c < C) v += W[((size_t)b * Np + i) * C + c] * uh[c];
+        lrow[i] = v;
+        acc[SC] += v * v;
+#pragma unroll
+        for (int c = 0; c < SC; ++c)
+            if (c < n) acc[c] += v * Vwb[(size_t)i * n + c];
+    }
+    T ssq[1] = {acc[SC]};
+    block_sum(ssq, 1, scratch);
+    __syncthreads();
+    block_sum(acc, n, scratch);
+    T q = T(0);
+#pragma unroll
+    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) {
+        T sacc = T(0);
+        if (c < C) for (int a = 0; a < C; ++a) sacc += Bm[((size_t)b * C + c) * C + a] * uh[a];
+        q += uh[c] * sacc;
+    }
+    const T kap = s2[b] * q + (jitter_new ? jitter_new[b] : T(0));
+    const T d2 = kap - ssq[0];
+    const bool ok = d2 > T(0);
+    const T d = ok ? (T)sqrt((double)d2) : T(1);
+    if (tid == 0) info[b] = ok ? 0 : N + 1;
+    __syncthreads();                                            // lrow complete for every thread
+    const int Js = N / NB, col0 = Js * NB, rr = N - col0;
+    if (ok) {
+        for (int j = tid; j < col0; j += ST) lop[lop_base<V>(j, Nl) + N] = lrow[j];
+        if (tid <= rr) {
+            const int jj = tid;                                 // column inside the diagonal block
+            T val;
+            if (jj == rr) val = T(1) / d;
+            else {
+                T a2 = T(0);
+                for (int ii = jj; ii < rr; ++ii) a2 += lrow[col0 + ii] * lop[lop_dinv(Js, ii, jj, Nl)];
+                val = -a2 / d;
+            }
+            lop[lop_dinv(Js, rr, jj, Nl)] = val;
+            lop[lop_dfull(Js, rr, jj, Nl)] = val;
+        }
+    }
+    if (tid < n) {
+        T yv = xdot_new[(size_t)b * n + tid];
+        for (int a = 0; a < C; ++a) yv -= uh[a] * M0[((size_t)b * C + a) * n + tid];
+        Vwb[(size_t)N * n + tid] = ok ? (yv - acc[tid]) / d : T(0);
+        X[((size_t)b * Ncap + N) * n + tid] = x_new[(size_t)b * n + tid];
+    }
+    if (tid < C) {
+        T sacc = T(0);
+        for (int a = 0; a < C; ++a) sacc += uh[a] * Bm[((size_t)b * C + a) * C + tid];
+        UHB[((size_t)b * Ncap + N) * C + tid] = ok ? sacc : T(0);
+    }
+}
+
+template <typename T>
+static int launch_gp_reserve(const T* Lin, const T* Vw_in, const T* X_in, const T* UHB_in, T* Lout, T* Vw_out, T* X_out,
+                             T* UHB_out, int Bt, int N, int NcapIn, int Ncap, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lin || !Vw_in || !X_in || !UHB_in || !Lout || !Vw_out || !X_out || !UHB_out) return BCBF_EINVAL;
+    if (N < 1 || Ncap < N || round_up(Ncap, NB) > ST * SMAXR) return BCBF_EINVAL;
+    if (NcapIn != 0 && (NcapIn < N || NcapIn > Ncap)) return BCBF_EINVAL;
+    if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+    if (Lin == Lout || Vw_in == Vw_out || X_in == X_out || UHB_in == UHB_out) return BCBF_EINVAL;
+    hipLaunchKernelGGL((gp_reserve_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, Vw_in, X_in, UHB_in, Lout,
+                       Vw_out, X_out, UHB_out, N, NcapIn, Ncap, n, m + 1);
+    return check_launch("gp_reserve");
+}
+
+template <typename T>
+static int launch_gp_append_inplace(T* Lop, T* Vw, T* X, T* UHB, const T* s2, const T* Bm, const T* M0, const T* x_new,
+                                    const T* uh_new, const T* xdot_new, const T* jitter_new, const T* W, int* info, int Bt,
+                                    int N, int Ncap, int n, int m, void* stream) {
+    hipLaunchKernelGGL((gp_append_inplace_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Vw, X, UHB, s2, Bm, M0,
+                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1);
+    return check_launch("gp_append_reserved");
+}
 }  // namespace bcbf
 
 extern "C" {
@@ -528,4 +666,31 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
                          int* info, int Bt, int N, void* stream) {
     return bcbf::launch_chol_append<double>(Lop_in, knew, kappa, Lop_out, info, Bt, N, stream);
 }
+
+// Capacity-reserving storage of the online path (see gp_reserve_kernel above).
+#define BCBF_RESERVED_ENTRY(SUF, T)                                                                                      \
+    int bcbf_gp_reserve_##SUF(const T* Lop_in, const T* Vw_in, const T* X_in, const T* UHB_in, T* Lop_r, T* Vw_r, T* X_r,   \
+                              T* UHB_r, int Bt, int N, int Ncap_in, int Ncap, int n, int m, void* stream) {             \
+        return bcbf::launch_gp_reserve<T>(Lop_in, Vw_in, X_in, UHB_in, Lop_r, Vw_r, X_r, UHB_r, Bt, N, Ncap_in, Ncap, n, m,  \
+                                          stream);                                                                       \
+    }                                                                                                                    \
+    int bcbf_gp_append_reserved_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,         \
+                                      const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,                   \
+                                      const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, int Bt, int N,   \
+                                      int Ncap, int n, int m, void* stream) {                                            \
+        if (Bt <= 0) return BCBF_OK;                                                                                     \
+        if (!Lop_r || !Vw_r || !X_r || !UHB_r || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !info ||  \
+            !Wwork || !Mk_work || !Bk_work)                                                                              \
+            return BCBF_EINVAL;                                                                                          \
+        if (N < 1 || N >= Ncap || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;  \
+        if (bcbf::round_up(Ncap, bcbf::NB) > bcbf::ST * bcbf::SMAXR) return BCBF_EINVAL;                                  \
+        const int rc = bcbf_posterior_query_reserved_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, nullptr,       \
+                                                           Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);          \
+        if (rc != BCBF_OK) return rc;                                                                                    \
+        return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
+                                                 Wwork, info, Bt, N, Ncap, n, m, stream);                                \
+    }
+BCBF_RESERVED_ENTRY(f32, float)
+BCBF_RESERVED_ENTRY(f64, double)
+#undef BCBF_RESERVED_ENTRY
 }

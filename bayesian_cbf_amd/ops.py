@@ -62,14 +62,20 @@ def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None):
     return Kb
 
 
-def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False):
-    """Fused K_b build + Cholesky + packing.  Returns (Lop[Bt,E], UHB[Bt,N,C], info[Bt], Ldense|None)."""
+def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None):
+    """Fused K_b build + Cholesky + packing.  Returns (Lop[Bt,E], UHB[Bt,N,C], info[Bt], Ldense|None).
+    out = (Lop, UHB, info): write into the caller's buffers (a closed loop that has bound their addresses)."""
     _chk(X, UH, Bm, ell, s2, jitter)
     Bt, N, n = X.shape
     C = UH.shape[2]
-    Lop = torch.empty(Bt, lop_elems(N, X.dtype), dtype=X.dtype, device=X.device)
-    UHB = torch.empty(Bt, N, C, dtype=X.dtype, device=X.device)
-    info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+    if out is not None:
+        Lop, UHB, info = out
+        _chk(X, Lop, UHB, info)
+        assert Lop.shape == (Bt, lop_elems(N, X.dtype)) and UHB.shape == (Bt, N, C) and info.shape == (Bt,)
+    else:
+        Lop = torch.empty(Bt, lop_elems(N, X.dtype), dtype=X.dtype, device=X.device)
+        UHB = torch.empty(Bt, N, C, dtype=X.dtype, device=X.device)
+        info = torch.empty(Bt, dtype=torch.int32, device=X.device)
     Ld = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device) if want_dense else None
     check(getattr(lib, "bcbf_refit" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
                                                _p(Ld), _p(info), Bt, N, n, C - 1, _stream(X)), "bcbf_refit")
@@ -87,12 +93,13 @@ def potrf(Kb, want_dense=False):
     return Lop, info, Ld
 
 
-def potrs(Lop, Xdot, UH, M0, want_alpha=True):
+def potrs(Lop, Xdot, UH, M0, want_alpha=True, out_Vw=None):
     """Vw = L^-1 (Xdot - UH M0), alpha = K_b^-1 (Xdot - UH M0)  (control_affine_model.py:525-545)."""
-    _chk(Lop, Xdot, UH, M0)
+    _chk(Lop, Xdot, UH, M0, out_Vw)
     Bt, N, n = Xdot.shape
     m = UH.shape[2] - 1
-    Vw = torch.empty(Bt, N, n, dtype=Xdot.dtype, device=Xdot.device)
+    Vw = torch.empty(Bt, N, n, dtype=Xdot.dtype, device=Xdot.device) if out_Vw is None else out_Vw
+    assert Vw.shape == (Bt, N, n)
     alpha = torch.empty_like(Vw) if want_alpha else None
     check(getattr(lib, "bcbf_potrs" + _suf(Xdot))(_p(Lop), _p(Xdot), _p(UH), _p(M0), _p(Vw), _p(alpha),
                                                   Bt, N, n, m, _stream(Xdot)), "bcbf_potrs")
@@ -139,6 +146,76 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
                                                    _p(Vw2), _p(X2), _p(UHB2), _p(info), Bt, N, n, C - 1, _stream(X)),
           "bcbf_gp_append")
     return Lout, Vw2, X2, UHB2, info
+
+
+class ReservedGP:
+    """Capacity-reserving storage of Bt independent GPs for the online path (bcbf.h: bcbf_gp_reserve,
+    bcbf_posterior_query_reserved, bcbf_gp_append_reserved).  Built from a fitted state of N points
+    (`refit` / `potrs` outputs); `append` enters one observation per instance IN PLACE -- no allocation, no copy of
+    the per-instance arrays, no re-pack of the operator -- until N reaches `capacity`; `grow(capacity)` re-reserves.
+    The work buffers of the forward solve are allocated once.  `N` is the live size; `Lop`, `Vw`, `X`, `UHB` are the
+    reserved buffers ([Bt, lop_elems(capacity)], [Bt, capacity, .])."""
+
+    def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None):
+        _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
+        self.Bt, self.N, self.n = X.shape
+        self.C = UHB.shape[2]
+        self.ell, self.s2, self.Bm, self.M0, self.A = ell, s2, Bm, M0, A
+        self.capacity = 0
+        self._fill(Lop, Vw, X, UHB, self.N, int(capacity))
+
+    def _fill(self, Lop, Vw, X, UHB, N, capacity, cap_in=0):
+        if capacity < N:
+            raise ValueError("capacity %d < %d live points" % (capacity, N))
+        f = dict(dtype=X.dtype, device=X.device)
+        Bt, n, C = self.Bt, self.n, self.C
+        Lr = torch.empty(Bt, lop_elems(capacity, X.dtype), **f)
+        Vr, Xr, Ur = torch.empty(Bt, capacity, n, **f), torch.empty(Bt, capacity, n, **f), torch.empty(Bt, capacity, C, **f)
+        check(getattr(lib, "bcbf_gp_reserve" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(Lr), _p(Vr), _p(Xr), _p(Ur), Bt, N,
+                                                        cap_in, capacity, n, C - 1, _stream(X)), "bcbf_gp_reserve")
+        self.Lop, self.Vw, self.X, self.UHB, self.capacity = Lr, Vr, Xr, Ur, capacity
+        Npc = (capacity + 31) // 32 * 32
+        self._Ww, self._Mkw, self._Bkw = torch.empty(Bt, Npc, C, **f), torch.empty(Bt, n, C, **f), torch.empty(Bt, C, C, **f)
+        self.info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+
+    def grow(self, capacity):
+        """Re-reserve for a larger capacity: ONE copy of the state (geometric growth amortises it to O(1) per append)."""
+        if capacity <= self.capacity:
+            return self
+        self._fill(self.Lop, self.Vw, self.X, self.UHB, self.N, int(capacity), cap_in=self.capacity)
+        return self
+
+    def posterior(self, xq, jitter2=None, want_W=False, out=None):
+        """(Mk[Bt,n,C], Bk[Bt,C,C]) (+ W[Bt,Np,C]) at one query per instance on the live points."""
+        _chk(self.X, xq, jitter2)
+        f = dict(dtype=self.X.dtype, device=self.X.device)
+        if out is None:
+            Mk, Bk = torch.empty(self.Bt, self.n, self.C, **f), torch.empty(self.Bt, self.C, self.C, **f)
+        else:
+            Mk, Bk = out
+        W = torch.empty(self.Bt, (self.N + 31) // 32 * 32, self.C, **f) if want_W else None
+        check(getattr(lib, "bcbf_posterior_query_reserved" + _suf(self.X))(
+            _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0), _p(xq),
+            _p(jitter2), _p(Mk), _p(Bk), _p(W), self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)),
+            "bcbf_posterior_query_reserved")
+        return (Mk, Bk, W) if want_W else (Mk, Bk)
+
+    def append(self, x_new, uh_new, xdot_new, jitter_new=None):
+        """One observation per instance, in place.  Returns info[Bt] (0, or N+1 where the new pivot was not positive: that
+        instance gained a neutral point -- retrying is the caller's business, as with `gp_append`)."""
+        if self.N >= self.capacity:
+            raise RuntimeError("ReservedGP is full (%d points): reserve a larger capacity" % self.capacity)
+        _chk(self.X, x_new, uh_new, xdot_new, jitter_new)
+        check(getattr(lib, "bcbf_gp_append_reserved" + _suf(self.X))(
+            _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0),
+            _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self.info), _p(self._Ww), _p(self._Mkw), _p(self._Bkw),
+            self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)), "bcbf_gp_append_reserved")
+        self.N += 1
+        return self.info
+
+    def live(self):
+        """Views of the live rows: (Vw[Bt,N,n], X[Bt,N,n], UHB[Bt,N,C]) (strided: not inputs of the packed-layout kernels)."""
+        return self.Vw[:, :self.N], self.X[:, :self.N], self.UHB[:, :self.N]
 
 
 def kb_inverse(Lop, N, gemm=True):

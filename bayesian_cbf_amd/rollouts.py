@@ -128,12 +128,16 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     return dict(stats=stats, x_final=x, min_h=min_h, dist_to_goal=dist_to_goal, traj=traj, loop_seconds=t_loop)
 
 
-def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True):
+def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True,
+                     reserved=True):
     """BASELINE configs[4]: every instance starts from an N0-point GP and takes one observation per control step
-    until it holds N1 points; each observation enters through `ops.gp_append` (bordered Cholesky on the packed
-    operator, whitened targets and per-refit arrays updated in the same launch) -- the reference refits from scratch
-    every `train_every_n_steps` (unicycle_move_to_pose.py:340-386).  Returns per-octave timings (HIP events) and the
-    deviation of the final posterior from a from-scratch refit of all N1 points."""
+    until it holds N1 points -- the reference refits from scratch every `train_every_n_steps`
+    (unicycle_move_to_pose.py:340-386).  reserved=True (default): capacity-reserving storage (`ops.ReservedGP`,
+    capacity N1): an observation enters IN PLACE -- one streaming forward solve + O(N) bytes written, no allocation, no
+    copies, no re-packing; the control step's posterior reads the same storage.  reserved=False: `ops.gp_append` on the
+    packed layout of exactly N points (every per-instance array copied per append, the operator re-packed every 32).
+    Returns per-octave timings (HIP events) and the deviation of the final posterior from a from-scratch refit of all
+    N1 points."""
     from .synthetic import make_instances, make_unicycle_task
     dev = torch.device(device)
     n, m = 3, 2
@@ -147,36 +151,51 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
     A = (0.01 * p["A"]).contiguous()
     ws = ops.control_workspace(Bt, 2, dtype, dev)
     x = task["x"].clone()
+    rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N1) if reserved else None
+    if reserved:
+        del Lop, Vw, UHB
     # pre-slice the observation stream (contiguous [N1][Bt,.]) so the timed loop holds only the path's own launches
     obs = [t.transpose(0, 1).contiguous() for t in (p["X"], p["UH"], p["Xdot"], p["jitter"])]
     edges = sorted({N0, N1} | {k for k in (256, 512, 1024, 2048) if N0 < k < N1})
-    segs, fails = [], 0
+    segs = []
+    fails = torch.zeros((), dtype=torch.int64, device=dev)
     for lo, hi in zip(edges[:-1], edges[1:]):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        t_step = t_app = 0.0
+        k = hi - lo
+        e = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(k)]
         torch.cuda.synchronize()
         for N in range(lo, hi):
-            e[0].record()
-            if with_control:
+            ev = e[N - lo]
+            ev[0].record()
+            if with_control and reserved:
+                # posterior on the reserved storage -> (M_k, B_k) are then INPUTS of the fused task-rows / terms / SOCP launch
+                rgp.posterior(x, out=(ws["Mk"], ws["Bk"]))
+                ops.unicycle_control_step(dict(A=A), task, ws, x, dt=0.0, L_mean=4.0, max_iters=20)
+            elif with_control:
                 gp = dict(Lop=Lop, Vw=Vw, X=X, UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=A)
                 ops.unicycle_control_step(gp, task, ws, x, dt=0.0, L_mean=4.0, max_iters=20)
-            e[1].record()
-            Lop, Vw, X, UHB, info = ops.gp_append(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], obs[0][N],
-                                                  obs[1][N], obs[2][N], obs[3][N])
-            e[2].record()
-            torch.cuda.synchronize()
-            t_step += e[0].elapsed_time(e[1])
-            t_app += e[1].elapsed_time(e[2])
-            fails += int((info != 0).sum())
-        k = hi - lo
-        isz = X.element_size()
+            ev[1].record()
+            if reserved:
+                info = rgp.append(obs[0][N], obs[1][N], obs[2][N], obs[3][N])
+            else:
+                Lop, Vw, X, UHB, info = ops.gp_append(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], obs[0][N],
+                                                      obs[1][N], obs[2][N], obs[3][N])
+            ev[2].record()
+            fails += (info != 0).sum()             # stays on the device: the loop never waits for the host
+        torch.cuda.synchronize()
+        t_step = sum(ev[0].elapsed_time(ev[1]) for ev in e)
+        t_app = sum(ev[1].elapsed_time(ev[2]) for ev in e)
+        isz = p["X"].element_size()
         segs.append(dict(N_from=lo, N_to=hi, control_step_ms=t_step / k, append_ms=t_app / k,
                          append_GBs_algorithmic=Bt * isz * ((lo + hi) / 2) ** 2 / 2 / (t_app / k * 1e-3) / 1e9))
-    out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype), segments=segs, append_failures=fails)
+    out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype), storage="reserved (in place)" if reserved else "packed (copy per append)",
+               segments=segs, append_failures=int(fails))
     if check:
         Lr, UHBr, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
         Vr, _ = ops.potrs(Lr, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
-        Mk, Bk = ops.posterior_step(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+        if reserved:
+            Mk, Bk = rgp.posterior(p["xq"])
+        else:
+            Mk, Bk = ops.posterior_step(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
         Mr, Br = ops.posterior_step(Lr, Vr, p["X"], UHBr, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
         prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
         out["refit_failures"] = int((info != 0).sum())

@@ -159,6 +159,44 @@ int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const d
                               double* Vw_out, double* X_out, double* UHB_out, int* info, double* Wwork, double* Mk_work,
                               double* Bk_work, int Bt, int N, int n, int m, void* stream);
 
+/* Capacity-reserving GP storage for the online path (BASELINE configs[4]; the reference refits from scratch,
+ * unicycle_move_to_pose.py:340-386).  The packed layout depends on the padded size and X / UH*B / Vw are [Bt,N,.] arrays,
+ * so bcbf_gp_append copies every per-instance array on each append and re-packs the operator at every multiple of 32.
+ * Reserved storage lays the operator out ONCE for Ncap points (bcbf_lop_elems(Ncap) elements per instance; rows / columns
+ * beyond the live N are identity padding) and gives X / UH*B / Vw Ncap rows per instance ([Bt,Ncap,.]):
+ *   bcbf_gp_reserve             copies a fitted state of N points into reserved storage of capacity Ncap: Ncap_in = 0 -> the
+ *                               inputs are bcbf_refit / bcbf_potrs outputs ([Bt,N,.], packed layout of N points);
+ *                               Ncap_in > 0 -> they are reserved storage of that capacity (growing the reservation);
+ *   bcbf_posterior_query_reserved   one query per instance on the first N points (the streaming kernel; W optional,
+ *                               [Bt, Np, 1+m], Np = N rounded up to 32);
+ *   bcbf_gp_append_reserved     one observation per instance enters IN PLACE: the forward solve W = L^-1 Phi(x_new) on the
+ *                               streaming kernel, then one operator row, one inverted-diagonal-block row and one row of
+ *                               each array are written -- O(N) bytes, no allocation, nothing copied.  N < Ncap; the
+ *                               caller's N grows by one.  Work buffers: Wwork[Bt, round_up(Ncap,32), 1+m],
+ *                               Mk_work[Bt,n,1+m], Bk_work[Bt,1+m,1+m].  info as bcbf_gp_append (N+1: neutral point). */
+int bcbf_gp_reserve_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in, float* Lop_r,
+                        float* Vw_r, float* X_r, float* UHB_r, int Bt, int N, int Ncap_in, int Ncap, int n, int m,
+                        void* stream);
+int bcbf_gp_reserve_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in, double* Lop_r,
+                        double* Vw_r, double* X_r, double* UHB_r, int Bt, int N, int Ncap_in, int Ncap, int n, int m,
+                        void* stream);
+int bcbf_posterior_query_reserved_f32(const float* Lop_r, const float* Vw_r, const float* X_r, const float* UHB_r,
+                                      const float* ell, const float* s2, const float* Bm, const float* M0, const float* xq,
+                                      const float* jitter2, float* Mk, float* Bk, float* W, int Bt, int N, int Ncap, int n,
+                                      int m, void* stream);
+int bcbf_posterior_query_reserved_f64(const double* Lop_r, const double* Vw_r, const double* X_r, const double* UHB_r,
+                                      const double* ell, const double* s2, const double* Bm, const double* M0,
+                                      const double* xq, const double* jitter2, double* Mk, double* Bk, double* W, int Bt,
+                                      int N, int Ncap, int n, int m, void* stream);
+int bcbf_gp_append_reserved_f32(float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
+                                const float* Bm, const float* M0, const float* x_new, const float* uh_new,
+                                const float* xdot_new, const float* jitter_new, int* info, float* Wwork, float* Mk_work,
+                                float* Bk_work, int Bt, int N, int Ncap, int n, int m, void* stream);
+int bcbf_gp_append_reserved_f64(double* Lop_r, double* Vw_r, double* X_r, double* UHB_r, const double* ell, const double* s2,
+                                const double* Bm, const double* M0, const double* x_new, const double* uh_new,
+                                const double* xdot_new, const double* jitter_new, int* info, double* Wwork, double* Mk_work,
+                                double* Bk_work, int Bt, int N, int Ncap, int n, int m, void* stream);
+
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */
 int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream);

@@ -30,6 +30,9 @@ int main(void) {
     EXPECT(bcbf_chol_append_f64(0, 0, 0, 0, 0, 0, 8, 0), BCBF_OK);
     EXPECT(bcbf_gp_append_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 2, 1, 0), BCBF_OK);
     EXPECT(bcbf_potri_f64(0, 0, 0, 8, 0), BCBF_OK);
+    EXPECT(bcbf_gp_reserve_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 16, 2, 1, 0), BCBF_OK);
+    EXPECT(bcbf_posterior_query_reserved_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
+    EXPECT(bcbf_gp_append_reserved_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_step_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_query_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_shared_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 3, 2, 0), BCBF_OK);
@@ -50,6 +53,10 @@ int main(void) {
     EXPECT(bcbf_socp_f64(d, d, d, d, d, d, i, i, 1, 5, 2, 20, 0), BCBF_EINVAL);                  /* K > 4 */
     EXPECT(bcbf_coneqp_f64(d, d, d, d, 99, 0, i, 1, d, i, i, 1, 20, 0), BCBF_EINVAL);            /* nv out of range */
     EXPECT(bcbf_chol_append_f64(d, d, d, d, i, 1, 32, 0), BCBF_EINVAL);                           /* in place across a padding boundary */
+    EXPECT(bcbf_gp_reserve_f64(d, d, d, d, d + 1, d + 1, d + 1, d + 1, 1, 8, 0, 4, 2, 1, 0), BCBF_EINVAL);   /* capacity < N */
+    EXPECT(bcbf_gp_reserve_f64(d, d, d, d, d, d, d, d, 1, 8, 0, 16, 2, 1, 0), BCBF_EINVAL);         /* in == out */
+    EXPECT(bcbf_gp_append_reserved_f64(d, d, d, d, d, d, d, d, d, d, d, 0, i, d, d, d, 1, 16, 16, 3, 2, 0), BCBF_EINVAL);  /* full */
+    EXPECT(bcbf_posterior_query_reserved_f64(d, d, d, d, d, d, d, d, d, 0, d, d, 0, 1, 16, 8, 3, 2, 0), BCBF_EINVAL);     /* Ncap < N */
     {   /* the row-count helper is pure host logic */
         int kinds[4] = {1, 2, 0, 1};
         EXPECT(bcbf_controller_cones_rows(kinds, 4, 2, 1) == 1 + 4 + 3 * 4 ? 0 : 1, 0);

@@ -281,6 +281,105 @@ def test_gp_append_failed_pivot_leaves_the_instance_unchanged(ops, N):
     assert torch.equal(L2[1, :E], Lop_in[1, :E])
 
 
+def test_c5_reserved_storage_growth_128_to_2048_vs_oracle(ops):
+    """BASELINE config 5 on the capacity-reserving storage (`ops.ReservedGP`: bcbf_gp_reserve / bcbf_gp_append_reserved /
+    bcbf_posterior_query_reserved): 1920 in-place appends, nothing re-packed or copied.  At N = 129, 160, 256, 512,
+    1024, 2048 against the ORACLE's from-scratch refactorisation (posterior and the whitened query W = L^-1 Phi, which
+    every row of the grown factor enters); the reservation is grown once on the way (1024 -> 2048); at the end the
+    live rows of X equal the observation stream."""
+    import scipy.linalg as sla
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, N0, N1, n, m = 3, 128, 2048, 3, 2
+    dtype = torch.float64
+    p = make_instances(Bt, N1, n, m, dtype=dtype, device=DEV, seed=5)
+    p["X"] = (p["X"] * 3.0).contiguous()
+    p["xq"] = (p["xq"] * 3.0).contiguous()
+    cut = lambda t, N: t[:, :N].contiguous()
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], N0), cut(p["UH"], N0), p["Bm"], p["ell"], p["s2"], cut(p["jitter"], N0))
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N0), cut(p["UH"], N0), p["M0"], want_alpha=False)
+    g = ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], 1024)
+    ptr = g.Lop.data_ptr()
+    h = {k: host(v) for k, v in p.items()}
+    checkpoints = {129, 160, 256, 512, 1024, 2048}
+    for N in range(N0, N1):
+        if g.N == g.capacity:
+            g.grow(2048)
+            ptr = g.Lop.data_ptr()
+        info = g.append(p["X"][:, N].contiguous(), p["UH"][:, N].contiguous(), p["Xdot"][:, N].contiguous(),
+                        p["jitter"][:, N].contiguous())
+        assert g.Lop.data_ptr() == ptr                      # in place
+        if N + 1 not in checkpoints:
+            continue
+        assert (info == 0).all() and g.N == N + 1
+        Nn = N + 1
+        Mk, Bk, W = g.posterior(p["xq"], want_W=True)
+        for i in (0, Bt - 1):
+            stt = ogp.refit_state(h["X"][i, :Nn], h["U"][i, :Nn], h["Xdot"][i, :Nn], h["Bm"][i], h["ell"][i], h["s2"][i],
+                                  h["M0"][i], h["jitter"][i, :Nn][None] / 1e-5)
+            Mk_o, Bk_o = ogp.posterior_step(stt["L"][None], stt["alpha"][None], h["X"][i, :Nn][None], stt["UHB"][None],
+                                            h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None],
+                                            h["xq"][i][None])
+            prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
+            rel_close(host(Mk)[i], Mk_o[0], 1e-7, scale=max(1.0, np.abs(Mk_o).max()), what="Mk N=%d" % Nn)
+            rel_close(host(Bk)[i], Bk_o[0], 1e-7, scale=prior, what="Bk N=%d" % Nn)
+            Phi = ogp.rbf_ard_kernel(h["X"][i, :Nn], h["xq"][i][None], h["ell"][i], h["s2"][i])[:, :1] * stt["UHB"]
+            W_o = sla.solve_triangular(stt["L"], Phi, lower=True)
+            rel_close(host(W)[i, :Nn], W_o, 1e-7, scale=max(np.abs(W_o).max(), 1e-3), what="W N=%d" % Nn)
+    Vw_l, X_l, UHB_l = g.live()
+    assert g.N == N1 and torch.equal(X_l, p["X"])
+    # the grown state, laid out for exactly N1 points again, is what refit + potrs give on the N1 points (device, 1e-9)
+    Lr, UHBr, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Vr, _ = ops.potrs(Lr, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    np.testing.assert_allclose(host(UHB_l), host(UHBr), rtol=1e-12, atol=1e-14)
+    rel_close(host(Vw_l), host(Vr), 1e-6, what="Vw")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
+    """Reserved storage holds the same GP as the packed layout: queries agree bit for bit with `posterior_step` on the
+    packed state at several live sizes / capacities (incl. a capacity that is no multiple of 32); a non-positive pivot
+    leaves the instance's posterior unchanged (neutral point) while the other instances learn; appending beyond the
+    capacity is refused."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, n, m = 5, 3, 2
+    for N, cap in ((40, 41), (96, 200), (130, 160)):
+        p = make_instances(Bt, N + 1, n, m, dtype=dtype, device=DEV, seed=N)
+        cut = lambda t, k: t[:, :k].contiguous()
+        X0, UH0 = cut(p["X"], N), cut(p["UH"], N)
+        # (a small refit jitter: the pivot of a duplicated point is ~ its own diagonal shift + the original's jitter)
+        jit0 = torch.full((Bt, N), 1e-9 if dtype == torch.float64 else 1e-5, dtype=dtype, device=DEV)
+        Lop, UHB, info, _ = ops.refit(X0, UH0, p["Bm"], p["ell"], p["s2"], jit0)
+        assert (info == 0).all()
+        Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N), UH0, p["M0"], want_alpha=False)
+        ref = ops.posterior_query(Lop, Vw, X0, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"], shared=False, want_W=True)
+        g = ops.ReservedGP(Lop, Vw, X0, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], cap)
+        got = g.posterior(p["xq"], want_W=True)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        x_new, uh_new, xd_new = p["X"][:, N].clone(), p["UH"][:, N].clone(), p["Xdot"][:, N].clone()
+        x_new[1], uh_new[1] = X0[1, 7], UH0[1, 7]                  # instance 1: an exact duplicate of point 7 ...
+        jit_new = torch.full((Bt,), 1e-6 if dtype == torch.float64 else 1e-3, dtype=dtype, device=DEV)
+        jit_new[1] = -jit_new[1]                                   # ... with a negative diagonal shift
+        info = g.append(x_new.contiguous(), uh_new.contiguous(), xd_new.contiguous(), jit_new)
+        assert info.cpu().tolist() == [0, N + 1, 0, 0, 0]
+        after = g.posterior(p["xq"])
+        tol = 1e-12 if dtype == torch.float64 else 1e-5
+        for a, b in zip(after, ref[:2]):
+            np.testing.assert_allclose(host(a)[1], host(b)[1], rtol=tol, atol=tol)      # unchanged
+            assert np.abs(host(a)[0] - host(b)[0]).max() > 0                            # the others did learn
+        # the same append through the packed path gives the same state on the healthy instances
+        L2, Vw2, X2, UHB2, info2 = ops.gp_append(Lop, Vw, X0, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], x_new.contiguous(),
+                                                 uh_new.contiguous(), xd_new.contiguous(), jit_new)
+        pk = ops.posterior_step(L2, Vw2, X2, UHB2, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+        for a, b in zip(after, pk):
+            np.testing.assert_allclose(host(a), host(b), rtol=1e-9 if dtype == torch.float64 else 2e-3,
+                                       atol=1e-9 if dtype == torch.float64 else 2e-3)
+        if cap == N + 1:
+            with pytest.raises(RuntimeError):
+                g.append(x_new.contiguous(), uh_new.contiguous(), xd_new.contiguous(), jit_new)
+
+
 # ------------------------------------------------------------------------------------------------ C1
 def test_c1_pendulum_learn_dynamics_matrix_vector_N64(ops):
     """BASELINE config 1 (`pendulum.learn_dynamics_matrix_vector`, N_train = 64): the experiment runs end to end on the

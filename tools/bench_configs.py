@@ -4,22 +4,13 @@ C2: batched kernel build + Cholesky + posterior, N=256, n=2, m=1, batch 1024, fp
 C3 pieces in fp64.  C5: growing N with chol_append."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
 
 
-def timeit(fn, reps=5, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+from _timing import timeit          # warms the clocks up first (tools/_timing.py)
 
 
 def config(Bt, N, n, m, dtype, name):

@@ -7,14 +7,8 @@ import torch
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
 
-def timeit(fn, reps=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import timeit          # warms the clocks up first (tools/_timing.py)
 
 for (Bt, N, n, m, dtype) in ((4096, 512, 2, 1, torch.float32), (4096, 512, 3, 2, torch.float32), (1024, 256, 2, 1, torch.float64)):
     p = make_instances(Bt, N, n, m, dtype=dtype, device="cuda", seed=3)
