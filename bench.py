@@ -56,7 +56,29 @@ def parse():
     ap.add_argument("--regime", choices=["independent", "shared"], default="independent",
                     help="independent: every instance owns its GP (headline, HBM bound); shared: one learned model, "
                          "`batch` closed loops (Monte-Carlo rollouts, BASELINE configs[3]; matrix-core bound)")
-    return ap.parse_args()
+    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
+                    help="c3 (default): this file's headline workload.  c4 / c5: the Monte-Carlo rollouts / online growth "
+                         "harnesses (examples_mc_rollouts.py, tools/bench_online.py) with the same --gpus N launcher; flags "
+                         "this parser does not know are passed on to them")
+    args, rest = ap.parse_known_args()
+    if args.config == "c3" and rest:
+        ap.error("unrecognized arguments: %s" % " ".join(rest))
+    args.rest = rest
+    return args
+
+
+def run_other_config(args):
+    """--config c4 | c5: hand over to that config's harness IN this process (it starts its own ranks for --gpus N, or
+    joins the launcher's job), with its BASELINE.json size as the default."""
+    import runpy
+    if args.config == "c4":
+        script = os.path.join(ROOT, "examples_mc_rollouts.py")
+        argv = ["--gpus", str(args.gpus)] + (args.rest or ["--trajectories", "32768", "--steps", "200", "--graph"])
+    else:
+        script = os.path.join(ROOT, "tools", "bench_online.py")
+        argv = ["--gpus", str(args.gpus)] + args.rest
+    sys.argv = [script] + argv
+    runpy.run_path(script, run_name="__main__")
 
 
 def measured_traffic(N, Bt, dtype_name, bytes_launch):
@@ -157,26 +179,16 @@ def cpu_baseline(p, task, sample, N, n, m):
 
 
 def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) under torch.distributed.run
-    as a CHILD process and exit with its code.  This parent never touches the GPU (no HIP call before or after)."""
-    import socket
-    import subprocess
-    if os.environ.get("BCBF_BENCH_SINGLE_DEVICE") != "1":
-        have = torch.cuda.device_count()          # counting devices does not initialise the runtime
-        if have < args.gpus:
-            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
-            return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.run(cmd, env=env).returncode
+    """`python bench.py --gpus N` without a launcher: N ranks (one process per GPU) under torch.distributed.run as a CHILD
+    process; this parent never touches the GPU (bayesian_cbf_amd.distributed.launch_ranks)."""
+    from bayesian_cbf_amd.distributed import launch_ranks as _launch
+    return _launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)
 
 
 def main():
     args = parse()
+    if args.config != "c3":
+        return run_other_config(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

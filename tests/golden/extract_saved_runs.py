@@ -143,5 +143,32 @@ def main():
         print(name, {k: np.shape(v) for k, v in out.items() if np.ndim(v)}, "tags:", sorted(ev)[:12])
 
 
+LEARNING_RUN = "unicycle_move_to_pose_fixed_learning_helps_avoid_getting_stuck_v1.6.3-1-g5fa08e8"
+
+
+def main_learning():
+    """The committed learning run that also logs the hyper-parameters per step (written with the REAL gpytorch, cvxpy and
+    GUROBI): per step t = 0..199 the state, the control, the kernel parameters as the reference's accessors return them
+    (`get_kernel_param`: A, B, lengthscale, scalefactor, unicycle_move_to_pose.py:975-978) and the logged covariances
+    `Fx_var` = custom_predict_fullmat(x_t)[1] ([9, 9] = kron(B_k, A)) and `Fxu_var` = fu_func_gp(u_t).knl(x_t, x_t) ([3, 3])
+    (:979-982).  Data of the reference, float32 as logged."""
+    rdir = os.path.join(REFERENCE, "docs", "saved-runs", LEARNING_RUN)
+    ev = parse_events(glob.glob(os.path.join(rdir, "events.out.tfevents.*"))[0])
+    cfg = json.load(open(os.path.join(rdir, "config.json")))
+    steps = sorted(ev["vis/state"])
+    st = lambda tag, shape: np.stack([np.asarray(ev[tag][s], dtype=np.float32).reshape(shape) for s in steps])
+    out = dict(steps=np.array(steps), state=st("vis/state", (3,)), uopt=st("vis/uopt", (2,)), xtp1=st("vis/xtp1", (3,)),
+               knl_A=st("vis/knl_A", (3, 3)), knl_B=st("vis/knl_B", (3, 3)), knl_lengthscale=st("vis/knl_lengthscale", (3,)),
+               knl_scalefactor=st("vis/knl_scalefactor", ()), Fx_var=st("vis/Fx_var", (9, 9)), Fxu_var=st("vis/Fxu_var", (3, 3)),
+               dt=cfg["dt"], numSteps=cfg["numSteps"], train_every_n_steps=cfg["train_every_n_steps"],
+               mean_L=cfg["mean_dynamics_gen"]["L"], true_L=cfg["true_dynamics_gen"]["L"],
+               max_risk=cfg["controller_class"]["max_risk"])
+    np.savez_compressed(os.path.join(HERE, "saved_run_learning_v1p6p3.npz"), **out)
+    print("saved_run_learning_v1p6p3", {k: np.shape(v) for k, v in out.items() if np.ndim(v)})
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    if "learning" in sys.argv:
+        sys.exit(main_learning())
+    main()
+    sys.exit(main_learning())

@@ -53,9 +53,12 @@ def test_shard_range_covers_everything():
 def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
     """`python bench.py --gpus 2` on a box without 2 GPUs: the launcher parent exits 2 before any rank starts."""
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
-                         text=True, timeout=300)
+    import pytest
     if torch.cuda.device_count() >= 2:
-        return
-    assert res.returncode == 2 and "only" in res.stderr
+        pytest.skip("two GPUs are visible: `bench.py --gpus 2` would run the full workload")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for script, extra in (("bench.py", []), ("bench.py", ["--config", "c4"]), ("bench.py", ["--config", "c5"]),
+                          ("examples_mc_rollouts.py", []), (os.path.join("tools", "bench_online.py"), [])):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"] + extra, env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert res.returncode == 2 and "only" in res.stderr, (script, extra, res.returncode, res.stderr[-500:])

@@ -62,3 +62,49 @@ def test_gpus_2_launches_two_ranks_itself():
     ms = out["comm"]["per_rank_ms_per_step"]
     assert len(ms) == 2 and abs(max(ms) - out["ms_per_step"]) < 1e-6
     assert abs(out["value"] - 2 * 256 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-9
+
+
+def _run_script(script, args, extra_env, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, env=env, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+TWO_RANKS_ONE_DEVICE = {"BCBF_BENCH_SINGLE_DEVICE": "1", "BCBF_BENCH_BACKEND": "gloo"}
+
+
+def test_c4_rollouts_two_ranks_equal_one_rank_statistics():
+    """BASELINE configs[3] harness: `--gpus 2` starts two ranks itself; each runs its contiguous shard of the trajectories,
+    one final reduction: counts add up to the one-rank job's, no collision / solver failure on either, the reported time is
+    the slowest rank's; `bench.py --config c4 --gpus 2` is the same harness."""
+    args = ["--trajectories", "128", "--steps", "25"]
+    one = _run_script("examples_mc_rollouts.py", args, {})
+    two = _run_script("examples_mc_rollouts.py", ["--gpus", "2"] + args, TWO_RANKS_ONE_DEVICE)
+    assert two["n_gpus"] == 2 and two["comm"]["world_size"] == 2 and two["comm"]["backend"] == "gloo"
+    assert len(two["comm"]["per_rank_seconds"]) == 2 and abs(max(two["comm"]["per_rank_seconds"]) - two["seconds"]) < 1e-9
+    assert two["count"] == one["count"] == 128 and two["solver_failures"] == one["solver_failures"] == 0
+    assert two["collisions"] == one["collisions"] == 0
+    assert two["min_h"] > 0 and abs(two["trajectory_steps_per_s"] - 128 * 25 / two["seconds"]) < 1e-6 * two["trajectory_steps_per_s"]
+    via_bench = _run_script("bench.py", ["--config", "c4", "--gpus", "2"] + args, TWO_RANKS_ONE_DEVICE)
+    assert via_bench["n_gpus"] == 2 and via_bench["count"] == 128
+
+
+def test_c5_online_growth_two_ranks():
+    """BASELINE configs[4] harness with two ranks (weak scaling: `--batch` instances per rank): per-segment times are the
+    slowest rank's, failures add up, the end-to-end deviation is the worst rank's."""
+    args = ["--batch", "8", "--n0", "40", "--n1", "100"]
+    two = _run_script(os.path.join("tools", "bench_online.py"), ["--gpus", "2"] + args, TWO_RANKS_ONE_DEVICE)
+    assert two["n_gpus"] == 2 and two["comm"]["world_size"] == 2 and two["scaling"] == "weak" and two["batch_per_gpu"] == 8
+    assert two["append_failures"] == 0 and two["refit_failures"] == 0
+    assert two["final_vs_refit"]["Mk"] < 1e-8 and two["final_vs_refit"]["Bk"] < 1e-8
+    assert [s["N_from"] for s in two["segments"]] == [40] and two["segments"][0]["append_ms"] > 0
+    assert abs(two["instance_appends_per_s"] - 60 * 8 * 2 / two["seconds"]) < 1e-6 * two["instance_appends_per_s"]
+    one = _run_script("bench.py", ["--config", "c5"] + args, {})
+    assert one["n_gpus"] == 1 and one["comm"]["world_size"] == 1 and one["final_vs_refit"]["Mk"] < 1e-8
