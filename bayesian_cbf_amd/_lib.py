@@ -23,10 +23,13 @@ _SIGS = {
     "bcbf_controller_cones_rows": (c_int, [ctypes.POINTER(c_int), c_int, c_int, c_int]),
     "bcbf_controller_cones_f32": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_f64": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
+    "bcbf_mll_grad_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bcbf_coneqp_f64": (c_int, [P, P, P, P, c_int, c_int, ctypes.POINTER(c_int), c_int, P, P, P, c_int, c_int, P]),
 }
 _TSIGS = {
     "bcbf_kb_build": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_kb_build_matern52": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_query_matern52": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_refit": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_potrf": [P, P, P, P, c_int, c_int, P],
     "bcbf_potrs": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
@@ -38,10 +41,11 @@ _TSIGS = {
     "bcbf_gp_append_reserved": [P] * 16 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_potri": [P, P, c_int, c_int, P],
     "bcbf_trtri": [P, P, c_int, c_int, P],
-    "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],
+    "bcbf_syrk_lt": [P, P, c_int, c_int, P],
     "bcbf_kb_build_rbflin": [P] * 8 + [c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query_rbflin": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
-    "bcbf_mll_grad_rbflin": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_mll_grad_rbflin": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P, P],
     "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_jets": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],

@@ -99,6 +99,8 @@ def posterior_for(reg, xb, jets):
         CT = C * (1 + n)
         return hp, Mk, Bk, xb.new_zeros(b, CT, CT), xb.new_zeros(b, n, CT)
     st = reg._state()
+    if jets:
+        reg._require_rbf("the derivative GP (rel-degree-2 conditions)")
     if not jets:
         _, Mk, Bk, _ = reg._query(xb, want_W=False)
         return st, Mk, Bk, None, None

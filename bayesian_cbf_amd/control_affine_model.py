@@ -113,7 +113,14 @@ class ControlAffineRegressor:
     ground_truth = False
 
     def __init__(self, x_dim, u_dim, device=None, default_device=default_device,
-                 gamma_length_scale_prior=None, model_class=None, rank=None, dtype=None, generator=None):
+                 gamma_length_scale_prior=None, model_class=None, rank=None, dtype=None, generator=None,
+                 data_kernel="rbf"):
+        """data_kernel: "rbf" (the reference's ScaleKernel(RBFKernel(ard)), :164-171) or the OPT-IN "matern52"
+        (ScaleKernel(MaternKernel(nu=2.5, ard)); no reference counterpart, parity unpinned, bcbf.h): prediction only --
+        hyper-parameters by value (`set_kernel_params`), no `fit` iterations, no `append_data`, no derivative GP."""
+        if data_kernel not in ops.DATA_KERNELS:
+            raise ValueError("data_kernel %r: one of %s" % (data_kernel, ops.DATA_KERNELS))
+        self.data_kernel = data_kernel
         self.device = torch.device(device or default_device())
         self.x_dim, self.u_dim = x_dim, u_dim
         self.model = KernelParams(x_dim, u_dim, rank=rank, dtype=dtype).to(self.device)
@@ -166,6 +173,11 @@ class ControlAffineRegressor:
         if isinstance(X, np.ndarray):
             X = torch.from_numpy(X)
         return X.to(device=self.device, dtype=self.dtype)
+
+    def _require_rbf(self, what):
+        if self.data_kernel != "rbf":
+            raise NotImplementedError("%s is built for the reference's RBF data kernel; the opt-in %r kernel offers "
+                                      "prediction only (bcbf.h)" % (what, self.data_kernel))
 
     def _require_gpu(self):
         if self.device.type != "cuda":
@@ -280,6 +292,7 @@ class ControlAffineRegressor:
         if training_iter <= 0:
             return self
         self._require_gpu()
+        self._require_rbf("fit(training_iter > 0): the likelihood gradient")
         params = [p for p in self.model.parameters() if p.requires_grad]
         optimizer = torch.optim.Adam(params, lr=lr)
         scheduler = torch.optim.lr_scheduler.MultiStepLR(
@@ -313,6 +326,7 @@ class ControlAffineRegressor:
         if self.Xtrain is None:
             return self.fit(Xn, Un, Yn, training_iter=0)
         self._require_gpu()
+        self._require_rbf("append_data (bcbf_gp_append forms the new kernel column)")
         st = self._state()                                    # builds it if the cache was cleared
         ones = torch.ones(1, 1, dtype=self.dtype, device=self.device)
         for i in range(Xn.shape[0]):
@@ -412,7 +426,12 @@ class ControlAffineRegressor:
         factor = cholesky_perturb_init
         for ntry in range(cholesky_tries):
             jitter = factor * self.rand_fn(N)
-            Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous())
+            if self.data_kernel == "rbf":
+                Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous())
+            else:                   # opt-in kernels: dense K_b, then the factorisation of a caller-supplied matrix
+                Kb = ops.kb_build(X, UH, hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous(), kernel=self.data_kernel)
+                Lop, info, _ = ops.potrf(Kb)
+                UHB = (UH @ hp["Bm"]).contiguous()
             if int(info[0]) == 0:
                 break
             if ntry == cholesky_tries - 1:
@@ -421,7 +440,7 @@ class ControlAffineRegressor:
         # only the whitened targets Vw = L^-1 Y enter the posterior (alpha = K_b^-1 Y is the fit's business): skip
         # the backward substitution
         Vw, _ = ops.potrs(Lop, self.XdotTrain[None], UH, hp["M0"], want_alpha=False)
-        st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, N=N, jitter=jitter[None].contiguous())
+        st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, N=N, jitter=jitter[None].contiguous(), kernel=self.data_kernel)
         self._cache["state"] = st
         return st
 
@@ -429,7 +448,7 @@ class ControlAffineRegressor:
         """Dense L = chol(K_b + jitter) (the matrix the reference caches, :379-385), from the cached state."""
         st = self._state()
         if "L" not in st:
-            Kb = ops.kb_build(st["X"], st["UH"], st["Bm"], st["ell"], st["s2"], st["jitter"])
+            Kb = ops.kb_build(st["X"], st["UH"], st["Bm"], st["ell"], st["s2"], st["jitter"], kernel=self.data_kernel)
             _, info, Ld = ops.potrf(Kb, want_dense=True)
             st["L"] = Ld[0]
         return st["L"]
@@ -446,13 +465,16 @@ class ControlAffineRegressor:
     def _query(self, Xtest, want_W):
         st = self._state()
         Mk, Bk, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
-                                        st["M0"], Xtest.contiguous(), shared=True, want_W=want_W)
+                                        st["M0"], Xtest.contiguous(), shared=True, want_W=want_W, kernel=self.data_kernel)
         return st, Mk, Bk, W
 
     def _prior_knl(self, X1, X2):
         m = self.model
         with torch.no_grad():
             d = (X1[:, None, :] - X2[None, :, :]) / m.lengthscale.detach().reshape(1, 1, -1)
+            if self.data_kernel == "matern52":
+                a = torch.sqrt(5.0 * (d * d).sum(-1))
+                return m.outputscale.detach() * (1.0 + a + a * a / 3.0) * torch.exp(-a)
             return m.outputscale.detach() * torch.exp(-0.5 * (d * d).sum(-1))
 
     def custom_predict(self, Xtest_in, Utest_in=None, UHfill=1, Xtestp_in=None, Utestp_in=None, UHfillp=1,

@@ -15,6 +15,30 @@ constexpr int MG_T = 256;
 // CM = compile-time bound on the columns of UH: BCBF_MAX_CTRL_DIM + 1 for the matrix-variate model, BCBF_MAX_TASK_DIM
 // for the expanded CoGP system with more than four task outputs (a comparator: one workgroup, registers to spare)
 
+// output slot o of the MG_MAXOUT sums of one model -> its place in the gradient arrays
+template <typename T, int CM>
+__device__ inline void mll_store(int o, double v, int b, int n, int C, T* g_ell, T* g_s2, T* g_B, T* g_lin) {
+    constexpr int NR = BCBF_MAX_STATE_DIM + 2 + CM * CM;
+    if (o < BCBF_MAX_STATE_DIM) { if (o < n) g_ell[(size_t)b * n + o] = (T)v; }
+    else if (o == BCBF_MAX_STATE_DIM) g_s2[b] = (T)v;
+    else if (o == NR - 1) { if (g_lin != nullptr) g_lin[b] = (T)v; }
+    else {
+        const int q = o - BCBF_MAX_STATE_DIM - 1, a = q / CM, c = q % CM;
+        if (a < C && c < C) g_B[((size_t)b * C + a) * C + c] = (T)v;
+    }
+}
+
+// second launch of the split form: the G partial sums of every output, added in the order part = 0 .. G-1
+template <typename T, int CM>
+__global__ void mll_reduce_kernel(const double* __restrict__ work, int G, int n, int C, T* g_ell, T* g_s2, T* g_B, T* g_lin) {
+    constexpr int NR = BCBF_MAX_STATE_DIM + 2 + CM * CM;
+    const int b = blockIdx.x, o = threadIdx.x;
+    if (o >= NR) return;
+    double v = 0.0;
+    for (int part = 0; part < G; ++part) v += work[((size_t)b * G + part) * NR + o];
+    mll_store<T, CM>(o, v, b, n, C, g_ell, g_s2, g_B, g_lin);
+}
+
 template <typename T, int CM>
 __global__ void __launch_bounds__(MG_T)
 mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T* __restrict__ Kinv,
@@ -22,14 +46,16 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
                 const T* __restrict__ Bm, const T* __restrict__ ell, const T* __restrict__ s2p,
                 T* __restrict__ g_ell, T* __restrict__ g_s2, T* __restrict__ g_B, T* __restrict__ logdetK,
                 T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C, int nt,
-                const T* __restrict__ lin, T* __restrict__ g_lin) {
+                const T* __restrict__ lin, T* __restrict__ g_lin, double* __restrict__ work) {
     // nt = number of target columns of R / alpha / A (== n for the matrix-variate model; 1 for the expanded
     // CoGP system); lin (optional) = weight of the linear part of the data kernel, k = exp(..) + lin x'x'.
     constexpr int V = Vec<T>::V;
     constexpr int MG_MAXOUT = BCBF_MAX_STATE_DIM + 2 + CM * CM;
     __shared__ double red[4][MG_MAXOUT];
     // grid (Bt, G): the N^2 pair terms of one GP are split over G workgroups (a fit is ONE model: a single workgroup
-    // left 255 CUs idle for 2 ms at N = 512); partial sums are added atomically into outputs the launcher has zeroed
+    // left 255 CUs idle for 2 ms at N = 512).  G > 1: every workgroup writes its partial sums (fp64) to the caller's
+    // workspace, work[(b G + part) NR + o], and mll_reduce_kernel adds them IN A FIXED ORDER -- two launches of the same
+    // inputs give bit-identical gradients (float atomics, the first form of this split, did not)
     const int b = blockIdx.x, tid = threadIdx.x, part = blockIdx.y, G = gridDim.y;
     const T* Xb = X + (size_t)b * N * n;
     const T* UHb = UH + (size_t)b * N * C;
@@ -116,18 +142,8 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     __syncthreads();
     if (tid < NR) {
         const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        T* dst = nullptr;
-        if (tid < BCBF_MAX_STATE_DIM) { if (tid < n) dst = g_ell + (size_t)b * n + tid; }
-        else if (tid == BCBF_MAX_STATE_DIM) dst = g_s2 + b;
-        else if (tid == NR - 1) { if (g_lin != nullptr) dst = g_lin + b; }
-        else {
-            const int o = tid - BCBF_MAX_STATE_DIM - 1, a = o / CM, c = o % CM;
-            if (a < C && c < C) dst = g_B + ((size_t)b * C + a) * C + c;
-        }
-        if (dst != nullptr) {
-            if (G == 1) *dst = (T)v;
-            else atomicAdd(dst, (T)v);
-        }
+        if (G > 1) work[((size_t)b * G + part) * NR + tid] = v;
+        else mll_store<T, CM>(tid, v, b, n, C, g_ell, g_s2, g_B, g_lin);
     }
     if (part != 0) return;
     // ---- phase 2: the small products (one output per thread, a loop over the N rows) and logdet (last wave)
@@ -149,10 +165,18 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     }
 }
 
+// workgroups per model of the split form (0 < Bt < 64 models: ~32 pair terms per thread, at most 128 workgroups)
+static int mll_split(int Bt, int N) {
+    if (Bt >= 64) return 1;
+    const long long per_wg = (long long)MG_T * 32;
+    long long G = ((long long)N * N + per_wg - 1) / per_wg;
+    return (int)(G > 128 ? 128 : (G < 1 ? 1 : G));
+}
+
 template <typename T>
 static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T* X, const T* UH, const T* R,
                            const T* Ainv, const T* Bm, const T* ell, const T* s2, T* g_ell, T* g_s2, T* g_B, T* logdetK,
-                           T* RtA, T* UHtA, int Bt, int N, int n, int m, void* stream, int nt = -1,
+                           T* RtA, T* UHtA, int Bt, int N, int n, int m, void* stream, void* work, int nt = -1,
                            const T* lin = nullptr, T* g_lin = nullptr) {
     if (nt < 0) nt = n;
     if (Bt <= 0) return BCBF_OK;
@@ -162,48 +186,51 @@ static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T*
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m + 1 > BCBF_MAX_TASK_DIM || nt < 1 || nt > BCBF_MAX_STATE_DIM)
         return BCBF_EINVAL;
     if ((m + 1) * nt > 128) return BCBF_EINVAL;                    // phase 2: one thread per entry of UH' alpha
-    // few models: spread each one's pair terms over G workgroups (partials meet in zeroed outputs by atomic adds)
-    int G = 1;
-    if (Bt < 64) {
-        const long long per_wg = (long long)MG_T * 32;             // ~32 pairs per thread
-        G = (int)(((long long)N * N + per_wg - 1) / per_wg);
-        if (G > 128) G = 128;
-        if (G < 1) G = 1;
+    // few models: spread each one's pair terms over G workgroups (needs the caller's workspace for the partial sums;
+    // without one the model stays on one workgroup)
+    const int G = work != nullptr ? mll_split(Bt, N) : 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (m <= BCBF_MAX_CTRL_DIM) {
+        constexpr int CM = BCBF_MAX_CTRL_DIM + 1;
+        hipLaunchKernelGGL((mll_grad_kernel<T, CM>), dim3(Bt, G), dim3(MG_T), 0, st, Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell,
+                           s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin, g_lin, (double*)work);
+        if (G > 1)
+            hipLaunchKernelGGL((mll_reduce_kernel<T, CM>), dim3(Bt), dim3(64), 0, st, (const double*)work, G, n, m + 1, g_ell,
+                               g_s2, g_B, g_lin);
+    } else {
+        constexpr int CM = BCBF_MAX_TASK_DIM;
+        hipLaunchKernelGGL((mll_grad_kernel<T, CM>), dim3(Bt, G), dim3(MG_T), 0, st, Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell,
+                           s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin, g_lin, (double*)work);
+        if (G > 1)
+            hipLaunchKernelGGL((mll_reduce_kernel<T, CM>), dim3(Bt), dim3(192), 0, st, (const double*)work, G, n, m + 1, g_ell,
+                               g_s2, g_B, g_lin);
     }
-    if (G > 1) {
-        const int C = m + 1;
-        (void)hipMemsetAsync(g_ell, 0, sizeof(T) * (size_t)Bt * n, (hipStream_t)stream);
-        (void)hipMemsetAsync(g_s2, 0, sizeof(T) * (size_t)Bt, (hipStream_t)stream);
-        (void)hipMemsetAsync(g_B, 0, sizeof(T) * (size_t)Bt * C * C, (hipStream_t)stream);
-        if (g_lin) (void)hipMemsetAsync(g_lin, 0, sizeof(T) * (size_t)Bt, (hipStream_t)stream);
-    }
-    if (m <= BCBF_MAX_CTRL_DIM)
-        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_CTRL_DIM + 1>), dim3(Bt, G), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
-                           X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt,
-                           lin, g_lin);
-    else
-        hipLaunchKernelGGL((mll_grad_kernel<T, BCBF_MAX_TASK_DIM>), dim3(Bt, G), dim3(MG_T), 0, (hipStream_t)stream, Lop, alpha, Kinv,
-                           X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt,
-                           lin, g_lin);
     return check_launch("mll_grad");
 }
 
 }  // namespace bcbf
 
 extern "C" {
+// bytes of the workspace `work` of bcbf_mll_grad* (partial sums of the split form; 0 = one workgroup per model anyway)
+size_t bcbf_mll_grad_work_bytes(int Bt, int N, int m) {
+    if (Bt <= 0 || N < 1 || m < 1) return 0;
+    const int G = bcbf::mll_split(Bt, N);
+    const int CM = m <= BCBF_MAX_CTRL_DIM ? BCBF_MAX_CTRL_DIM + 1 : BCBF_MAX_TASK_DIM;
+    return G > 1 ? sizeof(double) * (size_t)Bt * G * (BCBF_MAX_STATE_DIM + 2 + CM * CM) : 0;
+}
 int bcbf_mll_grad_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
                       const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
                       float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
-                      void* stream) {
+                      void* work, void* stream) {
     return bcbf::launch_mll_grad<float>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
-                                        UHtA, Bt, N, n, m, stream);
+                                        UHtA, Bt, N, n, m, stream, work);
 }
 int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
                       const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
                       double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
-                      int n, int m, void* stream) {
+                      int n, int m, void* work, void* stream) {
     return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
-                                         UHtA, Bt, N, n, m, stream);
+                                         UHtA, Bt, N, n, m, stream, work);
 }
 // Same sums for the data kernel s2 (exp(..) + lin x'x') and nt target columns (R, alpha [Bt,N,nt], Ainv [Bt,nt,nt],
 // RtA [Bt,nt,nt], UHtA [Bt,C,nt]); g_lin[Bt] = d log p / d lin.  nt = 1 with expanded inputs is the CoGP comparator
@@ -211,16 +238,16 @@ int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv
 int bcbf_mll_grad_rbflin_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
                              const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2,
                              const float* lin, float* g_ell, float* g_s2, float* g_lin, float* g_B, float* logdetK,
-                             float* RtA, float* UHtA, int Bt, int N, int n, int m, int nt, void* stream) {
+                             float* RtA, float* UHtA, int Bt, int N, int n, int m, int nt, void* work, void* stream) {
     return bcbf::launch_mll_grad<float>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
-                                        UHtA, Bt, N, n, m, stream, nt, lin, g_lin);
+                                        UHtA, Bt, N, n, m, stream, work, nt, lin, g_lin);
 }
 int bcbf_mll_grad_rbflin_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X,
                              const double* UH, const double* R, const double* Ainv, const double* Bm, const double* ell,
                              const double* s2, const double* lin, double* g_ell, double* g_s2, double* g_lin,
                              double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N, int n, int m,
-                             int nt, void* stream) {
+                             int nt, void* work, void* stream) {
     return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
-                                         UHtA, Bt, N, n, m, stream, nt, lin, g_lin);
+                                         UHtA, Bt, N, n, m, stream, work, nt, lin, g_lin);
 }
 }

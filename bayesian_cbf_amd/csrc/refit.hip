@@ -16,7 +16,7 @@ template <> __device__ inline double texp2<double>(double x) { return exp(x); }
 template <typename T>
 __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                                 const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
-                                T* __restrict__ Kb, int N, int n, int C, const T* __restrict__ lin) {
+                                T* __restrict__ Kb, int N, int n, int C, const T* __restrict__ lin, int kind) {
     const int b = blockIdx.y;
     const int i = blockIdx.x;
     const T* Xb = X + (size_t)b * N * n;
@@ -41,7 +41,10 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
 #pragma unroll
         for (int a = 0; a < BCBF_MAX_TASK_DIM; ++a)
             if (a < C) uu += ub[a] * UHb[(size_t)j * C + a];
-        T val = s2 * (texp2<T>(T(-0.5) * d2) + linv * dot) * uu;
+        // kind 0: RBF exp(-d2 / 2) (the reference's data kernel);  kind 1: Matern-5/2 (opt-in, bcbf.h)
+        const T a5 = (T)sqrt((double)(T(5) * d2));
+        const T shape = kind == 1 ? (T(1) + a5 + T(5) / T(3) * d2) * texp2<T>(-a5) : texp2<T>(T(-0.5) * d2);
+        T val = s2 * (shape + linv * dot) * uu;
         if (i == j && jitter) val += jitter[(size_t)b * N + i];
         Kb[((size_t)b * N + i) * N + j] = val;
     }
@@ -49,12 +52,12 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
 
 template <typename T>
 static int launch_kb_build(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,
-                           T* Kb, int Bt, int N, int n, int m, void* stream, const T* lin = nullptr) {
+                           T* Kb, int Bt, int N, int n, int m, void* stream, const T* lin = nullptr, int kind = 0) {
     if (Bt <= 0) return BCBF_OK;
     if (!X || !UH || !Bm || !ell || !s2 || !Kb) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m + 1 > BCBF_MAX_TASK_DIM) return BCBF_EINVAL;
     hipLaunchKernelGGL((kb_build_kernel<T>), dim3(N, Bt), dim3(256), 0, (hipStream_t)stream, X, UH, Bm, ell, s2,
-                       jitter, Kb, N, n, m + 1, lin);
+                       jitter, Kb, N, n, m + 1, lin, kind);
     return check_launch("kb_build");
 }
 
@@ -80,6 +83,14 @@ int bcbf_kb_build_rbflin_f64(const double* X, const double* UH, const double* Bm
                              const double* lin, const double* jitter, double* Kb, int Bt, int N, int n, int m,
                              void* stream) {
     return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, lin);
+}
+int bcbf_kb_build_matern52_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                               const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_kb_build<float>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, nullptr, 1);
+}
+int bcbf_kb_build_matern52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                               const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, nullptr, 1);
 }
 // both precisions factor on the matrix cores (refit_mfma.hip, refit_mfma64.hip)
 extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,

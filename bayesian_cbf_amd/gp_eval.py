@@ -97,6 +97,8 @@ class _ModelJets:
         f = dict(dtype=pts.dtype, device=pts.device)
         self.f = f
         fixed = isinstance(reg, FixedKernelGP)
+        if not fixed and hasattr(reg, "_require_rbf"):
+            reg._require_rbf("node-by-node evaluation of GP expression trees (analytic RBF derivatives)")
         hp = reg._hyper() if (fixed or reg.Xtrain is None) else reg._state()
         self.A = hp["A"][0]
         B, ell, s2 = hp["Bm"][0], hp["ell"][0], hp["s2"][0]

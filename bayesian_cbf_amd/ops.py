@@ -46,13 +46,25 @@ def lop_elems(N, dtype):
     return int(getattr(lib, "bcbf_lop_elems" + _SUF[dtype])(N))
 
 
-def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None):
+DATA_KERNELS = ("rbf", "matern52")
+
+
+def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None, kernel="rbf"):
     """K_b[Bt,N,N]  (control_affine_model.py:370-372 + make_psd diagonal :907-910); lin[Bt] adds the linear part of
-    the CoGP comparator's data kernel, k = s2 (exp(..) + lin x'x') (:1121-1122)."""
+    the CoGP comparator's data kernel, k = s2 (exp(..) + lin x'x') (:1121-1122).  kernel="matern52": the opt-in
+    Matern-5/2 data kernel (bcbf.h; parity unpinned -- the reference has no Matern kernel)."""
     _chk(X, UH, Bm, ell, s2, jitter, lin)
     Bt, N, n = X.shape
     m = UH.shape[2] - 1
     Kb = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device)
+    if kernel not in DATA_KERNELS:
+        raise ValueError("data kernel %r: one of %s" % (kernel, DATA_KERNELS))
+    if kernel == "matern52":
+        if lin is not None:
+            raise ValueError("the Matern-5/2 option has no linear part")
+        check(getattr(lib, "bcbf_kb_build_matern52" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Kb),
+                                                               Bt, N, n, m, _stream(X)), "bcbf_kb_build_matern52")
+        return Kb
     if lin is not None:
         check(getattr(lib, "bcbf_kb_build_rbflin" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(lin), _p(jitter),
                                                              _p(Kb), Bt, N, n, m, _stream(X)), "bcbf_kb_build_rbflin")
@@ -219,17 +231,35 @@ class ReservedGP:
 
 
 def kb_inverse(Lop, N, gemm=True):
-    """Dense K_b^-1 [Bt,N,N] from the packed factor (fit path only).  gemm=True: L^-1 from bcbf_trtri (the forward half
-    of the solve) and K_b^-1 = L^-T L^-1 as one library GEMM; gemm=False: bcbf_potri (forward + backward solves of the
-    identity: its backward half is latency bound, 2 ms at N = 512 for one model against 0.3 ms this way)."""
+    """Dense K_b^-1 [Bt,N,N] from the packed factor (fit path only).  gemm=True: L^-1 from bcbf_trtri (the forward half of
+    the solve) and K_b^-1 = L^-T L^-1 on the matrix cores (bcbf_syrk_lt: 32 x 32 tiles of the triangular product);
+    gemm=False: bcbf_potri (forward + backward solves of the identity: its backward half is latency bound, 2 ms at
+    N = 512 for one model against 0.3 ms this way)."""
     _chk(Lop)
     Bt = Lop.shape[0]
     Kinv = torch.empty(Bt, N, N, dtype=Lop.dtype, device=Lop.device)
     if gemm:
-        check(getattr(lib, "bcbf_trtri" + _suf(Lop))(_p(Lop), _p(Kinv), Bt, N, _stream(Lop)), "bcbf_trtri")
-        return torch.matmul(Kinv.transpose(1, 2), Kinv)
+        Linv = torch.empty(Bt, N, N, dtype=Lop.dtype, device=Lop.device)
+        check(getattr(lib, "bcbf_trtri" + _suf(Lop))(_p(Lop), _p(Linv), Bt, N, _stream(Lop)), "bcbf_trtri")
+        check(getattr(lib, "bcbf_syrk_lt" + _suf(Lop))(_p(Linv), _p(Kinv), Bt, N, _stream(Lop)), "bcbf_syrk_lt")
+        return Kinv
     check(getattr(lib, "bcbf_potri" + _suf(Lop))(_p(Lop), _p(Kinv), Bt, N, _stream(Lop)), "bcbf_potri")
     return Kinv
+
+
+_MLL_WORK = {}
+
+
+def _mll_work(Bt, N, m, device):
+    """Workspace of bcbf_mll_grad's split form (partial sums; reused between the iterations of a fit)."""
+    nbytes = int(lib.bcbf_mll_grad_work_bytes(Bt, N, m))
+    if nbytes == 0:
+        return None
+    key = (str(device), nbytes)
+    if key not in _MLL_WORK:
+        _MLL_WORK.clear()
+        _MLL_WORK[key] = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+    return _MLL_WORK[key]
 
 
 def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None):
@@ -246,14 +276,15 @@ def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None):
         logdet, RtA, UHtA = torch.empty(Bt, **f), torch.empty(Bt, nt, nt, **f), torch.empty(Bt, C, nt, **f)
         check(getattr(lib, "bcbf_mll_grad_rbflin" + _suf(X))(
             _p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm), _p(ell), _p(s2), _p(lin), _p(g_ell),
-            _p(g_s2), _p(g_lin), _p(g_B), _p(logdet), _p(RtA), _p(UHtA), Bt, N, n, C - 1, nt, _stream(X)),
-            "bcbf_mll_grad_rbflin")
+            _p(g_s2), _p(g_lin), _p(g_B), _p(logdet), _p(RtA), _p(UHtA), Bt, N, n, C - 1, nt,
+            _p(_mll_work(Bt, N, C - 1, X.device)), _stream(X)), "bcbf_mll_grad_rbflin")
         return g_ell, g_s2, g_B, logdet, RtA, UHtA, g_lin
     g_ell, g_s2, g_B = torch.empty(Bt, n, **f), torch.empty(Bt, **f), torch.empty(Bt, C, C, **f)
     logdet, RtA, UHtA = torch.empty(Bt, **f), torch.empty(Bt, n, n, **f), torch.empty(Bt, C, n, **f)
     check(getattr(lib, "bcbf_mll_grad" + _suf(X))(_p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm),
                                                   _p(ell), _p(s2), _p(g_ell), _p(g_s2), _p(g_B), _p(logdet), _p(RtA),
-                                                  _p(UHtA), Bt, N, n, C - 1, _stream(X)), "bcbf_mll_grad")
+                                                  _p(UHtA), Bt, N, n, C - 1, _p(_mll_work(Bt, N, C - 1, X.device)),
+                                                  _stream(X)), "bcbf_mll_grad")
     return g_ell, g_s2, g_B, logdet, RtA, UHtA
 
 
@@ -273,9 +304,10 @@ def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None)
     return Mk, Bk
 
 
-def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=True, want_W=False, lin=None):
+def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=True, want_W=False, lin=None, kernel="rbf"):
     """b queries against one shared GP (shared=True; GP tensors carry a leading axis of 1) or one query per
-    instance.  Returns (Mk[b,n,C], Bk[b,C,C], W[b,Np,C] | None).  lin: linear part of the data kernel (CoGP)."""
+    instance.  Returns (Mk[b,n,C], Bk[b,C,C], W[b,Np,C] | None).  lin: linear part of the data kernel (CoGP);
+    kernel="matern52": the opt-in Matern-5/2 data kernel (streaming kernel)."""
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, lin)
     N, n = X.shape[1], X.shape[2]
     C = UHB.shape[2]
@@ -286,6 +318,15 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
     Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
     Np = (N + 31) // 32 * 32
     W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
+    if kernel == "matern52":
+        if lin is not None:
+            raise ValueError("the Matern-5/2 option has no linear part")
+        check(getattr(lib, "bcbf_posterior_query_matern52" + _suf(X))(
+            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk), _p(W),
+            1 if shared else 0, b, N, n, C - 1, _stream(X)), "bcbf_posterior_query_matern52")
+        return Mk, Bk, W
+    if kernel != "rbf":
+        raise ValueError("data kernel %r: one of %s" % (kernel, DATA_KERNELS))
     if lin is not None:
         check(getattr(lib, "bcbf_posterior_query_rbflin" + _suf(X))(
             _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(lin), _p(Bm), _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk),

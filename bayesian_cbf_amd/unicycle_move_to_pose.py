@@ -297,6 +297,7 @@ class LearnedShiftInvariantDynamics:
         reg = self.learned_dynamics
         if not self.enable_learning or reg.Xtrain is None:
             return None
+        reg._require_rbf("the fused control step")
         st = reg._state()
         return {k: st[k] for k in ("Lop", "Vw", "X", "UHB", "ell", "s2", "Bm", "M0", "A")}
 

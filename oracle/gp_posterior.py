@@ -34,6 +34,18 @@ def rbf_ard_kernel(X1, X2, ell, s2):
     return s2 * np.exp(-0.5 * np.sum(d * d, axis=-1))
 
 
+def matern52_ard_kernel(X1, X2, ell, s2):
+    """OPT-IN data kernel (no reference counterpart -- the reference has no Matern kernel; PARITY UNPINNED):
+    gpytorch `ScaleKernel(MaternKernel(nu=2.5, ard_num_dims=n))`, restated from its published definition:
+    k = s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r),  r = |(x - x') / ell|.  Checked against scikit-learn's
+    `Matern(nu=2.5)` (an independent implementation) in tests/test_oracle_formulas.py."""
+    X1, X2 = np.atleast_2d(X1), np.atleast_2d(X2)
+    d = (X1[:, None, :] - X2[None, :, :]) / np.asarray(ell, dtype=np.float64).reshape(1, 1, -1)
+    r = np.sqrt((d * d).sum(-1))
+    a = np.sqrt(5.0) * r
+    return s2 * (1.0 + a + 5.0 / 3.0 * r * r) * np.exp(-a)
+
+
 def index_kernel_covar(covar_factor, raw_var):
     """gpytorch IndexKernel.covar_matrix = F F^T + diag(softplus(raw_var)); used for A and B
     (bayes_cbf/matrix_variate_multitask_kernel.py:37-41, control_affine_model.py:158-163)."""

@@ -901,3 +901,129 @@ def test_programs_with_more_than_four_cones_vs_oracle(ops, dtype, K):
         assert sol["status"] == "optimal"
         np.testing.assert_allclose(yh[i], sol["x"], rtol=1e-6 if dtype == torch.float64 else 1e-5,
                                    atol=1e-7 if dtype == torch.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
+    """The OPT-IN Matern-5/2 data kernel (bcbf_kb_build_matern52 -> bcbf_potrf -> bcbf_potrs ->
+    bcbf_posterior_query_matern52) against the oracle's formula (which is checked against scikit-learn's Matern):
+    dense K_b, and posterior M_k / B_k / W for per-instance queries and for queries of one shared model."""
+    import scipy.linalg as sla
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, N, n, m = 4, 70, 3, 2
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=12)
+    f64 = dtype == torch.float64
+    jit = p["jitter"] if f64 else (p["jitter"] * 100).contiguous()
+    Kb = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+    Lop, info, _ = ops.potrf(Kb)
+    assert (info == 0).all()
+    UHB = (p["UH"] @ p["Bm"]).contiguous()
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    Mk, Bk, W = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"], shared=False,
+                                    want_W=True, kernel="matern52")
+    one = lambda t: t[:1].contiguous()
+    Mk_s, Bk_s, _ = ops.posterior_query(one(Lop), one(Vw), one(p["X"]), one(UHB), one(p["ell"]), one(p["s2"]), one(p["Bm"]),
+                                        one(p["M0"]), p["xq"], shared=True, kernel="matern52")
+    h = {k: host(v) for k, v in p.items()}
+    hj = host(jit)
+    tol = 1e-9 if f64 else 2e-3
+    for i in range(Bt):
+        UH = h["UH"][i]
+        K_o = ogp.matern52_ard_kernel(h["X"][i], h["X"][i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
+        rel_close(host(Kb)[i], K_o, 1e-12 if f64 else 1e-5, what="Kb")
+        L = np.linalg.cholesky(K_o)
+        Y = h["Xdot"][i] - UH @ h["M0"][i]
+        for qi, (Mk_d, Bk_d) in enumerate(((host(Mk)[i], host(Bk)[i]),) + (((host(Mk_s)[j], host(Bk_s)[j]) for j in range(Bt)) if i == 0 else ())):
+            xq = h["xq"][i] if qi == 0 else h["xq"][qi - 1]
+            Phi = ogp.matern52_ard_kernel(h["X"][i], xq[None], h["ell"][i], h["s2"][i])[:, :1] * (UH @ h["Bm"][i])
+            W_o = sla.solve_triangular(L, Phi, lower=True)
+            Mk_o = h["M0"][i].T + sla.solve_triangular(L, Y, lower=True).T @ W_o
+            Bk_o = h["s2"][i] * h["Bm"][i] - W_o.T @ W_o
+            rel_close(Mk_d, Mk_o, tol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+            rel_close(Bk_d, Bk_o, tol, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
+            if qi == 0:
+                rel_close(host(W)[i, :N], W_o, tol, scale=max(np.abs(W_o).max(), 1e-3), what="W")
+    # the Matern posterior differs from the RBF one (the option is not silently ignored)
+    Lr, UHBr, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit)
+    Vr, _ = ops.potrs(Lr, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    Mr, Br = ops.posterior_step(Lr, Vr, p["X"], UHBr, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+    assert float((Br - Bk).abs().max()) > 1e-3
+
+
+def test_matern52_option_facade_prediction_only(ops):
+    """`ControlAffineRegressor(data_kernel="matern52")`: custom_predict / custom_predict_fullmat run on the Matern kernel
+    (against the oracle), while fit iterations, append_data and the derivative GP refuse (prediction-only option)."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor, ControlAffineRegressorExact
+    rng = np.random.default_rng(3)
+    N, n, m, b = 40, 2, 1, 5
+    X, U, Y = rng.normal(size=(N, n)), rng.normal(size=(N, m)), rng.normal(size=(N, n))
+    A, B = np.array([[1.0, 0.2], [0.2, 0.5]]), np.array([[0.8, 0.1], [0.1, 0.6]])
+    ell, s2, M0 = np.array([0.9, 1.3]), 0.7, rng.normal(size=(1 + m, n)) * 0.1
+    f = dict(dtype=torch.float64, device=DEV)
+    reg = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel="matern52")
+    reg.set_kernel_params(A=A, B=B, lengthscale=ell, scalefactor=s2, M0=M0)
+    reg.fit(torch.as_tensor(X, **f), torch.as_tensor(U, **f), torch.as_tensor(Y, **f), training_iter=0)
+    draws = []
+    orig = reg.rand_fn
+    reg.rand_fn = lambda k: draws.append(orig(k)) or draws[-1]
+    Xt, Ut = rng.normal(size=(b, n)), rng.normal(size=(b, m))
+    mean, cov = reg.custom_predict(torch.as_tensor(Xt, **f), torch.as_tensor(Ut, **f))
+    UH, UHt = np.c_[np.ones(N), U], np.c_[np.ones(b), Ut]
+    K = ogp.matern52_ard_kernel(X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(1e-5 * host(draws[0]))
+    L = np.linalg.cholesky(K)
+    ks = ogp.matern52_ard_kernel(X, Xt, ell, s2) * (UH @ B @ UHt.T)
+    import scipy.linalg as sla
+    v = sla.solve_triangular(L, ks, lower=True)
+    mean_o = UHt @ M0 + ks.T @ sla.cho_solve((L, True), Y - UH @ M0)
+    sv_o = ogp.matern52_ard_kernel(Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v.T @ v
+    rel_close(host(mean), mean_o, 1e-9, scale=max(1.0, np.abs(mean_o).max()), what="mean")
+    rel_close(host(cov)[0], np.kron(sv_o, A), 1e-9, what="cov")
+    with pytest.raises(NotImplementedError):
+        reg.fit(torch.as_tensor(X, **f), torch.as_tensor(U, **f), torch.as_tensor(Y, **f), training_iter=2)
+    with pytest.raises(NotImplementedError):
+        reg.append_data(torch.as_tensor(Xt[:1], **f), torch.as_tensor(Ut[:1], **f), torch.as_tensor(Y[:1], **f))
+    with pytest.raises(ValueError):
+        ControlAffineRegressorExact(n, m, device=DEV, data_kernel="matern32")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_syrk_kb_inverse_and_deterministic_likelihood_gradient(ops, dtype):
+    """Fit path without a BLAS call and without float atomics: K_b^-1 = Linv' Linv on the matrix cores (bcbf_syrk_lt) is the
+    inverse of the oracle's K_b (and symmetric bit for bit); bcbf_mll_grad's split form (partial sums through the
+    workspace, added in a fixed order) returns BIT-IDENTICAL gradients from repeated launches and agrees with the
+    one-workgroup form."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    from bayesian_cbf_amd import _lib
+    f64 = dtype == torch.float64
+    for N in (33, 100, 512):
+        Bt, n, m = 2, 3, 2
+        p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=N)
+        X = (p["X"] * 3.0).contiguous()                   # well conditioned: the check is on the arithmetic
+        jit = (p["jitter"] * (1 if f64 else 1e3)).contiguous()
+        Lop, UHB, info, _ = ops.refit(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit)
+        assert (info == 0).all()
+        Kinv = ops.kb_inverse(Lop, N)
+        assert torch.equal(Kinv, Kinv.transpose(1, 2))
+        Kb = ops.kb_build(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit).double()
+        res = (Kb @ Kinv.double() - torch.eye(N, dtype=torch.float64, device=DEV)).abs().max()
+        cond = float(torch.linalg.cond(Kb).max())
+        assert float(res) < (1e-13 if f64 else 1e-5) * cond, (N, float(res), cond)
+        np.testing.assert_allclose(host(Kinv), host(ops.kb_inverse(Lop, N, gemm=False)), rtol=0,
+                                   atol=(1e-9 if f64 else 1e-2) * float(Kinv.abs().max()))
+        R = (p["Xdot"] - p["UH"] @ p["M0"]).contiguous()
+        alpha = (Kinv @ R).contiguous()
+        Ainv = torch.linalg.inv(p["A"].double()).to(dtype).contiguous()
+        args = (Lop, alpha, Kinv, X, p["UH"], R, Ainv, p["Bm"], p["ell"], p["s2"])
+        first = ops.mll_grad(*args)
+        for _ in range(3):
+            again = ops.mll_grad(*args)
+            assert all(torch.equal(a, b) for a, b in zip(first, again)), "the split form must be deterministic"
+        assert int(_lib.lib.bcbf_mll_grad_work_bytes(Bt, N, m)) == (0 if N == 33 else 8 * Bt * min(128, -(-N * N // 8192)) * 26)
+        saved = ops._mll_work
+        ops._mll_work = lambda *a: None                   # no workspace: one workgroup per model
+        try:
+            single = ops.mll_grad(*args)
+        finally:
+            ops._mll_work = saved
+        for a, b in zip(first, single):
+            np.testing.assert_allclose(host(a), host(b), rtol=1e-10 if f64 else 2e-4, atol=(1e-10 if f64 else 2e-4) * float(b.abs().max()))

@@ -99,3 +99,24 @@ def test_reference_regression_fixture_posterior_is_finite():
                                 np.array([0.6931]), np.eye(1 + m)[None], np.zeros((1, 1 + m, n)), Xt)
     assert np.isfinite(Mk).all() and np.isfinite(Bk).all()
     assert np.all(np.linalg.eigvalsh(Bk[0]) > -1e-9)
+
+
+def test_matern52_option_formula_against_an_independent_implementation():
+    """The OPT-IN Matern-5/2 data kernel (no reference counterpart: parity unpinned) at formula level:
+    the oracle's restatement of gpytorch's ScaleKernel(MaternKernel(nu=2.5, ard)) equals scikit-learn's
+    `Matern(length_scale, nu=2.5)` (an independent implementation of the same published kernel) on random ARD inputs, has
+    k(x, x) = s2, is positive definite, and is below the RBF near the origin / above it in the tails (heavier tails)."""
+    from sklearn.gaussian_process.kernels import Matern
+    from oracle import gp_posterior as ogp
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3):
+        X1, X2 = rng.normal(size=(17, n)) * 2, rng.normal(size=(9, n)) * 2
+        ell, s2 = rng.uniform(0.3, 2.0, size=n), 0.7
+        K = ogp.matern52_ard_kernel(X1, X2, ell, s2)
+        np.testing.assert_allclose(K, s2 * Matern(length_scale=ell, nu=2.5)(X1, X2), rtol=1e-12, atol=1e-15)
+        Kxx = ogp.matern52_ard_kernel(X1, X1, ell, s2)
+        np.testing.assert_allclose(np.diag(Kxx), s2, rtol=1e-15)
+        assert np.linalg.eigvalsh(Kxx).min() > 0
+    r = np.array([[0.0], [0.3], [6.0]])
+    km, kr = ogp.matern52_ard_kernel(r, r[:1], [1.0], 1.0)[:, 0], ogp.rbf_ard_kernel(r, r[:1], [1.0], 1.0)[:, 0]
+    assert km[0] == kr[0] == 1.0 and km[1] < kr[1] and km[2] > kr[2]
