@@ -6,7 +6,8 @@ import os
 import torch  # noqa: F401  (loads the ROCm runtime first so libbcbf binds to the same libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbcbf.so")
+# BCBF_LIB_PATH: development hook of the tuning tools (a variant build of the same sources); the product is the in-tree library
+LIB_PATH = os.environ.get("BCBF_LIB_PATH") or os.path.join(_HERE, "libbcbf.so")
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 c_float, c_double = ctypes.c_float, ctypes.c_double

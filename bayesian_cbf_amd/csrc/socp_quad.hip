@@ -235,6 +235,9 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
     // the 1e-3 the fp32 path has to hold.  The kernel is latency bound on one wave per CU either way (47 -> 65 us per
     // 4096 programs) and runs beside the posterior stream of the other half batch in the pipelined step.
     using R = double;
+#ifdef BCBF_SOCP_SETPRIO
+    __builtin_amdgcn_s_setprio(BCBF_SOCP_SETPRIO);     // tuning knob: issue priority over co-resident streaming waves
+#endif
     constexpr int NV = M_ + 1, D = M_ + 2, C = M_ + 1;
     constexpr int Q = (M_ + 1) * M_ + (M_ + 1) + M_ + 1;
     constexpr int TW = M_ + 1 + M_ * M_ + M_ + 1;

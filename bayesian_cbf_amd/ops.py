@@ -691,7 +691,10 @@ class ConcurrentControlLoop:
     `unicycle_control_step` on the whole batch -- every instance takes one control step per `step()` -- but the device
     runs one part's solve launch (task rows + terms + SOCP + plant step: latency bound, one wave per CU) beside another
     part's posterior stream (HBM bound), and a part's posterior fills the tail of the other's.  At the BASELINE config the
-    serialized solve launch is 15-19 % of a single-stream step.  (An event-chained variant -- all posterior launches on one
+    serialized solve launch is 15-19 % of a single-stream step.  THREE parts are the sweet spot on this stack (BASELINE
+    config, ms per step: 1 part 0.409, 2 parts 0.357, 3 parts 0.315, 4 parts 0.446 -- with more part streams than the
+    runtime has hardware queues two streams share a queue and serialize); with three the solves are hidden completely
+    and the staggered posterior launches stream at a higher rate than one big launch.  (An event-chained variant -- all posterior launches on one
     stream, solves on side streams -- was measured and rejected: each cross-stream dependency costs ~10 us on this
     stack, which ate the whole gain.)  gp / task tensors with a leading axis of Bt are sliced per part; `x` [Bt,3] is
     advanced in place.
@@ -704,9 +707,12 @@ class ConcurrentControlLoop:
 
     def __init__(self, gp, task, x, parts=2, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100):
         Bt = x.shape[0]
-        if Bt % parts:
-            raise ValueError("batch %d is not divisible into %d parts" % (Bt, parts))
-        dev, Bc = x.device, Bt // parts
+        if not 1 <= parts <= Bt:
+            raise ValueError("cannot split a batch of %d into %d parts" % (Bt, parts))
+        dev = x.device
+        # contiguous part batches, the first Bt % parts of them one instance longer (4096 -> 1366 + 1365 + 1365)
+        base, rem = divmod(Bt, parts)
+        self.bounds = [(c * base + min(c, rem), (c + 1) * base + min(c + 1, rem)) for c in range(parts)]
         self.parts, self.x, self.device = parts, x, dev
         Kob = task["centers"].shape[1]
         self.ws = control_workspace(Bt, Kob, x.dtype, dev)
@@ -719,7 +725,7 @@ class ConcurrentControlLoop:
         a_key = ("A",) if (A.dim() == 3 and A.shape[0] == Bt and Bt > 1) else ()
         gp_keys = a_key if shared_model else self.GP_INSTANCE_KEYS + a_key
         for c in range(parts):
-            sl = slice(c * Bc, (c + 1) * Bc)
+            sl = slice(*self.bounds[c])
             # per-instance tensors are named, not inferred from their shape (with a small batch a global task tensor --
             # Kp[3], sign[3], tw[Kob], gammas[Kob], relax_mask[3] -- can have a leading dimension equal to Bt)
             def cut(k, v, keys):

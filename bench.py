@@ -22,6 +22,12 @@ import os
 import sys
 import time
 
+# The default schedule runs four part batches on four HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4)
+# hardware queues per process, the null stream included, and two streams that share a queue serialize (4 parts at the
+# default: 0.446 ms per step; with 8 queues: 0.309).  A runtime setting read when HIP initialises: set it before torch
+# loads, unless the caller already chose.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -37,7 +43,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (MI3
 F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64, dense (MI355X_MICROARCH.md)
 ACHIEVED_METHOD = ("algorithmic units of ALL launches of the kernel in the timed region / time during which at least one of "
                    "them was executing (HIP events around every launch, on its stream); kernel_ms = mean duration of one "
-                   "launch, as a kernel trace reports it -- with launches_per_step > 1 the launches overlap one another")
+                   "launch, as a kernel trace reports it -- with launches_per_step > 1 the launches overlap one another; "
+                   "algorithmic_*_per_launch / instances_per_launch are means over the part batches (sizes: *_by_part)")
 
 
 def parse():
@@ -50,9 +57,12 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--variant", default="dense")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="instances timed for the CPU baseline (0 = skip)")
-    ap.add_argument("--parts", type=int, default=2,
+    ap.add_argument("--parts", type=int, default=0,
                     help="part batches, each on its own HIP stream (ops.ConcurrentControlLoop): one part's solve launch "
-                         "runs beside another part's posterior stream; 1 = the whole batch on one stream")
+                         "runs beside the other parts' posterior streams; 1 = the whole batch on one stream.  0 (default) = the "
+                         "measured optimum: regime I 4 parts when the runtime has >= 6 hardware queues (GPU_MAX_HW_QUEUES, set "
+                         "to 8 above) else 3 (ms per step at the BASELINE config: 1 part 0.409, 2: 0.357, 3: 0.318, 4: 0.309 "
+                         "/ 0.446 with 4 queues, 5: 0.363); regime S 2 parts")
     ap.add_argument("--regime", choices=["independent", "shared"], default="independent",
                     help="independent: every instance owns its GP (headline, HBM bound); shared: one learned model, "
                          "`batch` closed loops (Monte-Carlo rollouts, BASELINE configs[3]; matrix-core bound)")
@@ -250,9 +260,14 @@ def main():
     # ---- one step = every instance takes one control step: posterior -> task rows + terms + SOCP -> plant step.
     # Default schedule: the batch is split into `parts` part batches (instances never interact), each on its own HIP
     # stream; the device overlaps one part's latency-bound solve launch with another part's HBM-bound posterior stream.
-    S = max(1, args.parts)
-    assert Bt % S == 0
-    Bc = Bt // S
+    try:
+        hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        hwq = 4
+    S = args.parts if args.parts > 0 else (2 if shared else (4 if hwq >= 6 else 3))
+    base_, rem_ = divmod(Bt, S)
+    Bcs = [base_ + (1 if c < rem_ else 0) for c in range(S)]         # instances per part batch (4096 -> 1366 + 1365 + 1365)
+    Bc = Bt / S                                                      # mean instances per launch
     dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
     gsl = slice(0, 1) if shared else slice(None)
     gp = dict(Lop=Lop[gsl], Vw=Vw[gsl], X=p["X"][gsl], UHB=UHB[gsl], ell=p["ell"][gsl], s2=p["s2"][gsl],
@@ -383,7 +398,8 @@ def main():
                          "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
                          "traffic": None, "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps,
                          "launches_per_step": S, "achieved_method": ACHIEVED_METHOD,
-                         "algorithmic_flops_per_launch": flops_launch, "queries_per_launch": Bc},
+                         "algorithmic_flops_per_launch": flops_launch, "queries_per_launch": Bc,
+                         "queries_per_launch_by_part": Bcs},
         }
         print(json.dumps(out))
     elif rank == 0:
@@ -394,7 +410,7 @@ def main():
         # pair, nothing else running -- bytes per launch / its own duration, the figure a kernel trace of a one-stream run gives
         alone = {}
         if S > 1:
-            for tag, cnt in (("part_batch", Bc), ("full_batch", Bt)):
+            for tag, cnt in (("part_batch", Bcs[0]), ("full_batch", Bt)):
                 sl = slice(0, cnt)
                 pa = [gp[k][sl] for k in ("Lop", "Vw", "X", "UHB", "ell", "s2", "Bm", "M0")] + [x[sl].contiguous()]
                 for _ in range(3):
@@ -434,7 +450,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "kernel_busy_ms_per_step": busy_ms / args.steps, "launches_per_step": S,
                          "achieved_method": ACHIEVED_METHOD,
-                         "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc},
+                         "algorithmic_bytes_per_launch": bytes_launch, "instances_per_launch": Bc,
+                         "instances_per_launch_by_part": Bcs,
+                         "algorithmic_bytes_per_step": algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bt},
         }
         if alone:
             alone["note"] = ("the same kernel with the device to itself, one launch per HIP-event pair, after the timed region: "

@@ -1237,13 +1237,20 @@ def test_device_posterior_against_the_committed_real_gpytorch_learning_run(dtype
             reg.fit(tt(X), tt(U), torch.zeros(X.shape[0], 3, **f), training_iter=0)   # (covariances do not depend on the targets)
         _, Fx = reg.custom_predict_fullmat(tt(xs[None]))
         Fxu = reg.fu_func_gp(tt(uh[1:])).knl(tt(x), tt(x))
-        Fx, Fxu = Fx.double().cpu().numpy(), Fxu.double().cpu().numpy()
+        Fx, Fxu = Fx.double().cpu().numpy(), Fxu.double().cpu().numpy().reshape(3, 3)      # (logged as [1, 3, 3])
+        f32 = dtype == torch.float32
+        # fp32: the hyper-parameters make a round trip through fp32 factors and B_k = s2 B - W'W cancels in fp32: errors
+        # relative to the PRIOR scale on top of the bounds of the fp64 path
+        prior_fxu = hp["s2"] * float(uh @ uh) * np.abs(hp["B"]).max() * np.abs(hp["A"]).max()
         if ts is None:
-            tol = 2e-6 if dtype == torch.float64 else 2e-5
-            np.testing.assert_allclose(Fx, R.G["Fx_var"][t], rtol=0, atol=tol)
-            np.testing.assert_allclose(Fxu, R.G["Fxu_var"][t], rtol=2e-6, atol=tol)
+            np.testing.assert_allclose(Fx, R.G["Fx_var"][t], rtol=2e-5 if f32 else 0, atol=2e-6)
+            np.testing.assert_allclose(Fxu, R.G["Fxu_var"][t], rtol=2e-5 if f32 else 2e-6, atol=2e-6)
             continue
         e1 = np.abs(Fx - R.G["Fx_var"][t]).max()
         e2 = np.abs(Fxu - R.G["Fxu_var"][t]).max()
         fxu = np.abs(R.G["Fxu_var"][t]).max()
-        assert e1 <= 2.5e-5 and e2 <= 3e-5 and e2 <= 2e-3 * fxu, (t, e1, e2, fxu)
+        # (fp32: DESIGN.md section 4 -- B_k to 1e-3 of the prior scale; the 159 training inputs of the last refits lie on
+        #  one line [0, 0, theta] and K_b is numerically rank deficient, the jitter schedule climbs)
+        slack = 1e-3 * prior_fxu if f32 else 0.0
+        slack1 = 1e-3 * hp["s2"] * np.abs(hp["B"]).max() * np.abs(hp["A"]).max() if f32 else 0.0
+        assert e1 <= 2.5e-5 + slack1 and e2 <= 3e-5 + slack and e2 <= 2e-3 * fxu + slack, (t, e1, e2, fxu, prior_fxu)

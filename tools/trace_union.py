@@ -40,25 +40,27 @@ def main():
     bench = json.loads(line)
     rf = bench["roofline"]
     per_step, steps, warm = int(rf["launches_per_step"]), int(bench["steps"]), int(bench["warmup"])
-    inst = int(rf.get("instances_per_launch", rf.get("queries_per_launch", 0)))
+    sizes = rf.get("instances_per_launch_by_part") or rf.get("queries_per_launch_by_part") or \
+        [int(rf.get("instances_per_launch", rf.get("queries_per_launch", 0)))]
+    sizes = set(int(v) for v in sizes)
     files = sorted(glob.glob(os.path.join(trace_dir, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getsize)
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
-            if needle in r["Kernel_Name"] and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) == inst:
+            if needle in r["Kernel_Name"] and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) in sizes:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     rows.sort()
     want = (warm + steps) * per_step
     if len(rows) < want:
-        raise SystemExit("trace holds %d dispatches of %r at %d workgroups, the run made >= %d" % (len(rows), needle, inst, want))
+        raise SystemExit("trace holds %d dispatches of %r at %s workgroups, the run made >= %d" % (len(rows), needle, sorted(sizes), want))
     timed = rows[warm * per_step:want]                  # dispatch order = start order: untimed steps first, re-measurements last
     u = union_ms(timed)
     unit = rf["unit"]
     per_launch = rf.get("algorithmic_bytes_per_launch", rf.get("algorithmic_flops_per_launch"))
     scale = 1e9 if unit == "GB/s" else 1e12
     achieved = per_launch * len(timed) / (u * 1e-3) / scale
-    out = dict(source="rocprofv3 --kernel-trace time stamps of %d dispatches (%d timed steps x %d launches) of %s, %d workgroups each"
-                      % (len(timed), steps, per_step, needle, inst),
+    out = dict(source="rocprofv3 --kernel-trace time stamps of %d dispatches (%d timed steps x %d launches) of %s, %s workgroups each"
+                      % (len(timed), steps, per_step, needle, sorted(sizes)),
                union_busy_ms=u, union_busy_ms_per_step=u / steps,
                mean_launch_ms=sum(b - a for a, b in timed) / len(timed) / 1e6,
                span_ms=(max(b for _, b in timed) - min(a for a, _ in timed)) / 1e6,
