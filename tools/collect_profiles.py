@@ -6,7 +6,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = R + "gpurun_out/%s/" % ROUND
 DST = R + "profiles/%s_" % ROUND
 
@@ -22,7 +22,7 @@ def last_json_line(path):
 
 
 # ---- kernel-trace summaries (libbcbf kernels only; the torch kernels of the synthetic-data generator are dropped)
-for tag in ("default", "parts1", "shared", "shared_f64"):
+for tag in ("default", "parts1", "shared", "shared_f64", "reldeg2"):
     f = latest("prof_%s/*/*_kernel_stats.csv" % tag)
     if not f:
         continue
@@ -32,53 +32,64 @@ for tag in ("default", "parts1", "shared", "shared_f64"):
     print(tag, [(r[0].split("(")[0][-44:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
 
 # ---- bench lines
-for a in ("bench_default", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_shared", "bench_shared_prof", "bench_shared_f64", "bench_shared_f64_prof", "bench_f64"):
+for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_parts2", "bench_parts3", "bench_shared", "bench_shared_prof", "bench_shared_f64", "bench_shared_f64_prof", "bench_f64"):
     if os.path.exists(SRC + a + ".json") and os.path.getsize(SRC + a + ".json"):
         d = last_json_line(SRC + a + ".json")
         json.dump(d, open(DST + a + ".json", "w"), indent=1)
         rf = d["roofline"]
         print(a, round(d["value"]), round(d["ms_per_step"], 4), "frac", round(rf["frac"], 4), "kernel_ms", round(rf["kernel_ms"], 4),
               "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
-for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
-          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt"):
+for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "online_growth_f64_packed.json", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
+          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
         shutil.copy(SRC + a, DST + a)
 
 # ---- HBM traffic of the roofline kernel from the three counter passes per schedule
 NOTE = ("FETCH_SIZE is in KiB and, on gfx950, counts 1/2 of the bytes of wide coalesced reads: bytes = FETCH_SIZE*1024*2; "
         "WRITE_SIZE*1024 exact.  Cross-check: TCC_MISS_sum * 128 B.  (MI355X_MICROARCH.md, HBM / rocprofv3 section)")
-for tag, sched, batch in (("default", "", 2048), ("defaultparts1", " --parts 1", 4096)):
-    raw = {}
+def traffic_pass(tag, kernel_sub, per_instance_alg, command, out_name, sizes=None, dtype="f32", n=3, m=2):
+    """Per-instance HBM traffic of one kernel from the three counter passes pmc_traffic_<tag>_{FETCH_SIZE,WRITE_SIZE,TCC..}."""
+    per_inst = collections.defaultdict(list)
+    launches = collections.defaultdict(list)
     for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
         f = latest("pmc_traffic_%s_%s/*/*_counter_collection.csv" % (tag, c))
         if not f:
             continue
-        per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            # (not the potrs instantiation; only launches of this schedule's size: the bench line's un-overlapped
-            #  measurements launch the same kernel on the part batch AND on the full batch)
-            if "posterior_step_kernel<float, 3, 4, 0, 1, false>" in r["Kernel_Name"] and \
-                    int(r["Grid_Size"]) // int(r["Workgroup_Size"]) == batch:
-                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in per.items():
-            raw[k] = dict(launches=len(v), mean=sum(v) / len(v), min=min(v), max=max(v))
-    if "FETCH_SIZE" not in raw or "WRITE_SIZE" not in raw:
-        continue
-    alg = 543744 * batch
-    fetch = raw["FETCH_SIZE"]["mean"] * 1024 * 2
-    write = raw["WRITE_SIZE"]["mean"] * 1024
-    out = dict(kernel="posterior_step_kernel<float,3,4,0,1,false>",
-               workload=dict(N_train=512, batch=batch, dtype="f32", n=3, m=2, schedule="bench.py" + sched),
-               commands=["rocprofv3 --pmc %s --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0%s"
-                         % (c, sched) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum")],
-               raw=raw, corrections=NOTE, fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
-               hbm_bytes_per_launch=fetch + write,
-               tcc_miss_bytes_per_launch=raw.get("TCC_MISS_sum", {}).get("mean", 0) * 128,
-               algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=(fetch + write) / alg)
-    name = DST + ("pmc_traffic.json" if tag == "default" else "pmc_traffic_parts1.json")
-    json.dump(out, open(name, "w"), indent=1)
-    print("traffic", tag, round(out["hbm_bytes_per_launch"]), "x algorithmic", round(out["traffic_over_algorithmic"], 4),
-          "launches", raw["FETCH_SIZE"]["launches"])
+            wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+            if kernel_sub in r["Kernel_Name"] and (sizes is None or wgs in sizes):
+                per_inst[r["Counter_Name"]].append(float(r["Counter_Value"]) / wgs)
+                launches[r["Counter_Name"]].append(wgs)
+    if "FETCH_SIZE" not in per_inst or "WRITE_SIZE" not in per_inst:
+        return
+    mean = lambda k: sum(per_inst[k]) / len(per_inst[k])
+    fetch, write = mean("FETCH_SIZE") * 1024 * 2, mean("WRITE_SIZE") * 1024
+    batch = sum(launches["FETCH_SIZE"]) / len(launches["FETCH_SIZE"])
+    out = dict(kernel=kernel_sub, workload=dict(N_train=512, batch=batch, dtype=dtype, n=n, m=m, schedule=command,
+                                                workgroups_per_launch=sorted(set(launches["FETCH_SIZE"]))),
+               commands=["rocprofv3 --pmc %s --kernel-trace --output-format csv -- python3 %s" % (c, command)
+                         for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum")],
+               launches=len(per_inst["FETCH_SIZE"]), corrections=NOTE, fetch_bytes_per_instance=fetch, write_bytes_per_instance=write,
+               hbm_bytes_per_instance=fetch + write, hbm_bytes_per_launch=(fetch + write) * batch,
+               tcc_miss_bytes_per_instance=(mean("TCC_MISS_sum") * 128 if "TCC_MISS_sum" in per_inst else None),
+               algorithmic_bytes_per_instance=per_instance_alg, algorithmic_bytes_per_launch=per_instance_alg * batch,
+               traffic_over_algorithmic=(fetch + write) / per_instance_alg)
+    json.dump(out, open(DST + out_name, "w"), indent=1)
+    print("traffic", tag, kernel_sub, round(fetch + write), "x algorithmic", round(out["traffic_over_algorithmic"], 4), "launches", out["launches"])
+
+
+HEAD = "posterior_step_kernel<float, 3, 4, 0, 1, false>"
+sizes_default = None
+try:
+    sizes_default = set(last_json_line(SRC + "bench_default.json")["roofline"]["instances_per_launch_by_part"])
+except Exception:
+    pass
+traffic_pass("default", HEAD, 543744, "bench.py --steps 5 --warmup 2 --cpu-sample 0", "pmc_traffic.json", sizes_default)
+traffic_pass("defaultparts1", HEAD, 543744, "bench.py --steps 5 --warmup 2 --cpu-sample 0 --parts 1", "pmc_traffic_parts1.json", {4096})
+# rel-degree-2 jets (tools/bench_reldeg2.py): the unicycle shape (12 right-hand sides) and the pendulum shape (6)
+traffic_pass("jets", "posterior_step_kernel<float, 3, 4, 3, 1, false>", 543744, "tools/bench_reldeg2.py", "pmc_traffic_jets_n3m2.json", {4096})
+traffic_pass("jets", "posterior_step_kernel<float, 2, 4, 2, 1, false>", 4 * (512 * 513 // 2 + 2 * 512 * 2 + 512 * 2), "tools/bench_reldeg2.py",
+             "pmc_traffic_jets_n2m1.json", {4096}, n=2, m=1)
 
 # ---- MFMA utilisation
 passes = {}

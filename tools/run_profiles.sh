@@ -1,19 +1,23 @@
-# One GPU call that produces everything tools/collect_profiles.py copies into profiles/ (ROUND tag = $1, default r02).
+# One GPU call that produces everything tools/collect_profiles.py copies into profiles/ (ROUND tag = $1, default r03).
 # Counters are collected in their own passes (--pmc + --kernel-trace only), as MI355X_MICROARCH.md prescribes.
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
-python bench.py --steps 200 --warmup 10 > $O/bench_default.json 2> $O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 bench.py --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_default_prof.json 2> $O/bench_default_prof.err
-python bench.py --steps 200 --warmup 10 --parts 1 --cpu-sample 0 > $O/bench_parts1.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_parts1 -- python3 bench.py --parts 1 --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_parts1_prof.json 2> $O/bench_parts1_prof.err
-python bench.py --steps 200 --warmup 10 --regime shared --cpu-sample 0 > $O/bench_shared.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared -- python3 bench.py --regime shared --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_shared_prof.json 2> $O/bench_shared_prof.err
-python bench.py --steps 200 --warmup 10 --regime shared --dtype f64 --cpu-sample 0 > $O/bench_shared_f64.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared_f64 -- python3 bench.py --regime shared --dtype f64 --steps 50 --warmup 5 --cpu-sample 0 > $O/bench_shared_f64_prof.json 2> $O/bench_shared_f64_prof.err
-python bench.py --steps 200 --warmup 10 --dtype f64 --cpu-sample 0 > $O/bench_f64.json 2>/dev/null
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/bench_driver_form.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 bench.py --steps 100 --warmup 60 --cpu-sample 0 > $O/bench_default_prof.json 2> $O/bench_default_prof.err
+python tools/trace_union.py $O/prof_default $O/bench_default_prof.json $O/bench_default_prof_union.json > $O/union_default.txt 2>&1
+python bench.py --parts 1 --cpu-sample 0 > $O/bench_parts1.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_parts1 -- python3 bench.py --parts 1 --steps 100 --warmup 60 --cpu-sample 0 > $O/bench_parts1_prof.json 2> $O/bench_parts1_prof.err
+python tools/trace_union.py $O/prof_parts1 $O/bench_parts1_prof.json $O/bench_parts1_prof_union.json > $O/union_parts1.txt 2>&1
+for P in 2 3; do python bench.py --parts $P --cpu-sample 0 > $O/bench_parts$P.json 2>/dev/null; done
+python bench.py --regime shared --cpu-sample 0 > $O/bench_shared.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared -- python3 bench.py --regime shared --steps 100 --warmup 60 --cpu-sample 0 > $O/bench_shared_prof.json 2> $O/bench_shared_prof.err
+python bench.py --regime shared --dtype f64 --cpu-sample 0 > $O/bench_shared_f64.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared_f64 -- python3 bench.py --regime shared --dtype f64 --steps 100 --warmup 60 --cpu-sample 0 > $O/bench_shared_f64_prof.json 2> $O/bench_shared_f64_prof.err
+python bench.py --dtype f64 --cpu-sample 0 > $O/bench_f64.json 2>/dev/null
 # HBM traffic of the roofline kernel (default schedule AND the one-stream schedule): three passes each
 for sched in "" "--parts 1"; do
   tag=$(echo "default$sched" | tr -d ' -')
@@ -22,6 +26,12 @@ for sched in "" "--parts 1"; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 $sched > $d.log 2>&1
   done
 done
+# ... and of the jets instantiations (rel-degree-2 path): three passes of tools/bench_reldeg2.py
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  d=$O/pmc_traffic_jets_$(echo $c | tr ' ' '_')
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 tools/bench_reldeg2.py > $d.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_reldeg2 -- python3 tools/bench_reldeg2.py > $O/reldeg2_prof.jsonl 2> $O/reldeg2_prof.err
 # MFMA utilisation of the matrix-core kernels
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pmc_shared -- python3 bench.py --regime shared --parts 1 --steps 10 --warmup 2 --cpu-sample 0 > $O/pmc_shared.log 2>&1
@@ -33,9 +43,10 @@ python tools/bench_configs.py 2>/dev/null > $O/configs.jsonl
 python tools/time_shared.py 2>/dev/null > $O/shared_queries.txt
 python tools/bench_refit_forms.py 2>/dev/null > $O/refit_forms.jsonl
 python tools/bench_refit_forms.py f32 2>/dev/null > $O/refit_forms_f32.jsonl
-python tools/bench_online.py 2>/dev/null > $O/online_growth_f64.json
+python tools/bench_online.py --repeat 3 2>/dev/null > $O/online_growth_f64.json
+python tools/bench_online.py --packed 2>/dev/null > $O/online_growth_f64_packed.json
 python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
-python tools/bench_speed_test.py 2>/dev/null > $O/speed_test.jsonl
+python tools/bench_speed_test.py --quick 2>/dev/null > $O/speed_test.jsonl
 python tools/bench_speed_test_unicycle.py --quick 2>/dev/null > $O/speed_test_unicycle.jsonl
 python tools/learn_dynamics_matrix_vector.py /tmp/learn_matrix_vector > /dev/null 2>&1; cp gpurun_out/learn_matrix_vector.jsonl $O/ 2>/dev/null
 python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -3 > $O/mc_rollouts.txt
