@@ -41,6 +41,9 @@
 // jets instantiations (NJ > 0: the rel-degree-2 path, up to 12 right-hand-side columns): columns per pipeline stage and
 // occupancy target per element type.  Their Gram / mean sums live in ONE matrix-core accumulator (see step 2b) instead
 // of 126 VALU accumulators per lane, which is what lets two waves share a SIMD with 4 columns per stage in flight.
+#ifndef BCBF_PQ_UNR
+#define BCBF_PQ_UNR 4        // several queries per workgroup (NQ > 1), fp32: columns per pipeline stage (fp64: 2 -- 4 spill)
+#endif
 #ifndef BCBF_PJ_UNR32
 #define BCBF_PJ_UNR32 4      // fp32, more than 6 right-hand-side columns (unicycle shape: 12); measured 4096 x 512, n=3, m=2:
                              // (UNR, waves/SIMD) = (2,1) 663 us, (2,2) 520, (4,1) 539, (4,2) 419, (8,1) 528
@@ -127,11 +130,13 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
                       T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
-                      int n, const T* __restrict__ lin, int nq, int Nl, int ldN, int kind) {
+                      int n, const T* __restrict__ lin, int nq, int Nl, int ldN, int kind, const T* __restrict__ xq2) {
     // Nl: the padded size the operator is LAID OUT for (>= Np; column lengths, block offsets, batch stride), ldN: rows
     // per instance of X / UH B / Vw.  Nl == Np, ldN == N: the packed layout of exactly N points; larger: capacity-
     // reserving storage of the online path (bcbf_gp_reserve), of which the first N points are live.
     // kind: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in; values only, the jets assume the RBF).
+    // xq2 (NQ = 2, one GP per workgroup): the workgroup's second query, xq2[b] (its first is xq[b]) -- the online path's
+    // control query and new observation share ONE pass over the instance's factor (bcbf_gp_append_reserved).
     static_assert(NQ == 1 || NJ == 0, "several queries per workgroup: values only");
     static_assert(!RHS || (NJ == 0 && NQ == 1), "right-hand-side mode: values only, one system per workgroup");
     const int cu = RHS ? nq : 0;        // RHS mode: columns of UH (the launcher passes it in the nq slot)
@@ -149,9 +154,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     };
     // jets: a w_J row is widened to 16 entries [w (CT), Vw row (n), zeros]: the 32 x 16 tile is both operands of the
     // matrix-core product of step 2b
-    constexpr bool MG = NJ > 0;                                // Gram / mean sums on the matrix cores
+    constexpr bool MG = NJ > 0 || NQ > 1;                      // Gram / mean sums on the matrix cores (the forms with
+                                                               // many right-hand-side columns: jets, several queries)
     constexpr int CW = MG ? 16 : CP;
-    static_assert(!MG || CT + NS <= 16 || CT + NJ <= 16, "jets: [W, Vw] must fit the 16 rows of one MFMA tile");
+    static_assert(!MG || CT + NS <= 16 || CT + NJ <= 16, "[W, Vw] must fit the 16 rows of one MFMA tile");
     __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
     __shared__ __attribute__((aligned(16))) T wbuf[NB][CW];
 
@@ -175,8 +181,9 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     for (int d = 0; d < NS; ++d) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {       // a query slot beyond the last query repeats the last one (not stored)
-            const int qx = NQ == 1 ? b : min(b * NQ + qi, nq - 1);
-            xqr[qi][d] = (!RHS && d < n) ? xq[(size_t)qx * n + d] : T(0);
+            const int qx = (NQ == 1 || xq2 != nullptr) ? b : min(b * NQ + qi, nq - 1);
+            const T* __restrict__ qsrc = (NQ > 1 && qi == 1 && xq2 != nullptr) ? xq2 : xq;
+            xqr[qi][d] = (!RHS && d < n) ? qsrc[(size_t)qx * n + d] : T(0);
         }
         iell[d] = (!RHS && d < n) ? T(1) / ell[(size_t)gb * n + d] : T(0);
     }
@@ -295,7 +302,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
     constexpr int UNR = NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
-                               : (NQ > 1 ? 2 : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
+                               : (NQ > 1 ? (sizeof(T) == 8 ? 2 : BCBF_PQ_UNR) : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
@@ -507,7 +514,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 
     // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
     if constexpr (RHS) return;
-    if constexpr (MG) {
+    if constexpr (MG && NJ > 0) {
         // jets: every lane of wave 0 writes its four entries (i = row(l / 16, r), j = l % 16) of [W, Vw]'[W, Vw]
         if (tid < 64) {
             const int j = tid & 15, grp = tid >> 4;
@@ -529,6 +536,45 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         const int d = i - CT;
                         Mb[d * CT + j] = val;
                         if (j < C) Mkb[d * C + j] = M0b[j * n + d] + val;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (MG && NQ > 1) {
+        // several queries per workgroup: query qi owns columns qi C .. qi C + C - 1; its Gram block is the diagonal block of
+        // the accumulator, its mean the rows CT .. CT + n - 1 of its columns
+        if (tid < 64) {
+            const int j = tid & 15, grp = tid >> 4;
+            const int qi = j / C, c = j - qi * C;
+            const int qx = b * NQ + qi;
+            if (j < CT && (xq2 != nullptr || qx < nq)) {
+                const T* M0b = M0 + (size_t)gb * C * n;
+                const T* Bmb = Bm + (size_t)gb * C * C;
+                double kss = (double)s2;                      // k(xq, xq) = s2 (1 + lin |xq|^2)
+                if (lin != nullptr) {
+                    double q2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (q == qi) {
+#pragma unroll
+                            for (int d = 0; d < NS; ++d) q2 += (double)xqr[q][d] * (double)xqr[q][d];
+                        }
+                    kss *= 1.0 + (double)linv * q2;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = Mfma16<T>::row(grp, r);
+                    const T val = gacc[r];
+                    if (i >= qi * C && i < qi * C + C) {
+                        const int a = i - qi * C;
+                        double v = kss * (double)Bmb[a * C + c] - (double)val;
+                        if (a == c && jitter2 != nullptr) v += (double)jitter2[(size_t)qx * C + a];
+                        Bk[(size_t)qx * C * C + a * C + c] = (T)v;
+                    } else if (i >= CT && i < CT + n) {
+                        const int d = i - CT;
+                        Mk[(size_t)qx * n * C + d * C + c] = M0b[c * n + d] + val;
                     }
                 }
             }
@@ -601,7 +647,8 @@ template <typename T>
 static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                  const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
                                  T* Wout, int shared, int Bt, int N, int n, int m, void* stream,
-                                 T* Gfull = nullptr, T* Mfull = nullptr, const T* lin = nullptr, int Ncap = 0, int kind = 0) {
+                                 T* Gfull = nullptr, T* Mfull = nullptr, const T* lin = nullptr, int Ncap = 0, int kind = 0,
+                                 const T* xq2 = nullptr) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
@@ -614,8 +661,18 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (threads > (sizeof(T) == 8 && Gfull == nullptr ? 512 : 256)) return BCBF_EINVAL;   // N <= 2048 (fp64 jets: 1024)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN, kind)
-#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt, Nl, ldN, 0)
+#define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN, kind, (const T*)nullptr)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt, Nl, ldN, 0, (const T*)nullptr)
+    if (xq2 != nullptr) {
+        // two queries per instance (xq[b], xq2[b]) on one pass over its factor: outputs interleaved, Mk / Bk [Bt, 2, ..],
+        // Wout [Bt, 2, Np, C]
+        if (shared || Gfull || lin || n > 4 || m > 2) return BCBF_EINVAL;
+#define BCBF_P2_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 2>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, 0, N, Np, n, lin, 2 * Bt, Nl, ldN, kind, xq2)
+        if (m == 1) BCBF_P2_LAUNCH(2);
+        else BCBF_P2_LAUNCH(3);
+#undef BCBF_P2_LAUNCH
+        return check_launch("posterior_pair");
+    }
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
         if (!Mfull || lin || kind != 0) return BCBF_EINVAL;
         if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
@@ -627,7 +684,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
       if constexpr (sizeof(T) == 8) {
         // fp64, one model, many queries: BCBF_PS_NQ queries per workgroup share the stream of L
         const dim3 gridq((Bt + BCBF_PS_NQ - 1) / BCBF_PS_NQ);
-#define BCBF_PQ_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, BCBF_PS_NQ>), gridq, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN, kind)
+#define BCBF_PQ_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, BCBF_PS_NQ>), gridq, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN, kind, (const T*)nullptr)
         if (m == 1) BCBF_PQ_LAUNCH(2);
         else BCBF_PQ_LAUNCH(3);
 #undef BCBF_PQ_LAUNCH
@@ -663,7 +720,7 @@ int launch_forward_stream(const T* Lop, const T* Xdot, const T* UH, const T* M0,
     if (n < 1 || n > 4 || cu < 1 || cu > BCBF_MAX_CTRL_DIM + 1 || threads > (sizeof(T) == 8 ? 512 : 256)) return 1;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_FS_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, true>), grid, block, 0, st, Lop, (const T*)nullptr, Xdot, UH, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, M0, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, Vw, (T*)nullptr, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, cu, Np, N, 0)
+#define BCBF_FS_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, true>), grid, block, 0, st, Lop, (const T*)nullptr, Xdot, UH, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, M0, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, Vw, (T*)nullptr, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, cu, Np, N, 0, (const T*)nullptr)
     switch (n) {
         case 1: case 2: BCBF_FS_LAUNCH(2); break;
         case 3: BCBF_FS_LAUNCH(3); break;
@@ -793,3 +850,17 @@ extern "C" int bcbf_posterior_query_matern52_f64(const double* Lop, const double
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream,
                                                nullptr, nullptr, nullptr, 0, 1);
 }
+
+// Two queries per instance on ONE pass over its factor (reserved storage): xq[Bt,n] and xq2[Bt,n] -> Mk2[Bt,2,n,1+m],
+// Bk2[Bt,2,1+m,1+m], W2[Bt,2,Np,1+m] (slot 0 = xq, slot 1 = xq2).  Internal to bcbf_gp_append_reserved (solve.hip).
+namespace bcbf {
+template <typename T>
+int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm,
+                                   const T* M0, const T* xq, const T* xq2, T* Mk2, T* Bk2, T* W2, int Bt, int N, int Ncap, int n,
+                                   int m, void* stream) {
+    return launch_posterior_step<T>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk2, Bk2, W2, 0, Bt, N, n, m, stream, nullptr,
+                                    nullptr, nullptr, Ncap, 0, xq2);
+}
+template int launch_posterior_pair_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int, void*);
+template int launch_posterior_pair_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, int, int, int, int, int, void*);
+}  // namespace bcbf

@@ -496,7 +496,10 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
                          const T* __restrict__ s2, const T* __restrict__ Bm, const T* __restrict__ M0,
                          const T* __restrict__ x_new, const T* __restrict__ uh_new, const T* __restrict__ xdot_new,
                          const T* __restrict__ jitter_new, const T* __restrict__ W, int* __restrict__ info,
-                         int N, int Ncap, int n, int C) {
+                         int N, int Ncap, int n, int C, int wq, const T* __restrict__ Mk2, const T* __restrict__ Bk2,
+                         T* __restrict__ Mk_out, T* __restrict__ Bk_out) {
+    // wq = 2: W / Mk2 / Bk2 hold TWO queries per instance (slot 0 = the caller's posterior query, slot 1 = x_new, both
+    // from one pass over the factor); slot 0's posterior is handed to Mk_out / Bk_out here
     constexpr int V = Vec<T>::V;
     __shared__ T lrow[ST * SMAXR];
     __shared__ T scratch[4 * SC];
@@ -515,7 +518,7 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
         T v = T(0);
 #pragma unroll
         for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
-            if (c < C) v += W[((size_t)b * Np + i) * C + c] * uh[c];
+            if (c < C) v += W[((size_t)(b * wq + wq - 1) * Np + i) * C + c] * uh[c];
         lrow[i] = v;
         acc[SC] += v * v;
 #pragma unroll
@@ -566,6 +569,10 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
         for (int a = 0; a < C; ++a) sacc += uh[a] * Bm[((size_t)b * C + a) * C + tid];
         UHB[((size_t)b * Ncap + N) * C + tid] = ok ? sacc : T(0);
     }
+    if (wq == 2 && Mk_out != nullptr) {
+        if (tid < n * C) Mk_out[(size_t)b * n * C + tid] = Mk2[(size_t)(2 * b) * n * C + tid];
+        else if (tid >= 64 && tid < 64 + C * C) Bk_out[(size_t)b * C * C + tid - 64] = Bk2[(size_t)(2 * b) * C * C + tid - 64];
+    }
 }
 
 template <typename T>
@@ -583,11 +590,17 @@ static int launch_gp_reserve(const T* Lin, const T* Vw_in, const T* X_in, const 
 }
 
 template <typename T>
+int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm,
+                                   const T* M0, const T* xq, const T* xq2, T* Mk2, T* Bk2, T* W2, int Bt, int N, int Ncap, int n,
+                                   int m, void* stream);          // posterior_step.hip
+
+template <typename T>
 static int launch_gp_append_inplace(T* Lop, T* Vw, T* X, T* UHB, const T* s2, const T* Bm, const T* M0, const T* x_new,
                                     const T* uh_new, const T* xdot_new, const T* jitter_new, const T* W, int* info, int Bt,
-                                    int N, int Ncap, int n, int m, void* stream) {
+                                    int N, int Ncap, int n, int m, void* stream, int wq = 1, const T* Mk2 = nullptr,
+                                    const T* Bk2 = nullptr, T* Mk_out = nullptr, T* Bk_out = nullptr) {
     hipLaunchKernelGGL((gp_append_inplace_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Vw, X, UHB, s2, Bm, M0,
-                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1);
+                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1, wq, Mk2, Bk2, Mk_out, Bk_out);
     return check_launch("gp_append_reserved");
 }
 }  // namespace bcbf
@@ -676,14 +689,28 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
     }                                                                                                                    \
     int bcbf_gp_append_reserved_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,         \
                                       const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,                   \
-                                      const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, int Bt, int N,   \
-                                      int Ncap, int n, int m, void* stream) {                                            \
+                                      const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, const T* xq,     \
+                                      T* Mk, T* Bk, int Bt, int N, int Ncap, int n, int m, void* stream) {               \
         if (Bt <= 0) return BCBF_OK;                                                                                     \
         if (!Lop_r || !Vw_r || !X_r || !UHB_r || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !info ||  \
-            !Wwork || !Mk_work || !Bk_work)                                                                              \
+            !Wwork || !Mk_work || !Bk_work || (xq && (!Mk || !Bk)))                                                      \
             return BCBF_EINVAL;                                                                                          \
         if (N < 1 || N >= Ncap || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;  \
         if (bcbf::round_up(Ncap, bcbf::NB) > bcbf::ST * bcbf::SMAXR) return BCBF_EINVAL;                                  \
+        if (xq != nullptr && n <= 4 && m <= 2) {                                                                         \
+            /* the caller's posterior query rides along: two queries per instance on one pass over the factor */        \
+            const int rc = bcbf::launch_posterior_pair_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new,   \
+                                                                   Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);  \
+            if (rc != BCBF_OK) return rc;                                                                                \
+            return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new,        \
+                                                     jitter_new, Wwork, info, Bt, N, Ncap, n, m, stream, 2, Mk_work,      \
+                                                     Bk_work, Mk, Bk);                                                   \
+        }                                                                                                                \
+        if (xq != nullptr) {                                                                                             \
+            const int rq = bcbf_posterior_query_reserved_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, nullptr, Mk,  \
+                                                               Bk, nullptr, Bt, N, Ncap, n, m, stream);                  \
+            if (rq != BCBF_OK) return rq;                                                                                \
+        }                                                                                                                \
         const int rc = bcbf_posterior_query_reserved_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, nullptr,       \
                                                            Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);          \
         if (rc != BCBF_OK) return rc;                                                                                    \

@@ -212,18 +212,29 @@ class ReservedGP:
             "bcbf_posterior_query_reserved")
         return (Mk, Bk, W) if want_W else (Mk, Bk)
 
-    def append(self, x_new, uh_new, xdot_new, jitter_new=None):
+    def append(self, x_new, uh_new, xdot_new, jitter_new=None, query=None, out=None):
         """One observation per instance, in place.  Returns info[Bt] (0, or N+1 where the new pivot was not positive: that
-        instance gained a neutral point -- retrying is the caller's business, as with `gp_append`)."""
+        instance gained a neutral point -- retrying is the caller's business, as with `gp_append`).
+        query[Bt,n] (with out = (Mk, Bk), or allocated): the posterior at `query` on the points BEFORE the append, computed
+        on the same pass over the factors as the append's forward solve -- a "posterior, then append" step for the traffic
+        of one; then returns (info, Mk, Bk)."""
         if self.N >= self.capacity:
             raise RuntimeError("ReservedGP is full (%d points): reserve a larger capacity" % self.capacity)
-        _chk(self.X, x_new, uh_new, xdot_new, jitter_new)
+        _chk(self.X, x_new, uh_new, xdot_new, jitter_new, query)
+        Mk = Bk = None
+        if query is not None:
+            f = dict(dtype=self.X.dtype, device=self.X.device)
+            Mk, Bk = out if out is not None else (torch.empty(self.Bt, self.n, self.C, **f), torch.empty(self.Bt, self.C, self.C, **f))
+            if self._Ww.shape[0] != 2 * self.Bt:                      # work buffers for two queries per instance
+                self._Ww = torch.empty(2 * self.Bt, *self._Ww.shape[1:], **f)
+                self._Mkw, self._Bkw = torch.empty(2 * self.Bt, self.n, self.C, **f), torch.empty(2 * self.Bt, self.C, self.C, **f)
         check(getattr(lib, "bcbf_gp_append_reserved" + _suf(self.X))(
             _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0),
             _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self.info), _p(self._Ww), _p(self._Mkw), _p(self._Bkw),
-            self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)), "bcbf_gp_append_reserved")
+            _p(query), _p(Mk), _p(Bk), self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)),
+            "bcbf_gp_append_reserved")
         self.N += 1
-        return self.info
+        return self.info if query is None else (self.info, Mk, Bk)
 
     def live(self):
         """Views of the live rows: (Vw[Bt,N,n], X[Bt,N,n], UHB[Bt,N,C]) (strided: not inputs of the packed-layout kernels)."""

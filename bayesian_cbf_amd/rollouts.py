@@ -129,12 +129,14 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
 
 
 def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True,
-                     reserved=True):
+                     reserved=True, fused=True):
     """BASELINE configs[4]: every instance starts from an N0-point GP and takes one observation per control step
     until it holds N1 points -- the reference refits from scratch every `train_every_n_steps`
     (unicycle_move_to_pose.py:340-386).  reserved=True (default): capacity-reserving storage (`ops.ReservedGP`,
     capacity N1): an observation enters IN PLACE -- one streaming forward solve + O(N) bytes written, no allocation, no
-    copies, no re-packing; the control step's posterior reads the same storage.  reserved=False: `ops.gp_append` on the
+    copies, no re-packing; the control step's posterior reads the same storage -- fused=True (default): on the SAME pass
+    over the factors as the append's forward solve (`append(..., query=x)`; per segment `append_ms` is then that one pass
+    + the in-place row writes, `control_step_ms` the solve launch alone).  reserved=False: `ops.gp_append` on the
     packed layout of exactly N points (every per-instance array copied per append, the operator re-packed every 32).
     Returns per-octave timings (HIP events) and the deviation of the final posterior from a from-scratch refit of all
     N1 points."""
@@ -166,8 +168,16 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
         for N in range(lo, hi):
             ev = e[N - lo]
             ev[0].record()
+            if with_control and reserved and fused:
+                # ONE pass over every instance's factor answers the control step's posterior query (on the N points) and the
+                # forward solve of the append; (M_k, B_k) are then INPUTS of the fused task-rows / terms / SOCP launch
+                info, _, _ = rgp.append(obs[0][N], obs[1][N], obs[2][N], obs[3][N], query=x, out=(ws["Mk"], ws["Bk"]))
+                ev[1].record()
+                ops.unicycle_control_step(dict(A=A), task, ws, x, dt=0.0, L_mean=4.0, max_iters=20)
+                ev[2].record()
+                fails += (info != 0).sum()
+                continue
             if with_control and reserved:
-                # posterior on the reserved storage -> (M_k, B_k) are then INPUTS of the fused task-rows / terms / SOCP launch
                 rgp.posterior(x, out=(ws["Mk"], ws["Bk"]))
                 ops.unicycle_control_step(dict(A=A), task, ws, x, dt=0.0, L_mean=4.0, max_iters=20)
             elif with_control:
@@ -185,9 +195,13 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
         t_step = sum(ev[0].elapsed_time(ev[1]) for ev in e)
         t_app = sum(ev[1].elapsed_time(ev[2]) for ev in e)
         isz = p["X"].element_size()
-        segs.append(dict(N_from=lo, N_to=hi, control_step_ms=t_step / k, append_ms=t_app / k,
+        if with_control and reserved and fused:
+            t_step, t_app = t_app, t_step              # (events: [0,1] = posterior + append, [1,2] = solve)
+        segs.append(dict(N_from=lo, N_to=hi, control_step_ms=t_step / k, append_ms=t_app / k, step_ms=(t_step + t_app) / k,
                          append_GBs_algorithmic=Bt * isz * ((lo + hi) / 2) ** 2 / 2 / (t_app / k * 1e-3) / 1e9))
-    out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype), storage="reserved (in place)" if reserved else "packed (copy per append)",
+    out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype),
+               storage=("reserved (in place)" + (", posterior query and append on one pass" if (fused and with_control) else ""))
+               if reserved else "packed (copy per append)",
                segments=segs, append_failures=int(fails))
     if check:
         Lr, UHBr, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])

@@ -193,8 +193,12 @@ int bcbf_posterior_query_matern52_f64(const double* Lop, const double* Vw, const
  *   bcbf_gp_append_reserved     one observation per instance enters IN PLACE: the forward solve W = L^-1 Phi(x_new) on the
  *                               streaming kernel, then one operator row, one inverted-diagonal-block row and one row of
  *                               each array are written -- O(N) bytes, no allocation, nothing copied.  N < Ncap; the
- *                               caller's N grows by one.  Work buffers: Wwork[Bt, round_up(Ncap,32), 1+m],
- *                               Mk_work[Bt,n,1+m], Bk_work[Bt,1+m,1+m].  info as bcbf_gp_append (N+1: neutral point). */
+ *                               caller's N grows by one.  info as bcbf_gp_append (N+1: neutral point).
+ *                               xq[Bt,n] (optional, with Mk[Bt,n,1+m], Bk[Bt,1+m,1+m]): the control step's posterior query on
+ *                               the N points BEFORE the append rides along -- both queries share ONE pass over each
+ *                               instance's factor (n <= 4, m <= 2; otherwise two passes), halving the traffic of a
+ *                               "posterior, then append" step.  Work buffers: Wwork[q Bt, round_up(Ncap,32), 1+m],
+ *                               Mk_work[q Bt,n,1+m], Bk_work[q Bt,1+m,1+m] with q = 2 when xq is given, else 1. */
 int bcbf_gp_reserve_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in, float* Lop_r,
                         float* Vw_r, float* X_r, float* UHB_r, int Bt, int N, int Ncap_in, int Ncap, int n, int m,
                         void* stream);
@@ -212,11 +216,13 @@ int bcbf_posterior_query_reserved_f64(const double* Lop_r, const double* Vw_r, c
 int bcbf_gp_append_reserved_f32(float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
                                 const float* Bm, const float* M0, const float* x_new, const float* uh_new,
                                 const float* xdot_new, const float* jitter_new, int* info, float* Wwork, float* Mk_work,
-                                float* Bk_work, int Bt, int N, int Ncap, int n, int m, void* stream);
+                                float* Bk_work, const float* xq, float* Mk, float* Bk, int Bt, int N, int Ncap, int n, int m,
+                                void* stream);
 int bcbf_gp_append_reserved_f64(double* Lop_r, double* Vw_r, double* X_r, double* UHB_r, const double* ell, const double* s2,
                                 const double* Bm, const double* M0, const double* x_new, const double* uh_new,
                                 const double* xdot_new, const double* jitter_new, int* info, double* Wwork, double* Mk_work,
-                                double* Bk_work, int Bt, int N, int Ncap, int n, int m, void* stream);
+                                double* Bk_work, const double* xq, double* Mk, double* Bk, int Bt, int N, int Ncap, int n,
+                                int m, void* stream);
 
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */

@@ -38,7 +38,7 @@ int main(void) {
     EXPECT(bcbf_kb_build_matern52_f32(0, 0, 0, 0, 0, 0, 0, 0, 8, 2, 1, 0), BCBF_OK);
     EXPECT(bcbf_posterior_query_matern52_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_query_reserved_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
-    EXPECT(bcbf_gp_append_reserved_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
+    EXPECT(bcbf_gp_append_reserved_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_step_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_query_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_shared_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 3, 2, 0), BCBF_OK);
@@ -62,7 +62,8 @@ int main(void) {
     EXPECT(bcbf_gp_reserve_f64(d, d, d, d, d + 1, d + 1, d + 1, d + 1, 1, 8, 0, 4, 2, 1, 0), BCBF_EINVAL);   /* capacity < N */
     EXPECT(bcbf_gp_reserve_f64(d, d, d, d, d, d, d, d, 1, 8, 0, 16, 2, 1, 0), BCBF_EINVAL);         /* in == out */
     EXPECT(bcbf_syrk_lt_f64(d, d, 1, 8, 0), BCBF_EINVAL);                                            /* in place */
-    EXPECT(bcbf_gp_append_reserved_f64(d, d, d, d, d, d, d, d, d, d, d, 0, i, d, d, d, 1, 16, 16, 3, 2, 0), BCBF_EINVAL);  /* full */
+    EXPECT(bcbf_gp_append_reserved_f64(d, d, d, d, d, d, d, d, d, d, d, 0, i, d, d, d, 0, 0, 0, 1, 16, 16, 3, 2, 0), BCBF_EINVAL);  /* full */
+    EXPECT(bcbf_gp_append_reserved_f64(d, d, d, d, d, d, d, d, d, d, d, 0, i, d, d, d, d, 0, 0, 1, 8, 16, 3, 2, 0), BCBF_EINVAL);   /* xq without Mk */
     EXPECT(bcbf_posterior_query_reserved_f64(d, d, d, d, d, d, d, d, d, 0, d, d, 0, 1, 16, 8, 3, 2, 0), BCBF_EINVAL);     /* Ncap < N */
     {   /* the row-count helper is pure host logic */
         int kinds[4] = {1, 2, 0, 1};

@@ -368,6 +368,15 @@ def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
         for a, b in zip(after, ref[:2]):
             np.testing.assert_allclose(host(a)[1], host(b)[1], rtol=tol, atol=tol)      # unchanged
             assert np.abs(host(a)[0] - host(b)[0]).max() > 0                            # the others did learn
+        # the append with the control query riding along (one pass over the factors for both) = query on the N + 1 - 1
+        # points, then the same append: bit-identical posterior of the query, same grown state
+        g2 = ops.ReservedGP(Lop, Vw, X0, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], cap)
+        info2q, Mk_q, Bk_q = g2.append(x_new.contiguous(), uh_new.contiguous(), xd_new.contiguous(), jit_new, query=p["xq"])
+        assert torch.equal(info2q, info)
+        np.testing.assert_allclose(host(Mk_q), host(ref[0]), rtol=1e-12 if dtype == torch.float64 else 1e-5, atol=1e-12 if dtype == torch.float64 else 1e-5)
+        np.testing.assert_allclose(host(Bk_q), host(ref[1]), rtol=0, atol=(1e-12 if dtype == torch.float64 else 1e-5) * float(ref[1].abs().max()))
+        for a, b in zip(g2.posterior(p["xq"]), after):
+            np.testing.assert_allclose(host(a), host(b), rtol=1e-11 if dtype == torch.float64 else 1e-4, atol=1e-11 if dtype == torch.float64 else 1e-4)
         # the same append through the packed path gives the same state on the healthy instances
         L2, Vw2, X2, UHB2, info2 = ops.gp_append(Lop, Vw, X0, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], x_new.contiguous(),
                                                  uh_new.contiguous(), xd_new.contiguous(), jit_new)

@@ -933,7 +933,8 @@ def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
         rel_close(host(Kb)[i], K_o, 1e-12 if f64 else 1e-5, what="Kb")
         L = np.linalg.cholesky(K_o)
         Y = h["Xdot"][i] - UH @ h["M0"][i]
-        for qi, (Mk_d, Bk_d) in enumerate(((host(Mk)[i], host(Bk)[i]),) + (((host(Mk_s)[j], host(Bk_s)[j]) for j in range(Bt)) if i == 0 else ())):
+        cases = [(host(Mk)[i], host(Bk)[i])] + ([(host(Mk_s)[j], host(Bk_s)[j]) for j in range(Bt)] if i == 0 else [])
+        for qi, (Mk_d, Bk_d) in enumerate(cases):
             xq = h["xq"][i] if qi == 0 else h["xq"][qi - 1]
             Phi = ogp.matern52_ard_kernel(h["X"][i], xq[None], h["ell"][i], h["s2"][i])[:, :1] * (UH @ h["Bm"][i])
             W_o = sla.solve_triangular(L, Phi, lower=True)
