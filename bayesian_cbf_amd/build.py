@@ -10,6 +10,10 @@ import os
 import subprocess
 import sys
 
+if __package__ in (None, ""):                      # `python bayesian_cbf_amd/build.py`
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    __package__ = "bayesian_cbf_amd"
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
@@ -25,7 +29,8 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.
 EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "posterior_shared_reg.hip": ["-Rpass-analysis=kernel-resource-usage"]}
 # kernels that must not touch scratch memory (posterior_shared_reg: an operand spilled between its explicit LDS read and
-# the explicit wait for it would be stored before it has arrived)
+# the explicit wait for it would be stored before it has arrived).  Their device assembly is also linted: no instruction may
+# name the destination of an LDS read that has not been waited for (check_lds_waits.py)
 NO_SCRATCH = {"posterior_shared_reg.hip"}
 
 
@@ -81,10 +86,32 @@ def _compile(item, force):
         extra.append("-DBCBF_PSR_DEV")        # host-side instrumentation only: one device instantiation per precision is
                                               # enough there (the 18 of the product build take minutes to compile)
     cmd = [_hipcc()] + flags + extra + tuning + ["-c", os.path.join(CSRC, src), "-o", obj]
+    guard = src in NO_SCRATCH and not ASAN and tag != "base"
+    tmpdir = None
+    if guard:
+        # keep the device assembly of this compile (-save-temps, in a scratch directory) for the LDS read / wait lint below
+        import tempfile
+        tmpdir = tempfile.mkdtemp(prefix="bcbf_asm_")
+        cmd = cmd[:-1] + [os.path.join(tmpdir, os.path.basename(obj)), "-save-temps=obj"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
-    if src in NO_SCRATCH and not ASAN and tag != "base":
+    if guard:
+        import glob
+        import shutil
+        from .check_lds_waits import check as _check_lds
+        asm = glob.glob(os.path.join(tmpdir, "*-hip-amdgcn-amd-amdhsa-%s.s" % ARCH))
+        try:
+            if len(asm) != 1:
+                raise RuntimeError("%s: no device assembly to check (%s)" % (src, asm))
+            bad, checked = _check_lds(open(asm[0]).read(), r"posterior_shared_reg_kernel")
+            if bad or not checked:
+                raise RuntimeError("%s [%s]: %d instruction(s) touch the destination of an LDS read that is still in flight "
+                                   "(explicit ds_read / s_waitcnt pairs; first: %s)" % (src, tag, len(bad), bad[:3]))
+            shutil.move(os.path.join(tmpdir, os.path.basename(obj)), obj)
+        finally:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+    if guard:
         import re
         names = re.findall(r"Function Name: (\S+)", res.stderr)
         sizes = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res.stderr)]

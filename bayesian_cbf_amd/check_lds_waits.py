@@ -1,0 +1,103 @@
+"""Build-time lint for kernels that issue LDS reads and wait for them by hand (posterior_shared_reg.hip: `ds_read` in
+one inline-asm statement, `s_waitcnt lgkmcnt(0)` in another, tens of instructions later).
+
+The compiler does not track the LGKM counter of inline assembly, so nothing but the source order keeps an instruction
+from touching a `ds_read` destination before its data has arrived: a copy, a coalescing move, a re-materialisation or
+a spill inserted between the read and the wait would read (or overwrite) stale registers, silently.  This check walks
+the DEVICE ASSEMBLY of every kernel whose name matches and verifies, instruction by instruction, that no instruction
+names a register that is the destination of an LDS read still in flight:
+
+  * `ds_read*` adds its destination registers to the in-flight set, in issue order;
+  * every other LGKM operation (LDS writes, scalar loads) takes a slot of the same counter; `s_waitcnt ... lgkmcnt(N)`
+    retires all but the N youngest operations (in-order return, the assumption the compiler's own counted waits make);
+  * any other instruction whose operands (destination or source) overlap an in-flight destination is a violation.
+
+It also covers the compiler's own LDS reads (which the compiler waits for itself), so a clean run means: in this code
+object no LDS read result is consumed early, by anyone.  Control flow is ignored (the kernels are straight-line apart
+from a few counted loops whose bodies end on a wait); a label does not clear the in-flight set.
+
+    python -m bayesian_cbf_amd.check_lds_waits file.s [kernel-name regex]
+"""
+import re
+import sys
+
+_REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+
+
+def _regs(text):
+    out = set()
+    for m in _REG.finditer(text):
+        bank = m.group(1)
+        if m.group(2) is not None:
+            out.add((bank, int(m.group(2))))
+        else:
+            out.update((bank, i) for i in range(int(m.group(3)), int(m.group(4)) + 1))
+    return out
+
+
+def check(asm_text, name_regex=r"."):
+    """Returns a list of (kernel, line number, instruction, registers) violations."""
+    pat = re.compile(name_regex)
+    bad, kernel, inflight = [], None, []           # inflight: list of register sets, oldest first
+    checked = 0
+    for ln, raw in enumerate(asm_text.splitlines(), 1):
+        line = raw.split(";")[0].strip()
+        if not line or line.startswith("."):
+            if raw.lstrip().startswith(".end_amdhsa_kernel") or raw.lstrip().startswith(".Lfunc_end"):
+                kernel, inflight = None, []
+            continue
+        m = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if m:
+            if not m.group(1).startswith(".L") and not m.group(1).startswith("BB"):
+                kernel = m.group(1) if pat.search(m.group(1)) else None
+                inflight = []
+                checked += kernel is not None
+            continue
+        if kernel is None:
+            continue
+        op, _, rest = line.partition(" ")
+        if op.startswith("ds_read") or op.startswith("ds_load"):
+            dest = rest.split(",")[0]
+            touched = _regs(rest.split(",", 1)[1]) if "," in rest else set()      # the address register must be ready too
+            pend = set().union(*inflight) if inflight else set()
+            if touched & pend:
+                bad.append((kernel, ln, line, sorted(touched & pend)))
+            inflight.append(_regs(dest))
+            continue
+        if op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_scratch_load"):
+            # every other LGKM operation (LDS writes / atomics, scalar loads) takes a slot of the counter too: a later
+            # `lgkmcnt(N)` counts it among the N youngest
+            if inflight:
+                hit = _regs(rest) & set().union(*inflight)
+                if hit and op.startswith("ds_"):
+                    bad.append((kernel, ln, line, sorted(hit)))
+            inflight.append(set())
+            continue
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", rest)
+            if m:
+                keep = int(m.group(1))
+                inflight = inflight[len(inflight) - keep:] if keep else []
+            elif re.fullmatch(r"\s*(0x[0-9a-fA-F]+|\d+)\s*", rest):             # raw immediate: treat as a full wait
+                inflight = []
+            continue
+        if not inflight:
+            continue
+        pend = set().union(*inflight)
+        hit = _regs(rest) & pend
+        if hit:
+            bad.append((kernel, ln, line, sorted(hit)))
+    return bad, checked
+
+
+def main():
+    text = open(sys.argv[1]).read()
+    bad, checked = check(text, sys.argv[2] if len(sys.argv) > 2 else r".")
+    for k, ln, ins, regs in bad[:40]:
+        print("%s:%d: %s   <- in-flight LDS destination %s" % (k[:60], ln, ins, regs[:6]))
+    print("%d kernel(s) checked, %d violation(s)" % (checked, len(bad)))
+    return 1 if bad or not checked else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -702,10 +702,12 @@ class ConcurrentControlLoop:
     `unicycle_control_step` on the whole batch -- every instance takes one control step per `step()` -- but the device
     runs one part's solve launch (task rows + terms + SOCP + plant step: latency bound, one wave per CU) beside another
     part's posterior stream (HBM bound), and a part's posterior fills the tail of the other's.  At the BASELINE config the
-    serialized solve launch is 15-19 % of a single-stream step.  THREE parts are the sweet spot on this stack (BASELINE
-    config, ms per step: 1 part 0.409, 2 parts 0.357, 3 parts 0.315, 4 parts 0.446 -- with more part streams than the
-    runtime has hardware queues two streams share a queue and serialize); with three the solves are hidden completely
-    and the staggered posterior launches stream at a higher rate than one big launch.  (An event-chained variant -- all posterior launches on one
+    serialized solve launch is 15-19 % of a single-stream step.  BASELINE config, ms per step: 1 part 0.408, 2 parts
+    0.358, 3 parts 0.314, 4 parts 0.309 -- PROVIDED the runtime has a hardware queue per part stream: ROCm maps the
+    streams of a process onto GPU_MAX_HW_QUEUES (default 4) queues, the null stream included, and two streams that share
+    a queue serialize (4 parts at the default: 0.446).  Export GPU_MAX_HW_QUEUES=8 before HIP initialises for four parts
+    (bench.py does), use three otherwise.  From three parts on the solves are hidden completely and the staggered
+    posterior launches stream at a higher rate than one big launch (0.90 of the HBM peak against 0.84).  (An event-chained variant -- all posterior launches on one
     stream, solves on side streams -- was measured and rejected: each cross-stream dependency costs ~10 us on this
     stack, which ate the whole gain.)  gp / task tensors with a leading axis of Bt are sliced per part; `x` [Bt,3] is
     advanced in place.

@@ -45,3 +45,31 @@ def test_ops_refuse_cpu_tensors(lib):
     X = torch.zeros(1, 8, 2)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.kb_build(X, torch.zeros(1, 8, 2), torch.eye(2)[None], torch.ones(1, 2), torch.ones(1))
+
+
+def test_lds_read_wait_lint_flags_early_use_and_accepts_waited_use():
+    """bayesian_cbf_amd/check_lds_waits.py (run by the build on posterior_shared_reg.hip's device assembly): an instruction
+    that touches the destination of an LDS read before the covering s_waitcnt is reported; counted waits retire the oldest
+    reads first; a kernel whose name does not match is ignored."""
+    from bayesian_cbf_amd.check_lds_waits import check
+    good = """
+_Z6kernelv:
+\tds_read_b64 v[10:11], v3 offset:16
+\tds_read_b32 v12, v3
+\tv_add_f32_e32 v1, v2, v4
+\ts_waitcnt lgkmcnt(1)
+\tv_mul_f64 v[20:21], v[10:11], v[10:11]
+\ts_waitcnt lgkmcnt(0)
+\tv_mfma_f32_16x16x4_f32 a[0:3], v12, v12, a[0:3]
+\ts_endpgm
+"""
+    bad, n = check(good, "kernel")
+    assert n == 1 and bad == []
+    early = good.replace("\tv_add_f32_e32 v1, v2, v4", "\tv_add_f32_e32 v1, v11, v4")       # reads v11 before the wait
+    bad, _ = check(early, "kernel")
+    assert len(bad) == 1 and bad[0][3] == [("v", 11)]
+    clobber = good.replace("\tv_add_f32_e32 v1, v2, v4", "\tv_mov_b32_e32 v12, 0")            # overwrites an in-flight destination
+    assert len(check(clobber, "kernel")[0]) == 1
+    wrong_wait = good.replace("lgkmcnt(1)", "lgkmcnt(2)")                                     # nothing retired yet
+    assert len(check(wrong_wait, "kernel")[0]) == 1
+    assert check(early, "other_name") == ([], 0)
