@@ -56,6 +56,7 @@ _TSIGS = {
     "bcbf_cbc_socp": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_unicycle_constraints": [P, P, P, P, "T", P, P, P, P, "T", P, P, P, P, c_int, c_int, P],
     "bcbf_unicycle_step": [P, P, "T", "T", c_int, P],
+    "bcbf_rollout_stats": [P] * 8 + [c_int, c_int, c_int, P],
     "bcbf_unicycle_control_step": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
 }
 

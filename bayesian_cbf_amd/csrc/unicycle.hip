@@ -42,9 +42,49 @@ __global__ void unicycle_step_kernel(T* __restrict__ x, const T* __restrict__ u,
     x[b * 3 + 2] += u1 / L_true * dt;
 }
 
+// Safety bookkeeping of one closed-loop step of a Monte-Carlo rollout (rollouts.monte_carlo_safety_rollouts), one launch
+// instead of eight elementwise ones: per trajectory  min_h = min(min_h, min_k cst_k / gamma_k)  over the obstacle rows
+// (h_k(x_t) before the step; a non-finite h counts as -inf: it can never pass for "collision-free"), and -- only where
+// the program was solved, the reference raises ValueError otherwise (unicycle_move_to_pose.py:954-964) --
+// cost += sum_i w_i y_i^2;  fails += (status != 0).
+template <typename T>
+__global__ void rollout_stats_kernel(const T* __restrict__ cst, const T* __restrict__ y, const int* __restrict__ status,
+                                     const T* __restrict__ w, const T* __restrict__ gammas, T* __restrict__ min_h,
+                                     T* __restrict__ cost, int* __restrict__ fails, int Bt, int Kob, int nv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Bt) return;
+    T h = INFINITY;
+    for (int k = 0; k < Kob; ++k) {
+        T hk = cst[(size_t)b * (1 + Kob) + 1 + k] / gammas[k];
+        if (!(hk == hk)) hk = -INFINITY;
+        h = hk < h ? hk : h;
+    }
+    if (Kob > 0) min_h[b] = h < min_h[b] ? h : min_h[b];
+    if (status[b] == 0) {
+        T c = T(0);
+        for (int i = 0; i < nv; ++i) c += w[(size_t)b * nv + i] * y[(size_t)b * nv + i] * y[(size_t)b * nv + i];
+        cost[b] += c;
+    } else {
+        fails[b] += 1;
+    }
+}
+
 }  // namespace bcbf
 
 extern "C" {
+#define BCBF_ROLLOUT_STATS(T, SUF)                                                                                    \
+    int bcbf_rollout_stats_##SUF(const T* cst, const T* y, const int* status, const T* w, const T* gammas, T* min_h,  \
+                                 T* cost, int* fails, int Bt, int Kob, int nv, void* stream) {                        \
+        if (Bt <= 0) return BCBF_OK;                                                                                  \
+        if (!cst || !y || !status || !w || !min_h || !cost || !fails || Kob < 0 || nv < 1 || (Kob > 0 && !gammas))    \
+            return BCBF_EINVAL;                                                                                       \
+        hipLaunchKernelGGL((bcbf::rollout_stats_kernel<T>), dim3((Bt + 255) / 256), dim3(256), 0, (hipStream_t)stream, \
+                           cst, y, status, w, gammas, min_h, cost, fails, Bt, Kob, nv);                               \
+        return bcbf::check_launch("rollout_stats");                                                                   \
+    }
+BCBF_ROLLOUT_STATS(float, f32)
+BCBF_ROLLOUT_STATS(double, f64)
+#undef BCBF_ROLLOUT_STATS
 #define BCBF_UNI(T, SUF)                                                                                              \
     int bcbf_unicycle_constraints_##SUF(const T* x, const T* plan, const T* dot_plan, const T* Kp, T clf_gamma,       \
                                         const T* centers, const T* radii, const T* tw, const T* gammas, T L_mean,     \

@@ -602,6 +602,14 @@ def unicycle_step(x, u, dt, L_true):
     return x
 
 
+def rollout_stats(cst, y, status, w, gammas, min_h, cost, fails):
+    """Safety bookkeeping of one closed-loop step (bcbf_rollout_stats): min_h, cost, fails updated in place."""
+    _chk(cst, y, w, gammas, min_h, cost)
+    Bt, Kob = cst.shape[0], cst.shape[1] - 1
+    check(getattr(lib, "bcbf_rollout_stats" + _suf(cst))(_p(cst), _p(y), _p(status), _p(w), _p(gammas), _p(min_h), _p(cost),
+                                                         _p(fails), Bt, Kob, y.shape[1], _stream(cst)), "bcbf_rollout_stats")
+
+
 def _control_step_args(gp, task, ws, x):
     """Argument checks shared by the two forms below: returns (gp with every key present, A[Bt,n,n], N, shared)."""
     Bt = x.shape[0]

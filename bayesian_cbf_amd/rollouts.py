@@ -66,7 +66,6 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     plan_all = torch.stack([planner.plan(t).to(dtype=dtype) for t in range(numSteps)]).to(dev)
     dplan_all = torch.stack([planner.dot_plan(t).to(dtype=dtype) for t in range(numSteps)]).to(dev)
     task["plan"], task["dot_plan"] = torch.empty(Bt, 3, **f), torch.empty(Bt, 3, **f)
-    igam = (1.0 / gam).contiguous()
     step = ops.unicycle_control_step_prepare(gp if gp is not None else fixed, task, ws, x, dt=dt, L_true=L_true,
                                              L_mean=L_mean, max_iters=max_iters)
     import time
@@ -81,16 +80,11 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
             task["plan"].copy_(plan_all[t])
             task["dot_plan"].copy_(dplan_all[t])
         step()       # one host call, two launches (one for the fixed-kernel model): rows -> terms -> SOCP -> plant step
-        # safety bookkeeping: h_k(x_t) = cst_k / gamma_k for the obstacle rows (before the step)
-        # (a non-finite h counts as a collision: NaN -> -inf, so it can never pass for "collision-free")
-        h_now = torch.nan_to_num((ws["cst"][:, 1:] * igam).amin(dim=1), nan=-math.inf)
-        torch.minimum(min_h, h_now, out=min_h)
-        solved = ws["status"] == 0
-        # an unsolved program (MAXITER / infeasible / bad cone) is where the reference raises ValueError
-        # (unicycle_move_to_pose.py:954-964): the kernel leaves that instance's state untouched for the step, its
-        # y is not a control and does not enter the cost, and the trajectory is reported in stats['solver_failures']
-        cost.add_(torch.where(solved, (w_cost * ws["y"] * ws["y"]).sum(dim=1), torch.zeros_like(cost)))
-        fails.add_(~solved)
+        # safety bookkeeping in ONE launch: min_h over the obstacle rows h_k(x_t) = cst_k / gamma_k (before the step; a
+        # non-finite h counts as a collision), and -- only where the program was solved: an unsolved program (MAXITER /
+        # infeasible / bad cone) is where the reference raises ValueError (unicycle_move_to_pose.py:954-964), the kernel
+        # leaves that instance's state untouched for the step and its y is not a control -- the cost; else a failure count
+        ops.rollout_stats(ws["cst"], ws["y"], ws["status"], w_cost, gam, min_h, cost, fails)
 
     torch.cuda.synchronize(dev)
     graph = None

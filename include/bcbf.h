@@ -180,6 +180,16 @@ int bcbf_posterior_query_matern52_f64(const double* Lop, const double* Vw, const
                                       const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                       int shared, int Bt, int N, int n, int m, void* stream);
 
+/* Safety bookkeeping of one closed-loop step of a Monte-Carlo rollout (BASELINE configs[3]; the statistics are this
+ * library's summary of `sample_generator_trajectory` runs, sampling.py:49-75): per trajectory
+ * min_h = min(min_h, min_k cst[b,1+k] / gammas[k]) over the Kob obstacle rows of bcbf_unicycle_control_step's `cst` output
+ * (h_k(x_t); non-finite -> -inf), and where status[b] == 0: cost += sum_i w[b,i] y[b,i]^2 (nv = m + 1 entries), else
+ * fails += 1 (the reference raises ValueError on an unsolved program, unicycle_move_to_pose.py:954-964). */
+int bcbf_rollout_stats_f32(const float* cst, const float* y, const int* status, const float* w, const float* gammas,
+                           float* min_h, float* cost, int* fails, int Bt, int Kob, int nv, void* stream);
+int bcbf_rollout_stats_f64(const double* cst, const double* y, const int* status, const double* w, const double* gammas,
+                           double* min_h, double* cost, int* fails, int Bt, int Kob, int nv, void* stream);
+
 /* Capacity-reserving GP storage for the online path (BASELINE configs[4]; the reference refits from scratch,
  * unicycle_move_to_pose.py:340-386).  The packed layout depends on the padded size and X / UH*B / Vw are [Bt,N,.] arrays,
  * so bcbf_gp_append copies every per-instance array on each append and re-packs the operator at every multiple of 32.

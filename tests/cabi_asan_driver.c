@@ -49,6 +49,8 @@ int main(void) {
     EXPECT(bcbf_coneqp_f64(0, 0, 0, 0, 3, 0, i, 1, 0, 0, 0, 0, 20, 0), BCBF_OK);
     EXPECT(bcbf_unicycle_constraints_f64(0, 0, 0, 0, 10.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 2, 0), BCBF_OK);
     EXPECT(bcbf_unicycle_step_f32(0, 0, 0.1f, 1.0f, 0, 0), BCBF_OK);
+    EXPECT(bcbf_rollout_stats_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 0), BCBF_OK);
+    EXPECT(bcbf_rollout_stats_f64(d, d, i, d, 0, d, d, i, 1, 2, 3, 0), BCBF_EINVAL);              /* obstacle rows without gammas */
     /* bad arguments with a non-empty batch: refused before anything is dereferenced or launched */
     EXPECT(bcbf_kb_build_f64(0, d, d, d, d, 0, d, 1, 8, 2, 1, 0), BCBF_EINVAL);                  /* X == NULL */
     EXPECT(bcbf_refit_f64(d, d, d, d, d, 0, 0, d, 0, i, 1, 8, 2, 1, 0), BCBF_EINVAL);            /* Lop == NULL */
