@@ -1028,3 +1028,50 @@ def test_syrk_kb_inverse_and_deterministic_likelihood_gradient(ops, dtype):
             ops._mll_work = saved
         for a, b in zip(first, single):
             np.testing.assert_allclose(host(a), host(b), rtol=1e-10 if f64 else 2e-4, atol=(1e-10 if f64 else 2e-4) * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (2, 2), (3, 2)])
+def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n, m, dtype):
+    """The jets instantiations (Gram / mean sums on the matrix-core accumulator of wave 0) for all four compiled (n, m) and
+    for training sizes that take one wave, several waves and a ragged last block per workgroup, against the oracle's
+    jets: M_k, B_k, dM_k/dx, dW_d'W, dW_d'dW_e, and the Wj output against the oracle's triangular solves."""
+    import scipy.linalg as sla
+    from oracle import cbc2 as oc2
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64 = dtype == torch.float64
+    C = m + 1
+    for N in (40, 300, 700):
+        Bt = 3
+        p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=100 * n + m + N)
+        X = (p["X"] * 2.0).contiguous()
+        xq = (p["xq"] * 2.0).contiguous()
+        jit = (p["jitter"] * (1 if f64 else 1e3)).contiguous()
+        Lop, UHB, info, _ = ops.refit(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit)
+        assert (info == 0).all()
+        Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+        Mk, Bk, G, Mj, Wj = ops.posterior_jets(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, want_W=True)
+        h = {k: host(v) for k, v in p.items()}
+        hX, hxq, hj = host(X), host(xq), host(jit)
+        tol = 1e-8 if f64 else 2e-3
+        for i in range(Bt):
+            st = ogp.refit_state(hX[i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i], hj[i][None] / 1e-5)
+            jets = oc2.posterior_jets(st["L"], st["Y"], hX[i], st["UHB"], h["ell"][i], float(h["s2"][i]), h["Bm"][i], h["M0"][i], hxq[i])
+            prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
+            rel_close(host(Mk)[i], jets["Mk"], tol, scale=max(1.0, np.abs(jets["Mk"]).max()), what="Mk N=%d" % N)
+            rel_close(host(Bk)[i], jets["Bk"], tol, scale=prior, what="Bk N=%d" % N)
+            Gh, Mjh = host(G)[i], host(Mj)[i]
+            assert np.array_equal(Gh, Gh.T)
+            gscale = max(np.abs(jets["G11"]).max(), np.abs(jets["G10"]).max(), prior, 1e-3)
+            rel_close(Gh[:C, :C], h["s2"][i] * h["Bm"][i] - jets["Bk"], tol, scale=gscale, what="G00")
+            for d in range(n):
+                rel_close(Gh[(1 + d) * C:(2 + d) * C, :C], jets["G10"][d], tol, scale=gscale, what="G10")
+                rel_close(Mjh[:, (1 + d) * C:(2 + d) * C], jets["dMk"][d], tol, scale=max(1.0, np.abs(jets["dMk"]).max()), what="dMk")
+                for e in range(n):
+                    rel_close(Gh[(1 + d) * C:(2 + d) * C, (1 + e) * C:(2 + e) * C], jets["G11"][d][e], tol, scale=gscale, what="G11")
+            kstar = ogp.rbf_ard_kernel(hX[i], hxq[i][None], h["ell"][i], h["s2"][i])[:, 0]
+            W_o = sla.solve_triangular(st["L"], kstar[:, None] * st["UHB"], lower=True)
+            rel_close(host(Wj)[i, :N, :C], W_o, tol, scale=max(np.abs(W_o).max(), 1e-3), what="Wj values")
+            d0 = -(hxq[i][0] - hX[i][:, 0]) / h["ell"][i][0] ** 2 * kstar
+            dW_o = sla.solve_triangular(st["L"], d0[:, None] * st["UHB"], lower=True)
+            rel_close(host(Wj)[i, :N, C:2 * C], dW_o, tol, scale=max(np.abs(dW_o).max(), 1e-3), what="Wj d/dx0")
