@@ -342,6 +342,9 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
 int launch_refit_wave32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                         const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info,
                         int Bt, int N, int Np, int n, int C, hipStream_t st);          // refit_wave64.hip
+int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                        const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                        hipStream_t st);                                               // refit_wave64.hip: two waves per instance
 
 }  // namespace bcbf
 
@@ -356,6 +359,17 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     // Batches: one wave per instance (refit_wave64.hip, also compiled for fp32); BCBF_REFIT_WAVE=0/1 forces a form
     bool per_wave = Bt >= BCBF_R32_WAVE_MIN_BATCH || (Bt >= 512 && Np <= 512) || (Bt >= 128 && Np <= 256) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
+    // Two waves per instance (refit_wave64.hip): measured crossover in fp32 (ms workgroup / wave / pair): 1024 x 128:
+    // 0.174 / 0.115 / 0.095, 1024 x 256: 0.441 / 0.333 / 0.247, 512 x 512: 1.31 / 1.31 / 1.04, 1024 x 512: 1.70 / 1.37 / 1.37,
+    // 4096 x 512: 6.6 / 4.7 / 6.3, 4096 x 128: 0.68 / 0.37 / 0.39, 64 x 512: 0.72 / 1.24 / 0.93
+    bool pair = Bt >= 64 && ((Np <= 128 && Bt <= 2048) || (Np > 128 && Np <= 256) || (Np > 256 && Np <= 512 && Bt >= 128 && Bt <= 1024));
+    if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1';
+    if (pair && !Kdense && !Ldense) {
+        if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+        launch_refit_pair32(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st);
+        return check_launch("refit_pair32");
+    }
     if (per_wave) {
         if (!Kdense) {
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;

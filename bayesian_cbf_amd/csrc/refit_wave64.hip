@@ -369,6 +369,282 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #endif
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// TWO WAVES PER INSTANCE (round 3): the same left-looking factorisation with the two kinds of work of a block column on
+// two waves of one workgroup, so that an instance's VALU / LDS phases (diagonal tile: factor + invert) run BESIDE its
+// matrix-core phases (the rank-32 update streams) instead of after them:
+//   wave 1, the STREAMER: for every tile (I, J) of block column J, I = J .. : kernel values K_b' -> S' -= L_J L_I'
+//           (the MFMA stream over all previous columns).  The diagonal tile's S' goes to LDS, every other S' to global
+//           memory in place of L_IJ; after each tile a sequence number in LDS tells the solver how far it got.
+//   wave 0, the SOLVER: waits for the diagonal tile, factors and inverts it (diag_tile64.h), stores the inverse, then
+//           takes the S' tiles as they arrive: L_IJ' = inv(L_JJ) S' (accumulator-layout reload, MFMA), stored over S'.
+//           When the column is complete it publishes the column count; the streamer starts column J + 1 on it.
+// Both fit the 256-register budget of two waves per SIMD (each role carries half of what the one-wave kernel holds), so
+// a SIMD hosts waves of two different instances.  Hand-offs are workgroup-scope (same CU, same L1): release fence ->
+// LDS sequence word -> acquire fence.  Same outputs, same packed layout, same info convention; no dense output.
+#ifndef BCBF_RP_KS64
+#define BCBF_RP_KS64 2           // k-steps (of 4 columns) per pipeline stage of the streamer, fp64 (4 spill: 112 B at 256 registers)
+#endif
+#ifndef BCBF_RP_KS32
+#define BCBF_RP_KS32 4           // ... fp32
+#endif
+template <typename T> struct RPShared {
+    RWShared<T> w;
+    int seq_tile;                // streamer -> solver: 64 J + (tiles of column J delivered)
+    int seq_col;                 // solver -> streamer: columns completed (a large number after a failed pivot)
+    int fail;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(128, 2)
+refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
+                  const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
+                  T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+    constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
+    using P = RW<T>;
+    using acc_t = typename P::acc_t;
+    using T2 = typename P::vec2;
+    __shared__ RPShared<T> shm;
+    __attribute__((address_space(3))) RPShared<T>& sp = *(__attribute__((address_space(3))) RPShared<T>*)&shm;
+    __attribute__((address_space(3))) RWShared<T>& sh = sp.w;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.x;
+    const int j16 = lane & 15, g = lane >> 4;
+    T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const T* Xb = X + (size_t)b * N * n;
+    const T* UHb = UH + (size_t)b * N * C;
+    const int nblk = Np / NB;
+    {   // UH B rows (both waves), the hand-off words
+        T Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+#pragma unroll
+        for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : T(0.0);
+        for (int i = threadIdx.x; i < N; i += 128)
+            for (int c = 0; c < C; ++c) {
+                T s = T(0.0);
+                for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                UHBout[((size_t)b * N + i) * C + c] = s;
+            }
+        if (threadIdx.x == 0) { sp.seq_tile = 0; sp.seq_col = 0; sp.fail = 0; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    auto wait_for = [&](__attribute__((address_space(3))) int* word, int want) {
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto publish = [&](__attribute__((address_space(3))) int* word, int value) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    if (wave == 1) {
+        // =============================== the STREAMER ===============================
+        const T* UHBb = UHBout + (size_t)b * N * C;
+        // (registers: the first four state components only -- no reference system has more; wider states take the
+        //  slow path below, reading the rest from memory)
+        T iell[4];
+        const T s2 = s2p[b];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xb), 0, N * n * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, N * C * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
+        for (int J = 0; J < nblk; ++J) {
+            const int col0 = J * NB;
+            wait_for(&sp.seq_col, J);                              // column J - 1 complete (its panels are read below)
+            if (__hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+            for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
+                const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+                sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
+            }
+            for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
+                const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+                sh.colUH[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : T(0.0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            T rx[2][4], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+            auto load_rows = [&](int I_) {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = I_ * NB + 2 * j16 + ib;
+                    const bool in = I_ < nblk && i < N;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
+#pragma unroll
+                    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
+                    rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
+                }
+            };
+            load_rows(J);
+            for (int I = J; I < nblk; ++I) {
+                const int irow = I * NB + 2 * j16;
+                acc_t acc[2][2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                        T cx[4], cu[4];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) {
+                            const int i = irow + ib;
+                            T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                            if (n > 4) {                                  // (wave-uniform, rare)
+                                for (int d = 4; d < n; ++d) {
+                                    const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
+                                    const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
+                                    d2 += z * z;
+                                }
+                            }
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                            T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
+                            val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;
+                            acc[cb][ib][r] = val;
+                        }
+                        // one column's inputs at a time: left alone the scheduler hoists the LDS reads of all eight
+                        // columns (64 values) to the top of the tile
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                load_rows(I + 1);
+                constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
+                T2 a_nxt[KS], b_nxt[KS];
+                auto fetch = [&](int kk) {
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        const int base = lop_base<V>(kk + 4 * s_ + g, Np);
+                        a_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + col0 + 2 * j16);
+                        b_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + irow);
+                    }
+                };
+                if (col0 > 0) fetch(0);
+                for (int kk = 0; kk < col0; kk += 4 * KS) {
+                    T a_cur[KS][2], b_cur[KS][2];
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        a_cur[s_][0] = -a_nxt[s_].x; a_cur[s_][1] = -a_nxt[s_].y;
+                        b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+                    }
+                    if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
+                }
+                if (I == J) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sh.d.tile[2 * P::midx(r, g) + cb][2 * j16 + ib] = acc[cb][ib][r];
+                } else {
+                    // S' parked in global memory where L_IJ will live: (c, i), (c, i + 1) adjacent -> one 16-byte store
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            T2 v; v.x = acc[cb][0][r]; v.y = acc[cb][1][r];
+                            *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + 2 * P::midx(r, g) + cb, Np) + irow) = v;
+                        }
+                }
+                publish(&sp.seq_tile, 64 * J + (I - J + 1));
+            }
+        }
+        return;
+    }
+    // =============================== the SOLVER ===============================
+    int fail = 0;
+    for (int J = 0; J < nblk; ++J) {
+        const int col0 = J * NB;
+        wait_for(&sp.seq_tile, 64 * J + 1);
+        const int bad = diag_factor_invert<T>(BCBF_LDS_TILE(T, sh.d), lane);
+        if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
+        {
+            const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
+#pragma unroll
+            for (int t = 0; t < NB * NB / 64; ++t) {
+                const int e = lane + 64 * t, c = e >> 5, r = e & 31;
+                const T xv = sh.d.xinv[r][c];
+                lop[bfull + e] = xv;
+                if (r >= c) lop[bpack + lop_dinv_col(c) + r] = xv;
+            }
+            if (lane < LOP_DB - 528) lop[bpack + 528 + lane] = T(0.0);
+        }
+        if (fail != 0) {
+            if (lane == 0) __hip_atomic_store(&sp.fail, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            publish(&sp.seq_col, 1 << 20);                         // lets the streamer run out
+            break;
+        }
+        T ainv[2][2][4];
+#pragma unroll
+        for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];
+        for (int I = J + 1; I < nblk; ++I) {
+            const int irow = I * NB + 2 * j16;
+            wait_for(&sp.seq_tile, 64 * J + (I - J + 1));
+            T2 sv[2][4];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sv[cb][r] = *reinterpret_cast<const T2*>(lop + lop_base<V>(col0 + 2 * P::midx(r, g) + cb, Np) + irow);
+            acc_t y[2][2];                                          // [ib][cbp]
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int cbp = 0; cbp < 2; ++cbp) {
+                    acc_t yy = {0, 0, 0, 0};
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
+                            yy = P::mfma(ainv[cbp][cb][r], ib == 0 ? sv[cb][r].x : sv[cb][r].y, yy);
+                    y[ib][cbp] = yy;
+                }
+            // every lane has read its S' values (the MFMAs above consumed them) before any lane overwrites the tile
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        lop[lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + irow + ib] = y[ib][cbp][r];
+        }
+        publish(&sp.seq_col, J + 1);
+    }
+    if (lane == 0) info[b] = fail;
+}
+
+template <typename T>
+static int launch_refit_pair(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, T* Lop, T* UHB,
+                             int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+    hipLaunchKernelGGL((refit_pair_kernel<T>), dim3(Bt), dim3(128), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C);
+    return 0;
+}
+int launch_refit_pair64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                        const double* jitter, double* Lop, double* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                        hipStream_t st) {
+    return launch_refit_pair<double>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
+}
+int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                        const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                        hipStream_t st) {
+    return launch_refit_pair<float>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
+}
+
 // Called by bcbf_refit_mfma_f64 / _f32 for batches.
 template <typename T>
 static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,
