@@ -43,13 +43,15 @@ python tools/bench_configs.py 2>/dev/null > $O/configs.jsonl
 python tools/time_shared.py 2>/dev/null > $O/shared_queries.txt
 python tools/bench_refit_forms.py 2>/dev/null > $O/refit_forms.jsonl
 python tools/bench_refit_forms.py f32 2>/dev/null > $O/refit_forms_f32.jsonl
-python tools/bench_online.py --repeat 3 2>/dev/null > $O/online_growth_f64.json
+python tools/bench_online.py --repeat 2 2>/dev/null > $O/online_growth_f64.json
+python tools/bench_online.py --unfused --repeat 3 2>/dev/null > $O/online_growth_f64_unfused3.json
 python tools/bench_online.py --packed 2>/dev/null > $O/online_growth_f64_packed.json
 python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
 python tools/bench_speed_test.py --quick 2>/dev/null > $O/speed_test.jsonl
 python tools/bench_speed_test_unicycle.py --quick 2>/dev/null > $O/speed_test_unicycle.jsonl
 python tools/learn_dynamics_matrix_vector.py /tmp/learn_matrix_vector > /dev/null 2>&1; cp gpurun_out/learn_matrix_vector.jsonl $O/ 2>/dev/null
-python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -3 > $O/mc_rollouts.txt
+python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -1 > $O/mc_rollouts.txt
+python examples_mc_rollouts.py --trajectories 32768 2>/dev/null | tail -1 >> $O/mc_rollouts.txt
 du -sh $O; ls $O | head -50
 # keep the merge small: the raw traces are not needed, only the csv summaries
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*_kernel_trace.csv" -size +2M -delete 2>/dev/null
