@@ -139,12 +139,15 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     const T* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
     const T* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
     T* Ld = Ldense ? Ldense + (size_t)b * N * N : nullptr;
-    T iell[BCBF_MAX_STATE_DIM], Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+    // (registers hold the first RXD state components of a row -- no reference system has more than 4; wider states read
+    //  the rest from memory in the value pass)
+    constexpr int RXD = 4;
+    T iell[RXD], Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
     T s2 = T(0.0);
     if (!FROM_DENSE) {
         s2 = s2p[b];
 #pragma unroll
-        for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
+        for (int d = 0; d < RXD; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
 #pragma unroll
         for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a)
             Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : T(0.0);
@@ -191,7 +194,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
         // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one tile ahead, so that the loads are in
         // flight during the previous tile's update stream instead of queueing behind its panel stores
-        T rx[2][BCBF_MAX_STATE_DIM], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+        T rx[2][RXD], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
         // Branch-free: every load is issued, a component the model does not have (d >= n, c >= C) or a row past the end
         // is an out-of-range buffer offset and reads as zero.  (Written with `if (d < n)` around plain loads each one
         // became its own basic block with a full wait behind it: ten serialized memory round trips per tile, 44 % of
@@ -203,7 +206,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 const int i = I_ * NB + 2 * j16 + ib;
                 const bool in = I_ < nblk && i < N;
 #pragma unroll
-                for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d)
+                for (int d = 0; d < RXD; ++d)
                     rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
 #pragma unroll
                 for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
@@ -251,8 +254,11 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                             for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
                             if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
-#pragma unroll
-                                for (int d = 4; d < BCBF_MAX_STATE_DIM; ++d) { const T z = (rx[ib][d] - sh.colX[c][d]) * iell[d]; d2 += z * z; }
+                                for (int d = 4; d < n; ++d) {
+                                    const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
+                                    const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
+                                    d2 += z * z;
+                                }
                             }
 #pragma unroll
                             for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
