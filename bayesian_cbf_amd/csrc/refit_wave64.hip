@@ -384,7 +384,8 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 //           memory in place of L_IJ; after each tile a sequence number in LDS tells the solver how far it got.
 //   wave 0, the SOLVER: waits for the diagonal tile, factors and inverts it (diag_tile64.h), stores the inverse, then
 //           takes the S' tiles as they arrive: L_IJ' = inv(L_JJ) S' (accumulator-layout reload, MFMA), stored over S'.
-//           When the column is complete it publishes the column count; the streamer starts column J + 1 on it.
+//           After each panel tile it publishes a count; the streamer's tile (I, J + 1) starts on L_{I,J} (it chases the
+//           solver down the column instead of waiting for the column to complete).
 // Both fit the 256-register budget of two waves per SIMD (each role carries half of what the one-wave kernel holds), so
 // a SIMD hosts waves of two different instances.  Hand-offs are workgroup-scope (same CU, same L1): release fence ->
 // LDS sequence word -> acquire fence.  Same outputs, same packed layout, same info convention; no dense output.
@@ -394,10 +395,20 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #ifndef BCBF_RP_KS32
 #define BCBF_RP_KS32 4           // ... fp32
 #endif
+// -DBCBF_RP_TRACE (development, tools/trace_refit_pair.py): 100 MHz time stamps of workgroup 0's two waves at every hand-off
+#ifdef BCBF_RP_TRACE
+__device__ long long rp_trace_buf[2][4096];
+extern "C" __attribute__((visibility("default"))) int bcbf_debug_rp_trace(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rp_trace_buf), sizeof(rp_trace_buf));
+}
+#define RP_T(w) do { if (b == 0 && lane == 0 && tix < 4096) rp_trace_buf[w][tix] = wall_clock64(); ++tix; } while (0)
+#else
+#define RP_T(w) do {} while (0)
+#endif
 template <typename T> struct RPShared {
     RWShared<T> w;
     int seq_tile;                // streamer -> solver: 64 J + (tiles of column J delivered)
-    int seq_col;                 // solver -> streamer: columns completed (a large number after a failed pivot)
+    int seq_col;                 // solver -> streamer: 64 J + (panel tiles of column J delivered) (a large number after a failed pivot)
     int fail;
 };
 
@@ -457,10 +468,9 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, N * C * ES, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
+        int tix = 0; (void)tix;
         for (int J = 0; J < nblk; ++J) {
             const int col0 = J * NB;
-            wait_for(&sp.seq_col, J);                              // column J - 1 complete (its panels are read below)
-            if (__hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
             for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
                 const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
                 sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
@@ -487,6 +497,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             for (int I = J; I < nblk; ++I) {
                 const int irow = I * NB + 2 * j16;
                 acc_t acc[2][2];
+                RP_T(1);                                           // 0: tile starts
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -519,6 +530,14 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 load_rows(I + 1);
+                RP_T(1);                                           // 1: values done
+                // the update reads block rows J and I of every earlier column: the last of them, L_{I,J-1}, is the panel
+                // tile the solver delivers I - J + 1 tiles into column J - 1 (the values above did not need it)
+                if (J > 0) {
+                    wait_for(&sp.seq_col, 64 * (J - 1) + (I - J + 1));
+                    if (__hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+                }
+                RP_T(1);                                           // 2: panel tile arrived
                 constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
                 T2 a_nxt[KS], b_nxt[KS];
                 auto fetch = [&](int kk) {
@@ -545,6 +564,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                             for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
                 }
+                RP_T(1);                                           // 3: update stream done
                 if (I == J) {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
@@ -563,16 +583,21 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         }
                 }
                 publish(&sp.seq_tile, 64 * J + (I - J + 1));
+                RP_T(1);                                           // 4: tile published
             }
         }
         return;
     }
     // =============================== the SOLVER ===============================
     int fail = 0;
+    int tix = 0; (void)tix;
     for (int J = 0; J < nblk; ++J) {
         const int col0 = J * NB;
+        RP_T(0);                                                   // column: 0 starts waiting for the diagonal tile
         wait_for(&sp.seq_tile, 64 * J + 1);
+        RP_T(0);                                                   // 1: tile arrived
         const int bad = diag_factor_invert<T>(BCBF_LDS_TILE(T, sh.d), lane);
+        RP_T(0);                                                   // 2: factored + inverted
         if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
         {
             const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
@@ -597,9 +622,12 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];
+        RP_T(0);                                                   // 3: inverse stored, operands loaded
         for (int I = J + 1; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;
+            RP_T(0);                                               // panel: 0 starts waiting
             wait_for(&sp.seq_tile, 64 * J + (I - J + 1));
+            RP_T(0);                                               // 1: S' arrived
             T2 sv[2][4];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
@@ -628,8 +656,9 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         lop[lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + irow + ib] = y[ib][cbp][r];
+            publish(&sp.seq_col, 64 * J + (I - J));
+            RP_T(0);                                               // 2: published
         }
-        publish(&sp.seq_col, J + 1);
     }
     if (lane == 0) info[b] = fail;
 }
