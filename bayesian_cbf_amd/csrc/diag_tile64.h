@@ -12,6 +12,9 @@
 // ~40 k cycles per tile measured in the kernel (the 32-step left-looking form it replaces: 65-77 k).
 #pragma once
 #include "bcbf_common.h"
+#ifndef BCBF_DT_STAMP
+#define BCBF_DT_STAMP(k) do {} while (0)      // development: refit_wave64.hip's -DBCBF_RP_TRACE time stamps
+#endif
 
 namespace bcbf {
 
@@ -95,6 +98,7 @@ template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* s
             for (int a = 0; a < 4; ++a) sh->P[rr][a] = S[q0 + a];
         }
         __builtin_amdgcn_wave_barrier();
+        BCBF_DT_STAMP(0);
         // (2) 4x4 diagonal block: Cholesky factor and inverse, redundantly in every lane
         const T d00 = sh->P[c0][0];
         const T d10 = sh->P[c0 + 1][0], d11 = sh->P[c0 + 1][1];
@@ -127,6 +131,7 @@ template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* s
             I4[0] = i00; I4[1] = i10; I4[2] = i11; I4[3] = i20; I4[4] = i21; I4[5] = i22;
             I4[6] = i30; I4[7] = i31; I4[8] = i32; I4[9] = i33;
         }
+        BCBF_DT_STAMP(1);
         // (3) this lane's row of the panel: l = P[rr][:] inv(L4)'   (rows of the block itself: L4; rows above: 0)
         const T pr0 = sh->P[rr][0], pr1 = sh->P[rr][1], pr2 = sh->P[rr][2], pr3 = sh->P[rr][3];
         T l0 = pr0 * i00;
@@ -144,6 +149,7 @@ template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* s
             sh->tile[rr][c0] = l0; sh->tile[rr][c0 + 1] = l1; sh->tile[rr][c0 + 2] = l2; sh->tile[rr][c0 + 3] = l3;
         }
         __builtin_amdgcn_wave_barrier();
+        BCBF_DT_STAMP(2);
         // (4) rank-4 update of the lane's 16 elements S[rr][16 hb + q] -= l[rr] . l[16 hb + q]
         //     (columns already factored receive garbage: they are never read again)
         if (s < NB / 4 - 1) {
@@ -160,6 +166,7 @@ template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* s
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        BCBF_DT_STAMP(3);
     }
     __builtin_amdgcn_wave_barrier();
     // ---- X = inv(L): lane = column rr; half hb forms rows 2hb, 2hb+1 of each 4-row step.  X lives in LDS
@@ -188,8 +195,148 @@ template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* s
                 sh->xinv[c0 + 3][rr] = c0 + 3 >= rr ? I4[6] * e0 + I4[7] * e1 + I4[8] * e2 + I4[9] * e3 : T(0.0);
             }
             __builtin_amdgcn_wave_barrier();
+            BCBF_DT_STAMP(4);
         }
     }
+    return bad;
+}
+
+
+// ---- the same tile out of MFMA ACCUMULATOR registers, the rank-4 updates on the matrix cores (round 3) ----
+// S arrives the way the update stream of refit_wave64.hip leaves it: S[cb][ib][r] in lane (j16 = lane & 15, g = lane >> 4) is
+// the element (p = 2 midx(r, g) + cb, q = 2 j16 + ib) of the symmetric tile (midx: the accumulator row of register r in
+// lane group g, g + 4r in fp64, 4g + r in fp32); the entries with p <= q are the ones read.  Step s (columns c0 = 4s ..):
+//   publish  rows c0..c0+3 of S sit in ONE register index of two (fp64) / one (fp32) lane group(s): 2 values per lane and
+//            column -> P[q][a]
+//   pivots   every lane factors and inverts the 4x4 diagonal block redundantly (as above)
+//   panel    lane (j16, g) forms l(q, c0 + g) for its two q from P[q][0..3] and row g of the 4x4 inverse -- exactly the A
+//            (row 2 j16 + cb) and B (row 2 j16 + ib) operands of  S -= l l'  as FOUR 16x16x4 MFMAs: no second trip
+//            through LDS, no 64 multiply-adds per lane
+//   inverse  W (starts as the identity, same layout) takes the same eliminations: rows c0..c0+3 of W are published like
+//            S's, X(c0 + g, q) = (row g of the 4x4 inverse) . W(c0.., q) is a row of inv(L) AND the B operand of
+//            W -= l X: four more MFMAs, off the pivots' critical path.  The serial 8-step inverse pass above is gone.
+// Outputs as above (sh->xinv = inv(L) [row][col] with zeros above the diagonal; sh->tile = L likewise when WANT_L -- the
+// packed operator stores only the inverse of a diagonal tile).
+template <typename T> __device__ inline int dt_midx(int r, int g) { return sizeof(T) == 8 ? g + 4 * r : 4 * g + r; }
+__device__ inline __attribute__((__vector_size__(4 * sizeof(double)))) double
+dt_mfma(double a, double b, __attribute__((__vector_size__(4 * sizeof(double)))) double c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ inline __attribute__((__vector_size__(4 * sizeof(float)))) float
+dt_mfma(float a, float b, __attribute__((__vector_size__(4 * sizeof(float)))) float c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <typename T, bool WANT_L, typename ACC>
+__device__ inline int diag_factor_invert_acc(DiagTileLds<T>* sh, ACC (&S)[2][2], int lane) {
+    const int j16 = lane & 15, g = lane >> 4;
+    ACC W[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[cb][ib][r] = (2 * dt_midx<T>(r, g) + cb == 2 * j16 + ib) ? T(1.0) : T(0.0);
+    int bad = 0;
+#pragma unroll
+    for (int s = 0; s < NB / 4; ++s) {
+        const int c0 = 4 * s;
+        // (1) rows c0..c0+3 of S and of W -> P / Lp  ([q][a])
+        if (sizeof(T) == 8) {
+            const int r0 = s >> 1, ga = (2 * s) & 3;
+            if (g == ga || g == ga + 1) {
+                const int a0 = g == ga ? 0 : 2;
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    sh->P[2 * j16 + ib][a0] = S[0][ib][r0];  sh->P[2 * j16 + ib][a0 + 1] = S[1][ib][r0];
+                    sh->Lp[2 * j16 + ib][a0] = W[0][ib][r0]; sh->Lp[2 * j16 + ib][a0 + 1] = W[1][ib][r0];
+                }
+            }
+        } else {
+            const int r0 = (2 * s) & 3;
+            if (g == (s >> 1)) {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    sh->P[2 * j16 + ib][0] = S[0][ib][r0];      sh->P[2 * j16 + ib][1] = S[1][ib][r0];
+                    sh->P[2 * j16 + ib][2] = S[0][ib][r0 + 1];  sh->P[2 * j16 + ib][3] = S[1][ib][r0 + 1];
+                    sh->Lp[2 * j16 + ib][0] = W[0][ib][r0];     sh->Lp[2 * j16 + ib][1] = W[1][ib][r0];
+                    sh->Lp[2 * j16 + ib][2] = W[0][ib][r0 + 1]; sh->Lp[2 * j16 + ib][3] = W[1][ib][r0 + 1];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        BCBF_DT_STAMP(0);
+        // (2) 4x4 diagonal block: Cholesky factor and inverse, redundantly in every lane
+        const T d00 = sh->P[c0][0];
+        const T d10 = sh->P[c0 + 1][0], d11 = sh->P[c0 + 1][1];
+        const T d20 = sh->P[c0 + 2][0], d21 = sh->P[c0 + 2][1], d22 = sh->P[c0 + 2][2];
+        const T d30 = sh->P[c0 + 3][0], d31 = sh->P[c0 + 3][1], d32 = sh->P[c0 + 3][2], d33 = sh->P[c0 + 3][3];
+        const T p0 = d00;
+        if (!(p0 > T(0.0)) && bad == 0) bad = c0 + 1;
+        const T r0_ = rsqrt_nr2(p0 > T(0.0) ? p0 : T(1.0));
+        const T l00 = p0 * r0_, l10 = d10 * r0_, l20 = d20 * r0_, l30 = d30 * r0_;
+        const T p1 = d11 - l10 * l10;
+        if (!(p1 > T(0.0)) && bad == 0) bad = c0 + 2;
+        const T r1_ = rsqrt_nr2(p1 > T(0.0) ? p1 : T(1.0));
+        const T l11 = p1 * r1_, l21 = (d21 - l20 * l10) * r1_, l31 = (d31 - l30 * l10) * r1_;
+        const T p2 = d22 - l20 * l20 - l21 * l21;
+        if (!(p2 > T(0.0)) && bad == 0) bad = c0 + 3;
+        const T r2_ = rsqrt_nr2(p2 > T(0.0) ? p2 : T(1.0));
+        const T l22 = p2 * r2_, l32 = (d32 - l30 * l20 - l31 * l21) * r2_;
+        const T p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+        if (!(p3 > T(0.0)) && bad == 0) bad = c0 + 4;
+        const T r3_ = rsqrt_nr2(p3 > T(0.0) ? p3 : T(1.0));
+        const T l33 = p3 * r3_;
+        const T i00 = r0_, i11 = r1_, i22 = r2_, i33 = r3_;
+        const T i10 = -(l10 * i00) * r1_;
+        const T i20 = -(l20 * i00 + l21 * i10) * r2_, i21 = -(l21 * i11) * r2_;
+        const T i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * r3_, i31 = -(l31 * i11 + l32 * i21) * r3_,
+                     i32 = -(l32 * i22) * r3_;
+        BCBF_DT_STAMP(1);
+        // (3) row g of the 4x4 inverse / column g of the 4x4 factor, then this lane's two panel entries and inverse entries
+        const T z = T(0.0);
+        const T k0 = g == 0 ? i00 : g == 1 ? i10 : g == 2 ? i20 : i30;
+        const T k1 = g == 0 ? z : g == 1 ? i11 : g == 2 ? i21 : i31;
+        const T k2 = g < 2 ? z : g == 2 ? i22 : i32;
+        const T k3 = g == 3 ? i33 : z;
+        const T f0 = g == 0 ? l00 : z;
+        const T f1 = g == 0 ? l10 : g == 1 ? l11 : z;
+        const T f2 = g == 0 ? l20 : g == 1 ? l21 : g == 2 ? l22 : z;
+        const T f3 = g == 0 ? l30 : g == 1 ? l31 : g == 2 ? l32 : l33;
+        // (this lane's rows of both publications: read HERE, behind the pivots -- 16 more live values across the four
+        //  rsqrt chains spill at 256 registers; the LDS round trip this exposes is a fifth of a microsecond per tile)
+        __builtin_amdgcn_sched_barrier(0);
+        T pr[2][4], pw[2][4];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { pr[ib][a] = sh->P[2 * j16 + ib][a]; pw[ib][a] = sh->Lp[2 * j16 + ib][a]; }
+        T la[2], xb[2];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int qa = 2 * j16 + ib - c0;              // row inside the block (0..3), negative above
+            T v = k0 * pr[ib][0] + k1 * pr[ib][1] + k2 * pr[ib][2] + k3 * pr[ib][3];
+            v = qa < 0 ? z : qa == 0 ? f0 : qa == 1 ? f1 : qa == 2 ? f2 : qa == 3 ? f3 : v;
+            la[ib] = v;
+            xb[ib] = k0 * pw[ib][0] + k1 * pw[ib][1] + k2 * pw[ib][2] + k3 * pw[ib][3];
+            if (WANT_L) sh->tile[2 * j16 + ib][c0 + g] = v;
+            sh->xinv[c0 + g][2 * j16 + ib] = xb[ib];
+        }
+        BCBF_DT_STAMP(2);
+        // (4) S -= l l',  W -= l X  on the matrix cores
+        if (s < NB / 4 - 1) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) S[cb][ib] = dt_mfma(-la[cb], la[ib], S[cb][ib]);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) W[cb][ib] = dt_mfma(-la[cb], xb[ib], W[cb][ib]);
+        }
+        BCBF_DT_STAMP(3);
+    }
+    __builtin_amdgcn_wave_barrier();
     return bad;
 }
 

@@ -346,6 +346,7 @@ int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const 
                         const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
                         hipStream_t st);                                               // refit_wave64.hip: two waves per instance
 
+
 }  // namespace bcbf
 
 extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
@@ -359,11 +360,11 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     // Batches: one wave per instance (refit_wave64.hip, also compiled for fp32); BCBF_REFIT_WAVE=0/1 forces a form
     bool per_wave = Bt >= BCBF_R32_WAVE_MIN_BATCH || (Bt >= 512 && Np <= 512) || (Bt >= 128 && Np <= 256) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
-    // Two waves per instance (refit_wave64.hip): measured crossover in fp32 (ms workgroup / wave / pair): 1024 x 128:
-    // 0.174 / 0.115 / 0.095, 1024 x 256: 0.441 / 0.333 / 0.247, 512 x 512: 1.31 / 1.31 / 1.04, 1024 x 512: 1.70 / 1.37 / 1.37,
-    // 4096 x 512: 6.6 / 4.7 / 6.3, 4096 x 128: 0.68 / 0.37 / 0.39, 64 x 512: 0.72 / 1.24 / 0.93
-    bool pair = Bt >= 64 && ((Np <= 128 && Bt <= 2048) || (Np > 128 && Np <= 256) || (Np > 256 && Np <= 512 && Bt >= 128 && Bt <= 1024));
-    if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1';
+    // Two waves per instance (refit_wave64.hip): measured in fp32 (ms workgroup / wave / two waves): 1024 x 128: 0.173 /
+    // 0.112 / 0.064, 4096 x 128: 0.68 / 0.34 / 0.24, 1024 x 256: 0.443 / 0.326 / 0.194, 4096 x 256: 1.76 / 1.00 / 0.89,
+    // 256 x 512: 1.17 / 1.26 / 0.88, 1024 x 512: 1.69 / 1.36 / 1.22, 4096 x 512: 6.6 / 4.5 / 5.6, 64 x 512: 0.71 / 1.22 / 0.78
+    bool pair = Bt >= 64 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 1024));
+    if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;

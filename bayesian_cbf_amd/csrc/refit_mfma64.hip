@@ -339,6 +339,7 @@ int launch_refit_pair64(const double* X, const double* UH, const double* Bm, con
                         const double* jitter, double* Lop, double* UHB, int* info, int Bt, int N, int Np, int n, int C,
                         hipStream_t st);                                               // refit_wave64.hip: two waves per instance
 
+
 }  // namespace bcbf
 
 extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const double* Bm, const double* ell,
@@ -362,13 +363,14 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     // form below.)
     bool per_wave = Bt >= 1024 || (Bt >= 512 && Np <= 256) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
-    // Two waves per instance (refit_wave64.hip, round 3: the diagonal tile of a block column is factored by one wave beside
-    // the other's update streams) wins for small systems at every batch from 64 on -- measured (tools/bench_refit_forms.py,
-    // ms wave / pair): 1024 x 256: 0.452 / 0.382, 4096 x 256: 1.76 / 1.67, 1024 x 128: 0.150 / 0.129, 64 x 256: 0.396 / 0.264
-    // (workgroup form 0.301) -- and loses from N = 512 on (1024 x 512: 2.09 / 2.51), where the one-wave form keeps more
-    // of the update stream in flight.  BCBF_REFIT_PAIR=0/1 forces the choice.
+    // Two waves per instance (refit_wave64.hip, round 3: the serial chain of diagonal tiles on one wave, every other tile on
+    // the other) wins for small systems at every batch from 64 on -- measured (tools/bench_refit_forms.py, ms workgroup /
+    // wave / two waves): 1024 x 256: 0.818 / 0.461 / 0.320, 4096 x 256: 3.26 / 1.80 / 1.37, 1024 x 128: 0.319 / 0.156 / 0.101,
+    // 64 x 256: 0.305 / 0.403 / 0.206 -- and loses at N = 512 (256 x 512: 1.12 / 1.78 / 1.39, 1024 x 512: 3.06 / 2.09 / 2.22),
+    // where the one-wave form (512 registers) keeps more of the update stream in flight.  BCBF_REFIT_PAIR=0/1 forces the
+    // choice (N <= 512).
     bool pair = Bt >= 64 && Np <= 256;
-    if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1';
+    if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         launch_refit_pair64(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st);
         return check_launch("refit_pair64");

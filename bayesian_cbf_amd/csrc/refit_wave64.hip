@@ -30,6 +30,12 @@
 // workgroup-form kernels, refit_mfma*.hip: they run four waves per SIMD against a 128 / 256-register cap, waits are
 // hidden by the other waves and the extra values in flight spill.)
 #include "bcbf_common.h"
+#ifdef BCBF_RP_TRACE
+// time stamps inside the diagonal tile's factor + inverse (first call of workgroup 0 only), after the hand-off stamps
+namespace bcbf { __device__ long long rp_trace_buf[2][4096]; __device__ int dt_trace_n; }
+#define BCBF_DT_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { const int i_ = bcbf::dt_trace_n; \
+    if (i_ < 40) { bcbf::rp_trace_buf[0][4000 + i_] = ((long long)(k) << 56) | (long long)wall_clock64(); bcbf::dt_trace_n = i_ + 1; } } } while (0)
+#endif
 #include "diag_tile64.h"
 
 namespace bcbf {
@@ -105,6 +111,7 @@ template <> struct RW<double> {
     __device__ static acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     __device__ static double exp_neg(double x) { return exp_neg64(x); }
     __device__ static double bload(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+    __device__ static double2 bload2(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 };
 template <> struct RW<float> {
     using acc_t = f32x4w;
@@ -114,6 +121,7 @@ template <> struct RW<float> {
     __device__ static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     __device__ static float exp_neg(float x) { return __expf(-x); }
     __device__ static float bload(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+    __device__ static float2 bload2(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 };
 
 template <typename T, bool FROM_DENSE, int OCC>
@@ -375,55 +383,68 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #endif
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// TWO WAVES PER INSTANCE (round 3): the same left-looking factorisation with the two kinds of work of a block column on
-// two waves of one workgroup, so that an instance's VALU / LDS phases (diagonal tile: factor + invert) run BESIDE its
-// matrix-core phases (the rank-32 update streams) instead of after them:
-//   wave 1, the STREAMER: for every tile (I, J) of block column J, I = J .. : kernel values K_b' -> S' -= L_J L_I'
-//           (the MFMA stream over all previous columns).  The diagonal tile's S' goes to LDS, every other S' to global
-//           memory in place of L_IJ; after each tile a sequence number in LDS tells the solver how far it got.
-//   wave 0, the SOLVER: waits for the diagonal tile, factors and inverts it (diag_tile64.h), stores the inverse, then
-//           takes the S' tiles as they arrive: L_IJ' = inv(L_JJ) S' (accumulator-layout reload, MFMA), stored over S'.
-//           After each panel tile it publishes a count; the streamer's tile (I, J + 1) starts on L_{I,J} (it chases the
-//           solver down the column instead of waiting for the column to complete).
-// Both fit the 256-register budget of two waves per SIMD (each role carries half of what the one-wave kernel holds), so
-// a SIMD hosts waves of two different instances.  Hand-offs are workgroup-scope (same CU, same L1): release fence ->
-// LDS sequence word -> acquire fence.  Same outputs, same packed layout, same info convention; no dense output.
 #ifndef BCBF_RP_KS64
-#define BCBF_RP_KS64 2           // k-steps (of 4 columns) per pipeline stage of the streamer, fp64 (4 spill: 112 B at 256 registers)
+#define BCBF_RP_KS64 2           // k-steps (of 4 columns) per pipeline stage of the update stream, fp64 (4: no faster, spills more)
 #endif
 #ifndef BCBF_RP_KS32
 #define BCBF_RP_KS32 4           // ... fp32
 #endif
 // -DBCBF_RP_TRACE (development, tools/trace_refit_pair.py): 100 MHz time stamps of workgroup 0's two waves at every hand-off
 #ifdef BCBF_RP_TRACE
-__device__ long long rp_trace_buf[2][4096];
 extern "C" __attribute__((visibility("default"))) int bcbf_debug_rp_trace(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rp_trace_buf), sizeof(rp_trace_buf));
 }
-#define RP_T(w) do { if (b == 0 && lane == 0 && tix < 4096) rp_trace_buf[w][tix] = wall_clock64(); ++tix; } while (0)
+#define RP_T(w) do { if (b == 0 && lane == 0 && tix < 4000) rp_trace_buf[w][tix] = wall_clock64(); ++tix; } while (0)
 #else
 #define RP_T(w) do {} while (0)
 #endif
-template <typename T> struct RPShared {
-    RWShared<T> w;
-    int seq_tile;                // streamer -> solver: 64 J + (tiles of column J delivered)
-    int seq_col;                 // solver -> streamer: 64 J + (panel tiles of column J delivered) (a large number after a failed pivot)
+constexpr int RA_MAXBLK = 16;          // block columns the look-ahead form handles (Np <= 512)
+
+// ----------------------------------------------------------------------------------------------------------------
+// TWO WAVES PER INSTANCE (round 3): the same left-looking factorisation with its serial chain -- factor the diagonal tile
+// of block column J, solve the one panel tile below it, bring the next diagonal tile up to date, factor it -- on wave 0,
+// which does NOTHING ELSE; every other tile of the matrix is wave 1's, which works one block column behind:
+//   wave 0, the CHAIN:  the diagonal tile's values and its updates over the columns that are complete are formed while it
+//           waits; S'_JJ -= L_{J,J-1} L_{J,J-1}' as soon as wave 1 delivers that panel tile; factor + invert on the matrix
+//           cores straight out of the accumulators (diag_tile64.h: diag_factor_invert_acc); column count -> LDS word
+//           (wave 1 takes the inverse out of LDS); inverse -> global memory.
+//   wave 1, the BULK:  S' of the column's first panel tile is formed while it waits; on the column count: inv(L_JJ) ->
+//           registers, L_{J+1,J}' = inv(L_JJ) S' -> stored, published (the chain continues on it); then every other tile
+//           of column J: values, update stream, solve straight out of the accumulators (no S' parked in memory), store.
+// Hand-offs are three counters in LDS (diagonal tiles inverted; first panel tiles delivered; columns complete: release
+// fence -> word -> acquire fence, workgroup scope: same CU, same L1); wave 1 fences once per column for everything but
+// the chain's tile.  Both waves fit the 256-register budget of two waves per SIMD, so a SIMD hosts waves of two different
+// instances.  Same outputs, same packed layout, same info convention; no dense output.
+// (A first split -- wave 1 streaming every tile's S' through memory, wave 0 factoring the diagonal tiles and solving the
+// parked S' -- left the streamer as the critical path, moved a quarter more bytes and was 15 % slower: 0.377 against
+// 0.320 ms at 1024 x 256 fp64, tools/bench_refit_forms.py.)
+#ifdef BCBF_RP_TRACE
+#define RA_T(w) RP_T(w)
+#else
+#define RA_T(w) do {} while (0)
+#endif
+template <typename T> struct RAShared {
+    DiagTile<T> d;                            // wave 0's
+    T colX[2][NB][BCBF_MAX_STATE_DIM];        // [wave]: each wave stages the column block it is forming values for
+    T colUH[2][NB][BCBF_MAX_CTRL_DIM + 1];
+    unsigned pack_rc[LOP_DB / 2];             // (row, column) of the entries of a packed inverted diagonal block, two per word
+    int inv_ready;                            // wave 0 -> 1: diagonal tiles factored, inverse in global memory (a large number after a failed pivot)
+    int first_done;                           // wave 1 -> 0: columns J whose first panel tile L_{J+1,J} is complete
+    int cols_done;                            // wave 1 -> 0: columns complete
     int fail;
 };
 
 template <typename T>
 __global__ void __launch_bounds__(128, 2)
 refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
-                  const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
-                  T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+                   const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
+                   T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
     using P = RW<T>;
     using acc_t = typename P::acc_t;
     using T2 = typename P::vec2;
-    __shared__ RPShared<T> shm;
-    __attribute__((address_space(3))) RPShared<T>& sp = *(__attribute__((address_space(3))) RPShared<T>*)&shm;
-    __attribute__((address_space(3))) RWShared<T>& sh = sp.w;
+    __shared__ RAShared<T> shm;
+    __attribute__((address_space(3))) RAShared<T>& sp = *(__attribute__((address_space(3))) RAShared<T>*)&shm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x;
     const int j16 = lane & 15, g = lane >> 4;
@@ -441,7 +462,22 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
                 UHBout[((size_t)b * N + i) * C + c] = s;
             }
-        if (threadIdx.x == 0) { sp.seq_tile = 0; sp.seq_col = 0; sp.fail = 0; }
+        if (threadIdx.x == 0) { sp.inv_ready = 0; sp.first_done = 0; sp.cols_done = 0; sp.fail = 0; }
+        for (int w = threadIdx.x; w < LOP_DB / 2; w += 128) {      // packed triangle, column-major: entry k <-> (r, c), r >= c
+            unsigned word = 0;
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * w + h;
+                // column c starts at entry c (65 - c) / 2: the root of that quadratic, then one step either way
+                int c = (int)((65.0f - __builtin_sqrtf(4225.0f - 8.0f * (float)(k < 528 ? k : 527))) * 0.5f);
+                c = c < 0 ? 0 : c > NB - 1 ? NB - 1 : c;
+                if (c < NB - 1 && lop_dinv_col(c + 1) + c + 1 <= k) ++c;
+                if (lop_dinv_col(c) + c > k) --c;
+                const int r = k - lop_dinv_col(c);
+                const unsigned rc = k < 528 ? (unsigned)(r | (c << 8)) : 0xffffu;
+                word |= rc << (16 * h);
+            }
+            sp.pack_rc[w] = word;
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -454,186 +490,222 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    auto failed = [&]() { return __hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
 
-    if (wave == 1) {
-        // =============================== the STREAMER ===============================
-        const T* UHBb = UHBout + (size_t)b * N * C;
-        // (registers: the first four state components only -- no reference system has more; wider states take the
-        //  slow path below, reading the rest from memory)
-        T iell[4];
-        const T s2 = s2p[b];
+    // ---- what both waves do to a tile: kernel values, the update stream (each on its own registers and its own column
+    //      block in LDS)
+    const T* UHBb = UHBout + (size_t)b * N * C;
+    // (registers: the first four state components only -- no reference system has more; wider states take the slow
+    //  path below, reading the rest from memory)
+    T iell[4];
+    const T s2 = s2p[b];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
-        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xb), 0, N * n * ES, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, N * C * ES, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
-        int tix = 0; (void)tix;
-        for (int J = 0; J < nblk; ++J) {
-            const int col0 = J * NB;
-            for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
-                const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
-                sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
-            }
-            for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
-                const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
-                sh.colUH[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : T(0.0);
-            }
-            __builtin_amdgcn_wave_barrier();
-            T rx[2][4], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
-            auto load_rows = [&](int I_) {
+    for (int d = 0; d < 4; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xb), 0, N * n * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, N * C * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
+    auto& cX = sp.colX[wave];
+    auto& cU = sp.colUH[wave];
+    auto stage_col = [&](int J) {
+        const int col0 = J * NB;
+        __builtin_amdgcn_wave_barrier();                           // every lane is done with the previous column block
+        for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
+            const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+            cX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
+        }
+        for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
+            const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+            cU[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : T(0.0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    T rx[2][4], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+    auto load_rows = [&](int I_) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int i = I_ * NB + 2 * j16 + ib;
+            const bool in = I_ < nblk && i < N;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
+#pragma unroll
+            for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
+            rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
+        }
+    };
+    // acc[cb][ib][r] = K_b'(column col0 + 2 midx(r, g) + cb, row 32 I + 2 j16 + ib)   (rows of block row I in rx / ru / rj)
+    auto values = [&](acc_t (&acc)[2][2], int I, int J) {
+        const int col0 = J * NB, irow = I * NB + 2 * j16;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                T cx[4], cu[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { cx[d] = cX[c][d]; cu[d] = cU[c][d]; }
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {
-                    const int i = I_ * NB + 2 * j16 + ib;
-                    const bool in = I_ < nblk && i < N;
+                    const int i = irow + ib;
+                    T d2 = T(0.0), uu = T(0.0);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
+                    for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                    if (n > 4) {                                  // (wave-uniform, rare)
+                        for (int d = 4; d < n; ++d) {
+                            const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
+                            const T z = (xi - cX[c][d]) / ell[(size_t)b * n + d];
+                            d2 += z * z;
+                        }
+                    }
 #pragma unroll
-                    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
-                    rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
+                    for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                    T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
+                    val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;
+                    acc[cb][ib][r] = -val;                         // the accumulators carry -S' (see update)
                 }
-            };
-            load_rows(J);
-            for (int I = J; I < nblk; ++I) {
-                const int irow = I * NB + 2 * j16;
-                acc_t acc[2][2];
-                RP_T(1);                                           // 0: tile starts
+                // one column's inputs at a time: left alone the scheduler hoists the LDS reads of all eight columns
+                // (64 values) to the top of the tile
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    // acc += L_{J, k0..k1} L_{I, k0..k1}'   (columns k0 <= k < k1 of the packed operator; software pipelined).  acc holds
+    // -S': the MFMA has no negate modifier, and flipping an operand costs four VALU instructions per k-step against once
+    // per tile at the consumer.  Addresses: inside block column K the packed columns are a fixed stride apart, so a load
+    // is  buffer base + SCALAR offset (column block, k-step) + per-lane offset (lane group's column, row)  -- two
+    // multiply-adds per fetch instead of the full column-offset polynomial per load (the VALU work of this loop was
+    // a third of its time: the wave issues in order, address arithmetic does not hide behind its own MFMAs)
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(lop, 0, (int)(lop_elems<V>(Np) * ES), 0x00020000);
+    auto update = [&](acc_t (&acc)[2][2], int I, int J, int k0, int k1) {
+        constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
+        const int col0 = J * NB, irow = I * NB + 2 * j16;
+        if (k0 >= k1) return;
+        T2 a_nxt[KS], b_nxt[KS];
+        auto fetch = [&](int kk) {
+            const int K = kk / NB, stride = Np - NB * (K + 1);     // (wave-uniform: scalar registers)
+            // (lop_base of a block column's first column is NEGATIVE for K = 0 -- rows count from 32 (K + 1) -- and a
+            //  scalar offset is unsigned: the row bias goes into the per-lane part, which it leaves non-negative)
+            const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+            const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const int so = (base + 4 * s_ * stride) * ES;
+                a_nxt[s_] = P::bload2(rsL, va, so);
+                b_nxt[s_] = P::bload2(rsL, vb, so);
+            }
+        };
+        fetch(k0);
+        for (int kk = k0; kk < k1; kk += 4 * KS) {
+            T a_cur[KS][2], b_cur[KS][2];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+            }
+            if (kk + 4 * KS < k1) fetch(kk + 4 * KS);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
-                        T cx[4], cu[4];
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
-#pragma unroll
-                        for (int ib = 0; ib < 2; ++ib) {
-                            const int i = irow + ib;
-                            T d2 = T(0.0), uu = T(0.0);
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
-                            if (n > 4) {                                  // (wave-uniform, rare)
-                                for (int d = 4; d < n; ++d) {
-                                    const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
-                                    const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
-                                    d2 += z * z;
-                                }
-                            }
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
-                            T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
-                            val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;
-                            acc[cb][ib][r] = val;
-                        }
-                        // one column's inputs at a time: left alone the scheduler hoists the LDS reads of all eight
-                        // columns (64 values) to the top of the tile
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                load_rows(I + 1);
-                RP_T(1);                                           // 1: values done
-                // the update reads block rows J and I of every earlier column: the last of them, L_{I,J-1}, is the panel
-                // tile the solver delivers I - J + 1 tiles into column J - 1 (the values above did not need it)
-                if (J > 0) {
-                    wait_for(&sp.seq_col, 64 * (J - 1) + (I - J + 1));
-                    if (__hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
-                }
-                RP_T(1);                                           // 2: panel tile arrived
-                constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
-                T2 a_nxt[KS], b_nxt[KS];
-                auto fetch = [&](int kk) {
-#pragma unroll
-                    for (int s_ = 0; s_ < KS; ++s_) {
-                        const int base = lop_base<V>(kk + 4 * s_ + g, Np);
-                        a_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + col0 + 2 * j16);
-                        b_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + irow);
-                    }
-                };
-                if (col0 > 0) fetch(0);
-                for (int kk = 0; kk < col0; kk += 4 * KS) {
-                    T a_cur[KS][2], b_cur[KS][2];
-#pragma unroll
-                    for (int s_ = 0; s_ < KS; ++s_) {
-                        a_cur[s_][0] = -a_nxt[s_].x; a_cur[s_][1] = -a_nxt[s_].y;
-                        b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
-                    }
-                    if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
-#pragma unroll
-                    for (int s_ = 0; s_ < KS; ++s_)
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                            for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
-                }
-                RP_T(1);                                           // 3: update stream done
-                if (I == J) {
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                        for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sh.d.tile[2 * P::midx(r, g) + cb][2 * j16 + ib] = acc[cb][ib][r];
-                } else {
-                    // S' parked in global memory where L_IJ will live: (c, i), (c, i + 1) adjacent -> one 16-byte store
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            T2 v; v.x = acc[cb][0][r]; v.y = acc[cb][1][r];
-                            *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + 2 * P::midx(r, g) + cb, Np) + irow) = v;
-                        }
-                }
-                publish(&sp.seq_tile, 64 * J + (I - J + 1));
-                RP_T(1);                                           // 4: tile published
-            }
+                    for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
         }
+    };
+    int tix = 0; (void)tix;
+
+    if (wave == 0) {
+        // =============================== the CHAIN ===============================
+        int fail = 0;
+        for (int J = 0; J < nblk; ++J) {
+            const int col0 = J * NB;
+            acc_t acc[2][2];
+            RA_T(0);                                               // 0: column starts
+            // the diagonal tile: values, the updates over the columns whose panels of block row J exist ...
+            stage_col(J);
+            load_rows(J);
+            values(acc, J, J);
+            if (J > 1) {
+                wait_for(&sp.cols_done, J - 1);                    // L_{J,J-2} (and every tile left of it)
+                update(acc, J, J, 0, col0 - NB);
+            }
+            RA_T(0);                                               // 1: prepared
+            if (J > 0) {                                           // ... and, as soon as wave 1 delivers it, over L_{J,J-1}
+                wait_for(&sp.first_done, J);
+                update(acc, J, J, col0 - NB, col0);
+            }
+            RA_T(0);                                               // 2: diagonal tile up to date
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = -acc[cb][ib];
+            const int bad = diag_factor_invert_acc<T, false>(BCBF_LDS_TILE(T, sp.d), acc, lane);
+            RA_T(0);                                               // 3: factored + inverted
+            if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
+            if (fail != 0) {
+                if (lane == 0) __hip_atomic_store(&sp.fail, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                publish(&sp.inv_ready, 1 << 20);                   // lets wave 1 run out
+                break;
+            }
+            // wave 1 takes inv(L_JJ) out of LDS (nothing writes xinv again before wave 1 has delivered this column's
+            // first panel tile): the copy to global memory is off the chain
+            publish(&sp.inv_ready, J + 1);
+            {
+                // 16-byte stores (13 instructions for both copies instead of 33 of 8 bytes: under load it is the number
+                // of store instructions a wave pays for, not their bytes)
+                const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
+#pragma unroll
+                for (int t = 0; t < NB * NB / 128; ++t) {
+                    const int e = 2 * lane + 128 * t, c = e >> 5, r = e & 31;
+                    T2 v; v.x = sp.d.xinv[r][c]; v.y = sp.d.xinv[r + 1][c];
+                    *reinterpret_cast<T2*>(lop + bfull + e) = v;
+                }
+#pragma unroll
+                for (int t = 0; t < (LOP_DB + 127) / 128; ++t) {
+                    const int k = 2 * lane + 128 * t;                  // two consecutive entries of the packed triangle
+                    if (k < LOP_DB) {
+                        const unsigned rc = sp.pack_rc[k >> 1];        // (r0 | c0 << 8 | r1 << 16 | c1 << 24), 0xff.. = padding
+                        const int r0 = rc & 0xff, c0 = (rc >> 8) & 0xff, r1 = (rc >> 16) & 0xff, c1 = rc >> 24;
+                        T2 v;
+                        v.x = r0 < NB ? sp.d.xinv[r0][c0] : T(0.0);
+                        v.y = r1 < NB ? sp.d.xinv[r1][c1] : T(0.0);
+                        *reinterpret_cast<T2*>(lop + bpack + k) = v;
+                    }
+                }
+            }
+            RA_T(0);                                               // 4: inverse stored, published
+        }
+        if (lane == 0) info[b] = fail;
         return;
     }
-    // =============================== the SOLVER ===============================
-    int fail = 0;
-    int tix = 0; (void)tix;
-    for (int J = 0; J < nblk; ++J) {
+    // =============================== the BULK ===============================
+    for (int J = 0; J + 1 < nblk; ++J) {
         const int col0 = J * NB;
-        RP_T(0);                                                   // column: 0 starts waiting for the diagonal tile
-        wait_for(&sp.seq_tile, 64 * J + 1);
-        RP_T(0);                                                   // 1: tile arrived
-        const int bad = diag_factor_invert<T>(BCBF_LDS_TILE(T, sh.d), lane);
-        RP_T(0);                                                   // 2: factored + inverted
-        if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
-        {
-            const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
-#pragma unroll
-            for (int t = 0; t < NB * NB / 64; ++t) {
-                const int e = lane + 64 * t, c = e >> 5, r = e & 31;
-                const T xv = sh.d.xinv[r][c];
-                lop[bfull + e] = xv;
-                if (r >= c) lop[bpack + lop_dinv_col(c) + r] = xv;
-            }
-            if (lane < LOP_DB - 528) lop[bpack + 528 + lane] = T(0.0);
-        }
-        if (fail != 0) {
-            if (lane == 0) __hip_atomic_store(&sp.fail, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            publish(&sp.seq_col, 1 << 20);                         // lets the streamer run out
-            break;
-        }
         T ainv[2][2][4];
-#pragma unroll
-        for (int cbp = 0; cbp < 2; ++cbp)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];
-        RP_T(0);                                                   // 3: inverse stored, operands loaded
+        RA_T(1);                                                   // 0: column starts
+        stage_col(J);
+        load_rows(J + 1);
         for (int I = J + 1; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;
-            RP_T(0);                                               // panel: 0 starts waiting
-            wait_for(&sp.seq_tile, 64 * J + (I - J + 1));
-            RP_T(0);                                               // 1: S' arrived
-            T2 sv[2][4];
+            acc_t acc[2][2];
+            values(acc, I, J);
+            load_rows(I + 1);
+            update(acc, I, J, 0, col0);
+            if (I == J + 1) {
+                // (the first tile's S' was formed before this wait: it is the tile the chain continues on)
+                RA_T(1);                                           // 1: first S' formed
+                wait_for(&sp.inv_ready, J + 1);
+                if (failed()) return;
+                RA_T(1);                                           // 2: inv(L_JJ) arrived
+                // A operands of the panel solve: output row c' = 16 cbp + j16, contraction index c = 2 midx(r, g) + cb
+                // (the column an accumulator register of S' holds); inv(L_JJ) is lower triangular: c' < 16 meets c < 16
+                // only (PANEL_R0)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int cbp = 0; cbp < 2; ++cbp)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sv[cb][r] = *reinterpret_cast<const T2*>(lop + lop_base<V>(col0 + 2 * P::midx(r, g) + cb, Np) + irow);
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -sp.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];   // (acc = -S')
+            }
+            // L_IJ' = inv(L_JJ) S': the accumulator registers of S' are the B operands
             acc_t y[2][2];                                          // [ib][cbp]
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib)
@@ -644,39 +716,43 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
-                            yy = P::mfma(ainv[cbp][cb][r], ib == 0 ? sv[cb][r].x : sv[cb][r].y, yy);
+                            yy = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], yy);
                     y[ib][cbp] = yy;
                 }
-            // every lane has read its S' values (the MFMAs above consumed them) before any lane overwrites the tile
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
+            for (int cbp = 0; cbp < 2; ++cbp)
 #pragma unroll
-                for (int cbp = 0; cbp < 2; ++cbp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        lop[lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + irow + ib] = y[ib][cbp][r];
-            publish(&sp.seq_col, 64 * J + (I - J));
-            RP_T(0);                                               // 2: published
+                for (int r = 0; r < 4; ++r) {
+                    T2 v; v.x = y[0][cbp][r]; v.y = y[1][cbp][r];       // rows irow, irow + 1 adjacent: one 16-byte store
+                    *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + irow) = v;
+                }
+            if (I == J + 1) {
+                publish(&sp.first_done, J + 1);
+                RA_T(1);                                           // 3: the chain's panel tile delivered
+            }
         }
+        // one fence for the rest of the column: nobody reads these tiles before the next column (this wave: as update
+        // operands from the next column on; the chain: for the diagonal tile after next)
+        publish(&sp.cols_done, J + 1);
+        RA_T(1);                                                   // 4: column complete
     }
-    if (lane == 0) info[b] = fail;
 }
 
 template <typename T>
 static int launch_refit_pair(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, T* Lop, T* UHB,
-                             int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+                              int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+    if (Np / NB > RA_MAXBLK) return -1;
     hipLaunchKernelGGL((refit_pair_kernel<T>), dim3(Bt), dim3(128), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C);
     return 0;
 }
 int launch_refit_pair64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
-                        const double* jitter, double* Lop, double* UHB, int* info, int Bt, int N, int Np, int n, int C,
-                        hipStream_t st) {
+                         const double* jitter, double* Lop, double* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                         hipStream_t st) {
     return launch_refit_pair<double>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
 }
 int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
-                        const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
-                        hipStream_t st) {
+                         const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                         hipStream_t st) {
     return launch_refit_pair<float>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
 }
 

@@ -2,11 +2,7 @@
 """Time line of the two waves of one instance in the two-waves-per-instance refit (development).
 
     tools/build_variant.sh rptrace refit_wave64.hip -DBCBF_RP_TRACE
-    BCBF_LIB_PATH=tools/_variants/libbcbf_rptrace.so python tools/trace_refit_pair.py [f32|f64] [batch] [N]
-
-Prints, per block column, where the streamer (values / wait for the solver / update stream / hand-off) and the solver
-(wait for the diagonal tile / factor + invert / stores / per panel tile: wait, solve, hand-off) of workgroup 0 spent
-their time, in microseconds."""
+    BCBF_LIB_PATH=tools/_variants/libbcbf_rptrace.so python tools/trace_refit_pair.py [f32|f64] [batch] [N]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,23 +24,28 @@ rc = _lib.lib.bcbf_debug_rp_trace(ctypes.c_void_p(buf.ctypes.data)); assert rc =
 nb = (N + 31) // 32
 t0 = min(buf[0][0], buf[1][0])
 us = lambda v: (v - t0) / 100.0
-so, st = buf[0], buf[1]
-i0 = i1 = 0
-tot = dict(values=0.0, s_wait=0.0, update=0.0, s_pub=0.0, d_wait=0.0, factor=0.0, store=0.0, p_wait=0.0, panel=0.0)
-print("col | streamer: start  values  wait  update  publish (per tile, us) | solver: diag-wait factor store | panels: wait solve+publish")
+tot = dict(c_prep=0.0, c_wait_last=0.0, factor=0.0, c_store=0.0, b_first=0.0, b_wait=0.0, b_solve=0.0, b_rest=0.0)
+print("J | chain: @start prepare wait+last-update factor store | bulk: @start first-S' wait solve+deliver rest")
 for J in range(nb):
-    srow = []
-    for I in range(J, nb):
-        a = [us(st[i1 + k]) for k in range(5)]; i1 += 5
-        srow.append("%d:%.1f v%.1f w%.1f u%.1f p%.1f" % (I, a[0], a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3]))
-        tot["values"] += a[1] - a[0]; tot["s_wait"] += a[2] - a[1]; tot["update"] += a[3] - a[2]; tot["s_pub"] += a[4] - a[3]
-    c = [us(so[i0 + k]) for k in range(4)]; i0 += 4
-    tot["d_wait"] += c[1] - c[0]; tot["factor"] += c[2] - c[1]; tot["store"] += c[3] - c[2]
-    prow = []
-    for I in range(J + 1, nb):
-        q = [us(so[i0 + k]) for k in range(3)]; i0 += 3
-        prow.append("%d:w%.1f s%.1f" % (I, q[1] - q[0], q[2] - q[1]))
-        tot["p_wait"] += q[1] - q[0]; tot["panel"] += q[2] - q[1]
-    print("J=%d S[%s]\n     V[@%.1f wait %.1f factor %.1f store %.1f | %s]" % (J, "  ".join(srow), c[0], c[1] - c[0], c[2] - c[1], c[3] - c[2], " ".join(prow)))
-print("end: streamer %.1f us, solver %.1f us" % (us(st[i1 - 1]), us(so[i0 - 1])))
-print({k: round(v, 1) for k, v in tot.items()})
+    a = [us(buf[0][5 * J + k]) for k in range(5)]
+    line = "J=%d  chain @%.1f prep %.1f wait+last %.1f factor %.1f store %.1f" % (J, a[0], a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3])
+    tot["c_prep"] += a[1] - a[0]; tot["c_wait_last"] += a[2] - a[1]; tot["factor"] += a[3] - a[2]; tot["c_store"] += a[4] - a[3]
+    if J + 1 < nb:
+        q = [us(buf[1][5 * J + k]) for k in range(5)]
+        line += "   | bulk @%.1f first %.1f wait %.1f solve %.1f rest %.1f" % (q[0], q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3])
+        tot["b_first"] += q[1] - q[0]; tot["b_wait"] += q[2] - q[1]; tot["b_solve"] += q[3] - q[2]; tot["b_rest"] += q[4] - q[3]
+    print(line)
+print("end: chain %.1f us, bulk %.1f us" % (us(buf[0][5 * nb - 1]), us(buf[1][5 * (nb - 1) - 1])))
+print({k: round(float(v), 1) for k, v in tot.items()})
+# inside the first diagonal tile's factor + inverse (first launch): stamps (code << 56 | time)
+st = buf[0][4000:4040]
+if st[0]:
+    tm = [(int(v) >> 56, (int(v) & ((1 << 56) - 1)) / 100.0) for v in st if v]
+    names = {0: "publish", 1: "pivots4x4", 2: "row+publish", 3: "rank4", 4: "inverse-step"}
+    prev = tm[0][1]
+    agg = {}
+    row = []
+    for code, t in tm[1:]:
+        row.append("%s %.2f" % (names[code], t - prev)); agg[names[code]] = agg.get(names[code], 0.0) + t - prev; prev = t
+    print("diagonal tile, first call (us between stamps):", " | ".join(row))
+    print({k: round(v, 2) for k, v in agg.items()})
