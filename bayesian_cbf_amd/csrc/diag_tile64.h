@@ -215,7 +215,7 @@ template <typename T> __device__ inline int diag_factor_invert(DiagTileLds<T>* s
 //   inverse  W (starts as the identity, same layout) takes the same eliminations: rows c0..c0+3 of W are published like
 //            S's, X(c0 + g, q) = (row g of the 4x4 inverse) . W(c0.., q) is a row of inv(L) AND the B operand of
 //            W -= l X: four more MFMAs, off the pivots' critical path.  The serial 8-step inverse pass above is gone.
-// Outputs as above (sh->xinv = inv(L) [row][col] with zeros above the diagonal; sh->tile = L likewise when WANT_L -- the
+// Outputs as above (sh->xinv = inv(L) [row][col] with zeros above the diagonal; sh->tile = L likewise when want_l (wave-uniform) -- the
 // packed operator stores only the inverse of a diagonal tile).
 template <typename T> __device__ inline int dt_midx(int r, int g) { return sizeof(T) == 8 ? g + 4 * r : 4 * g + r; }
 __device__ inline __attribute__((__vector_size__(4 * sizeof(double)))) double
@@ -227,8 +227,8 @@ dt_mfma(float a, float b, __attribute__((__vector_size__(4 * sizeof(float)))) fl
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <typename T, bool WANT_L, typename ACC>
-__device__ inline int diag_factor_invert_acc(DiagTileLds<T>* sh, ACC (&S)[2][2], int lane) {
+template <typename T, typename ACC>
+__device__ inline int diag_factor_invert_acc(DiagTileLds<T>* sh, ACC (&S)[2][2], int lane, bool want_l) {
     const int j16 = lane & 15, g = lane >> 4;
     ACC W[2][2];
 #pragma unroll
@@ -319,7 +319,7 @@ __device__ inline int diag_factor_invert_acc(DiagTileLds<T>* sh, ACC (&S)[2][2],
             v = qa < 0 ? z : qa == 0 ? f0 : qa == 1 ? f1 : qa == 2 ? f2 : qa == 3 ? f3 : v;
             la[ib] = v;
             xb[ib] = k0 * pw[ib][0] + k1 * pw[ib][1] + k2 * pw[ib][2] + k3 * pw[ib][3];
-            if (WANT_L) sh->tile[2 * j16 + ib][c0 + g] = v;
+            if (want_l) sh->tile[2 * j16 + ib][c0 + g] = v;
             sh->xinv[c0 + g][2 * j16 + ib] = xb[ib];
         }
         BCBF_DT_STAMP(2);

@@ -360,10 +360,10 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     // Batches: one wave per instance (refit_wave64.hip, also compiled for fp32); BCBF_REFIT_WAVE=0/1 forces a form
     bool per_wave = Bt >= BCBF_R32_WAVE_MIN_BATCH || (Bt >= 512 && Np <= 512) || (Bt >= 128 && Np <= 256) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
-    // Two waves per instance (refit_wave64.hip): measured in fp32 (ms workgroup / wave / two waves): 1024 x 128: 0.173 /
-    // 0.112 / 0.064, 4096 x 128: 0.68 / 0.34 / 0.24, 1024 x 256: 0.443 / 0.326 / 0.194, 4096 x 256: 1.76 / 1.00 / 0.89,
-    // 256 x 512: 1.17 / 1.26 / 0.88, 1024 x 512: 1.69 / 1.36 / 1.22, 4096 x 512: 6.6 / 4.5 / 5.6, 64 x 512: 0.71 / 1.22 / 0.78
-    bool pair = Bt >= 64 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 1024));
+    // Two waves per instance (refit_wave64.hip): measured in fp32 (ms workgroup / wave / two waves): 1024 x 128: 0.172 /
+    // 0.077 / 0.063, 4096 x 128: 0.68 / 0.19 / 0.24, 1024 x 256: 0.443 / 0.237 / 0.195, 4096 x 256: 1.75 / 0.66 / 0.89,
+    // 256 x 512: 1.17 / 0.97 / 0.87, 1024 x 512: 1.68 / 1.14 / 1.22, 4096 x 512: 6.6 / 3.7 / 5.6, 64 x 512: 0.71 / 0.94 / 0.77
+    bool pair = Bt >= 64 && Bt <= 1024 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 512));
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;

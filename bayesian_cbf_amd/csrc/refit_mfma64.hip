@@ -364,12 +364,12 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     bool per_wave = Bt >= 1024 || (Bt >= 512 && Np <= 256) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
     // Two waves per instance (refit_wave64.hip, round 3: the serial chain of diagonal tiles on one wave, every other tile on
-    // the other) wins for small systems at every batch from 64 on -- measured (tools/bench_refit_forms.py, ms workgroup /
-    // wave / two waves): 1024 x 256: 0.818 / 0.461 / 0.320, 4096 x 256: 3.26 / 1.80 / 1.37, 1024 x 128: 0.319 / 0.156 / 0.101,
-    // 64 x 256: 0.305 / 0.403 / 0.206 -- and loses at N = 512 (256 x 512: 1.12 / 1.78 / 1.39, 1024 x 512: 3.06 / 2.09 / 2.22),
-    // where the one-wave form (512 registers) keeps more of the update stream in flight.  BCBF_REFIT_PAIR=0/1 forces the
-    // choice (N <= 512).
-    bool pair = Bt >= 64 && Np <= 256;
+    // the other) wins for small systems while one round of workgroups holds the batch -- measured (tools/bench_refit_forms.py,
+    // ms workgroup / wave / two waves): 1024 x 256: 0.822 / 0.357 / 0.328, 64 x 256: 0.303 / 0.311 / 0.204, 1024 x 128: 0.319 /
+    // 0.104 / 0.100, 64 x 128: 0.132 / 0.093 / 0.066; a tie at 4096 (x 256: 3.24 / 1.367 / 1.390) -- and loses at N = 512
+    // (256 x 512: 1.12 / 1.50 / 1.40, 1024 x 512: 3.06 / 1.88 / 2.26), where the one-wave form (512 registers) keeps more of the
+    // update stream in flight.  BCBF_REFIT_PAIR=0/1 forces the choice (N <= 512).
+    bool pair = Bt >= 64 && Bt <= 1024 && Np <= 256;
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         launch_refit_pair64(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st);

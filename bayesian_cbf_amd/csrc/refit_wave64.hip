@@ -75,7 +75,26 @@ template <typename T> struct RWShared {
     DiagTile<T> d;                            // the diagonal tile's working set (diag_tile64.h)
     T colX[NB][BCBF_MAX_STATE_DIM];
     T colUH[NB][BCBF_MAX_CTRL_DIM + 1];
+    unsigned pack_rc[LOP_DB / 2];             // (row, column) of the entries of a packed inverted diagonal block, two per word
 };
+// packed lower triangle, column-major: entry k <-> (r, c), r >= c; (r | c << 8) per entry, 0xffff = the block's padding
+__device__ inline void rw_pack_table(__attribute__((address_space(3))) unsigned* tab, int tid, int nthreads) {
+    for (int w = tid; w < LOP_DB / 2; w += nthreads) {
+        unsigned word = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * w + h;
+            // column c starts at entry c (65 - c) / 2: the root of that quadratic, then one step either way
+            int c = (int)((65.0f - __builtin_sqrtf(4225.0f - 8.0f * (float)(k < 528 ? k : 527))) * 0.5f);
+            c = c < 0 ? 0 : c > NB - 1 ? NB - 1 : c;
+            if (c < NB - 1 && lop_dinv_col(c + 1) + c + 1 <= k) ++c;
+            if (lop_dinv_col(c) + c > k) --c;
+            const int r = k - lop_dinv_col(c);
+            const unsigned rc = k < 528 ? (unsigned)(r | (c << 8)) : 0xffffu;
+            word |= rc << (16 * h);
+        }
+        tab[w] = word;
+    }
+}
 
 // exp(-x) for x >= 0 in full double precision: k = rint(x log2 e), r = k ln2 - x in [-ln2/2, ln2/2] (two-part ln2),
 // degree-12 Taylor polynomial (truncation 1.7e-16), scaled by 2^-k.  Half the instructions of the library exp (no
@@ -179,6 +198,9 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, FROM_DENSE ? 0 : N * C * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : X), 0, (!FROM_DENSE && jitter) ? N * ES : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(lop, 0, (unsigned)min((size_t)0xfffffff0u, lop_elems<V>(Np) * ES), 0x00020000);
+    rw_pack_table(sh.pack_rc, lane, 64);
+    __builtin_amdgcn_wave_barrier();
 #ifdef BCBF_RW64_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -225,7 +247,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         load_rows(J);
         for (int I = J; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;                    // + ib
-            acc_t acc[2][2];                                      // [cb][ib]:  S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
+            acc_t acc[2][2];                                      // [cb][ib]: -S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
                                                                   // the two halves of an operand are adjacent rows, one 16-byte load)
             // ---- initial value K_b'(c, i).  Straight-line: the column's inputs come from LDS as fixed-width rows (4 state
             //      components, 4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE
@@ -243,7 +265,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                             T val;
                             if (i >= N || j >= N) val = (i == j) ? T(1.0) : T(0.0);      // padding: identity
                             else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
-                            acc[cb][ib][r] = val;
+                            acc[cb][ib][r] = -val;
                         }
                 }
             } else {
@@ -272,21 +294,30 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                             for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
                             T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
                             val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;   // padding: identity
-                            acc[cb][ib][r] = val;
+                            acc[cb][ib][r] = -val;                // the accumulators carry -S' (see the update stream)
                         }
                     }
             }
             load_rows(I + 1);
             RW_ACC(1);                                            // K_b values
-            // ---- S' -= L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight)
+            // ---- -S' += L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight).  The
+            //      accumulators hold -S': the MFMA has no negate modifier, and flipping an operand costs four VALU instructions
+            //      per k-step against once per tile at the consumer.  Addresses: inside block column K the packed columns are
+            //      a fixed stride apart, so a load is  buffer base + SCALAR offset (column block, k-step) + per-lane offset
+            //      (lane group's column, row): two multiply-adds per fetch instead of the column-offset polynomial per load
+            //      (a wave issues in order: address arithmetic does not hide behind its own MFMAs)
             constexpr int KS = sizeof(T) == 4 ? BCBF_RW32_KS : BCBF_RW64_KS;
             T2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
             auto fetch = [&](int kk) {
+                const int K = kk / NB, stride = Np - NB * (K + 1);   // (wave-uniform: scalar registers)
+                // (the row bias -32 (K + 1) of a packed column goes into the per-lane part: a scalar offset is unsigned)
+                const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) {
-                    const int base = lop_base<V>(kk + 4 * s_ + g, Np);
-                    a_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + col0 + 2 * j16);
-                    b_nxt[s_] = *reinterpret_cast<const T2*>(lop + base + irow);
+                    const int so = (base + 4 * s_ * stride) * ES;
+                    a_nxt[s_] = P::bload2(rsL, va, so);
+                    b_nxt[s_] = P::bload2(rsL, vb, so);
                 }
             };
             if (col0 > 0) fetch(0);
@@ -294,7 +325,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 T a_cur[KS][2], b_cur[KS][2];
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) {
-                    a_cur[s_][0] = -a_nxt[s_].x; a_cur[s_][1] = -a_nxt[s_].y;                // D = (-A) B + C
+                    a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
                     b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
                 }
                 if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
@@ -313,29 +344,35 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sh.d.tile[2 * P::midx(r, g) + cb][2 * j16 + ib] = acc[cb][ib][r];
-                __builtin_amdgcn_wave_barrier();
-                const int bad = diag_factor_invert<T>(BCBF_LDS_TILE(T, sh.d), lane);          // diag_tile64.h: tile -> L, xinv -> inv(L)
+                    for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = -acc[cb][ib];
+                // diag_tile64.h: on the matrix cores, out of the accumulators; xinv -> inv(L), tile -> L (dense output only)
+                const int bad = diag_factor_invert_acc<T>(BCBF_LDS_TILE(T, sh.d), acc, lane, Ld != nullptr);
                 RW_ACC(3);                                        // factor + inverse
                 if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
                 if (Ld && lane < NB && col0 + lane < N) {
                     for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = sh.d.tile[lane][c];
                 }
                 {
-                    // global copies from LDS, contiguous across the wave: the full column-major tile (shared-model
-                    // kernel) and the packed lower triangle (streaming kernels); element e = 32 c + r
-                    {
-                        const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
+                    // global copies from LDS, contiguous across the wave, 16-byte stores: the full column-major tile
+                    // (shared-model kernel) and the packed lower triangle (streaming kernels)
+                    const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
 #pragma unroll
-                        for (int t = 0; t < NB * NB / 64; ++t) {
-                            const int e = lane + 64 * t, c = e >> 5, r = e & 31;
-                            const T xv = sh.d.xinv[r][c];
-                            lop[bfull + e] = xv;
-                            if (r >= c) lop[bpack + lop_dinv_col(c) + r] = xv;
+                    for (int t = 0; t < NB * NB / 128; ++t) {
+                        const int e = 2 * lane + 128 * t, c = e >> 5, r = e & 31;
+                        T2 v; v.x = sh.d.xinv[r][c]; v.y = sh.d.xinv[r + 1][c];
+                        *reinterpret_cast<T2*>(lop + bfull + e) = v;
+                    }
+#pragma unroll
+                    for (int t = 0; t < (LOP_DB + 127) / 128; ++t) {
+                        const int k = 2 * lane + 128 * t;              // two consecutive entries of the packed triangle
+                        if (k < LOP_DB) {
+                            const unsigned rc = sh.pack_rc[k >> 1];    // (r0 | c0 << 8 | r1 << 16 | c1 << 24), 0xff.. = padding
+                            const int r0 = rc & 0xff, c0 = (rc >> 8) & 0xff, r1 = (rc >> 16) & 0xff, c1 = rc >> 24;
+                            T2 v;
+                            v.x = r0 < NB ? sh.d.xinv[r0][c0] : T(0.0);
+                            v.y = r1 < NB ? sh.d.xinv[r1][c1] : T(0.0);
+                            *reinterpret_cast<T2*>(lop + bpack + k) = v;
                         }
-                        if (lane < LOP_DB - 528) lop[bpack + 528 + lane] = T(0.0);                  // the block's padding
                     }
                 }
                 if (fail != 0) break;
@@ -347,29 +384,35 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];
+                        for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];   // (acc = -S')
                 RW_ACC(4);                                        // stores of the inverse
             } else {
-                // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of S' are the B operands)
+                // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of -S' are the B operands, ainv = -inv(L_JJ))
+                acc_t y[2][2];                                      // [ib][cbp]
 #pragma unroll
-                for (int ib = 0; ib < 2; ++ib) {
-                    const int i = irow + ib;
+                for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
                     for (int cbp = 0; cbp < 2; ++cbp) {
-                        acc_t y = {0, 0, 0, 0};
+                        acc_t yy = {0, 0, 0, 0};
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                             for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
-                                y = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], y);
+                                yy = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], yy);
+                        y[ib][cbp] = yy;
+                    }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int c = 16 * cbp + P::midx(r, g);
-                            lop[lop_base<V>(col0 + c, Np) + i] = y[r];
-                            if (Ld && i < N && col0 + c < N) Ld[(size_t)i * N + col0 + c] = y[r];
+                for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * cbp + P::midx(r, g);
+                        T2 v; v.x = y[0][cbp][r]; v.y = y[1][cbp][r];   // rows irow, irow + 1 adjacent: one 16-byte store
+                        *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + c, Np) + irow) = v;
+                        if (Ld && col0 + c < N) {
+                            if (irow < N) Ld[(size_t)irow * N + col0 + c] = v.x;
+                            if (irow + 1 < N) Ld[(size_t)(irow + 1) * N + col0 + c] = v.y;
                         }
                     }
-                }
                 RW_ACC(5);                                        // panel solve + stores
             }
         }
@@ -463,21 +506,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 UHBout[((size_t)b * N + i) * C + c] = s;
             }
         if (threadIdx.x == 0) { sp.inv_ready = 0; sp.first_done = 0; sp.cols_done = 0; sp.fail = 0; }
-        for (int w = threadIdx.x; w < LOP_DB / 2; w += 128) {      // packed triangle, column-major: entry k <-> (r, c), r >= c
-            unsigned word = 0;
-            for (int h = 0; h < 2; ++h) {
-                const int k = 2 * w + h;
-                // column c starts at entry c (65 - c) / 2: the root of that quadratic, then one step either way
-                int c = (int)((65.0f - __builtin_sqrtf(4225.0f - 8.0f * (float)(k < 528 ? k : 527))) * 0.5f);
-                c = c < 0 ? 0 : c > NB - 1 ? NB - 1 : c;
-                if (c < NB - 1 && lop_dinv_col(c + 1) + c + 1 <= k) ++c;
-                if (lop_dinv_col(c) + c > k) --c;
-                const int r = k - lop_dinv_col(c);
-                const unsigned rc = k < 528 ? (unsigned)(r | (c << 8)) : 0xffffu;
-                word |= rc << (16 * h);
-            }
-            sp.pack_rc[w] = word;
-        }
+        rw_pack_table(sp.pack_rc, threadIdx.x, 128);
     }
     __threadfence_block();
     __syncthreads();
@@ -637,7 +666,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = -acc[cb][ib];
-            const int bad = diag_factor_invert_acc<T, false>(BCBF_LDS_TILE(T, sp.d), acc, lane);
+            const int bad = diag_factor_invert_acc<T>(BCBF_LDS_TILE(T, sp.d), acc, lane, false);
             RA_T(0);                                               // 3: factored + inverted
             if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
             if (fail != 0) {
