@@ -536,17 +536,30 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
     auto& cX = sp.colX[wave];
     auto& cU = sp.colUH[wave];
-    auto stage_col = [&](int J) {
+    // a column block's inputs, zero-filled to fixed widths: loads ISSUED early (into registers, out-of-range offsets read
+    // as zero), written to LDS when the previous block's values are done -- the round trip hides under other work
+    const __amdgpu_buffer_rsrc_t rsUH = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHb), 0, N * C * ES, 0x00020000);
+    constexpr int SX = NB * BCBF_MAX_STATE_DIM / 64, SU = NB * (BCBF_MAX_CTRL_DIM + 1) / 64;
+    T sx[SX], su[SU];
+    auto stage_issue = [&](int J) {
         const int col0 = J * NB;
+#pragma unroll
+        for (int t = 0; t < SX; ++t) {
+            const int e = lane + 64 * t, c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+            sx[t] = P::bload(rsX, (col0 + c < N && d < n) ? ((col0 + c) * n + d) * ES : -ES);
+        }
+#pragma unroll
+        for (int t = 0; t < SU; ++t) {
+            const int e = lane + 64 * t, c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+            su[t] = P::bload(rsUH, (col0 + c < N && a < C) ? ((col0 + c) * C + a) * ES : -ES);
+        }
+    };
+    auto stage_commit = [&]() {
         __builtin_amdgcn_wave_barrier();                           // every lane is done with the previous column block
-        for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
-            const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
-            cX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
-        }
-        for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
-            const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
-            cU[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : T(0.0);
-        }
+#pragma unroll
+        for (int t = 0; t < SX; ++t) { const int e = lane + 64 * t; cX[e / BCBF_MAX_STATE_DIM][e % BCBF_MAX_STATE_DIM] = sx[t]; }
+#pragma unroll
+        for (int t = 0; t < SU; ++t) { const int e = lane + 64 * t; cU[e / (BCBF_MAX_CTRL_DIM + 1)][e % (BCBF_MAX_CTRL_DIM + 1)] = su[t]; }
         __builtin_amdgcn_wave_barrier();
     };
     T rx[2][4], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
@@ -644,13 +657,15 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     if (wave == 0) {
         // =============================== the CHAIN ===============================
         int fail = 0;
+        load_rows(0);
+        stage_issue(0);
+        stage_commit();
         for (int J = 0; J < nblk; ++J) {
             const int col0 = J * NB;
             acc_t acc[2][2];
             RA_T(0);                                               // 0: column starts
-            // the diagonal tile: values, the updates over the columns whose panels of block row J exist ...
-            stage_col(J);
-            load_rows(J);
+            // the diagonal tile: values (its inputs were fetched under the previous column's inverse copy), the updates
+            // over the columns whose panels of block row J exist ...
             values(acc, J, J);
             if (J > 1) {
                 wait_for(&sp.cols_done, J - 1);                    // L_{J,J-2} (and every tile left of it)
@@ -677,6 +692,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             // wave 1 takes inv(L_JJ) out of LDS (nothing writes xinv again before wave 1 has delivered this column's
             // first panel tile): the copy to global memory is off the chain
             publish(&sp.inv_ready, J + 1);
+            if (J + 1 < nblk) { load_rows(J + 1); stage_issue(J + 1); }
             {
                 // 16-byte stores (13 instructions for both copies instead of 33 of 8 bytes: under load it is the number
                 // of store instructions a wave pays for, not their bytes)
@@ -700,18 +716,18 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     }
                 }
             }
+            if (J + 1 < nblk) stage_commit();
             RA_T(0);                                               // 4: inverse stored, published
         }
         if (lane == 0) info[b] = fail;
         return;
     }
     // =============================== the BULK ===============================
+    if (nblk > 1) { load_rows(1); stage_issue(0); stage_commit(); }
     for (int J = 0; J + 1 < nblk; ++J) {
         const int col0 = J * NB;
         T ainv[2][2][4];
         RA_T(1);                                                   // 0: column starts
-        stage_col(J);
-        load_rows(J + 1);
         for (int I = J + 1; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;
             acc_t acc[2][2];
@@ -762,7 +778,9 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         }
         // one fence for the rest of the column: nobody reads these tiles before the next column (this wave: as update
         // operands from the next column on; the chain: for the diagonal tile after next)
+        if (J + 2 < nblk) { load_rows(J + 2); stage_issue(J + 1); }    // (the next column's inputs: in flight under the fence)
         publish(&sp.cols_done, J + 1);
+        if (J + 2 < nblk) stage_commit();
         RA_T(1);                                                   // 4: column complete
     }
 }
