@@ -199,6 +199,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : X), 0, (!FROM_DENSE && jitter) ? N * ES : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(lop, 0, (unsigned)min((size_t)0xfffffff0u, lop_elems<V>(Np) * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsUH = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHb), 0, FROM_DENSE ? 0 : N * C * ES, 0x00020000);
     rw_pack_table(sh.pack_rc, lane, 64);
     __builtin_amdgcn_wave_barrier();
 #ifdef BCBF_RW64_PROF
@@ -208,15 +209,25 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     for (int J = 0; J < nblk && fail == 0; ++J) {
         const int col0 = J * NB;
         if (!FROM_DENSE) {
-            // (zero-filled to the full widths: the value pass below reads fixed-width rows without a branch)
-            for (int e = lane; e < NB * BCBF_MAX_STATE_DIM; e += 64) {
-                const int c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
-                sh.colX[c][d] = (col0 + c < N && d < n) ? Xb[(size_t)(col0 + c) * n + d] : T(0.0);
+            // (zero-filled to the full widths: the value pass below reads fixed-width rows without a branch; the loads
+            //  themselves are branch-free too -- an absent component is an out-of-range buffer offset and reads as zero --
+            //  and all in flight together)
+            constexpr int SX = NB * BCBF_MAX_STATE_DIM / 64, SU = NB * (BCBF_MAX_CTRL_DIM + 1) / 64;
+            T sx[SX], su[SU];
+#pragma unroll
+            for (int t = 0; t < SX; ++t) {
+                const int e = lane + 64 * t, c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+                sx[t] = P::bload(rsX, (col0 + c < N && d < n) ? ((col0 + c) * n + d) * ES : -ES);
             }
-            for (int e = lane; e < NB * (BCBF_MAX_CTRL_DIM + 1); e += 64) {
-                const int c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
-                sh.colUH[c][a] = (col0 + c < N && a < C) ? UHb[(size_t)(col0 + c) * C + a] : T(0.0);
+#pragma unroll
+            for (int t = 0; t < SU; ++t) {
+                const int e = lane + 64 * t, c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+                su[t] = P::bload(rsUH, (col0 + c < N && a < C) ? ((col0 + c) * C + a) * ES : -ES);
             }
+#pragma unroll
+            for (int t = 0; t < SX; ++t) { const int e = lane + 64 * t; sh.colX[e / BCBF_MAX_STATE_DIM][e % BCBF_MAX_STATE_DIM] = sx[t]; }
+#pragma unroll
+            for (int t = 0; t < SU; ++t) { const int e = lane + 64 * t; sh.colUH[e / (BCBF_MAX_CTRL_DIM + 1)][e % (BCBF_MAX_CTRL_DIM + 1)] = su[t]; }
         }
         __builtin_amdgcn_wave_barrier();
         RW_ACC(0);                                             // column staging
@@ -554,6 +565,9 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             su[t] = P::bload(rsUH, (col0 + c < N && a < C) ? ((col0 + c) * C + a) * ES : -ES);
         }
     };
+    // (fp32 only: in fp64 the 48 registers that stay live across the inverse copy / the column fence spill -- 320 B of
+    //  scratch against 104 -- and the kernel is slower for it; there a column's inputs are fetched where they are used)
+    constexpr bool EARLY = sizeof(T) == 4;
     auto stage_commit = [&]() {
         __builtin_amdgcn_wave_barrier();                           // every lane is done with the previous column block
 #pragma unroll
@@ -657,15 +671,14 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     if (wave == 0) {
         // =============================== the CHAIN ===============================
         int fail = 0;
-        load_rows(0);
-        stage_issue(0);
-        stage_commit();
+        if (EARLY) { load_rows(0); stage_issue(0); stage_commit(); }
         for (int J = 0; J < nblk; ++J) {
             const int col0 = J * NB;
             acc_t acc[2][2];
             RA_T(0);                                               // 0: column starts
-            // the diagonal tile: values (its inputs were fetched under the previous column's inverse copy), the updates
-            // over the columns whose panels of block row J exist ...
+            // the diagonal tile: values (fp32: its inputs were fetched under the previous column's inverse copy), the
+            // updates over the columns whose panels of block row J exist ...
+            if (!EARLY) { load_rows(J); stage_issue(J); stage_commit(); }
             values(acc, J, J);
             if (J > 1) {
                 wait_for(&sp.cols_done, J - 1);                    // L_{J,J-2} (and every tile left of it)
@@ -692,7 +705,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             // wave 1 takes inv(L_JJ) out of LDS (nothing writes xinv again before wave 1 has delivered this column's
             // first panel tile): the copy to global memory is off the chain
             publish(&sp.inv_ready, J + 1);
-            if (J + 1 < nblk) { load_rows(J + 1); stage_issue(J + 1); }
+            if (EARLY && J + 1 < nblk) { load_rows(J + 1); stage_issue(J + 1); }
             {
                 // 16-byte stores (13 instructions for both copies instead of 33 of 8 bytes: under load it is the number
                 // of store instructions a wave pays for, not their bytes)
@@ -716,18 +729,19 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     }
                 }
             }
-            if (J + 1 < nblk) stage_commit();
+            if (EARLY && J + 1 < nblk) stage_commit();
             RA_T(0);                                               // 4: inverse stored, published
         }
         if (lane == 0) info[b] = fail;
         return;
     }
     // =============================== the BULK ===============================
-    if (nblk > 1) { load_rows(1); stage_issue(0); stage_commit(); }
+    if (EARLY && nblk > 1) { load_rows(1); stage_issue(0); stage_commit(); }
     for (int J = 0; J + 1 < nblk; ++J) {
         const int col0 = J * NB;
         T ainv[2][2][4];
         RA_T(1);                                                   // 0: column starts
+        if (!EARLY) { load_rows(J + 1); stage_issue(J); stage_commit(); }
         for (int I = J + 1; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;
             acc_t acc[2][2];
@@ -778,9 +792,9 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         }
         // one fence for the rest of the column: nobody reads these tiles before the next column (this wave: as update
         // operands from the next column on; the chain: for the diagonal tile after next)
-        if (J + 2 < nblk) { load_rows(J + 2); stage_issue(J + 1); }    // (the next column's inputs: in flight under the fence)
+        if (EARLY && J + 2 < nblk) { load_rows(J + 2); stage_issue(J + 1); }    // (the next column's inputs: in flight under the fence)
         publish(&sp.cols_done, J + 1);
-        if (J + 2 < nblk) stage_commit();
+        if (EARLY && J + 2 < nblk) stage_commit();
         RA_T(1);                                                   // 4: column complete
     }
 }
