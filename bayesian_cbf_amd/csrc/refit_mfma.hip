@@ -363,7 +363,8 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     // Two waves per instance (refit_wave64.hip): measured in fp32 (ms workgroup / wave / two waves): 1024 x 128: 0.172 /
     // 0.077 / 0.063, 4096 x 128: 0.68 / 0.19 / 0.24, 1024 x 256: 0.443 / 0.237 / 0.195, 4096 x 256: 1.75 / 0.66 / 0.89,
     // 256 x 512: 1.17 / 0.97 / 0.87, 1024 x 512: 1.68 / 1.14 / 1.22, 4096 x 512: 6.6 / 3.7 / 5.6, 64 x 512: 0.71 / 0.94 / 0.77
-    bool pair = Bt >= 64 && Bt <= 1024 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 512));
+    // ONE model (tools/time_refit_one.py, us workgroup / two waves): N = 128: 105 / 41, 256: 236 / 131, 512: 705 / 741.
+    bool pair = Bt <= 1024 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 512));
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;

@@ -369,7 +369,9 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     // 0.104 / 0.100, 64 x 128: 0.132 / 0.093 / 0.066; a tie at 4096 (x 256: 3.24 / 1.367 / 1.390) -- and loses at N = 512
     // (256 x 512: 1.12 / 1.50 / 1.40, 1024 x 512: 3.06 / 1.88 / 2.26), where the one-wave form (512 registers) keeps more of the
     // update stream in flight.  BCBF_REFIT_PAIR=0/1 forces the choice (N <= 512).
-    bool pair = Bt >= 64 && Bt <= 1024 && Np <= 256;
+    // ONE model (the facade's fit / clear_cache path; tools/time_refit_one.py, us workgroup / two waves): N = 128: 133 / 61,
+    // 256: 308 / 199, 512: 901 / 1193 -- the two-wave form from a single instance on.
+    bool pair = Bt <= 1024 && Np <= 256;
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         launch_refit_pair64(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st);
