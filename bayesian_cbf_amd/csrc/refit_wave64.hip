@@ -56,6 +56,12 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #ifndef BCBF_RW32_KS
 #define BCBF_RW32_KS 8
 #endif
+#ifndef BCBF_RW32_PAIRS
+#define BCBF_RW32_PAIRS 1        // two tiles of a block column per pass of the update stream (shared A operand)
+#endif
+#ifndef BCBF_RW64_PAIRS
+#define BCBF_RW64_PAIRS 0        // fp64: measured slower below N = 1024 (4096 x 512: 8.15 against 7.4 ms; 1024 x 1024: 14.1 against 14.7)
+#endif
 #ifndef BCBF_RW64_KS
 #define BCBF_RW64_KS 8           // k-steps (of 4 columns) per software-pipeline stage of the update stream (8 beats 4 by 4 %)
 #endif
@@ -233,125 +239,203 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         RW_ACC(0);                                             // column staging
         T ainv[2][2][4];                                  // inv(L_JJ) as panel-solve A operands, loaded after the diagonal tile
 
-        // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one tile ahead, so that the loads are in
-        // flight during the previous tile's update stream instead of queueing behind its panel stores
-        T rx[2][RXD], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
-        // Branch-free: every load is issued, a component the model does not have (d >= n, c >= C) or a row past the end
-        // is an out-of-range buffer offset and reads as zero.  (Written with `if (d < n)` around plain loads each one
-        // became its own basic block with a full wait behind it: ten serialized memory round trips per tile, 44 % of
-        // the kernel at N = 256.)
-        auto load_rows = [&](int I_) {
-            if (FROM_DENSE) return;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                const int i = I_ * NB + 2 * j16 + ib;
-                const bool in = I_ < nblk && i < N;
-#pragma unroll
-                for (int d = 0; d < RXD; ++d)
-                    rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
-#pragma unroll
-                for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
-                    ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
-                rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
-            }
-        };
-        load_rows(J);
-        for (int I = J; I < nblk; ++I) {
-            const int irow = I * NB + 2 * j16;                    // + ib
-            acc_t acc[2][2];                                      // [cb][ib]: -S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
-                                                                  // the two halves of an operand are adjacent rows, one 16-byte load)
-            // ---- initial value K_b'(c, i).  Straight-line: the column's inputs come from LDS as fixed-width rows (4 state
-            //      components, 4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE
-            //      read per column for both rows of the lane.  (With `if (d < n)` around each LDS read every read sat in a
-            //      basic block of its own with a full wait behind it: 120 serialized LDS round trips per tile.)
-            if (FROM_DENSE) {
+        // fp32: two tiles of a block column per pass of the update stream (they share the A operand: three panel reads where
+        // two single tiles make four -- 4096 x 512 fp32 fetches 21 GB past L2 per launch for a 2 GB result, PMC).  fp64: one
+        // tile per pass -- the pair path needs more than the 512 registers there and measured slower below N = 1024 (4096 x
+        // 512: 8.15 against 7.4 ms).  Two bodies: the single-tile stream written over the pair path's helpers came out
+        // with twice the register moves in its loop (177 instructions per 32 MFMAs against 111) and lost 5 %.
+        constexpr bool PAIRS = sizeof(T) == 4 ? BCBF_RW32_PAIRS : BCBF_RW64_PAIRS;
+        if constexpr (PAIRS) {
+            // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one step ahead, so that the loads are in
+            // flight during the previous step's update stream instead of queueing behind its panel stores.
+            // Branch-free: every load is issued, a component the model does not have (d >= n, c >= C) or a row past the end
+            // is an out-of-range buffer offset and reads as zero.  (Written with `if (d < n)` around plain loads each one
+            // became its own basic block with a full wait behind it: ten serialized memory round trips per tile, 44 % of
+            // the kernel at N = 256.)
+            struct Rows { T rx[2][RXD], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2]; };
+            Rows rw0, rw1;
+            auto load_rows = [&](Rows& q, int I_) {
+                if (FROM_DENSE) return;
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {
-                    const int i = irow + ib;
+                    const int i = I_ * NB + 2 * j16 + ib;
+                    const bool in = I_ < nblk && i < N;
+#pragma unroll
+                    for (int d = 0; d < RXD; ++d)
+                        q.rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
+#pragma unroll
+                    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
+                        q.ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
+                    q.rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
+                }
+            };
+            // ---- initial value of a tile: acc[cb][ib][r] = -K_b'(c = 2 (4r + g) + cb, i = 32 I + 2 j16 + ib)  (the accumulators
+            //      carry -S', see the update stream; halves interleaved: the two halves of an operand are adjacent rows, one
+            //      16-byte load).  Straight-line: the column's inputs come from LDS as fixed-width rows (4 state components,
+            //      4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE read per column for
+            //      both rows of the lane.  (With `if (d < n)` around each LDS read every read sat in a basic block of its own
+            //      with a full wait behind it: 120 serialized LDS round trips per tile.)
+            auto values = [&](acc_t (&acc)[2][2], const Rows& q, int I) {
+                const int irow = I * NB + 2 * j16;
+                if (FROM_DENSE) {
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        const int i = irow + ib;
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                                T val;
+                                if (i >= N || j >= N) val = (i == j) ? T(1.0) : T(0.0);      // padding: identity
+                                else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
+                                acc[cb][ib][r] = -val;
+                            }
+                    }
+                } else {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
-                            T val;
-                            if (i >= N || j >= N) val = (i == j) ? T(1.0) : T(0.0);      // padding: identity
-                            else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
-                            acc[cb][ib][r] = -val;
-                        }
-                }
-            } else {
+                            T cx[4], cu[4];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                            for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
-                        T cx[4], cu[4];
+                            for (int ib = 0; ib < 2; ++ib) {
+                                const int i = irow + ib;
+                                T d2 = T(0.0), uu = T(0.0);
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
-#pragma unroll
-                        for (int ib = 0; ib < 2; ++ib) {
-                            const int i = irow + ib;
-                            T d2 = T(0.0), uu = T(0.0);
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
-                            if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
-                                for (int d = 4; d < n; ++d) {
-                                    const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
-                                    const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
-                                    d2 += z * z;
+                                for (int d = 0; d < 4; ++d) { const T z = (q.rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                                if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
+                                    for (int d = 4; d < n; ++d) {
+                                        const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
+                                        const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
+                                        d2 += z * z;
+                                    }
                                 }
+#pragma unroll
+                                for (int a_ = 0; a_ < 4; ++a_) uu += q.ru[ib][a_] * cu[a_];
+                                T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? q.rj[ib] : T(0.0));
+                                val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;   // padding: identity
+                                acc[cb][ib][r] = -val;
                             }
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
-                            T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
-                            val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;   // padding: identity
-                            acc[cb][ib][r] = -val;                // the accumulators carry -S' (see the update stream)
                         }
-                    }
-            }
-            load_rows(I + 1);
-            RW_ACC(1);                                            // K_b values
-            // ---- -S' += L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight).  The
-            //      accumulators hold -S': the MFMA has no negate modifier, and flipping an operand costs four VALU instructions
-            //      per k-step against once per tile at the consumer.  Addresses: inside block column K the packed columns are
-            //      a fixed stride apart, so a load is  buffer base + SCALAR offset (column block, k-step) + per-lane offset
-            //      (lane group's column, row): two multiply-adds per fetch instead of the column-offset polynomial per load
-            //      (a wave issues in order: address arithmetic does not hide behind its own MFMAs)
-            constexpr int KS = sizeof(T) == 4 ? BCBF_RW32_KS : BCBF_RW64_KS;
-            T2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
-            auto fetch = [&](int kk) {
-                const int K = kk / NB, stride = Np - NB * (K + 1);   // (wave-uniform: scalar registers)
-                // (the row bias -32 (K + 1) of a packed column goes into the per-lane part: a scalar offset is unsigned)
-                const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
-                const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
-#pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_) {
-                    const int so = (base + 4 * s_ * stride) * ES;
-                    a_nxt[s_] = P::bload2(rsL, va, so);
-                    b_nxt[s_] = P::bload2(rsL, vb, so);
                 }
             };
-            if (col0 > 0) fetch(0);
-            for (int kk = 0; kk < col0; kk += 4 * KS) {
-                T a_cur[KS][2], b_cur[KS][2];
+            // ---- -S' += L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight), for NT = 1 or
+            //      2 tiles of the block column at once: the two tiles share the A operand (block row J), so a pair reads three
+            //      panels where two single tiles read four -- the batches this form serves are bound by exactly that traffic
+            //      (4096 x 512 fp32: 21 GB fetched past L2 per launch for a 2 GB result, PMC).  The accumulators hold -S': the MFMA
+            //      has no negate modifier, and flipping an operand costs four VALU instructions per k-step against once per tile
+            //      at the consumer.  Addresses: inside block column K the packed columns are a fixed stride apart, so a load is
+            //      buffer base + SCALAR offset (column block, k-step) + per-lane offset (lane group's column, row): two
+            //      multiply-adds per fetch instead of the column-offset polynomial per load (a wave issues in order: address
+            //      arithmetic does not hide behind its own MFMAs)
+            // (two separate bodies: written as one body over NT the single-tile stream came out with twice the register moves and
+            //  six times the waits in its loop -- 177 instructions per 32 MFMAs against 111 -- and fp64 lost 5 %)
+            auto update = [&](acc_t (&acc)[2][2], int I) {
+                constexpr int KS = sizeof(T) == 4 ? BCBF_RW32_KS : BCBF_RW64_KS;
+                const int irow = I * NB + 2 * j16;
+                T2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
+                auto fetch = [&](int kk) {
+                    const int K = kk / NB, stride = Np - NB * (K + 1);   // (wave-uniform: scalar registers)
+                    // (the row bias -32 (K + 1) of a packed column goes into the per-lane part: a scalar offset is unsigned)
+                    const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                    const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
 #pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_) {
-                    a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
-                    b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        const int so = (base + 4 * s_ * stride) * ES;
+                        a_nxt[s_] = P::bload2(rsL, va, so);
+                        b_nxt[s_] = P::bload2(rsL, vb, so);
+                    }
+                };
+                if (col0 > 0) fetch(0);
+                for (int kk = 0; kk < col0; kk += 4 * KS) {
+                    T a_cur[KS][2], b_cur[KS][2];
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                        b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+                    }
+                    if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib)
+                                acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
                 }
-                if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
+            };
+            auto update2 = [&](acc_t (&acc0)[2][2], acc_t (&acc1)[2][2], int I) {       // tiles I and I + 1
+                constexpr int KS = (sizeof(T) == 4 ? BCBF_RW32_KS : BCBF_RW64_KS) / 2;
+                const int irow = I * NB + 2 * j16;
+                T2 a_nxt[KS], b0_nxt[KS], b1_nxt[KS];
+                auto fetch = [&](int kk) {
+                    const int K = kk / NB, stride = Np - NB * (K + 1);
+                    const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                    const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
 #pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_)
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        const int so = (base + 4 * s_ * stride) * ES;
+                        a_nxt[s_] = P::bload2(rsL, va, so);
+                        b0_nxt[s_] = P::bload2(rsL, vb, so);
+                        b1_nxt[s_] = P::bload2(rsL, vb + NB * ES, so);
+                    }
+                };
+                if (col0 > 0) fetch(0);
+                for (int kk = 0; kk < col0; kk += 4 * KS) {
+                    T a_cur[KS][2], b0_cur[KS][2], b1_cur[KS][2];
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                        b0_cur[s_][0] = b0_nxt[s_].x; b0_cur[s_][1] = b0_nxt[s_].y;
+                        b1_cur[s_][0] = b1_nxt[s_].x; b1_cur[s_][1] = b1_nxt[s_].y;
+                    }
+                    if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
 #pragma unroll
-                        for (int ib = 0; ib < 2; ++ib)
-                            acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
-            }
+                    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib) {
+                                acc0[cb][ib] = P::mfma(a_cur[s_][cb], b0_cur[s_][ib], acc0[cb][ib]);
+                                acc1[cb][ib] = P::mfma(a_cur[s_][cb], b1_cur[s_][ib], acc1[cb][ib]);
+                            }
+                }
+            };
+            // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of -S' are the B operands, ainv = -inv(L_JJ))
+            auto solve_store = [&](acc_t (&acc)[2][2], int I) {
+                const int irow = I * NB + 2 * j16;
+#pragma unroll
+                for (int cbp = 0; cbp < 2; ++cbp) {                     // (one half of the output columns at a time: 2 results live)
+                    acc_t y[2];                                         // [ib]
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        acc_t yy = {0, 0, 0, 0};
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
+                                yy = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], yy);
+                        y[ib] = yy;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * cbp + P::midx(r, g);
+                        T2 v; v.x = y[0][r]; v.y = y[1][r];             // rows irow, irow + 1 adjacent: one 16-byte store
+                        *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + c, Np) + irow) = v;
+                        if (Ld && col0 + c < N) {
+                            if (irow < N) Ld[(size_t)irow * N + col0 + c] = v.x;
+                            if (irow + 1 < N) Ld[(size_t)(irow + 1) * N + col0 + c] = v.y;
+                        }
+                    }
+                }
+            };
 
-            RW_ACC(2);                                            // update stream
-            if (I == J) {
-                // =================== the diagonal tile: factor L_JJ, invert it ===================
+            // =================== the diagonal tile: factor L_JJ, invert it ===================
+            auto diag_tile = [&](acc_t (&acc)[2][2]) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -386,7 +470,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         }
                     }
                 }
-                if (fail != 0) break;
+                if (fail != 0) return;
                 // A operands of the panel solve: output row c' = 16 cbp + j16, contraction index c = 2 (4r + g) + cb (the
                 // column an accumulator register of S' holds).  inv(L_JJ) is lower triangular: c' < 16 meets c < 16 only,
                 // that is r < 2
@@ -396,35 +480,238 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];   // (acc = -S')
-                RW_ACC(4);                                        // stores of the inverse
-            } else {
-                // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of -S' are the B operands, ainv = -inv(L_JJ))
-                acc_t y[2][2];                                      // [ib][cbp]
+            };
+            load_rows(rw0, J);
+            {
+                {
+                    acc_t acc[2][2];
+                    values(acc, rw0, J);
+                    load_rows(rw0, J + 1);
+                    load_rows(rw1, J + 2);
+                    RW_ACC(1);
+                    update(acc, J);
+                    RW_ACC(2);
+                    diag_tile(acc);
+                    RW_ACC(4);
+                    if (fail != 0) break;
+                }
+                // the tiles below it, two at a time
+                for (int I = J + 1; I < nblk; I += 2) {
+                    acc_t acc0[2][2], acc1[2][2];
+                    if (I + 1 < nblk) {
+                        values(acc0, rw0, I);
+                        values(acc1, rw1, I + 1);
+                        load_rows(rw0, I + 2);
+                        load_rows(rw1, I + 3);
+                        RW_ACC(1);
+                        update2(acc0, acc1, I);
+                        RW_ACC(2);
+                        solve_store(acc0, I);
+                        solve_store(acc1, I + 1);
+                    } else {
+                        values(acc0, rw0, I);
+                        RW_ACC(1);
+                        update(acc0, I);
+                        RW_ACC(2);
+                        solve_store(acc0, I);
+                    }
+                    RW_ACC(5);
+                }
+            }
+        } else {
+            // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one tile ahead, so that the loads are in
+            // flight during the previous tile's update stream instead of queueing behind its panel stores
+            T rx[2][RXD], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+            // Branch-free: every load is issued, a component the model does not have (d >= n, c >= C) or a row past the end
+            // is an out-of-range buffer offset and reads as zero.  (Written with `if (d < n)` around plain loads each one
+            // became its own basic block with a full wait behind it: ten serialized memory round trips per tile, 44 % of
+            // the kernel at N = 256.)
+            auto load_rows = [&](int I_) {
+                if (FROM_DENSE) return;
 #pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = I_ * NB + 2 * j16 + ib;
+                    const bool in = I_ < nblk && i < N;
 #pragma unroll
-                    for (int cbp = 0; cbp < 2; ++cbp) {
-                        acc_t yy = {0, 0, 0, 0};
+                    for (int d = 0; d < RXD; ++d)
+                        rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
+#pragma unroll
+                    for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
+                        ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
+                    rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
+                }
+            };
+            load_rows(J);
+            for (int I = J; I < nblk; ++I) {
+                const int irow = I * NB + 2 * j16;                    // + ib
+                acc_t acc[2][2];                                      // [cb][ib]: -S'[c = 2 (4r + g) + cb][i = 2 j16 + ib]  (halves interleaved:
+                                                                      // the two halves of an operand are adjacent rows, one 16-byte load)
+                // ---- initial value K_b'(c, i).  Straight-line: the column's inputs come from LDS as fixed-width rows (4 state
+                //      components, 4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE
+                //      read per column for both rows of the lane.  (With `if (d < n)` around each LDS read every read sat in a
+                //      basic block of its own with a full wait behind it: 120 serialized LDS round trips per tile.)
+                if (FROM_DENSE) {
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        const int i = irow + ib;
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                            for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
-                                yy = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], yy);
-                        y[ib][cbp] = yy;
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                                T val;
+                                if (i >= N || j >= N) val = (i == j) ? T(1.0) : T(0.0);      // padding: identity
+                                else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
+                                acc[cb][ib][r] = -val;
+                            }
                     }
+                } else {
 #pragma unroll
-                for (int cbp = 0; cbp < 2; ++cbp)
+                    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * cbp + P::midx(r, g);
-                        T2 v; v.x = y[0][cbp][r]; v.y = y[1][cbp][r];   // rows irow, irow + 1 adjacent: one 16-byte store
-                        *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + c, Np) + irow) = v;
-                        if (Ld && col0 + c < N) {
-                            if (irow < N) Ld[(size_t)irow * N + col0 + c] = v.x;
-                            if (irow + 1 < N) Ld[(size_t)(irow + 1) * N + col0 + c] = v.y;
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                            T cx[4], cu[4];
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib) {
+                                const int i = irow + ib;
+                                T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                                if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
+                                    for (int d = 4; d < n; ++d) {
+                                        const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
+                                        const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
+                                        d2 += z * z;
+                                    }
+                                }
+#pragma unroll
+                                for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                                T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
+                                val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;   // padding: identity
+                                acc[cb][ib][r] = -val;                // the accumulators carry -S' (see the update stream)
+                            }
+                        }
+                }
+                load_rows(I + 1);
+                RW_ACC(1);                                            // K_b values
+                // ---- -S' += L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight).  The
+                //      accumulators hold -S': the MFMA has no negate modifier, and flipping an operand costs four VALU instructions
+                //      per k-step against once per tile at the consumer.  Addresses: inside block column K the packed columns are
+                //      a fixed stride apart, so a load is  buffer base + SCALAR offset (column block, k-step) + per-lane offset
+                //      (lane group's column, row): two multiply-adds per fetch instead of the column-offset polynomial per load
+                //      (a wave issues in order: address arithmetic does not hide behind its own MFMAs)
+                constexpr int KS = sizeof(T) == 4 ? BCBF_RW32_KS : BCBF_RW64_KS;
+                T2 a_nxt[KS], b_nxt[KS];                         // (.x, .y) = the two halves cb / ib: adjacent rows, one 16-byte load
+                auto fetch = [&](int kk) {
+                    const int K = kk / NB, stride = Np - NB * (K + 1);   // (wave-uniform: scalar registers)
+                    // (the row bias -32 (K + 1) of a packed column goes into the per-lane part: a scalar offset is unsigned)
+                    const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                    const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        const int so = (base + 4 * s_ * stride) * ES;
+                        a_nxt[s_] = P::bload2(rsL, va, so);
+                        b_nxt[s_] = P::bload2(rsL, vb, so);
+                    }
+                };
+                if (col0 > 0) fetch(0);
+                for (int kk = 0; kk < col0; kk += 4 * KS) {
+                    T a_cur[KS][2], b_cur[KS][2];
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_) {
+                        a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                        b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+                    }
+                    if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
+#pragma unroll
+                    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib)
+                                acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
+                }
+
+                RW_ACC(2);                                            // update stream
+                if (I == J) {
+                    // =================== the diagonal tile: factor L_JJ, invert it ===================
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = -acc[cb][ib];
+                    // diag_tile64.h: on the matrix cores, out of the accumulators; xinv -> inv(L), tile -> L (dense output only)
+                    const int bad = diag_factor_invert_acc<T>(BCBF_LDS_TILE(T, sh.d), acc, lane, Ld != nullptr);
+                    RW_ACC(3);                                        // factor + inverse
+                    if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
+                    if (Ld && lane < NB && col0 + lane < N) {
+                        for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = sh.d.tile[lane][c];
+                    }
+                    {
+                        // global copies from LDS, contiguous across the wave, 16-byte stores: the full column-major tile
+                        // (shared-model kernel) and the packed lower triangle (streaming kernels)
+                        const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
+#pragma unroll
+                        for (int t = 0; t < NB * NB / 128; ++t) {
+                            const int e = 2 * lane + 128 * t, c = e >> 5, r = e & 31;
+                            T2 v; v.x = sh.d.xinv[r][c]; v.y = sh.d.xinv[r + 1][c];
+                            *reinterpret_cast<T2*>(lop + bfull + e) = v;
+                        }
+#pragma unroll
+                        for (int t = 0; t < (LOP_DB + 127) / 128; ++t) {
+                            const int k = 2 * lane + 128 * t;              // two consecutive entries of the packed triangle
+                            if (k < LOP_DB) {
+                                const unsigned rc = sh.pack_rc[k >> 1];    // (r0 | c0 << 8 | r1 << 16 | c1 << 24), 0xff.. = padding
+                                const int r0 = rc & 0xff, c0 = (rc >> 8) & 0xff, r1 = (rc >> 16) & 0xff, c1 = rc >> 24;
+                                T2 v;
+                                v.x = r0 < NB ? sh.d.xinv[r0][c0] : T(0.0);
+                                v.y = r1 < NB ? sh.d.xinv[r1][c1] : T(0.0);
+                                *reinterpret_cast<T2*>(lop + bpack + k) = v;
+                            }
                         }
                     }
-                RW_ACC(5);                                        // panel solve + stores
+                    if (fail != 0) break;
+                    // A operands of the panel solve: output row c' = 16 cbp + j16, contraction index c = 2 (4r + g) + cb (the
+                    // column an accumulator register of S' holds).  inv(L_JJ) is lower triangular: c' < 16 meets c < 16 only,
+                    // that is r < 2
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];   // (acc = -S')
+                    RW_ACC(4);                                        // stores of the inverse
+                } else {
+                    // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of -S' are the B operands, ainv = -inv(L_JJ))
+                    acc_t y[2][2];                                      // [ib][cbp]
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                        for (int cbp = 0; cbp < 2; ++cbp) {
+                            acc_t yy = {0, 0, 0, 0};
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                                for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
+                                    yy = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], yy);
+                            y[ib][cbp] = yy;
+                        }
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * cbp + P::midx(r, g);
+                            T2 v; v.x = y[0][cbp][r]; v.y = y[1][cbp][r];   // rows irow, irow + 1 adjacent: one 16-byte store
+                            *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + c, Np) + irow) = v;
+                            if (Ld && col0 + c < N) {
+                                if (irow < N) Ld[(size_t)irow * N + col0 + c] = v.x;
+                                if (irow + 1 < N) Ld[(size_t)(irow + 1) * N + col0 + c] = v.y;
+                            }
+                        }
+                    RW_ACC(5);                                        // panel solve + stores
+                }
             }
         }
         __threadfence_block();                 // this block column's panels are read back (by other lanes) from here on

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python tools/time_refit_one.py 2>/dev/null | tail -2
-python tools/bench_speed_test.py --quick 2>/dev/null | cut -c1-260 | tail -4
-python tools/prof_fit.py 2>/dev/null | tail -6
+python -m pytest tests -m gpu -x -q -k "refit or fit or golden or config or parity" 2>&1 | tail -2
+timeout 300 python tools/check_refit_forms.py 2>&1 | tail -1
+python tools/time_refit_wave.py "v=" 2>/dev/null | tail -1
+python tools/time_refit_wave.py "v=" 2>/dev/null | tail -1
