@@ -358,13 +358,14 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     const int Np = round_up(N, NB);
     hipStream_t st = (hipStream_t)stream;
     // Batches: one wave per instance (refit_wave64.hip, also compiled for fp32); BCBF_REFIT_WAVE=0/1 forces a form
-    bool per_wave = Bt >= BCBF_R32_WAVE_MIN_BATCH || (Bt >= 512 && Np <= 512) || (Bt >= 128 && Np <= 256) || (Bt >= 64 && Np <= 128);
+    bool per_wave = Bt >= BCBF_R32_WAVE_MIN_BATCH || (Bt >= 256 && Np <= 1024) || (Bt >= 128 && Np <= 512) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
     // Two waves per instance (refit_wave64.hip): measured in fp32 (ms workgroup / wave / two waves): 1024 x 128: 0.172 /
-    // 0.077 / 0.063, 4096 x 128: 0.68 / 0.19 / 0.24, 1024 x 256: 0.443 / 0.237 / 0.195, 4096 x 256: 1.75 / 0.66 / 0.89,
-    // 256 x 512: 1.17 / 0.97 / 0.87, 1024 x 512: 1.68 / 1.14 / 1.22, 4096 x 512: 6.6 / 3.7 / 5.6, 64 x 512: 0.71 / 0.94 / 0.77
+    // 0.070 / 0.058, 4096 x 128: 0.67 / 0.20 / 0.22, 1024 x 256: 0.441 / 0.220 / 0.186, 4096 x 256: 1.76 / 0.69 / 0.84,
+    // 256 x 512: 1.17 / 0.90 / 0.85, 512 x 512: 1.31 / 0.93 / 0.93, 1024 x 512: 1.69 / 1.04 / 1.18, 4096 x 512: 6.6 / 3.7 / 5.4,
+    // 64 x 512: 0.72 / 0.87 / 0.75, 256 x 1024: 5.5 / 5.3 / -
     // ONE model (tools/time_refit_one.py, us workgroup / two waves): N = 128: 105 / 41, 256: 236 / 131, 512: 705 / 741.
-    bool pair = Bt <= 1024 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 512));
+    bool pair = Bt <= 1024 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 256));
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     if (pair && !Kdense && !Ldense) {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
