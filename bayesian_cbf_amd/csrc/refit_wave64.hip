@@ -6,20 +6,20 @@
 // instance is owned by a single wave (no workgroup barriers, per-wave LDS), so every SIMD of the chip advances its own
 // chain, and the chain itself is rebuilt around 4-column blocks:
 //
-//   diagonal tile S (32x32, symmetric), lane = (row r = lane & 31, column half hb = lane >> 5) holds S[r][16hb .. 16hb+15]
-//   in registers.  8 steps, step s = columns 4s..4s+3:
-//     publish the four raw columns (LDS) -> every lane factors AND inverts the 4x4 diagonal block redundantly (4 rsqrt
-//     chains: the only serial part) -> lane r forms its row of the panel l[r][0..3] = P[r][:] inv(L4)' -> publish ->
-//     rank-4 update of the lane's 16 elements.
-//   inverse X = inv(L): lane = column c, 8 block steps; the two halves each form two of the four dot products of a
-//     step and swap them (v_permlane32_swap), then multiply by the 4x4 inverse kept from the factor.
-//   ~13 k cycles per tile instead of ~65 k.
+//   diagonal tile S (32x32, symmetric): round 2 held it as lane = (row, column half) with the four raw columns of a step
+//   published to LDS, the 4x4 diagonal block factored AND inverted redundantly in every lane (4 rsqrt chains: the only
+//   serial part), a rank-4 update of 16 elements per lane and a separate 8-step inverse pass (diag_tile64.h:
+//   diag_factor_invert, still used by the few-instances fp32 form): ~13 k cycles per tile instead of ~65 k.  Round 3
+//   (diag_factor_invert_acc): the tile never leaves the MFMA accumulator layout the update stream produces, the rank-4
+//   updates are four 16x16x4 MFMAs whose operands ARE the panel entries a lane has just formed, and the inverse rides
+//   along as a second accumulator set: 14.5 -> 8.4 us per tile.
 //
 // The rank-32 updates (v_mfma_f64_16x16x4_f64 on transposed tiles, operands straight from the packed operator: the
 // two 16-row halves of a tile are interleaved, MFMA index mu of half h = tile row 2 mu + h, so that a lane's two operand
 // values are adjacent rows and arrive in one 16-byte load) and the panel solve (accumulator registers as B operands)
-// are those of refit_mfma64.hip, run tile after tile by the owning wave.  Same outputs, same packed layout
-// (bcbf_common.h), same info convention.
+// are those of refit_mfma64.hip, run tile after tile by the owning wave (fp32: two tiles of a block column per pass,
+// sharing the A operand).  Same outputs, same packed layout (bcbf_common.h), same info convention.  The second kernel of
+// this file gives an instance TWO waves (small systems: a serial chain wave and a bulk wave with look-ahead).
 //
 // A wave alone on its SIMD hides nothing: every wait is paid in full.  What that meant here (cycle counters,
 // -DBCBF_RW64_PROF, N = 256): the K_b value pass was 44 % of the kernel -- not its arithmetic, but `if (d < n)` around
