@@ -752,7 +752,7 @@ constexpr int RA_MAXBLK = 16;          // block columns the look-ahead form hand
 //   wave 1, the BULK:  S' of the column's first panel tile is formed while it waits; on the column count: inv(L_JJ) ->
 //           registers, L_{J+1,J}' = inv(L_JJ) S' -> stored, published (the chain continues on it); then every other tile
 //           of column J: values, update stream, solve straight out of the accumulators (no S' parked in memory), store.
-// Hand-offs are three counters in LDS (diagonal tiles inverted; first panel tiles delivered; columns complete: release
+// Hand-offs are four counters in LDS (diagonal tiles inverted; first / second panel tiles delivered; columns complete: release
 // fence -> word -> acquire fence, workgroup scope: same CU, same L1); wave 1 fences once per column for everything but
 // the chain's tile.  Both waves fit the 256-register budget of two waves per SIMD, so a SIMD hosts waves of two different
 // instances.  Same outputs, same packed layout, same info convention; no dense output.
@@ -771,6 +771,7 @@ template <typename T> struct RAShared {
     unsigned pack_rc[LOP_DB / 2];             // (row, column) of the entries of a packed inverted diagonal block, two per word
     int inv_ready;                            // wave 0 -> 1: diagonal tiles factored, inverse in global memory (a large number after a failed pivot)
     int first_done;                           // wave 1 -> 0: columns J whose first panel tile L_{J+1,J} is complete
+    int second_done;                          // wave 1 -> 0: ... whose second panel tile L_{J+2,J} is complete too
     int cols_done;                            // wave 1 -> 0: columns complete
     int fail;
 };
@@ -803,7 +804,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
                 UHBout[((size_t)b * N + i) * C + c] = s;
             }
-        if (threadIdx.x == 0) { sp.inv_ready = 0; sp.first_done = 0; sp.cols_done = 0; sp.fail = 0; }
+        if (threadIdx.x == 0) { sp.inv_ready = 0; sp.first_done = 0; sp.second_done = 0; sp.cols_done = 0; sp.fail = 0; }
         rw_pack_table(sp.pack_rc, threadIdx.x, 128);
     }
     __threadfence_block();
@@ -953,6 +954,33 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
         }
     };
+    // the diagonal tile's stream: both operands are block row J (one load per k-step instead of two)
+    auto update_diag = [&](acc_t (&acc)[2][2], int J, int k0, int k1) {
+        constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
+        const int col0 = J * NB;
+        if (k0 >= k1) return;
+        T2 a_nxt[KS];
+        auto fetch = [&](int kk) {
+            const int K = kk / NB, stride = Np - NB * (K + 1);
+            const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+            const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) a_nxt[s_] = P::bload2(rsL, va, (base + 4 * s_ * stride) * ES);
+        };
+        fetch(k0);
+        for (int kk = k0; kk < k1; kk += 4 * KS) {
+            T a_cur[KS][2];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) { a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y; }
+            if (kk + 4 * KS < k1) fetch(kk + 4 * KS);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], a_cur[s_][ib], acc[cb][ib]);
+        }
+    };
     int tix = 0; (void)tix;
 
     if (wave == 0) {
@@ -968,13 +996,13 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             if (!EARLY) { load_rows(J); stage_issue(J); stage_commit(); }
             values(acc, J, J);
             if (J > 1) {
-                wait_for(&sp.cols_done, J - 1);                    // L_{J,J-2} (and every tile left of it)
-                update(acc, J, J, 0, col0 - NB);
+                wait_for(&sp.second_done, J - 1);                  // L_{J,J-2}: the second tile of column J - 2 (and every tile left of it)
+                update_diag(acc, J, 0, col0 - NB);
             }
             RA_T(0);                                               // 1: prepared
             if (J > 0) {                                           // ... and, as soon as wave 1 delivers it, over L_{J,J-1}
                 wait_for(&sp.first_done, J);
-                update(acc, J, J, col0 - NB, col0);
+                update_diag(acc, J, col0 - NB, col0);
             }
             RA_T(0);                                               // 2: diagonal tile up to date
 #pragma unroll
@@ -1075,6 +1103,8 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             if (I == J + 1) {
                 publish(&sp.first_done, J + 1);
                 RA_T(1);                                           // 3: the chain's panel tile delivered
+            } else if (I == J + 2) {
+                publish(&sp.second_done, J + 1);                   // (the chain's next diagonal tile but one starts on it)
             }
         }
         // one fence for the rest of the column: nobody reads these tiles before the next column (this wave: as update
