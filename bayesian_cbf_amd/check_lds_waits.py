@@ -35,6 +35,36 @@ def _regs(text):
     return out
 
 
+_PK32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mov_b32")
+
+
+def _touched(op, rest):
+    """Registers an instruction reads or writes.  Packed-f32 operations name 64-bit source pairs but read only the halves
+    their op_sel / op_sel_hi modifiers select (low result: element op_sel[k], default 0; high result: element
+    op_sel_hi[k], default 1) -- `v_pk_fma_f32 v[0:1], v[70:71], ... op_sel_hi:[0,1,1]` reads v70 twice and never v71."""
+    if not op.startswith(_PK32):
+        return _regs(rest)
+    mods = {}
+    for name in ("op_sel", "op_sel_hi"):
+        m = re.search(r"\b%s:\[([01,\s]+)\]" % name, rest)
+        if m:
+            mods[name] = [int(v) for v in m.group(1).replace(" ", "").split(",")]
+    body = re.split(r"\s+(?:op_sel|op_sel_hi|neg_lo|neg_hi|clamp)\b", rest)[0]
+    ops = [o.strip() for o in re.split(r",(?![^\[]*\])", body)]
+    out = _regs(ops[0])                                   # the destination pair is written whole
+    for k, src in enumerate(ops[1:]):
+        m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", src)
+        if not m:
+            out |= _regs(src)                             # a single register, a constant: as written
+            continue
+        lo = int(m.group(2))
+        sel = mods.get("op_sel", [0, 0, 0])
+        sel_hi = mods.get("op_sel_hi", [1, 1, 1])
+        for e in {sel[k] if k < len(sel) else 0, sel_hi[k] if k < len(sel_hi) else 1}:
+            out.add((m.group(1), lo + e))
+    return out
+
+
 def check(asm_text, name_regex=r"."):
     """Returns a list of (kernel, line number, instruction, registers) violations."""
     pat = re.compile(name_regex)
@@ -84,7 +114,7 @@ def check(asm_text, name_regex=r"."):
         if not inflight:
             continue
         pend = set().union(*inflight)
-        hit = _regs(rest) & pend
+        hit = _touched(op, rest) & pend
         if hit:
             bad.append((kernel, ln, line, sorted(hit)))
     return bad, checked

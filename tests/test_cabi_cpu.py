@@ -73,3 +73,10 @@ _Z6kernelv:
     wrong_wait = good.replace("lgkmcnt(1)", "lgkmcnt(2)")                                     # nothing retired yet
     assert len(check(wrong_wait, "kernel")[0]) == 1
     assert check(early, "other_name") == ([], 0)
+    # packed fp32: a 64-bit source pair is read only where op_sel / op_sel_hi point -- v[10:11] with op_sel_hi:[0,..] reads
+    # v10 twice and never the in-flight v11; with the default modifiers it reads both halves
+    pk_ok = good.replace("\tv_add_f32_e32 v1, v2, v4", "\tds_read_b32 v9, v3\n\ts_waitcnt lgkmcnt(0)\n\tds_read_b32 v11, v3\n"
+                         "\tv_pk_fma_f32 v[30:31], v[10:11], v[32:33], v[30:31] op_sel_hi:[0,1,1]\n\ts_waitcnt lgkmcnt(0)")
+    assert check(pk_ok, "kernel")[0] == []
+    pk_bad = pk_ok.replace(" op_sel_hi:[0,1,1]", "")
+    assert [b[3] for b in check(pk_bad, "kernel")[0]] == [[("v", 11)]]
