@@ -871,6 +871,52 @@ def test_refit_one_wave_per_instance_vs_oracle_and_workgroup_form(ops, N, n, m, 
         rel_close(host(Bk)[i], Bk_o[0], 1e-8 if f64 else 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("Bt,N,n,m", [(1, 1, 2, 1), (70, 31, 3, 2), (70, 33, 3, 2), (3, 100, 6, 3), (70, 256, 2, 1), (9, 500, 3, 2)])
+def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, Bt, N, n, m, dtype, monkeypatch):
+    """The two-waves-per-instance form of the refit (refit_wave64.hip: refit_pair_kernel -- a chain wave that factors and
+    inverts the diagonal tiles on the matrix cores, a bulk wave one block column behind; N <= 512, no dense output) forced
+    by BCBF_REFIT_PAIR=1 against the one-wave form on the same inputs -- packed operator incl. both copies of the inverted
+    diagonal blocks, UH*B, per-instance failure index (a failed pivot in one instance) -- and, through potrs + the posterior
+    kernel, against the oracle.  Shapes: one row, a ragged last block, a state wider than the registers hold (n = 6), the
+    largest system of the form, one instance and an odd batch."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64 = dtype == torch.float64
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=300 + N)
+    p["X"] = (p["X"] * 2.0).contiguous()
+    jit = p["jitter"].clone()
+    X, UH = p["X"].clone(), p["UH"].clone()
+    bad = Bt > 5 and N >= 31
+    if bad:                                    # instance 5: a duplicated point with a negative shift -> pivot 21 fails
+        X[5, 20], UH[5, 20] = X[5, 3], UH[5, 3]
+        jit[5] = 0.0
+        jit[5, 20] = -1e-3 if f64 else -1e-2
+    args = (X, UH, p["Bm"], p["ell"], p["s2"], jit)
+    monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
+    monkeypatch.setenv("BCBF_REFIT_PAIR", "1")
+    Lop_p, UHB_p, info_p, _ = ops.refit(*args)
+    monkeypatch.setenv("BCBF_REFIT_PAIR", "0")
+    Lop_w, UHB_w, info_w, _ = ops.refit(*args)
+    torch.cuda.synchronize()
+    ip = info_p.cpu().numpy()
+    assert np.array_equal(ip, info_w.cpu().numpy())
+    good = ip == 0
+    assert good.sum() == (Bt - 1 if bad else Bt) and (not bad or ip[5] == 21)
+    assert torch.equal(UHB_p, UHB_w)
+    for i in np.nonzero(good)[0][:8]:          # (fp32: two factorizations of K_b with cond ~1e5, inverses of its diagonal blocks)
+        rel_close(host(Lop_p[i]), host(Lop_w[i]), 1e-8 if f64 else 2e-3, what="Lop vs one-wave form [%d]" % i)
+    Vw, _ = ops.potrs(Lop_p, p["Xdot"], UH, p["M0"], want_alpha=False)
+    Mk, Bk = ops.posterior_step(Lop_p, Vw, X, UHB_p, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+    h = {k: host(v) for k, v in dict(X=X, U=p["U"], Xdot=p["Xdot"], Bm=p["Bm"], ell=p["ell"], s2=p["s2"], M0=p["M0"], jit=jit).items()}
+    for i in (0, Bt - 1):
+        st = ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                             h["jit"][i][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None], h["ell"][i][None],
+                                        h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], host(p["xq"])[i][None])
+        rel_close(host(Mk)[i], Mk_o[0], 1e-8 if f64 else 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+        rel_close(host(Bk)[i], Bk_o[0], 1e-8 if f64 else 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("K", [5, 7])
 def test_programs_with_more_than_four_cones_vs_oracle(ops, dtype, K):
