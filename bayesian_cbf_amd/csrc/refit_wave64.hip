@@ -1134,6 +1134,382 @@ int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const 
     return launch_refit_pair<float>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// FEW LARGE INSTANCES: A TEAM OF WAVES PER INSTANCE (round 3).  The two-wave kernel above with the bulk role on NW - 1
+// waves: wave 0 is still the serial chain (diagonal tiles on the matrix cores, nothing else), bulk wave w takes every
+// (NW - 1)-th tile of a block column.  A tile's inputs come from whichever waves made the tiles to its left, so the
+// hand-off is per BLOCK ROW: pdone[I] counts the columns whose L_IJ is complete (it only ever grows: L_{I,J+1} is started
+// by a wave that has seen L_IJ).  Bulk wave 0 (the tile the chain continues on) takes inv(L_JJ) out of LDS as in the
+// two-wave kernel; the others may be columns behind and read the copy in global memory, behind a second counter.
+// One workgroup of NW = 8 waves per instance: two waves per SIMD, 256 registers each, one instance per CU -- the form
+// for a handful of systems of N >= 512 (the facade's fit / clear_cache refits of ONE model), where the workgroup form
+// leaves three of its four waves waiting on the diagonal tile.
+constexpr int RT_MAXBLK = 64;          // block columns the team form handles (N <= 2048)
+template <typename T, int NW> struct RTShared {
+    DiagTile<T> d;                            // wave 0's
+    T colX[NW][NB][BCBF_MAX_STATE_DIM];       // [wave]: each wave stages the column block it is forming values for
+    T colUH[NW][NB][BCBF_MAX_CTRL_DIM + 1];
+    unsigned pack_rc[LOP_DB / 2];
+    int pdone[RT_MAXBLK];                     // block row I: columns J whose L_IJ is complete
+    int inv_ready;                            // diagonal tiles factored, inverse in LDS
+    int inv_global;                           // ... and copied to global memory
+    int fail;
+};
+
+template <typename T, int NW>
+__global__ void __launch_bounds__(64 * NW, 1)
+refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
+                   const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
+                   T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+    constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
+    using P = RW<T>;
+    using acc_t = typename P::acc_t;
+    using T2 = typename P::vec2;
+    __shared__ RTShared<T, NW> shm;
+    __attribute__((address_space(3))) RTShared<T, NW>& sp = *(__attribute__((address_space(3))) RTShared<T, NW>*)&shm;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.x;
+    const int j16 = lane & 15, g = lane >> 4;
+    T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    const T* Xb = X + (size_t)b * N * n;
+    const T* UHb = UH + (size_t)b * N * C;
+    const int nblk = Np / NB;
+    {   // UH B rows (all waves), the hand-off words
+        T Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+#pragma unroll
+        for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : T(0.0);
+        for (int i = threadIdx.x; i < N; i += 64 * NW)
+            for (int c = 0; c < C; ++c) {
+                T s = T(0.0);
+                for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                UHBout[((size_t)b * N + i) * C + c] = s;
+            }
+        if (threadIdx.x == 0) { sp.inv_ready = 0; sp.inv_global = 0; sp.fail = 0; }
+        for (int i = threadIdx.x; i < RT_MAXBLK; i += 64 * NW) sp.pdone[i] = 0;
+        rw_pack_table(sp.pack_rc, threadIdx.x, 64 * NW);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (a waiter also leaves when a pivot has failed: the wave it waits for may have left already)
+    auto wait_for = [&](__attribute__((address_space(3))) int* word, int want) {
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want &&
+               __hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto publish = [&](__attribute__((address_space(3))) int* word, int value) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto failed = [&]() { return __hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+
+    // ---- what both waves do to a tile: kernel values, the update stream (each on its own registers and its own column
+    //      block in LDS)
+    const T* UHBb = UHBout + (size_t)b * N * C;
+    // (registers: the first four state components only -- no reference system has more; wider states take the slow
+    //  path below, reading the rest from memory)
+    T iell[4];
+    const T s2 = s2p[b];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xb), 0, N * n * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, N * C * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
+    auto& cX = sp.colX[wave];
+    auto& cU = sp.colUH[wave];
+    // a column block's inputs, zero-filled to fixed widths: loads ISSUED early (into registers, out-of-range offsets read
+    // as zero), written to LDS when the previous block's values are done -- the round trip hides under other work
+    const __amdgpu_buffer_rsrc_t rsUH = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHb), 0, N * C * ES, 0x00020000);
+    constexpr int SX = NB * BCBF_MAX_STATE_DIM / 64, SU = NB * (BCBF_MAX_CTRL_DIM + 1) / 64;
+    T sx[SX], su[SU];
+    auto stage_issue = [&](int J) {
+        const int col0 = J * NB;
+#pragma unroll
+        for (int t = 0; t < SX; ++t) {
+            const int e = lane + 64 * t, c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+            sx[t] = P::bload(rsX, (col0 + c < N && d < n) ? ((col0 + c) * n + d) * ES : -ES);
+        }
+#pragma unroll
+        for (int t = 0; t < SU; ++t) {
+            const int e = lane + 64 * t, c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+            su[t] = P::bload(rsUH, (col0 + c < N && a < C) ? ((col0 + c) * C + a) * ES : -ES);
+        }
+    };
+    // (fp32 only: in fp64 the 48 registers that stay live across the inverse copy / the column fence spill -- 320 B of
+    //  scratch against 104 -- and the kernel is slower for it; there a column's inputs are fetched where they are used)
+    constexpr bool EARLY = false;                      // (a column's inputs are fetched where they are used)
+    auto stage_commit = [&]() {
+        __builtin_amdgcn_wave_barrier();                           // every lane is done with the previous column block
+#pragma unroll
+        for (int t = 0; t < SX; ++t) { const int e = lane + 64 * t; cX[e / BCBF_MAX_STATE_DIM][e % BCBF_MAX_STATE_DIM] = sx[t]; }
+#pragma unroll
+        for (int t = 0; t < SU; ++t) { const int e = lane + 64 * t; cU[e / (BCBF_MAX_CTRL_DIM + 1)][e % (BCBF_MAX_CTRL_DIM + 1)] = su[t]; }
+        __builtin_amdgcn_wave_barrier();
+    };
+    T rx[2][4], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
+    auto load_rows = [&](int I_) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int i = I_ * NB + 2 * j16 + ib;
+            const bool in = I_ < nblk && i < N;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) rx[ib][d] = P::bload(rsX, (in && d < n) ? (i * n + d) * ES : -ES);
+#pragma unroll
+            for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) ru[ib][c] = P::bload(rsU, (in && c < C) ? (i * C + c) * ES : -ES);
+            rj[ib] = P::bload(rsJ, in ? i * ES : -ES);
+        }
+    };
+    // acc[cb][ib][r] = K_b'(column col0 + 2 midx(r, g) + cb, row 32 I + 2 j16 + ib)   (rows of block row I in rx / ru / rj)
+    auto values = [&](acc_t (&acc)[2][2], int I, int J) {
+        const int col0 = J * NB, irow = I * NB + 2 * j16;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                T cx[4], cu[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { cx[d] = cX[c][d]; cu[d] = cU[c][d]; }
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int i = irow + ib;
+                    T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+                    if (n > 4) {                                  // (wave-uniform, rare)
+                        for (int d = 4; d < n; ++d) {
+                            const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
+                            const T z = (xi - cX[c][d]) / ell[(size_t)b * n + d];
+                            d2 += z * z;
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                    T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
+                    val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;
+                    acc[cb][ib][r] = -val;                         // the accumulators carry -S' (see update)
+                }
+                // one column's inputs at a time: left alone the scheduler hoists the LDS reads of all eight columns
+                // (64 values) to the top of the tile
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    // acc += L_{J, k0..k1} L_{I, k0..k1}'   (columns k0 <= k < k1 of the packed operator; software pipelined).  acc holds
+    // -S': the MFMA has no negate modifier, and flipping an operand costs four VALU instructions per k-step against once
+    // per tile at the consumer.  Addresses: inside block column K the packed columns are a fixed stride apart, so a load
+    // is  buffer base + SCALAR offset (column block, k-step) + per-lane offset (lane group's column, row)  -- two
+    // multiply-adds per fetch instead of the full column-offset polynomial per load (the VALU work of this loop was
+    // a third of its time: the wave issues in order, address arithmetic does not hide behind its own MFMAs)
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(lop, 0, (int)(lop_elems<V>(Np) * ES), 0x00020000);
+    auto update = [&](acc_t (&acc)[2][2], int I, int J, int k0, int k1) {
+        constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
+        const int col0 = J * NB, irow = I * NB + 2 * j16;
+        if (k0 >= k1) return;
+        T2 a_nxt[KS], b_nxt[KS];
+        auto fetch = [&](int kk) {
+            const int K = kk / NB, stride = Np - NB * (K + 1);     // (wave-uniform: scalar registers)
+            // (lop_base of a block column's first column is NEGATIVE for K = 0 -- rows count from 32 (K + 1) -- and a
+            //  scalar offset is unsigned: the row bias goes into the per-lane part, which it leaves non-negative)
+            const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+            const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const int so = (base + 4 * s_ * stride) * ES;
+                a_nxt[s_] = P::bload2(rsL, va, so);
+                b_nxt[s_] = P::bload2(rsL, vb, so);
+            }
+        };
+        fetch(k0);
+        for (int kk = k0; kk < k1; kk += 4 * KS) {
+            T a_cur[KS][2], b_cur[KS][2];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+            }
+            if (kk + 4 * KS < k1) fetch(kk + 4 * KS);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
+        }
+    };
+    // the diagonal tile's stream: both operands are block row J (one load per k-step instead of two)
+    auto update_diag = [&](acc_t (&acc)[2][2], int J, int k0, int k1) {
+        constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
+        const int col0 = J * NB;
+        if (k0 >= k1) return;
+        T2 a_nxt[KS];
+        auto fetch = [&](int kk) {
+            const int K = kk / NB, stride = Np - NB * (K + 1);
+            const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+            const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) a_nxt[s_] = P::bload2(rsL, va, (base + 4 * s_ * stride) * ES);
+        };
+        fetch(k0);
+        for (int kk = k0; kk < k1; kk += 4 * KS) {
+            T a_cur[KS][2];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) { a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y; }
+            if (kk + 4 * KS < k1) fetch(kk + 4 * KS);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = P::mfma(a_cur[s_][cb], a_cur[s_][ib], acc[cb][ib]);
+        }
+    };
+    int tix = 0; (void)tix;
+
+    if (wave == 0) {
+        // =============================== the CHAIN ===============================
+        int fail = 0;
+        for (int J = 0; J < nblk; ++J) {
+            const int col0 = J * NB;
+            acc_t acc[2][2];
+            load_rows(J); stage_issue(J); stage_commit();
+            values(acc, J, J);
+            if (J > 1) {
+                wait_for(&sp.pdone[J], J - 1);                     // L_{J,J-2} and every tile left of it
+                if (failed()) break;
+                update_diag(acc, J, 0, col0 - NB);
+            }
+            if (J > 0) {                                           // ... and, as soon as it is delivered, over L_{J,J-1}
+                wait_for(&sp.pdone[J], J);
+                if (failed()) break;
+                update_diag(acc, J, col0 - NB, col0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = -acc[cb][ib];
+            const int bad = diag_factor_invert_acc<T>(BCBF_LDS_TILE(T, sp.d), acc, lane, false);
+            if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
+            if (fail != 0) {
+                if (lane == 0) __hip_atomic_store(&sp.fail, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;                                             // (every waiter polls the flag)
+            }
+            // bulk wave 0 takes inv(L_JJ) out of LDS (nothing writes xinv again before it has delivered this column's first
+            // panel tile); the others read the copy in global memory once the second counter says it is complete
+            publish(&sp.inv_ready, J + 1);
+            {
+                const int bfull = lop_dfull_block(J, Np), bpack = lop_dinv_block(J, Np);
+#pragma unroll
+                for (int t = 0; t < NB * NB / 128; ++t) {
+                    const int e = 2 * lane + 128 * t, c = e >> 5, r = e & 31;
+                    T2 v; v.x = sp.d.xinv[r][c]; v.y = sp.d.xinv[r + 1][c];
+                    *reinterpret_cast<T2*>(lop + bfull + e) = v;
+                }
+#pragma unroll
+                for (int t = 0; t < (LOP_DB + 127) / 128; ++t) {
+                    const int k_ = 2 * lane + 128 * t;
+                    if (k_ < LOP_DB) {
+                        const unsigned rc = sp.pack_rc[k_ >> 1];
+                        const int r0 = rc & 0xff, c0 = (rc >> 8) & 0xff, r1 = (rc >> 16) & 0xff, c1 = rc >> 24;
+                        T2 v;
+                        v.x = r0 < NB ? sp.d.xinv[r0][c0] : T(0.0);
+                        v.y = r1 < NB ? sp.d.xinv[r1][c1] : T(0.0);
+                        *reinterpret_cast<T2*>(lop + bpack + k_) = v;
+                    }
+                }
+            }
+            publish(&sp.inv_global, J + 1);
+        }
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+    // =============================== the BULK waves ===============================
+    // bulk wave w takes the tiles I = J + 1 + w, J + 1 + w + (NW - 1), ... of block column J; per block row I a word in LDS
+    // counts the columns whose L_IJ is complete (whoever made them)
+    constexpr int NBW = NW - 1;
+    const int w = wave - 1;
+    for (int J = 0; J + 1 < nblk; ++J) {
+        const int col0 = J * NB;
+        if (J + 1 + w >= nblk) break;                              // (no tile of this or any later column for this wave)
+        T ainv[2][2][4];
+        load_rows(J + 1 + w); stage_issue(J); stage_commit();
+        for (int I = J + 1 + w; I < nblk; I += NBW) {
+            const int irow = I * NB + 2 * j16;
+            acc_t acc[2][2];
+            values(acc, I, J);
+            load_rows(I + NBW);
+            if (J > 0) {
+                wait_for(&sp.pdone[I], J);                         // block rows I and J complete through column J - 1
+                wait_for(&sp.pdone[J], J);
+                if (failed()) return;
+            }
+            update(acc, I, J, 0, col0);
+            if (I == J + 1 + w) {
+                // (this wave's first tile of the column: its S' was formed before this wait)
+                if (w == 0) {
+                    wait_for(&sp.inv_ready, J + 1);
+                    if (failed()) return;
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -sp.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];   // (acc = -S')
+                } else {
+                    wait_for(&sp.inv_global, J + 1);
+                    if (failed()) return;
+                    const T* xf = lop + lop_dfull_block(J, Np);
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -xf[NB * (2 * P::midx(r, g) + cb) + 16 * cbp + j16];
+                }
+            }
+            // L_IJ' = inv(L_JJ) S': the accumulator registers of -S' are the B operands, ainv = -inv(L_JJ)
+#pragma unroll
+            for (int cbp = 0; cbp < 2; ++cbp) {
+                acc_t y[2];
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    acc_t yy = {0, 0, 0, 0};
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
+                            yy = P::mfma(ainv[cbp][cb][r], acc[cb][ib][r], yy);
+                    y[ib] = yy;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T2 v; v.x = y[0][r]; v.y = y[1][r];
+                    *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + irow) = v;
+                }
+            }
+            publish(&sp.pdone[I], J + 1);
+        }
+    }
+}
+
+template <typename T>
+static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, T* Lop, T* UHB,
+                             int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+    if (Np / NB > RT_MAXBLK) return -1;
+    hipLaunchKernelGGL((refit_team_kernel<T, 8>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C);
+    return 0;
+}
+int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                        const double* jitter, double* Lop, double* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                        hipStream_t st) {
+    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
+}
+int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                        const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                        hipStream_t st) {
+    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
+}
+
 // Called by bcbf_refit_mfma_f64 / _f32 for batches.
 template <typename T>
 static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,

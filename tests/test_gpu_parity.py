@@ -872,14 +872,18 @@ def test_refit_one_wave_per_instance_vs_oracle_and_workgroup_form(ops, N, n, m, 
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("Bt,N,n,m", [(1, 1, 2, 1), (70, 31, 3, 2), (70, 33, 3, 2), (3, 100, 6, 3), (70, 256, 2, 1), (9, 500, 3, 2)])
-def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, Bt, N, n, m, dtype, monkeypatch):
-    """The two-waves-per-instance form of the refit (refit_wave64.hip: refit_pair_kernel -- a chain wave that factors and
-    inverts the diagonal tiles on the matrix cores, a bulk wave one block column behind; N <= 512, no dense output) forced
-    by BCBF_REFIT_PAIR=1 against the one-wave form on the same inputs -- packed operator incl. both copies of the inverted
-    diagonal blocks, UH*B, per-instance failure index (a failed pivot in one instance) -- and, through potrs + the posterior
-    kernel, against the oracle.  Shapes: one row, a ragged last block, a state wider than the registers hold (n = 6), the
-    largest system of the form, one instance and an odd batch."""
+@pytest.mark.parametrize("form,Bt,N,n,m", [("pair", 1, 1, 2, 1), ("pair", 70, 31, 3, 2), ("pair", 70, 33, 3, 2), ("pair", 3, 100, 6, 3),
+                                          ("pair", 70, 256, 2, 1), ("pair", 9, 500, 3, 2),
+                                          ("team", 1, 1, 2, 1), ("team", 7, 33, 3, 2), ("team", 3, 100, 6, 3), ("team", 9, 500, 3, 2),
+                                          ("team", 2, 1000, 3, 3), ("team", 1, 2048, 3, 2)])
+def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt, N, n, m, dtype, monkeypatch):
+    """The chain + bulk forms of the refit (refit_wave64.hip: a chain wave that factors and inverts the diagonal tiles on the
+    matrix cores; `pair`: one bulk wave a block column behind, N <= 512; `team`: seven bulk waves sharing a column's
+    tiles, hand-offs per block row, N <= 2048; no dense output) forced by BCBF_REFIT_PAIR=1 / BCBF_REFIT_TEAM=1 against the
+    one-wave form on the same inputs -- packed operator incl. both copies of the inverted diagonal blocks, UH*B,
+    per-instance failure index (a failed pivot in one instance) -- and, through potrs + the posterior kernel, against the
+    oracle.  Shapes: one row, a ragged last block, a state wider than the registers hold (n = 6), the largest systems of
+    the forms, one instance and odd batches."""
     from bayesian_cbf_amd.synthetic import make_instances
     f64 = dtype == torch.float64
     p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=300 + N)
@@ -892,9 +896,14 @@ def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, Bt, N, n,
         jit[5] = 0.0
         jit[5, 20] = -1e-3 if f64 else -1e-2
     args = (X, UH, p["Bm"], p["ell"], p["s2"], jit)
-    monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
-    monkeypatch.setenv("BCBF_REFIT_PAIR", "1")
+    if form == "pair":
+        monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
+        monkeypatch.setenv("BCBF_REFIT_PAIR", "1")
+    else:
+        monkeypatch.setenv("BCBF_REFIT_TEAM", "1")
     Lop_p, UHB_p, info_p, _ = ops.refit(*args)
+    monkeypatch.setenv("BCBF_REFIT_TEAM", "0")
+    monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
     monkeypatch.setenv("BCBF_REFIT_PAIR", "0")
     Lop_w, UHB_w, info_w, _ = ops.refit(*args)
     torch.cuda.synchronize()
