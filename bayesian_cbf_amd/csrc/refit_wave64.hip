@@ -1156,11 +1156,12 @@ template <typename T, int NW> struct RTShared {
     int fail;
 };
 
-template <typename T, int NW>
+template <typename T, int NW, bool FROM_DENSE>
 __global__ void __launch_bounds__(64 * NW, 1)
 refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
-                   T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+                   const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt,
+                   int N, int Np, int n, int C) {
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
     using P = RW<T>;
     using acc_t = typename P::acc_t;
@@ -1171,19 +1172,23 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     const int b = blockIdx.x;
     const int j16 = lane & 15, g = lane >> 4;
     T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
-    const T* Xb = X + (size_t)b * N * n;
-    const T* UHb = UH + (size_t)b * N * C;
+    // (FROM_DENSE: K_b is given -- bcbf_potrf -- and the kernel values are read, not formed; no X / UH / UH B)
+    const T* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
+    const T* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
+    const T* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
     const int nblk = Np / NB;
     {   // UH B rows (all waves), the hand-off words
-        T Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
+        if constexpr (!FROM_DENSE) {
+            T Bmr[(BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1)];
 #pragma unroll
-        for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : T(0.0);
-        for (int i = threadIdx.x; i < N; i += 64 * NW)
-            for (int c = 0; c < C; ++c) {
-                T s = T(0.0);
-                for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
-                UHBout[((size_t)b * N + i) * C + c] = s;
-            }
+            for (int a = 0; a < (BCBF_MAX_CTRL_DIM + 1) * (BCBF_MAX_CTRL_DIM + 1); ++a) Bmr[a] = a < C * C ? Bm[(size_t)b * C * C + a] : T(0.0);
+            for (int i = threadIdx.x; i < N; i += 64 * NW)
+                for (int c = 0; c < C; ++c) {
+                    T s = T(0.0);
+                    for (int a = 0; a < C; ++a) s += UHb[(size_t)i * C + a] * Bmr[a * C + c];
+                    UHBout[((size_t)b * N + i) * C + c] = s;
+                }
+        }
         if (threadIdx.x == 0) { sp.inv_ready = 0; sp.inv_global = 0; sp.fail = 0; }
         for (int i = threadIdx.x; i < RT_MAXBLK; i += 64 * NW) sp.pdone[i] = 0;
         rw_pack_table(sp.pack_rc, threadIdx.x, 64 * NW);
@@ -1205,25 +1210,26 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
     // ---- what both waves do to a tile: kernel values, the update stream (each on its own registers and its own column
     //      block in LDS)
-    const T* UHBb = UHBout + (size_t)b * N * C;
+    const T* UHBb = FROM_DENSE ? nullptr : UHBout + (size_t)b * N * C;
     // (registers: the first four state components only -- no reference system has more; wider states take the slow
     //  path below, reading the rest from memory)
     T iell[4];
-    const T s2 = s2p[b];
+    const T s2 = FROM_DENSE ? T(0.0) : s2p[b];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) iell[d] = d < n ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xb), 0, N * n * ES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHBb), 0, N * C * ES, 0x00020000);
+    for (int d = 0; d < 4; ++d) iell[d] = (!FROM_DENSE && d < n) ? T(1.0) / ell[(size_t)b * n + d] : T(0.0);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(FROM_DENSE ? Lop : Xb), 0, FROM_DENSE ? 0 : N * n * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(FROM_DENSE ? Lop : UHBb), 0, FROM_DENSE ? 0 : N * C * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(jitter ? jitter + (size_t)b * N : X), 0, jitter ? N * ES : 0, 0x00020000);
+        const_cast<T*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : Lop), 0, (!FROM_DENSE && jitter) ? N * ES : 0, 0x00020000);
     auto& cX = sp.colX[wave];
     auto& cU = sp.colUH[wave];
     // a column block's inputs, zero-filled to fixed widths: loads ISSUED early (into registers, out-of-range offsets read
     // as zero), written to LDS when the previous block's values are done -- the round trip hides under other work
-    const __amdgpu_buffer_rsrc_t rsUH = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(UHb), 0, N * C * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsUH = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(FROM_DENSE ? Lop : UHb), 0, FROM_DENSE ? 0 : N * C * ES, 0x00020000);
     constexpr int SX = NB * BCBF_MAX_STATE_DIM / 64, SU = NB * (BCBF_MAX_CTRL_DIM + 1) / 64;
     T sx[SX], su[SU];
     auto stage_issue = [&](int J) {
+        if (FROM_DENSE) return;
         const int col0 = J * NB;
 #pragma unroll
         for (int t = 0; t < SX; ++t) {
@@ -1240,6 +1246,7 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     //  scratch against 104 -- and the kernel is slower for it; there a column's inputs are fetched where they are used)
     constexpr bool EARLY = false;                      // (a column's inputs are fetched where they are used)
     auto stage_commit = [&]() {
+        if (FROM_DENSE) return;
         __builtin_amdgcn_wave_barrier();                           // every lane is done with the previous column block
 #pragma unroll
         for (int t = 0; t < SX; ++t) { const int e = lane + 64 * t; cX[e / BCBF_MAX_STATE_DIM][e % BCBF_MAX_STATE_DIM] = sx[t]; }
@@ -1249,6 +1256,7 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     };
     T rx[2][4], ru[2][BCBF_MAX_CTRL_DIM + 1], rj[2];
     auto load_rows = [&](int I_) {
+        if (FROM_DENSE) return;
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             const int i = I_ * NB + 2 * j16 + ib;
@@ -1263,6 +1271,23 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     // acc[cb][ib][r] = K_b'(column col0 + 2 midx(r, g) + cb, row 32 I + 2 j16 + ib)   (rows of block row I in rx / ru / rj)
     auto values = [&](acc_t (&acc)[2][2], int I, int J) {
         const int col0 = J * NB, irow = I * NB + 2 * j16;
+        if constexpr (FROM_DENSE) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int i = irow + ib;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
+                        T val;
+                        if (i >= N || j >= N) val = (i == j) ? T(1.0) : T(0.0);          // padding: identity
+                        else val = (j <= i) ? Kb[(size_t)i * N + j] : Kb[(size_t)j * N + i];
+                        acc[cb][ib][r] = -val;
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -1493,21 +1518,24 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 }
 
 template <typename T>
-static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, T* Lop, T* UHB,
-                             int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, const T* Kdense,
+                             T* Lop, T* UHB, int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
     if (Np / NB > RT_MAXBLK) return -1;
-    hipLaunchKernelGGL((refit_team_kernel<T, 8>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C);
+    if (Kdense)
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, true>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C);
+    else
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, false>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C);
     return 0;
 }
 int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
-                        const double* jitter, double* Lop, double* UHB, int* info, int Bt, int N, int Np, int n, int C,
-                        hipStream_t st) {
-    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
+                        const double* jitter, const double* Kdense, double* Lop, double* UHB, int* info, int Bt, int N, int Np,
+                        int n, int C, hipStream_t st) {
+    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C, st);
 }
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
-                        const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
-                        hipStream_t st) {
-    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, st);
+                        const float* jitter, const float* Kdense, float* Lop, float* UHB, int* info, int Bt, int N, int Np,
+                        int n, int C, hipStream_t st) {
+    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C, st);
 }
 
 // Called by bcbf_refit_mfma_f64 / _f32 for batches.
