@@ -378,7 +378,8 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     bool pair = Bt <= 1024 && Np <= 256;
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     // A team of eight waves per instance (refit_wave64.hip: one chain wave, seven bulk waves; one workgroup per CU at a
-    // time) while ONE round of workgroups holds the batch, two rounds from N = 512 on -- measured on 256 CUs
+    // time) while ONE round of workgroups holds the batch, two rounds from N = 512 on, four from 1024 (1024 x 1024 fp32: 6.57 / 6.90)
+    // -- measured on 256 CUs
     // (tools/check_refit_team.py, ms team / best other form), fp32: 1 x 512: 0.27 / 0.71, 256 x 512: 0.30 / 0.86, 512 x 512:
     // 0.61 / 0.93, 1024 x 512: 1.22 / 1.04, 1 x 1024: 1.31 / 2.81, 512 x 1024: 3.32 / 5.89, 256 x 256: 0.108 / 0.140,
     // 512 x 256: 0.21 / 0.16, 256 x 128: 0.047 / 0.045; fp64: 1 x 512: 0.43 / 0.90, 256 x 512: 0.52 / 1.12, 512 x 512:
@@ -391,7 +392,7 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
         (void)hipDeviceGetAttribute(&c_, hipDeviceAttributeMultiprocessorCount, dev_);
         cus_ = c_ > 0 ? c_ : 256;
     }
-    bool team = Np / NB <= 64 && ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_));
+    bool team = Np / NB <= 64 && ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
     if (getenv("BCBF_REFIT_WAVE") || getenv("BCBF_REFIT_PAIR")) team = false;      // (another form is being forced)
     if (const char* e = getenv("BCBF_REFIT_TEAM")) team = e[0] == '1' && Np / NB <= 64;
     if (team && !Ldense) {
