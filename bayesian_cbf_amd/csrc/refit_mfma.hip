@@ -348,8 +348,8 @@ int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const 
 
 
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
-                        const float* jitter, const float* Kdense, float* Lop, float* UHB, int* info, int Bt, int N, int Np,
-                        int n, int C, hipStream_t st);                                 // refit_wave64.hip: a team of eight waves per instance
+                        const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N,
+                        int Np, int n, int C, hipStream_t st);                         // refit_wave64.hip: a team of eight waves per instance
 
 }  // namespace bcbf
 
@@ -390,12 +390,12 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     bool team = Np / NB <= 64 && ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
     if (getenv("BCBF_REFIT_WAVE") || getenv("BCBF_REFIT_PAIR")) team = false;      // (another form is being forced)
     if (const char* e = getenv("BCBF_REFIT_TEAM")) team = e[0] == '1' && Np / NB <= 64;
-    if (team && !Ldense) {
+    if (team) {
         if (!Kdense) {
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
             if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
         }
-        launch_refit_team32(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, m + 1, st);
+        launch_refit_team32(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);
         return check_launch("refit_team32");
     }
     if (pair && !Kdense && !Ldense) {

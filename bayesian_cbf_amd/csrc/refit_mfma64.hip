@@ -341,8 +341,8 @@ int launch_refit_pair64(const double* X, const double* UH, const double* Bm, con
 
 
 int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
-                        const double* jitter, const double* Kdense, double* Lop, double* UHB, int* info, int Bt, int N, int Np,
-                        int n, int C, hipStream_t st);                                 // refit_wave64.hip: a team of eight waves per instance
+                        const double* jitter, const double* Kdense, double* Lop, double* UHB, double* Ldense, int* info, int Bt, int N,
+                        int Np, int n, int C, hipStream_t st);                         // refit_wave64.hip: a team of eight waves per instance
 
 }  // namespace bcbf
 
@@ -395,12 +395,12 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     bool team = Np / NB <= 64 && ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
     if (getenv("BCBF_REFIT_WAVE") || getenv("BCBF_REFIT_PAIR")) team = false;      // (another form is being forced)
     if (const char* e = getenv("BCBF_REFIT_TEAM")) team = e[0] == '1' && Np / NB <= 64;
-    if (team && !Ldense) {
+    if (team) {
         if (!Kdense) {
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
             if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
         }
-        launch_refit_team64(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, m + 1, st);
+        launch_refit_team64(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);
         return check_launch("refit_team64");
     }
     if (pair && !Kdense && !Ldense) {

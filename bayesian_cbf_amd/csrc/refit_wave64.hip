@@ -1160,8 +1160,8 @@ template <typename T, int NW, bool FROM_DENSE>
 __global__ void __launch_bounds__(64 * NW, 1)
 refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
-                   const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt,
-                   int N, int Np, int n, int C) {
+                   const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout, T* __restrict__ Ldense,
+                   int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
     using P = RW<T>;
     using acc_t = typename P::acc_t;
@@ -1176,6 +1176,7 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     const T* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
     const T* UHb = FROM_DENSE ? nullptr : UH + (size_t)b * N * C;
     const T* Kb = FROM_DENSE ? Kdense + (size_t)b * N * N : nullptr;
+    T* Ld = Ldense ? Ldense + (size_t)b * N * N : nullptr;          // dense L on request (zeros above the diagonal)
     const int nblk = Np / NB;
     {   // UH B rows (all waves), the hand-off words
         if constexpr (!FROM_DENSE) {
@@ -1189,6 +1190,8 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     UHBout[((size_t)b * N + i) * C + c] = s;
                 }
         }
+        if (Ld)
+            for (int e = threadIdx.x; e < N * N; e += 64 * NW) { const int i = e / N, j = e - i * N; if (j > i) Ld[e] = T(0.0); }
         if (threadIdx.x == 0) { sp.inv_ready = 0; sp.inv_global = 0; sp.fail = 0; }
         for (int i = threadIdx.x; i < RT_MAXBLK; i += 64 * NW) sp.pdone[i] = 0;
         rw_pack_table(sp.pack_rc, threadIdx.x, 64 * NW);
@@ -1413,8 +1416,11 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) acc[cb][ib] = -acc[cb][ib];
-            const int bad = diag_factor_invert_acc<T>(BCBF_LDS_TILE(T, sp.d), acc, lane, false);
+            const int bad = diag_factor_invert_acc<T>(BCBF_LDS_TILE(T, sp.d), acc, lane, Ld != nullptr);
             if (bad != 0 && col0 + bad <= N) fail = col0 + bad;
+            if (Ld && lane < NB && col0 + lane < N) {
+                for (int c = 0; c <= lane; ++c) if (col0 + c < N) Ld[(size_t)(col0 + lane) * N + col0 + c] = sp.d.tile[lane][c];
+            }
             if (fail != 0) {
                 if (lane == 0) __hip_atomic_store(&sp.fail, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;                                             // (every waiter polls the flag)
@@ -1508,8 +1514,13 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * cbp + P::midx(r, g);
                     T2 v; v.x = y[0][r]; v.y = y[1][r];
-                    *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + irow) = v;
+                    *reinterpret_cast<T2*>(lop + lop_base<V>(col0 + c, Np) + irow) = v;
+                    if (Ld && col0 + c < N) {
+                        if (irow < N) Ld[(size_t)irow * N + col0 + c] = v.x;
+                        if (irow + 1 < N) Ld[(size_t)(irow + 1) * N + col0 + c] = v.y;
+                    }
                 }
             }
             publish(&sp.pdone[I], J + 1);
@@ -1519,23 +1530,23 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
 template <typename T>
 static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, const T* Kdense,
-                             T* Lop, T* UHB, int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+                             T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
     if (Np / NB > RT_MAXBLK) return -1;
     if (Kdense)
-        hipLaunchKernelGGL((refit_team_kernel<T, 8, true>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C);
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, true>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
     else
-        hipLaunchKernelGGL((refit_team_kernel<T, 8, false>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C);
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, false>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
     return 0;
 }
 int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
-                        const double* jitter, const double* Kdense, double* Lop, double* UHB, int* info, int Bt, int N, int Np,
-                        int n, int C, hipStream_t st) {
-    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C, st);
+                        const double* jitter, const double* Kdense, double* Lop, double* UHB, double* Ldense, int* info, int Bt, int N,
+                        int Np, int n, int C, hipStream_t st) {
+    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, st);
 }
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
-                        const float* jitter, const float* Kdense, float* Lop, float* UHB, int* info, int Bt, int N, int Np,
-                        int n, int C, hipStream_t st) {
-    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, info, Bt, N, Np, n, C, st);
+                        const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N,
+                        int Np, int n, int C, hipStream_t st) {
+    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, st);
 }
 
 // Called by bcbf_refit_mfma_f64 / _f32 for batches.
