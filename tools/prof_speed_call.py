@@ -3,9 +3,13 @@ import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExact, ControlAffineRegressorVector
-from tools.bench_speed_test import pendulum_data
+import math
+from bayesian_cbf_amd.pendulum import PendulumDynamicsModel, ControlRandom, sampling_pendulum_data
 from torch.profiler import profile, ProfilerActivity
-X, U, dX = pendulum_data()
+torch.manual_seed(0)
+dX, X, U = (a.numpy() for a in sampling_pendulum_data(PendulumDynamicsModel(m=1, n=2), D=2000, dt=0.01,
+                                                       x0=torch.tensor([5 * math.pi / 6, -0.01]),
+                                                       controller=ControlRandom(mass=1, gravity=10, length=1).control))
 for cls in (ControlAffineRegressorExact, ControlAffineRegressorVector):
     for N in (256, 512):
         idx = np.random.default_rng(1).permutation(len(X) - 1)[:N]
