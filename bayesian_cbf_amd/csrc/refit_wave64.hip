@@ -1211,7 +1211,7 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     };
     auto failed = [&]() { return __hip_atomic_load(&sp.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
 
-    // ---- what both waves do to a tile: kernel values, the update stream (each on its own registers and its own column
+    // ---- what every wave does to a tile: kernel values, the update stream (each on its own registers and its own column
     //      block in LDS)
     const T* UHBb = FROM_DENSE ? nullptr : UHBout + (size_t)b * N * C;
     // (registers: the first four state components only -- no reference system has more; wider states take the slow
@@ -1226,8 +1226,7 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         const_cast<T*>((!FROM_DENSE && jitter) ? jitter + (size_t)b * N : Lop), 0, (!FROM_DENSE && jitter) ? N * ES : 0, 0x00020000);
     auto& cX = sp.colX[wave];
     auto& cU = sp.colUH[wave];
-    // a column block's inputs, zero-filled to fixed widths: loads ISSUED early (into registers, out-of-range offsets read
-    // as zero), written to LDS when the previous block's values are done -- the round trip hides under other work
+    // a column block's inputs, zero-filled to fixed widths (out-of-range offsets read as zero), through registers into LDS
     const __amdgpu_buffer_rsrc_t rsUH = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(FROM_DENSE ? Lop : UHb), 0, FROM_DENSE ? 0 : N * C * ES, 0x00020000);
     constexpr int SX = NB * BCBF_MAX_STATE_DIM / 64, SU = NB * (BCBF_MAX_CTRL_DIM + 1) / 64;
     T sx[SX], su[SU];
@@ -1245,9 +1244,6 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             su[t] = P::bload(rsUH, (col0 + c < N && a < C) ? ((col0 + c) * C + a) * ES : -ES);
         }
     };
-    // (fp32 only: in fp64 the 48 registers that stay live across the inverse copy / the column fence spill -- 320 B of
-    //  scratch against 104 -- and the kernel is slower for it; there a column's inputs are fetched where they are used)
-    constexpr bool EARLY = false;                      // (a column's inputs are fetched where they are used)
     auto stage_commit = [&]() {
         if (FROM_DENSE) return;
         __builtin_amdgcn_wave_barrier();                           // every lane is done with the previous column block
