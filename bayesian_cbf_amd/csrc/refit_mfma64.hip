@@ -342,7 +342,7 @@ int launch_refit_pair64(const double* X, const double* UH, const double* Bm, con
 
 int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                         const double* jitter, const double* Kdense, double* Lop, double* UHB, double* Ldense, int* info, int Bt, int N,
-                        int Np, int n, int C, hipStream_t st);                         // refit_wave64.hip: a team of eight waves per instance
+                        int Np, int n, int C, int nw, hipStream_t st);                 // refit_wave64.hip: a team of eight (four) waves per instance
 
 }  // namespace bcbf
 
@@ -365,7 +365,7 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     // instance's update stream.  (The 4-column-blocked diagonal tile of the per-wave form was also tried here for wave 0:
     // it needs ~100 more registers than this kernel's 256 budget leaves, spills, and is 7 % slower than the 32-step
     // form below.)
-    bool per_wave = Bt >= 1024 || (Bt >= 512 && Np <= 256) || (Bt >= 64 && Np <= 128);
+    bool per_wave = Bt >= 1024 || (Bt >= 512 && Np <= 512) || (Bt >= 64 && Np <= 128);
     if (const char* e = getenv("BCBF_REFIT_WAVE")) per_wave = e[0] == '1';
     // Two waves per instance (refit_wave64.hip, round 3: the serial chain of diagonal tiles on one wave, every other tile on
     // the other) wins for small systems while one round of workgroups holds the batch -- measured (tools/bench_refit_forms.py,
@@ -393,14 +393,18 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
         cus_ = c_ > 0 ? c_ : 256;
     }
     bool team = Np / NB <= 64 && ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
+    // ... of four waves (two workgroups per CU) for cus < batch <= 2 cus at 256 <= N <= 512: 512 x 256 fp64 0.259 (two waves per
+    // instance) / 0.210, fp32 0.162 / 0.136; 512 x 512 fp32 0.62 (team of eight, two rounds) / 0.53
+    int team_nw = 8;
+    if (Np / NB <= 16 && Np >= 256 && Bt > cus_ && Bt <= 2 * cus_ && !Kdense) { team = true; team_nw = 4; }
     if (getenv("BCBF_REFIT_WAVE") || getenv("BCBF_REFIT_PAIR")) team = false;      // (another form is being forced)
-    if (const char* e = getenv("BCBF_REFIT_TEAM")) team = e[0] == '1' && Np / NB <= 64;
+    if (const char* e = getenv("BCBF_REFIT_TEAM")) { team = e[0] == '1' && Np / NB <= 64; if (e[0] == '1' && e[1] == '4') team_nw = 4; else if (e[0] == '1' && e[1] == '8') team_nw = 8; }
     if (team) {
         if (!Kdense) {
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
             if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
         }
-        launch_refit_team64(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, st);
+        launch_refit_team64(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, team_nw, st);
         return check_launch("refit_team64");
     }
     if (pair && !Kdense && !Ldense) {

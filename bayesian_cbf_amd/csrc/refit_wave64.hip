@@ -1141,7 +1141,7 @@ int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const 
 // hand-off is per BLOCK ROW: pdone[I] counts the columns whose L_IJ is complete (it only ever grows: L_{I,J+1} is started
 // by a wave that has seen L_IJ).  Bulk wave 0 (the tile the chain continues on) takes inv(L_JJ) out of LDS as in the
 // two-wave kernel; the others may be columns behind and read the copy in global memory, behind a second counter.
-// One workgroup of NW = 8 waves per instance: two waves per SIMD, 256 registers each, one instance per CU -- the form
+// One workgroup of NW = 8 waves per instance (NW = 4: two instances per CU): two waves per SIMD, 256 registers each -- the form
 // for a handful of systems of N >= 512 (the facade's fit / clear_cache refits of ONE model), where the workgroup form
 // leaves three of its four waves waiting on the diagonal tile.
 constexpr int RT_MAXBLK = 64;          // block columns the team form handles (N <= 2048)
@@ -1157,7 +1157,7 @@ template <typename T, int NW> struct RTShared {
 };
 
 template <typename T, int NW, bool FROM_DENSE>
-__global__ void __launch_bounds__(64 * NW, 1)
+__global__ void __launch_bounds__(64 * NW, 8 / NW)
 refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
                    const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout, T* __restrict__ Ldense,
@@ -1526,8 +1526,14 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
 template <typename T>
 static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, const T* Kdense,
-                             T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
+                             T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, int nw, hipStream_t st) {
     if (Np / NB > RT_MAXBLK) return -1;
+    // four waves per instance (two workgroups per CU) when the batch needs more than one workgroup per CU but not more than
+    // two: 512 x 256 fp64 0.259 (two waves per instance) / 0.330 (team of eight, two rounds) / 0.210 ms
+    if (nw == 4 && !Kdense) {
+        hipLaunchKernelGGL((refit_team_kernel<T, 4, false>), dim3(Bt), dim3(256), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        return 0;
+    }
     if (Kdense)
         hipLaunchKernelGGL((refit_team_kernel<T, 8, true>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
     else
@@ -1536,13 +1542,13 @@ static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell,
 }
 int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                         const double* jitter, const double* Kdense, double* Lop, double* UHB, double* Ldense, int* info, int Bt, int N,
-                        int Np, int n, int C, hipStream_t st) {
-    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, st);
+                        int Np, int n, int C, int nw, hipStream_t st) {
+    return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, nw, st);
 }
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                         const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N,
-                        int Np, int n, int C, hipStream_t st) {
-    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, st);
+                        int Np, int n, int C, int nw, hipStream_t st) {
+    return launch_refit_team<float>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, nw, st);
 }
 
 // Called by bcbf_refit_mfma_f64 / _f32 for batches.

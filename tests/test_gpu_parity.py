@@ -875,11 +875,12 @@ def test_refit_one_wave_per_instance_vs_oracle_and_workgroup_form(ops, N, n, m, 
 @pytest.mark.parametrize("form,Bt,N,n,m", [("pair", 1, 1, 2, 1), ("pair", 70, 31, 3, 2), ("pair", 70, 33, 3, 2), ("pair", 3, 100, 6, 3),
                                           ("pair", 70, 256, 2, 1), ("pair", 9, 500, 3, 2),
                                           ("team", 1, 1, 2, 1), ("team", 7, 33, 3, 2), ("team", 3, 100, 6, 3), ("team", 9, 500, 3, 2),
-                                          ("team", 2, 1000, 3, 3), ("team", 1, 2048, 3, 2)])
+                                          ("team", 2, 1000, 3, 3), ("team", 1, 2048, 3, 2),
+                                          ("team4", 7, 33, 3, 2), ("team4", 5, 300, 6, 3), ("team4", 2, 500, 3, 2)])
 def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt, N, n, m, dtype, monkeypatch):
     """The chain + bulk forms of the refit (refit_wave64.hip: a chain wave that factors and inverts the diagonal tiles on the
-    matrix cores; `pair`: one bulk wave a block column behind, N <= 512; `team`: seven bulk waves sharing a column's
-    tiles, hand-offs per block row, N <= 2048; no dense output) forced by BCBF_REFIT_PAIR=1 / BCBF_REFIT_TEAM=1 against the
+    matrix cores; `pair`: one bulk wave a block column behind, N <= 512; `team` / `team4`: seven / three bulk waves sharing a
+    column's tiles, hand-offs per block row, N <= 2048) forced by BCBF_REFIT_PAIR=1 / BCBF_REFIT_TEAM=1 against the
     one-wave form on the same inputs -- packed operator incl. both copies of the inverted diagonal blocks, UH*B,
     per-instance failure index (a failed pivot in one instance) -- and, through potrs + the posterior kernel, against the
     oracle.  Shapes: one row, a ragged last block, a state wider than the registers hold (n = 6), the largest systems of
@@ -900,7 +901,7 @@ def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt,
         monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
         monkeypatch.setenv("BCBF_REFIT_PAIR", "1")
     else:
-        monkeypatch.setenv("BCBF_REFIT_TEAM", "1")
+        monkeypatch.setenv("BCBF_REFIT_TEAM", "14" if form == "team4" else "18")   # (four / eight waves per instance)
     Lop_p, UHB_p, info_p, _ = ops.refit(*args)
     monkeypatch.setenv("BCBF_REFIT_TEAM", "0")
     monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
