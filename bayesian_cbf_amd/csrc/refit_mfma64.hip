@@ -384,7 +384,7 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     // 0.61 / 0.93, 1024 x 512: 1.22 / 1.04, 1 x 1024: 1.31 / 2.81, 512 x 1024: 3.32 / 5.89, 256 x 256: 0.108 / 0.140,
     // 512 x 256: 0.21 / 0.16, 256 x 128: 0.047 / 0.045; fp64: 1 x 512: 0.43 / 0.90, 256 x 512: 0.52 / 1.12, 512 x 512:
     // 1.04 / 1.55, 1 x 1024: 2.31 / 3.57, 1 x 2048: 16.8 / 19.3, 256 x 256: 0.173 / 0.219.  BCBF_REFIT_TEAM=0/1 forces the
-    // choice (N <= 2048)
+    // choice (N <= 8192)
     static int cus_ = 0;
     if (cus_ == 0) {
         int dev_ = 0, c_ = 256;
@@ -392,13 +392,14 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
         (void)hipDeviceGetAttribute(&c_, hipDeviceAttributeMultiprocessorCount, dev_);
         cus_ = c_ > 0 ? c_ : 256;
     }
-    bool team = Np / NB <= 64 && ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
+    bool team = Np / NB <= 64 &&       // (N <= 2048: beyond, no better than the workgroup form -- 1 x 4096 fp64: 128 / 125 ms)
+                ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
     // ... of four waves (two workgroups per CU) for cus < batch <= 2 cus at 256 <= N <= 512: 512 x 256 fp64 0.259 (two waves per
     // instance) / 0.210, fp32 0.162 / 0.136; 512 x 512 fp32 0.62 (team of eight, two rounds) / 0.53
     int team_nw = 8;
     if (Np / NB <= 16 && Np >= 256 && Bt > cus_ && Bt <= 2 * cus_ && !Kdense) { team = true; team_nw = 4; }
     if (getenv("BCBF_REFIT_WAVE") || getenv("BCBF_REFIT_PAIR")) team = false;      // (another form is being forced)
-    if (const char* e = getenv("BCBF_REFIT_TEAM")) { team = e[0] == '1' && Np / NB <= 64; if (e[0] == '1' && e[1] == '4') team_nw = 4; else if (e[0] == '1' && e[1] == '8') team_nw = 8; }
+    if (const char* e = getenv("BCBF_REFIT_TEAM")) { team = e[0] == '1' && Np / NB <= 256; if (e[0] == '1' && e[1] == '4') team_nw = 4; else if (e[0] == '1' && e[1] == '8') team_nw = 8; }
     if (team) {
         if (!Kdense) {
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;

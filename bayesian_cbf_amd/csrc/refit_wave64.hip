@@ -1144,7 +1144,7 @@ int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const 
 // One workgroup of NW = 8 waves per instance (NW = 4: two instances per CU): two waves per SIMD, 256 registers each -- the form
 // for a handful of systems of N >= 512 (the facade's fit / clear_cache refits of ONE model), where the workgroup form
 // leaves three of its four waves waiting on the diagonal tile.
-constexpr int RT_MAXBLK = 64;          // block columns the team form handles (N <= 2048)
+constexpr int RT_MAXBLK = 256;         // block columns the team form handles (N <= 8192)
 template <typename T, int NW> struct RTShared {
     DiagTile<T> d;                            // wave 0's
     T colX[NW][NB][BCBF_MAX_STATE_DIM];       // [wave]: each wave stages the column block it is forming values for
