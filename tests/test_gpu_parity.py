@@ -927,6 +927,43 @@ def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt,
         rel_close(host(Bk)[i], Bk_o[0], 1e-8 if f64 else 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
 
 
+@pytest.mark.timeout(180)
+def test_refit_handoff_protocols_soak(ops, monkeypatch):
+    """The chain / bulk refit kernels hand work over through spin waits on LDS counters; a lost wake-up would be a hang.
+    A few hundred synchronised launches over random shapes, precisions, forms (library's choice, two waves, team of eight /
+    four, one wave), dense outputs and failed pivots in random places (the long version: tools/stress_refit.py); every
+    launch must come back, and the failure index must not depend on the form."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    rng = np.random.default_rng(7)
+    forms = {"default": {}, "pair": {"BCBF_REFIT_WAVE": "1", "BCBF_REFIT_PAIR": "1"}, "team8": {"BCBF_REFIT_TEAM": "18"},
+             "team4": {"BCBF_REFIT_TEAM": "14"}, "wave": {"BCBF_REFIT_WAVE": "1", "BCBF_REFIT_PAIR": "0"}}
+    launches = 0
+    for _ in range(40):
+        dtype = torch.float64 if rng.random() < 0.5 else torch.float32
+        N = int(rng.choice([1, 31, 33, 100, 256, 300, 512]))
+        Bt = int(rng.choice([1, 2, 7, 64, 300, 513]))
+        n, m = [(2, 1), (3, 2), (6, 3)][int(rng.integers(3))]
+        p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=int(rng.integers(1000)))
+        jit = p["jitter"].clone()
+        for _k in range(int(rng.integers(0, 3))):
+            jit[int(rng.integers(Bt)), int(rng.integers(N))] = -10.0
+        infos = {}
+        for name, env in forms.items():
+            for k in ("BCBF_REFIT_TEAM", "BCBF_REFIT_WAVE", "BCBF_REFIT_PAIR"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for _rep in range(2):
+                _, _, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, want_dense=bool(rng.random() < 0.2 and N <= 300))
+                torch.cuda.synchronize()
+                launches += 1
+            infos[name] = info.cpu().numpy()
+        if dtype == torch.float64:              # (fp32: a pivot at rounding level may fail in one form and not in another)
+            for name in forms:
+                assert np.array_equal(infos[name], infos["wave"]), (name, N, Bt)
+    assert launches == 400
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("K", [5, 7])
 def test_programs_with_more_than_four_cones_vs_oracle(ops, dtype, K):
