@@ -40,7 +40,8 @@ for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_par
         print(a, round(d["value"]), round(d["ms_per_step"], 4), "frac", round(rf["frac"], 4), "kernel_ms", round(rf["kernel_ms"], 4),
               "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
 for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "online_growth_f64_unfused.json", "online_growth_f64_unfused3.json", "online_growth_f64_packed.json", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
-          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt"):
+          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt", "pmc_traffic_refit.json",
+          "refit_pair_timeline.txt"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
         shutil.copy(SRC + a, DST + a)
 

@@ -52,6 +52,7 @@ python tools/bench_speed_test_unicycle.py --quick 2>/dev/null > $O/speed_test_un
 python tools/learn_dynamics_matrix_vector.py /tmp/learn_matrix_vector > /dev/null 2>&1; cp gpurun_out/learn_matrix_vector.jsonl $O/ 2>/dev/null
 python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -1 > $O/mc_rollouts.txt
 python examples_mc_rollouts.py --trajectories 32768 2>/dev/null | tail -1 >> $O/mc_rollouts.txt
+bash tools/run_pmc_refit_traffic.sh $R > /dev/null 2>&1      # refit traffic past L2 -> $O/pmc_traffic_refit.json
 du -sh $O; ls $O | head -50
 # keep the merge small: the raw traces are not needed, only the csv summaries
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*_kernel_trace.csv" -size +2M -delete 2>/dev/null
