@@ -400,13 +400,13 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
             if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
         }
-        launch_refit_team32(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, team_nw, st);
+        if (launch_refit_team32(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, m + 1, team_nw, st) != 0) return BCBF_EINVAL;       // a size the form does not address
         return check_launch("refit_team32");
     }
     if (pair && !Kdense && !Ldense) {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
-        launch_refit_pair32(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st);
+        if (launch_refit_pair32(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st) != 0) return BCBF_EINVAL;       // a size the form does not address
         return check_launch("refit_pair32");
     }
     if (per_wave) {

@@ -1120,6 +1120,7 @@ template <typename T>
 static int launch_refit_pair(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, T* Lop, T* UHB,
                               int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
     if (Np / NB > RA_MAXBLK) return -1;
+    if ((unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;    // 32-bit byte offsets
     hipLaunchKernelGGL((refit_pair_kernel<T>), dim3(Bt), dim3(128), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C);
     return 0;
 }
@@ -1528,6 +1529,8 @@ template <typename T>
 static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, const T* Kdense,
                              T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, int nw, hipStream_t st) {
     if (Np / NB > RT_MAXBLK) return -1;
+    // the kernel addresses one instance's operator with 32-bit byte offsets (buffer resource size, scalar + lane offsets)
+    if ((unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;
     // four waves per instance (two workgroups per CU) when the batch needs more than one workgroup per CU but not more than
     // two: 512 x 256 fp64 0.259 (two waves per instance) / 0.330 (team of eight, two rounds) / 0.210 ms
     if (nw == 4 && !Kdense) {

@@ -43,22 +43,108 @@ def reduce_rollout_stats(collisions, min_h, cost_sum, solver_failures, count):
 # One launcher for every multi-GPU harness (bench.py = config 3, examples_mc_rollouts.py = config 4,
 # tools/bench_online.py = config 5): `python <script> --gpus N` starts N ranks itself, or runs as one rank of an external
 # `python -m torch.distributed.run ... <script> --gpus N`.
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _visible_list():
+    """Entries of the runtime's device filter, or None when there is none (HIP / ROCr / the CUDA spelling torch honours)."""
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(k)
+        if v is not None:
+            return [e for e in v.split(",") if e.strip() != ""]
+    return None
+
+
+def visible_gpu_count(nodes_dir=None, dev_dir="/dev"):
+    """(count, how): GPUs this user can open, WITHOUT a HIP / HSA call in this process.
+
+    1. the kernel driver's topology in sysfs: a node of /sys/class/kfd/kfd/topology/nodes/*/properties with
+       `simd_count` > 0 is a GPU (CPU nodes carry 0); it counts when its render node /dev/dri/renderD<drm_render_minor>
+       and /dev/kfd are accessible to this user; narrowed by the *_VISIBLE_DEVICES filter;
+    2. where sysfs is not there (containers that only pass /dev/kfd through): a short-lived CHILD python that prints
+       `torch.cuda.device_count()` and exits -- whatever the runtime does in there dies with it.
+    Never `torch.cuda.device_count()` in this process: without amdsmi it falls back to hipGetDeviceCount, which brings
+    the runtime up in a parent that is about to start the ranks."""
+    n = None
+    try:
+        n = 0
+        nodes_dir = nodes_dir or KFD_NODES
+        for node in sorted(os.listdir(nodes_dir)):
+            with open(os.path.join(nodes_dir, node, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            # a container / cgroup may expose fewer devices than the host's topology lists: count a GPU only when its
+            # render node is there and this user may open it (an access() check, not an open())
+            minor = int(props.get("drm_render_minor", "-1"))
+            if minor >= 0 and not os.access(os.path.join(dev_dir, "dri", "renderD%d" % minor), os.R_OK | os.W_OK):
+                continue
+            n += 1
+        if not os.access(os.path.join(dev_dir, "kfd"), os.R_OK | os.W_OK):
+            n = 0
+        how = "sysfs"
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                 capture_output=True, text=True, timeout=600)
+            n, how = int(out.stdout.strip().splitlines()[-1]), "child"
+        except Exception:
+            return 0, "unknown"
+        return n, how                      # (the child applied the *_VISIBLE_DEVICES filter itself)
+    vis = _visible_list()
+    if vis is not None:
+        n = min(n, len(vis))
+    return n, how
+
+
+def open_gpu_descriptors():
+    """Targets of this process's open descriptors that belong to the GPU driver (/dev/kfd, /dev/dri/renderD*): empty as
+    long as nothing has initialised the runtime here."""
+    out = []
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                tgt = os.readlink("/proc/self/fd/" + fd)
+            except OSError:
+                continue
+            if tgt == "/dev/kfd" or tgt.startswith("/dev/dri/renderD"):
+                out.append(tgt)
+    except OSError:
+        pass
+    return out
+
+
 def launch_ranks(script, argv, gpus):
     """Start `gpus` ranks of `script argv` (one process per GPU) under torch.distributed.run as a CHILD process and return
-    its exit code.  The calling parent never touches the GPU (no HIP call before or after; counting devices does not
-    initialise the runtime) and never replaces itself (no exec).  Refuses (exit code 2) when fewer GPUs are visible,
-    unless BCBF_BENCH_SINGLE_DEVICE=1 (test hook: every rank on cuda:0)."""
+    its exit code.  The calling parent never touches the GPU -- devices are counted from sysfs or by a throw-away child
+    (`visible_gpu_count`), there is no HIP call before or after -- and never replaces itself (no exec).  Refuses (exit
+    code 2) when fewer GPUs are visible, unless BCBF_BENCH_SINGLE_DEVICE=1 (test hook: every rank on cuda:0), and (exit
+    code 3) when this process already holds the GPU driver open: the ranks must be children of a clean parent.
+    BCBF_LAUNCH_REPORT=<path>: what the parent saw at the moment it spawned, as JSON (tests)."""
+    have, how = None, "not counted (BCBF_BENCH_SINGLE_DEVICE=1)"
     if os.environ.get("BCBF_BENCH_SINGLE_DEVICE") != "1":
-        have = torch.cuda.device_count()
+        have, how = visible_gpu_count()
         if have < gpus:
-            sys.stderr.write("%s: --gpus %d but only %d GPU(s) visible\n" % (os.path.basename(script), gpus, have))
+            sys.stderr.write("%s: --gpus %d but only %d GPU(s) visible (%s)\n" % (os.path.basename(script), gpus, have, how))
             return 2
+    held = open_gpu_descriptors()
+    if held:
+        sys.stderr.write("%s: the launcher process has the GPU driver open (%s); start the ranks from a process that has "
+                         "not initialised HIP\n" % (os.path.basename(script), ", ".join(sorted(set(held)))))
+        return 3
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script)] + list(argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rep = os.environ.get("BCBF_LAUNCH_REPORT")
+    if rep:
+        import json
+        with open(rep, "w") as fh:
+            json.dump(dict(pid=os.getpid(), gpus=gpus, counted=have, how=how, gpu_descriptors=held, cmd=cmd), fh)
     return subprocess.run(cmd, env=env).returncode
 
 

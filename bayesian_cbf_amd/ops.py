@@ -262,15 +262,18 @@ _MLL_WORK = {}
 
 
 def _mll_work(Bt, N, m, device):
-    """Workspace of bcbf_mll_grad's split form (partial sums; reused between the iterations of a fit)."""
+    """Workspace of bcbf_mll_grad's split form (partial sums; reused between the iterations of a fit).  One buffer per
+    (device, HIP stream): fits on different streams / threads never share partial sums, and a buffer is only ever
+    replaced by a LARGER one on its own stream, where stream order puts the free behind the launches that read it (the
+    launches go through ctypes, so torch's allocator sees no other stream using the block)."""
     nbytes = int(lib.bcbf_mll_grad_work_bytes(Bt, N, m))
     if nbytes == 0:
         return None
-    key = (str(device), nbytes)
-    if key not in _MLL_WORK:
-        _MLL_WORK.clear()
-        _MLL_WORK[key] = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
-    return _MLL_WORK[key]
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    buf = _MLL_WORK.get(key)
+    if buf is None or buf.numel() * 8 < nbytes:
+        buf = _MLL_WORK[key] = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+    return buf
 
 
 def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None):

@@ -68,12 +68,20 @@ def parse():
                          "`batch` closed loops (Monte-Carlo rollouts, BASELINE configs[3]; matrix-core bound)")
     ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default): this file's headline workload.  c4 / c5: the Monte-Carlo rollouts / online growth "
-                         "harnesses (examples_mc_rollouts.py, tools/bench_online.py) with the same --gpus N launcher; flags "
-                         "this parser does not know are passed on to them")
-    args, rest = ap.parse_known_args()
-    if args.config == "c3" and rest:
-        ap.error("unrecognized arguments: %s" % " ".join(rest))
-    args.rest = rest
+                         "harnesses (examples_mc_rollouts.py, tools/bench_online.py) with the same --gpus N launcher: "
+                         "EVERY other flag on the command line (also --steps / --batch / --dtype ...) goes to that harness "
+                         "untouched and means what the harness says it means")
+    # c4 / c5: only --config and --gpus are this file's; the rest of the command line is the harness's own (a shared
+    # flag name such as --steps or --batch must not be swallowed here and replaced by the harness default)
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--config", choices=["c3", "c4", "c5"], default="c3")
+    pre.add_argument("--gpus", type=int, default=1)
+    pargs, rest = pre.parse_known_args()
+    if pargs.config != "c3":
+        pargs.rest = rest
+        return pargs
+    args = ap.parse_args()
+    args.rest = []
     return args
 
 
@@ -199,7 +207,8 @@ def main():
     args = parse()
     if args.config != "c3":
         return run_other_config(args)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # BCBF_BENCH_FORCE_LAUNCH=1 (test hook): also a one-GPU run goes through the launcher parent -> child rank path
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and "WORLD_SIZE" in os.environ:

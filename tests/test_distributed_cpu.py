@@ -62,3 +62,86 @@ def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
         res = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"] + extra, env=env, capture_output=True,
                              text=True, timeout=300)
         assert res.returncode == 2 and "only" in res.stderr, (script, extra, res.returncode, res.stderr[-500:])
+
+
+def _fake_topology(tmp_path, simd_counts, minors, present_minors, kfd=True):
+    nodes = tmp_path / "nodes"
+    dev = tmp_path / "dev"
+    (dev / "dri").mkdir(parents=True)
+    if kfd:
+        (dev / "kfd").write_text("")
+    for m in present_minors:
+        (dev / "dri" / ("renderD%d" % m)).write_text("")
+    for i, (sc, mn) in enumerate(zip(simd_counts, minors)):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n" % (0 if sc else 64, sc, mn))
+    return str(nodes), str(dev)
+
+
+def test_visible_gpu_count_reads_the_driver_topology_not_hip(tmp_path, monkeypatch):
+    """The launcher parent counts GPUs from the kfd topology in sysfs: CPU nodes (simd_count 0) do not count, a GPU whose
+    render node this user cannot open does not count, the *_VISIBLE_DEVICES filter narrows, and torch.cuda is never asked."""
+    from bayesian_cbf_amd import distributed as D
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("HIP asked in the parent")))
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    nodes, dev = _fake_topology(tmp_path / "a", [0, 0, 1024, 1024, 1024], [-1, -1, 128, 129, 130], [128, 129, 130])
+    assert D.visible_gpu_count(nodes, dev) == (3, "sysfs")
+    nodes, dev = _fake_topology(tmp_path / "b", [0, 1024, 1024, 1024], [-1, 128, 129, 130], [129])      # one-GPU container
+    assert D.visible_gpu_count(nodes, dev) == (1, "sysfs")
+    nodes, dev = _fake_topology(tmp_path / "c", [0, 1024], [-1, 128], [128], kfd=False)
+    assert D.visible_gpu_count(nodes, dev) == (0, "sysfs")
+    nodes, dev = _fake_topology(tmp_path / "d", [1024] * 8, list(range(128, 136)), list(range(128, 136)))
+    assert D.visible_gpu_count(nodes, dev) == (8, "sysfs")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3")
+    assert D.visible_gpu_count(nodes, dev) == (2, "sysfs")
+
+
+_RANK_SCRIPT = """import os, sys
+print("rank %s of %s" % (os.environ["RANK"], os.environ["WORLD_SIZE"]), flush=True)
+"""
+
+_PARENT = """import json, os, sys
+sys.path.insert(0, %(root)r)
+from bayesian_cbf_amd import distributed as D
+D.visible_gpu_count = lambda *a: (2, "test")          # (this box has no GPU; the count is not what is under test)
+%(extra)s
+sys.exit(D.launch_ranks(%(script)r, [], 2))
+"""
+
+
+def test_launcher_parent_is_clean_when_it_spawns_and_refuses_when_it_is_not(tmp_path):
+    """The path an 8-GPU `bench.py --gpus 8` takes: the parent process spawns torch.distributed.run as a child while
+    holding NO descriptor of the GPU driver (/dev/kfd, /dev/dri/renderD*) -- recorded at the moment of the spawn -- and both
+    ranks run.  A parent that does hold one refuses with exit code 3 instead of starting ranks."""
+    import json
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rep = tmp_path / "report.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BCBF_BENCH_SINGLE_DEVICE")}
+    env["BCBF_LAUNCH_REPORT"] = str(rep)
+    res = subprocess.run([sys.executable, "-c", _PARENT % dict(root=ROOT, script=str(script), extra="")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "rank 0 of 2" in res.stdout and "rank 1 of 2" in res.stdout
+    r = json.loads(rep.read_text())
+    assert r["gpu_descriptors"] == [] and r["counted"] == 2 and r["gpus"] == 2
+    assert "torch.distributed.run" in r["cmd"] and "--master-addr" in r["cmd"] and "127.0.0.1" in r["cmd"]
+    rep.unlink()
+    dirty = "D.open_gpu_descriptors = lambda: ['/dev/kfd']"
+    res = subprocess.run([sys.executable, "-c", _PARENT % dict(root=ROOT, script=str(script), extra=dirty)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 3 and "GPU driver open" in res.stderr and not rep.exists() and "rank 0" not in res.stdout
+
+
+def test_open_gpu_descriptors_sees_a_held_device_node(tmp_path, monkeypatch):
+    """open_gpu_descriptors() really reads /proc/self/fd: a descriptor whose target is named like a render node shows up."""
+    from bayesian_cbf_amd import distributed as D
+    assert D.open_gpu_descriptors() == []
+    real = os.readlink
+    held = open(os.devnull)
+    monkeypatch.setattr(os, "readlink", lambda p: "/dev/dri/renderD128" if p.endswith("/%d" % held.fileno()) else real(p))
+    assert D.open_gpu_descriptors() == ["/dev/dri/renderD128"]
+    held.close()

@@ -94,6 +94,7 @@ def test_c4_rollouts_two_ranks_equal_one_rank_statistics():
     assert two["min_h"] > 0 and abs(two["trajectory_steps_per_s"] - 128 * 25 / two["seconds"]) < 1e-6 * two["trajectory_steps_per_s"]
     via_bench = _run_script("bench.py", ["--config", "c4", "--gpus", "2"] + args, TWO_RANKS_ONE_DEVICE)
     assert via_bench["n_gpus"] == 2 and via_bench["count"] == 128
+    assert via_bench["steps"] == 25 and via_bench["trajectories"] == 128      # flags bench.py also defines reach the harness
 
 
 def test_c5_online_growth_two_ranks():
@@ -108,3 +109,19 @@ def test_c5_online_growth_two_ranks():
     assert abs(two["instance_appends_per_s"] - 60 * 8 * 2 / two["seconds"]) < 1e-6 * two["instance_appends_per_s"]
     one = _run_script("bench.py", ["--config", "c5"] + args, {})
     assert one["n_gpus"] == 1 and one["comm"]["world_size"] == 1 and one["final_vs_refit"]["Mk"] < 1e-8
+    assert one["batch_per_gpu"] == 8 and [s["N_from"] for s in one["segments"]] == [40]     # --batch 8 was not swallowed
+    for s in two["segments"] + one["segments"]:
+        assert abs(s["step_ms"] - (s["append_ms"] + s["control_step_ms"])) < 1e-9
+
+
+def test_one_gpu_run_through_the_unhooked_launcher_parent(tmp_path):
+    """The path `bench.py --gpus 8` takes on an 8-GPU node, on the one GPU there is: NO single-device hook, so the parent
+    counts the devices itself (sysfs / throw-away child, never HIP in the parent), holds no descriptor of the GPU driver
+    when it spawns torch.distributed.run, and the child rank runs the bench over RCCL (world size 1)."""
+    rep = tmp_path / "launch.json"
+    out = _run(["--gpus", "1", "--cpu-sample", "0"], {"BCBF_BENCH_FORCE_LAUNCH": "1", "BCBF_BENCH_FORCE_DIST": "1",
+                                                      "BCBF_LAUNCH_REPORT": str(rep)})
+    r = json.loads(rep.read_text())
+    assert r["how"] in ("sysfs", "child") and r["counted"] >= 1 and r["gpu_descriptors"] == [] and r["gpus"] == 1
+    assert out["n_gpus"] == 1 and out["comm"]["backend"] == "rccl" and out["comm"]["world_size"] == 1
+    assert out["value"] > 0

@@ -48,7 +48,7 @@ for _ in range(a.repeat):
     fails = ctx.reduce_sum([out["append_failures"], out["refit_failures"]])
     if ctx.rank == 0:
         for s, (ta, tc) in zip(segs, v[:-1].tolist()):
-            s["append_ms"], s["control_step_ms"] = ta, tc
+            s["append_ms"], s["control_step_ms"], s["step_ms"] = ta, tc, ta + tc      # all three the slowest rank's
             s.pop("append_GBs_algorithmic", None)
         appends = (a.n1 - a.n0) * a.batch * ctx.world
         out.update(config="c5: online GP growth", n_gpus=ctx.world, batch_per_gpu=a.batch, scaling="weak", seconds=el,

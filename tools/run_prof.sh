@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8   # the setting bench.py gives itself; under rocprofv3 the runtime is up before Python runs
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 200 --warmup 10 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_shared -- python3 bench.py --regime shared --steps 50 --warmup 5 --cpu-sample 0 > gpurun_out/bench_shared_prof.json 2> gpurun_out/bench_shared_prof.err

@@ -2,6 +2,7 @@
 # Counters are collected in their own passes (--pmc + --kernel-trace only), as MI355X_MICROARCH.md prescribes.
 R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8   # the setting bench.py gives itself; under rocprofv3 the runtime is up before Python runs
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
