@@ -50,7 +50,8 @@ _TSIGS = {
     "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_jets": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
-    "bcbf_cbc2_terms": [P] * 15 + [c_int, c_int, c_int, P],
+    "bcbf_cbc2_terms": [P] * 15 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_clean_hessian": [P, P, P, c_int, c_int, c_double, c_int, P],
     "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_socp": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_cbc_socp": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],

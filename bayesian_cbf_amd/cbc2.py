@@ -109,6 +109,11 @@ def posterior_for(reg, xb, jets):
     return st, Mk, Bk, G, Mj
 
 
+def _hessian_mode():
+    from . import gp_algebra
+    return gp_algebra.HESSIAN_CLEANUP
+
+
 def reldeg2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
     """Closed form of the reference call
         cbc2_quadratic_terms(lambda u: cbc2_gp(h, grad_h, regressor, u, k_alpha), x, u0)   (cbc2.py:7-33)
@@ -138,8 +143,8 @@ def reldeg2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
     rep = lambda t: t.expand(b, *t.shape[1:]).contiguous()
     (mA, mb), (Q, p, r), mean, var, status = ops.cbc2_terms(
         Mk, Bk, G, Mj, rep(st["A"]), rep(st["Bm"]), rep(st["ell"]), rep(st["s2"]), hv.contiguous(), gh, Hh,
-        torch.as_tensor(k_alpha, **f), ub)
-    if bool((status != 0).any()):
+        torch.as_tensor(k_alpha, **f), ub, hessian_mode=_hessian_mode())
+    if bool((status == 1).any()):
         raise AssertionError(" Hessian must be positive definite")      # gp_algebra.py:386
     if single:
         return (mA[0], mb[0]), (Q[0], p[0], r[0]), mean[0], var[0]
@@ -246,11 +251,8 @@ def lie1_gradient(model, grad_gp, x, eigeps=2e-3):
     Agh = A @ gh
     HAg = Hh @ Agh
     H = (Hh @ A @ Hh) * s00 + torch.outer(HAg, s_i) + torch.outer(s_i, HAg) + (gh @ Agh) * sij
-    w, V = torch.linalg.eigh((0.5 * (H + H.t())).cpu())          # n x n, n <= 4: host side
-    w, V = w.to(H), V.to(H)
-    assert bool((w > -eigeps).all()), " Hessian must be positive definite"
-    if bool((w < 0).any()):
-        H = (V * w.clamp_min(0.0)) @ V.t()
+    from .gp_algebra import clean_kernel_hessian
+    H, _ = clean_kernel_hessian(H, eigeps)                       # n x n, n <= 4: host side (gp_algebra.py:384-392)
     return gmean.to(dtype=x.dtype, device=x.device), H.to(dtype=x.dtype, device=x.device)
 
 
@@ -275,7 +277,10 @@ def cbc2_quadratic_terms(cbc2, x, u, *more):
         return reldeg2_quadratic_terms(cbc2, x, u, *more)
     expr = cbc2(u)
     if not hasattr(expr, "quadratic_terms"):
-        raise TypeError("cbc2(u) must be a GP expression of this package (gp_algebra / cbc2_gp / RelDeg*Safety.cbc)")
+        # a foreign callable (anything with .mean(x) / .knl(x, x') differentiable in u): the reference's own autograd
+        # extraction, on the host (misc.get_affine_terms / get_quadratic_terms)
+        from .misc import quadratic_terms_by_autograd
+        return quadratic_terms_by_autograd(cbc2, x, u)
     return expr.quadratic_terms(x, u)
 
 

@@ -417,7 +417,18 @@ class ControlAffineRegressor:
     def _state(self, cholesky_tries=10, cholesky_perturb_init=1e-5, cholesky_perturb_scale=10):
         """K_b build + jittered Cholesky with x10 retry (make_psd, :899-921) + whitened targets."""
         if "state" in self._cache:
-            return self._cache["state"]
+            st = self._cache["state"]
+            if st["_versions"] != self._param_versions():
+                # A hyper-parameter was written since the factor entered the cache and nobody called clear_cache().  The
+                # reference caches ONLY the Cholesky factor, under a key that ignores its arguments (:379-385); every
+                # other quantity of a query -- k(X, x*), UH B, Y = Xdot - UH M0, the prior term -- is formed from the LIVE
+                # parameters (:525-547, 1034-1055).  Same here: keep Lop, refresh the rest.
+                hp = self._hyper()
+                st.update(hp)
+                st["UHB"] = (st["UH"] @ hp["Bm"]).contiguous()
+                st["Vw"], _ = ops.potrs(st["Lop"], self.XdotTrain[None], st["UH"], hp["M0"], want_alpha=False)
+                st["_versions"] = self._param_versions()
+            return st
         self._require_gpu()
         hp = self._hyper()
         X = self.Xtrain[None]
@@ -440,15 +451,21 @@ class ControlAffineRegressor:
         # only the whitened targets Vw = L^-1 Y enter the posterior (alpha = K_b^-1 Y is the fit's business): skip
         # the backward substitution
         Vw, _ = ops.potrs(Lop, self.XdotTrain[None], UH, hp["M0"], want_alpha=False)
-        st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, N=N, jitter=jitter[None].contiguous(), kernel=self.data_kernel)
+        st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, N=N, jitter=jitter[None].contiguous(), kernel=self.data_kernel,
+                  factor_hp=dict(Bm=hp["Bm"], ell=hp["ell"], s2=hp["s2"]), _versions=self._param_versions())
         self._cache["state"] = st
         return st
+
+    def _param_versions(self):
+        """(identity, in-place version) of every model parameter: changes when one is written (no device sync)."""
+        return tuple((id(p), p._version) for p in self.model.parameters())
 
     def _perturbed_cholesky(self, *a, **k):
         """Dense L = chol(K_b + jitter) (the matrix the reference caches, :379-385), from the cached state."""
         st = self._state()
         if "L" not in st:
-            Kb = ops.kb_build(st["X"], st["UH"], st["Bm"], st["ell"], st["s2"], st["jitter"], kernel=self.data_kernel)
+            fh = st["factor_hp"]                     # (the hyper-parameters the cached factor was computed with)
+            Kb = ops.kb_build(st["X"], st["UH"], fh["Bm"], fh["ell"], fh["s2"], st["jitter"], kernel=self.data_kernel)
             _, info, Ld = ops.potrf(Kb, want_dense=True)
             st["L"] = Ld[0]
         return st["L"]

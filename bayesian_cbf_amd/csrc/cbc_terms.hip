@@ -2,6 +2,7 @@
 // their second-order-cone form.  One lane per (instance, constraint); closed form of what the
 // reference obtains with autograd through its gp_algebra expression.
 #include "bcbf_common.h"
+#include "geev_small.h"
 
 namespace bcbf {
 
@@ -102,14 +103,16 @@ static int launch_cbc_terms(const T* Mk, const T* Bk, const T* A, const T* grad,
 // (closed form of cbc2_gp + cbc2_quadratic_terms, cbc2.py:7-33, gp_algebra.py:133-168, 319-402;
 // SURVEY.md A.4).  One lane per instance, fp64 internally.
 //   out[Bt, m + 1 + m*m + m + 1 + 2] = (mean_A[m], mean_b, Q[m,m], p[m], r, mean(u0), var(u0))
-//   status: 0 ok, 1 = kernel Hessian has an eigenvalue < -2e-3 (the reference asserts, gp_algebra.py:386).
+//   status: 0 ok, 1 = kernel Hessian has an eigenvalue <= -2e-3 (the reference asserts, gp_algebra.py:386),
+//           4 = the clean-up branch of gp_algebra.py:387-392 ran (eigenvalues in (-2e-3, 0) zeroed), 6 = it ran through
+//           the projection because the general eigen-solver saw a complex pair (geev_small.h).
 template <typename T>
 __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict__ Bk, const T* __restrict__ G,
                                   const T* __restrict__ Mj, const T* __restrict__ A, const T* __restrict__ Bm,
                                   const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ hval,
                                   const T* __restrict__ gh_, const T* __restrict__ Hh_, const T* __restrict__ kalpha,
                                   const T* __restrict__ u0_, T* __restrict__ out, int* __restrict__ status,
-                                  int Bt, int n, int m) {
+                                  int Bt, int n, int m, int hessian_mode) {
     constexpr int NN = 4, MM = BCBF_MAX_CTRL_DIM, CC = MM + 1;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= Bt) return;
@@ -166,33 +169,10 @@ __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict_
             }
             H[i][j] = hah * s00 + HAg[i] * s_i[j] + s_i[i] * HAg[j] + phi0 * sij;
         }
-    // smallest eigenvalue check by a few Jacobi sweeps on the symmetric part (n <= 4)
-    int st = 0;
-    {
-        double S[NN][NN], Vv[NN][NN];
-        for (int i = 0; i < NN; ++i) for (int j = 0; j < NN; ++j) { S[i][j] = 0.5 * (H[i][j] + H[j][i]); Vv[i][j] = i == j ? 1.0 : 0.0; }
-        for (int sweep = 0; sweep < 12; ++sweep)
-            for (int p_ = 0; p_ < n; ++p_)
-                for (int q = p_ + 1; q < n; ++q) {
-                    if (fabs(S[p_][q]) < 1e-300) continue;
-                    const double th = 0.5 * (S[q][q] - S[p_][p_]) / S[p_][q];
-                    const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                    const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
-                    for (int k = 0; k < n; ++k) { const double a_ = S[k][p_], b_ = S[k][q]; S[k][p_] = cs * a_ - sn * b_; S[k][q] = sn * a_ + cs * b_; }
-                    for (int k = 0; k < n; ++k) { const double a_ = S[p_][k], b_ = S[q][k]; S[p_][k] = cs * a_ - sn * b_; S[q][k] = sn * a_ + cs * b_; }
-                    for (int k = 0; k < n; ++k) { const double a_ = Vv[k][p_], b_ = Vv[k][q]; Vv[k][p_] = cs * a_ - sn * b_; Vv[k][q] = sn * a_ + cs * b_; }
-                }
-        bool neg = false;
-        for (int i = 0; i < n; ++i) { if (S[i][i] < -2e-3) st = 1; if (S[i][i] < 0.0) neg = true; }
-        if (neg && st == 0) {      // zero the small negative eigenvalues (gp_algebra.py:387-392)
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) {
-                    double t = 0;
-                    for (int k = 0; k < n; ++k) t += Vv[i][k] * fmax(S[k][k], 0.0) * Vv[j][k];
-                    H[i][j] = t;
-                }
-        }
-    }
+    // gp_algebra.py:384-392: assert no eigenvalue <= -2e-3, rebuild H with the ones in (-2e-3, 0) zeroed -- by the
+    // reference's own formula on xGEEV's eigenvectors (geev_small.h), or the spectral projection (hessian_mode 1)
+    static_assert(NN == geev::NMAX, "geev_small.h is written for n <= 4");
+    const int st = geev::clean_hessian(n, H, 2e-3, hessian_mode);
     // C(a) = (d/dz [A gh(z) s(z,a;z,e0)])',  J[k][i] = (A Hh)[k][i] s(a,e0) + Agh[k] dsdz_i(a,e0)
     double Cu0[NN][NN], C0[NN][NN];
     for (int which = 0; which < 2; ++which) {
@@ -252,15 +232,39 @@ __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict_
     if (status) status[b] = st;
 }
 
+// The clean-up alone on a batch of n x n matrices (row-major, n <= 4): what GradientGP.knl(x, x) does to its Hessian
+// (gp_algebra.py:384-392).  The facade's single-state paths and the tests call it; cbc2_terms_kernel has it inline.
+template <typename T>
+__global__ void clean_hessian_kernel(const T* __restrict__ Hin, T* __restrict__ Hout, int* __restrict__ status, int Bt,
+                                     int n, double eps, int mode) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Bt) return;
+    double H[geev::NMAX][geev::NMAX];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) H[i][j] = (double)Hin[((size_t)b * n + i) * n + j];
+    const int st = geev::clean_hessian(n, H, eps, mode);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Hout[((size_t)b * n + i) * n + j] = (T)H[i][j];
+    if (status) status[b] = st;
+}
+
+template <typename T>
+static int launch_clean_hessian(const T* Hin, T* Hout, int* status, int Bt, int n, double eps, int mode, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Hin || !Hout || n < 1 || n > geev::NMAX || (mode != 0 && mode != 1) || !(eps > 0.0)) return BCBF_EINVAL;
+    hipLaunchKernelGGL((clean_hessian_kernel<T>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, Hin, Hout, status,
+                       Bt, n, eps, mode);
+    return check_launch("clean_hessian");
+}
+
 template <typename T>
 static int launch_cbc2_terms(const T* Mk, const T* Bk, const T* G, const T* Mj, const T* A, const T* Bm, const T* ell,
                              const T* s2, const T* h, const T* gh, const T* Hh, const T* kalpha, const T* u0, T* out,
-                             int* status, int Bt, int n, int m, void* stream) {
+                             int* status, int Bt, int n, int m, int hessian_mode, void* stream) {
     if (Bt <= 0) return BCBF_OK;
+    if (hessian_mode != 0 && hessian_mode != 1) return BCBF_EINVAL;
     if (!Mk || !Bk || !G || !Mj || !A || !Bm || !ell || !s2 || !h || !gh || !Hh || !kalpha || !u0 || !out) return BCBF_EINVAL;
     if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     hipLaunchKernelGGL((cbc2_terms_kernel<T>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, Mk, Bk, G, Mj, A,
-                       Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m);
+                       Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode);
     return check_launch("cbc2_terms");
 }
 
@@ -277,16 +281,22 @@ int bcbf_cbc_terms_f64(const double* Mk, const double* Bk, const double* A, cons
                        double* terms, double* cones, int* cstatus, int Bt, int K, int n, int m, void* stream) {
     return bcbf::launch_cbc_terms<double>(Mk, Bk, A, grad, cst, sign, fhat, ghat, terms, cones, cstatus, Bt, K, n, m, stream);
 }
+int bcbf_clean_hessian_f32(const float* Hin, float* Hout, int* status, int Bt, int n, double eps, int mode, void* stream) {
+    return bcbf::launch_clean_hessian<float>(Hin, Hout, status, Bt, n, eps, mode, stream);
+}
+int bcbf_clean_hessian_f64(const double* Hin, double* Hout, int* status, int Bt, int n, double eps, int mode, void* stream) {
+    return bcbf::launch_clean_hessian<double>(Hin, Hout, status, Bt, n, eps, mode, stream);
+}
 int bcbf_cbc2_terms_f32(const float* Mk, const float* Bk, const float* G, const float* Mj, const float* A,
                         const float* Bm, const float* ell, const float* s2, const float* h, const float* gh,
                         const float* Hh, const float* kalpha, const float* u0, float* out, int* status,
-                        int Bt, int n, int m, void* stream) {
-    return bcbf::launch_cbc2_terms<float>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, stream);
+                        int Bt, int n, int m, int hessian_mode, void* stream) {
+    return bcbf::launch_cbc2_terms<float>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, stream);
 }
 int bcbf_cbc2_terms_f64(const double* Mk, const double* Bk, const double* G, const double* Mj, const double* A,
                         const double* Bm, const double* ell, const double* s2, const double* h, const double* gh,
                         const double* Hh, const double* kalpha, const double* u0, double* out, int* status,
-                        int Bt, int n, int m, void* stream) {
-    return bcbf::launch_cbc2_terms<double>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, stream);
+                        int Bt, int n, int m, int hessian_mode, void* stream) {
+    return bcbf::launch_cbc2_terms<double>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, stream);
 }
 }

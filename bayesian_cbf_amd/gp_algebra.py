@@ -210,6 +210,41 @@ class GaussianProcessMatmulExpr(GaussianProcessExpr):
 GaussianProcessDetMatmulExpr = GaussianProcessMatmulExpr
 
 
+EPS = 2e-3            # gp_algebra.py:317
+
+# How the Hessian clean-up of GradientGP.knl (gp_algebra.py:384-392) rebuilds the matrix when an eigenvalue lies in
+# (-EPS, 0):  "reference" = the reference's own `eigenvectors.T @ diag(evalz) @ eigenvectors` on the GENERAL eigen-solver's
+# output (the default: results identical to the reference's);  "project" = the spectral projection V max(L, 0) V' of the
+# symmetric part (what a PSD clean-up is usually meant to be; differs from the reference whenever the branch runs).
+HESSIAN_CLEANUP = "reference"
+
+
+def clean_kernel_hessian(H, eigeps=EPS, mode=None):
+    """gp_algebra.py:384-392 on one n x n Hessian (host side: n <= 4).  Returns (H_clean, fired).
+
+    mode "reference" is the reference's code path statement by statement: `torch.eig` (= LAPACK xGEEV; torch.linalg.eig
+    today) on H in its own dtype, `assert (eigenvalues > -eigeps).all()`, eigenvalues in (-eigeps, 0) set to zero,
+    `eigenvectors.T @ diag(evalz) @ eigenvectors`.  NB that product pairs eigenvalue k with ROW k of the eigenvector
+    matrix, so it depends on the solver's eigenvalue order and eigenvector signs (csrc/geev_small.h)."""
+    mode = mode or HESSIAN_CLEANUP
+    if mode == "project":
+        w, V = torch.linalg.eigh((0.5 * (H + H.t())).cpu())
+        assert bool((w > -eigeps).all()), " Hessian must be positive definite"
+        if bool((w < 0).any()):
+            return ((V * w.clamp_min(0.0)) @ V.t()).to(H), True
+        return H, False
+    if mode != "reference":
+        raise ValueError("HESSIAN_CLEANUP must be 'reference' or 'project', got %r" % (mode,))
+    w, V = torch.linalg.eig(H.detach().cpu())
+    evalz, eigenvectors = w.real.clone(), V.real
+    assert bool((evalz > -eigeps).all()), " Hessian must be positive definite"
+    small_neg_eig = (evalz > -eigeps) & (evalz < 0)
+    if bool(small_neg_eig.any()):
+        evalz[small_neg_eig] = 0
+        return (eigenvectors.t() @ torch.diag(evalz) @ eigenvectors).to(H), True
+    return H, False
+
+
 class GradientGP(GaussianProcessExpr):
     """grad_x of a scalar GP expression (gp_algebra.py:319-402).  Supported operand: Det(grad_h).t() @ f_gp (the Lie
     derivative L_f h); mean(x) = grad (grad_h' m_f)(x), knl(x, x) = d2/dx dx' of its kernel, from the posterior jets."""

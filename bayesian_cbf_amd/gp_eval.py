@@ -335,13 +335,9 @@ class Evaluator:
 
 
 def _clean_hessian(H, eigeps=2e-3):
-    """gp_algebra.py:384-392: eigenvalues in (-eps, 0) are rounding -- assert none below, clamp the rest (projection
-    V max(L, 0) V'; the reference rebuilds V' L V, which depends on the eigenvector ordering: DESIGN.md 8)."""
-    w, V = torch.linalg.eigh((0.5 * (H + H.t())).cpu())
-    assert bool((w > -eigeps).all()), " Hessian must be positive definite"
-    if bool((w < 0).any()):
-        return ((V * w.clamp_min(0.0)) @ V.t()).to(H)
-    return H
+    """gp_algebra.py:384-392 (the reference's formula by default; `gp_algebra.HESSIAN_CLEANUP`)."""
+    from .gp_algebra import clean_kernel_hessian
+    return clean_kernel_hessian(H, eigeps)[0]
 
 
 # ------------------------------------------------------------------------------------------------ public entry points

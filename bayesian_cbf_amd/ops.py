@@ -394,9 +394,27 @@ def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False, want_W=Fa
     return (Mk, Bk, G, Mj, Wj) if want_W else (Mk, Bk, G, Mj)
 
 
-def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0):
+HESSIAN_MODES = {"reference": 0, "project": 1}
+
+
+def clean_hessian(H, eigeps=2e-3, mode="reference"):
+    """The eigenvalue clean-up GradientGP.knl(x, x) applies to its Hessian (gp_algebra.py:384-392) on a batch H[b,n,n]
+    (n <= 4) on the device.  mode "reference": `eigenvectors.T @ diag(evalz) @ eigenvectors` with the general solver's
+    eigenvectors (csrc/geev_small.h); "project": spectral projection of the symmetric part.  Returns (H_clean, status):
+    status 0 untouched, 1 an eigenvalue <= -eigeps (H returned unchanged; the reference asserts), 4 / 6 cleaned."""
+    _chk(H)
+    b, n, _ = H.shape
+    out = torch.empty_like(H)
+    status = torch.empty(b, dtype=torch.int32, device=H.device)
+    check(getattr(lib, "bcbf_clean_hessian" + _suf(H))(_p(H), _p(out), _p(status), b, n, float(eigeps),
+                                                       HESSIAN_MODES[mode], _stream(H)), "bcbf_clean_hessian")
+    return out, status
+
+
+def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, hessian_mode="reference"):
     """Rel-degree-2 terms (cbc2_gp + cbc2_quadratic_terms, cbc2.py:7-33).  Returns
-    ((mean_A[b,m], mean_b[b]), (Q[b,m,m], p[b,m], r[b]), mean[b], var[b], status[b])."""
+    ((mean_A[b,m], mean_b[b]), (Q[b,m,m], p[b,m], r[b]), mean[b], var[b], status[b]); status 1 = the reference's
+    positive-definiteness assert fails, 4 / 6 = the Hessian clean-up ran (`clean_hessian`), 0 otherwise."""
     _chk(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0)
     b, n, C = Mk.shape
     m = C - 1
@@ -404,7 +422,7 @@ def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0):
     status = torch.empty(b, dtype=torch.int32, device=Mk.device)
     check(getattr(lib, "bcbf_cbc2_terms" + _suf(Mk))(_p(Mk), _p(Bk), _p(G), _p(Mj), _p(A), _p(Bm), _p(ell), _p(s2),
                                                      _p(h), _p(gh), _p(Hh), _p(kalpha), _p(u0), _p(out), _p(status),
-                                                     b, n, m, _stream(Mk)), "bcbf_cbc2_terms")
+                                                     b, n, m, HESSIAN_MODES[hessian_mode], _stream(Mk)), "bcbf_cbc2_terms")
     o = 0
     mean_A = out[:, o:o + m]; o += m
     mean_b = out[:, o]; o += 1

@@ -335,15 +335,26 @@ int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X
  * h[Bt], gh[Bt,n], Hh[Bt,n,n] = barrier value, gradient, Hessian at x; u0[Bt,m] linearisation point (the
  * cross term cov(grad L_f h, f+gu) is frozen there, as the reference's autograd does); kalpha[2].
  * out[Bt, m+1+m*m+m+1+2] = (mean_A[m], mean_b, Q[m,m], p[m], r, mean(u0), var(u0));
- * status[Bt] (optional): 1 if the kernel Hessian has an eigenvalue < -2e-3 (the reference asserts). */
+ * The kernel Hessian d2 k_{L_f h} / dx dx' at x' = x goes through the reference's eigenvalue clean-up
+ * (gp_algebra.py:384-392): hessian_mode 0 = the reference's formula `eigenvectors.T @ diag(evalz) @ eigenvectors` on the
+ * eigenvectors of the GENERAL solver (xGEEV's order and signs, csrc/geev_small.h); 1 = the spectral projection
+ * V max(L,0) V' of the symmetric part (what rounds 1-3 did; differs from the reference whenever the branch runs).
+ * status[Bt] (optional): 0 = nothing to clean, 1 = an eigenvalue <= -2e-3 (the reference asserts), 4 = eigenvalues in
+ * (-2e-3, 0) were zeroed, 6 = zeroed through the projection because xGEEV's path met a complex pair. */
 int bcbf_cbc2_terms_f32(const float* Mk, const float* Bk, const float* G, const float* Mj, const float* A,
                         const float* Bm, const float* ell, const float* s2, const float* h, const float* gh,
                         const float* Hh, const float* kalpha, const float* u0, float* out, int* status,
-                        int Bt, int n, int m, void* stream);
+                        int Bt, int n, int m, int hessian_mode, void* stream);
 int bcbf_cbc2_terms_f64(const double* Mk, const double* Bk, const double* G, const double* Mj, const double* A,
                         const double* Bm, const double* ell, const double* s2, const double* h, const double* gh,
                         const double* Hh, const double* kalpha, const double* u0, double* out, int* status,
-                        int Bt, int n, int m, void* stream);
+                        int Bt, int n, int m, int hessian_mode, void* stream);
+
+/* The clean-up of gp_algebra.py:384-392 alone, on a batch of n x n matrices (row-major, n <= 4): every eigenvalue must
+ * be > -eps (else status 1 and the matrix is returned unchanged); eigenvalues in (-eps, 0) are zeroed and the matrix
+ * rebuilt (mode / status as in bcbf_cbc2_terms).  Hout may alias Hin.  Replaces the torch.eig block of GradientGP.knl. */
+int bcbf_clean_hessian_f32(const float* Hin, float* Hout, int* status, int Bt, int n, double eps, int mode, void* stream);
+int bcbf_clean_hessian_f64(const double* Hin, double* Hout, int* status, int Bt, int n, double eps, int mode, void* stream);
 
 /* K8 (rel-degree 1) + K9: constraint terms and their cone form, K constraints per instance.
  *   mean(u) = bfe'u + e,  var(u) = u'V u + bfv'u + v   for  sign*(grad' (fhat + ghat u + F(x)[1;u]) + cst)

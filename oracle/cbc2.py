@@ -15,6 +15,37 @@ from .gp_posterior import rbf_ard_kernel
 EIG_EPS = 2e-3   # gp_algebra.py:317: eigenvalues of the kernel Hessian in (-EPS, 0) are treated as rounding
 
 
+def clean_hessian(H, eps=EIG_EPS, mode="reference"):
+    """gp_algebra.py:384-392, restated literally.  Returns (H_clean, branch_fired).
+
+        eigenvalues, eigenvectors = torch.eig(Hxx_k, eigenvectors=True)
+        assert (eigenvalues[:, 0] > -eigeps).all()
+        small_neg_eig = (eigenvalues[:, 0] > -eigeps) & (eigenvalues[:, 0] < 0)
+        evalz[small_neg_eig] = 0;   Hxx_k = eigenvectors.T @ diag(evalz) @ eigenvectors
+
+    `torch.eig` was LAPACK's GENERAL solver xGEEV (real parts of the eigenvalues, eigenvectors as columns); the harness
+    that executes the reference maps it onto torch.linalg.eig (tests/golden/_refenv.py) and so does this function -- the
+    SAME library call, because `V' diag(l) V` pairs eigenvalue k with ROW k of V and therefore depends on the order and
+    the signs xGEEV happens to return (numpy's LAPACK build differs from torch's in ~2 % of 3x3 / 4x4 cases).
+    mode="project" is the spectral projection V max(l,0) V' of the symmetric part (the non-default switch of the build)."""
+    H = np.asarray(H, dtype=np.float64)
+    if mode == "project":
+        w, V = np.linalg.eigh(0.5 * (H + H.T))
+        assert (w > -eps).all(), "Hessian must be positive definite (gp_algebra.py:386)"
+        if (w < 0).any():
+            return V @ np.diag(np.maximum(w, 0.0)) @ V.T, True
+        return H, False
+    import torch
+    lam, vec = torch.linalg.eig(torch.from_numpy(H.copy()))
+    evalz, eigenvectors = lam.real.numpy().copy(), vec.real.numpy()
+    assert (evalz > -eps).all(), "Hessian must be positive definite (gp_algebra.py:386)"
+    small_neg_eig = (evalz > -eps) & (evalz < 0)
+    if small_neg_eig.any():
+        evalz[small_neg_eig] = 0.0
+        return eigenvectors.T @ np.diag(evalz) @ eigenvectors, True
+    return H, False
+
+
 def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x):
     """Value and first x-derivatives of the posterior factors at one query x.
 
@@ -39,7 +70,7 @@ def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x):
     return dict(Mk=Mk, dMk=dMk, Bk=Bk, G10=G10, G11=G11)
 
 
-def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0):
+def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0, hessian_mode="reference", info=None):
     """((mean_A, mean_b), (Q, p, r), mean(u0), var(u0)) of cbc2_quadratic_terms(cbc2_gp(...), x, u0).
 
     h, gh[n], Hh[n,n]: barrier value, gradient, Hessian at x.  The cross term C = cov(grad L_f h, f+gu)
@@ -67,11 +98,10 @@ def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0):
                      for i in range(n)])
     HAg = Hh @ Agh
     H = (Hh @ A @ Hh) * s00 + np.outer(HAg, s_i) + np.outer(s_i, HAg) + phi0 * s_ij
-    w = np.linalg.eigvalsh(0.5 * (H + H.T))
-    assert (w > -EIG_EPS).all(), "Hessian must be positive definite (gp_algebra.py:386)"
-    if (w < 0).any():       # the reference zeroes small negative eigenvalues (:387-392)
-        wv, V = np.linalg.eigh(0.5 * (H + H.T))
-        H = V @ np.diag(np.maximum(wv, 0.0)) @ V.T
+    H, fired = clean_hessian(H, EIG_EPS, hessian_mode)       # the reference zeroes small negative eigenvalues (:384-392)
+    if info is not None:
+        info["branch_fired"] = bool(fired)
+        info["H"] = H
 
     def Cmat(a):            # C = (d/dz [ A gh(z) s(z,a;z,e0) ])'
         sa0 = a @ Bk @ e0

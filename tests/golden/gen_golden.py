@@ -534,6 +534,174 @@ def main_gp_algebra():
 
 
 
+# ----------------------------------------------------------------------------------------------
+# The eigenvalue clean-up of GradientGP.knl at x' == x (bayes_cbf/gp_algebra.py:384-392) with the branch FIRING:
+#     eigenvalues in (-2e-3, 0)  ->  Hxx_k = eigenvectors.T @ diag(evalz) @ eigenvectors      (torch.eig = xGEEV)
+# No other golden family reaches it (the Hessians there are positive definite).  Two families:
+#   hessclean_handmade.npz   leaf GPs with the bilinear kernel k(x, x') = x' M x (its cross Hessian is M itself), M built
+#                            with one eigenvalue in (-1.5e-3, -1e-5) -- dense, with zero rows / columns (a barrier gradient
+#                            with a zero component: xGEBAL's permutation), slightly non-symmetric -- and controls that do
+#                            not fire; n = 1..4
+#   eigfired_*.npz           the regressor path end to end (cbc2_gp + cbc2_quadratic_terms) in a state the reference can
+#                            really be in: the Cholesky factor cached under a key that ignores its arguments
+#                            (control_affine_model.py:379-385) and the output scale changed afterwards WITHOUT clear_cache():
+#                            the posterior "kernel" k_new B - W'W is then slightly indefinite.  The scale bump is bisected
+#                            per query state so that the smallest eigenvalue of the Hessian lands near -1e-3.
+# Every record carries `branch_fired` (was torch.eig asked for eigenvectors) and `agree_openblas`: whether numpy's LAPACK
+# build gives the same V' L V as torch's (it pairs eigenvalue k with ROW k of V, so it depends on xGEEV's order and signs).
+class EigRecorder:
+    """Counts the torch.eig calls of the reference that ask for eigenvectors (= the clean-up branch ran)."""
+
+    def __enter__(self):
+        self._orig = torch.eig
+        self.fired = 0
+
+        def rec(A, eigenvectors=False):
+            if eigenvectors:
+                self.fired += 1
+            return self._orig(A, eigenvectors=eigenvectors)
+        torch.eig = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.eig = self._orig
+        return False
+
+
+def _literal_with_numpy(H, eps=2e-3):
+    w, V = np.linalg.eig(H)
+    ev = w.real.copy()
+    small = (ev > -eps) & (ev < 0)
+    if not small.any():
+        return H
+    ev[small] = 0.0
+    return V.real.T @ np.diag(ev) @ V.real
+
+
+def gen_hessclean_handmade():
+    import bayes_cbf.gp_algebra as rga
+    rng = np.random.RandomState(20240)
+    Ms, outs, fired, agree, kinds = {}, {}, {}, {}, {}
+    for n in (1, 2, 3, 4):
+        Ms[n], outs[n], fired[n], agree[n], kinds[n] = [], [], [], [], []
+        for t in range(24):
+            A = rng.randn(n, n)
+            w, V = np.linalg.eigh(A + A.T)
+            w = np.abs(w) + 0.05
+            kind = ("neg", "neg", "pos", "neg_zero_rows", "neg_asym", "neg_two")[t % 6]
+            if kind != "pos":
+                w[0] = -rng.uniform(1e-5, 1.5e-3)
+            if kind == "neg_two" and n > 2:
+                w[1] = -rng.uniform(1e-5, 1.5e-3)
+            M = (V * w) @ V.T
+            M = 0.5 * (M + M.T)
+            if kind == "neg_zero_rows" and n > 1:
+                for z in rng.permutation(n)[:rng.randint(1, n)]:
+                    M[z, :] = 0.0
+                    M[:, z] = 0.0
+                if n - int((np.abs(M).sum(0) == 0).sum()) >= 1:
+                    nzi = np.where(np.abs(M).sum(0) != 0)[0]
+                    if len(nzi):                       # keep a small negative eigenvalue inside the non-zero block
+                        wb, Vb = np.linalg.eigh(M[np.ix_(nzi, nzi)])
+                        wb = np.abs(wb) + 0.05
+                        wb[0] = -rng.uniform(1e-5, 1.5e-3)
+                        M[np.ix_(nzi, nzi)] = (Vb * wb) @ Vb.T
+            if kind == "neg_asym":
+                M = M + 1e-16 * rng.randn(n, n)
+            Mt = torch.tensor(M)
+            leaf = rga.GaussianProcess(lambda x: x.sum(), lambda x, xp, Mt=Mt: x @ Mt @ xp, (1,), name="bilinear")
+            x = torch.tensor(rng.randn(n))
+            with EigRecorder() as er:
+                Hc = rga.GradientGP(leaf, x_shape=(n,)).knl(x, x)
+            Hc = t2n(Hc)
+            Ms[n].append(M)
+            outs[n].append(Hc)
+            fired[n].append(er.fired > 0)
+            agree[n].append(bool(np.allclose(_literal_with_numpy(M), Hc, rtol=0, atol=1e-10)))
+            kinds[n].append(kind)
+    out = {}
+    for n in Ms:
+        out.update({"M_n%d" % n: np.stack(Ms[n]), "t_knl_n%d" % n: np.stack(outs[n]), "branch_fired_n%d" % n: np.array(fired[n]),
+                    "agree_openblas_n%d" % n: np.array(agree[n]), "kind_n%d" % n: np.array(kinds[n])})
+    np.savez_compressed(os.path.join(HERE, "hessclean_handmade.npz"), **out)
+    print("hessclean_handmade:", {n: (int(np.sum(fired[n])), int(np.sum(agree[n])), len(fired[n])) for n in Ms},
+          "(fired, numpy-LAPACK agrees, cases)")
+
+
+def gen_eigfired(tag, n, m, N, seed, kind, S=4, target=(-1.4e-3, -0.6e-3)):
+    from bayes_cbf.cbc2 import cbc2_gp
+    from bayes_cbf.gp_algebra import DeterministicGP
+    from bayes_cbf.misc import t_hessian
+    reg, X, U, Xdot = make_regressor(cam.ControlAffineRegressor, n, m, N, seed, spread=0.9)
+    out = dict(X=t2n(X), U=t2n(U), Xdot=t2n(Xdot), kind=kind, **hyper(reg, n, m))
+    out["s2_L"] = out.pop("s2")                      # the output scale the cached factor was computed with
+    h, gh, hess = _h_funcs(kind, n)
+    k_alpha = [1.0, 3.0]
+    out["k_alpha"] = np.array(k_alpha)
+    torch.manual_seed(seed + 3)
+    xs = 0.5 * (2 * torch.rand(S, n) - 1)
+    u0s = torch.rand(S, m)
+    raw = reg.model.input_covar.raw_outputscale
+    raw0 = raw.detach().clone()
+    recs = {k: [] for k in ("mean_A", "mean_b", "Q", "p", "r", "mean", "var", "h", "gh", "hess", "Hraw", "Hclean")}
+    s2_q, fired, agree = [], [], []
+    with RandRecorder() as rr:
+        reg.custom_predict(xs[:1].clone())           # the factor enters the cache here, at raw0
+        L1h = DeterministicGP(gh, shape=(n,), name="grad h").t() @ reg.f_func_gp()
+
+        def min_eig(x, bump):
+            with torch.no_grad():
+                raw.copy_(raw0 + bump)
+            Hraw = t_hessian(L1h.knl, x.clone(), x.detach().clone())
+            return float(torch.linalg.eigvalsh(0.5 * (Hraw + Hraw.t()))[0]), Hraw
+
+        for i in range(S):
+            x, u0 = xs[i].clone(), u0s[i].clone()
+            lo, hi = 0.0, 0.05
+            while min_eig(x, hi)[0] > target[1]:     # grow the bump until the Hessian is indefinite enough
+                hi *= 2.0
+                assert hi < 50.0, "no bump makes this Hessian indefinite"
+            for _ in range(200):
+                mid = 0.5 * (lo + hi)
+                e, _ = min_eig(x, mid)
+                if target[0] < e < target[1]:
+                    break
+                lo, hi = (mid, hi) if e >= target[1] else (lo, mid)
+            else:
+                raise AssertionError("bisection did not land in the target interval")
+            e, Hraw = min_eig(x, mid)
+            with EigRecorder() as er:
+                (mA, mb), (Q, p_, r_), mean, var = cbc2_quadratic_terms(
+                    lambda u: cbc2_gp(h, gh, reg, u, k_alpha), x, u0)
+                from bayes_cbf.gp_algebra import GradientGP
+                Hclean = GradientGP(L1h, x_shape=(n,)).knl(x, x)
+            for k, v in zip(("mean_A", "mean_b", "Q", "p", "r", "mean", "var", "Hraw", "Hclean"),
+                            (mA, mb, Q, p_, r_, mean, var, Hraw, Hclean)):
+                recs[k].append(t2n(v))
+            recs["h"].append(t2n(h(x)))
+            recs["gh"].append(t2n(gh(x)))
+            recs["hess"].append(t2n(hess(x)))
+            s2_q.append(float(t2n(reg.get_kernel_param("scalefactor"))))
+            fired.append(er.fired > 0)
+            agree.append(bool(np.allclose(_literal_with_numpy(t2n(Hraw)), t2n(Hclean), rtol=0, atol=1e-9 * float(Hraw.abs().max()))))
+    assert len(rr.draws) == 1            # only the K_b jitter of the one cached factor
+    assert all(fired), fired
+    out.update(jitter_rand=np.stack(rr.draws), L=t2n(reg._cache["perturbed_cholesky"]), xs=t2n(xs), u0s=t2n(u0s),
+               s2_q=np.array(s2_q), branch_fired=np.array(fired), agree_openblas=np.array(agree))
+    for k, v in recs.items():
+        out["t_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "eigfired_%s.npz" % tag), **out)
+    eigs = [np.linalg.eigvalsh(0.5 * (H + H.T)) for H in out["t_Hraw"]]
+    print("eigfired_%s: n=%d m=%d N=%d kind=%s  s2_L=%.4f  s2_q=%s  fired=%s  numpy-LAPACK agrees=%s\n   eig(Hraw)=%s"
+          % (tag, n, m, N, kind, out["s2_L"], np.round(s2_q, 4), fired, agree, [np.round(e, 5).tolist() for e in eigs]))
+
+
+def main_eigfired():
+    gen_hessclean_handmade()
+    gen_eigfired("pendulum_N16", n=2, m=1, N=16, seed=81, kind="radial")
+    gen_eigfired("n3m2_N24", n=3, m=2, N=24, seed=83, kind="generic")
+
+
 def gen_facade():
     """Small host-side surfaces of the path, recorded from the executed reference:
     HetergeneousMatrixVariateMean.forward (matrix_variate_multitask_model.py:44-66) on observation rows, matrix rows, a
@@ -587,6 +755,8 @@ def gen_facade():
 if __name__ == '__main__':
     if 'facade' in sys.argv:
         gen_facade()
+    elif 'eigfired' in sys.argv:
+        main_eigfired()
     elif 'gp_algebra' in sys.argv:
         main_gp_algebra()
     elif 'cogp' in sys.argv:

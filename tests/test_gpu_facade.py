@@ -185,6 +185,53 @@ def test_cbc2_quadratic_terms_reldeg2_facade(path):
     assert abs(sf.safety_factor() - np.sqrt(0.99 / 0.01)) < 1e-12
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "eigfired_*.npz"))), ids=os.path.basename)
+def test_cbc2_quadratic_terms_facade_with_the_hessian_cleanup_firing(path):
+    """The state the eigfired_* vectors were recorded in, reproduced through the façade the way a user gets into it: the
+    factor enters the cache at output scale s2_L, then `raw_outputscale` is WRITTEN without clear_cache() -- the reference
+    keeps the stale factor and forms everything else from the live parameters (control_affine_model.py:379-385), and so
+    does the façade.  cbc2_quadratic_terms (device kernel, reference formula) and GradientGP.knl(x, x) (host statement of
+    gp_algebra.py:384-392) reproduce the reference with its clean-up branch firing; with HESSIAN_CLEANUP = "project" they
+    do not; clear_cache() ends the stale state."""
+    from bayesian_cbf_amd import gp_algebra as ga
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    inv_softplus = lambda v: torch.log(torch.expm1(v))
+    from bayesian_cbf_amd.cbc2 import cbc2_quadratic_terms
+    g = np.load(path)
+    gl = dict(g)
+    gl["s2"] = g["s2_L"]
+    reg = make(ControlAffineRegressor, gl, [g["jitter_rand"][0]])
+    n = g["X"].shape[1]
+    reg.custom_predict(t(g["xs"][:1]))                                   # the factor is cached here
+    hs = {tuple(np.round(x, 12)): (h, gh, H) for x, h, gh, H in zip(g["xs"], g["t_h"], g["t_gh"], g["t_hess"])}
+    look = lambda x: hs[tuple(np.round(x.detach().cpu().numpy(), 12))]
+    for i in range(len(g["xs"])):
+        with torch.no_grad():
+            reg.model.raw_outputscale.copy_(inv_softplus(t(g["s2_q"][i])).reshape(()))
+        x, u0 = t(g["xs"][i]), t(g["u0s"][i])
+        res = cbc2_quadratic_terms(reg, lambda z: look(z)[0], lambda z: look(z)[1], lambda z: look(z)[2], x, u0, g["k_alpha"])
+        (mA, mb), (Q, p, r), mean, var = res
+        for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
+            ref = g["t_" + name][i]
+            np.testing.assert_allclose(val.detach().cpu().numpy().reshape(np.shape(ref)), ref, rtol=1e-6, atol=1e-8)
+        L1h = ga.DeterministicGP(lambda z: look(z)[1], shape=(n,), name="grad h", jac=lambda z: look(z)[2]).t() @ reg.f_func_gp()
+        Hc = ga.GradientGP(L1h, x_shape=(n,)).knl(x, x)
+        np.testing.assert_allclose(Hc.cpu().numpy(), g["t_Hclean"][i], rtol=0, atol=1e-8 * np.abs(g["t_Hraw"][i]).max())
+        ga.HESSIAN_CLEANUP = "project"
+        try:
+            Hp = ga.GradientGP(L1h, x_shape=(n,)).knl(x, x)
+            varp = cbc2_quadratic_terms(reg, lambda z: look(z)[0], lambda z: look(z)[1], lambda z: look(z)[2], x, u0, g["k_alpha"])[3]
+        finally:
+            ga.HESSIAN_CLEANUP = "reference"
+        assert np.abs(Hp.cpu().numpy() - g["t_Hclean"][i]).max() > 1e-5
+        assert abs(float(varp) - float(np.ravel(g["t_var"][i])[0])) > 1e-6 * abs(float(np.ravel(g["t_var"][i])[0]))
+        w = np.linalg.eigvalsh(Hp.cpu().numpy())
+        assert w.min() > -1e-10                                            # (the projection IS positive semi-definite)
+    reg.clear_cache()                                                      # fresh factor at the live scale: a valid posterior
+    H = ga.GradientGP(L1h, x_shape=(n,)).knl(x, x).cpu().numpy()
+    assert np.linalg.eigvalsh(0.5 * (H + H.T)).min() > 0
+
+
 def test_monte_carlo_rollouts_reproduce_saved_run_from_the_logged_start():
     """Config-4 driver: with zero start noise every trajectory is the reference's committed run
     (max_risk 0.01, true L = 12): the batched closed loop reproduces the logged 200-step state sequence."""

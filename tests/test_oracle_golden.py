@@ -179,6 +179,59 @@ def test_reldeg2_terms_match_reference(path):
             np.testing.assert_allclose(np.asarray(val).reshape(np.shape(ref)), ref, rtol=1e-9, atol=1e-11)
 
 
+def test_hessian_cleanup_restated_literally_matches_reference_where_the_branch_fires():
+    """gp_algebra.py:384-392 on the executed reference's own outputs: 96 hand-made Hessians (n = 1..4; 80 with an eigenvalue in
+    (-1.5e-3, 0): dense, with zero rows / columns, slightly non-symmetric, two negative eigenvalues; 16 controls).  The
+    oracle's literal restatement gives the reference's `eigenvectors.T @ diag(evalz) @ eigenvectors` to rounding, fires
+    exactly where the reference fired -- and the spectral projection (the non-default switch) does NOT give those numbers."""
+    from oracle import cbc2 as oc2
+    g = np.load(os.path.join(GOLDEN, "hessclean_handmade.npz"))
+    n_fired, n_proj_differs = 0, 0
+    for n in (1, 2, 3, 4):
+        for M, ref, fired in zip(g["M_n%d" % n], g["t_knl_n%d" % n], g["branch_fired_n%d" % n]):
+            H, f = oc2.clean_hessian(M)
+            assert f == bool(fired)
+            np.testing.assert_allclose(H, ref, rtol=0, atol=1e-12 * max(1.0, np.abs(M).max()))
+            n_fired += int(f)
+            if f and n > 1:
+                Hp, _ = oc2.clean_hessian(M, mode="project")
+                n_proj_differs += int(np.abs(Hp - ref).max() > 1e-6)
+    assert n_fired == 80 and n_proj_differs >= 50, (n_fired, n_proj_differs)
+
+
+EIGFIRED_FILES = sorted(glob.glob(os.path.join(GOLDEN, "eigfired_*.npz")))
+
+
+@pytest.mark.parametrize("path", EIGFIRED_FILES, ids=os.path.basename)
+def test_reldeg2_terms_with_the_cleanup_branch_firing_match_reference(path):
+    """cbc2_gp + cbc2_quadratic_terms of the executed reference in a state where GradientGP.knl's clean-up branch FIRES in
+    every record (`branch_fired`): the Cholesky factor is the cached one of an earlier output scale `s2_L`
+    (control_affine_model.py:379-385: the cache key ignores its arguments), the query runs at `s2_q[i]`.  The oracle's
+    closed form with the literal clean-up holds 1e-9; raw and cleaned Hessians are pinned too."""
+    from oracle import cbc2 as oc2
+    g = np.load(path)
+    X, U, Xdot = g["X"], g["U"], g["Xdot"]
+    A, B, ell, M0 = g["A"], g["B"], g["ell"], g["M0"]
+    st = gp.refit_state(X, U, Xdot, B, ell, float(g["s2_L"]), M0, g["jitter_rand"])
+    close(st["L"], g["L"])
+    assert g["branch_fired"].all()
+    for i in range(len(g["xs"])):
+        s2 = float(g["s2_q"][i])
+        jets = oc2.posterior_jets(st["L"], st["Y"], X, st["UHB"], ell, s2, B, M0, g["xs"][i])
+        info = {}
+        (mA, mb), (Q, p, r), mean, var = oc2.cbc2_terms(jets, A, B, ell, s2, float(g["t_h"][i]), g["t_gh"][i],
+                                                       g["t_hess"][i], g["k_alpha"], g["u0s"][i], info=info)
+        assert info["branch_fired"]
+        np.testing.assert_allclose(info["H"], g["t_Hclean"][i], rtol=0, atol=1e-9 * np.abs(g["t_Hraw"][i]).max())
+        for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
+            ref = g["t_" + name][i]
+            np.testing.assert_allclose(np.asarray(val).reshape(np.shape(ref)), ref, rtol=1e-9, atol=1e-11)
+        # ... and the projection gives different terms here (so the fixture does tell the two formulas apart)
+        (_, _), (Qp, pp, rp), _, varp = oc2.cbc2_terms(jets, A, B, ell, s2, float(g["t_h"][i]), g["t_gh"][i],
+                                                      g["t_hess"][i], g["k_alpha"], g["u0s"][i], hessian_mode="project")
+        assert abs(float(varp) - float(np.ravel(g["t_var"][i])[0])) > 1e-6 * abs(float(np.ravel(g["t_var"][i])[0]))
+
+
 CONTROLLER_FILES = sorted(glob.glob(os.path.join(GOLDEN, "controllers_*.npz")))
 
 
