@@ -277,6 +277,8 @@ class ControlAffineRegressor:
                 p.grad.detach_()
                 p.grad.zero_()
 
+    FIT_DTYPE = torch.float64          # dtype the marginal likelihood and its gradient are evaluated in (None = the model's)
+
     def fit(self, Xtrain_in, Utrain_in, XdotTrain_in, training_iter=50, lr=0.1, **kw):
         """Store the training set and optimise the hyper-parameters (control_affine_model.py:268-335):
         `training_iter` Adam steps (lr, MultiStepLR at 30/60/80/90 %) on -log p(Y)/(N n), targets perturbed by
@@ -354,14 +356,20 @@ class ControlAffineRegressor:
         into the raw parameters' .grad.  Returns the loss as a float."""
         m = self.model
         ell, s2, A, B, M0 = m.lengthscale, m.outputscale, m.A, m.B, m.M0          # carry the autograd graph
-        hp = self._hyper()
-        X = self.Xtrain[None]
-        UH = torch.cat([torch.ones_like(self.Utrain[:, :1]), self.Utrain], dim=1)[None].contiguous()
+        # The likelihood is evaluated in FIT_DTYPE (fp64) whatever the model's dtype: K_b has no noise term, so a model
+        # that fits well has cond(K_b) ~ N s2 / jitter ~ 1e7..1e8 -- beyond fp32.  In fp32 the factorisation then fails at
+        # the base jitter level, the x10 retries change the OBJECTIVE from one iteration to the next and a fit could end
+        # worse than it started (round 3, N >= 384).  The parameters, their gradients and the prediction stay in the
+        # model's dtype; only the N x N work of an iteration is carried out in fp64 (SURVEY 8b: "fp32 may accumulate in fp64").
+        wd = self.FIT_DTYPE or self.dtype
+        hp = {k: v.to(wd) for k, v in self._hyper().items()}
+        X = self.Xtrain.to(wd)[None]
+        UH = torch.cat([torch.ones_like(self.Utrain[:, :1]), self.Utrain], dim=1).to(wd)[None].contiguous()
         N, n = self.Xtrain.shape
         Y = self.XdotTrain
         if perturb_targets:
             Y = Y * (1 + 1e-6 * torch.rand_like(Y))                                # :318-321
-        Y = Y[None].contiguous()
+        Y = Y.to(wd)[None].contiguous()
         # jitter schedule of make_psd (1e-5 rand, x10 on a failed pivot).  Inside one fit() an iteration starts ONE level
         # below the level that last worked, never below 1e-5 (`_fit_jitter`): in fp32 the first level fails at every
         # iteration of a well-fitted model and each failed attempt is a whole factorisation, but a level raised at a
@@ -369,7 +377,7 @@ class ControlAffineRegressor:
         # inflated jitter while `_state()` (make_psd's own schedule, from 1e-5) predicts with a smaller one
         factor = max(1e-5, (getattr(self, "_fit_jitter", None) or 1e-5) / 10)
         for ntry in range(10):
-            jit = (factor * self.rand_fn(N))[None].contiguous() if jitter is None else jitter
+            jit = (factor * self.rand_fn(N)).to(wd)[None].contiguous() if jitter is None else jitter.to(wd)
             Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit)
             if int(info[0]) == 0:
                 break
@@ -396,8 +404,8 @@ class ControlAffineRegressor:
         gM0 = UHtA[0] @ Ainv                                                       # d log p / dM0  [C,n]
         torch.autograd.backward(
             [ell, s2, A, B, M0],
-            [(-scale * g_ell[0]).reshape(ell.shape), (-scale * g_s2[0]).reshape(s2.shape), -scale * gA,
-             -scale * g_B[0], -scale * gM0])
+            [(-scale * g_ell[0]).reshape(ell.shape).to(ell.dtype), (-scale * g_s2[0]).reshape(s2.shape).to(s2.dtype),
+             (-scale * gA).to(A.dtype), (-scale * g_B[0]).to(B.dtype), (-scale * gM0).to(M0.dtype)])
         loss = float(nll) * scale
         if self.gamma_length_scale_prior is not None:                              # GammaPrior on the lengthscale (:164-171)
             c, r = self.gamma_length_scale_prior
@@ -974,17 +982,18 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         come from `bcbf_mll_grad_rbflin` on the expanded system (one target column)."""
         m = self.model
         ell, s2, lin, Sigma, M0 = m.lengthscale, m.outputscale, m.variance, m.Sigma, m.M0
-        hp = self._hyper()
+        wd = self.FIT_DTYPE or self.dtype                 # the likelihood in fp64 whatever the model's dtype (see the matrix-variate class)
+        hp = {k: v.to(wd) for k, v in self._hyper().items()}
         n = self.x_dim
-        Xe, UHe, UH = self._expand(self.Xtrain, self.Utrain)
+        Xe, UHe, UH = self._expand(self.Xtrain.to(wd), self.Utrain.to(wd))
         Ne, Ce = Xe.shape[0], UHe.shape[1]
         Y = self.XdotTrain
         if perturb_targets:
             Y = Y * (1 + 1e-6 * torch.rand_like(Y))
-        Ye = (Y - UH @ hp["M0"]).reshape(1, Ne, 1).contiguous()
+        Ye = (Y.to(wd) - UH @ hp["M0"]).reshape(1, Ne, 1).contiguous()
         factor = max(1e-5, (getattr(self, "_fit_jitter", None) or 1e-5) / 10)   # (decaying level: see the matrix-variate class)
         for ntry in range(10):
-            jit = (factor * self.rand_fn(Ne))[None].contiguous() if jitter is None else jitter
+            jit = (factor * self.rand_fn(Ne)).to(wd)[None].contiguous() if jitter is None else jitter.to(wd)
             Kb = ops.kb_build(Xe[None], UHe[None], hp["Bm"], hp["ell"], hp["s2"], jit, lin=hp["lin"])
             Lop, info, _ = ops.potrf(Kb)
             if int(info[0]) == 0:
@@ -1004,8 +1013,8 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         gM0 = UHtA[0, :, 0].reshape(1 + self.u_dim, n)                                     # d log p / d M0 [1+m, n]
         torch.autograd.backward(
             [ell, s2, lin, Sigma, M0],
-            [(-scale * g_ell[0].sum()).reshape(ell.shape), (-scale * g_s2[0]).reshape(s2.shape),
-             (-scale * g_lin[0]).reshape(lin.shape), -scale * g_B[0], -scale * gM0])
+            [(-scale * g_ell[0].sum()).reshape(ell.shape).to(ell.dtype), (-scale * g_s2[0]).reshape(s2.shape).to(s2.dtype),
+             (-scale * g_lin[0]).reshape(lin.shape).to(lin.dtype), (-scale * g_B[0]).to(Sigma.dtype), (-scale * gM0).to(M0.dtype)])
         loss = float(nll) * scale
         if self.gamma_length_scale_prior is not None:
             c, r = self.gamma_length_scale_prior

@@ -312,3 +312,73 @@ def speed_test_matrix_vector_exp(max_train_variations=(256, 256 + 64, 256 + 128,
                 logger.add_scalars(name, dict(elapsed=elapsed), max_train)
                 logger.add_tensors(name, dict(errors=np.asarray(errors)), max_train)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# The run-script entry points (`run.sh:17-21` calls them by name): experiment half + the NUMBERS half of the reference's
+# `_vis` functions (what they read back from the event file and write next to it).  The plotting half (matplotlib figures,
+# LaTeX labels, xdg-open) is out of scope (SURVEY 2 / DESIGN 8).
+def _newest_events_file(logs_dir):
+    import glob
+    import os
+    return max(glob.glob(os.path.join(logs_dir, "*.tfevents*")), key=lambda f: os.stat(f).st_mtime)
+
+
+def learn_dynamics_matrix_vector_vis(exps=("matrix", "vector"), events_file=None):
+    """pendulum.py:1215-1242 without the figure: reads the logged grids back from the event file, computes the
+    variance-weighted error of every experiment (`measure_batch_error` on the per-point covariance blocks, :1121-1139) and
+    writes them to `vector_matrix_learning_error.txt` beside the event file in the reference's format (one row, %.03f,
+    header = names).  Returns (error_file, {name: error})."""
+    import os.path as osp
+    import numpy as np
+    from .tblog import load_tensorboard_scalars
+    logdata = load_tensorboard_scalars(events_file)
+    errors = dict()
+    for exp in exps:
+        key = "log_learned_model/" + exp + "/Fx/"
+        logged = dict(FX_learned=logdata[key + "FX_learned"][0][1], var_FX=logdata[key + "var_FX"][0][1],
+                      FX_true=logdata[key + "FX_true"][0][1])
+        errors[exp] = float(learned_model_error(logged))
+    error_file = osp.join(osp.dirname(events_file), "vector_matrix_learning_error.txt")
+    np.savetxt(error_file, [[errors[e] for e in exps]], fmt="%.03f", header=" ".join(exps))
+    return error_file, errors
+
+
+def learn_dynamics_matrix_vector(logger_class=None, **kw):
+    """pendulum.py:1244-1246: the experiment (`learn_dynamics_matrix_vector_exp`, logged under `data/runs/
+    learn_matrix_vector_<version>` unless `logger_class` says otherwise), then the numbers of `_vis`.  Returns the event
+    file, as the reference's `_exp` does."""
+    from functools import partial
+    from .tblog import TBLogger
+    logger = (logger_class or partial(TBLogger, exp_tags=["learn_matrix_vector"], runs_dir="data/runs"))()
+    res = learn_dynamics_matrix_vector_exp(logger=logger, **kw)
+    events_file = _newest_events_file(logger.experiment_logs_dir)
+    learn_dynamics_matrix_vector_vis(exps=tuple(res), events_file=events_file)
+    return events_file
+
+
+def speed_test_matrix_vector_vis(events_file, exp_conf=("vectordiag", "matrixdiag", "vector", "matrix")):
+    """pendulum.py:1396-1430 without the figure: {name: dict(training_samples, elapsed [s per call], errors)} read back
+    from the event file (tags `<name>/elapsed`, `<name>/errors`)."""
+    from .tblog import load_tensorboard_scalars
+    logdata = load_tensorboard_scalars(events_file)
+    out = dict()
+    for gp in exp_conf:
+        if gp + "/elapsed" not in logdata:
+            continue
+        training_samples, elapsed = zip(*logdata[gp + "/elapsed"])
+        _, errors = zip(*logdata[gp + "/errors"])
+        out[gp] = dict(training_samples=list(training_samples), elapsed=list(elapsed), errors=list(errors))
+    return out
+
+
+def speed_test_matrix_vector(logger_class=None, **kw):
+    """pendulum.py:1433-1435: the published speed test (`speed_test_matrix_vector_exp`, logged under `data/runs/
+    speed_test_matrix_vector_<version>`), then the read-back of `_vis`.  Returns the event file."""
+    from functools import partial
+    from .tblog import TBLogger
+    logger = (logger_class or partial(TBLogger, exp_tags=["speed_test_matrix_vector"], runs_dir="data/runs"))()
+    speed_test_matrix_vector_exp(logger=logger, **kw)
+    events_file = _newest_events_file(logger.experiment_logs_dir)
+    speed_test_matrix_vector_vis(events_file)
+    return events_file

@@ -404,7 +404,10 @@ def main():
                        "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
                        "regime": "shared GP (S)", "inputs": args.variant, "schedule": schedule,
                        "parallelism": "closed loops sharded, dp%d" % world},
-            "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
+            "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3]),
+                       # `value` counts every instance-step the hot path ran (posterior + terms + solve attempt); this is
+                       # the share of them whose program was solved (the rest are infeasible: the oracle agrees)
+                       "solved_instance_steps_per_s": value * float(stats[1]) / total_instances},
             "comm": comm,
             "timed_region": region,
             "roofline": {"bound": "mfma", "kernel": shared_kernel,
@@ -457,7 +460,10 @@ def main():
                                    "CBCs) + SOCP per step, independent GP per instance",
                        "N_train": N, "state_dim": n, "ctrl_dim": m, "batch_per_gpu": Bt, "constraints": K,
                        "regime": "independent GPs (I)", "inputs": args.variant, "schedule": schedule, "parallelism": "instances sharded, dp%d" % world},
-            "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3])},
+            "solver": {"optimal_fraction": float(stats[1]) / total_instances, "mean_iters": float(stats[3]),
+                       # `value` counts every instance-step the hot path ran (posterior + terms + solve attempt); this is
+                       # the share of them whose program was solved (the rest are infeasible: the oracle agrees)
+                       "solved_instance_steps_per_s": value * float(stats[1]) / total_instances},
             "comm": comm,
             "timed_region": region,
             "roofline": {"bound": "hbm", "kernel": "posterior_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

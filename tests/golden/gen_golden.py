@@ -702,6 +702,82 @@ def main_eigfired():
     gen_eigfired("n3m2_N24", n=3, m=2, N=24, seed=83, kind="generic")
 
 
+# ----------------------------------------------------------------------------------------------
+# bayes_cbf/misc.py helper surface (t_jac, t_hessian, get_affine_terms, get_quadratic_terms, torch_kron, epsilon,
+# store_args, DynamicsModel.forward / step / F_func, ZeroDynamicsModel) and cbc2_quadratic_terms on a callable that is
+# plain torch (hand-made GaussianProcess leaves): recorded from the executed reference.
+def gen_misc():
+    import bayes_cbf.misc as rm
+    import bayes_cbf.gp_algebra as rga
+    torch.manual_seed(5)
+    out = {}
+    n = 3
+    W = torch.randn(4, n)
+    x = torch.randn(n)
+    fvec = lambda z: torch.tanh(W @ z) * (z @ z)
+    with rm.variable_required_grad(x) as xg:
+        out["jac_vec"] = t2n(rm.t_jac(fvec(xg), xg))
+        out["jac_scalar"] = t2n(rm.t_jac(fvec(xg).sum(), xg))
+    out.update(W=t2n(W), x=t2n(x))
+    P = torch.randn(n, n)
+    xp = torch.randn(n)
+    f2 = lambda a, b: torch.sin(a @ P @ b) + (a * a) @ (b * b)
+    out.update(P=t2n(P), xp=t2n(xp), hess=t2n(rm.t_hessian(f2, x.clone(), xp.clone())))
+    Qm, pv, r0 = torch.randn(n, n), torch.randn(n), 0.7          # Qm NOT symmetric: get_quadratic_terms does not symmetrise
+    quad = lambda z: z @ Qm @ z + pv @ z + r0
+    aff = lambda z: pv @ z + r0
+    q, l, c = rm.get_quadratic_terms(quad, x.clone())
+    a, b = rm.get_affine_terms(aff, x.clone())
+    out.update(Qm=t2n(Qm), pv=t2n(pv), r0=r0, quad_Q=t2n(q), quad_p=t2n(l), quad_r=t2n(c), aff_a=t2n(a), aff_b=t2n(b))
+    A5, B5 = torch.randn(5, 2, 2), torch.randn(5, 3, 3)
+    A0, B0 = torch.randn(2, 3), torch.randn(3, 2)
+    out.update(kron_A=t2n(A5), kron_B=t2n(B5), kron_AB=t2n(rm.torch_kron(A5, B5)), kron_A0=t2n(A0), kron_B0=t2n(B0),
+               kron_AB0=t2n(rm.torch_kron(A0, B0, batch_dims=0)))
+    out["epsilon"] = np.array([rm.epsilon(i) for i in (0, 10, 500, 1000)] + [rm.epsilon(3, interpolate={0: 2.0, 10: 0.5})])
+    out["normalize_radians"] = np.array([rm.normalize_radians(v) for v in (-7.0, -3.2, 0.0, 3.2, 9.5)])
+
+    class Plant(rm.DynamicsModel):
+        ctrl_size, state_size = 2, 3
+        f_func = lambda self, X: torch.sin(X) * 0.5
+        g_func = lambda self, X: torch.stack([torch.cos(X), X * 0.3], dim=-1)
+    pl = Plant()
+    Xb, Ub = torch.randn(4, 3), torch.randn(4, 2, 1)
+    out.update(dyn_X=t2n(Xb), dyn_U=t2n(Ub), dyn_fwd_batch=t2n(pl.forward(Xb, Ub)), dyn_fwd_single=t2n(pl.forward(Xb[0], Ub[0, :, 0])),
+               dyn_F=t2n(pl.F_func(Xb)))
+    pl.set_init_state(Xb[1])
+    s1 = pl.step(Ub[1, :, 0], 0.05)
+    s2 = pl.step(Ub[2, :, 0], 0.05)
+    out.update(dyn_step_x=np.stack([t2n(s1["x"]), t2n(s2["x"])]), dyn_step_xdot=np.stack([t2n(s1["xdot"]), t2n(s2["xdot"])]))
+    z = rm.ZeroDynamicsModel(2, 3)
+    out.update(zero_f=t2n(z.f_func(Xb)), zero_g=t2n(z.g_func(Xb)), zero_f1=t2n(z.f_func(Xb[0])), zero_g1=t2n(z.g_func(Xb[0])))
+
+    class Store:
+        @rm.store_args
+        def __init__(self, a, b=2, c="see"):          # (a keyword-only default trips a bug in the reference, misc.py:64)
+            self.ran = True
+    st = Store(1, c="given")
+    out["store_args"] = np.array([str(getattr(st, k, "<unset>")) for k in ("a", "b", "c", "ran")])
+    # cbc2_quadratic_terms on a plain-torch callable u -> GP (hand-made leaves; affine mean / quadratic kernel in u)
+    Pm = dict(W1=t2n(torch.randn(n, n)), A1=None)
+    A1 = torch.randn(n, n)
+    A1 = A1 @ A1.t() + torch.eye(n)
+    G = torch.randn(n, 2)
+    rbf = lambda a, b: torch.exp(-0.5 * ((a - b) ** 2).sum())
+
+    def cbc(u):
+        uh = torch.cat([torch.ones(1), u])
+        f = rga.GaussianProcess(lambda z: torch.sin(W[:n] @ z) + G @ u, lambda a, b: rbf(a, b) * A1 * (uh @ uh), (n,), name="fu")
+        d = rga.DeterministicGP(lambda z: torch.tanh(z), shape=(n,), name="d")
+        return d.t() @ f
+    u0 = torch.rand(2)
+    from bayes_cbf.cbc2 import cbc2_quadratic_terms as rq
+    (mA, mb), (kQ, kp, kr), mean, var = rq(cbc, x.clone(), u0)
+    out.update(cbc_A1=t2n(A1), cbc_G=t2n(G), cbc_u0=t2n(u0), cbc_mean_A=t2n(mA), cbc_mean_b=t2n(mb), cbc_Q=t2n(kQ), cbc_p=t2n(kp),
+               cbc_r=t2n(kr), cbc_mean=t2n(mean), cbc_var=t2n(var))
+    np.savez_compressed(os.path.join(HERE, "misc_surfaces.npz"), **{k: v for k, v in out.items() if v is not None})
+    print("misc_surfaces:", sorted(out))
+
+
 def gen_facade():
     """Small host-side surfaces of the path, recorded from the executed reference:
     HetergeneousMatrixVariateMean.forward (matrix_variate_multitask_model.py:44-66) on observation rows, matrix rows, a
@@ -757,6 +833,8 @@ if __name__ == '__main__':
         gen_facade()
     elif 'eigfired' in sys.argv:
         main_eigfired()
+    elif 'misc' in sys.argv:
+        gen_misc()
     elif 'gp_algebra' in sys.argv:
         main_gp_algebra()
     elif 'cogp' in sys.argv:
