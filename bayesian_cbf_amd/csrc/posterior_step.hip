@@ -124,7 +124,7 @@ template <> struct Mfma16<double> {
 // [N, n]; no Gram / mean.  C = number of solved columns (>= n; extra columns are zero).
 template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false>
 __global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256),
-                                   (NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
+                                   (NJ > 0 ? (sizeof(T) == 8 || C * (1 + NJ) > 12 || NJ > 3 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
@@ -156,8 +156,12 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // matrix-core product of step 2b
     constexpr bool MG = NJ > 0 || NQ > 1;                      // Gram / mean sums on the matrix cores (the forms with
                                                                // many right-hand-side columns: jets, several queries)
-    constexpr int CW = MG ? 16 : CP;
-    static_assert(!MG || CT + NS <= 16 || CT + NJ <= 16, "[W, Vw] must fit the 16 rows of one MFMA tile");
+    // ... in one 16-column tile when CT + n <= 16 (every shape up to the unicycle's n=3, m=2), in two otherwise
+    // (n=3 m=3, n=4 m=2, n=4 m=3: CT = 16, 15, 20): the product is then 2 x 2 accumulators
+    constexpr int NEEDW = CT + (NJ > 0 ? NJ : NS);
+    constexpr int NT = MG ? (NEEDW + 15) / 16 : 1;
+    constexpr int CW = MG ? 16 * NT : CP;
+    static_assert(NT <= 2, "[W, Vw] must fit 32 tile columns");
     __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
     __shared__ __attribute__((aligned(16))) T wbuf[NB][CW];
 
@@ -291,7 +295,11 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     for (int d = 0; d < (MG ? 1 : NS); ++d)
 #pragma unroll
         for (int c = 0; c < (MG ? 1 : CT); ++c) mk[d][c] = T(0);
-    typename Mfma16<T>::acc_t gacc = {T(0), T(0), T(0), T(0)};      // jets: [W, Vw]' [W, Vw] summed over all rows
+    typename Mfma16<T>::acc_t gacc[NT][NT];                         // jets: [W, Vw]' [W, Vw] summed over all rows
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) gacc[ti][tj] = typename Mfma16<T>::acc_t{T(0), T(0), T(0), T(0)};
     if constexpr (MG) {                                             // columns CT + n .. 15 of the tile stay zero
         for (int i = tid; i < NB * CW; i += blockDim.x) wbuf[i / CW][i % CW] = T(0);
     }
@@ -301,7 +309,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
-    constexpr int UNR = NJ > 0 ? (sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
+    constexpr int UNR = NJ > 0 ? (CT > 12 ? 2 : sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
                                : (NQ > 1 ? (sizeof(T) == 8 ? 2 : BCBF_PQ_UNR) : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
@@ -489,8 +497,13 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 const int kq = tid >> 4, ci = tid & 15;
 #pragma unroll
                 for (int s8 = 0; s8 < NB / 4; ++s8) {
-                    const T a = wbuf[4 * s8 + kq][ci];
-                    gacc = Mfma16<T>::mac(a, a, gacc);
+                    T a[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a[t] = wbuf[4 * s8 + kq][16 * t + ci];
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < NT; ++tj) gacc[ti][tj] = Mfma16<T>::mac(a[ti], a[tj], gacc[ti][tj]);
                 }
             }
         }
@@ -517,7 +530,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     if constexpr (MG && NJ > 0) {
         // jets: every lane of wave 0 writes its four entries (i = row(l / 16, r), j = l % 16) of [W, Vw]'[W, Vw]
         if (tid < 64) {
-            const int j = tid & 15, grp = tid >> 4;
+            const int grp = tid >> 4;
             T* Gb = Gfull + (size_t)b * CT * CT;
             T* Mb = Mfull + (size_t)b * n * CT;
             const T* M0b = M0 + (size_t)gb * C * n;
@@ -525,9 +538,13 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             T* Mkb = Mk + (size_t)b * n * C;
             T* Bkb = Bk + (size_t)b * C * C;
 #pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = Mfma16<T>::row(grp, r);
-                const T val = gacc[r];
+                const int i = 16 * ti + Mfma16<T>::row(grp, r), j = 16 * tj + (tid & 15);
+                const T val = gacc[ti][tj][r];
                 if (j < CT) {
                     if (i < CT) {
                         Gb[i * CT + j] = val;
@@ -566,7 +583,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = Mfma16<T>::row(grp, r);
-                    const T val = gacc[r];
+                    const T val = gacc[0][0][r];
                     if (i >= qi * C && i < qi * C + C) {
                         const int a = i - qi * C;
                         double v = kss * (double)Bmb[a * C + c] - (double)val;
@@ -675,11 +692,22 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     }
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
         if (!Mfull || lin || kind != 0) return BCBF_EINVAL;
-        if (n == 2 && m == 1) BCBF_PJ_LAUNCH(2, 2);
-        else if (n == 3 && m == 2) BCBF_PJ_LAUNCH(3, 3);
-        else if (n == 2 && m == 2) BCBF_PJ_LAUNCH(3, 2);
-        else if (n == 1 && m == 1) BCBF_PJ_LAUNCH(2, 1);
-        else return BCBF_EINVAL;
+        if (n > 4) return BCBF_EINVAL;                  // (the rel-degree-2 terms kernel holds n <= 4 too)
+        switch (10 * n + m) {                           // every (n <= 4, m <= 3): C = 1 + m columns x (1 + n) jets
+            case 11: BCBF_PJ_LAUNCH(2, 1); break;
+            case 12: BCBF_PJ_LAUNCH(3, 1); break;
+            case 13: BCBF_PJ_LAUNCH(4, 1); break;
+            case 21: BCBF_PJ_LAUNCH(2, 2); break;
+            case 22: BCBF_PJ_LAUNCH(3, 2); break;
+            case 23: BCBF_PJ_LAUNCH(4, 2); break;
+            case 31: BCBF_PJ_LAUNCH(2, 3); break;
+            case 32: BCBF_PJ_LAUNCH(3, 3); break;
+            case 33: BCBF_PJ_LAUNCH(4, 3); break;
+            case 41: BCBF_PJ_LAUNCH(2, 4); break;
+            case 42: BCBF_PJ_LAUNCH(3, 4); break;
+            case 43: BCBF_PJ_LAUNCH(4, 4); break;
+            default: return BCBF_EINVAL;
+        }
     } else if (BCBF_PS_NQ > 1 && shared && sizeof(T) == 8 && n <= 4 && m <= 2 && Bt >= 2 * BCBF_PS_NQ) {
       if constexpr (sizeof(T) == 8) {
         // fp64, one model, many queries: BCBF_PS_NQ queries per workgroup share the stream of L

@@ -320,7 +320,7 @@ int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double*
  * (Np = N rounded up to 32), from which the caller forms derivative kernels between two DIFFERENT states,
  * d/dx_d d/dx'_e B_k(x,x') = d2k/dx_d dx'_e Bm - dW_d(x)'dW_e(x')  (GradientGP.knl(x, x'), gp_algebra.py:355-393).
  * Replaces autograd through custom_predict inside GradientGP (gp_algebra.py:340-402).
- * Compiled for (n,m) in {(1,1),(2,1),(2,2),(3,2)}. */
+ * Every (n <= 4, m <= 3) is compiled (shapes with (1+m)(1+n) + n > 16 use two matrix-core tile columns). */
 int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
                             const float* ell, const float* s2, const float* Bm, const float* M0,
                             const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj, int shared,

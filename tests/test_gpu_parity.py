@@ -1247,11 +1247,14 @@ def test_syrk_kb_inverse_and_deterministic_likelihood_gradient(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (2, 2), (3, 2)])
+@pytest.mark.parametrize("n,m", [(n_, m_) for n_ in (1, 2, 3, 4) for m_ in (1, 2, 3)])
 def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n, m, dtype):
-    """The jets instantiations (Gram / mean sums on the matrix-core accumulator of wave 0) for all four compiled (n, m) and
-    for training sizes that take one wave, several waves and a ragged last block per workgroup, against the oracle's
-    jets: M_k, B_k, dM_k/dx, dW_d'W, dW_d'dW_e, and the Wj output against the oracle's triangular solves."""
+    """The jets instantiations (Gram / mean sums on the matrix-core accumulators of wave 0) for EVERY (n <= 4, m <= 3) --
+    wherever the value kernels and the rel-degree-2 terms kernel work (gp_algebra.py:319-402, cbc2.py:26-33 hold for any
+    state / control dimension); (3,3), (4,2), (4,3) have more than 16 tile columns and run the 2 x 2 accumulator form --
+    and for training sizes that take one wave, several waves and a ragged last block per workgroup, against the oracle's
+    jets: M_k, B_k, dM_k/dx, dW_d'W, dW_d'dW_e, the Wj output against the oracle's triangular solves, and the
+    rel-degree-2 terms of a random quadratic barrier formed from those jets (bcbf_cbc2_terms) against the oracle's."""
     import scipy.linalg as sla
     from oracle import cbc2 as oc2
     from bayesian_cbf_amd.synthetic import make_instances
@@ -1291,3 +1294,36 @@ def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n
             d0 = -(hxq[i][0] - hX[i][:, 0]) / h["ell"][i][0] ** 2 * kstar
             dW_o = sla.solve_triangular(st["L"], d0[:, None] * st["UHB"], lower=True)
             rel_close(host(Wj)[i, :N, C:2 * C], dW_o, tol, scale=max(np.abs(dW_o).max(), 1e-3), what="Wj d/dx0")
+        # rel-degree-2 terms from these jets: h(x) = 1/2 x'Px + q'x - 1 with a random symmetric P
+        rng = np.random.RandomState(7 * n + m + N)
+        P = rng.randn(n, n)
+        P = 0.5 * (P + P.T) + n * np.eye(n)
+        qv, u0, ka = rng.randn(n), rng.rand(Bt, m), np.array([1.0, 3.0])
+        hv = np.array([0.5 * x_ @ P @ x_ + qv @ x_ - 1.0 for x_ in hxq])
+        gh = np.stack([P @ x_ + qv for x_ in hxq])
+        Hh = np.broadcast_to(P, (Bt, n, n)).copy()
+        (mA, mb), (Q, pp, r), mean, var, status = ops.cbc2_terms(
+            Mk, Bk, G, Mj, p["A"], p["Bm"], p["ell"], p["s2"], dev(hv, dtype), dev(gh, dtype), dev(Hh, dtype), dev(ka, dtype),
+            dev(u0, dtype))
+        assert (status == 0).all()
+        ttol = 1e-7 if f64 else 1e-4
+        for i in range(Bt):
+            st = ogp.refit_state(hX[i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i], hj[i][None] / 1e-5)
+            jets = oc2.posterior_jets(st["L"], st["Y"], hX[i], st["UHB"], h["ell"][i], float(h["s2"][i]), h["Bm"][i], h["M0"][i], hxq[i])
+            if not f64:
+                # fp32: the jets were held to 2e-3 of their scale above; the terms are differences of products of them, so
+                # the terms KERNEL is checked on the jets it was given (the device's, widened to fp64)
+                Gh, Mjh = host(G)[i], host(Mj)[i]
+                blk = lambda d: slice((1 + d) * C, (2 + d) * C)
+                jets = dict(Mk=host(Mk)[i], Bk=host(Bk)[i], dMk=np.stack([Mjh[:, blk(d)] for d in range(n)]),
+                            G10=np.stack([Gh[blk(d), :C] for d in range(n)]),
+                            G11=np.stack([np.stack([Gh[blk(d), blk(e)] for e in range(n)]) for d in range(n)]))
+            (oA, ob), (oQ, op_, or_), omean, ovar = oc2.cbc2_terms(jets, h["A"][i], h["Bm"][i], h["ell"][i], float(h["s2"][i]),
+                                                                   float(hv[i]), gh[i], Hh[i], ka, u0[i])
+            for name, val, ref in (("mean_A", mA, oA), ("mean_b", mb, ob), ("Q", Q, oQ), ("p", pp, op_), ("r", r, or_),
+                                   ("mean", mean, omean), ("var", var, ovar)):
+                ref = np.asarray(ref)
+                # (the variance polynomial's coefficients cancel against one another: one scale for Q, p, r, var)
+                vs = max(np.abs(oQ).max(), np.abs(op_).max(), abs(float(or_)), abs(float(ovar)), 1e-2)
+                ms = max(np.abs(oA).max(), abs(float(ob)), abs(float(omean)), 1e-2)
+                rel_close(host(val)[i].reshape(ref.shape), ref, ttol, scale=ms if name.startswith("mean") else vs, what=name)
