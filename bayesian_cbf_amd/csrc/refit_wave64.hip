@@ -29,6 +29,7 @@
 // 0.63 -> 0.45 ms at 1024 x 256, 10.7 -> 8.2 ms at 4096 x 512 (same box).  (The same rewrite LOSES in the
 // workgroup-form kernels, refit_mfma*.hip: they run four waves per SIMD against a 128 / 256-register cap, waits are
 // hidden by the other waves and the extra values in flight spill.)
+#include <type_traits>
 #include "bcbf_common.h"
 #ifdef BCBF_RP_TRACE
 // time stamps inside the diagonal tile's factor + inverse (first call of workgroup 0 only), after the hand-off stamps
@@ -59,6 +60,24 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #ifndef BCBF_RW32_PAIRS
 #define BCBF_RW32_PAIRS 1        // two tiles of a block column per pass of the update stream (shared A operand)
 #endif
+#ifndef BCBF_RW32_SUPER
+#define BCBF_RW32_SUPER 1        // fp32, N >= 512: TWO block columns per pass (64-column super-panels, 2 x 2 tiles per stream pass): the
+                                 // panels left of a super-panel are streamed once per 64 columns instead of once per 32.  Measured
+                                 // (ms off / on): 4096 x 1024 27.4 / 21.8, 1024 x 512 1.03 / 0.98, 4096 x 512 3.79 / 3.67 (FETCH_SIZE 17.3 ->
+                                 // 14.2 GB at two waves per SIMD, 11.0 GB at one); N = 256: 4096 x 256 0.70 / 0.82 -- too few columns
+                                 // left of a super-panel to pay for the wider working set: off below N = 512
+#endif
+#ifndef BCBF_RW32_SUPER_KS
+#define BCBF_RW32_SUPER_KS 4     // k-steps per pipeline stage of the four-stream pass (1 / 2 / 4 / 8 measured: 4 and 8 level, 1 loses 30 %)
+#endif
+#ifndef BCBF_RW32_SUPER_DIAG3
+#define BCBF_RW32_SUPER_DIAG3 1  // 1: the three tiles of the diagonal 2 x 2 block in one stream pass; 0: the diagonal tile by itself first (measured:
+                                 // more scratch, not less -- the extra stream instantiation costs more than the two tiles it parks)
+#endif
+#ifndef BCBF_RW32_SUPER_AHEAD
+#define BCBF_RW32_SUPER_AHEAD 0  // 1: row inputs of the next tile pair loaded before the stream pass -- 36 registers live across it; at two waves
+                                 // per SIMD that is 80 B more scratch and 4096 x 512 runs 3.95 instead of 3.67 ms
+#endif
 #ifndef BCBF_RW64_PAIRS
 #define BCBF_RW64_PAIRS 0        // fp64: measured slower below N = 1024 (4096 x 512: 8.15 against 7.4 ms; 1024 x 1024: 14.1 against 14.7)
 #endif
@@ -77,11 +96,13 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 
 constexpr int RW_WPB = BCBF_RW64_WPB;
 
-template <typename T> struct RWShared {
+template <typename T, bool SUP = false> struct RWShared {
     DiagTile<T> d;                            // the diagonal tile's working set (diag_tile64.h)
     T colX[NB][BCBF_MAX_STATE_DIM];
     T colUH[NB][BCBF_MAX_CTRL_DIM + 1];
     unsigned pack_rc[LOP_DB / 2];             // (row, column) of the entries of a packed inverted diagonal block, two per word
+    T colX2[SUP ? NB : 1][BCBF_MAX_STATE_DIM];          // second block column of a super-panel (fp32 one-wave form)
+    T colUH2[SUP ? NB : 1][BCBF_MAX_CTRL_DIM + 1];
 };
 // packed lower triangle, column-major: entry k <-> (r, c), r >= c; (r | c << 8) per entry, 0xffff = the block's padding
 __device__ inline void rw_pack_table(__attribute__((address_space(3))) unsigned* tab, int tid, int nthreads) {
@@ -149,7 +170,9 @@ template <> struct RW<float> {
     __device__ static float2 bload2(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 };
 
-template <typename T, bool FROM_DENSE, int OCC>
+// SUP (fp32): the super-panel form (two block columns per pass, N >= 512) -- its own instantiation, so that the plain form
+// keeps the registers and the LDS it had (compiled into one kernel, 4096 x 256 went from 0.70 to 0.79 ms for code it never runs)
+template <typename T, bool FROM_DENSE, int OCC, bool SUP = false>
 __global__ void __launch_bounds__(64 * RW_WPB, OCC)
 refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                     const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
@@ -159,12 +182,13 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     using P = RW<T>;
     using acc_t = typename P::acc_t;
     using T2 = typename P::vec2;
-    __shared__ RWShared<T> shm[RW_WPB];
+    static_assert(!SUP || (sizeof(T) == 4 && BCBF_RW32_PAIRS), "the super-panel form is the fp32 pair path's");
+    __shared__ RWShared<T, SUP> shm[RW_WPB];
     // wave-uniform instance index: the per-instance pointers and hyper-parameters then live in SGPRs (scalar loads)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x * RW_WPB + wave;
     if (b >= Bt) return;                                      // whole wave: no workgroup barrier anywhere below
-    __attribute__((address_space(3))) RWShared<T>& sh = *(__attribute__((address_space(3))) RWShared<T>*)&shm[wave];   // keep ds_* ops
+    __attribute__((address_space(3))) RWShared<T, SUP>& sh = *(__attribute__((address_space(3))) RWShared<T, SUP>*)&shm[wave];   // keep ds_* ops
     const int j16 = lane & 15, g = lane >> 4;                 // MFMA roles
 
     T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
@@ -234,6 +258,22 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             for (int t = 0; t < SX; ++t) { const int e = lane + 64 * t; sh.colX[e / BCBF_MAX_STATE_DIM][e % BCBF_MAX_STATE_DIM] = sx[t]; }
 #pragma unroll
             for (int t = 0; t < SU; ++t) { const int e = lane + 64 * t; sh.colUH[e / (BCBF_MAX_CTRL_DIM + 1)][e % (BCBF_MAX_CTRL_DIM + 1)] = su[t]; }
+            if (SUP && J + 1 < nblk) {      // super-panel: the inputs of block column J + 1 too
+#pragma unroll
+                for (int t = 0; t < SX; ++t) {
+                    const int e = lane + 64 * t, c = e / BCBF_MAX_STATE_DIM, d = e % BCBF_MAX_STATE_DIM;
+                    sx[t] = P::bload(rsX, (col0 + NB + c < N && d < n) ? ((col0 + NB + c) * n + d) * ES : -ES);
+                }
+#pragma unroll
+                for (int t = 0; t < SU; ++t) {
+                    const int e = lane + 64 * t, c = e / (BCBF_MAX_CTRL_DIM + 1), a = e % (BCBF_MAX_CTRL_DIM + 1);
+                    su[t] = P::bload(rsUH, (col0 + NB + c < N && a < C) ? ((col0 + NB + c) * C + a) * ES : -ES);
+                }
+#pragma unroll
+                for (int t = 0; t < SX; ++t) { const int e = lane + 64 * t; sh.colX2[e / BCBF_MAX_STATE_DIM][e % BCBF_MAX_STATE_DIM] = sx[t]; }
+#pragma unroll
+                for (int t = 0; t < SU; ++t) { const int e = lane + 64 * t; sh.colUH2[e / (BCBF_MAX_CTRL_DIM + 1)][e % (BCBF_MAX_CTRL_DIM + 1)] = su[t]; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
         RW_ACC(0);                                             // column staging
@@ -275,7 +315,9 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
             //      4 control components; zeros beyond n / C, where iell and the row inputs are zero too), ONE read per column for
             //      both rows of the lane.  (With `if (d < n)` around each LDS read every read sat in a basic block of its own
             //      with a full wait behind it: 120 serialized LDS round trips per tile.)
-            auto values = [&](acc_t (&acc)[2][2], const Rows& q, int I) {
+            auto values_s = [&](acc_t (&acc)[2][2], const Rows& q, int I, auto sel) {
+                constexpr int SEL = decltype(sel)::value;          // 0: block column J (colX / colUH), 1: block column J + 1
+                const int col0 = (J + SEL) * NB;                   // (shadows the loop's col0)
                 const int irow = I * NB + 2 * j16;
                 if (FROM_DENSE) {
 #pragma unroll
@@ -300,7 +342,10 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                             const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
                             T cx[4], cu[4];
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
+                            for (int d = 0; d < 4; ++d) {
+                                cx[d] = SEL ? sh.colX2[c][d] : sh.colX[c][d];
+                                cu[d] = SEL ? sh.colUH2[c][d] : sh.colUH[c][d];
+                            }
 #pragma unroll
                             for (int ib = 0; ib < 2; ++ib) {
                                 const int i = irow + ib;
@@ -310,7 +355,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 if (n > 4) {                                          // (wave-uniform; no reference system has n > 4)
                                     for (int d = 4; d < n; ++d) {
                                         const T xi = i < N ? Xb[(size_t)i * n + d] : T(0.0);
-                                        const T z = (xi - sh.colX[c][d]) / ell[(size_t)b * n + d];
+                                        const T z = (xi - (SEL ? sh.colX2[c][d] : sh.colX[c][d])) / ell[(size_t)b * n + d];
                                         d2 += z * z;
                                     }
                                 }
@@ -323,6 +368,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         }
                 }
             };
+            auto values = [&](acc_t (&acc)[2][2], const Rows& q, int I) { values_s(acc, q, I, std::integral_constant<int, 0>{}); };
             // ---- -S' += L_J L_I'  over all previous columns (software pipelined: next stage's operands in flight), for NT = 1 or
             //      2 tiles of the block column at once: the two tiles share the A operand (block row J), so a pair reads three
             //      panels where two single tiles read four -- the batches this form serves are bound by exactly that traffic
@@ -406,7 +452,8 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 }
             };
             // ---- panel:  L_IJ' = inv(L_JJ) S'   (accumulator registers of -S' are the B operands, ainv = -inv(L_JJ))
-            auto solve_store = [&](acc_t (&acc)[2][2], int I) {
+            auto solve_store_s = [&](acc_t (&acc)[2][2], int I, int Jc, const T (&ainv)[2][2][4]) {
+                const int col0 = Jc * NB;                               // (shadows the loop's col0 / ainv)
                 const int irow = I * NB + 2 * j16;
 #pragma unroll
                 for (int cbp = 0; cbp < 2; ++cbp) {                     // (one half of the output columns at a time: 2 results live)
@@ -434,8 +481,11 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 }
             };
 
+            auto solve_store = [&](acc_t (&acc)[2][2], int I) { solve_store_s(acc, I, J, ainv); };
+
             // =================== the diagonal tile: factor L_JJ, invert it ===================
-            auto diag_tile = [&](acc_t (&acc)[2][2]) {
+            auto diag_tile_s = [&](acc_t (&acc)[2][2], int Jc, T (&ainv)[2][2][4]) {
+                const int J = Jc, col0 = Jc * NB;                       // (shadow the loop's J / col0 / ainv)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -481,6 +531,232 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ainv[cbp][cb][r] = -sh.d.xinv[16 * cbp + j16][2 * P::midx(r, g) + cb];   // (acc = -S')
             };
+            auto diag_tile = [&](acc_t (&acc)[2][2]) { diag_tile_s(acc, J, ainv); };
+            if constexpr (SUP) {
+            if (J + 1 < nblk) {
+                // ============ SUPER-PANEL: block columns J and J + 1 in one pass over everything to their left ============
+                // Left-looking with 32-column panels reads, for every tile (I, J), the block rows I and J of all columns
+                // left of J: 2 J panels per tile, 5.4 MB per instance at N = 512 for a 0.5 MB factor -- and with ~2000
+                // instances in flight (1 GB) none of it hits a cache: C3 fp32 fetched 17.3 GB per launch and ran at the
+                // speed of those re-reads (profiles/r03_pmc_traffic_refit.json).  A wave that holds the 2 x 2 tiles
+                // (I, I+1) x (J, J+1) at once reads FOUR block rows (J, J+1, I, I+1) for FOUR tiles: one panel per tile
+                // instead of 1.5 (pairs) or 2 (single tiles).  What a column still owes its left neighbour INSIDE the
+                // super-panel -- tile (I, J+1) needs L_IJ L_{J+1,J}' -- is a 32-deep update from panels this wave has just
+                // stored (L2 / L1 hits), applied after the tiles of column J are solved.
+                const int col1 = col0 + NB;
+                T ainv1[2][2][4];
+                constexpr int KS4 = BCBF_RW32_SUPER_KS;
+                auto negate = [&](acc_t (&acc)[2][2]) { (void)acc; };
+                (void)negate;
+                // -S' += L_a L_b' for k in [k0, k1): one tile, A operand = block row at arow0, B operand = rows of tile I
+                auto update_r = [&](acc_t (&acc)[2][2], int arow0, int I, int k0, int k1) {
+                    constexpr int KS = 4;
+                    const int irow = I * NB + 2 * j16;
+                    T2 a_nxt[KS], b_nxt[KS];
+                    auto fetch = [&](int kk) {
+                        const int K = kk / NB, stride = Np - NB * (K + 1);
+                        const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                        const int va = (g * stride + arow0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_) {
+                            const int so = (base + 4 * s_ * stride) * ES;
+                            a_nxt[s_] = P::bload2(rsL, va, so);
+                            b_nxt[s_] = P::bload2(rsL, vb, so);
+                        }
+                    };
+                    if (k1 > k0) fetch(k0);
+                    for (int kk = k0; kk < k1; kk += 4 * KS) {
+                        T a_cur[KS][2], b_cur[KS][2];
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_) {
+                            a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                            b_cur[s_][0] = b_nxt[s_].x; b_cur[s_][1] = b_nxt[s_].y;
+                        }
+                        if (kk + 4 * KS < k1) fetch(kk + 4 * KS);
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                                for (int ib = 0; ib < 2; ++ib)
+                                    acc[cb][ib] = P::mfma(a_cur[s_][cb], b_cur[s_][ib], acc[cb][ib]);
+                    }
+                };
+                // ... two tiles I, I + 1 of one block column (shared A operand)
+                auto update2_r = [&](acc_t (&acc0)[2][2], acc_t (&acc1)[2][2], int arow0, int I, int k0, int k1) {
+                    constexpr int KS = 4;
+                    const int irow = I * NB + 2 * j16;
+                    T2 a_nxt[KS], b0_nxt[KS], b1_nxt[KS];
+                    auto fetch = [&](int kk) {
+                        const int K = kk / NB, stride = Np - NB * (K + 1);
+                        const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                        const int va = (g * stride + arow0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_) {
+                            const int so = (base + 4 * s_ * stride) * ES;
+                            a_nxt[s_] = P::bload2(rsL, va, so);
+                            b0_nxt[s_] = P::bload2(rsL, vb, so);
+                            b1_nxt[s_] = P::bload2(rsL, vb + NB * ES, so);
+                        }
+                    };
+                    if (k1 > k0) fetch(k0);
+                    for (int kk = k0; kk < k1; kk += 4 * KS) {
+                        T a_cur[KS][2], b0_cur[KS][2], b1_cur[KS][2];
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_) {
+                            a_cur[s_][0] = a_nxt[s_].x; a_cur[s_][1] = a_nxt[s_].y;
+                            b0_cur[s_][0] = b0_nxt[s_].x; b0_cur[s_][1] = b0_nxt[s_].y;
+                            b1_cur[s_][0] = b1_nxt[s_].x; b1_cur[s_][1] = b1_nxt[s_].y;
+                        }
+                        if (kk + 4 * KS < k1) fetch(kk + 4 * KS);
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                                for (int ib = 0; ib < 2; ++ib) {
+                                    acc0[cb][ib] = P::mfma(a_cur[s_][cb], b0_cur[s_][ib], acc0[cb][ib]);
+                                    acc1[cb][ib] = P::mfma(a_cur[s_][cb], b1_cur[s_][ib], acc1[cb][ib]);
+                                }
+                    }
+                };
+                // ... the 2 x 2 tiles (I, I+1) x (J, J+1) over k in [0, col0): four operand streams for four tiles.  NR = 1: only
+                // row block I (the odd tile at the bottom), three streams for two tiles.  I == J + 1 - 1 ... the diagonal 2 x 2
+                // block is the same pass with the B streams BEING the A streams (DIAG: tiles (J,J), (J+1,J), (J+1,J+1); the
+                // fourth accumulator is not used)
+                auto update4 = [&](acc_t (&a00)[2][2], acc_t (&a01)[2][2], acc_t (&a10)[2][2], acc_t (&a11)[2][2], int I, auto nr,
+                                   auto diag) {
+                    constexpr int NR = decltype(nr)::value;
+                    constexpr int DIAG = (int)decltype(diag)::value;      // 1: tiles (J,J), (J+1,J), (J+1,J+1) from the two A streams; 2: the last two
+                    constexpr int KS = KS4;
+                    const int irow = I * NB + 2 * j16;
+                    T2 aj_nxt[KS], ak_nxt[KS], b0_nxt[DIAG ? 1 : KS], b1_nxt[(DIAG || NR < 2) ? 1 : KS];
+                    auto fetch = [&](int kk) {
+                        const int K = kk / NB, stride = Np - NB * (K + 1);
+                        const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (kk - K * NB) * stride;
+                        const int va = (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, vb = (g * stride + irow - NB * (K + 1)) * ES;
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_) {
+                            const int so = (base + 4 * s_ * stride) * ES;
+                            aj_nxt[s_] = P::bload2(rsL, va, so);
+                            ak_nxt[s_] = P::bload2(rsL, va + NB * ES, so);
+                            if constexpr (!DIAG) {
+                                b0_nxt[s_] = P::bload2(rsL, vb, so);
+                                if constexpr (NR == 2) b1_nxt[s_] = P::bload2(rsL, vb + NB * ES, so);
+                            }
+                        }
+                    };
+                    if (col0 > 0) fetch(0);
+                    for (int kk = 0; kk < col0; kk += 4 * KS) {
+                        T aj[KS][2], ak[KS][2], b0[KS][2], b1[KS][2];
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_) {
+                            aj[s_][0] = aj_nxt[s_].x; aj[s_][1] = aj_nxt[s_].y;
+                            ak[s_][0] = ak_nxt[s_].x; ak[s_][1] = ak_nxt[s_].y;
+                            if constexpr (!DIAG) {
+                                b0[s_][0] = b0_nxt[s_].x; b0[s_][1] = b0_nxt[s_].y;
+                                if constexpr (NR == 2) { b1[s_][0] = b1_nxt[s_].x; b1[s_][1] = b1_nxt[s_].y; }
+                            }
+                        }
+                        if (kk + 4 * KS < col0) fetch(kk + 4 * KS);
+#pragma unroll
+                        for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                                for (int ib = 0; ib < 2; ++ib) {
+                                    if constexpr (DIAG != 0) {
+                                        if constexpr (DIAG == 1) a00[cb][ib] = P::mfma(aj[s_][cb], aj[s_][ib], a00[cb][ib]);      // (J,   J)
+                                        a10[cb][ib] = P::mfma(aj[s_][cb], ak[s_][ib], a10[cb][ib]);      // (J+1, J)
+                                        a11[cb][ib] = P::mfma(ak[s_][cb], ak[s_][ib], a11[cb][ib]);      // (J+1, J+1)
+                                    } else {
+                                        a00[cb][ib] = P::mfma(aj[s_][cb], b0[s_][ib], a00[cb][ib]);      // (I,   J)
+                                        a01[cb][ib] = P::mfma(ak[s_][cb], b0[s_][ib], a01[cb][ib]);      // (I,   J+1)
+                                        if constexpr (NR == 2) {
+                                            a10[cb][ib] = P::mfma(aj[s_][cb], b1[s_][ib], a10[cb][ib]);  // (I+1, J)
+                                            a11[cb][ib] = P::mfma(ak[s_][cb], b1[s_][ib], a11[cb][ib]);  // (I+1, J+1)
+                                        }
+                                    }
+                                }
+                    }
+                };
+                using IC0 = std::integral_constant<int, 0>;
+                using IC1 = std::integral_constant<int, 1>;
+                using IC2 = std::integral_constant<int, 2>;
+                // stores of this wave feed loads of other lanes of this wave below: wave scope, program order -- the fence keeps
+                // the compiler from moving the loads up and drains the stores first
+                auto wave_fence = [&]() {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
+                // ---- the diagonal 2 x 2 block
+                load_rows(rw0, J);
+                load_rows(rw1, J + 1);
+                {
+                    acc_t t10[2][2], t11[2][2];
+#if BCBF_RW32_SUPER_DIAG3
+                    acc_t t00[2][2];
+                    values_s(t00, rw0, J, IC0{});
+                    values_s(t10, rw1, J + 1, IC0{});
+                    values_s(t11, rw1, J + 1, IC1{});
+                    load_rows(rw0, J + 2);
+                    load_rows(rw1, J + 3);
+                    update4(t00, t00, t10, t11, J, IC2{}, std::true_type{});
+                    diag_tile_s(t00, J, ainv);
+                    if (fail != 0) break;
+#else
+                    {   // (the diagonal tile by itself first: its factorisation wants the registers the other two tiles would hold)
+                        acc_t t00[2][2];
+                        values_s(t00, rw0, J, IC0{});
+                        update_r(t00, col0, J, 0, col0);
+                        diag_tile_s(t00, J, ainv);
+                        if (fail != 0) break;
+                    }
+                    values_s(t10, rw1, J + 1, IC0{});
+                    values_s(t11, rw1, J + 1, IC1{});
+                    load_rows(rw0, J + 2);
+                    load_rows(rw1, J + 3);
+                    update4(t10, t10, t10, t11, J, IC2{}, std::integral_constant<int, 2>{});
+#endif
+                    solve_store_s(t10, J + 1, J, ainv);                     // L_{J+1,J}
+                    wave_fence();
+                    update_r(t11, col1, J + 1, col0, col1);                 // -= L_{J+1,J} L_{J+1,J}'
+                    diag_tile_s(t11, J + 1, ainv1);
+                    if (fail != 0) break;
+                }
+                // ---- the tiles below it: two block rows x two block columns per pass
+                for (int I = J + 2; I < nblk; I += 2) {
+                    acc_t t00[2][2], t01[2][2];
+                    if (I + 1 < nblk) {
+                        acc_t t10[2][2], t11[2][2];
+                        values_s(t00, rw0, I, IC0{});
+                        values_s(t01, rw0, I, IC1{});
+                        values_s(t10, rw1, I + 1, IC0{});
+                        values_s(t11, rw1, I + 1, IC1{});
+                        if (BCBF_RW32_SUPER_AHEAD) { load_rows(rw0, I + 2); load_rows(rw1, I + 3); }
+                        update4(t00, t01, t10, t11, I, IC2{}, std::false_type{});
+                        solve_store_s(t00, I, J, ainv);
+                        solve_store_s(t10, I + 1, J, ainv);
+                        wave_fence();
+                        update2_r(t01, t11, col1, I, col0, col1);           // -= L_{I,J} L_{J+1,J}',  L_{I+1,J} L_{J+1,J}'
+                        solve_store_s(t01, I, J + 1, ainv1);
+                        solve_store_s(t11, I + 1, J + 1, ainv1);
+                        if (!BCBF_RW32_SUPER_AHEAD) { load_rows(rw0, I + 2); load_rows(rw1, I + 3); }
+                    } else {
+                        values_s(t00, rw0, I, IC0{});
+                        values_s(t01, rw0, I, IC1{});
+                        update4(t00, t01, t00, t01, I, IC1{}, std::false_type{});
+                        solve_store_s(t00, I, J, ainv);
+                        wave_fence();
+                        update_r(t01, col1, I, col0, col1);
+                        solve_store_s(t01, I, J + 1, ainv1);
+                    }
+                }
+                ++J;                                                        // (the loop's own ++J makes it two)
+                continue;
+            }
+            }
             load_rows(rw0, J);
             {
                 {
@@ -1563,18 +1839,24 @@ static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell,
     int dev_ = 0, cus = 256;
     (void)hipGetDevice(&dev_);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
-    const bool two = sizeof(T) == 4 && Bt >= 8 * cus;          // more than one instance per SIMD
-#define BCBF_RW_LAUNCH(OCC_)                                                                                              \
+    bool two = sizeof(T) == 4 && Bt >= 8 * cus;                // more than one instance per SIMD
+    if (const char* e = getenv("BCBF_RW32_OCC")) two = e[0] == '2';      // (development: force the allocation)
+#define BCBF_RW_LAUNCH(OCC_, ...)                                                                                         \
     do {                                                                                                                  \
         if (Kdense)                                                                                                       \
             hipLaunchKernelGGL((refit_wave_kernel<T, true, OCC_>), grid, block, 0, st, nullptr, nullptr, nullptr, nullptr,  \
                                nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, Bt, N, Np, 0, 0);                    \
         else                                                                                                              \
-            hipLaunchKernelGGL((refit_wave_kernel<T, false, OCC_>), grid, block, 0, st, X, UH, Bm, ell, s2, jitter,        \
+            hipLaunchKernelGGL((refit_wave_kernel<T, false, OCC_, ##__VA_ARGS__>), grid, block, 0, st, X, UH, Bm, ell, s2, jitter,        \
                                nullptr, Lop, UHB, Ldense, info, Bt, N, Np, n, C);                                         \
     } while (0)
     if constexpr (sizeof(T) == 4) {
-        if (two) BCBF_RW_LAUNCH(2); else BCBF_RW_LAUNCH(1);
+        // super-panels from N = 512 on (BCBF_RW32_SUPER; never for a given dense K_b or a dense output: those are the
+        // few-system paths)
+        bool sup = BCBF_RW32_SUPER && BCBF_RW32_PAIRS && Np >= 512 && !Kdense && !Ldense;
+        if (const char* e = getenv("BCBF_RW32_SUPER_FORCE")) sup = e[0] == '1' && !Kdense;      // (development)
+        if (sup) { if (two) BCBF_RW_LAUNCH(2, true); else BCBF_RW_LAUNCH(1, true); }
+        else { if (two) BCBF_RW_LAUNCH(2); else BCBF_RW_LAUNCH(1); }
     } else {
         BCBF_RW_LAUNCH(BCBF_RW64_OCC);
     }
