@@ -218,7 +218,7 @@ class MeanAdjustedModel(SumDynamicModels):
     `online_update` switch on the incremental (`bcbf_gp_append`) updates described there."""
 
     def __init__(self, x_dim, u_dim, mean_dynamics_model_class, model, max_train=None, train_every_n_steps=None,
-                 enable_learning=None, dt=None, training_iter=100, hyper_refit_every=1, online_update=False):
+                 enable_learning=None, dt=None, training_iter=100, hyper_refit_every=1, online_update=False, window=None):
         from .online import OnlineLearner
         self.mean_dynamics_model = mean_dynamics_model_class()
         super().__init__(model, self.mean_dynamics_model)
@@ -227,7 +227,7 @@ class MeanAdjustedModel(SumDynamicModels):
         self._learner = OnlineLearner(
             model, self._residual_targets, dt, train_every_n_steps, max_train, training_iter,
             subsample=lambda count, k: torch.randint(count, (k,)),        # :360-362: WITH replacement, as upstream
-            enable_learning=bool(enable_learning), hyper_refit_every=hyper_refit_every, online_update=online_update)
+            enable_learning=bool(enable_learning), hyper_refit_every=hyper_refit_every, online_update=online_update, window=window)
 
     Xtrain = property(lambda self: self._learner.Xtrain)
     Utrain = property(lambda self: self._learner.Utrain)

@@ -18,13 +18,20 @@ What this class adds on the same schedule (both off by default = the reference's
 
 When the training set would exceed `max_train` the window is re-drawn as the reference draws it (random subsample of
 the whole buffer, `subsample`) and factored from scratch -- a bordered factor cannot drop rows.
+
+* ``window = W`` (instead of `max_train`; needs one of the two options above): the model holds the MOST RECENT samples, a
+  sliding window that moves in steps of 32 (the packed factor's block size): between W and W + 31 samples; when the next
+  one would make it W + 32 the 32 oldest leave and the window is factored from scratch at the current hyper-parameters
+  (`fit(..., training_iter=0)`: one matrix-core refit per 32 observations -- cheaper than a rank-32 update of the trailing
+  factor would be, and exactly the from-scratch factor; `ops.ReservedGP(window=...)` is the batched form).  No random
+  re-draw ever happens: the controller's model is always the newest data.
 """
 import torch
 
 
 class OnlineLearner:
     def __init__(self, regressor, residual_targets, dt, train_every_n_steps, max_train, training_iter, subsample,
-                 enable_learning=True, hyper_refit_every=1, online_update=False, transform=None):
+                 enable_learning=True, hyper_refit_every=1, online_update=False, transform=None, window=None):
         """residual_targets(X[k,n], U[k,m], Xdot[k,n]) -> the regressor's targets (Xdot minus the prior mean);
         subsample(count, max_train) -> index tensor (the reference's two classes draw it differently);
         transform(X) -> regressor inputs (e.g. the shift-invariant wrapper)."""
@@ -33,6 +40,8 @@ class OnlineLearner:
         self.subsample, self.enable_learning = subsample, enable_learning
         self.hyper_refit_every, self.online_update = max(1, int(hyper_refit_every)), online_update
         self.transform = transform or (lambda X: X)
+        self.window = None if window is None else int(window)
+        self.lo = 0                    # window mode: the regressor holds buffer samples [lo, n_in_model)
         self.Xtrain, self.Utrain = [], []
         self.n_scheduled = 0           # scheduled refit points seen so far
         self.n_in_model = None         # the regressor holds exactly buffer samples [0, n_in_model); None: a subsample
@@ -45,9 +54,23 @@ class OnlineLearner:
         U = torch.stack([u.reshape(-1) for u in self.Utrain[lo:hi]])
         return X[:-1], U, (X[1:] - X[:-1]) / self.dt
 
+    BLOCK = 32
+
+    def _window_lo(self, count):
+        """Start of the sliding window for `count` samples: the largest multiple of 32 that keeps at most W + 31 of them."""
+        over = count - self.window
+        return 0 if over < self.BLOCK else (over // self.BLOCK) * self.BLOCK
+
     def _refit_from_scratch(self, training_iter):
         count = len(self.Xtrain) - 1
         if count <= 0:
+            return
+        if self.window is not None:
+            self.lo = self._window_lo(count)
+            X, U, Xdot = self._samples(self.lo, count)
+            self.regressor.fit(self.transform(X), U, self.residual_targets(X, U, Xdot), training_iter=training_iter)
+            self.n_in_model = count
+            self.has_been_trained_once = True
             return
         X, U, Xdot = self._samples(0, count)
         Y = self.residual_targets(X, U, Xdot)
@@ -64,7 +87,10 @@ class OnlineLearner:
         count = len(self.Xtrain) - 1
         if self.n_in_model is None or not self.has_been_trained_once:
             return False
-        if self.max_train is not None and count > self.max_train:
+        if self.window is not None:
+            if self._window_lo(count) != self.lo:
+                return False                        # the window moves on by a block: factor it from scratch (hyper-parameters kept)
+        elif self.max_train is not None and count > self.max_train:
             return False
         if count > self.n_in_model:
             X, U, Xdot = self._samples(self.n_in_model, count)

@@ -166,25 +166,60 @@ class ReservedGP:
     (`refit` / `potrs` outputs); `append` enters one observation per instance IN PLACE -- no allocation, no copy of
     the per-instance arrays, no re-pack of the operator -- until N reaches `capacity`; `grow(capacity)` re-reserves.
     The work buffers of the forward solve are allocated once.  `N` is the live size; `Lop`, `Vw`, `X`, `UHB` are the
-    reserved buffers ([Bt, lop_elems(capacity)], [Bt, capacity, .])."""
+    reserved buffers ([Bt, lop_elems(capacity)], [Bt, capacity, .]).
 
-    def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None):
+    window = W (with the raw data of the initial points: UH, Xdot, jitter): a SLIDING WINDOW over the most recent points at
+    the granularity of the packed layout's 32-row blocks (the reference keeps a random subsample of at most
+    `max_train` points and refactorises from scratch, unicycle_move_to_pose.py:373-384, controllers.py:348-352).  The live
+    size runs between W and W + 31; the append that would make it W + 32 first drops the OLDEST 32 points
+    (`drop_oldest_block`): the remaining rows move up and the factor of the window is recomputed from the data by the
+    batched refit kernel.  Why a refit and not the rank-32 update L22' L22'' = L22 L22' + L21 L21' of the trailing factor: the
+    update is 32 dependent sweeps of Givens-type row operations over the whole trailing factor (2 * 32 N^2 flop = 17 MFLOP at
+    N = 512, latency bound, plus re-inverting every diagonal block of the packed layout), the refit is N^3 / 3 = 45 MFLOP on
+    the matrix cores at 18-50 TFLOP/s -- 0.5 ms for 256 windows of 512 points in fp64, once per 32 appends of 0.47 ms each --
+    and it leaves EXACTLY the factor a from-scratch refit of the window gives (no accumulation over wrap-arounds).
+    Needs capacity >= W + 32."""
+
+    BLOCK = 32
+
+    def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None):
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
         self.Bt, self.N, self.n = X.shape
         self.C = UHB.shape[2]
         self.ell, self.s2, self.Bm, self.M0, self.A = ell, s2, Bm, M0, A
         self.capacity = 0
+        self.window = None if window is None else int(window)
+        self.drops = 0
         self._fill(Lop, Vw, X, UHB, self.N, int(capacity))
+        if self.window is not None:
+            if UH is None or Xdot is None:
+                raise ValueError("a sliding window refits from the data: pass UH and Xdot (and the jitter) of the initial points")
+            if self.capacity < self.window + self.BLOCK or self.N > self.window + self.BLOCK - 1:
+                raise ValueError("window %d needs capacity >= %d and at most %d initial points" % (self.window, self.window + self.BLOCK,
+                                                                                                   self.window + self.BLOCK - 1))
+            _chk(UH, Xdot, jitter)
+            f = dict(dtype=X.dtype, device=X.device)
+            # raw rows of the live points (the reserved arrays hold derived quantities: UH B, L^-1 (Xdot - UH M0))
+            self._rUH, self._rY = torch.zeros(self.Bt, self.capacity, self.C, **f), torch.zeros(self.Bt, self.capacity, self.n, **f)
+            self._rJ = torch.zeros(self.Bt, self.capacity, **f)
+            self._rUH[:, :self.N], self._rY[:, :self.N] = UH, Xdot
+            if jitter is not None:
+                self._rJ[:, :self.N] = jitter
 
-    def _fill(self, Lop, Vw, X, UHB, N, capacity, cap_in=0):
+    def _fill(self, Lop, Vw, X, UHB, N, capacity, cap_in=0, reuse=False):
         if capacity < N:
             raise ValueError("capacity %d < %d live points" % (capacity, N))
         f = dict(dtype=X.dtype, device=X.device)
         Bt, n, C = self.Bt, self.n, self.C
-        Lr = torch.empty(Bt, lop_elems(capacity, X.dtype), **f)
-        Vr, Xr, Ur = torch.empty(Bt, capacity, n, **f), torch.empty(Bt, capacity, n, **f), torch.empty(Bt, capacity, C, **f)
+        if reuse:                                     # re-lay a packed state out INTO the buffers this object already owns
+            Lr, Vr, Xr, Ur = self.Lop, self.Vw, self.X, self.UHB
+        else:
+            Lr = torch.empty(Bt, lop_elems(capacity, X.dtype), **f)
+            Vr, Xr, Ur = torch.empty(Bt, capacity, n, **f), torch.empty(Bt, capacity, n, **f), torch.empty(Bt, capacity, C, **f)
         check(getattr(lib, "bcbf_gp_reserve" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(Lr), _p(Vr), _p(Xr), _p(Ur), Bt, N,
                                                         cap_in, capacity, n, C - 1, _stream(X)), "bcbf_gp_reserve")
+        if reuse:
+            return
         self.Lop, self.Vw, self.X, self.UHB, self.capacity = Lr, Vr, Xr, Ur, capacity
         Npc = (capacity + 31) // 32 * 32
         self._Ww, self._Mkw, self._Bkw = torch.empty(Bt, Npc, C, **f), torch.empty(Bt, n, C, **f), torch.empty(Bt, C, C, **f)
@@ -194,8 +229,36 @@ class ReservedGP:
         """Re-reserve for a larger capacity: ONE copy of the state (geometric growth amortises it to O(1) per append)."""
         if capacity <= self.capacity:
             return self
+        if self.window is not None:
+            raise RuntimeError("a windowed ReservedGP keeps its capacity (window + 32 suffices)")
         self._fill(self.Lop, self.Vw, self.X, self.UHB, self.N, int(capacity), cap_in=self.capacity)
         return self
+
+    def drop_oldest_block(self, max_tries=10):
+        """Window mode: forget the 32 oldest points.  The raw rows move up, the window's factor and whitened targets are
+        recomputed from them (`refit` with the jitter every point ENTERED with -- an instance whose factorisation fails
+        retries with its jitter x10, as make_psd does, control_affine_model.py:903-919) and laid out into the reserved
+        buffers this object already owns.  Returns info[Bt] of the last factorisation (0 = fine)."""
+        if self.window is None:
+            raise RuntimeError("drop_oldest_block needs a ReservedGP built with window=...")
+        k = self.BLOCK
+        N2 = self.N - k
+        if N2 < 1:
+            raise RuntimeError("nothing would be left")
+        X = self.X[:, k:self.N].contiguous()
+        UH, Y, J = self._rUH[:, k:self.N].contiguous(), self._rY[:, k:self.N].contiguous(), self._rJ[:, k:self.N].contiguous()
+        for ntry in range(max_tries):
+            Lop, UHB, info, _ = refit(X, UH, self.Bm, self.ell, self.s2, J)
+            bad = info != 0
+            if not bool(bad.any()):                   # (one host round trip per 32 appends)
+                break
+            J = torch.where(bad[:, None], J * 10, J)
+        Vw, _ = potrs(Lop, Y, UH, self.M0, want_alpha=False)
+        self._rUH[:, :N2], self._rY[:, :N2], self._rJ[:, :N2] = UH, Y, J
+        self._fill(Lop, Vw, X, UHB, N2, self.capacity, reuse=True)
+        self.N = N2
+        self.drops += 1
+        return info
 
     def posterior(self, xq, jitter2=None, want_W=False, out=None):
         """(Mk[Bt,n,C], Bk[Bt,C,C]) (+ W[Bt,Np,C]) at one query per instance on the live points."""
@@ -218,9 +281,15 @@ class ReservedGP:
         query[Bt,n] (with out = (Mk, Bk), or allocated): the posterior at `query` on the points BEFORE the append, computed
         on the same pass over the factors as the append's forward solve -- a "posterior, then append" step for the traffic
         of one; then returns (info, Mk, Bk)."""
+        if self.window is not None and self.N >= self.window + self.BLOCK:
+            raise RuntimeError("window mode: the live size is already window + 32 (drop_oldest_block failed?)")
         if self.N >= self.capacity:
             raise RuntimeError("ReservedGP is full (%d points): reserve a larger capacity" % self.capacity)
         _chk(self.X, x_new, uh_new, xdot_new, jitter_new, query)
+        if self.window is not None:                   # raw row of the new point (row N of the raw arrays)
+            self._rUH[:, self.N], self._rY[:, self.N] = uh_new, xdot_new
+            if jitter_new is not None:
+                self._rJ[:, self.N] = jitter_new
         Mk = Bk = None
         if query is not None:
             f = dict(dtype=self.X.dtype, device=self.X.device)
@@ -234,6 +303,8 @@ class ReservedGP:
             _p(query), _p(Mk), _p(Bk), self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)),
             "bcbf_gp_append_reserved")
         self.N += 1
+        if self.window is not None and self.N >= self.window + self.BLOCK:
+            self.drop_oldest_block()                  # AFTER the append: the posterior the caller asked for saw every point
         return self.info if query is None else (self.info, Mk, Bk)
 
     def live(self):

@@ -123,7 +123,7 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
 
 
 def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True,
-                     reserved=True, fused=True):
+                     reserved=True, fused=True, window=None):
     """BASELINE configs[4]: every instance starts from an N0-point GP and takes one observation per control step
     until it holds N1 points -- the reference refits from scratch every `train_every_n_steps`
     (unicycle_move_to_pose.py:340-386).  reserved=True (default): capacity-reserving storage (`ops.ReservedGP`,
@@ -132,6 +132,10 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
     over the factors as the append's forward solve (`append(..., query=x)`; per segment `append_ms` is then that one pass
     + the in-place row writes, `control_step_ms` the solve launch alone).  reserved=False: `ops.gp_append` on the
     packed layout of exactly N points (every per-instance array copied per append, the operator re-packed every 32).
+    window = W (reserved storage only): a sliding window over the most recent points (`ops.ReservedGP(window=W)`): the GP
+    grows from N0 to W, then every 32nd append drops the oldest 32 points and refits the window (the drop is inside that
+    step's `append_ms`); N1 is then the number of observations seen, the final check is against a from-scratch refit of the
+    LAST window.
     Returns per-octave timings (HIP events) and the deviation of the final posterior from a from-scratch refit of all
     N1 points."""
     from .synthetic import make_instances, make_unicycle_task
@@ -147,12 +151,17 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
     A = (0.01 * p["A"]).contiguous()
     ws = ops.control_workspace(Bt, 2, dtype, dev)
     x = task["x"].clone()
-    rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N1) if reserved else None
+    if window is not None:
+        assert reserved and N0 <= window, "a sliding window runs on reserved storage, from at most `window` points"
+        rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + 32, window=window,
+                             UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    else:
+        rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N1) if reserved else None
     if reserved:
         del Lop, Vw, UHB
     # pre-slice the observation stream (contiguous [N1][Bt,.]) so the timed loop holds only the path's own launches
     obs = [t.transpose(0, 1).contiguous() for t in (p["X"], p["UH"], p["Xdot"], p["jitter"])]
-    edges = sorted({N0, N1} | {k for k in (256, 512, 1024, 2048) if N0 < k < N1})
+    edges = sorted({N0, N1} | {k for k in (256, 512, 1024, 2048) if N0 < k < N1} | ({window} if window and N0 < window < N1 else set()))
     segs = []
     fails = torch.zeros((), dtype=torch.int64, device=dev)
     for lo, hi in zip(edges[:-1], edges[1:]):
@@ -197,7 +206,12 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
                storage=("reserved (in place)" + (", posterior query and append on one pass" if (fused and with_control) else ""))
                if reserved else "packed (copy per append)",
                segments=segs, append_failures=int(fails))
+    if window is not None:
+        out.update(window=window, drops=rgp.drops, live_points=rgp.N)
     if check:
+        if window is not None:                           # the last window: points N1 - live .. N1 - 1 of the stream
+            lo = N1 - rgp.N
+            p = {k: (v[:, lo:N1].contiguous() if k in ("X", "UH", "Xdot", "jitter") else v) for k, v in p.items()}
         Lr, UHBr, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
         Vr, _ = ops.potrs(Lr, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
         if reserved:

@@ -200,7 +200,7 @@ class LearnedShiftInvariantDynamics:
 
     def __init__(self, dt=None, learned_dynamics=None, learned_dynamics_class=None, mean_dynamics=None, max_train=200,
                  training_iter=100, shift_invariant=True, train_every_n_steps=20, enable_learning=True, device="cuda",
-                 dtype=torch.float64, hyper_refit_every=1, online_update=False):
+                 dtype=torch.float64, hyper_refit_every=1, online_update=False, window=None):
         """hyper_refit_every / online_update: see `online.OnlineLearner` (defaults = the reference's schedule)."""
         from .control_affine_model import ControlAffineRegressorExactRankOne
         from .online import OnlineLearner
@@ -221,7 +221,7 @@ class LearnedShiftInvariantDynamics:
         self._learner = OnlineLearner(self.learned_dynamics, self._residual_targets, dt, train_every_n_steps, max_train,
                                       training_iter, subsample, enable_learning=enable_learning,
                                       hyper_refit_every=hyper_refit_every, online_update=online_update,
-                                      transform=self._trans_invariant_wrapper)
+                                      transform=self._trans_invariant_wrapper, window=window)
 
     # the controller's buffers (:340-354), owned by the learner
     Xtrain = property(lambda self: self._learner.Xtrain)

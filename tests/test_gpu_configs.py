@@ -281,6 +281,72 @@ def test_gp_append_failed_pivot_leaves_the_instance_unchanged(ops, N):
     assert torch.equal(L2[1, :E], Lop_in[1, :E])
 
 
+def test_sliding_window_on_reserved_storage_vs_oracle_refit_of_the_window(ops):
+    """SURVEY 8f #2, the windowed form (`ops.ReservedGP(window=W)`): the GP grows to W + 31 points, then every 32nd append
+    drops the 32 oldest.  After several wrap-arounds (5 drops) and at points in between, the posterior on the live window
+    equals the ORACLE's from-scratch refit of exactly those points (same jitter draws) to 1e-7; the live size stays in
+    [W, W + 31]; the reserved buffers never move; the live rows are the most recent observations in order.  Also the fused
+    form (posterior query on the same pass as the append) across a drop."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, N0, W, n, m = 3, 40, 64, 3, 2
+    N1 = W + 32 * 5 + 17
+    dtype = torch.float64
+    p = make_instances(Bt, N1, n, m, dtype=dtype, device=DEV, seed=15)
+    p["X"] = (p["X"] * 3.0).contiguous()
+    p["xq"] = (p["xq"] * 3.0).contiguous()
+    cut = lambda t, N: t[:, :N].contiguous()
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], N0), cut(p["UH"], N0), p["Bm"], p["ell"], p["s2"], cut(p["jitter"], N0))
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N0), cut(p["UH"], N0), p["M0"], want_alpha=False)
+    with pytest.raises(ValueError):
+        ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + 31, window=W,
+                       UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    g = ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + 32, window=W,
+                       UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    ptr = g.Lop.data_ptr()
+    h = {k: host(v) for k, v in p.items()}
+
+    def check(seen, Mk=None, Bk=None, nseen=None):
+        nseen = seen if nseen is None else nseen               # points the posterior saw (fused: before the append's own point)
+        lo = seen - g.N if Mk is None else lo_before
+        if Mk is None:
+            Mk, Bk = g.posterior(p["xq"])
+        for i in range(Bt):
+            sl = slice(lo, nseen)
+            stt = ogp.refit_state(h["X"][i, sl], h["U"][i, sl], h["Xdot"][i, sl], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                                  h["jitter"][i, sl][None] / 1e-5)
+            Mk_o, Bk_o = ogp.posterior_step(stt["L"][None], stt["alpha"][None], h["X"][i, sl][None], stt["UHB"][None],
+                                            h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], h["xq"][i][None])
+            prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
+            rel_close(host(Mk)[i], Mk_o[0], 1e-7, scale=max(1.0, np.abs(Mk_o).max()), what="Mk after %d" % seen)
+            rel_close(host(Bk)[i], Bk_o[0], 1e-7, scale=prior, what="Bk after %d" % seen)
+
+    checkpoints = {W, W + 31, W + 32, W + 33, W + 64, W + 100, W + 160, N1}
+    for N in range(N0, N1):
+        row = lambda k: p[k][:, N].contiguous()
+        if N + 1 == W + 96:                                     # the fused form across a drop: the query sees the points BEFORE it
+            lo_before, n_before = N - g.N, N
+            info, Mk, Bk = g.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=p["xq"])
+            assert g.drops == 3 and g.N == W
+            check(N + 1, Mk, Bk, nseen=n_before)
+        else:
+            info = g.append(row("X"), row("UH"), row("Xdot"), row("jitter"))
+        assert (info == 0).all() and g.Lop.data_ptr() == ptr
+        assert (N + 1 < W + 32 and g.N == N + 1) or W <= g.N <= W + 31
+        if N + 1 in checkpoints:
+            check(N + 1)
+    assert g.drops == 5 and g.N == W + 17
+    np.testing.assert_array_equal(host(g.X[:, :g.N]), h["X"][:, N1 - g.N:N1])
+    with pytest.raises(RuntimeError):
+        g.grow(4096)
+    # the harness of config 5 in window mode: grow 48 -> 96, slide to 200 observations
+    from bayesian_cbf_amd.rollouts import online_gp_growth
+    out = online_gp_growth(4, 48, 200, window=96)
+    assert out["drops"] == 3 and out["live_points"] == 96 + 8 and out["append_failures"] == 0
+    assert out["final_vs_refit"]["Mk"] < 1e-8 and out["final_vs_refit"]["Bk"] < 1e-8
+    assert [s_["N_from"] for s_ in out["segments"]] == [48, 96]
+
+
 def test_c5_reserved_storage_growth_128_to_2048_vs_oracle(ops):
     """BASELINE config 5 on the capacity-reserving storage (`ops.ReservedGP`: bcbf_gp_reserve / bcbf_gp_append_reserved /
     bcbf_posterior_query_reserved): 1920 in-place appends, nothing re-packed or copied.  At N = 129, 160, 256, 512,

@@ -1042,6 +1042,46 @@ def test_learner_schedule_hyper_refit_every_and_window():
         assert torch.isfinite(m).all() and torch.isfinite(c).all() and reg.Xtrain.shape[0] == 40
 
 
+def test_learner_sliding_window_keeps_the_most_recent_samples():
+    """OnlineLearner(window=W) (SURVEY 8f #2 in the windowed form): with online updates every sample enters through
+    append_data; whenever the model would hold W + 32 samples the 32 oldest leave and the window is factored from scratch
+    at the current hyper-parameters -- never a random re-draw.  The regressor always holds the most recent samples, between
+    W and W + 31 of them, and predicts like a regressor fitted on exactly those (same hyper-parameters)."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExactRankOne
+    from bayesian_cbf_amd.unicycle_move_to_pose import AckermannDrive, LearnedShiftInvariantDynamics
+    T_ = 150
+    X, U = _closed_loop_samples(T_)
+    dyn = LearnedShiftInvariantDynamics(dt=0.02, mean_dynamics=AckermannDrive(L=12.0), training_iter=0, train_every_n_steps=10,
+                                        max_train=10 ** 6, device=DEV, online_update=True, hyper_refit_every=10 ** 6, window=64)
+    reg = dyn.learned_dynamics
+    log = []
+    fit0, app0 = reg.fit, reg.append_data
+    reg.fit = lambda *a, **k: log.append(("fit", a[0].shape[0])) or fit0(*a, **k)
+    reg.append_data = lambda *a, **k: log.append(("app", a[0].shape[0])) or app0(*a, **k)
+    for k in range(T_):
+        dyn.train(t(X[k]), t(U[k]))
+        if reg.Xtrain is not None:
+            count = k - 1                                    # samples with a finite-difference target before this call
+            assert reg.Xtrain.shape[0] == count - dyn._learner.lo and (count < 96 or 64 <= reg.Xtrain.shape[0] <= 95)
+    lo, count = dyn._learner.lo, T_ - 2
+    assert lo == 64 and reg.Xtrain.shape[0] == count - lo
+    fits = [e for e in log if e[0] == "fit"]
+    assert fits == [("fit", 9), ("fit", 64), ("fit", 64)], fits            # the first scheduled fit, then one per block that left
+    assert all(e == ("app", 1) for e in log if e[0] == "app")
+    want = t(X[lo:count] * np.array([0, 0, 1.0]))                        # shift-invariant inputs of the most recent samples
+    assert torch.equal(reg.Xtrain, want)
+    ref = ControlAffineRegressorExactRankOne(3, 2, device=DEV, dtype=torch.float64)
+    ref.load_state_dict(reg.state_dict())
+    ref.fit(reg.Xtrain, reg.Utrain, reg.XdotTrain, training_iter=0)
+    xt, ut = t(X[:5] * np.array([0, 0, 1.0])), t(U[:5])
+    m1, c1 = reg.custom_predict(xt, ut)
+    m2, c2 = ref.custom_predict(xt, ut)
+    # (the two regressors drew different jitters, 1e-5 rand on the diagonal of K_b: agreement to that level; the exact
+    #  comparison with the oracle's refit of a window is test_sliding_window_on_reserved_storage_vs_oracle_refit_of_the_window)
+    assert float((m1 - m2).abs().max()) < 1e-3 * max(1.0, float(m2.abs().max()))
+    assert float((c1 - c2).abs().max()) < 1e-4              # (at training inputs the variance itself is at the jitter level)
+
+
 GPALG_FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "gpalgebra_*.npz")) if "handmade" not in f)
 
 

@@ -23,6 +23,8 @@ ap.add_argument("--no-control", action="store_true")
 ap.add_argument("--packed", action="store_true", help="the packed layout of exactly N points (copy per append) instead of reserved storage")
 ap.add_argument("--unfused", action="store_true", help="reserved storage, but the control query and the append each make their own pass")
 ap.add_argument("--repeat", type=int, default=1, help="runs (reproducibility of the per-segment figures)")
+ap.add_argument("--window", type=int, default=0, help="sliding window of the most recent W points (ops.ReservedGP(window=W)): grow "
+                                                      "to W, then drop the oldest 32 every 32 appends; --n1 = observations seen")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and a.gpus > 1:
     from bayesian_cbf_amd.distributed import launch_ranks
@@ -35,7 +37,8 @@ for _ in range(a.repeat):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = online_gp_growth(a.batch, a.n0, a.n1, dtype=torch.float64 if a.dtype == "f64" else torch.float32, device=ctx.device,
-                           seed=5 + ctx.rank, with_control=not a.no_control, reserved=not a.packed, fused=not a.unfused)
+                           seed=5 + ctx.rank, with_control=not a.no_control, reserved=not a.packed, fused=not a.unfused,
+                           window=a.window or None)
     torch.cuda.synchronize()
     el, per_rank = ctx.reduce_times(time.perf_counter() - t0)
     # the slowest rank's figure per segment, the worst rank's deviation, the sum of failures: one short reduction each
