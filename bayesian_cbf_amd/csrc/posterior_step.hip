@@ -44,6 +44,9 @@
 #ifndef BCBF_PQ_UNR
 #define BCBF_PQ_UNR 4        // several queries per workgroup (NQ > 1), fp32: columns per pipeline stage (fp64: 2 -- 4 spill)
 #endif
+#ifndef BCBF_PQ_UNR64
+#define BCBF_PQ_UNR64 2      // fp64, several queries per workgroup (shared model; the online path's query + append pair)
+#endif
 #ifndef BCBF_PJ_UNR32
 #define BCBF_PJ_UNR32 4      // fp32, more than 6 right-hand-side columns (unicycle shape: 12); measured 4096 x 512, n=3, m=2:
                              // (UNR, waves/SIMD) = (2,1) 663 us, (2,2) 520, (4,1) 539, (4,2) 419, (8,1) 528
@@ -122,7 +125,12 @@ template <> struct Mfma16<double> {
 // instead of kernel values: r_i = X[i][0..n) - sum_a UHB[i][a] M0[a][0..n)  (X := Xdot [N,n], UHB := UH [N,cu], M0 [cu,n]:
 // the whitened targets Vw = L^-1 (Xdot - UH M0) of bcbf_potrs, control_affine_model.py:525-545), written to Wout as
 // [N, n]; no Gram / mean.  C = number of solved columns (>= n; extra columns are zero).
-template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false>
+// XC = 1 (values only, NQ = 1): ONE extra right-hand-side column rides along -- the column the online path's append needs,
+// l = L^-1 (k(X, x2) o (UH B uh2)) for the new observation (x2, uh2): the bordered factor's new row is l itself, its pivot
+// sqrt(kappa - l'l), the new whitened target (y - Vw'l) / d (gp_append_inplace_kernel).  Round 3 answered the control query and
+// the append on one pass with TWO full queries (2 C = 6 columns at the unicycle shape): in fp64 that form fits two columns
+// per pipeline stage and streamed at 4.0 TB/s at N >= 1024; C + 1 = 4 columns run the plain kernel's schedule.
+template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false, int XC = 0>
 __global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256),
                                    (NJ > 0 ? (sizeof(T) == 8 || C * (1 + NJ) > 12 || NJ > 3 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
@@ -130,7 +138,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                       const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
                       T* __restrict__ Wout, T* __restrict__ Gfull, T* __restrict__ Mfull, int shared, int N, int Np,
-                      int n, const T* __restrict__ lin, int nq, int Nl, int ldN, int kind, const T* __restrict__ xq2) {
+                      int n, const T* __restrict__ lin, int nq, int Nl, int ldN, int kind, const T* __restrict__ xq2,
+                      const T* __restrict__ uh2 = nullptr) {
     // Nl: the padded size the operator is LAID OUT for (>= Np; column lengths, block offsets, batch stride), ldN: rows
     // per instance of X / UH B / Vw.  Nl == Np, ldN == N: the packed layout of exactly N points; larger: capacity-
     // reserving storage of the online path (bcbf_gp_reserve), of which the first N points are live.
@@ -139,13 +148,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // control query and new observation share ONE pass over the instance's factor (bcbf_gp_append_reserved).
     static_assert(NQ == 1 || NJ == 0, "several queries per workgroup: values only");
     static_assert(!RHS || (NJ == 0 && NQ == 1), "right-hand-side mode: values only, one system per workgroup");
+    static_assert(XC == 0 || (XC == 1 && NJ == 0 && NQ == 1 && !RHS), "extra column: values only, one query per workgroup");
     const int cu = RHS ? nq : 0;        // RHS mode: columns of UH (the launcher passes it in the nq slot)
     constexpr int V = Vec<T>::V;
-    constexpr int CT = C * (1 + NJ) * NQ;     // right-hand-side columns
+    constexpr int CT = C * (1 + NJ) * NQ + XC;     // right-hand-side columns
     using VecT = typename Vec<T>::type;
     constexpr int RPB = NB / V;          // row blocks per diagonal block
     constexpr int CP = (CT + 3) / 4 * 4; // padded RHS count in LDS
-    constexpr int CQ = CT / NQ;                                // columns of one query
+    constexpr int CQ = (CT - XC) / NQ;                         // columns of one query
     constexpr int NG = NQ * (CQ * (CQ + 1) / 2);               // Gram entries kept: per query, upper triangle
     // (a <= c, same query) -> slot; with NQ = 1 this is the upper triangle of the full CT x CT Gram
     auto gidx = [](int a, int c) {
@@ -154,7 +164,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     };
     // jets: a w_J row is widened to 16 entries [w (CT), Vw row (n), zeros]: the 32 x 16 tile is both operands of the
     // matrix-core product of step 2b
-    constexpr bool MG = NJ > 0 || NQ > 1;                      // Gram / mean sums on the matrix cores (the forms with
+    constexpr bool MG = NJ > 0 || NQ > 1 || XC > 0;            // Gram / mean sums on the matrix cores (the forms with
                                                                // many right-hand-side columns: jets, several queries)
     // ... in one 16-column tile when CT + n <= 16 (every shape up to the unicycle's n=3, m=2), in two otherwise
     // (n=3 m=3, n=4 m=2, n=4 m=3: CT = 16, 15, 20): the product is then 2 x 2 accumulators
@@ -190,6 +200,13 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
             xqr[qi][d] = (!RHS && d < n) ? qsrc[(size_t)qx * n + d] : T(0);
         }
         iell[d] = (!RHS && d < n) ? T(1) / ell[(size_t)gb * n + d] : T(0);
+    }
+    T x2r[XC ? NS : 1], uh2r[XC ? C : 1];                      // the append's new observation (XC)
+    if constexpr (XC > 0) {
+#pragma unroll
+        for (int d = 0; d < NS; ++d) x2r[d] = d < n ? xq2[(size_t)b * n + d] : T(0);
+#pragma unroll
+        for (int c = 0; c < C; ++c) uh2r[c] = uh2[(size_t)b * C + c];
     }
     const T s2 = RHS ? T(0) : s2p[gb];
     // optional linear part of the data kernel, k = s2 (exp(..) + lin x'x') (the CoGP comparator's RBF + Linear,
@@ -272,6 +289,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     shape = (T(1) + a5 + T(5) / T(3) * d2) * texp<T>(-a5);
                 } else shape = texp<T>(T(-0.5) * d2);
                 const T k = s2 * (shape + linv * dot);
+                if constexpr (XC > 0) {                // the extra column: k(X_i, x2) (UH B)_i . uh2
+                    T e2 = T(0), ud = T(0);
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) { const T z = (xv[v][d] - x2r[d]) * iell[d]; e2 += z * z; }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) ud += uv[v][c] * uh2r[c];
+                    BCBF_ACC(r, v, CT - 1) = s2 * texp<T>(T(-0.5) * e2) * ud;
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const T ub = uv[v][c];             // 0 for rows >= N and idle lanes: the row contributes nothing
@@ -310,7 +335,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
     constexpr int UNR = NJ > 0 ? (CT > 12 ? 2 : sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
-                               : (NQ > 1 ? (sizeof(T) == 8 ? 2 : BCBF_PQ_UNR) : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
+                               : (NQ > 1 ? (sizeof(T) == 8 ? BCBF_PQ_UNR64 : BCBF_PQ_UNR) : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
@@ -437,6 +462,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                         for (int c = 0; c < C; ++c) if (c < n) Wout[((size_t)b * ldN + row0 + di) * n + c] = w[c];
                     }
+                } else if (XC > 0) {                            // the append's column l, a vector [Np] per instance
+                    if (Wout != nullptr) Wout[(size_t)b * Np + row0 + di] = w[CT - 1];
                 } else if (NJ > 0 && Wout != nullptr) {        // jets: all CT columns [Phi, dPhi/dx_1 ..] of this row
 #pragma unroll
                     for (int c = 0; c < CT; ++c) Wout[((size_t)b * Np + row0 + di) * CT + c] = w[c];
@@ -489,25 +516,28 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #endif
                 }
             }
-            if constexpr (MG) {
-                // 2b. Gram and mean sums of the block on the matrix cores: with T_J = [w_J, Vw_J, 0] (32 x 16, in wbuf),
-                // gacc += T_J' T_J -- rows / columns < CT: the Gram Wj'Wj, rows CT .. CT+n-1: Vw'Wj.  A and B operand of
-                // a k-step are the SAME register (a[i][k] = T_J[k][i] = b[k][i]); 8 k-steps of 4 rows; the reads are
-                // 64 consecutive words each.  One accumulator (4 registers) replaces CT (CT+1) / 2 + n CT VALU sums.
-                const int kq = tid >> 4, ci = tid & 15;
-#pragma unroll
-                for (int s8 = 0; s8 < NB / 4; ++s8) {
-                    T a[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) a[t] = wbuf[4 * s8 + kq][16 * t + ci];
-#pragma unroll
-                    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                        for (int tj = 0; tj < NT; ++tj) gacc[ti][tj] = Mfma16<T>::mac(a[ti], a[tj], gacc[ti][tj]);
-                }
-            }
         }
         __syncthreads();
+        if constexpr (MG) {
+            // 2b. Gram and mean sums of the block on the matrix cores: with T_J = [w_J, Vw_J, 0] (32 x 16, in wbuf),
+            // gacc += T_J' T_J -- rows / columns < CT: the Gram Wj'Wj, rows CT .. CT+n-1: Vw'Wj.  A and B operand of
+            // a k-step are the SAME register (a[i][k] = T_J[k][i] = b[k][i]); 8 k-steps of 4 rows; the reads are
+            // 64 consecutive words each.  One accumulator (4 registers) replaces CT (CT+1) / 2 + n CT VALU sums.
+            // AFTER the barrier and spread over the workgroup's waves (wave w takes k-steps w, w + nw, ...; the partial
+            // accumulators meet in the epilogue): inside wave 0's diagonal step these MFMAs were part of the serial chain
+            // every other wave waits for -- at N >= 1024 in fp64 (6-8 waves) a sixth of a block's time.  wbuf is not written
+            // again before the next block's first barrier.
+            const int nw = blockDim.x >> 6, wv = tid >> 6, kq = (tid >> 4) & 3, ci = tid & 15;
+            for (int s8 = wv; s8 < NB / 4; s8 += nw) {
+                T a[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a[t] = wbuf[4 * s8 + kq][16 * t + ci];
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) gacc[ti][tj] = Mfma16<T>::mac(a[ti], a[tj], gacc[ti][tj]);
+            }
+        }
         // 3. rows below the block:  r -= L[:, J] w_J   (group 0 of this block is already in flight)
         if (J + 1 < nblk) {
             issue_diag(J + 1);
@@ -527,6 +557,29 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 
     // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
     if constexpr (RHS) return;
+    if constexpr (MG) {
+        // the waves' partial accumulators -> wave 0 (through wbuf, free now: one accumulator register of every wave at a time)
+        const int nw = blockDim.x >> 6;
+        if (nw > 1) {
+            T* red = &wbuf[0][0];
+            static_assert(!MG || NB * CW >= 512, "reduction buffer: 8 waves x 64 lanes");
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        __syncthreads();
+                        if (tid >= 64) red[tid] = gacc[ti][tj][r];
+                        __syncthreads();
+                        if (tid < 64) {
+                            T sum = gacc[ti][tj][r];
+                            for (int w_ = 1; w_ < nw; ++w_) sum += red[w_ * 64 + tid];
+                            gacc[ti][tj][r] = sum;
+                        }
+                    }
+        }
+    }
     if constexpr (MG && NJ > 0) {
         // jets: every lane of wave 0 writes its four entries (i = row(l / 16, r), j = l % 16) of [W, Vw]'[W, Vw]
         if (tid < 64) {
@@ -554,6 +607,34 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         Mb[d * CT + j] = val;
                         if (j < C) Mkb[d * C + j] = M0b[j * n + d] + val;
                     }
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (XC > 0) {
+        // query + one column: the query's Gram block / mean as usual; row / column C of the accumulator is the column l:
+        // (C, C) = l'l, (CT + d, C) = (Vw'l)_d -> Gfull[b][1 + n]
+        if (tid < 64) {
+            const int j = tid & 15, grp = tid >> 4;
+            const T* M0b = M0 + (size_t)gb * C * n;
+            const T* Bmb = Bm + (size_t)gb * C * C;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = Mfma16<T>::row(grp, r);
+                const T val = gacc[0][0][r];
+                if (j < C) {
+                    if (i < C) {
+                        double v = (double)s2 * (double)Bmb[i * C + j] - (double)val;
+                        if (i == j && jitter2 != nullptr) v += (double)jitter2[(size_t)b * C + i];
+                        Bk[(size_t)b * C * C + i * C + j] = (T)v;
+                    } else if (i >= CT && i < CT + n) {
+                        const int d = i - CT;
+                        Mk[(size_t)b * n * C + d * C + j] = M0b[j * n + d] + val;
+                    }
+                } else if (j == C && Gfull != nullptr) {
+                    if (i == C) Gfull[(size_t)b * (1 + n)] = val;
+                    else if (i >= CT && i < CT + n) Gfull[(size_t)b * (1 + n) + 1 + (i - CT)] = val;
                 }
             }
         }
@@ -889,6 +970,31 @@ int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const 
     return launch_posterior_step<T>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk2, Bk2, W2, 0, Bt, N, n, m, stream, nullptr,
                                     nullptr, nullptr, Ncap, 0, xq2);
 }
+// The online path's fused pass: posterior (Mk, Bk) at xq AND the append's column l = L^-1 (k(X, x_new) o (UH B uh_new)) with its
+// sums (lsum[Bt, 1 + n] = l'l, Vw'l) on ONE pass over every instance's factor (reserved storage, capacity Ncap)
+template <typename T>
+int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
+                                           const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
+                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM || Ncap < N) return BCBF_EINVAL;
+    constexpr int V = Vec<T>::V;
+    const int Np = round_up(N, NB), Nl = round_up(Ncap, NB);
+    const int threads = round_up(Np / V / 2, 64);
+    if (threads > (sizeof(T) == 8 ? 512 : 256)) return BCBF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(Bt), block(threads);
+#define BCBF_PX_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, 0, x_new, uh_new)
+    switch (m) {
+        case 1: BCBF_PX_LAUNCH(2); break;
+        case 2: BCBF_PX_LAUNCH(3); break;
+        default: BCBF_PX_LAUNCH(4); break;
+    }
+#undef BCBF_PX_LAUNCH
+    return check_launch("posterior_query_column");
+}
+template int launch_posterior_query_column_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, int, int, int, void*);
+template int launch_posterior_query_column_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int, int, int, int, int, void*);
 template int launch_posterior_pair_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int, void*);
 template int launch_posterior_pair_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, int, int, int, int, int, void*);
 }  // namespace bcbf

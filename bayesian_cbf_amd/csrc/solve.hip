@@ -497,9 +497,10 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
                          const T* __restrict__ x_new, const T* __restrict__ uh_new, const T* __restrict__ xdot_new,
                          const T* __restrict__ jitter_new, const T* __restrict__ W, int* __restrict__ info,
                          int N, int Ncap, int n, int C, int wq, const T* __restrict__ Mk2, const T* __restrict__ Bk2,
-                         T* __restrict__ Mk_out, T* __restrict__ Bk_out) {
+                         T* __restrict__ Mk_out, T* __restrict__ Bk_out, const T* __restrict__ lsum = nullptr) {
     // wq = 2: W / Mk2 / Bk2 hold TWO queries per instance (slot 0 = the caller's posterior query, slot 1 = x_new, both
     // from one pass over the factor); slot 0's posterior is handed to Mk_out / Bk_out here
+    // wq = 3: W IS the column l [Bt, Np] (posterior_step_kernel<.., XC = 1>) and lsum[Bt, 1 + n] = (l'l, Vw'l) came with it
     constexpr int V = Vec<T>::V;
     __shared__ T lrow[ST * SMAXR];
     __shared__ T scratch[4 * SC];
@@ -514,6 +515,13 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
     T acc[SC + 1];
 #pragma unroll
     for (int c = 0; c < SC + 1; ++c) acc[c] = T(0);
+    T ssq[1];
+    if (wq == 3) {
+        for (int i = tid; i < N; i += ST) lrow[i] = W[(size_t)b * Np + i];
+        ssq[0] = lsum[(size_t)b * (1 + n)];
+#pragma unroll
+        for (int c = 0; c < SC; ++c) acc[c] = c < n ? lsum[(size_t)b * (1 + n) + 1 + c] : T(0);
+    } else {
     for (int i = tid; i < N; i += ST) {
         T v = T(0);
 #pragma unroll
@@ -525,10 +533,11 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
         for (int c = 0; c < SC; ++c)
             if (c < n) acc[c] += v * Vwb[(size_t)i * n + c];
     }
-    T ssq[1] = {acc[SC]};
+    ssq[0] = acc[SC];
     block_sum(ssq, 1, scratch);
     __syncthreads();
     block_sum(acc, n, scratch);
+    }
     T q = T(0);
 #pragma unroll
     for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) {
@@ -593,14 +602,18 @@ template <typename T>
 int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm,
                                    const T* M0, const T* xq, const T* xq2, T* Mk2, T* Bk2, T* W2, int Bt, int N, int Ncap, int n,
                                    int m, void* stream);          // posterior_step.hip
+template <typename T>
+int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
+                                           const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
+                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream);   // posterior_step.hip
 
 template <typename T>
 static int launch_gp_append_inplace(T* Lop, T* Vw, T* X, T* UHB, const T* s2, const T* Bm, const T* M0, const T* x_new,
                                     const T* uh_new, const T* xdot_new, const T* jitter_new, const T* W, int* info, int Bt,
                                     int N, int Ncap, int n, int m, void* stream, int wq = 1, const T* Mk2 = nullptr,
-                                    const T* Bk2 = nullptr, T* Mk_out = nullptr, T* Bk_out = nullptr) {
+                                    const T* Bk2 = nullptr, T* Mk_out = nullptr, T* Bk_out = nullptr, const T* lsum = nullptr) {
     hipLaunchKernelGGL((gp_append_inplace_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Vw, X, UHB, s2, Bm, M0,
-                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1, wq, Mk2, Bk2, Mk_out, Bk_out);
+                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1, wq, Mk2, Bk2, Mk_out, Bk_out, lsum);
     return check_launch("gp_append_reserved");
 }
 }  // namespace bcbf
@@ -697,8 +710,19 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
             return BCBF_EINVAL;                                                                                          \
         if (N < 1 || N >= Ncap || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;  \
         if (bcbf::round_up(Ncap, bcbf::NB) > bcbf::ST * bcbf::SMAXR) return BCBF_EINVAL;                                  \
+        if (xq != nullptr && n <= 4 && !getenv("BCBF_APPEND_PAIR")) {                                                    \
+            /* the caller's posterior query rides along: its C columns + the ONE column the append needs, one pass over  \
+               the factor (Wwork: the column l [Bt, Np]; Mk_work: its sums [Bt, 1 + n]) */                               \
+            const int rc = bcbf::launch_posterior_query_column_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq,  \
+                                                                           x_new, uh_new, Mk, Bk, Wwork, Mk_work, Bt, N,  \
+                                                                           Ncap, n, m, stream);                          \
+            if (rc != BCBF_OK) return rc;                                                                                \
+            return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new,        \
+                                                     jitter_new, Wwork, info, Bt, N, Ncap, n, m, stream, 3, nullptr,      \
+                                                     nullptr, nullptr, nullptr, Mk_work);                                \
+        }                                                                                                                \
         if (xq != nullptr && n <= 4 && m <= 2) {                                                                         \
-            /* the caller's posterior query rides along: two queries per instance on one pass over the factor */        \
+            /* (round 3's form, BCBF_APPEND_PAIR=1: two full queries per instance on one pass) */                        \
             const int rc = bcbf::launch_posterior_pair_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new,   \
                                                                    Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);  \
             if (rc != BCBF_OK) return rc;                                                                                \
