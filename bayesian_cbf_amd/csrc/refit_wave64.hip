@@ -702,8 +702,11 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     values_s(t11, rw1, J + 1, IC1{});
                     load_rows(rw0, J + 2);
                     load_rows(rw1, J + 3);
+                    RW_ACC(1);
                     update4(t00, t00, t10, t11, J, IC2{}, std::true_type{});
+                    RW_ACC(2);
                     diag_tile_s(t00, J, ainv);
+                    RW_ACC(4);
                     if (fail != 0) break;
 #else
                     {   // (the diagonal tile by itself first: its factorisation wants the registers the other two tiles would hold)
@@ -721,8 +724,11 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #endif
                     solve_store_s(t10, J + 1, J, ainv);                     // L_{J+1,J}
                     wave_fence();
+                    RW_ACC(5);
                     update_r(t11, col1, J + 1, col0, col1);                 // -= L_{J+1,J} L_{J+1,J}'
+                    RW_ACC(2);
                     diag_tile_s(t11, J + 1, ainv1);
+                    RW_ACC(4);
                     if (fail != 0) break;
                 }
                 // ---- the tiles below it: two block rows x two block columns per pass
@@ -735,14 +741,19 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         values_s(t10, rw1, I + 1, IC0{});
                         values_s(t11, rw1, I + 1, IC1{});
                         if (BCBF_RW32_SUPER_AHEAD) { load_rows(rw0, I + 2); load_rows(rw1, I + 3); }
+                        RW_ACC(1);
                         update4(t00, t01, t10, t11, I, IC2{}, std::false_type{});
+                        RW_ACC(2);
                         solve_store_s(t00, I, J, ainv);
                         solve_store_s(t10, I + 1, J, ainv);
                         wave_fence();
+                        RW_ACC(5);
                         update2_r(t01, t11, col1, I, col0, col1);           // -= L_{I,J} L_{J+1,J}',  L_{I+1,J} L_{J+1,J}'
+                        RW_ACC(2);
                         solve_store_s(t01, I, J + 1, ainv1);
                         solve_store_s(t11, I + 1, J + 1, ainv1);
                         if (!BCBF_RW32_SUPER_AHEAD) { load_rows(rw0, I + 2); load_rows(rw1, I + 3); }
+                        RW_ACC(5);
                     } else {
                         values_s(t00, rw0, I, IC0{});
                         values_s(t01, rw0, I, IC1{});
@@ -997,6 +1008,10 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #ifdef BCBF_RW64_PROF
     if (Ld && lane == 0 && N > 8)
         for (int k = 0; k < 6; ++k) Ld[1 + k] = (T)prof[k];
+    // (no dense output: the counters go above the diagonal of the first full inverse tile -- column 31, rows 0..5, zeros
+    //  otherwise; development builds only)
+    if (!Ld && lane == 0)
+        for (int k = 0; k < 6; ++k) lop[lop_dfull_block(0, Np) + NB * 31 + k] = (T)prof[k];
 #endif
 }
 
