@@ -50,7 +50,11 @@ _TSIGS = {
     "bcbf_posterior_step": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_jets": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
-    "bcbf_cbc2_terms": [P] * 15 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_cbc2_terms": [P] * 15 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_refit_matern52": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_jets_matern52": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_mll_grad_matern52": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],
+    "bcbf_gp_append_matern52": [P] * 17 + [c_int, c_int, c_int, c_int, P],
     "bcbf_clean_hessian": [P, P, P, c_int, c_int, c_double, c_int, P],
     "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_socp": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],

@@ -99,13 +99,11 @@ def posterior_for(reg, xb, jets):
         CT = C * (1 + n)
         return hp, Mk, Bk, xb.new_zeros(b, CT, CT), xb.new_zeros(b, n, CT)
     st = reg._state()
-    if jets:
-        reg._require_rbf("the derivative GP (rel-degree-2 conditions)")
     if not jets:
         _, Mk, Bk, _ = reg._query(xb, want_W=False)
         return st, Mk, Bk, None, None
     Mk, Bk, G, Mj = ops.posterior_jets(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
-                                       st["M0"], xb, shared=True)
+                                       st["M0"], xb, shared=True, kernel=getattr(reg, "data_kernel", "rbf"))
     return st, Mk, Bk, G, Mj
 
 
@@ -143,7 +141,7 @@ def reldeg2_quadratic_terms(regressor, h, grad_h, hess_h, x, u0, k_alpha):
     rep = lambda t: t.expand(b, *t.shape[1:]).contiguous()
     (mA, mb), (Q, p, r), mean, var, status = ops.cbc2_terms(
         Mk, Bk, G, Mj, rep(st["A"]), rep(st["Bm"]), rep(st["ell"]), rep(st["s2"]), hv.contiguous(), gh, Hh,
-        torch.as_tensor(k_alpha, **f), ub, hessian_mode=_hessian_mode())
+        torch.as_tensor(k_alpha, **f), ub, hessian_mode=_hessian_mode(), kernel=getattr(regressor, "data_kernel", "rbf"))
     if bool((status == 1).any()):
         raise AssertionError(" Hessian must be positive definite")      # gp_algebra.py:386
     if single:
@@ -247,7 +245,8 @@ def lie1_gradient(model, grad_gp, x, eigeps=2e-3):
     idx = [(1 + i) * C for i in range(n)]
     Gm = G[0]
     s00, s_i = Bk[0, 0, 0], -Gm[idx, 0]
-    sij = torch.diag(s2 / (ell * ell) * B00) - Gm[idx][:, idx]
+    kxx = 5.0 / 3.0 if getattr(reg, "data_kernel", "rbf") == "matern52" else 1.0     # d2 k / dx dx' at x' = x, in units of s2 / ell^2
+    sij = torch.diag(kxx * s2 / (ell * ell) * B00) - Gm[idx][:, idx]
     Agh = A @ gh
     HAg = Hh @ Agh
     H = (Hh @ A @ Hh) * s00 + torch.outer(HAg, s_i) + torch.outer(s_i, HAg) + (gh @ Agh) * sij

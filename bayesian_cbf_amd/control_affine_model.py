@@ -116,8 +116,9 @@ class ControlAffineRegressor:
                  gamma_length_scale_prior=None, model_class=None, rank=None, dtype=None, generator=None,
                  data_kernel="rbf"):
         """data_kernel: "rbf" (the reference's ScaleKernel(RBFKernel(ard)), :164-171) or the OPT-IN "matern52"
-        (ScaleKernel(MaternKernel(nu=2.5, ard)); no reference counterpart, parity unpinned, bcbf.h): prediction only --
-        hyper-parameters by value (`set_kernel_params`), no `fit` iterations, no `append_data`, no derivative GP."""
+        (ScaleKernel(MaternKernel(nu=2.5, ard)); no reference counterpart, parity unpinned, bcbf.h): prediction, `fit`,
+        `append_data` and the derivative GP (rel-degree-2 conditions, expression trees) run on it; the matrix-core regime-S
+        query and the fused unicycle control step stay with the RBF."""
         if data_kernel not in ops.DATA_KERNELS:
             raise ValueError("data_kernel %r: one of %s" % (data_kernel, ops.DATA_KERNELS))
         self.data_kernel = data_kernel
@@ -314,7 +315,6 @@ class ControlAffineRegressor:
         if training_iter <= 0:
             return self
         self._require_gpu()
-        self._require_rbf("fit(training_iter > 0): the likelihood gradient")
         params = [p for p in self.model.parameters() if p.requires_grad]
         optimizer = torch.optim.Adam(params, lr=lr)
         scheduler = torch.optim.lr_scheduler.MultiStepLR(
@@ -348,7 +348,6 @@ class ControlAffineRegressor:
         if self.Xtrain is None:
             return self.fit(Xn, Un, Yn, training_iter=0)
         self._require_gpu()
-        self._require_rbf("append_data (bcbf_gp_append forms the new kernel column)")
         st = self._state()                                    # builds it if the cache was cleared
         ones = torch.ones(1, 1, dtype=self.dtype, device=self.device)
         for i in range(Xn.shape[0]):
@@ -357,7 +356,7 @@ class ControlAffineRegressor:
             for ntry in range(cholesky_tries):
                 jit = (factor * self.rand_fn(1)).reshape(1).contiguous()
                 Lop, Vw, X, UHB, info = ops.gp_append(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
-                                                      st["M0"], x_new, uh_new, y_new, jit)
+                                                      st["M0"], x_new, uh_new, y_new, jit, kernel=self.data_kernel)
                 if int(info[0]) == 0:
                     break                                      # (a failed pivot leaves st["Lop"] untouched: retry on it)
                 if ntry == cholesky_tries - 1:
@@ -398,7 +397,7 @@ class ControlAffineRegressor:
         factor = max(1e-5, (getattr(self, "_fit_jitter", None) or 1e-5) / 10)
         for ntry in range(10):
             jit = (factor * self.rand_fn(N)).to(wd)[None].contiguous() if jitter is None else jitter.to(wd)
-            Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit)
+            Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit, kernel=self.data_kernel)
             if int(info[0]) == 0:
                 break
             if ntry == 9 or jitter is not None:
@@ -416,7 +415,7 @@ class ControlAffineRegressor:
         Ainv = torch.linalg.inv(Ad_h).to(Ad)
         logdetA = float(torch.logdet(Ad_h))
         g_ell, g_s2, g_B, logdetK, RtA, UHtA = ops.mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv[None].contiguous(),
-                                                            hp["Bm"], hp["ell"], hp["s2"])
+                                                            hp["Bm"], hp["ell"], hp["s2"], kernel=self.data_kernel)
         scale = 1.0 / (N * n)
         nll = 0.5 * torch.trace(Ainv @ RtA[0]) + 0.5 * n * logdetK[0] + 0.5 * N * logdetA \
             + 0.5 * N * n * math.log(2 * math.pi)
@@ -498,7 +497,7 @@ class ControlAffineRegressor:
         N = X.shape[1]
         factor = cholesky_perturb_init
         Lop, start = None, 0
-        if self.rand_fn is self._default_rand_fn and self.data_kernel == "rbf" and K > 1:
+        if self.rand_fn is self._default_rand_fn and K > 1:
             # make_psd's schedule (:903-919) -- draw 1e-5 rand, factor, x10 and draw again on failure -- with the first K
             # levels factored SPECULATIVELY in one launch (K instances of the same system, one jitter vector each) and ONE
             # round trip to the host: an fp32 model of a few hundred points fails the first two or three levels on every
@@ -513,7 +512,8 @@ class ControlAffineRegressor:
                 states.append(self._rng_state())
                 f *= cholesky_perturb_scale
             rep = lambda t: t.expand(K, *t.shape[1:]).contiguous()
-            Lk, UHBk, infok, _ = ops.refit(Xk, UHk, rep(hp["Bm"]), rep(hp["ell"]), rep(hp["s2"]), torch.stack(jits))
+            Lk, UHBk, infok, _ = ops.refit(Xk, UHk, rep(hp["Bm"]), rep(hp["ell"]), rep(hp["s2"]), torch.stack(jits),
+                                           kernel=self.data_kernel)
             ok = (infok == 0).tolist()
             if any(ok):
                 j = ok.index(True)
@@ -526,12 +526,7 @@ class ControlAffineRegressor:
                     raise RuntimeError("cholesky: pivot %d is not positive after %d jitter retries" % (int(infok[-1]), cholesky_tries))
         for ntry in range(start, cholesky_tries):
             jitter = factor * self.rand_fn(N)
-            if self.data_kernel == "rbf":
-                Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous())
-            else:                   # opt-in kernels: dense K_b, then the factorisation of a caller-supplied matrix
-                Kb = ops.kb_build(X, UH, hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous(), kernel=self.data_kernel)
-                Lop, info, _ = ops.potrf(Kb)
-                UHB = (UH @ hp["Bm"]).contiguous()
+            Lop, UHB, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jitter[None].contiguous(), kernel=self.data_kernel)
             if int(info[0]) == 0:
                 break
             if ntry == cholesky_tries - 1:

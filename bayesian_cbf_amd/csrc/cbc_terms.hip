@@ -112,7 +112,7 @@ __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict_
                                   const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ hval,
                                   const T* __restrict__ gh_, const T* __restrict__ Hh_, const T* __restrict__ kalpha,
                                   const T* __restrict__ u0_, T* __restrict__ out, int* __restrict__ status,
-                                  int Bt, int n, int m, int hessian_mode) {
+                                  int Bt, int n, int m, int hessian_mode, int kernel_kind) {
     constexpr int NN = 4, MM = BCBF_MAX_CTRL_DIM, CC = MM + 1;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= Bt) return;
@@ -156,6 +156,7 @@ __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict_
     double e0[CC];
     for (int a = 0; a < CC; ++a) e0[a] = a == 0 ? 1.0 : 0.0;
     const double s00 = Bkd[0][0];
+    const double kxx = kernel_kind == 1 ? 5.0 / 3.0 : 1.0;      // d2 k / dx_d dx'_d at x' = x in units of s2 / ell_d^2: RBF 1, Matern-5/2 5/3
     double s_i[NN], H[NN][NN];
     for (int i = 0; i < NN; ++i) s_i[i] = i < n ? -Gat(1 + i, 0, 0, 0) : 0.0;
     for (int i = 0; i < NN; ++i)
@@ -165,7 +166,7 @@ __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict_
             double sij = 0;
             if (i < n && j < n) {
                 const double li = (double)ell[(size_t)b * n + i];
-                sij = (i == j ? s2 / (li * li) * B00 : 0.0) - Gat(1 + i, 0, 1 + j, 0);
+                sij = (i == j ? kxx * s2 / (li * li) * B00 : 0.0) - Gat(1 + i, 0, 1 + j, 0);
             }
             H[i][j] = hah * s00 + HAg[i] * s_i[j] + s_i[i] * HAg[j] + phi0 * sij;
         }
@@ -258,13 +259,13 @@ static int launch_clean_hessian(const T* Hin, T* Hout, int* status, int Bt, int 
 template <typename T>
 static int launch_cbc2_terms(const T* Mk, const T* Bk, const T* G, const T* Mj, const T* A, const T* Bm, const T* ell,
                              const T* s2, const T* h, const T* gh, const T* Hh, const T* kalpha, const T* u0, T* out,
-                             int* status, int Bt, int n, int m, int hessian_mode, void* stream) {
+                             int* status, int Bt, int n, int m, int hessian_mode, int kernel_kind, void* stream) {
     if (Bt <= 0) return BCBF_OK;
-    if (hessian_mode != 0 && hessian_mode != 1) return BCBF_EINVAL;
+    if ((hessian_mode != 0 && hessian_mode != 1) || (kernel_kind != 0 && kernel_kind != 1)) return BCBF_EINVAL;
     if (!Mk || !Bk || !G || !Mj || !A || !Bm || !ell || !s2 || !h || !gh || !Hh || !kalpha || !u0 || !out) return BCBF_EINVAL;
     if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     hipLaunchKernelGGL((cbc2_terms_kernel<T>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, Mk, Bk, G, Mj, A,
-                       Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode);
+                       Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, kernel_kind);
     return check_launch("cbc2_terms");
 }
 
@@ -290,13 +291,13 @@ int bcbf_clean_hessian_f64(const double* Hin, double* Hout, int* status, int Bt,
 int bcbf_cbc2_terms_f32(const float* Mk, const float* Bk, const float* G, const float* Mj, const float* A,
                         const float* Bm, const float* ell, const float* s2, const float* h, const float* gh,
                         const float* Hh, const float* kalpha, const float* u0, float* out, int* status,
-                        int Bt, int n, int m, int hessian_mode, void* stream) {
-    return bcbf::launch_cbc2_terms<float>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, stream);
+                        int Bt, int n, int m, int hessian_mode, int kernel_kind, void* stream) {
+    return bcbf::launch_cbc2_terms<float>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, kernel_kind, stream);
 }
 int bcbf_cbc2_terms_f64(const double* Mk, const double* Bk, const double* G, const double* Mj, const double* A,
                         const double* Bm, const double* ell, const double* s2, const double* h, const double* gh,
                         const double* Hh, const double* kalpha, const double* u0, double* out, int* status,
-                        int Bt, int n, int m, int hessian_mode, void* stream) {
-    return bcbf::launch_cbc2_terms<double>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, stream);
+                        int Bt, int n, int m, int hessian_mode, int kernel_kind, void* stream) {
+    return bcbf::launch_cbc2_terms<double>(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, out, status, Bt, n, m, hessian_mode, kernel_kind, stream);
 }
 }

@@ -46,7 +46,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
                 const T* __restrict__ Bm, const T* __restrict__ ell, const T* __restrict__ s2p,
                 T* __restrict__ g_ell, T* __restrict__ g_s2, T* __restrict__ g_B, T* __restrict__ logdetK,
                 T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C, int nt,
-                const T* __restrict__ lin, T* __restrict__ g_lin, double* __restrict__ work) {
+                const T* __restrict__ lin, T* __restrict__ g_lin, double* __restrict__ work, int kind) {
     // nt = number of target columns of R / alpha / A (== n for the matrix-variate model; 1 for the expanded
     // CoGP system); lin (optional) = weight of the linear part of the data kernel, k = exp(..) + lin x'x'.
     constexpr int V = Vec<T>::V;
@@ -91,7 +91,12 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
             d2 += z * z;
             dot += xi * xj;
         }
-        const double krbf = exp(-0.5 * d2);
+        double krbf, kder;                                   // kernel shape; its d / d ell_d is kder * z_d^2 / ell_d
+        if (kind == 1) {                                     // Matern-5/2 (opt-in)
+            const double a5 = sqrt(5.0 * d2), e5 = exp(-a5);
+            krbf = (1.0 + a5 + 5.0 / 3.0 * d2) * e5;
+            kder = 5.0 / 3.0 * (1.0 + a5) * e5;
+        } else { krbf = exp(-0.5 * d2); kder = krbf; }
         const double kij = krbf + linv * dot;
         double ui[CM], uj[CM], uij = 0.0;
 #pragma unroll
@@ -121,7 +126,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
         const double Gk = G * kij;
         gs += Gk * uij;
         glin += G * s2 * uij * dot;
-        const double GK = G * krbf * s2 * uij;               // G_ij times the RBF part of K_ij
+        const double GK = G * kder * s2 * uij;               // G_ij times the length-scale derivative's shape factor
 #pragma unroll
         for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) gl[d] += GK * dz2[d] * iell[d];       // z^2 / ell = dx^2 / ell^3
 #pragma unroll
@@ -177,7 +182,7 @@ template <typename T>
 static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T* X, const T* UH, const T* R,
                            const T* Ainv, const T* Bm, const T* ell, const T* s2, T* g_ell, T* g_s2, T* g_B, T* logdetK,
                            T* RtA, T* UHtA, int Bt, int N, int n, int m, void* stream, void* work, int nt = -1,
-                           const T* lin = nullptr, T* g_lin = nullptr) {
+                           const T* lin = nullptr, T* g_lin = nullptr, int kind = 0) {
     if (nt < 0) nt = n;
     if (Bt <= 0) return BCBF_OK;
     if (!Lop || !alpha || !Kinv || !X || !UH || !R || !Ainv || !Bm || !ell || !s2 || !g_ell || !g_s2 || !g_B || !logdetK ||
@@ -193,14 +198,14 @@ static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T*
     if (m <= BCBF_MAX_CTRL_DIM) {
         constexpr int CM = BCBF_MAX_CTRL_DIM + 1;
         hipLaunchKernelGGL((mll_grad_kernel<T, CM>), dim3(Bt, G), dim3(MG_T), 0, st, Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell,
-                           s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin, g_lin, (double*)work);
+                           s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin, g_lin, (double*)work, kind);
         if (G > 1)
             hipLaunchKernelGGL((mll_reduce_kernel<T, CM>), dim3(Bt), dim3(64), 0, st, (const double*)work, G, n, m + 1, g_ell,
                                g_s2, g_B, g_lin);
     } else {
         constexpr int CM = BCBF_MAX_TASK_DIM;
         hipLaunchKernelGGL((mll_grad_kernel<T, CM>), dim3(Bt, G), dim3(MG_T), 0, st, Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell,
-                           s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin, g_lin, (double*)work);
+                           s2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, lin, g_lin, (double*)work, kind);
         if (G > 1)
             hipLaunchKernelGGL((mll_reduce_kernel<T, CM>), dim3(Bt), dim3(192), 0, st, (const double*)work, G, n, m + 1, g_ell,
                                g_s2, g_B, g_lin);
@@ -231,6 +236,21 @@ int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv
                       int n, int m, void* work, void* stream) {
     return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
                                          UHtA, Bt, N, n, m, stream, work);
+}
+// ... for the opt-in Matern-5/2 data kernel (the reference has none; bcbf_kb_build_matern52)
+int bcbf_mll_grad_matern52_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                               const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
+                               float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
+                               void* work, void* stream) {
+    return bcbf::launch_mll_grad<float>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                        UHtA, Bt, N, n, m, stream, work, -1, nullptr, nullptr, 1);
+}
+int bcbf_mll_grad_matern52_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
+                               const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
+                               double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
+                               int n, int m, void* work, void* stream) {
+    return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                         UHtA, Bt, N, n, m, stream, work, -1, nullptr, nullptr, 1);
 }
 // Same sums for the data kernel s2 (exp(..) + lin x'x') and nt target columns (R, alpha [Bt,N,nt], Ainv [Bt,nt,nt],
 // RtA [Bt,nt,nt], UHtA [Bt,C,nt]); g_lin[Bt] = d log p / d lin.  nt = 1 with expanded inputs is the CoGP comparator

@@ -283,12 +283,15 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     d2 += z * z;
                     dot += xv[v][d] * xqr[qi][d];
                 }
-                T shape;
+                T shape, dshape;                       // dshape: d shape / d x_q,d = dshape * (X_id - x_q,d) / ell_d^2
                 if (kind == 1) {                       // Matern-5/2: (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r), r^2 = d2
                     const T a5 = (T)sqrt((double)(T(5) * d2));
-                    shape = (T(1) + a5 + T(5) / T(3) * d2) * texp<T>(-a5);
-                } else shape = texp<T>(T(-0.5) * d2);
+                    const T e5 = texp<T>(-a5);
+                    shape = (T(1) + a5 + T(5) / T(3) * d2) * e5;
+                    dshape = T(5) / T(3) * (T(1) + a5) * e5;
+                } else { shape = texp<T>(T(-0.5) * d2); dshape = shape; }
                 const T k = s2 * (shape + linv * dot);
+                const T kd = s2 * dshape;              // (jets: no linear part)
                 if constexpr (XC > 0) {                // the extra column: k(X_i, x2) (UH B)_i . uh2
                     T e2 = T(0), ud = T(0);
 #pragma unroll
@@ -304,7 +307,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                     for (int d = 0; d < NJ; ++d) {     // d Phi / d x_d = -(x_d - X_id)/ell_d^2 * Phi
                         const T dz = (xv[v][d] - xqr[qi][d]) * iell[d] * iell[d];
-                        BCBF_ACC(r, v, (1 + d) * C + c) = dz * k * ub;
+                        BCBF_ACC(r, v, (1 + d) * C + c) = dz * kd * ub;
                     }
                 }
             }
@@ -760,7 +763,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
 #define BCBF_PS_LAUNCH(CC, NSS) hipLaunchKernelGGL((posterior_step_kernel<T, CC, NSS, 0>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, nullptr, nullptr, shared, N, Np, n, lin, Bt, Nl, ldN, kind, (const T*)nullptr)
-#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt, Nl, ldN, 0, (const T*)nullptr)
+#define BCBF_PJ_LAUNCH(CC, NN) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, NN>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt, Nl, ldN, kind, (const T*)nullptr)
     if (xq2 != nullptr) {
         // two queries per instance (xq[b], xq2[b]) on one pass over its factor: outputs interleaved, Mk / Bk [Bt, 2, ..],
         // Wout [Bt, 2, Np, C]
@@ -772,7 +775,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
         return check_launch("posterior_pair");
     }
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
-        if (!Mfull || lin || kind != 0) return BCBF_EINVAL;
+        if (!Mfull || lin || (kind != 0 && kind != 1)) return BCBF_EINVAL;
         if (n > 4) return BCBF_EINVAL;                  // (the rel-degree-2 terms kernel holds n <= 4 too)
         switch (10 * n + m) {                           // every (n <= 4, m <= 3): C = 1 + m columns x (1 + n) jets
             case 11: BCBF_PJ_LAUNCH(2, 1); break;
@@ -902,8 +905,7 @@ extern "C" int bcbf_posterior_query_rbflin_f64(const double* Lop, const double* 
 // Mj[Bt,n,CT] = Vw'Wj (so Mk = M0' + Mj[:, :C], dMk/dx_d = Mj[:, (1+d)C:(2+d)C]).  Feeds bcbf_cbc2_terms.
 // Wj (optional, [Bt, Np, CT]) = L^-1 [Phi, dPhi/dx_d]: lets the caller form the derivative kernels between two
 // DIFFERENT states, d/dx d/dx' B_k(x, x') = d2k/dxdx' Bm - dW_d(x)'dW_e(x')  (GradientGP.knl(x, x'), gp_algebra.py:355-393).
-// Replaces autograd through custom_predict in GradientGP (gp_algebra.py:340-402).  Compiled for
-// (n,m) in {(1,1),(2,1),(2,2),(3,2)}.
+// Replaces autograd through custom_predict in GradientGP (gp_algebra.py:340-402).  Every (n <= 4, m <= 3).
 extern "C" int bcbf_posterior_jets_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
                                        const float* ell, const float* s2, const float* Bm, const float* M0,
                                        const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj,
@@ -943,6 +945,25 @@ extern "C" int bcbf_posterior_query_reserved_f64(const double* Lop, const double
 
 // The same queries with the Matern-5/2 data kernel  k = s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r),  r^2 = sum_d ((x_d - x'_d) / ell_d)^2
 // (gpytorch MaternKernel(nu = 2.5, ard) under ScaleKernel).  OPT-IN and parity unpinned: the reference has no Matern
+// (and the derivative jets of the same kernel, bcbf_posterior_jets_matern52: d k / d x_d = -(5/3) s2 (1 + a) exp(-a) (x_d - x'_d) / ell_d^2)
+extern "C" int bcbf_posterior_jets_matern52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                                const float* ell, const float* s2, const float* Bm, const float* M0,
+                                                const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj,
+                                                int shared, int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!G || !Mj) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, Wj, shared, Bt, N, n, m, stream, G, Mj,
+                                              nullptr, 0, 1);
+}
+extern "C" int bcbf_posterior_jets_matern52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                                const double* ell, const double* s2, const double* Bm, const double* M0,
+                                                const double* xq, double* Mk, double* Bk, double* G, double* Mj, double* Wj,
+                                                int shared, int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!G || !Mj) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, Wj, shared, Bt, N, n, m, stream, G, Mj,
+                                               nullptr, 0, 1);
+}
 // kernel (its data kernels are RBF and RBF + Linear); offered because the task statement names an "RBF x Matern" kernel
 // build.  Streaming kernel only (shared != 0: one GP, many queries, from cache); K_b: bcbf_kb_build_matern52 + bcbf_potrf.
 extern "C" int bcbf_posterior_query_matern52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,

@@ -1448,7 +1448,9 @@ template <typename T, int NW> struct RTShared {
     int fail;
 };
 
-template <typename T, int NW, bool FROM_DENSE>
+// KIND: data kernel of the on-the-fly K_b values -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_refit_matern52:
+// only this form is compiled for it, the team of eight serves every batch size there)
+template <typename T, int NW, bool FROM_DENSE, int KIND = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW)
 refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
@@ -1602,7 +1604,12 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
-                    T val = s2 * P::exp_neg(T(T(0.5)) * d2) * uu + (i == j ? rj[ib] : T(0.0));
+                    T shape;
+                    if constexpr (KIND == 1) {                     // Matern-5/2: (1 + a + a^2 / 3) exp(-a), a = sqrt(5 d2)
+                        const T a5 = (T)__builtin_sqrt((double)(T(5.0) * d2));
+                        shape = (T(1.0) + a5 + T(5.0) / T(3.0) * d2) * P::exp_neg(a5);
+                    } else shape = P::exp_neg(T(T(0.5)) * d2);
+                    T val = s2 * shape * uu + (i == j ? rj[ib] : T(0.0));
                     val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;
                     acc[cb][ib][r] = -val;                         // the accumulators carry -S' (see update)
                 }
@@ -1818,8 +1825,14 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
 template <typename T>
 static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter, const T* Kdense,
-                             T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, int nw, hipStream_t st) {
+                             T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, int nw, hipStream_t st,
+                             int kind = 0) {
     if (Np / NB > RT_MAXBLK) return -1;
+    if (kind == 1) {
+        if (Kdense || (unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 1>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        return 0;
+    }
     // the kernel addresses one instance's operator with 32-bit byte offsets (buffer resource size, scalar + lane offsets)
     if ((unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;
     // four waves per instance (two workgroups per CU) when the batch needs more than one workgroup per CU but not more than
@@ -1839,6 +1852,26 @@ int launch_refit_team64(const double* X, const double* UH, const double* Bm, con
                         int Np, int n, int C, int nw, hipStream_t st) {
     return launch_refit_team<double>(X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, nw, st);
 }
+}  // namespace bcbf
+
+// Fused K_b build + jittered Cholesky + packing with the OPT-IN Matern-5/2 data kernel (the reference has no Matern kernel;
+// BASELINE.json's north_star names one): arguments of bcbf_refit.  One form -- a team of eight waves per instance.
+#define BCBF_REFIT_MATERN(SUF, T)                                                                                           \
+    extern "C" int bcbf_refit_matern52_##SUF(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,   \
+                                             T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int n, int m, void* stream) { \
+        using namespace bcbf;                                                                                                \
+        if (Bt <= 0) return BCBF_OK;                                                                                         \
+        if (!X || !UH || !Bm || !ell || !s2 || !Lop || !UHB || !info || N < 1) return BCBF_EINVAL;                            \
+        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;                            \
+        if (launch_refit_team<T>(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, round_up(N, NB), n,      \
+                                 m + 1, 8, (hipStream_t)stream, 1) != 0)                                                     \
+            return BCBF_EINVAL;                                                                                              \
+        return check_launch("refit_matern52");                                                                               \
+    }
+BCBF_REFIT_MATERN(f32, float)
+BCBF_REFIT_MATERN(f64, double)
+#undef BCBF_REFIT_MATERN
+namespace bcbf {
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                         const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N,
                         int Np, int n, int C, int nw, hipStream_t st) {

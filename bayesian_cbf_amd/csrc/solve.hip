@@ -225,6 +225,7 @@ struct AppendFused {
     const T *Vw_in, *X_in, *UHB_in, *ell, *s2, *Bm, *M0, *x_new, *uh_new, *xdot_new, *jitter_new;
     T *Vw_out, *X_out, *UHB_out;
     int n, C;
+    int kind;            // data kernel of the new column: 0 = RBF, 1 = Matern-5/2 (opt-in)
     const T* Wgiven;     // optional: W = L^-1 Phi(x_new) [Bt, NpI, C] from the streaming posterior kernel (bcbf_gp_append_stream):
                          // l = W uh_new, the forward solve below is skipped
 };
@@ -321,7 +322,10 @@ chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict
 #pragma unroll
                 for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
                     if (c < C) uu += f.UHB_in[((size_t)b * N + i) * C + c] * f.uh_new[(size_t)b * C + c];
-                v = s2v * (T)exp((double)(T(-0.5) * d2)) * uu;
+                if (f.kind == 1) {
+                    const double a5 = sqrt(5.0 * (double)d2);
+                    v = s2v * (T)((1.0 + a5 + 5.0 / 3.0 * (double)d2) * exp(-a5)) * uu;
+                } else v = s2v * (T)exp((double)(T(-0.5) * d2)) * uu;
             }
             y[r] = v;
         }
@@ -442,7 +446,7 @@ template <typename T>
 static int launch_gp_append(const T* Lin, const T* Vw_in, const T* X_in, const T* UHB_in, const T* ell, const T* s2,
                             const T* Bm, const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,
                             const T* jitter_new, T* Lout, T* Vw_out, T* X_out, T* UHB_out, int* info, int Bt, int N,
-                            int n, int m, void* stream, const T* Wgiven = nullptr) {
+                            int n, int m, void* stream, const T* Wgiven = nullptr, int kind = 0) {
     if (Bt <= 0) return BCBF_OK;
     if (!Lin || !Vw_in || !X_in || !UHB_in || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !Lout ||
         !Vw_out || !X_out || !UHB_out || !info || N < 1)
@@ -453,7 +457,7 @@ static int launch_gp_append(const T* Lin, const T* Vw_in, const T* X_in, const T
     if (NpO > ST * SMAXR) return BCBF_EINVAL;
     if (Lin == Lout && NpI != NpO) return BCBF_EINVAL;
     AppendFused<T> f{Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, Vw_out, X_out, UHB_out,
-                     n, m + 1, Wgiven};
+                     n, m + 1, kind, Wgiven};
     hipLaunchKernelGGL((chol_append_kernel<T, true>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lin, nullptr, nullptr,
                        Lout, info, N, NpI, NpO, f);
     return check_launch("gp_append");
@@ -683,6 +687,22 @@ int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const d
     if (rc != BCBF_OK) return rc;
     return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
                                           jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, Wwork);
+}
+// ... with the opt-in Matern-5/2 data kernel for the new column (the simple forward solve; no reference counterpart)
+int bcbf_gp_append_matern52_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                                const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                                const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                                float* Vw_out, float* X_out, float* UHB_out, int* info, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_gp_append<float>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                         jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, nullptr, 1);
+}
+int bcbf_gp_append_matern52_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                                const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                                const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                                double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
+                                void* stream) {
+    return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                          jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, nullptr, 1);
 }
 int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
                          int* info, int Bt, int N, void* stream) {

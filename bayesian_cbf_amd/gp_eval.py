@@ -97,15 +97,23 @@ class _ModelJets:
         f = dict(dtype=pts.dtype, device=pts.device)
         self.f = f
         fixed = isinstance(reg, FixedKernelGP)
-        if not fixed and hasattr(reg, "_require_rbf"):
-            reg._require_rbf("node-by-node evaluation of GP expression trees (analytic RBF derivatives)")
+        kernel = "rbf" if fixed else getattr(reg, "data_kernel", "rbf")
         hp = reg._hyper() if (fixed or reg.Xtrain is None) else reg._state()
         self.A = hp["A"][0]
         B, ell, s2 = hp["Bm"][0], hp["ell"][0], hp["s2"][0]
-        # ---- prior kernel and its derivatives (RBF-ARD; the fixed-kernel models have a constant kernel)
+        # ---- prior kernel and its derivatives (RBF-ARD, or the opt-in Matern-5/2; the fixed-kernel models have a constant kernel)
         d = (pts[0] - pts[1]) / (ell * ell)                          # (x - x') / ell^2
         if fixed:
             k, kx, kp, kxp = s2, pts.new_zeros(n), pts.new_zeros(n), pts.new_zeros(n, n)
+        elif kernel == "matern52":
+            # k = s2 (1 + a + a^2/3) e^-a, a = sqrt5 r;  dk/dx = -g d with g = (5/3) s2 (1 + a) e^-a;
+            # d2k / dx_d dx'_e = g delta_de / ell_d^2 - (25/3) s2 e^-a d_d d_e
+            a = torch.sqrt(5.0 * ((pts[0] - pts[1]) ** 2 / (ell * ell)).sum())
+            ea = torch.exp(-a)
+            k = s2 * (1.0 + a + a * a / 3.0) * ea
+            g_ = 5.0 / 3.0 * s2 * (1.0 + a) * ea
+            kx, kp = -d * g_, d * g_
+            kxp = torch.diag(1.0 / (ell * ell)) * g_ - (25.0 / 3.0) * s2 * ea * torch.outer(d, d)
         else:
             k = s2 * torch.exp(-0.5 * ((pts[0] - pts[1]) ** 2 / (ell * ell)).sum())
             kx, kp = -d * k, d * k
@@ -122,12 +130,12 @@ class _ModelJets:
             st = hp
             if order == 0:
                 Mk, _, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
-                                               st["M0"], pts, shared=True, want_W=True)
+                                               st["M0"], pts, shared=True, want_W=True, kernel=kernel)
                 self.Mk = Mk
                 self.B00 = self.B00 - W[0].t() @ W[1]
             else:
                 Mk, _, _, Mj, Wj = ops.posterior_jets(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"],
-                                                      st["Bm"], st["M0"], pts, shared=True, want_W=True)
+                                                      st["Bm"], st["M0"], pts, shared=True, want_W=True, kernel=kernel)
                 self.Mk = Mk
                 self.dMk = torch.stack([Mj[:, :, (1 + dd) * C:(2 + dd) * C] for dd in range(n)], dim=1)
                 G = (Wj[0].t() @ Wj[1]).reshape(1 + n, C, 1 + n, C)    # [a, c, b, c'] = W_a(x)' W_b(x')

@@ -74,9 +74,16 @@ def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None, kernel="rbf"):
     return Kb
 
 
-def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None):
+def _kern(base, kernel):
+    if kernel not in DATA_KERNELS:
+        raise ValueError("kernel %r: one of %s" % (kernel, DATA_KERNELS))
+    return base + ("_matern52" if kernel == "matern52" else "")
+
+
+def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None, kernel="rbf"):
     """Fused K_b build + Cholesky + packing.  Returns (Lop[Bt,E], UHB[Bt,N,C], info[Bt], Ldense|None).
-    out = (Lop, UHB, info): write into the caller's buffers (a closed loop that has bound their addresses)."""
+    out = (Lop, UHB, info): write into the caller's buffers (a closed loop that has bound their addresses).
+    kernel="matern52": the opt-in Matern-5/2 data kernel (bcbf_refit_matern52)."""
     _chk(X, UH, Bm, ell, s2, jitter)
     Bt, N, n = X.shape
     C = UH.shape[2]
@@ -89,8 +96,8 @@ def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None):
         UHB = torch.empty(Bt, N, C, dtype=X.dtype, device=X.device)
         info = torch.empty(Bt, dtype=torch.int32, device=X.device)
     Ld = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device) if want_dense else None
-    check(getattr(lib, "bcbf_refit" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
-                                               _p(Ld), _p(info), Bt, N, n, C - 1, _stream(X)), "bcbf_refit")
+    check(getattr(lib, _kern("bcbf_refit", kernel) + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
+                                                              _p(Ld), _p(info), Bt, N, n, C - 1, _stream(X)), "bcbf_refit")
     return Lop, UHB, info, Ld
 
 
@@ -131,7 +138,7 @@ def chol_append(Lop, knew, kappa, N):
 GP_APPEND_STREAM_MIN_N = int(os.environ.get("BCBF_APPEND_STREAM_MIN_N", "384"))
 
 
-def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new=None):
+def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new=None, kernel="rbf"):
     """Online update: one observation per instance enters the GP without refactorisation.
     Returns (Lop', Vw'[Bt,N+1,n], X'[Bt,N+1,n], UHB'[Bt,N+1,C], info).  The operator is updated in place
     (the returned Lop' IS Lop) while N+1 stays inside the same 32-row padding, re-packed otherwise.
@@ -145,6 +152,11 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
     Lout = Lop if same_pad else torch.empty(Bt, lop_elems(N + 1, X.dtype), **f)
     Vw2, X2, UHB2 = torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, C, **f)
     info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+    if kernel != "rbf":                                # opt-in kernels: the simple forward solve
+        check(getattr(lib, _kern("bcbf_gp_append", kernel) + _suf(X))(
+            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(x_new), _p(uh_new), _p(xdot_new),
+            _p(jitter_new), _p(Lout), _p(Vw2), _p(X2), _p(UHB2), _p(info), Bt, N, n, C - 1, _stream(X)), "bcbf_gp_append")
+        return Lout, Vw2, X2, UHB2, info
     if N >= GP_APPEND_STREAM_MIN_N:
         Np = (N + 31) // 32 * 32
         Ww, Mkw, Bkw = torch.empty(Bt, Np, C, **f), torch.empty(Bt, n, C, **f), torch.empty(Bt, C, C, **f)
@@ -347,7 +359,7 @@ def _mll_work(Bt, N, m, device):
     return buf
 
 
-def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None):
+def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None, kernel="rbf"):
     """O(N^2) sums of the marginal-log-likelihood gradient (bcbf.h K12).  Returns
     (g_ell[Bt,n], g_s2[Bt], g_B[Bt,C,C], logdetK[Bt], RtA[Bt,nt,nt], UHtA[Bt,C,nt]) (+ g_lin[Bt] when `lin` is given:
     RBF + Linear data kernel, nt = R.shape[2] target columns)."""
@@ -366,7 +378,7 @@ def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None):
         return g_ell, g_s2, g_B, logdet, RtA, UHtA, g_lin
     g_ell, g_s2, g_B = torch.empty(Bt, n, **f), torch.empty(Bt, **f), torch.empty(Bt, C, C, **f)
     logdet, RtA, UHtA = torch.empty(Bt, **f), torch.empty(Bt, n, n, **f), torch.empty(Bt, C, n, **f)
-    check(getattr(lib, "bcbf_mll_grad" + _suf(X))(_p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm),
+    check(getattr(lib, _kern("bcbf_mll_grad", kernel) + _suf(X))(_p(Lop), _p(alpha), _p(Kinv), _p(X), _p(UH), _p(R), _p(Ainv), _p(Bm),
                                                   _p(ell), _p(s2), _p(g_ell), _p(g_s2), _p(g_B), _p(logdet), _p(RtA),
                                                   _p(UHtA), Bt, N, n, C - 1, _p(_mll_work(Bt, N, C - 1, X.device)),
                                                   _stream(X)), "bcbf_mll_grad")
@@ -445,7 +457,7 @@ def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=
     return Mk, Bk, W
 
 
-def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False, want_W=False):
+def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False, want_W=False, kernel="rbf"):
     """(Mk, Bk, G[b,CT,CT], Mj[b,n,CT]) with CT = (1+m)(1+n): value + first x-derivative jets
     (replaces autograd through custom_predict in GradientGP, gp_algebra.py:340-402).  want_W: also
     Wj[b,Np,CT] = L^-1 [Phi, dPhi/dx_d] (fifth return value), for derivative kernels between different states."""
@@ -458,10 +470,9 @@ def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False, want_W=Fa
     Mk, Bk = torch.empty(b, n, C, **f), torch.empty(b, C, C, **f)
     G, Mj = torch.empty(b, CT, CT, **f), torch.empty(b, n, CT, **f)
     Wj = torch.empty(b, (N + 31) // 32 * 32, CT, **f) if want_W else None
-    check(getattr(lib, "bcbf_posterior_jets" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm),
-                                                        _p(M0), _p(xq), _p(Mk), _p(Bk), _p(G), _p(Mj), _p(Wj),
-                                                        1 if shared else 0, b, N, n, C - 1, _stream(X)),
-          "bcbf_posterior_jets")
+    check(getattr(lib, _kern("bcbf_posterior_jets", kernel) + _suf(X))(
+        _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq), _p(Mk), _p(Bk), _p(G), _p(Mj), _p(Wj),
+        1 if shared else 0, b, N, n, C - 1, _stream(X)), "bcbf_posterior_jets")
     return (Mk, Bk, G, Mj, Wj) if want_W else (Mk, Bk, G, Mj)
 
 
@@ -482,7 +493,7 @@ def clean_hessian(H, eigeps=2e-3, mode="reference"):
     return out, status
 
 
-def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, hessian_mode="reference"):
+def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, hessian_mode="reference", kernel="rbf"):
     """Rel-degree-2 terms (cbc2_gp + cbc2_quadratic_terms, cbc2.py:7-33).  Returns
     ((mean_A[b,m], mean_b[b]), (Q[b,m,m], p[b,m], r[b]), mean[b], var[b], status[b]); status 1 = the reference's
     positive-definiteness assert fails, 4 / 6 = the Hessian clean-up ran (`clean_hessian`), 0 otherwise."""
@@ -493,7 +504,8 @@ def cbc2_terms(Mk, Bk, G, Mj, A, Bm, ell, s2, h, gh, Hh, kalpha, u0, hessian_mod
     status = torch.empty(b, dtype=torch.int32, device=Mk.device)
     check(getattr(lib, "bcbf_cbc2_terms" + _suf(Mk))(_p(Mk), _p(Bk), _p(G), _p(Mj), _p(A), _p(Bm), _p(ell), _p(s2),
                                                      _p(h), _p(gh), _p(Hh), _p(kalpha), _p(u0), _p(out), _p(status),
-                                                     b, n, m, HESSIAN_MODES[hessian_mode], _stream(Mk)), "bcbf_cbc2_terms")
+                                                     b, n, m, HESSIAN_MODES[hessian_mode], DATA_KERNELS.index(kernel),
+                                                     _stream(Mk)), "bcbf_cbc2_terms")
     o = 0
     mean_A = out[:, o:o + m]; o += m
     mean_b = out[:, o]; o += 1

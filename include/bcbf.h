@@ -165,8 +165,43 @@ int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const d
  * kernel anywhere (its data kernels: ScaleKernel(RBFKernel(ard)), control_affine_model.py:164-171, and RBF + Linear,
  * :1121-1122); it is offered because the task statement names an "RBF x Matern kernel-block build", checked at formula level
  * against an independent implementation (scikit-learn's Matern(nu=2.5)), and is never the default.
- * The path: bcbf_kb_build_matern52 -> bcbf_potrf -> bcbf_potrs -> bcbf_posterior_query_matern52 (streaming kernel; `shared`
- * as in bcbf_posterior_query).  Not offered with this kernel: the fused refit, jets, the likelihood gradient. */
+ * The path: bcbf_refit_matern52 (fused build + jittered Cholesky + packing; or bcbf_kb_build_matern52 -> bcbf_potrf) ->
+ * bcbf_potrs -> bcbf_posterior_query_matern52 (streaming kernel; `shared` as in bcbf_posterior_query); rel-degree-2:
+ * bcbf_posterior_jets_matern52 + bcbf_cbc2_terms(kernel_kind = 1); fit: bcbf_mll_grad_matern52; online: bcbf_gp_append_matern52.
+ * (Round 4: fused refit, jets, likelihood gradient, append.)  Not offered with this kernel: the matrix-core regime-S query
+ * and the fused unicycle control step (both read the RBF through their own value code). */
+int bcbf_refit_matern52_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                            const float* jitter, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N, int n, int m,
+                            void* stream);
+int bcbf_refit_matern52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                            const double* jitter, double* Lop, double* UHB, double* Ldense, int* info, int Bt, int N, int n, int m,
+                            void* stream);
+/* arguments of bcbf_posterior_jets / bcbf_mll_grad / bcbf_gp_append */
+int bcbf_posterior_jets_matern52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                     const float* ell, const float* s2, const float* Bm, const float* M0,
+                                     const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj, int shared,
+                                     int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_jets_matern52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                     const double* ell, const double* s2, const double* Bm, const double* M0,
+                                     const double* xq, double* Mk, double* Bk, double* G, double* Mj, double* Wj, int shared,
+                                     int Bt, int N, int n, int m, void* stream);
+int bcbf_mll_grad_matern52_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                               const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
+                               float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
+                               void* work, void* stream);
+int bcbf_mll_grad_matern52_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
+                               const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
+                               double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
+                               int n, int m, void* work, void* stream);
+int bcbf_gp_append_matern52_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                                const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                                const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                                float* Vw_out, float* X_out, float* UHB_out, int* info, int Bt, int N, int n, int m, void* stream);
+int bcbf_gp_append_matern52_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                                const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                                const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                                double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
+                                void* stream);
 int bcbf_kb_build_matern52_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                                const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream);
 int bcbf_kb_build_matern52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
@@ -339,16 +374,18 @@ int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X
  * (gp_algebra.py:384-392): hessian_mode 0 = the reference's formula `eigenvectors.T @ diag(evalz) @ eigenvectors` on the
  * eigenvectors of the GENERAL solver (xGEEV's order and signs, csrc/geev_small.h); 1 = the spectral projection
  * V max(L,0) V' of the symmetric part (what rounds 1-3 did; differs from the reference whenever the branch runs).
+ * kernel_kind: the data kernel the jets came from, 0 = RBF (the reference's), 1 = Matern-5/2 (its prior term
+ * d2 k / dx_d dx'_d at x' = x is (5/3) s2 / ell_d^2 instead of s2 / ell_d^2).
  * status[Bt] (optional): 0 = nothing to clean, 1 = an eigenvalue <= -2e-3 (the reference asserts), 4 = eigenvalues in
  * (-2e-3, 0) were zeroed, 6 = zeroed through the projection because xGEEV's path met a complex pair. */
 int bcbf_cbc2_terms_f32(const float* Mk, const float* Bk, const float* G, const float* Mj, const float* A,
                         const float* Bm, const float* ell, const float* s2, const float* h, const float* gh,
                         const float* Hh, const float* kalpha, const float* u0, float* out, int* status,
-                        int Bt, int n, int m, int hessian_mode, void* stream);
+                        int Bt, int n, int m, int hessian_mode, int kernel_kind, void* stream);
 int bcbf_cbc2_terms_f64(const double* Mk, const double* Bk, const double* G, const double* Mj, const double* A,
                         const double* Bm, const double* ell, const double* s2, const double* h, const double* gh,
                         const double* Hh, const double* kalpha, const double* u0, double* out, int* status,
-                        int Bt, int n, int m, int hessian_mode, void* stream);
+                        int Bt, int n, int m, int hessian_mode, int kernel_kind, void* stream);
 
 /* The clean-up of gp_algebra.py:384-392 alone, on a batch of n x n matrices (row-major, n <= 4): every eigenvalue must
  * be > -eps (else status 1 and the matrix is returned unchanged); eigenvalues in (-eps, 0) are zeroed and the matrix

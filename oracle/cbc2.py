@@ -10,7 +10,7 @@ misc.py:268-285).  Everything is a function of the *jet* of the posterior at x:
 import numpy as np
 import scipy.linalg as sla
 
-from .gp_posterior import rbf_ard_kernel
+from .gp_posterior import rbf_ard_kernel, matern52_ard_kernel, matern52_ard_grad
 
 EIG_EPS = 2e-3   # gp_algebra.py:317: eigenvalues of the kernel Hessian in (-EPS, 0) are treated as rounding
 
@@ -46,7 +46,7 @@ def clean_hessian(H, eps=EIG_EPS, mode="reference"):
     return H, False
 
 
-def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x):
+def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x, kernel="rbf"):
     """Value and first x-derivatives of the posterior factors at one query x.
 
     Returns dict(Mk[n,C], dMk[n(d),n,C], Bk[C,C], G10[n(d),C,C] = dW_d'W, G11[n,n,C,C] = dW_d'dW_e).
@@ -54,13 +54,17 @@ def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x):
     through k(X, x), :442-443.)
     """
     n = X.shape[1]
-    kstar = rbf_ard_kernel(X, x[None], ell, s2)[:, 0]
+    if kernel == "matern52":                  # the opt-in data kernel (no reference counterpart)
+        kstar = matern52_ard_kernel(X, x[None], ell, s2)[:, 0]
+        dkm = matern52_ard_grad(X, x, ell, s2)
+    else:
+        kstar = rbf_ard_kernel(X, x[None], ell, s2)[:, 0]
     Phi = kstar[:, None] * UHB
     W = sla.solve_triangular(L, Phi, lower=True)
     Vw = sla.solve_triangular(L, Y, lower=True)
     dW = []
     for d in range(n):
-        dk = -(x[d] - X[:, d]) / ell[d] ** 2 * kstar
+        dk = dkm[:, d] if kernel == "matern52" else -(x[d] - X[:, d]) / ell[d] ** 2 * kstar
         dW.append(sla.solve_triangular(L, dk[:, None] * UHB, lower=True))
     Mk = M0.T + Vw.T @ W
     dMk = np.stack([Vw.T @ dW[d] for d in range(n)])
@@ -70,7 +74,7 @@ def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x):
     return dict(Mk=Mk, dMk=dMk, Bk=Bk, G10=G10, G11=G11)
 
 
-def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0, hessian_mode="reference", info=None):
+def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0, hessian_mode="reference", info=None, kernel="rbf"):
     """((mean_A, mean_b), (Q, p, r), mean(u0), var(u0)) of cbc2_quadratic_terms(cbc2_gp(...), x, u0).
 
     h, gh[n], Hh[n,n]: barrier value, gradient, Hessian at x.  The cross term C = cov(grad L_f h, f+gu)
@@ -94,7 +98,8 @@ def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0, hessian_mode="refer
     # H_ij = d2/dx_i dx'_j [ gh(x)'A gh(x') s(x,e0;x',e0) ] at x' = x
     s00 = Bk[0, 0]
     s_i = np.array([-G10[i][0, 0] for i in range(n)])                 # ds/dx_i (= ds/dx'_i by symmetry)
-    s_ij = np.array([[(s2 / ell[i] ** 2 * Bm[0, 0] if i == j else 0.0) - G11[i][j][0, 0] for j in range(n)]
+    kxx = 5.0 / 3.0 if kernel == "matern52" else 1.0        # d2 k / dx_d dx'_d at x' = x in units of s2 / ell_d^2
+    s_ij = np.array([[(kxx * s2 / ell[i] ** 2 * Bm[0, 0] if i == j else 0.0) - G11[i][j][0, 0] for j in range(n)]
                      for i in range(n)])
     HAg = Hh @ Agh
     H = (Hh @ A @ Hh) * s00 + np.outer(HAg, s_i) + np.outer(s_i, HAg) + phi0 * s_ij

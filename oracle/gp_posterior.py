@@ -46,6 +46,15 @@ def matern52_ard_kernel(X1, X2, ell, s2):
     return s2 * (1.0 + a + 5.0 / 3.0 * r * r) * np.exp(-a)
 
 
+def matern52_ard_grad(X, x, ell, s2):
+    """d k(X_i, x) / d x_d [N, n] of the opt-in Matern-5/2 kernel: -(5/3) s2 (1 + a) exp(-a) (x_d - X_id) / ell_d^2, a = sqrt5 r
+    (differentiating the definition above; checked against central differences in tests/test_oracle_formulas.py)."""
+    ell = np.asarray(ell, dtype=np.float64)
+    z = (np.asarray(x)[None, :] - np.atleast_2d(X)) / ell
+    a = np.sqrt(5.0 * (z * z).sum(-1))
+    return -(5.0 / 3.0) * s2 * ((1.0 + a) * np.exp(-a))[:, None] * z / ell
+
+
 def index_kernel_covar(covar_factor, raw_var):
     """gpytorch IndexKernel.covar_matrix = F F^T + diag(softplus(raw_var)); used for A and B
     (bayes_cbf/matrix_variate_multitask_kernel.py:37-41, control_affine_model.py:158-163)."""
@@ -60,9 +69,10 @@ def homogeneous_controls(U, fill=1.0):
 
 
 # --------------------------------------------------------------------------- refit state
-def kb_matrix(X, UH, Bm, ell, s2):
-    """K_b = k(X,X) o (UH Bm UH^T)   (control_affine_model.py:370-372)."""
-    return rbf_ard_kernel(X, X, ell, s2) * (UH @ Bm @ UH.T)
+def kb_matrix(X, UH, Bm, ell, s2, kernel="rbf"):
+    """K_b = k(X,X) o (UH Bm UH^T)   (control_affine_model.py:370-372).  kernel="matern52": the opt-in data kernel."""
+    k = matern52_ard_kernel if kernel == "matern52" else rbf_ard_kernel
+    return k(X, X, ell, s2) * (UH @ Bm @ UH.T)
 
 
 def make_psd(Kb, rand_draws, cholesky_tries=10, perturb_init=1e-5, perturb_scale=10):
@@ -249,7 +259,7 @@ def chol_append(L, knew, kappa):
 
 
 # --------------------------------------------------------------------------- marginal likelihood (fit)
-def marginal_log_likelihood(X, UH, Y, A, Bm, ell, s2, M0, jitter):
+def marginal_log_likelihood(X, UH, Y, A, Bm, ell, s2, M0, jitter, kernel="rbf"):
     """log p(vec Y) of the training set under the matrix-variate prior: covariance K_b (x) A over (points, state dims)
     (HetergeneousMatrixVariateKernel on mask-1 rows, matrix_variate_multitask_kernel.py:112-118: K11 = (H K(x)B H') (x) A,
     H K(x)B H' = k(X,X) o (UH B UH')), constant mean UH M0, no observation noise (IdentityLikelihood,
@@ -258,7 +268,7 @@ def marginal_log_likelihood(X, UH, Y, A, Bm, ell, s2, M0, jitter):
     lives in the un-vendored gpytorch fork: PARITY UNPINNED, restated from the Gaussian log density.
       log p = -1/2 tr(A^-1 R' K_b^-1 R) - n/2 logdet K_b - N/2 logdet A - N n/2 log 2 pi,   R = Y - UH M0."""
     N, n = Y.shape
-    Kb = kb_matrix(X, UH, Bm, ell, s2) + np.diag(np.asarray(jitter, dtype=np.float64))
+    Kb = kb_matrix(X, UH, Bm, ell, s2, kernel) + np.diag(np.asarray(jitter, dtype=np.float64))
     L = np.linalg.cholesky(Kb)
     R = Y - UH @ M0
     W = sla.solve_triangular(L, R, lower=True)

@@ -1167,40 +1167,147 @@ def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
     assert float((Br - Bk).abs().max()) > 1e-3
 
 
-def test_matern52_option_facade_prediction_only(ops):
-    """`ControlAffineRegressor(data_kernel="matern52")`: custom_predict / custom_predict_fullmat run on the Matern kernel
-    (against the oracle), while fit iterations, append_data and the derivative GP refuse (prediction-only option)."""
+def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
+    """`ControlAffineRegressor(data_kernel="matern52")` (opt-in; no reference counterpart, formulas pinned in
+    tests/test_oracle_formulas.py): custom_predict against the oracle; the likelihood gradient of fit() against central
+    differences of the oracle's Matern likelihood; fit() lowers the loss; append_data equals a from-scratch state on all the
+    points; the rel-degree-2 terms (derivative GP on the Matern jets) against the oracle's closed form."""
+    import scipy.linalg as sla
+    from oracle import cbc2 as oc2
     from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor, ControlAffineRegressorExact
+    from bayesian_cbf_amd.cbc2 import cbc2_quadratic_terms
     rng = np.random.default_rng(3)
     N, n, m, b = 40, 2, 1, 5
     X, U, Y = rng.normal(size=(N, n)), rng.normal(size=(N, m)), rng.normal(size=(N, n))
     A, B = np.array([[1.0, 0.2], [0.2, 0.5]]), np.array([[0.8, 0.1], [0.1, 0.6]])
     ell, s2, M0 = np.array([0.9, 1.3]), 0.7, rng.normal(size=(1 + m, n)) * 0.1
     f = dict(dtype=torch.float64, device=DEV)
+    T_ = lambda a: torch.as_tensor(np.ascontiguousarray(a), **f)
     reg = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel="matern52")
     reg.set_kernel_params(A=A, B=B, lengthscale=ell, scalefactor=s2, M0=M0)
-    reg.fit(torch.as_tensor(X, **f), torch.as_tensor(U, **f), torch.as_tensor(Y, **f), training_iter=0)
+    reg.fit(T_(X), T_(U), T_(Y), training_iter=0)
     draws = []
     orig = reg.rand_fn
     reg.rand_fn = lambda k: draws.append(orig(k)) or draws[-1]
     Xt, Ut = rng.normal(size=(b, n)), rng.normal(size=(b, m))
-    mean, cov = reg.custom_predict(torch.as_tensor(Xt, **f), torch.as_tensor(Ut, **f))
+    mean, cov = reg.custom_predict(T_(Xt), T_(Ut))
     UH, UHt = np.c_[np.ones(N), U], np.c_[np.ones(b), Ut]
-    K = ogp.matern52_ard_kernel(X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(1e-5 * host(draws[0]))
+    jit0 = 1e-5 * host(draws[0])
+    K = ogp.matern52_ard_kernel(X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(jit0)
     L = np.linalg.cholesky(K)
     ks = ogp.matern52_ard_kernel(X, Xt, ell, s2) * (UH @ B @ UHt.T)
-    import scipy.linalg as sla
     v = sla.solve_triangular(L, ks, lower=True)
     mean_o = UHt @ M0 + ks.T @ sla.cho_solve((L, True), Y - UH @ M0)
     sv_o = ogp.matern52_ard_kernel(Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v.T @ v
     rel_close(host(mean), mean_o, 1e-9, scale=max(1.0, np.abs(mean_o).max()), what="mean")
     rel_close(host(cov)[0], np.kron(sv_o, A), 1e-9, what="cov")
-    with pytest.raises(NotImplementedError):
-        reg.fit(torch.as_tensor(X, **f), torch.as_tensor(U, **f), torch.as_tensor(Y, **f), training_iter=2)
-    with pytest.raises(NotImplementedError):
-        reg.append_data(torch.as_tensor(Xt[:1], **f), torch.as_tensor(Ut[:1], **f), torch.as_tensor(Y[:1], **f))
+    # ---- rel-degree-2 terms through the facade (bcbf_posterior_jets_matern52 + bcbf_cbc2_terms(kernel_kind = 1))
+    Pm = np.array([[1.3, 0.2], [0.2, 0.8]])
+    qv = np.array([0.3, -0.4])
+    hfun = lambda z: 0.5 * z @ T_(Pm) @ z + T_(qv) @ z - 1.0
+    gfun = lambda z: T_(Pm) @ z + T_(qv)
+    Hfun = lambda z: T_(Pm)
+    x0, u0, ka = Xt[0], rng.random(m), np.array([1.0, 3.0])
+    (mA, mb), (Q, pp, r), mean2, var2 = cbc2_quadratic_terms(reg, hfun, gfun, Hfun, T_(x0), T_(u0), ka)
+    Yr = Y - UH @ M0
+    jets = oc2.posterior_jets(L, Yr, X, UH @ B, ell, s2, B, M0, x0, kernel="matern52")
+    (oA, ob), (oQ, op_, or_), omean, ovar = oc2.cbc2_terms(jets, A, B, ell, s2, float(0.5 * x0 @ Pm @ x0 + qv @ x0 - 1.0), Pm @ x0 + qv,
+                                                           Pm, ka, u0, kernel="matern52")
+    for name, val, ref in (("mean_A", mA, oA), ("mean_b", mb, ob), ("Q", Q, oQ), ("p", pp, op_), ("r", r, or_), ("mean", mean2, omean),
+                           ("var", var2, ovar)):
+        ref = np.asarray(ref)
+        rel_close(host(val).reshape(ref.shape), ref, 1e-7, scale=max(np.abs(ref).max(), abs(float(ovar)), 1e-2), what=name)
+    # ---- append_data: the last 6 points enter one by one == a state fitted on all the points (same jitter draws)
+    reg2 = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel="matern52")
+    reg2.set_kernel_params(A=A, B=B, lengthscale=ell, scalefactor=s2, M0=M0)
+    jall = rng.random(N)
+    seq = iter([jall[:N - 6]] + [jall[N - 6 + k:N - 5 + k] for k in range(6)])
+    reg2.rand_fn = lambda k: T_(next(seq)[:k])
+    reg2.fit(T_(X[:N - 6]), T_(U[:N - 6]), T_(Y[:N - 6]), training_iter=0)
+    reg2._state()
+    reg2.append_data(T_(X[N - 6:]), T_(U[N - 6:]), T_(Y[N - 6:]))
+    assert reg2.Xtrain.shape[0] == N
+    reg2.rand_fn = lambda k: T_(np.zeros(k))
+    m2, c2 = reg2.custom_predict(T_(Xt), T_(Ut))
+    K2 = ogp.matern52_ard_kernel(X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(1e-5 * jall)
+    L2 = np.linalg.cholesky(K2)
+    v2 = sla.solve_triangular(L2, ks, lower=True)
+    rel_close(host(m2), UHt @ M0 + ks.T @ sla.cho_solve((L2, True), Y - UH @ M0), 1e-8, scale=max(1.0, np.abs(mean_o).max()), what="mean after append")
+    rel_close(host(c2)[0], np.kron(ogp.matern52_ard_kernel(Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v2.T @ v2, A), 1e-7, what="cov after append")
+    # ---- the likelihood gradient against central differences of the oracle's Matern likelihood, then a short fit
+    jfix = 1e-5 * np.linspace(0.1, 0.9, N)
+    reg.rand_fn = lambda k: T_(np.linspace(0.1, 0.9, N)[:k])
+
+    def oracle_loss():
+        mm = reg.model
+        with torch.no_grad():
+            return -ogp.marginal_log_likelihood(X, UH, Y, mm.A.cpu().numpy(), mm.B.cpu().numpy(), mm.lengthscale.cpu().numpy().ravel(),
+                                                float(mm.outputscale), mm.M0.cpu().numpy(), jfix, kernel="matern52") / (N * n)
+    for p_ in reg.model.parameters():
+        p_.grad = None
+    loss = reg.neg_mll_backward()
+    np.testing.assert_allclose(loss, oracle_loss(), rtol=1e-9, atol=1e-10)
+    for name, p_ in reg.model.named_parameters():
+        flat, gflat = p_.data.view(-1), p_.grad.view(-1)
+        for k in range(min(flat.numel(), 3)):
+            old, h = float(flat[k]), 1e-5
+            flat[k] = old + h; lp = oracle_loss()
+            flat[k] = old - h; lm = oracle_loss()
+            flat[k] = old
+            np.testing.assert_allclose(float(gflat[k]), (lp - lm) / (2 * h), rtol=3e-5, atol=3e-7, err_msg="%s[%d]" % (name, k))
+    reg.rand_fn = orig
+    reg.fit(T_(X), T_(U), T_(Y), training_iter=15)
+    assert reg.fit_losses[-1] < reg.fit_losses[0]
     with pytest.raises(ValueError):
         ControlAffineRegressorExact(n, m, device=DEV, data_kernel="matern32")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_matern52_fused_refit_equals_build_then_factor_and_jets_vs_oracle(ops, dtype):
+    """bcbf_refit_matern52 (fused values + jittered Cholesky + packing, the team form) gives the factor of
+    bcbf_kb_build_matern52 -> bcbf_potrf (posterior through either within rounding); bcbf_posterior_jets_matern52 against the
+    oracle's Matern jets for batches of instances, two shapes, ragged N."""
+    from oracle import cbc2 as oc2
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64 = dtype == torch.float64
+    for (N, n, m) in ((100, 2, 1), (300, 3, 2)):
+        Bt = 3
+        p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=40 + N)
+        X, xq = (p["X"] * 2.0).contiguous(), (p["xq"] * 2.0).contiguous()
+        jit = (p["jitter"] * (1 if f64 else 1e2)).contiguous()
+        Lop, UHB, info, _ = ops.refit(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+        assert (info == 0).all()
+        Kb = ops.kb_build(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+        Lop2, info2, _ = ops.potrf(Kb)
+        assert (info2 == 0).all()
+        Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+        Vw2, _ = ops.potrs(Lop2, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+        q = lambda L_, V_: ops.posterior_query(L_, V_, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, kernel="matern52")
+        (Mk1, Bk1, _), (Mk2, Bk2, _) = q(Lop, Vw), q(Lop2, Vw2)
+        tol = 1e-9 if f64 else 2e-3
+        rel_close(host(Mk1), host(Mk2), tol, scale=max(1.0, float(Mk2.abs().max())), what="Mk fused vs build+factor")
+        rel_close(host(Bk1), host(Bk2), tol, scale=float((p["s2"][:, None, None] * p["Bm"]).abs().max()), what="Bk fused vs build+factor")
+        Mk, Bk, G, Mj = ops.posterior_jets(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, kernel="matern52")
+        h = {k: host(v) for k, v in p.items()}
+        hX, hxq, hj = host(X), host(xq), host(jit)
+        C = m + 1
+        jt = 1e-8 if f64 else 3e-3
+        for i in range(Bt):
+            UH = h["UH"][i]
+            K = ogp.matern52_ard_kernel(hX[i], hX[i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
+            L = np.linalg.cholesky(K)
+            jets = oc2.posterior_jets(L, h["Xdot"][i] - UH @ h["M0"][i], hX[i], UH @ h["Bm"][i], h["ell"][i], float(h["s2"][i]), h["Bm"][i],
+                                      h["M0"][i], hxq[i], kernel="matern52")
+            prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
+            rel_close(host(Mk)[i], jets["Mk"], jt, scale=max(1.0, np.abs(jets["Mk"]).max()), what="Mk")
+            rel_close(host(Bk)[i], jets["Bk"], jt, scale=prior, what="Bk")
+            Gh, Mjh = host(G)[i], host(Mj)[i]
+            gscale = max(np.abs(jets["G11"]).max(), np.abs(jets["G10"]).max(), prior, 1e-3)
+            for d in range(n):
+                rel_close(Gh[(1 + d) * C:(2 + d) * C, :C], jets["G10"][d], jt, scale=gscale, what="G10")
+                rel_close(Mjh[:, (1 + d) * C:(2 + d) * C], jets["dMk"][d], jt, scale=max(1.0, np.abs(jets["dMk"]).max()), what="dMk")
+                for e in range(n):
+                    rel_close(Gh[(1 + d) * C:(2 + d) * C, (1 + e) * C:(2 + e) * C], jets["G11"][d][e], jt, scale=gscale, what="G11")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
