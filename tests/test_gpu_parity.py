@@ -1282,7 +1282,7 @@ def test_matern52_fused_refit_equals_build_then_factor_and_jets_vs_oracle(ops, d
         assert (info2 == 0).all()
         Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
         Vw2, _ = ops.potrs(Lop2, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
-        q = lambda L_, V_: ops.posterior_query(L_, V_, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, kernel="matern52")
+        q = lambda L_, V_: ops.posterior_query(L_, V_, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, shared=False, kernel="matern52")
         (Mk1, Bk1, _), (Mk2, Bk2, _) = q(Lop, Vw), q(Lop2, Vw2)
         tol = 1e-9 if f64 else 2e-3
         rel_close(host(Mk1), host(Mk2), tol, scale=max(1.0, float(Mk2.abs().max())), what="Mk fused vs build+factor")
