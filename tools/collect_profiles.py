@@ -6,7 +6,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = R + "gpurun_out/%s/" % ROUND
 DST = R + "profiles/%s_" % ROUND
 
@@ -39,7 +39,7 @@ for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_par
         rf = d["roofline"]
         print(a, round(d["value"]), round(d["ms_per_step"], 4), "frac", round(rf["frac"], 4), "kernel_ms", round(rf["kernel_ms"], 4),
               "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
-for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "online_growth_f64_unfused.json", "online_growth_f64_unfused3.json", "online_growth_f64_packed.json", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
+for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "online_growth_f64_unfused.json", "online_growth_f64_unfused3.json", "online_growth_f64_packed.json", "online_growth_f64_batch1024.json", "online_growth_f64_pairform.json", "online_window512_f64.json", "online_window1024_f64.json", "speed_call_host.txt", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
           "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt", "pmc_traffic_refit.json",
           "refit_pair_timeline.txt"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
@@ -79,7 +79,7 @@ def traffic_pass(tag, kernel_sub, per_instance_alg, command, out_name, sizes=Non
     print("traffic", tag, kernel_sub, round(fetch + write), "x algorithmic", round(out["traffic_over_algorithmic"], 4), "launches", out["launches"])
 
 
-HEAD = "posterior_step_kernel<float, 3, 4, 0, 1, false>"
+HEAD = "posterior_step_kernel<float, 3, 4, 0, 1, false"        # (+ the XC parameter from round 4 on)
 sizes_default = None
 try:
     sizes_default = set(last_json_line(SRC + "bench_default.json")["roofline"]["instances_per_launch_by_part"])
@@ -88,8 +88,8 @@ except Exception:
 traffic_pass("default", HEAD, 543744, "bench.py --steps 5 --warmup 2 --cpu-sample 0", "pmc_traffic.json", sizes_default)
 traffic_pass("defaultparts1", HEAD, 543744, "bench.py --steps 5 --warmup 2 --cpu-sample 0 --parts 1", "pmc_traffic_parts1.json", {4096})
 # rel-degree-2 jets (tools/bench_reldeg2.py): the unicycle shape (12 right-hand sides) and the pendulum shape (6)
-traffic_pass("jets", "posterior_step_kernel<float, 3, 4, 3, 1, false>", 543744, "tools/bench_reldeg2.py", "pmc_traffic_jets_n3m2.json", {4096})
-traffic_pass("jets", "posterior_step_kernel<float, 2, 4, 2, 1, false>", 4 * (512 * 513 // 2 + 2 * 512 * 2 + 512 * 2), "tools/bench_reldeg2.py",
+traffic_pass("jets", "posterior_step_kernel<float, 3, 4, 3, 1, false", 543744, "tools/bench_reldeg2.py", "pmc_traffic_jets_n3m2.json", {4096})
+traffic_pass("jets", "posterior_step_kernel<float, 2, 4, 2, 1, false", 4 * (512 * 513 // 2 + 2 * 512 * 2 + 512 * 2), "tools/bench_reldeg2.py",
              "pmc_traffic_jets_n2m1.json", {4096}, n=2, m=1)
 
 # ---- MFMA utilisation

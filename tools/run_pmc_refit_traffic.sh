@@ -1,6 +1,6 @@
 # Memory traffic of the refit kernels past L2 (FETCH_SIZE / WRITE_SIZE / L2 hits, one PMC pass each, counters + kernel trace
 # only): config 2 (fp64 1024 x 256, two waves per instance) and config 3 (fp32 4096 x 512, one wave per instance).
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # the setting bench.py gives itself; under rocprofv3 the runtime is up before Python runs
 cd $GRAFT_REPO_ROOT

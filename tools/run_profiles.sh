@@ -1,6 +1,6 @@
 # One GPU call that produces everything tools/collect_profiles.py copies into profiles/ (ROUND tag = $1, default r03).
 # Counters are collected in their own passes (--pmc + --kernel-trace only), as MI355X_MICROARCH.md prescribes.
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # the setting bench.py gives itself; under rocprofv3 the runtime is up before Python runs
 cd $GRAFT_REPO_ROOT
@@ -47,6 +47,11 @@ python tools/bench_refit_forms.py f32 2>/dev/null > $O/refit_forms_f32.jsonl
 python tools/bench_online.py --repeat 2 2>/dev/null > $O/online_growth_f64.json
 python tools/bench_online.py --unfused --repeat 3 2>/dev/null > $O/online_growth_f64_unfused3.json
 python tools/bench_online.py --packed 2>/dev/null > $O/online_growth_f64_packed.json
+python tools/bench_online.py --batch 1024 2>/dev/null > $O/online_growth_f64_batch1024.json
+BCBF_APPEND_PAIR=1 python tools/bench_online.py 2>/dev/null > $O/online_growth_f64_pairform.json
+python tools/bench_online.py --n1 1536 --window 512 2>/dev/null > $O/online_window512_f64.json
+python tools/bench_online.py --n0 512 --n1 2560 --window 1024 2>/dev/null > $O/online_window1024_f64.json
+python tools/prof_speed_host.py 2>/dev/null | head -3 > $O/speed_call_host.txt
 python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
 python tools/bench_speed_test.py --quick 2>/dev/null > $O/speed_test.jsonl
 python tools/bench_speed_test_unicycle.py --quick 2>/dev/null > $O/speed_test_unicycle.jsonl
