@@ -70,9 +70,6 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #ifndef BCBF_RW32_SUPER_KS
 #define BCBF_RW32_SUPER_KS 4     // k-steps per pipeline stage of the four-stream pass (1 / 2 / 4 / 8 measured: 4 and 8 level, 1 loses 30 %)
 #endif
-#ifndef BCBF_RW32_PKVALUES
-#define BCBF_RW32_PKVALUES 1     // fp32 one-wave form: K_b values of a lane's two rows as packed pairs (v_pk_*)
-#endif
 #ifndef BCBF_RW32_SUPER_DIAG3
 #define BCBF_RW32_SUPER_DIAG3 1  // 1: the three tiles of the diagonal 2 x 2 block in one stream pass; 0: the diagonal tile by itself first (measured:
                                  // more scratch, not less -- the extra stream instantiation costs more than the two tiles it parks)
@@ -337,49 +334,6 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 acc[cb][ib][r] = -val;
                             }
                     }
-                } else if (BCBF_RW32_PKVALUES && sizeof(T) == 4 && n <= 4) {
-                    // fp32: the lane's two rows (ib = 0, 1) as ONE packed pair per quantity -- v_pk_add / v_pk_mul / v_pk_fma on
-                    // (row, row + 1) halve the VALU instructions of the value pass, which nothing overlaps in a one-wave
-                    // kernel (24 % of an instance's cycles at N = 512, tools/prof_refit32.py); the jitter (diagonal tiles only)
-                    // and the identity padding (last block row / column of a ragged N only) sit behind wave-uniform branches
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    f2 rx2[4], ru2[4];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) { rx2[d] = f2{(float)q.rx[0][d], (float)q.rx[1][d]}; ru2[d] = f2{(float)q.ru[0][d], (float)q.ru[1][d]}; }
-                    const bool on_diag = I == J + SEL;
-                    const bool ragged = N != Np && (I == nblk - 1 || J + SEL == nblk - 1);
-                    const float ks = -0.5f * 1.4426950408889634f;
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int c = 2 * P::midx(r, g) + cb, j = col0 + c;
-                            float cx[4], cu[4];
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                cx[d] = (float)(SEL ? sh.colX2[c][d] : sh.colX[c][d]);
-                                cu[d] = (float)(SEL ? sh.colUH2[c][d] : sh.colUH[c][d]);
-                            }
-                            f2 d2 = f2{0.0f, 0.0f}, uu = f2{0.0f, 0.0f};
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const f2 z = (rx2[d] - f2{cx[d], cx[d]}) * f2{(float)iell[d], (float)iell[d]};
-                                d2 = z * z + d2;
-                                uu = ru2[d] * f2{cu[d], cu[d]} + uu;
-                            }
-                            const f2 t = d2 * f2{ks, ks};
-                            f2 val = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * uu * f2{(float)s2, (float)s2};
-                            if (on_diag) {
-                                if (irow == j) val.x += (float)q.rj[0];
-                                if (irow + 1 == j) val.y += (float)q.rj[1];
-                            }
-                            if (ragged) {
-                                if (irow >= N || j >= N) val.x = (irow == j) ? 1.0f : 0.0f;
-                                if (irow + 1 >= N || j >= N) val.y = (irow + 1 == j) ? 1.0f : 0.0f;
-                            }
-                            acc[cb][0][r] = (T)(-val.x);
-                            acc[cb][1][r] = (T)(-val.y);
-                        }
                 } else {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
