@@ -35,7 +35,7 @@ def union_ms(spans):
 
 def main():
     trace_dir, bench_json, out_json = sys.argv[1:4]
-    needle = sys.argv[4] if len(sys.argv) > 4 else "posterior_step_kernel<float, 3, 4, 0, 1, false>"
+    needle = sys.argv[4] if len(sys.argv) > 4 else "posterior_step_kernel<float, 3, 4, 0, 1, false"
     line = [l for l in open(bench_json) if l.startswith("{")][-1]
     bench = json.loads(line)
     rf = bench["roofline"]
