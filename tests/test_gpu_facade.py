@@ -1406,3 +1406,45 @@ def test_fp32_fit_improves_the_likelihood_for_all_four_regressors_at_speed_test_
         mean, _ = reg.custom_predict(Xt[:64], Ut[:64], compute_cov=False)
         err = float((mean - Yt[:64]).abs().max()) / float(Yt.abs().max())
         assert mean.dtype == torch.float32 and err < 0.05, (name, N, err)
+
+
+@pytest.mark.parametrize("own_generator", [True, False], ids=["regressor-generator", "global-generator"])
+def test_speculative_jitter_levels_leave_the_sequential_random_stream(own_generator):
+    """`_state()` factors make_psd's first four jitter levels in one launch (control_affine_model.py:903-919 is sequential:
+    draw 1e-5 rand, factor, x10 and draw again on failure).  The result must be the sequential protocol's in every respect:
+    same level, same jitter vector, same factor -- and the random stream afterwards continues where the sequential protocol
+    would have left it (the make_psd draw of the next prediction, the jitter of the next refit).  An fp32 model on dense
+    data needs level 2 or 3, so draws really are made and taken back."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExact
+    rng = np.random.default_rng(0)
+    N = 300
+    X = rng.uniform(-1, 1, size=(N, 2)) * 0.5
+    U = rng.normal(size=(N, 1))
+    Y = np.sin(X) + 0.3 * U
+    f32 = dict(dtype=torch.float32, device=DEV)
+    outs = []
+    for speculative in (True, False):
+        gen = torch.Generator(device=DEV).manual_seed(123) if own_generator else None
+        torch.manual_seed(5)                                 # (the index kernels A, B are initialised from the global generator)
+        reg = ControlAffineRegressorExact(2, 1, device=DEV, dtype=torch.float32, generator=gen)
+        reg.set_kernel_params(lengthscale=np.array([1.5, 1.5]), scalefactor=1.0)
+        reg.fit(torch.as_tensor(X, **f32), torch.as_tensor(U, **f32), torch.as_tensor(Y, **f32), training_iter=0)
+        if not own_generator:
+            torch.manual_seed(123)
+        if not speculative:                                  # a wrapped draw function takes the sequential loop
+            inner = reg.rand_fn
+            reg.rand_fn = lambda k: inner(k)
+        Xt = torch.as_tensor(rng.uniform(-1, 1, size=(7, 2)) * 0.5 if speculative else outs[0]["Xt"], **f32)
+        rec = dict(Xt=Xt.cpu().numpy())
+        for rep in range(2):                                 # two refits: the second one's draws follow the first one's
+            fm, fv = reg.custom_predict_fullmat(Xt)
+            st = reg._state()
+            rec["jit%d" % rep], rec["fm%d" % rep], rec["fv%d" % rep] = st["jitter"].clone(), fm.clone(), fv.clone()
+            reg.clear_cache()
+        rec["next"] = reg.rand_fn(5).clone()
+        outs.append(rec)
+    a, b = outs
+    level = float(a["jit0"].max())
+    assert level > 1e-5, "the first level succeeded: nothing was speculated (%g)" % level
+    for k in ("jit0", "jit1", "fm0", "fm1", "fv0", "fv1", "next"):
+        assert torch.equal(a[k], b[k]), k
