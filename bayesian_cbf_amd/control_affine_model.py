@@ -206,6 +206,9 @@ class ControlAffineRegressor:
                                "and there is no CPU path" % self.device)
 
     def clear_cache(self):
+        st = self._cache.get("state") if isinstance(getattr(self, "_cache", None), dict) else None
+        if st is not None and "_pending" in st:
+            self._resolve_pending(st)             # (the random stream is put where the sequential protocol leaves it)
         self._cache = dict()
 
     def get_kernel_param(self, name):
@@ -475,10 +478,34 @@ class ControlAffineRegressor:
 
     SPECULATIVE_LEVELS = 4           # jitter levels factored in ONE launch (1e-5 .. 1e-2 by default)
 
-    def _state(self, cholesky_tries=10, cholesky_perturb_init=1e-5, cholesky_perturb_scale=10):
-        """K_b build + jittered Cholesky with x10 retry (make_psd, :899-921) + whitened targets."""
+    def _resolve_pending(self, st):
+        """A state built with `_state(defer=True)` chose its jitter level ON THE DEVICE; which level that was is only needed
+        on the host to put the random stream back (and to notice that all speculative levels failed).  Waits for the
+        factorisation alone (an event behind it, the flags in pinned memory).  Returns False if the state had to be rebuilt."""
+        pend = st.pop("_pending", None)
+        if pend is None:
+            return True
+        host_ok, ev, states, K, factor_next, args = pend
+        ev.synchronize()
+        ok = host_ok.tolist()
+        if any(ok):
+            self._rng_restore(states[ok.index(True)])
+            return True
+        # every speculative level failed (the state above was built on a failed factor): go on sequentially from level K
+        self._cache.pop("state", None)
+        self._state(*args, _resume=(K, factor_next))
+        return False
+
+    def _state(self, cholesky_tries=10, cholesky_perturb_init=1e-5, cholesky_perturb_scale=10, defer=False, _resume=None):
+        """K_b build + jittered Cholesky with x10 retry (make_psd, :899-921) + whitened targets.
+        defer=True (the caller promises to call `_resolve_pending(st)` before its next random draw and before it hands
+        anything to the user): the successful jitter level is selected on the device and the host does not wait for the
+        factorisation here."""
         if "state" in self._cache:
             st = self._cache["state"]
+            if "_pending" in st and not defer:
+                if not self._resolve_pending(st):
+                    st = self._cache["state"]
             if st["_versions"] != self._param_versions():
                 # A hyper-parameter was written since the factor entered the cache and nobody called clear_cache().  The
                 # reference caches ONLY the Cholesky factor, under a key that ignores its arguments (:379-385); every
@@ -496,8 +523,10 @@ class ControlAffineRegressor:
         X, UH, Xk, UHk = self._train_views(K)
         N = X.shape[1]
         factor = cholesky_perturb_init
-        Lop, start = None, 0
-        if self.rand_fn is self._default_rand_fn and K > 1:
+        Lop, start, pending = None, 0, None
+        if _resume is not None:                           # (after K failed speculative levels: their draws stand)
+            start, factor = _resume
+        if _resume is None and self.rand_fn is self._default_rand_fn and K > 1:
             # make_psd's schedule (:903-919) -- draw 1e-5 rand, factor, x10 and draw again on failure -- with the first K
             # levels factored SPECULATIVELY in one launch (K instances of the same system, one jitter vector each) and ONE
             # round trip to the host: an fp32 model of a few hundred points fails the first two or three levels on every
@@ -512,10 +541,25 @@ class ControlAffineRegressor:
                 states.append(self._rng_state())
                 f *= cholesky_perturb_scale
             rep = lambda t: t.expand(K, *t.shape[1:]).contiguous()
-            Lk, UHBk, infok, _ = ops.refit(Xk, UHk, rep(hp["Bm"]), rep(hp["ell"]), rep(hp["s2"]), torch.stack(jits),
+            jstack = torch.stack(jits)
+            Lk, UHBk, infok, _ = ops.refit(Xk, UHk, rep(hp["Bm"]), rep(hp["ell"]), rep(hp["s2"]), jstack,
                                            kernel=self.data_kernel)
-            ok = (infok == 0).tolist()
-            if any(ok):
+            if defer:
+                okk = infok == 0
+                host_ok = self._derived.get("pinned_ok")
+                if host_ok is None or host_ok.numel() != K:
+                    host_ok = self._derived["pinned_ok"] = torch.empty(K, dtype=torch.bool).pin_memory()
+                host_ok.copy_(okk, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                sel = torch.argmax(okk.to(torch.uint8)).reshape(1)            # the FIRST level that factored (0 if none did)
+                Lop, UHB, jitter = Lk.index_select(0, sel), UHBk.index_select(0, sel), jstack.index_select(0, sel)[0]
+                pending = (host_ok, ev, states, K, f, (cholesky_tries, cholesky_perturb_init, cholesky_perturb_scale))
+                start = cholesky_tries
+            ok = [] if defer else (infok == 0).tolist()
+            if defer:
+                pass
+            elif any(ok):
                 j = ok.index(True)
                 self._rng_restore(states[j])
                 Lop, UHB, jitter = Lk[j:j + 1], UHBk[j:j + 1], jits[j]
@@ -532,11 +576,15 @@ class ControlAffineRegressor:
             if ntry == cholesky_tries - 1:
                 raise RuntimeError("cholesky: pivot %d is not positive after %d jitter retries" % (int(info[0]), cholesky_tries))
             factor = factor * cholesky_perturb_scale
+        if Lop is None:
+            raise RuntimeError("cholesky: no jitter level up to %g made K_b positive definite" % factor)
         # only the whitened targets Vw = L^-1 Y enter the posterior (alpha = K_b^-1 Y is the fit's business): skip
         # the backward substitution
         Vw, _ = ops.potrs(Lop, self.XdotTrain[None], UH, hp["M0"], want_alpha=False)
         st = dict(hp, X=X, UH=UH, Lop=Lop, UHB=UHB, Vw=Vw, N=N, jitter=jitter[None].contiguous(), kernel=self.data_kernel,
                   factor_hp=dict(Bm=hp["Bm"], ell=hp["ell"], s2=hp["s2"]), _versions=self._param_versions())
+        if pending is not None:
+            st["_pending"] = pending
         self._cache["state"] = st
         return st
 
@@ -563,8 +611,8 @@ class ControlAffineRegressor:
         Utest = self._ensure_device_dtype(Utest_in)
         return torch.cat((Utest.new_full((Utest.shape[0], 1), fill), Utest), dim=-1)
 
-    def _query(self, Xtest, want_W):
-        st = self._state()
+    def _query(self, Xtest, want_W, defer=False):
+        st = self._state(defer=defer)
         Mk, Bk, W = ops.posterior_query(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"],
                                         st["M0"], Xtest.contiguous(), shared=True, want_W=want_W, kernel=self.data_kernel)
         return st, Mk, Bk, W
@@ -735,12 +783,18 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
         if self.Xtrain is None:
             mean = self.model.M0.detach().t()[None].expand(b, -1, -1)
             return mean, A, B * self._prior_knl(Xtest, Xtestp)[:, :, None, None]
-        st, Mk, Bk, W = self._query(Xtest, want_W=compute_cov)
+        # (deferred: the refit's jitter level is chosen on the device; the host only needs it for the random stream, which the
+        #  make_psd draw below is the next to touch -- everything up to there is queued without waiting for the factorisation)
+        st, Mk, Bk, W = self._query(Xtest, want_W=compute_cov, defer=True)
         if not compute_cov:
+            if not self._resolve_pending(st):
+                return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov)
             return Mk, A, Xtest.new_zeros(b, bp, C, C)
-        Wp = W if Xtestp_in is None else self._query(Xtestp, want_W=True)[3]
+        Wp = W if Xtestp_in is None else self._query(Xtestp, want_W=True, defer=True)[3]
         BkXX = (self._prior_knl(Xtest, Xtestp)[:, :, None, None] * B
                 - torch.einsum("bnc,pnd->bpcd", W, Wp))
+        if not self._resolve_pending(st):                 # all speculative levels failed (rare): start over on the rebuilt state
+            return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov)
         # make_psd(BkXX) on the [b(1+m)] x [b'(1+m)] matrix: 1e-5 * rand on its diagonal (:1089, :907-910)
         # with its retry schedule: x10 until the perturbed matrix factors, RuntimeError after 10 tries (:903-919).
         # The factorisation is the library's (bcbf_potrf) and is run for query sets of up to one 32 x 32 tile
