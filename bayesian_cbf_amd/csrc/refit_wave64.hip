@@ -74,6 +74,16 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #define BCBF_RW32_SUPER_DIAG3 1  // 1: the three tiles of the diagonal 2 x 2 block in one stream pass; 0: the diagonal tile by itself first (measured:
                                  // more scratch, not less -- the extra stream instantiation costs more than the two tiles it parks)
 #endif
+#ifndef BCBF_RW_SUPER_AINV_LDS
+#define BCBF_RW_SUPER_AINV_LDS 1 // super-panels: the two inverted diagonal tiles stay in LDS and the panel solves read their operands from
+                                 // there right before use (16 ds_reads per solve pair) instead of holding 2 x 16 (fp64: 2 x 32) registers
+#endif
+#ifndef BCBF_RW64_SUPER
+#define BCBF_RW64_SUPER 1        // fp64 batches from N = 1024: the same super-panels (the plain fp64 path reads TWO panels per tile)
+#endif
+#ifndef BCBF_RW64_SUPER_KS
+#define BCBF_RW64_SUPER_KS 2
+#endif
 #ifndef BCBF_RW32_SUPER_AHEAD
 #define BCBF_RW32_SUPER_AHEAD 0  // 1: row inputs of the next tile pair loaded before the stream pass -- 36 registers live across it; at two waves
                                  // per SIMD that is 80 B more scratch and 4096 x 512 runs 3.95 instead of 3.67 ms
@@ -103,6 +113,7 @@ template <typename T, bool SUP = false> struct RWShared {
     unsigned pack_rc[LOP_DB / 2];             // (row, column) of the entries of a packed inverted diagonal block, two per word
     T colX2[SUP ? NB : 1][BCBF_MAX_STATE_DIM];          // second block column of a super-panel (fp32 one-wave form)
     T colUH2[SUP ? NB : 1][BCBF_MAX_CTRL_DIM + 1];
+    T xinvJ[SUP ? NB : 1][DT_LS];                       // inv(L_JJ) of the super-panel's FIRST column (d.xinv holds the second's)
 };
 // packed lower triangle, column-major: entry k <-> (r, c), r >= c; (r | c << 8) per entry, 0xffff = the block's padding
 __device__ inline void rw_pack_table(__attribute__((address_space(3))) unsigned* tab, int tid, int nthreads) {
@@ -182,7 +193,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     using P = RW<T>;
     using acc_t = typename P::acc_t;
     using T2 = typename P::vec2;
-    static_assert(!SUP || (sizeof(T) == 4 && BCBF_RW32_PAIRS), "the super-panel form is the fp32 pair path's");
+    static_assert(!SUP || sizeof(T) == 8 || BCBF_RW32_PAIRS, "the super-panel form lives in the pair path");
     __shared__ RWShared<T, SUP> shm[RW_WPB];
     // wave-uniform instance index: the per-instance pointers and hyper-parameters then live in SGPRs (scalar loads)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -284,7 +295,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         // tile per pass -- the pair path needs more than the 512 registers there and measured slower below N = 1024 (4096 x
         // 512: 8.15 against 7.4 ms).  Two bodies: the single-tile stream written over the pair path's helpers came out
         // with twice the register moves in its loop (177 instructions per 32 MFMAs against 111) and lost 5 %.
-        constexpr bool PAIRS = sizeof(T) == 4 ? BCBF_RW32_PAIRS : BCBF_RW64_PAIRS;
+        constexpr bool PAIRS = SUP || (sizeof(T) == 4 ? BCBF_RW32_PAIRS : BCBF_RW64_PAIRS);
         if constexpr (PAIRS) {
             // inputs of a tile's two rows per lane (x_i, (UH B)_i, jitter_i): loaded one step ahead, so that the loads are in
             // flight during the previous step's update stream instead of queueing behind its panel stores.
@@ -545,12 +556,31 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 // stored (L2 / L1 hits), applied after the tiles of column J are solved.
                 const int col1 = col0 + NB;
                 T ainv1[2][2][4];
-                constexpr int KS4 = BCBF_RW32_SUPER_KS;
+                auto load_ainv = [&](T (&av)[2][2][4], auto second) {
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int rr_ = 16 * cbp + j16, cc_ = 2 * P::midx(r, g) + cb;
+                                av[cbp][cb][r] = -(decltype(second)::value ? sh.d.xinv[rr_][cc_] : sh.xinvJ[rr_][cc_]);
+                            }
+                };
+                auto keep_first_inverse = [&]() {              // d.xinv -> xinvJ (the second factorisation overwrites d.xinv)
+                    if (BCBF_RW_SUPER_AINV_LDS) {
+                        for (int e = lane; e < NB * NB; e += 64) sh.xinvJ[e >> 5][e & 31] = sh.d.xinv[e >> 5][e & 31];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                };
+                constexpr int KS4 = sizeof(T) == 4 ? BCBF_RW32_SUPER_KS : BCBF_RW64_SUPER_KS;
                 auto negate = [&](acc_t (&acc)[2][2]) { (void)acc; };
                 (void)negate;
                 // -S' += L_a L_b' for k in [k0, k1): one tile, A operand = block row at arow0, B operand = rows of tile I
                 auto update_r = [&](acc_t (&acc)[2][2], int arow0, int I, int k0, int k1) {
-                    constexpr int KS = 4;
+                    constexpr int KS = sizeof(T) == 4 ? 4 : 2;
                     const int irow = I * NB + 2 * j16;
                     T2 a_nxt[KS], b_nxt[KS];
                     auto fetch = [&](int kk) {
@@ -584,7 +614,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                 };
                 // ... two tiles I, I + 1 of one block column (shared A operand)
                 auto update2_r = [&](acc_t (&acc0)[2][2], acc_t (&acc1)[2][2], int arow0, int I, int k0, int k1) {
-                    constexpr int KS = 4;
+                    constexpr int KS = sizeof(T) == 4 ? 4 : 2;
                     const int irow = I * NB + 2 * j16;
                     T2 a_nxt[KS], b0_nxt[KS], b1_nxt[KS];
                     auto fetch = [&](int kk) {
@@ -706,6 +736,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     update4(t00, t00, t10, t11, J, IC2{}, std::true_type{});
                     RW_ACC(2);
                     diag_tile_s(t00, J, ainv);
+                    keep_first_inverse();
                     RW_ACC(4);
                     if (fail != 0) break;
 #else
@@ -714,6 +745,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         values_s(t00, rw0, J, IC0{});
                         update_r(t00, col0, J, 0, col0);
                         diag_tile_s(t00, J, ainv);
+                        keep_first_inverse();
                         if (fail != 0) break;
                     }
                     values_s(t10, rw1, J + 1, IC0{});
@@ -744,24 +776,48 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         RW_ACC(1);
                         update4(t00, t01, t10, t11, I, IC2{}, std::false_type{});
                         RW_ACC(2);
-                        solve_store_s(t00, I, J, ainv);
-                        solve_store_s(t10, I + 1, J, ainv);
+                        if (BCBF_RW_SUPER_AINV_LDS) {
+                            T av[2][2][4];
+                            load_ainv(av, std::false_type{});
+                            solve_store_s(t00, I, J, av);
+                            solve_store_s(t10, I + 1, J, av);
+                        } else {
+                            solve_store_s(t00, I, J, ainv);
+                            solve_store_s(t10, I + 1, J, ainv);
+                        }
                         wave_fence();
                         RW_ACC(5);
                         update2_r(t01, t11, col1, I, col0, col1);           // -= L_{I,J} L_{J+1,J}',  L_{I+1,J} L_{J+1,J}'
                         RW_ACC(2);
-                        solve_store_s(t01, I, J + 1, ainv1);
-                        solve_store_s(t11, I + 1, J + 1, ainv1);
+                        if (BCBF_RW_SUPER_AINV_LDS) {
+                            T av[2][2][4];
+                            load_ainv(av, std::true_type{});
+                            solve_store_s(t01, I, J + 1, av);
+                            solve_store_s(t11, I + 1, J + 1, av);
+                        } else {
+                            solve_store_s(t01, I, J + 1, ainv1);
+                            solve_store_s(t11, I + 1, J + 1, ainv1);
+                        }
                         if (!BCBF_RW32_SUPER_AHEAD) { load_rows(rw0, I + 2); load_rows(rw1, I + 3); }
                         RW_ACC(5);
                     } else {
                         values_s(t00, rw0, I, IC0{});
                         values_s(t01, rw0, I, IC1{});
                         update4(t00, t01, t00, t01, I, IC1{}, std::false_type{});
-                        solve_store_s(t00, I, J, ainv);
-                        wave_fence();
-                        update_r(t01, col1, I, col0, col1);
-                        solve_store_s(t01, I, J + 1, ainv1);
+                        if (BCBF_RW_SUPER_AINV_LDS) {
+                            T av[2][2][4];
+                            load_ainv(av, std::false_type{});
+                            solve_store_s(t00, I, J, av);
+                            wave_fence();
+                            update_r(t01, col1, I, col0, col1);
+                            load_ainv(av, std::true_type{});
+                            solve_store_s(t01, I, J + 1, av);
+                        } else {
+                            solve_store_s(t00, I, J, ainv);
+                            wave_fence();
+                            update_r(t01, col1, I, col0, col1);
+                            solve_store_s(t01, I, J + 1, ainv1);
+                        }
                     }
                 }
                 ++J;                                                        // (the loop's own ++J makes it two)
@@ -1906,7 +1962,11 @@ static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell,
         if (sup) { if (two) BCBF_RW_LAUNCH(2, true); else BCBF_RW_LAUNCH(1, true); }
         else { if (two) BCBF_RW_LAUNCH(2); else BCBF_RW_LAUNCH(1); }
     } else {
-        BCBF_RW_LAUNCH(BCBF_RW64_OCC);
+        // fp64: from N = 1024 (1024 x 1024 14.5 -> 12.7 ms; at N = 512 the four fp64 tiles -- 128 accumulator registers -- cost
+        // more than the halved panel reads save: 4096 x 512 7.35 -> 9.1 ms)
+        bool sup = BCBF_RW64_SUPER && Np >= 1024 && !Kdense && !Ldense;
+        if (const char* e = getenv("BCBF_RW64_SUPER_FORCE")) sup = e[0] == '1' && !Kdense;      // (development)
+        if (sup) BCBF_RW_LAUNCH(BCBF_RW64_OCC, true); else BCBF_RW_LAUNCH(BCBF_RW64_OCC);
     }
 #undef BCBF_RW_LAUNCH
     return 0;
