@@ -78,6 +78,16 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #define BCBF_RW_SUPER_AINV_LDS 1 // super-panels: the two inverted diagonal tiles stay in LDS and the panel solves read their operands from
                                  // there right before use (16 ds_reads per solve pair) instead of holding 2 x 16 (fp64: 2 x 32) registers
 #endif
+#ifndef BCBF_RW_SUPER_INREG
+#define BCBF_RW_SUPER_INREG 1    // super-panels: the 32-deep update of column J + 1 by column J takes the just-solved tiles L_IJ' straight from the
+                                 // registers they were solved into (accumulator layout = B operand with a permuted contraction order; the A
+                                 // operand L_{J+1,J} is loaded once per super-panel in that order) -- no store -> fence -> load round trip per
+                                 // row pair, no B streams
+#endif
+#ifndef BCBF_RW_SUPER_A2_RELOAD
+#define BCBF_RW_SUPER_A2_RELOAD 0   // 1: that A operand is re-read (L2 hits) at every row pair instead of living in 16 registers across the stream loops
+                                    // (parking it in LDS instead costs the 4 KB that take the kernel's LDS past 160 KB / 8 waves per CU)
+#endif
 #ifndef BCBF_RW64_SUPER
 #define BCBF_RW64_SUPER 1        // fp64 batches from N = 1024: the same super-panels (the plain fp64 path reads TWO panels per tile)
 #endif
@@ -567,6 +577,54 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 av[cbp][cb][r] = -(decltype(second)::value ? sh.d.xinv[rr_][cc_] : sh.xinvJ[rr_][cc_]);
                             }
                 };
+                // panel solve that also hands the solved tile back: yk[cbp][ib][r] = L_IJ'(c = 16 cbp + midx(r, g), i = irow + ib)
+                auto solve_store_keep = [&](acc_t (&acc)[2][2], int I, int Jc, const T (&av)[2][2][4], acc_t (&yk)[2][2]) {
+                    const int cbase = Jc * NB, irow = I * NB + 2 * j16;
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp) {
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) {
+                            acc_t yy = {0, 0, 0, 0};
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                                for (int r = 0; r < (cbp == 0 ? P::PANEL_R0 : 4); ++r)
+                                    yy = P::mfma(av[cbp][cb][r], acc[cb][ib][r], yy);
+                            yk[cbp][ib] = yy;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * cbp + P::midx(r, g);
+                            T2 v; v.x = yk[cbp][0][r]; v.y = yk[cbp][1][r];
+                            *reinterpret_cast<T2*>(lop + lop_base<V>(cbase + c, Np) + irow) = v;
+                        }
+                    }
+                };
+                // A operand of the in-register update: L_{J+1,J}[rows 2 j16, 2 j16 + 1 of block J + 1][column col0 + 16 cbp + midx(r, g)]
+                // (fp32 at one wave per SIMD only: at two the 16 + 16 extra live registers spill -- 4096 x 512: 3.57 with, 3.48 ms
+                //  without; fp64, where they are 32 + 32: 1024 x 1024 13.8 with, 12.8 ms without.  Where it is on: 1024 x 512 0.99 ->
+                //  0.95 ms, 4096 x 1024 21.3 -> 20.3 ms)
+                constexpr bool INREG = BCBF_RW_SUPER_INREG && OCC == 1 && sizeof(T) == 4;
+                T2 a2[2][4];
+                auto load_a2 = [&]() {
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            a2[cbp][r] = *reinterpret_cast<const T2*>(lop + lop_base<V>(col0 + 16 * cbp + P::midx(r, g), Np) + col1 + 2 * j16);
+                };
+                // -S'(I, J+1) += L_{J+1,J} L_IJ'  with L_IJ' out of the registers of its solve
+                auto inner_update = [&](acc_t (&t)[2][2], const acc_t (&yk)[2][2]) {
+#pragma unroll
+                    for (int cbp = 0; cbp < 2; ++cbp)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib) {
+                                t[0][ib] = P::mfma(a2[cbp][r].x, yk[cbp][ib][r], t[0][ib]);
+                                t[1][ib] = P::mfma(a2[cbp][r].y, yk[cbp][ib][r], t[1][ib]);
+                            }
+                };
                 auto keep_first_inverse = [&]() {              // d.xinv -> xinvJ (the second factorisation overwrites d.xinv)
                     if (BCBF_RW_SUPER_AINV_LDS) {
                         for (int e = lane; e < NB * NB; e += 64) sh.xinvJ[e >> 5][e & 31] = sh.d.xinv[e >> 5][e & 31];
@@ -757,6 +815,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     solve_store_s(t10, J + 1, J, ainv);                     // L_{J+1,J}
                     wave_fence();
                     RW_ACC(5);
+                    if (INREG && !BCBF_RW_SUPER_A2_RELOAD) load_a2();
                     update_r(t11, col1, J + 1, col0, col1);                 // -= L_{J+1,J} L_{J+1,J}'
                     RW_ACC(2);
                     diag_tile_s(t11, J + 1, ainv1);
@@ -776,6 +835,17 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         RW_ACC(1);
                         update4(t00, t01, t10, t11, I, IC2{}, std::false_type{});
                         RW_ACC(2);
+                        if (INREG && BCBF_RW_SUPER_AINV_LDS) {
+                            T av[2][2][4];
+                            acc_t y0[2][2], y1[2][2];
+                            if (BCBF_RW_SUPER_A2_RELOAD) load_a2();
+                            load_ainv(av, std::false_type{});
+                            solve_store_keep(t00, I, J, av, y0);
+                            inner_update(t01, y0);
+                            solve_store_keep(t10, I + 1, J, av, y1);
+                            inner_update(t11, y1);
+                            RW_ACC(5);
+                        } else {
                         if (BCBF_RW_SUPER_AINV_LDS) {
                             T av[2][2][4];
                             load_ainv(av, std::false_type{});
@@ -788,6 +858,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         wave_fence();
                         RW_ACC(5);
                         update2_r(t01, t11, col1, I, col0, col1);           // -= L_{I,J} L_{J+1,J}',  L_{I+1,J} L_{J+1,J}'
+                        }
                         RW_ACC(2);
                         if (BCBF_RW_SUPER_AINV_LDS) {
                             T av[2][2][4];
@@ -804,7 +875,16 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         values_s(t00, rw0, I, IC0{});
                         values_s(t01, rw0, I, IC1{});
                         update4(t00, t01, t00, t01, I, IC1{}, std::false_type{});
-                        if (BCBF_RW_SUPER_AINV_LDS) {
+                        if (INREG && BCBF_RW_SUPER_AINV_LDS) {
+                            T av[2][2][4];
+                            acc_t y0[2][2];
+                            if (BCBF_RW_SUPER_A2_RELOAD) load_a2();
+                            load_ainv(av, std::false_type{});
+                            solve_store_keep(t00, I, J, av, y0);
+                            inner_update(t01, y0);
+                            load_ainv(av, std::true_type{});
+                            solve_store_s(t01, I, J + 1, av);
+                        } else if (BCBF_RW_SUPER_AINV_LDS) {
                             T av[2][2][4];
                             load_ainv(av, std::false_type{});
                             solve_store_s(t00, I, J, av);
@@ -1943,7 +2023,8 @@ static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell,
     int dev_ = 0, cus = 256;
     (void)hipGetDevice(&dev_);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
-    bool two = sizeof(T) == 4 && Bt >= 8 * cus;                // more than one instance per SIMD
+    bool two = sizeof(T) == 4 && Bt >= 8 * cus && Np < 1024;   // more than one instance per SIMD (N >= 1024: one wave with all 512
+                                                               // registers is faster even then, 4096 x 1024: 20.7 against 21.6 ms)
     if (const char* e = getenv("BCBF_RW32_OCC")) two = e[0] == '2';      // (development: force the allocation)
 #define BCBF_RW_LAUNCH(OCC_, ...)                                                                                         \
     do {                                                                                                                  \
