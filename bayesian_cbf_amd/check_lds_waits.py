@@ -12,6 +12,11 @@ names a register that is the destination of an LDS read still in flight:
     retires all but the N youngest operations (in-order return, the assumption the compiler's own counted waits make);
   * any other instruction whose operands (destination or source) overlap an in-flight destination is a violation.
 
+One idiom is exempt: the compiler's expansion of a 64-bit multiply, `v_mov_b32 vL, x` immediately followed by
+`v_mad_u64_u32 v[..], s[..], y, k, v[L:L+1]`, keeps only the LOW word of the result and leaves the high word of the addend
+pair undefined -- the register allocator may name any register there, including an in-flight destination, and its
+contents do not reach the value.
+
 It also covers the compiler's own LDS reads (which the compiler waits for itself), so a clean run means: in this code
 object no LDS read result is consumed early, by anyone.  Control flow is ignored (the kernels are straight-line apart
 from a few counted loops whose bodies end on a wait); a label does not clear the in-flight set.
@@ -70,8 +75,10 @@ def check(asm_text, name_regex=r"."):
     pat = re.compile(name_regex)
     bad, kernel, inflight = [], None, []           # inflight: list of register sets, oldest first
     checked = 0
+    prev = ""
     for ln, raw in enumerate(asm_text.splitlines(), 1):
         line = raw.split(";")[0].strip()
+        prev_line, prev = prev, (line if line and not line.startswith(".") else prev)
         if not line or line.startswith("."):
             if raw.lstrip().startswith(".end_amdhsa_kernel") or raw.lstrip().startswith(".Lfunc_end"):
                 kernel, inflight = None, []
@@ -115,6 +122,12 @@ def check(asm_text, name_regex=r"."):
             continue
         pend = set().union(*inflight)
         hit = _touched(op, rest) & pend
+        if hit and op == "v_mad_u64_u32":
+            # 64-bit multiply expansion: undefined high word of the addend pair (see the module docstring)
+            m = re.search(r",\s*v\[(\d+):(\d+)\]\s*$", rest)
+            pm = re.match(r"v_mov_b32(?:_e32)?\s+v(\d+),", prev_line)
+            if m and pm and int(pm.group(1)) == int(m.group(1)) and hit == {("v", int(m.group(2)))}:
+                hit = set()
         if hit:
             bad.append((kernel, ln, line, sorted(hit)))
     return bad, checked

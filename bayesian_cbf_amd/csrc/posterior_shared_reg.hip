@@ -38,6 +38,9 @@ using u32x4r = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 #ifndef BCBF_PSR_OCC2
 #define BCBF_PSR_OCC2 1
 #endif
+#ifndef BCBF_PSR_QW5
+#define BCBF_PSR_QW5 1
+#endif
 constexpr int PSR_MAXBLK = 16;           // N <= 512
 
 // compile-time loop: the body sees a constant index (every wreg[][] subscript must be one, or the array leaves the
@@ -135,7 +138,11 @@ template <int CTRL> __device__ inline double dpp_bc(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
-template <typename T, int C, int NS, int OCC>
+// QW: queries per wave -- 4 (one per lane quad, 4 columns each: component 3 of the unicycle's C = 3 is a zero column) or,
+// for C = 3 only, 5 (three adjacent columns each, column 15 idle): 15 of the 16 MFMA columns carry a query instead of 12.
+// Chosen by the launcher when the queries no longer fit one wave per SIMD at QW = 4 (a fifth fewer waves for the same
+// queries; with one round of waves either way the quads' cheaper broadcasts win).
+template <typename T, int C, int NS, int OCC, int QW = 4>
 __global__ void __launch_bounds__(256, OCC)
 posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                             const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
@@ -144,7 +151,8 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
                             T* __restrict__ Wout, int nq, int N, int Np, int n) {
     using P = PSR<T>;
     using acc_t = typename P::acc_t;
-    constexpr int V = Vec<T>::V, QW = 4, ES = (int)sizeof(T);
+    constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
+    static_assert(QW == 4 || (QW == 5 && C == 3), "five queries per wave: three columns each");
     constexpr int REGBLK = P::REGBLK, SLABBLK = PSR_MAXBLK - 1 - REGBLK;
     constexpr int TILE = NB * NB;                      // elements per tile buffer
     extern __shared__ double smem_psr[];
@@ -163,9 +171,19 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     for (int i = threadIdx.x; i < Np * C; i += blockDim.x) Us[i] = i < N * C ? UHB[i] : T(0);
 
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    const int ql = j >> 2, c = j & 3;                  // query slot in the wave, component
+    const int ql = QW == 4 ? j >> 2 : j / 3, c = QW == 4 ? j & 3 : j - 3 * (j / 3);   // query slot in the wave, component
+    const bool slot = QW == 4 || j < 15;               // (QW = 5: column 15 belongs to no query)
     const int q = (blockIdx.x * 4 + wave) * QW + ql;
-    const bool qok = q < nq, cok = c < C;              // (a wave past the end still stages tiles and meets the barriers)
+    const bool qok = slot && q < nq, cok = slot && c < C;   // (a wave past the end still stages tiles and meets the barriers)
+    // value of the lane holding component A of this lane's query: a quad broadcast (QW = 4); among three adjacent lanes
+    // (QW = 5) the row shift by A - c
+    auto gb = [&](auto ac, T v) -> T {
+        constexpr int A = decltype(ac)::value;
+        if constexpr (QW == 4) return dpp_bc<0x55 * A>(v);
+        else if constexpr (A == 0) { const T m1 = dpp_bc<0x111>(v), m2 = dpp_bc<0x112>(v); return c == 0 ? v : (c == 1 ? m1 : m2); }
+        else if constexpr (A == 1) { const T p1 = dpp_bc<0x101>(v), m1 = dpp_bc<0x111>(v); return c == 0 ? p1 : (c == 1 ? v : m1); }
+        else { const T p2 = dpp_bc<0x102>(v), p1 = dpp_bc<0x101>(v); return c == 0 ? p2 : (c == 1 ? p1 : v); }
+    };
     const int qq = qok ? q : nq - 1;
 
     T xqr[NS], iell[NS];
@@ -247,9 +265,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
         for (int e = 0; e < 8; ++e) {
             const T v = pend[e];
             const int row = Ib * NB + P::colstep(e) + P::LANECOL * g;
-            const T vb[4] = {dpp_bc<0x00>(v), dpp_bc<0x55>(v), dpp_bc<0xAA>(v), dpp_bc<0xFF>(v)};
-#pragma unroll
-            for (int a_ = 0; a_ < C; ++a_) gram[a_] += v * vb[a_];             // lane c: G[c][a]
+            static_for<0, C>([&](auto ac) { gram[decltype(ac)::value] += v * gb(ac, v); });   // lane c: G[c][a]
 #pragma unroll
             for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;        // lane c: (Vw'W)[d][c]
         }
@@ -261,6 +277,24 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     T phi[8];
     auto phi_tile = [&](auto Ic_) {
         constexpr int I = decltype(Ic_)::value;
+        if constexpr (QW == 5) {
+            // lane c evaluates the rows of registers c, c + 3, c + 6 (the last one clamped: register 7 twice)
+            T km[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = min(c + 3 * i, 7);
+                const int row_m = I * NB + P::colstep(e) + P::LANECOL * g;
+                T d2 = T(0);
+#pragma unroll
+                for (int d = 0; d < NS; ++d) { const T z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
+                km[i] = s2 * P::exp_(T(-0.5) * d2);
+            }
+            static_for<0, 8>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                phi[e] = gb(Ic<e % 3>{}, km[e / 3]) * Us[(I * NB + P::colstep(e) + P::LANECOL * g) * C + cc] * cmask;
+            });
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row_m = I * NB + P::colstep(4 * u) + P::LANECOL * g + (P::colstep(1) - P::colstep(0)) * c;
@@ -386,7 +420,7 @@ template <typename T> static bool psr_fits(int N, int n, int m) {
     return n <= 4 && Np <= NB * PSR_MAXBLK && psr_lds_bytes<T>(Np, n, m) <= 160 * 1024;
 }
 template <typename T, int C, int NS>
-static void launch_psr(dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X, const T* UHB,
+static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X, const T* UHB,
                        const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
                        T* W, int nq, int N, int Np, int n) {
     // fp32 with enough queries for two waves per SIMD (more than 16 per CU-SIMD: > 4096 on 256 CUs): the 256-register
@@ -394,17 +428,39 @@ static void launch_psr(dim3 grid, size_t lds, hipStream_t st, const T* Lop, cons
     int dev_ = 0, cus = 256;
     (void)hipGetDevice(&dev_);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
-    const bool two = sizeof(T) == 4 && BCBF_PSR_OCC2 && nq > 16 * cus && lds <= 64 * 1024;
-    auto go = [&](auto occ) {
-        constexpr int OCC = decltype(occ)::value;
-        static int opt_in[64] = {0};           // largest dynamic LDS size opted into, per device
-        int& lds_opt_in = opt_in[dev_ & 63];
+    // Queries per wave (4, or 5 when C = 3) and waves per SIMD (1, or 2 in fp32): the launch runs in rounds of 4 (8) waves
+    // per CU and a round costs the same however full it is, so the cheapest of the four combinations by
+    //   rounds x (time of one round relative to the four-query one-wave form: 1.0 | 1.1 with five queries, x 1.7 at two waves per SIMD)
+    // (measured, N = 512, us per round: fp32 48 / 53 / 82 / 92, fp64 85 / 92): five queries per wave pay when they save a round --
+    // 5120 queries: fp32 0.053 ms (76 TFLOP/s) against 0.082, fp64 0.093 (43 TFLOP/s) against 0.170; 20480: fp32 0.187 against
+    // 0.245 -- and lose a tenth when they do not (16384: fp32 0.185 against 0.164).
+    static const int qw_force = [] { const char* e = getenv("BCBF_PSR_QW"); return e ? atoi(e) : 0; }();      // (development)
+    const bool can5 = C == 3 && BCBF_PSR_QW5, can2 = sizeof(T) == 4 && BCBF_PSR_OCC2 && lds <= 64 * 1024;
+    bool five = false, two = false;
+    double best = 1e30;
+    for (int f = 0; f <= (can5 ? 1 : 0); ++f)
+        for (int t = 0; t <= (can2 ? 1 : 0); ++t) {
+            if (qw_force && (qw_force == 5) != (f == 1) && can5) continue;
+            const long w = f ? (nq + 4) / 5 : (nq + 3) / 4, slots = (long)(t ? 8 : 4) * cus;
+            const double cost = (double)((w + slots - 1) / slots) * (f ? 1.1 : 1.0) * (t ? 1.7 : 1.0);
+            if (cost < best) { best = cost; five = f; two = t; }
+        }
+    const int waves = five ? (nq + 4) / 5 : (nq + 3) / 4;
+    const dim3 grid((waves + 3) / 4);                  // 256 threads per workgroup, four waves
+    auto go5 = [&](auto occ, auto qw) {
+        constexpr int OCC = decltype(occ)::value, QW = decltype(qw)::value;
+        static int opt_in[2][64] = {{0}};           // largest dynamic LDS size opted into, per device
+        int& lds_opt_in = opt_in[QW == 5][dev_ & 63];
         if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
-            (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, OCC, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             lds_opt_in = (int)lds;
         }
-        hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, OCC>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
+        hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, OCC, QW>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
                            xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+    };
+    auto go = [&](auto occ) {
+        if constexpr (C == 3 && BCBF_PSR_QW5) { if (five) { go5(occ, Ic<5>{}); return; } }
+        go5(occ, Ic<4>{});
     };
     if constexpr (sizeof(T) == 4 && BCBF_PSR_OCC2) {
         if (two) go(Ic<2>{}); else go(Ic<1>{});
@@ -418,15 +474,15 @@ static void launch_psr(dim3 grid, size_t lds, hipStream_t st, const T* Lop, cons
 // instantiates launch_psr_c<T, C> and its kernels -- and once with -DBCBF_PSR_PART_BASE for the dispatchers and C entry
 // points, which only see the declaration below.  No part macro: everything in one unit.
 template <typename T, int C>
-void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
+void launch_psr_c(int NSp, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
                   const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
                   T* Mk, T* Bk, T* W, int nq, int N, int Np, int n);
 #ifndef BCBF_PSR_PART_BASE
 template <typename T, int C>
-void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
+void launch_psr_c(int NSp, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
                   const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
                   T* Mk, T* Bk, T* W, int nq, int N, int Np, int n) {
-#define BCBF_PSR(NSV) launch_psr<T, C, NSV>(grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
+#define BCBF_PSR(NSV) launch_psr<T, C, NSV>(lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
     switch (NSp) {
 #ifndef BCBF_PSR_DEV              // (development: the C = 3, NS = 3 instantiations only)
         case 2: BCBF_PSR(2); break;
@@ -444,7 +500,7 @@ void launch_psr_c(int NSp, dim3 grid, size_t lds, hipStream_t st, const T* Lop, 
 #else
 #define BCBF_PSR_PT float
 #endif
-template void launch_psr_c<BCBF_PSR_PT, BCBF_PSR_PART_C>(int, dim3, size_t, hipStream_t, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
+template void launch_psr_c<BCBF_PSR_PT, BCBF_PSR_PART_C>(int, size_t, hipStream_t, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
                                                          const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
                                                          const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
                                                          BCBF_PSR_PT*, BCBF_PSR_PT*, BCBF_PSR_PT*, int, int, int, int);
@@ -464,17 +520,15 @@ int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* 
     if (!psr_fits<T>(N, n, m)) return BCBF_EINVAL;
     const int Np = round_up(N, NB), NSp = psr_state_dim(n);
     const size_t lds = psr_lds_bytes<T>(Np, n, m);
-    const int waves = (nq + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((waves + 3) / 4);                        // 256 threads: one wave per SIMD (W takes the accumulation registers)
     switch (m) {
 #ifdef BCBF_PSR_DEV
-        case 2: launch_psr_c<T, 3>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 2: launch_psr_c<T, 3>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
         default: break;
 #else
-        case 1: launch_psr_c<T, 2>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
-        case 2: launch_psr_c<T, 3>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
-        default: launch_psr_c<T, 4>(NSp, grid, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 1: launch_psr_c<T, 2>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 2: launch_psr_c<T, 3>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        default: launch_psr_c<T, 4>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
 #endif
     }
     return check_launch("posterior_shared_reg");

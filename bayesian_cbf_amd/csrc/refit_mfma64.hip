@@ -393,7 +393,7 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
         cus_ = c_ > 0 ? c_ : 256;
     }
     bool team = Np / NB <= 64 &&       // (N <= 2048: beyond, no better than the workgroup form -- 1 x 4096 fp64: 128 / 125 ms)
-                ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= 4 * cus_));
+                ((Np >= 256 && Bt <= cus_) || (Np >= 512 && Bt <= 2 * cus_) || (Np >= 1024 && Bt <= ((Kdense || Ldense) ? 4 : 2) * cus_));   // (1024 x 1024 fp64: team 13.2, one wave with super-panels 12.8 ms)
     // ... of four waves (two workgroups per CU) for cus < batch <= 2 cus at 256 <= N <= 512: 512 x 256 fp64 0.259 (two waves per
     // instance) / 0.210, fp32 0.162 / 0.136; 512 x 512 fp32 0.62 (team of eight, two rounds) / 0.53
     int team_nw = 8;

@@ -80,3 +80,11 @@ _Z6kernelv:
     assert check(pk_ok, "kernel")[0] == []
     pk_bad = pk_ok.replace(" op_sel_hi:[0,1,1]", "")
     assert [b[3] for b in check(pk_bad, "kernel")[0]] == [[("v", 11)]]
+    # the compiler's 64-bit multiply expansion names an undefined high word in the addend pair: exempt only in that exact shape
+    mul64 = good.replace("\tv_add_f32_e32 v1, v2, v4", "\tv_mov_b32_e32 v10, v7\n\tv_mad_u64_u32 v[30:31], s[8:9], v31, 12, v[10:11]")
+    assert [b[3] for b in check(mul64, "kernel")[0]] == [[("v", 10)], [("v", 10), ("v", 11)]]   # (here v10 itself is in flight: both lines are violations)
+    mul64_ok = good.replace("ds_read_b64 v[10:11]", "ds_read_b32 v11").replace(
+        "\tv_add_f32_e32 v1, v2, v4", "\tv_mov_b32_e32 v10, v7\n\tv_mad_u64_u32 v[30:31], s[8:9], v31, 12, v[10:11]").replace(
+        "v_mul_f64 v[20:21], v[10:11], v[10:11]", "v_mul_f32 v20, v11, v11")
+    assert check(mul64_ok, "kernel")[0] == []
+    assert len(check(mul64_ok.replace("\tv_mov_b32_e32 v10, v7\n", ""), "kernel")[0]) == 1       # without the preceding low-word move: reported

@@ -633,6 +633,47 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
     rel_close(host(Bk2), Bk_o, 1e-9 if f64 else 1e-3, scale=prior, what="Bk(query)")
 
 
+@pytest.mark.parametrize("N,n,dtype,mult", [(512, 3, torch.float32, 16), (480, 4, torch.float64, 16), (100, 2, torch.float64, 16),
+                                            (512, 3, torch.float64, 16), (288, 4, torch.float32, 16), (512, 3, torch.float32, 32),
+                                            (200, 2, torch.float32, 32), (320, 3, torch.float64, 32)])
+def test_shared_gp_five_queries_per_wave_form(ops, N, n, dtype, mult):
+    """m = 2 (three columns per query), more queries than one wave per SIMD holds at four per wave: the launcher packs FIVE
+    queries into the 16 matrix-core columns of a wave (posterior_shared_reg.hip, QW = 5) when that saves a round of waves:
+    mult = 16: one wave per SIMD; 32: fp32 two waves per SIMD, fp64 two rounds.  Against the fp64 oracle on a sample of the queries, and against the same batch cut into pieces that take the
+    four-per-wave form (same arithmetic per query: only the lane a value sits in differs)."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64, m = dtype == torch.float64, 2
+    p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=41 + N)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert int(info[0]) == 0
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    b = mult * cus + 503                                       # ragged: not a multiple of 5, 20 or 4
+    g = torch.Generator(device="cpu").manual_seed(7)
+    xq = (p["X"][0, torch.randint(0, N, (b,), generator=g).to(DEV)] + 0.3 * torch.randn(b, n, generator=g).to(DEV, dtype)).contiguous()
+    j2 = (1e-5 * torch.rand(b, m + 1, generator=g)).to(DEV, dtype)
+    Mk, Bk, W = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, j2, want_W=True)
+    scale = float(p["s2"][0]) * float(p["Bm"][0].abs().max())
+    for a in range(0, b, 1024):
+        Mk1, Bk1, W1 = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq[a:a + 1024].contiguous(),
+                                            j2[a:a + 1024].contiguous(), want_W=True)
+        tol = 1e-13 if f64 else 1e-6
+        rel_close(host(Mk[a:a + 1024]), host(Mk1), tol, scale=max(1.0, float(Mk1.abs().max())), what="Mk")
+        rel_close(host(Bk[a:a + 1024]), host(Bk1), tol, scale=scale, what="Bk")
+        rel_close(host(W[a:a + 1024]), host(W1), tol, scale=max(1e-3, float(W1.abs().max())), what="W")
+    pick = torch.randint(0, b, (48,), generator=g)
+    pick[:3] = torch.tensor([0, b - 1, b - 2])
+    h = {k: host(v) for k, v in p.items()}
+    st = ogp.refit_state(h["X"][0], h["U"][0], h["Xdot"][0], h["Bm"][0], h["ell"][0], h["s2"][0], h["M0"][0],
+                         h["jitter"][0][None] / 1e-5)
+    rep = lambda a_: np.broadcast_to(a_[None], (len(pick),) + a_.shape)
+    Mk_o, Bk_o = ogp.posterior_step(rep(st["L"]), rep(st["alpha"]), rep(h["X"][0]), rep(st["UHB"]), rep(h["ell"][0]),
+                                    rep(h["s2"][0]), rep(h["Bm"][0]), rep(h["M0"][0]), host(xq)[pick.numpy()],
+                                    jitter2=host(j2)[pick.numpy()])
+    rel_close(host(Mk)[pick.numpy()], Mk_o, 1e-9 if f64 else 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk vs oracle")
+    rel_close(host(Bk)[pick.numpy()], Bk_o, 1e-9 if f64 else 1e-3, scale=h["s2"][0] * np.abs(h["Bm"][0]).max(), what="Bk vs oracle")
+
+
 def test_shared_gp_two_waves_per_simd_form_equals_one_wave_form(ops):
     """fp32, more queries than one wave per SIMD holds (> 16 per compute unit): the launcher takes the 256-register
     instantiation of the register-resident kernel (two workgroups per CU, plain operand loads).  Same arithmetic in the

@@ -1,0 +1,16 @@
+"""Regime S kernel alone over query counts (N = 512, n = 3, m = 2): the launcher's choice of queries per wave (4 | 5) and waves
+per SIMD shows as steps at multiples of 4096 / 5120 queries.   python tools/time_shared_sweep.py"""
+import os, sys, json, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import timeit
+from bayesian_cbf_amd import ops
+from bayesian_cbf_amd.synthetic import make_instances
+for dtype in (torch.float64, torch.float32):
+    p = make_instances(1, 512, 3, 2, dtype=dtype, device="cuda", seed=1)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    for b in (2048, 4096, 4097, 5120, 6144, 8192, 10240, 12288, 15360, 16384, 20480, 32768, 40960):
+        xq = (p["X"][0, torch.randint(0, 512, (b,), device="cuda")] + 0.3 * torch.randn(b, 3, device="cuda", dtype=dtype)).contiguous()
+        t = timeit(lambda: ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq))
+        print(json.dumps({"dtype": str(dtype)[6:], "queries": b, "ms": round(t, 4), "TFLOPs": round(b * 3 * 512 * 512 / (t * 1e-3) / 1e12, 2)}), flush=True)
