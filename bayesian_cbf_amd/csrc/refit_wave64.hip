@@ -78,6 +78,15 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #define BCBF_RW_SUPER_AINV_LDS 1 // super-panels: the two inverted diagonal tiles stay in LDS and the panel solves read their operands from
                                  // there right before use (16 ds_reads per solve pair) instead of holding 2 x 16 (fp64: 2 x 32) registers
 #endif
+#ifndef BCBF_RW_VALUES_FAST
+#define BCBF_RW_VALUES_FAST 1    // K_b values of tiles off the diagonal and clear of the padding without the per-value compares / selects
+#endif
+#ifndef BCBF_RW_FAST44
+#define BCBF_RW_FAST44 0
+#endif
+#ifndef BCBF_RW_VALUES_FAST_DIAG
+#define BCBF_RW_VALUES_FAST_DIAG 1
+#endif
 #ifndef BCBF_RW_SUPER_INREG
 #define BCBF_RW_SUPER_INREG 1    // super-panels: the 32-deep update of column J + 1 by column J takes the just-solved tiles L_IJ' straight from the
                                  // registers they were solved into (accumulator layout = B operand with a permuted contraction order; the A
@@ -355,6 +364,40 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 acc[cb][ib][r] = -val;
                             }
                     }
+                } else if (BCBF_RW_VALUES_FAST && sizeof(T) == 4 && (BCBF_RW_VALUES_FAST_DIAG || I > J + 1) && I != J + SEL && (I + 1) * NB <= N && col0 + NB <= N && n <= 4) {
+                    // a tile off the diagonal and clear of the padding (120 of the 136 tiles at N = 512): no diagonal jitter, no
+                    // identity padding -- 16 instructions per value instead of 30 (the common shapes n <= 3, C <= 3 skip the zero
+                    // fourth component as well).  fp32 only: compiled into the fp64 super-panel instantiation (256 + 256 registers
+                    // and scratch) the same statements produced wrong tiles -- (3, 3) body: the last diagonal tile, (4, 4) body:
+                    // zeros from the third block row on -- while every fp32 form passes the parity tests with it; unexplained,
+                    // and the fp64 value pass is dominated by its 25-instruction exp anyway
+                    const T ms2 = -s2;
+                    auto fast = [&](auto ndc, auto ncc) {
+                        constexpr int ND = decltype(ndc)::value, NC = decltype(ncc)::value;
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int c = 2 * P::midx(r, g) + cb;
+                                T cx[4], cu[4];
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) {
+                                    cx[d] = SEL ? sh.colX2[c][d] : sh.colX[c][d];
+                                    cu[d] = SEL ? sh.colUH2[c][d] : sh.colUH[c][d];
+                                }
+#pragma unroll
+                                for (int ib = 0; ib < 2; ++ib) {
+                                    T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                                    for (int d = 0; d < ND; ++d) { const T z = (q.rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+#pragma unroll
+                                    for (int a_ = 0; a_ < NC; ++a_) uu += q.ru[ib][a_] * cu[a_];
+                                    acc[cb][ib][r] = ms2 * P::exp_neg(T(T(0.5)) * d2) * uu;
+                                }
+                            }
+                    };
+                    if (!BCBF_RW_FAST44 && OCC == 1 && n <= 3 && C <= 3) fast(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});   // (two waves per SIMD: one body -- the second costs registers there, 4096 x 256 0.72 against 0.77 ms)
+                    else fast(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
                 } else {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)

@@ -1077,8 +1077,10 @@ def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt,
     good = ip == 0
     assert good.sum() == (Bt - 1 if bad else Bt) and (not bad or ip[5] == 21)
     assert torch.equal(UHB_p, UHB_w)
-    for i in np.nonzero(good)[0][:8]:          # (fp32: two factorizations of K_b with cond ~1e5, inverses of its diagonal blocks)
-        rel_close(host(Lop_p[i]), host(Lop_w[i]), 1e-8 if f64 else 2e-3, what="Lop vs one-wave form [%d]" % i)
+    # (fp32: two factorizations of K_b with cond ~1e5 and the inverses of its diagonal blocks; the forms round K_b's entries
+    #  differently since the one-wave form's interior tiles skip the jitter / padding selects: cond x eps = 6e-3)
+    for i in np.nonzero(good)[0][:8]:
+        rel_close(host(Lop_p[i]), host(Lop_w[i]), 1e-8 if f64 else 5e-3, what="Lop vs one-wave form [%d]" % i)
     Vw, _ = ops.potrs(Lop_p, p["Xdot"], UH, p["M0"], want_alpha=False)
     Mk, Bk = ops.posterior_step(Lop_p, Vw, X, UHB_p, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
     h = {k: host(v) for k, v in dict(X=X, U=p["U"], Xdot=p["Xdot"], Bm=p["Bm"], ell=p["ell"], s2=p["s2"], M0=p["M0"], jit=jit).items()}

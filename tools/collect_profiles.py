@@ -32,7 +32,7 @@ for tag in ("default", "parts1", "shared", "shared_f64", "reldeg2"):
     print(tag, [(r[0].split("(")[0][-44:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
 
 # ---- bench lines
-for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_parts2", "bench_parts3", "bench_shared", "bench_shared_prof", "bench_shared_f64", "bench_shared_f64_prof", "bench_f64"):
+for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_parts1", "bench_parts1_prof", "bench_parts2", "bench_parts3", "bench_shared", "bench_shared_prof", "bench_shared_f64", "bench_shared_f64_prof", "bench_f64", "bench_shared_b10240", "bench_shared_b10240_f64"):
     if os.path.exists(SRC + a + ".json") and os.path.getsize(SRC + a + ".json"):
         d = last_json_line(SRC + a + ".json")
         json.dump(d, open(DST + a + ".json", "w"), indent=1)
@@ -40,7 +40,7 @@ for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_par
         print(a, round(d["value"]), round(d["ms_per_step"], 4), "frac", round(rf["frac"], 4), "kernel_ms", round(rf["kernel_ms"], 4),
               "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
 for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "online_growth_f64_unfused.json", "online_growth_f64_unfused3.json", "online_growth_f64_packed.json", "online_growth_f64_batch1024.json", "online_growth_f64_pairform.json", "online_window512_f64.json", "online_window1024_f64.json", "speed_call_host.txt", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
-          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt", "pmc_traffic_refit.json",
+          "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "shared_sweep.jsonl", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt", "pmc_traffic_refit.json",
           "refit_pair_timeline.txt"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
         shutil.copy(SRC + a, DST + a)

@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared -- python
 python bench.py --regime shared --dtype f64 --cpu-sample 0 > $O/bench_shared_f64.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_shared_f64 -- python3 bench.py --regime shared --dtype f64 --steps 100 --warmup 60 --cpu-sample 0 > $O/bench_shared_f64_prof.json 2> $O/bench_shared_f64_prof.err
 python bench.py --dtype f64 --cpu-sample 0 > $O/bench_f64.json 2>/dev/null
+# regime S at a batch whose part batches (two of 5120 loops) take the five-queries-per-wave form
+python bench.py --regime shared --batch 10240 --cpu-sample 0 > $O/bench_shared_b10240.json 2>/dev/null
+python bench.py --regime shared --batch 10240 --dtype f64 --cpu-sample 0 > $O/bench_shared_b10240_f64.json 2>/dev/null
 # HBM traffic of the roofline kernel (default schedule AND the one-stream schedule): three passes each
 for sched in "" "--parts 1"; do
   tag=$(echo "default$sched" | tr -d ' -')
@@ -42,6 +45,7 @@ for cfg in C2 C3f64 C3 N1024f64; do
 done
 python tools/bench_configs.py 2>/dev/null > $O/configs.jsonl
 python tools/time_shared.py 2>/dev/null > $O/shared_queries.txt
+python tools/time_shared_sweep.py 2>/dev/null > $O/shared_sweep.jsonl
 python tools/bench_refit_forms.py 2>/dev/null > $O/refit_forms.jsonl
 python tools/bench_refit_forms.py f32 2>/dev/null > $O/refit_forms_f32.jsonl
 python tools/bench_online.py --repeat 2 2>/dev/null > $O/online_growth_f64.json
