@@ -93,6 +93,10 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
                                  // operand L_{J+1,J} is loaded once per super-panel in that order) -- no store -> fence -> load round trip per
                                  // row pair, no B streams
 #endif
+#ifndef BCBF_RW_SUPER_INREG_OCC2
+#define BCBF_RW_SUPER_INREG_OCC2 1    // ... at two waves per SIMD too, with the A operand re-read per row pair (after the leaner value pass: 4096 x 512
+                                      // 3.14 -> 3.09 ms; before it the extra live registers cost 3 %)
+#endif
 #ifndef BCBF_RW_SUPER_A2_RELOAD
 #define BCBF_RW_SUPER_A2_RELOAD 0   // 1: that A operand is re-read (L2 hits) at every row pair instead of living in 16 registers across the stream loops
                                     // (parking it in LDS instead costs the 4 KB that take the kernel's LDS past 160 KB / 8 waves per CU)
@@ -644,10 +648,12 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     }
                 };
                 // A operand of the in-register update: L_{J+1,J}[rows 2 j16, 2 j16 + 1 of block J + 1][column col0 + 16 cbp + midx(r, g)]
-                // (fp32 at one wave per SIMD only: at two the 16 + 16 extra live registers spill -- 4096 x 512: 3.57 with, 3.48 ms
-                //  without; fp64, where they are 32 + 32: 1024 x 1024 13.8 with, 12.8 ms without.  Where it is on: 1024 x 512 0.99 ->
-                //  0.95 ms, 4096 x 1024 21.3 -> 20.3 ms)
-                constexpr bool INREG = BCBF_RW_SUPER_INREG && OCC == 1 && sizeof(T) == 4;
+                // (fp32 only: in fp64, where the extra live registers are 32 + 32, 1024 x 1024 takes 13.8 ms with it, 12.8 without.
+                //  One wave per SIMD: 1024 x 512 0.99 -> 0.95 ms, 4096 x 1024 21.3 -> 20.3 ms.  Two waves per SIMD: the operand is
+                //  re-read at every row pair (L2 hits) instead of held -- 4096 x 512 3.14 -> 3.09 ms; with the round's first value
+                //  pass, which left fewer registers, the same switch cost 3 %)
+                constexpr bool INREG = BCBF_RW_SUPER_INREG && (OCC == 1 || BCBF_RW_SUPER_INREG_OCC2) && sizeof(T) == 4;
+                constexpr bool A2_RELOAD = BCBF_RW_SUPER_A2_RELOAD || OCC == 2;
                 T2 a2[2][4];
                 auto load_a2 = [&]() {
 #pragma unroll
@@ -858,7 +864,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                     solve_store_s(t10, J + 1, J, ainv);                     // L_{J+1,J}
                     wave_fence();
                     RW_ACC(5);
-                    if (INREG && !BCBF_RW_SUPER_A2_RELOAD) load_a2();
+                    if (INREG && !A2_RELOAD) load_a2();
                     update_r(t11, col1, J + 1, col0, col1);                 // -= L_{J+1,J} L_{J+1,J}'
                     RW_ACC(2);
                     diag_tile_s(t11, J + 1, ainv1);
@@ -881,7 +887,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         if (INREG && BCBF_RW_SUPER_AINV_LDS) {
                             T av[2][2][4];
                             acc_t y0[2][2], y1[2][2];
-                            if (BCBF_RW_SUPER_A2_RELOAD) load_a2();
+                            if (A2_RELOAD) load_a2();
                             load_ainv(av, std::false_type{});
                             solve_store_keep(t00, I, J, av, y0);
                             inner_update(t01, y0);
@@ -921,7 +927,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         if (INREG && BCBF_RW_SUPER_AINV_LDS) {
                             T av[2][2][4];
                             acc_t y0[2][2];
-                            if (BCBF_RW_SUPER_A2_RELOAD) load_a2();
+                            if (A2_RELOAD) load_a2();
                             load_ainv(av, std::false_type{});
                             solve_store_keep(t00, I, J, av, y0);
                             inner_update(t01, y0);
