@@ -25,8 +25,11 @@ SOURCES = ["common.hip", "posterior_step.hip", "posterior_shared.hip", "posterio
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]
 # per-file extras.  posterior_shared: MFMA results are consumed by VALU code every block, so keep the accumulators
-# in VGPRs (no v_accvgpr round trips)
+# in VGPRs (no v_accvgpr round trips).  refit_wave64: the SLP vectorizer packs the K_b value pass into v_pk_mul_f32 pairs it
+# has to assemble with register moves (more instructions and more live registers than the scalar fmas): without it the
+# fp32 batch form at two waves per SIMD runs 4096 x 256 in 0.63 instead of 0.71 ms, everything else within 1 %
 EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "refit_wave64.hip": ["-fno-slp-vectorize"],
                "posterior_shared_reg.hip": ["-Rpass-analysis=kernel-resource-usage"]}
 # kernels that must not touch scratch memory (posterior_shared_reg: an operand spilled between its explicit LDS read and
 # the explicit wait for it would be stored before it has arrived).  Their device assembly is also linted: no instruction may

@@ -6,7 +6,8 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 name=$1; src=$2; shift 2
 mkdir -p $ROOT/tools/_variants
 obj=$ROOT/tools/_variants/${src%.hip}_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$ROOT/include -I$ROOT/bayesian_cbf_amd/csrc "$@" -c $ROOT/bayesian_cbf_amd/csrc/$src -o $obj
+extra=""; [ "$src" = refit_wave64.hip ] && extra="-fno-slp-vectorize"   # (build.py EXTRA_FLAGS)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$ROOT/include -I$ROOT/bayesian_cbf_amd/csrc $extra "$@" -c $ROOT/bayesian_cbf_amd/csrc/$src -o $obj
 others=$(ls $ROOT/bayesian_cbf_amd/csrc/_obj/*.o | grep -v "/${src%.hip}\(_[a-z0-9]*\)\?\.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_variants/libbcbf_$name.so $obj $others
 echo built tools/_variants/libbcbf_$name.so
