@@ -84,6 +84,9 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 #ifndef BCBF_RW_FAST44
 #define BCBF_RW_FAST44 0
 #endif
+#ifndef BCBF_RW_VALUES_FAST64
+#define BCBF_RW_VALUES_FAST64 1
+#endif
 #ifndef BCBF_RW_VALUES_FAST_DIAG
 #define BCBF_RW_VALUES_FAST_DIAG 1
 #endif
@@ -368,13 +371,10 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 acc[cb][ib][r] = -val;
                             }
                     }
-                } else if (BCBF_RW_VALUES_FAST && sizeof(T) == 4 && (BCBF_RW_VALUES_FAST_DIAG || I > J + 1) && I != J + SEL && (I + 1) * NB <= N && col0 + NB <= N && n <= 4) {
+                } else if (BCBF_RW_VALUES_FAST && (sizeof(T) == 4 || BCBF_RW_VALUES_FAST64) && (BCBF_RW_VALUES_FAST_DIAG || I > J + 1) && I != J + SEL && (I + 1) * NB <= N && col0 + NB <= N && n <= 4) {
                     // a tile off the diagonal and clear of the padding (120 of the 136 tiles at N = 512): no diagonal jitter, no
                     // identity padding -- 16 instructions per value instead of 30 (the common shapes n <= 3, C <= 3 skip the zero
-                    // fourth component as well).  fp32 only: compiled into the fp64 super-panel instantiation (256 + 256 registers
-                    // and scratch) the same statements produced wrong tiles -- (3, 3) body: the last diagonal tile, (4, 4) body:
-                    // zeros from the third block row on -- while every fp32 form passes the parity tests with it; unexplained,
-                    // and the fp64 value pass is dominated by its 25-instruction exp anyway
+                    // fourth component as well)
                     const T ms2 = -s2;
                     auto fast = [&](auto ndc, auto ncc) {
                         constexpr int ND = decltype(ndc)::value, NC = decltype(ncc)::value;
@@ -400,6 +400,22 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 }
                             }
                     };
+                    // Every row input is pinned as "used" here (empty asm statements with the value as input: no instruction).
+                    // Observed without the pins: the fp64 super-panel instantiation (256 + 256 registers, scratch) came out WRONG with
+                    // this branch, deterministically -- the last diagonal tile of every system factored as if it had no jitter
+                    // (three-component body), zeros from the third block row on (four-component body) -- and correct again as soon
+                    // as the branch merely NAMED q.rj (a select that is never taken was enough).  The inputs this branch does not
+                    // read (rj; rx[.][3], ru[.][3]) are live only into the other branch; whatever the optimizer does with their
+                    // loads then (sinking them is what the symptom suggests), the values that arrive there were not the ones
+                    // load_rows fetched.  fp32 passed every parity test without the pins; it gets them all the same.
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        asm volatile("" :: "v"(q.rj[ib]));
+#pragma unroll
+                        for (int d = 0; d < RXD; ++d) asm volatile("" :: "v"(q.rx[ib][d]));
+#pragma unroll
+                        for (int a_ = 0; a_ < BCBF_MAX_CTRL_DIM + 1; ++a_) asm volatile("" :: "v"(q.ru[ib][a_]));
+                    }
                     if (!BCBF_RW_FAST44 && OCC == 1 && n <= 3 && C <= 3) fast(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});   // (two waves per SIMD: one body -- the second costs registers there, 4096 x 256 0.72 against 0.77 ms)
                     else fast(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
                 } else {
@@ -1037,6 +1053,35 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                                 acc[cb][ib][r] = -val;
                             }
                     }
+                } else if (BCBF_RW_VALUES_FAST && I != J && (I + 1) * NB <= N && col0 + NB <= N && n <= 4) {
+                    // (the lean value pass of the tile-pair path above, for the single-tile stream: interior tiles; inputs pinned)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        asm volatile("" :: "v"(rj[ib]));
+#pragma unroll
+                        for (int d = 0; d < RXD; ++d) asm volatile("" :: "v"(rx[ib][d]));
+#pragma unroll
+                        for (int a = 0; a < BCBF_MAX_CTRL_DIM + 1; ++a) asm volatile("" :: "v"(ru[ib][a]));
+                    }
+                    const T ms2 = -s2;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 2 * P::midx(r, g) + cb;
+                            T cx[4], cu[4];
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) { cx[d] = sh.colX[c][d]; cu[d] = sh.colUH[c][d]; }
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib) {
+                                T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+#pragma unroll
+                                for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                                acc[cb][ib][r] = ms2 * P::exp_neg(T(T(0.5)) * d2) * uu;
+                            }
+                        }
                 } else {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
