@@ -1401,6 +1401,38 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     // acc[cb][ib][r] = K_b'(column col0 + 2 midx(r, g) + cb, row 32 I + 2 j16 + ib)   (rows of block row I in rx / ru / rj)
     auto values = [&](acc_t (&acc)[2][2], int I, int J) {
         const int col0 = J * NB, irow = I * NB + 2 * j16;
+        if (BCBF_RW_VALUES_FAST && I != J && (I + 1) * NB <= N && col0 + NB <= N && n <= 4) {
+            // interior tile: the lean value pass of refit_wave_kernel (no jitter / padding selects; row inputs pinned, see there)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                asm volatile("" :: "v"(rj[ib]));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) asm volatile("" :: "v"(rx[ib][d]));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(ru[ib][a]));
+            }
+            const T ms2 = -s2;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 2 * P::midx(r, g) + cb;
+                    T cx[4], cu[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { cx[d] = cX[c][d]; cu[d] = cU[c][d]; }
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                        acc[cb][ib][r] = ms2 * P::exp_neg(T(T(0.5)) * d2) * uu;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -1809,6 +1841,38 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         acc[cb][ib][r] = -val;
                     }
             }
+            return;
+        }
+        if (BCBF_RW_VALUES_FAST && KIND == 0 && I != J && (I + 1) * NB <= N && col0 + NB <= N && n <= 4) {
+            // interior tile: the lean value pass of refit_wave_kernel (no jitter / padding selects; row inputs pinned, see there)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                asm volatile("" :: "v"(rj[ib]));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) asm volatile("" :: "v"(rx[ib][d]));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(ru[ib][a]));
+            }
+            const T ms2 = -s2;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 2 * P::midx(r, g) + cb;
+                    T cx[4], cu[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { cx[d] = cX[c][d]; cu[d] = cU[c][d]; }
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        T d2 = T(0.0), uu = T(0.0);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { const T z = (rx[ib][d] - cx[d]) * iell[d]; d2 += z * z; }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
+                        acc[cb][ib][r] = ms2 * P::exp_neg(T(T(0.5)) * d2) * uu;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             return;
         }
 #pragma unroll
