@@ -265,7 +265,13 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
         for (int e = 0; e < 8; ++e) {
             const T v = pend[e];
             const int row = Ib * NB + P::colstep(e) + P::LANECOL * g;
-            static_for<0, C>([&](auto ac) { gram[decltype(ac)::value] += v * gb(ac, v); });   // lane c: G[c][a]
+            // lane (component c): gram[k] += W[row][c] W[row][c - k] -- the neighbour k lanes down is component c - k of the SAME
+            // query for k <= c (quads and the three-lane groups alike); entries with k > c are never read
+            static_for<0, C>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k == 0) gram[0] += v * v;
+                else gram[k] += v * dpp_bc<0x110 + k>(v);          // row_shr:k
+            });
 #pragma unroll
             for (int d = 0; d < NS; ++d) mk[d] += Vs[row * NS + d] * v;        // lane c: (Vw'W)[d][c]
         }
@@ -390,6 +396,20 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     // ---- the four lane groups hold different rows: combine, then write Mk[q][d][c], Bk[q][c][a]
 #pragma unroll
     for (int a = 0; a < C; ++a) { gram[a] += __shfl_xor(gram[a], 16, 64); gram[a] += __shfl_xor(gram[a], 32, 64); }
+    // gram[k] = G[c][c - k] (k <= c).  Row c of the symmetric block: G[c][a] = gram[c - a] for a <= c, and for a > c the entry
+    // G[a][c] = gram[a - c] of the lane a - c further up
+    T grow[C];
+#pragma unroll
+    for (int a = 0; a < C; ++a) grow[a] = T(0);
+    static_for<0, C>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T up = k == 0 ? gram[0] : __shfl(gram[k], (lane + k) & 63, 64);      // lane j + k holds G[c + k][c]
+#pragma unroll
+        for (int a = 0; a < C; ++a) {
+            if (a == c + k) grow[a] = up;
+            if (k > 0 && a == c - k) grow[a] = gram[k];
+        }
+    });
 #pragma unroll
     for (int d = 0; d < NS; ++d) { mk[d] += __shfl_xor(mk[d], 16, 64); mk[d] += __shfl_xor(mk[d], 32, 64); }
     if (g == 0 && qok && cok) {
@@ -398,7 +418,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
             if (d < n) Mk[((size_t)q * n + d) * C + c] = M0[c * n + d] + mk[d];
 #pragma unroll
         for (int a = 0; a < C; ++a) {
-            T v = s2 * Bm[c * C + a] - gram[a];
+            T v = s2 * Bm[c * C + a] - grow[a];
             if (a == c && jitter2 != nullptr) v += jitter2[(size_t)q * C + c];
             Bk[((size_t)q * C + c) * C + a] = v;
         }
@@ -430,10 +450,10 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_);
     // Queries per wave (4, or 5 when C = 3) and waves per SIMD (1, or 2 in fp32): the launch runs in rounds of 4 (8) waves
     // per CU and a round costs the same however full it is, so the cheapest of the four combinations by
-    //   rounds x (time of one round relative to the four-query one-wave form: 1.0 | 1.1 with five queries, x 1.7 at two waves per SIMD)
-    // (measured, N = 512, us per round: fp32 48 / 53 / 82 / 92, fp64 85 / 92): five queries per wave pay when they save a round --
-    // 5120 queries: fp32 0.053 ms (76 TFLOP/s) against 0.082, fp64 0.093 (43 TFLOP/s) against 0.170; 20480: fp32 0.187 against
-    // 0.245 -- and lose a tenth when they do not (16384: fp32 0.185 against 0.164).
+    //   rounds x (time of one round relative to the four-query one-wave form: 1.0 | 1.05 with five queries, x 1.7 at two waves per SIMD)
+    // (measured, N = 512, us per round: fp32 48 / 50 / 82 / 86, fp64 84 / 88): five queries per wave pay when they save a round --
+    // 5120 queries: fp32 0.050 ms (80 TFLOP/s) against 0.082, fp64 0.088 (46 TFLOP/s) against 0.168; 20480: fp32 0.171 against
+    // 0.245 -- and lose a twentieth when they do not.
     static const int qw_force = [] { const char* e = getenv("BCBF_PSR_QW"); return e ? atoi(e) : 0; }();      // (development)
     const bool can5 = C == 3 && BCBF_PSR_QW5, can2 = sizeof(T) == 4 && BCBF_PSR_OCC2 && lds <= 64 * 1024;
     bool five = false, two = false;
@@ -442,7 +462,7 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
         for (int t = 0; t <= (can2 ? 1 : 0); ++t) {
             if (qw_force && (qw_force == 5) != (f == 1) && can5) continue;
             const long w = f ? (nq + 4) / 5 : (nq + 3) / 4, slots = (long)(t ? 8 : 4) * cus;
-            const double cost = (double)((w + slots - 1) / slots) * (f ? 1.1 : 1.0) * (t ? 1.7 : 1.0);
+            const double cost = (double)((w + slots - 1) / slots) * (f ? 1.05 : 1.0) * (t ? 1.7 : 1.0);
             if (cost < best) { best = cost; five = f; two = t; }
         }
     const int waves = five ? (nq + 4) / 5 : (nq + 3) / 4;
