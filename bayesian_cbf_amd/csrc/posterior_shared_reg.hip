@@ -138,10 +138,11 @@ template <int CTRL> __device__ inline double dpp_bc(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
-// QW: queries per wave -- 4 (one per lane quad, 4 columns each: component 3 of the unicycle's C = 3 is a zero column) or,
-// for C = 3 only, 5 (three adjacent columns each, column 15 idle): 15 of the 16 MFMA columns carry a query instead of 12.
-// Chosen by the launcher when the queries no longer fit one wave per SIMD at QW = 4 (a fifth fewer waves for the same
-// queries; with one round of waves either way the quads' cheaper broadcasts win).
+// QW: queries per wave -- 4 (one per lane quad, 4 columns each: component 3 of the unicycle's C = 3 is a zero column, two of
+// the pendulum's C = 2) or the dense packing, C adjacent columns per query: 5 queries for C = 3 (column 15 idle: 15 of the 16
+// MFMA columns carry a query instead of 12), 8 for C = 2 (16 instead of 8).  Chosen by the launcher when the queries no longer
+// fit one wave per SIMD at QW = 4 (a fifth / half fewer waves for the same queries; with one round of waves either way the
+// quads' cheaper broadcasts win).
 template <typename T, int C, int NS, int OCC, int QW = 4>
 __global__ void __launch_bounds__(256, OCC)
 posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
@@ -152,7 +153,8 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     using P = PSR<T>;
     using acc_t = typename P::acc_t;
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
-    static_assert(QW == 4 || (QW == 5 && C == 3), "five queries per wave: three columns each");
+    static_assert(QW == 4 || (QW == 5 && C == 3) || (QW == 8 && C == 2), "dense packing: C adjacent columns per query");
+    constexpr int STR = QW == 4 ? 4 : C;               // columns from one query to the next
     constexpr int REGBLK = P::REGBLK, SLABBLK = PSR_MAXBLK - 1 - REGBLK;
     constexpr int TILE = NB * NB;                      // elements per tile buffer
     extern __shared__ double smem_psr[];
@@ -171,8 +173,8 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     for (int i = threadIdx.x; i < Np * C; i += blockDim.x) Us[i] = i < N * C ? UHB[i] : T(0);
 
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    const int ql = QW == 4 ? j >> 2 : j / 3, c = QW == 4 ? j & 3 : j - 3 * (j / 3);   // query slot in the wave, component
-    const bool slot = QW == 4 || j < 15;               // (QW = 5: column 15 belongs to no query)
+    const int ql = j / STR, c = j - STR * ql;          // query slot in the wave, component
+    const bool slot = j < QW * STR;                    // (QW = 5: column 15 belongs to no query)
     const int q = (blockIdx.x * 4 + wave) * QW + ql;
     const bool qok = slot && q < nq, cok = slot && c < C;   // (a wave past the end still stages tiles and meets the barriers)
     // value of the lane holding component A of this lane's query: a quad broadcast (QW = 4); among three adjacent lanes
@@ -180,6 +182,10 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     auto gb = [&](auto ac, T v) -> T {
         constexpr int A = decltype(ac)::value;
         if constexpr (QW == 4) return dpp_bc<0x55 * A>(v);
+        else if constexpr (STR == 2) {
+            if constexpr (A == 0) { const T m1 = dpp_bc<0x111>(v); return c == 0 ? v : m1; }
+            else { const T p1 = dpp_bc<0x101>(v); return c == 0 ? p1 : v; }
+        }
         else if constexpr (A == 0) { const T m1 = dpp_bc<0x111>(v), m2 = dpp_bc<0x112>(v); return c == 0 ? v : (c == 1 ? m1 : m2); }
         else if constexpr (A == 1) { const T p1 = dpp_bc<0x101>(v), m1 = dpp_bc<0x111>(v); return c == 0 ? p1 : (c == 1 ? v : m1); }
         else { const T p2 = dpp_bc<0x102>(v), p1 = dpp_bc<0x101>(v); return c == 0 ? p2 : (c == 1 ? p1 : v); }
@@ -283,12 +289,13 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     T phi[8];
     auto phi_tile = [&](auto Ic_) {
         constexpr int I = decltype(Ic_)::value;
-        if constexpr (QW == 5) {
-            // lane c evaluates the rows of registers c, c + 3, c + 6 (the last one clamped: register 7 twice)
-            T km[3];
+        if constexpr (QW != 4) {
+            // lane c evaluates the rows of registers c, c + STR, c + 2 STR, ... (the last one clamped: register 7 twice)
+            constexpr int NE = (8 + STR - 1) / STR;
+            T km[NE];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int e = min(c + 3 * i, 7);
+            for (int i = 0; i < NE; ++i) {
+                const int e = min(c + STR * i, 7);
                 const int row_m = I * NB + P::colstep(e) + P::LANECOL * g;
                 T d2 = T(0);
 #pragma unroll
@@ -297,7 +304,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
             }
             static_for<0, 8>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
-                phi[e] = gb(Ic<e % 3>{}, km[e / 3]) * Us[(I * NB + P::colstep(e) + P::LANECOL * g) * C + cc] * cmask;
+                phi[e] = gb(Ic<e % STR>{}, km[e / STR]) * Us[(I * NB + P::colstep(e) + P::LANECOL * g) * C + cc] * cmask;
             });
             return;
         }
@@ -455,22 +462,23 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
     // 5120 queries: fp32 0.050 ms (80 TFLOP/s) against 0.082, fp64 0.088 (46 TFLOP/s) against 0.168; 20480: fp32 0.171 against
     // 0.245 -- and lose a twentieth when they do not.
     static const int qw_force = [] { const char* e = getenv("BCBF_PSR_QW"); return e ? atoi(e) : 0; }();      // (development)
-    const bool can5 = C == 3 && BCBF_PSR_QW5, can2 = sizeof(T) == 4 && BCBF_PSR_OCC2 && lds <= 64 * 1024;
+    constexpr int QWD = C == 3 ? 5 : C == 2 ? 8 : 4;   // queries per wave of the dense packing
+    const bool can5 = QWD != 4 && BCBF_PSR_QW5, can2 = sizeof(T) == 4 && BCBF_PSR_OCC2 && lds <= 64 * 1024;
     bool five = false, two = false;
     double best = 1e30;
     for (int f = 0; f <= (can5 ? 1 : 0); ++f)
         for (int t = 0; t <= (can2 ? 1 : 0); ++t) {
-            if (qw_force && (qw_force == 5) != (f == 1) && can5) continue;
-            const long w = f ? (nq + 4) / 5 : (nq + 3) / 4, slots = (long)(t ? 8 : 4) * cus;
+            if (qw_force && (qw_force != 4) != (f == 1) && can5) continue;
+            const long w = f ? (nq + QWD - 1) / QWD : (nq + 3) / 4, slots = (long)(t ? 8 : 4) * cus;
             const double cost = (double)((w + slots - 1) / slots) * (f ? 1.05 : 1.0) * (t ? 1.7 : 1.0);
             if (cost < best) { best = cost; five = f; two = t; }
         }
-    const int waves = five ? (nq + 4) / 5 : (nq + 3) / 4;
+    const int waves = five ? (nq + QWD - 1) / QWD : (nq + 3) / 4;
     const dim3 grid((waves + 3) / 4);                  // 256 threads per workgroup, four waves
     auto go5 = [&](auto occ, auto qw) {
         constexpr int OCC = decltype(occ)::value, QW = decltype(qw)::value;
         static int opt_in[2][64] = {{0}};           // largest dynamic LDS size opted into, per device
-        int& lds_opt_in = opt_in[QW == 5][dev_ & 63];
+        int& lds_opt_in = opt_in[QW != 4][dev_ & 63];
         if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
             (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, OCC, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             lds_opt_in = (int)lds;
@@ -479,7 +487,7 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
                            xq, jitter2, Mk, Bk, W, nq, N, Np, n);
     };
     auto go = [&](auto occ) {
-        if constexpr (C == 3 && BCBF_PSR_QW5) { if (five) { go5(occ, Ic<5>{}); return; } }
+        if constexpr (QWD != 4 && BCBF_PSR_QW5) { if (five) { go5(occ, Ic<QWD>{}); return; } }
         go5(occ, Ic<4>{});
     };
     if constexpr (sizeof(T) == 4 && BCBF_PSR_OCC2) {

@@ -633,16 +633,18 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
     rel_close(host(Bk2), Bk_o, 1e-9 if f64 else 1e-3, scale=prior, what="Bk(query)")
 
 
-@pytest.mark.parametrize("N,n,dtype,mult", [(512, 3, torch.float32, 16), (480, 4, torch.float64, 16), (100, 2, torch.float64, 16),
-                                            (512, 3, torch.float64, 16), (288, 4, torch.float32, 16), (512, 3, torch.float32, 32),
-                                            (200, 2, torch.float32, 32), (320, 3, torch.float64, 32)])
-def test_shared_gp_five_queries_per_wave_form(ops, N, n, dtype, mult):
-    """m = 2 (three columns per query), more queries than one wave per SIMD holds at four per wave: the launcher packs FIVE
-    queries into the 16 matrix-core columns of a wave (posterior_shared_reg.hip, QW = 5) when that saves a round of waves:
+@pytest.mark.parametrize("N,n,dtype,mult,m", [(512, 3, torch.float32, 16, 2), (480, 4, torch.float64, 16, 2), (100, 2, torch.float64, 16, 2),
+                                              (512, 3, torch.float64, 16, 2), (288, 4, torch.float32, 16, 2), (512, 3, torch.float32, 32, 2),
+                                              (200, 2, torch.float32, 32, 2), (320, 3, torch.float64, 32, 2),
+                                              (128, 2, torch.float32, 16, 1), (512, 2, torch.float64, 16, 1), (320, 3, torch.float32, 32, 1),
+                                              (96, 1, torch.float64, 32, 1)])
+def test_shared_gp_five_queries_per_wave_form(ops, N, n, dtype, mult, m):
+    """m = 2 / m = 1 (three / two columns per query), more queries than one wave per SIMD holds at four per wave: the launcher packs
+    FIVE / EIGHT queries into the 16 matrix-core columns of a wave (posterior_shared_reg.hip, QW = 5 / 8) when that saves a round of waves:
     mult = 16: one wave per SIMD; 32: fp32 two waves per SIMD, fp64 two rounds.  Against the fp64 oracle on a sample of the queries, and against the same batch cut into pieces that take the
     four-per-wave form (same arithmetic per query: only the lane a value sits in differs)."""
     from bayesian_cbf_amd.synthetic import make_instances
-    f64, m = dtype == torch.float64, 2
+    f64 = dtype == torch.float64
     p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=41 + N)
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     assert int(info[0]) == 0
@@ -657,7 +659,10 @@ def test_shared_gp_five_queries_per_wave_form(ops, N, n, dtype, mult):
     for a in range(0, b, 1024):
         Mk1, Bk1, W1 = ops.posterior_shared(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq[a:a + 1024].contiguous(),
                                             j2[a:a + 1024].contiguous(), want_W=True)
-        tol = 1e-13 if f64 else 1e-6
+        tol = 1e-10 if f64 else 2e-4          # (the two forms are separate instantiations: a multiply-add contracted in one and not
+                                              #  in the other moves a kernel value by an ulp, and the triangular solve amplifies it by
+                                              #  the factor's condition number -- fp32, n = 2: 1e-5 at N = 128; both forms then sit
+                                              #  equally far from the fp64 answer)
         rel_close(host(Mk[a:a + 1024]), host(Mk1), tol, scale=max(1.0, float(Mk1.abs().max())), what="Mk")
         rel_close(host(Bk[a:a + 1024]), host(Bk1), tol, scale=scale, what="Bk")
         rel_close(host(W[a:a + 1024]), host(W1), tol, scale=max(1e-3, float(W1.abs().max())), what="W")
