@@ -1098,6 +1098,31 @@ def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt,
         rel_close(host(Bk)[i], Bk_o[0], 1e-8 if f64 else 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
 
 
+@pytest.mark.parametrize("dtype,N,n,m", [(torch.float64, 1024, 3, 2), (torch.float64, 1100, 2, 1), (torch.float32, 512, 3, 2),
+                                         (torch.float32, 1000, 4, 3), (torch.float32, 576, 3, 1)], ids=["f64-1024", "f64-1100", "f32-512", "f32-1000", "f32-576"])
+def test_refit_super_panel_form_equals_plain_form(ops, dtype, N, n, m, monkeypatch):
+    """One-wave refit: the 64-column super-panel instantiation (2 x 2 tiles per stream pass, lean value pass, in-register second
+    update) against the plain instantiation of the same kernel on the same inputs, entry by entry -- incl. a ragged last block
+    and an odd number of block columns -- and per-instance failure index.  (The super-panel fp64 instantiation sits at 256 + 256
+    registers plus scratch; this is the check that caught a build of it whose last diagonal tile lost its jitter.)"""
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64 = dtype == torch.float64
+    p = make_instances(6, N, n, m, dtype=dtype, device=DEV, seed=900 + N)
+    args = (p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
+    key = "BCBF_RW64_SUPER_FORCE" if f64 else "BCBF_RW32_SUPER_FORCE"
+    monkeypatch.setenv(key, "1")
+    Lop_s, UHB_s, info_s, _ = ops.refit(*args)
+    monkeypatch.setenv(key, "0")
+    Lop_p, UHB_p, info_p, _ = ops.refit(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(info_s, info_p) and int((info_s == 0).sum()) >= 4     # (a system that fp32 cannot factor fails in both forms alike)
+    assert torch.equal(UHB_s, UHB_p)
+    for i in torch.nonzero(info_s == 0).flatten().tolist():
+        # (fp64: both forms accumulate the same products in a different order; fp32: cond x eps, as between the other forms)
+        rel_close(host(Lop_s[i]), host(Lop_p[i]), 1e-9 if f64 else 5e-3, what="super-panel vs plain form [%d]" % i)
+
+
 @pytest.mark.timeout(180)
 def test_refit_handoff_protocols_soak(ops, monkeypatch):
     """The chain / bulk refit kernels hand work over through spin waits on LDS counters; a lost wake-up would be a hang.
