@@ -1121,6 +1121,18 @@ def test_refit_super_panel_form_equals_plain_form(ops, dtype, N, n, m, monkeypat
     for i in torch.nonzero(info_s == 0).flatten().tolist():
         # (fp64: both forms accumulate the same products in a different order; fp32: cond x eps, as between the other forms)
         rel_close(host(Lop_s[i]), host(Lop_p[i]), 1e-9 if f64 else 5e-3, what="super-panel vs plain form [%d]" % i)
+    if not f64:
+        # fp32 again with a jitter of order 1 on the diagonal: K_b is then well conditioned, the two forms agree to rounding, and
+        # a jitter entry that went missing or to the wrong row would stand out
+        big = (p["jitter"] * 5e4).contiguous()
+        monkeypatch.setenv(key, "1")
+        Lb_s, _, ib_s, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], big)
+        monkeypatch.setenv(key, "0")
+        Lb_p, _, ib_p, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], big)
+        torch.cuda.synchronize()
+        assert int((ib_s != 0).sum()) == 0 and int((ib_p != 0).sum()) == 0
+        for i in range(6):
+            rel_close(host(Lb_s[i]), host(Lb_p[i]), 2e-5, what="super-panel vs plain form, large jitter [%d]" % i)
 
 
 @pytest.mark.timeout(180)
