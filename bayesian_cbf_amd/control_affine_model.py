@@ -618,13 +618,14 @@ class ControlAffineRegressor:
         return st, Mk, Bk, W
 
     def _prior_knl(self, X1, X2):
-        m = self.model
+        hp = self._hyper()                           # (length scales / output scale as cached per parameter version)
+        ell, s2 = hp["ell"].reshape(1, 1, -1), hp["s2"].reshape(())
         with torch.no_grad():
-            d = (X1[:, None, :] - X2[None, :, :]) / m.lengthscale.detach().reshape(1, 1, -1)
+            d = (X1[:, None, :] - X2[None, :, :]) / ell
             if self.data_kernel == "matern52":
                 a = torch.sqrt(5.0 * (d * d).sum(-1))
-                return m.outputscale.detach() * (1.0 + a + a * a / 3.0) * torch.exp(-a)
-            return m.outputscale.detach() * torch.exp(-0.5 * (d * d).sum(-1))
+                return s2 * (1.0 + a + a * a / 3.0) * torch.exp(-a)
+            return s2 * torch.exp(-0.5 * (d * d).sum(-1))
 
     def custom_predict(self, Xtest_in, Utest_in=None, UHfill=1, Xtestp_in=None, Utestp_in=None, UHfillp=1,
                        compute_cov=True, grad_gp=False, grad_check=False, scalar_var_only=False):
@@ -778,7 +779,8 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
         """(mean_k[b,n,1+m], A[n,n], BkXX[b,b',1+m,1+m]) incl. the second make_psd jitter (:1089)."""
         Xtest = self._ensure_device_dtype(Xtest_in)
         Xtestp = self._ensure_device_dtype(Xtestp_in) if Xtestp_in is not None else Xtest
-        A, B = self.model.A.detach(), self.model.B.detach()
+        hp = self._hyper()                           # (A, B as cached per parameter version: the same tensors the device path takes)
+        A, B = hp["A"][0], hp["Bm"][0]
         b, bp, C = Xtest.shape[0], Xtestp.shape[0], 1 + self.u_dim
         if self.Xtrain is None:
             mean = self.model.M0.detach().t()[None].expand(b, -1, -1)
