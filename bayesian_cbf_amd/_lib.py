@@ -56,6 +56,7 @@ _TSIGS = {
     "bcbf_mll_grad_matern52": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],
     "bcbf_gp_append_matern52": [P] * 17 + [c_int, c_int, c_int, c_int, P],
     "bcbf_clean_hessian": [P, P, P, c_int, c_int, c_double, c_int, P],
+    "bcbf_predict_assemble": [P] * 10 + [c_int] * 5 + [P],
     "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_socp": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_cbc_socp": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P],

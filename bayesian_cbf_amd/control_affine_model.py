@@ -590,7 +590,9 @@ class ControlAffineRegressor:
 
     def _param_versions(self):
         """(identity, in-place version) of every model parameter: changes when one is written (no device sync)."""
-        return tuple((id(p), p._version) for p in self.model.parameters())
+        m = self.model
+        ps = m._parameters.values() if not m._modules else m.parameters()    # (a flat module: its own dict, no recursive walk)
+        return tuple((id(p), p._version) for p in ps)
 
     def _perturbed_cholesky(self, *a, **k):
         """Dense L = chol(K_b + jitter) (the matrix the reference caches, :379-385), from the cached state."""
@@ -775,8 +777,10 @@ class ControlAffineRegressor:
 class ControlAffineRegressorExact(ControlAffineRegressor):
     """Matrix-variate view (control_affine_model.py:930-1096)."""
 
-    def _custom_predict_matrix(self, Xtest_in, Xtestp_in=None, compute_cov=True):
-        """(mean_k[b,n,1+m], A[n,n], BkXX[b,b',1+m,1+m]) incl. the second make_psd jitter (:1089)."""
+    def _custom_predict_matrix(self, Xtest_in, Xtestp_in=None, compute_cov=True, fused_kron=False):
+        """(mean_k[b,n,1+m], A[n,n], BkXX[b,b',1+m,1+m]) incl. the second make_psd jitter (:1089).  fused_kron (the caller is
+        `custom_predict_fullmat`): the third entry is kron(Bk2, A) [b(1+m)n, b'(1+m)n] instead, when the set is large enough
+        for the one-launch assembly -- the caller tells the two by the rank."""
         Xtest = self._ensure_device_dtype(Xtest_in)
         Xtestp = self._ensure_device_dtype(Xtestp_in) if Xtestp_in is not None else Xtest
         hp = self._hyper()                           # (A, B as cached per parameter version: the same tensors the device path takes)
@@ -793,6 +797,22 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
                 return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov)
             return Mk, A, Xtest.new_zeros(b, bp, C, C)
         Wp = W if Xtestp_in is None else self._query(Xtestp, want_W=True, defer=True)[3]
+        if fused_kron and b == bp and b * C > 32:
+            # query sets beyond one 32 x 32 tile (the first make_psd draw is kept unchecked there, see below): prior kernel, the
+            # subtraction of W'W and the Kronecker product with A in ONE launch (bcbf_predict_assemble) instead of ~20, queued behind the query
+            # without waiting for the factorisation; the jitter diagonal follows once the pending level is known (the draw is
+            # the next use of the random stream after it)
+            G = torch.einsum("bnc,pnd->bpcd", W, Wp).contiguous()
+            _, kron = ops.predict_assemble(G, Xtest.contiguous(), Xtestp.contiguous(), hp["ell"].reshape(-1), hp["s2"],
+                                           B.contiguous(), A.contiguous(), None, want_BkXX=False, want_kron=True,
+                                           kernel=self.data_kernel)
+            if not self._resolve_pending(st):
+                return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov, fused_kron)
+            jit = 1e-5 * self.rand_fn(b * C)
+            n = A.shape[0]
+            blocks = kron.view(b * C, n, b * C, n).diagonal(dim1=0, dim2=2)        # [n, n, b C]: the diagonal n x n blocks (a view)
+            blocks += A[:, :, None] * jit[None, None, :]
+            return Mk, A, kron
         BkXX = (self._prior_knl(Xtest, Xtestp)[:, :, None, None] * B
                 - torch.einsum("bnc,pnd->bpcd", W, Wp))
         if not self._resolve_pending(st):                 # all speculative levels failed (rare): start over on the rebuilt state
@@ -839,8 +859,10 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
 
     def custom_predict_fullmat(self, Xtest_in, Xtestp_in=None):
         """(vec(M_k)[b(1+m)n], kron(B_k, A)[b(1+m)n, b(1+m)n])  (:963-980)."""
-        meanFX, A, BkXX = self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov=True)
+        meanFX, A, BkXX = self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov=True, fused_kron=True)
         b, n, C = meanFX.shape
+        if BkXX.dim() == 2:                                # (assembled on the device: bcbf_predict_assemble)
+            return meanFX.transpose(-2, -1).reshape(-1), BkXX
         Bk2 = BkXX.transpose(2, 1).reshape(b * C, b * C)
         return meanFX.transpose(-2, -1).reshape(-1), torch_kron(Bk2, A)
 

@@ -476,6 +476,30 @@ def posterior_jets(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, shared=False, want_W=Fa
     return (Mk, Bk, G, Mj, Wj) if want_W else (Mk, Bk, G, Mj)
 
 
+def predict_assemble(G, Xq, Xqp, ell, s2, Bm, A=None, jitter=None, want_BkXX=True, want_kron=False, kernel="rbf"):
+    """Predictive covariance of a query set against ONE GP in one launch, from the Gram G[b, b', 1+m, 1+m] = W_b' W'_b' of its
+    whitened cross-covariances (`posterior_query(..., want_W=True)`; `torch.einsum("bnc,pnd->bpcd", W, Wp)`):
+    BkXX[b, b', 1+m, 1+m] = k(x_b, x'_b') Bm - G (+ `jitter`[b (1+m)] on its diagonal: make_psd, control_affine_model.py:1089)
+    and / or kron(Bk2, A) [b (1+m) n, b' (1+m) n] (`custom_predict_fullmat`, :963-980).
+    Xq[b, n], Xqp[b', n], ell[n], s2[1], Bm[1+m, 1+m], A[n, n]."""
+    _chk(G, Xq, Xqp, ell, s2, Bm, A, jitter)
+    if kernel not in DATA_KERNELS:
+        raise ValueError("kernel %r: one of %s" % (kernel, DATA_KERNELS))
+    b, bp, C, _ = G.shape
+    n = Xq.shape[1]
+    if G.shape[3] != C or Xq.shape[0] != b or Xqp.shape[0] != bp or Xqp.shape[1] != n:
+        raise ValueError("predict_assemble: inconsistent shapes")
+    if want_kron and A is None:
+        raise ValueError("predict_assemble: the Kronecker product needs A")
+    BkXX = torch.empty(b, bp, C, C, dtype=G.dtype, device=G.device) if want_BkXX else None
+    Kron = torch.empty(b * C * n, bp * C * n, dtype=G.dtype, device=G.device) if want_kron else None
+    check(getattr(lib, "bcbf_predict_assemble" + _suf(G))(
+        _p(G), _p(Xq), _p(Xqp), _p(ell), _p(s2), _p(Bm), _p(A) if A is not None else None,
+        _p(jitter) if jitter is not None else None, _p(BkXX) if want_BkXX else None, _p(Kron) if want_kron else None,
+        b, bp, n, C - 1, DATA_KERNELS.index(kernel), _stream(G)), "bcbf_predict_assemble")
+    return BkXX, Kron
+
+
 HESSIAN_MODES = {"reference": 0, "project": 1}
 
 

@@ -348,6 +348,23 @@ int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double*
                               const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                               int Bt, int N, int n, int m, void* stream);
 
+/* Full predictive covariance of a query SET against one GP in one launch, from the Gram G[b, b', 1+m, 1+m] = W_b' Wp_b' of the
+ * whitened cross-covariances of its points (W = L^-1 Phi: the W output of bcbf_posterior_query / _shared; the Gram is a plain
+ * GEMM on the caller's side):
+ *   BkXX[b, b', 1+m, 1+m] = k(x_b, x'_b') Bm - G[b, b']   (+ jitter[b (1+m) + c] on the entries b = b', c = d: the make_psd
+ *                           draw of the reference, control_affine_model.py:1089; jitter may be NULL and needs b == b')
+ *   Kron[b (1+m) n, b' (1+m) n] = kron(Bk2, A), Bk2 = BkXX with the axes ordered (b, c, b', d)   (torch_kron(Bk2, A), :978)
+ * Either output may be NULL.  Xq[b, n], Xqp[bp, n] the test points, ell[n], s2[1], Bm[(1+m)^2], A[n^2] of the one model;
+ * kernel_kind 0 = RBF, 1 = the opt-in Matern-5/2.  Replaces the tail of ControlAffineRegressorExact._custom_predict_matrix
+ * and custom_predict_fullmat (control_affine_model.py:1051-1091, 963-980: k_b(X*, X*) B - v'v, make_psd, the Kronecker
+ * product -- ~20 torch launches on the host path of the published speed test, pendulum.py:1367-1372). */
+int bcbf_predict_assemble_f32(const float* G, const float* Xq, const float* Xqp, const float* ell, const float* s2,
+                              const float* Bm, const float* A, const float* jitter, float* BkXX, float* Kron, int b, int bp,
+                              int n, int m, int kernel_kind, void* stream);
+int bcbf_predict_assemble_f64(const double* G, const double* Xq, const double* Xqp, const double* ell, const double* s2,
+                              const double* Bm, const double* A, const double* jitter, double* BkXX, double* Kron, int b, int bp,
+                              int n, int m, int kernel_kind, void* stream);
+
 /* Posterior jets: value and first x-derivatives of the posterior factors (one query per instance, or per
  * query of a shared GP).  CT = (1+m)(1+n) right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] of the same stream:
  *   G[Bt,CT,CT] = Wj'Wj,  Mj[Bt,n,CT] = Vw'Wj   (Mk = M0' + Mj[:, :C]; dMk/dx_d = Mj[:, (1+d)C:(2+d)C]),

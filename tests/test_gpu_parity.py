@@ -633,6 +633,48 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
     rel_close(host(Bk2), Bk_o, 1e-9 if f64 else 1e-3, scale=prior, what="Bk(query)")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("N,n,m,b,bp,kernel", [(100, 2, 1, 37, 37, "rbf"), (64, 3, 2, 50, 21, "rbf"), (33, 4, 3, 16, 16, "rbf"),
+                                               (130, 2, 1, 5, 70, "rbf"), (96, 3, 2, 40, 40, "matern52")])
+def test_predict_assemble_vs_oracle_formula(ops, dtype, N, n, m, b, bp, kernel):
+    """bcbf_predict_assemble (the one-launch tail of _custom_predict_matrix / custom_predict_fullmat, control_affine_model.py:
+    1051-1091, 963-980): from the Gram G = W'W', BkXX = k(X*, X*') B - G (+ the make_psd jitter on its diagonal when b == b') and kron(Bk2, A),
+    against the oracle's statements of the same lines evaluated in fp64 on the device's own W (ragged tiles, b != b', every
+    (n, m) extreme, both data kernels)."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64 = dtype == torch.float64
+    p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=70 + N)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"], kernel=kernel)
+    assert int(info[0]) == 0
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"])
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda k: (p["X"][0, torch.randint(0, N, (k,), generator=g).to(DEV)] + 0.3 * torch.randn(k, n, generator=g).to(DEV, dtype)).contiguous()
+    Xq, Xqp = mk(b), mk(bp)
+    if b == bp:
+        Xqp = Xq
+    q = lambda x: ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], x, shared=True, want_W=True, kernel=kernel)[2]
+    W, Wp = q(Xq), q(Xqp)
+    jit = (1e-5 * torch.rand(b * (m + 1), generator=g)).to(DEV, dtype) if b == bp else None
+    A = p["A"][0].contiguous()
+    G = torch.einsum("bnc,pnd->bpcd", W[:, :N], Wp[:, :N]).contiguous()
+    BkXX, Kron = ops.predict_assemble(G, Xq, Xqp, p["ell"][0].contiguous(), p["s2"], p["Bm"][0].contiguous(), A, jit,
+                                      want_BkXX=True, want_kron=True, kernel=kernel)
+    h = lambda t: host(t).astype(np.float64)
+    knl = ogp.matern52_ard_kernel if kernel == "matern52" else ogp.rbf_ard_kernel
+    KB = knl(h(Xq), h(Xqp), h(p["ell"][0]), float(p["s2"][0]))[:, :, None, None] * h(p["Bm"][0])[None, None]
+    ref = KB - np.einsum("bic,pid->bpcd", h(W)[:, :N], h(Wp)[:, :N])                    # (:1079-1088 on the device's W)
+    if jit is not None:
+        C = m + 1
+        for i in range(b):
+            ref[i, i] += np.diag(h(jit).reshape(b, C)[i])                                # (:1089, first draw)
+    scale = float(p["s2"][0]) * float(p["Bm"][0].abs().max())
+    rel_close(h(BkXX), ref, 1e-12 if f64 else 2e-5, scale=scale, what="BkXX")
+    Bk2 = ref.transpose(0, 2, 1, 3).reshape(b * (m + 1), bp * (m + 1))                    # (:975)
+    rel_close(h(Kron), np.kron(Bk2, h(A)), 1e-12 if f64 else 2e-5, scale=scale * float(A.abs().max()), what="kron(Bk2, A)")
+    only, _ = ops.predict_assemble(G, Xq, Xqp, p["ell"][0].contiguous(), p["s2"], p["Bm"][0].contiguous(), None, jit, kernel=kernel)
+    assert torch.equal(only, BkXX)
+
+
 @pytest.mark.parametrize("N,n,dtype,mult,m", [(512, 3, torch.float32, 16, 2), (480, 4, torch.float64, 16, 2), (100, 2, torch.float64, 16, 2),
                                               (512, 3, torch.float64, 16, 2), (288, 4, torch.float32, 16, 2), (512, 3, torch.float32, 32, 2),
                                               (200, 2, torch.float32, 32, 2), (320, 3, torch.float64, 32, 2),
