@@ -68,7 +68,8 @@ using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
                                  // left of a super-panel to pay for the wider working set: off below N = 512
 #endif
 #ifndef BCBF_RW32_SUPER_KS
-#define BCBF_RW32_SUPER_KS 4     // k-steps per pipeline stage of the four-stream pass (1 / 2 / 4 / 8 measured: 4 and 8 level, 1 loses 30 %)
+#define BCBF_RW32_SUPER_KS 4     // k-steps per pipeline stage of the four-stream pass at two waves per SIMD (2: +3 %, 8: +12 % -- registers); at one
+                                 // wave per SIMD the stage is 8 deep (1024 x 512 0.90 -> 0.88 ms, 4096 x 1024 20.0 -> 19.6)
 #endif
 #ifndef BCBF_RW32_SUPER_DIAG3
 #define BCBF_RW32_SUPER_DIAG3 1  // 1: the three tiles of the diagonal 2 x 2 block in one stream pass; 0: the diagonal tile by itself first (measured:
@@ -698,7 +699,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                 };
-                constexpr int KS4 = sizeof(T) == 4 ? BCBF_RW32_SUPER_KS : BCBF_RW64_SUPER_KS;
+                constexpr int KS4 = sizeof(T) == 4 ? (OCC == 1 ? 8 : BCBF_RW32_SUPER_KS) : BCBF_RW64_SUPER_KS;
                 auto negate = [&](acc_t (&acc)[2][2]) { (void)acc; };
                 (void)negate;
                 // -S' += L_a L_b' for k in [k0, k1): one tile, A operand = block row at arow0, B operand = rows of tile I
