@@ -437,6 +437,27 @@ BCBF_HD inline void project_psd(int n, double H[NMAX][NMAX], double w[NMAX], dou
 BCBF_HD inline int clean_hessian(int n, double H[NMAX][NMAX], double eps, int mode) {
     double w[NMAX], Vs[NMAX][NMAX], S[NMAX][NMAX];
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) S[i][j] = 0.5 * (H[i][j] + H[j][i]);
+    {   // The common case first: a symmetric part that is positive definite by a wide margin has no eigenvalue < 0 and the
+        // matrix stays as it is (status 0) -- decided by an unpivoted Cholesky whose pivots all exceed 1e-10 of the trace
+        // (a negative eigenvalue forces a pivot <= 0 up to rounding, 1e-16 of the trace: the margin cannot be bridged), without
+        // the twelve Jacobi sweeps below.  Anything closer to singular than that takes the full path.
+        double L[NMAX][NMAX], tr = 0.0;
+        for (int i = 0; i < n; ++i) tr += fabs(S[i][i]);
+        bool pd = tr > 0.0;
+        for (int j = 0; j < n && pd; ++j) {
+            double d = S[j][j];
+            for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+            if (!(d > 1e-10 * tr)) { pd = false; break; }
+            const double r = 1.0 / sqrt(d);
+            L[j][j] = d * r;
+            for (int i = j + 1; i < n; ++i) {
+                double t = S[i][j];
+                for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+                L[i][j] = t * r;
+            }
+        }
+        if (pd) return 0;
+    }
     project_psd(n, S, w, Vs);                              // eigenvalues of the symmetric part decide which branch runs
     bool neg = false, bad = false;
     for (int i = 0; i < n; ++i) { if (w[i] <= -eps) bad = true; if (w[i] < 0.0) neg = true; }
