@@ -17,6 +17,7 @@ P = c_void_p
 _SIGS = {
     "bcbf_version": (c_int, []),
     "bcbf_last_error": (ctypes.c_char_p, []),
+    "bcbf_hbm_read_probe": (c_int, [P, c_size_t, P, ctypes.POINTER(c_size_t), P]),
     "bcbf_lop_elems_f32": (c_size_t, [c_int]),
     "bcbf_lop_elems_f64": (c_size_t, [c_int]),
     "bcbf_posterior_shared_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),

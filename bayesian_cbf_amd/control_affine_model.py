@@ -182,6 +182,7 @@ class ControlAffineRegressor:
             if v is not None:
                 setattr(self, name, v.to(dtype))
         self.clear_cache()
+        self._derived = dict()       # (module.to() replaces parameter storage without bumping any version counter)
         return self
 
     def double_(self):
@@ -205,11 +206,15 @@ class ControlAffineRegressor:
             raise RuntimeError("bayesian_cbf_amd runs its arithmetic in libbcbf on a ROCm GPU; model device is %s "
                                "and there is no CPU path" % self.device)
 
-    def clear_cache(self):
+    def clear_cache(self, hyper=False):
+        """control_affine_model.py:387-388.  `hyper=True` also drops the host-side constants derived from the parameters
+        (needed only after a write the version counters cannot see, see `_param_versions`)."""
         st = self._cache.get("state") if isinstance(getattr(self, "_cache", None), dict) else None
         if st is not None and "_pending" in st:
             self._resolve_pending(st)             # (the random stream is put where the sequential protocol leaves it)
         self._cache = dict()
+        if hyper:
+            self._derived = dict()
 
     def get_kernel_param(self, name):
         """control_affine_model.py:876-888."""
@@ -589,10 +594,13 @@ class ControlAffineRegressor:
         return st
 
     def _param_versions(self):
-        """(identity, in-place version) of every model parameter: changes when one is written (no device sync)."""
+        """(identity, in-place version, storage, dtype, device) of every model parameter: changes when one is written in
+        place, re-pointed (`p.data = ...`) or cast / moved by `module.to()` (no device sync).  An in-place write THROUGH
+        `p.data` (`p.data.copy_(...)`) bumps no counter torch exposes; the reference never does that -- call
+        `clear_cache(hyper=True)` after one."""
         m = self.model
         ps = m._parameters.values() if not m._modules else m.parameters()    # (a flat module: its own dict, no recursive walk)
-        return tuple((id(p), p._version) for p in ps)
+        return tuple((id(p), p._version, p.data_ptr(), p.dtype, p.device) for p in ps)
 
     def _perturbed_cholesky(self, *a, **k):
         """Dense L = chol(K_b + jitter) (the matrix the reference caches, :379-385), from the cached state."""

@@ -46,6 +46,28 @@ def lop_elems(N, dtype):
     return int(getattr(lib, "bcbf_lop_elems" + _SUF[dtype])(N))
 
 
+def hbm_read_probe(buf, launches=10, warm=2):
+    """Measured read-only HBM ceiling of this device in GB/s over the caller's (large, resident) buffer `buf`:
+    `launches` timed launches of `bcbf_hbm_read_probe` (16-byte non-temporal loads, nothing written), each between its own
+    pair of HIP events on the current stream.  Returns dict(best_gbs, mean_gbs, bytes, launches)."""
+    if not buf.is_cuda or not buf.is_contiguous():
+        raise RuntimeError("hbm_read_probe needs a contiguous device buffer")
+    nbytes = buf.numel() * buf.element_size()
+    sink = torch.zeros(256, dtype=torch.float32, device=buf.device)
+    got = ctypes.c_size_t(0)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for _ in range(warm):
+        check(lib.bcbf_hbm_read_probe(_p(buf), nbytes, _p(sink), ctypes.byref(got), _stream(buf)), "bcbf_hbm_read_probe")
+    for e0, e1 in evs:
+        e0.record()
+        check(lib.bcbf_hbm_read_probe(_p(buf), nbytes, _p(sink), ctypes.byref(got), _stream(buf)), "bcbf_hbm_read_probe")
+        e1.record()
+    torch.cuda.synchronize(buf.device)
+    ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    return dict(best_gbs=got.value / (min(ms) * 1e-3) / 1e9, mean_gbs=got.value / (sum(ms) / len(ms) * 1e-3) / 1e9,
+                bytes=int(got.value), launches=launches)
+
+
 DATA_KERNELS = ("rbf", "matern52")
 
 

@@ -122,6 +122,13 @@ def monte_carlo_safety_rollouts(Bt, numSteps=200, dt=0.05, gp=None, kernel_diag_
     return dict(stats=stats, x_final=x, min_h=min_h, dist_to_goal=dist_to_goal, traj=traj, loop_seconds=t_loop)
 
 
+def online_pass_bytes(N, n, m, itemsize):
+    """Algorithmic HBM bytes of ONE instance's append (+ control query) pass at N live points: the packed factor
+    N(N+1)/2, the whitened targets and inputs N n each, the UH B rows N (1+m) -- read once -- and what the append writes:
+    the new factor row (N + 1), one row of Vw / X / UH B."""
+    return itemsize * (N * (N + 1) // 2 + 2 * N * n + N * (1 + m) + (N + 1) + 2 * n + (1 + m))
+
+
 def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True,
                      reserved=True, fused=True, window=None):
     """BASELINE configs[4]: every instance starts from an N0-point GP and takes one observation per control step
@@ -200,8 +207,22 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
         isz = p["X"].element_size()
         if with_control and reserved and fused:
             t_step, t_app = t_app, t_step              # (events: [0,1] = posterior + append, [1,2] = solve)
-        segs.append(dict(N_from=lo, N_to=hi, control_step_ms=t_step / k, append_ms=t_app / k, step_ms=(t_step + t_app) / k,
-                         append_GBs_algorithmic=Bt * isz * ((lo + hi) / 2) ** 2 / 2 / (t_app / k * 1e-3) / 1e9))
+        seg = dict(N_from=lo, N_to=hi, control_step_ms=t_step / k, append_ms=t_app / k, step_ms=(t_step + t_app) / k,
+                   append_GBs_algorithmic=Bt * isz * ((lo + hi) / 2) ** 2 / 2 / (t_app / k * 1e-3) / 1e9)
+        if reserved and window is None:
+            # roofline of the pass that dominates an append (+ the control query riding on it): every instance's packed factor,
+            # whitened targets, inputs and UH B rows read once (SURVEY 8d's per-instance figure at the live N), summed over the
+            # segment's appends; the O(N) bytes an append writes are counted too
+            byt = sum(online_pass_bytes(N, n, m, isz) for N in range(lo, hi)) * Bt
+            passes = 1 if (with_control and fused) or not with_control else 2
+            gbs = byt * passes / (t_app * 1e-3) / 1e9 if passes == 1 else None
+            seg["roofline"] = dict(bound="hbm", kernel="posterior_step_kernel<%s, %d, 4, 0, 1, false, 1> (query columns + the append's column on "
+                                   "one pass) + gp_append_rows" % ("double" if isz == 8 else "float", 1 + m),
+                                   algorithmic_bytes_per_launch=byt / k, achieved=gbs, peak=8000.0, unit="GB/s",
+                                   frac=None if gbs is None else gbs / 8000.0, traffic=None,
+                                   how="sum over the segment's appends of Bt x online_pass_bytes(N) / sum of the HIP-event "
+                                       "intervals around append(+query) [ms = append_ms]")
+        segs.append(seg)
     out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype),
                storage=("reserved (in place)" + (", posterior query and append on one pass" if (fused and with_control) else ""))
                if reserved else "packed (copy per append)",

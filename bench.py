@@ -131,20 +131,85 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(p, task, sample, N, n, m):
-    """The oracle (a numpy / torch-CPU port of the reference's arithmetic, Cholesky factor cached as the reference caches
-    it between refits) timed on this host on a bounded sample of the same workload, three ways:
-    (a) reference style, one instance at a time, one thread; (b) vectorised over the batch, one thread; (c) vectorised,
-    16 threads (more threads are slower, see below).  `value` is the fastest of them, `cores` the threads it used."""
+_CPU_SHARED = {}
+
+
+def _cpu_worker(lo, hi, reps, barrier, queue):
+    """One worker PROCESS of the process-per-core CPU baseline: the reference-style scalar loop (one instance per call,
+    one thread) over its slice of the sample.  Refit (cached upstream) before the barrier, untimed."""
     from threadpoolctl import threadpool_limits
+    from oracle import control_step as ostep, gp_posterior as ogp
+    import torch as _t
+    _t.set_num_threads(1)
+    h = _CPU_SHARED["h"]
+    with threadpool_limits(limits=1):
+        states = [ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                                  h["jitter"][i][None] / 1e-5) for i in range(lo, hi)]
+        barrier.wait()
+        t0 = time.time()
+        for _ in range(reps):
+            for i in range(lo, hi):
+                st = states[i - lo]
+                Mk, Bk = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None],
+                                            h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None],
+                                            h["x"][i][None])
+                ostep.control_step(h["x"][i], h["plan"][i], h["dot_plan"][i], Mk[0], Bk[0], h["A"][i], h["Kp"], 10.0,
+                                   h["centers"][i], h["radii"][i], h["tw"], h["gammas"], 4.0, h["w"][i], h["r"][i],
+                                   h["rho"][i], h["relax_mask"])
+        queue.put((t0, time.time(), (hi - lo) * reps))
+
+
+def cpu_baseline(sample, N, n, m, seed=1234, task_seed=99):
+    """The oracle (a numpy / torch-CPU port of the reference's arithmetic, Cholesky factor cached as the reference caches
+    it between refits) timed on this host on a bounded sample of the same workload -- the same generators and seeds as
+    the GPU run, drawn on the CPU -- four ways (SURVEY.md 8d): (a) reference style, one instance at a time, one thread;
+    (b) vectorised over the batch, one thread; (c) vectorised, 16 threads (more threads are slower, see below);
+    (d) the reference-style loop as one PROCESS per core (up to 64 workers, one thread each, a slice of the sample each).
+    `value` is the fastest of them, `cores` the threads / processes it used.
+    MUST run before this process's first GPU call: (d) forks workers, and nothing that has initialised the GPU may
+    spawn or replace a process on this pool -- main() calls it first and it refuses otherwise."""
+    from threadpoolctl import threadpool_limits
+    from bayesian_cbf_amd.distributed import open_gpu_descriptors
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
     from oracle import batched as ob, control_step as ostep, gp_posterior as ogp
     L_mean = 4.0
-    take = lambda v, k: v[:k] if (v.dim() > 0 and v.shape[0] >= k and v.shape[0] == p["X"].shape[0]) else v
+    ncpu = os.cpu_count() or 1
+    gpu_fds = open_gpu_descriptors()
     variants = []
+    f64 = torch.float64
+    p = make_instances(sample, N, n, m, dtype=f64, device="cpu", seed=seed)
+    task = make_unicycle_task(sample, dtype=f64, device="cpu", seed=task_seed)
+    take = lambda v, k: v[:k] if (v.dim() > 0 and v.shape[0] >= k and v.shape[0] == sample) else v
+
+    # ---- (d) process per core: reference-style scalar loop, workers forked BEFORE anything touches the GPU
+    workers = min(ncpu, 64, sample)
+    if gpu_fds:
+        variants.append(dict(name="scalar loop, one process per core: SKIPPED (this process already holds %s)" % gpu_fds[0],
+                             cores=0, value=0.0, instances=0, seconds=0.0))
+    elif workers > 1:
+        import multiprocessing as mp
+        per = max(1, min(32, sample // workers))
+        sd = workers * per
+        _CPU_SHARED["h"] = {k: take(v, sd).numpy() for k, v in {**p, **task}.items()}
+        ctx = mp.get_context("fork")
+        barrier, queue = ctx.Barrier(workers), ctx.Queue()
+        reps = max(1, int(round(1200 / per)))            # ~1200 instance-steps per worker: a few seconds each
+        procs = [ctx.Process(target=_cpu_worker, args=(w * per, (w + 1) * per, reps, barrier, queue)) for w in range(workers)]
+        for pr in procs:
+            pr.start()
+        res = [queue.get() for _ in procs]
+        for pr in procs:
+            pr.join()
+        el = max(r[1] for r in res) - min(r[0] for r in res)
+        done = sum(r[2] for r in res)
+        variants.append(dict(name="scalar loop (reference style), one process per core, one thread each", cores=workers,
+                             value=done / el, instances=sd, passes=reps, seconds=el,
+                             per_worker_value=[r[2] / (r[1] - r[0]) for r in res][:4]))
+        _CPU_SHARED.clear()
 
     # ---- (a) scalar loop, 1 thread
     sa = min(sample, 2048)
-    h = {k: take(v, sa).double().cpu().numpy() for k, v in {**p, **task}.items()}
+    h = {k: take(v, sa).numpy() for k, v in {**p, **task}.items()}
     states = [ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
                               h["jitter"][i][None] / 1e-5) for i in range(sa)]      # refit: not timed (cached upstream)
     with threadpool_limits(limits=1):
@@ -164,7 +229,7 @@ def cpu_baseline(p, task, sample, N, n, m):
 
     # ---- (b), (c) vectorised over the batch (torch CPU: batched triangular solve + the batched cone solver)
     sv = min(sample, 1024)
-    q = {k: take(v, sv).double().cpu() for k, v in {**p, **task}.items()}
+    q = {k: take(v, sv) for k, v in {**p, **task}.items()}
     Ls, Vws, UHBs = [], [], []
     for c0 in range(0, sv, 128):                                # refit in slices: not timed
         sl = slice(c0, min(c0 + 128, sv))
@@ -173,7 +238,6 @@ def cpu_baseline(p, task, sample, N, n, m):
         Ls.append(L_); Vws.append(Vw_); UHBs.append(UHB_)
     L_, Vw_, UHB_ = torch.cat(Ls), torch.cat(Vws), torch.cat(UHBs)
     del Ls, Vws, UHBs
-    ncpu = os.cpu_count() or 1
     # torch's CPU kernels on [B, 512, 512] batches stop scaling (and collapse under oversubscription: 256 threads took
     # 240 s for the pass one thread does in 0.4 s on the EPYC 9575F host): the multi-thread variant uses 16
     many = min(ncpu, 16)
@@ -189,10 +253,12 @@ def cpu_baseline(p, task, sample, N, n, m):
             el = (time.perf_counter() - t0) / reps
         variants.append(dict(name="vectorised over the batch (torch CPU)", cores=threads, value=sv / el, instances=sv,
                              seconds=el))
+    torch.set_num_threads(ncpu)
     best = max(variants, key=lambda v: v["value"])
     return dict(value=best["value"], unit="control steps/s (instance-steps)", cores=best["cores"], kind="port",
-                sample="%s; %d instances of the same N=%d,n=%d,m=%d workload per pass, factor cached; fp64; "
-                       "host: %s, %d hardware threads" % (best["name"], best["instances"], N, n, m, cpu_model(), ncpu),
+                sample="%s; %d instances of the same N=%d,n=%d,m=%d workload (same generator and seeds, drawn on the CPU) per "
+                       "pass, factor cached; fp64; measured before this process's first GPU call; host: %s, %d hardware threads"
+                       % (best["name"], best["instances"], N, n, m, cpu_model(), ncpu),
                 cpu_model=cpu_model(), host_threads=ncpu, variants=variants)
 
 
@@ -215,6 +281,11 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used\n" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the CPU baseline (rank 0 of a one-GPU run) is measured FIRST: its process-per-core variant forks workers, which must
+    # happen before this process initialises the GPU
+    cpu_base = None
+    if world == 1 and rank == 0 and args.cpu_sample > 0 and args.regime == "independent":
+        cpu_base = cpu_baseline(args.cpu_sample, args.ntrain, 3, 2, seed=1234 + rank, task_seed=99 + rank)
     # test hooks (one-GPU boxes): BCBF_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, BCBF_BENCH_BACKEND=gloo
     # replaces RCCL -- the N>1 code path is then exercised without a second GPU
     if os.environ.get("BCBF_BENCH_SINGLE_DEVICE") == "1":
@@ -474,13 +545,21 @@ def main():
                          "instances_per_launch_by_part": Bcs,
                          "algorithmic_bytes_per_step": algorithmic_bytes_per_instance(N, n, m, p["X"].element_size()) * Bt},
         }
+        # the vendor figure AND a ceiling measured on this box -- the operator buffer the kernel streams, read
+        # once per launch by bcbf_hbm_read_probe (same 16-byte non-temporal loads, no arithmetic), after the timed region
+        probe = ops.hbm_read_probe(Lop, launches=10)
+        out["roofline"]["peak_measured"] = probe["best_gbs"]
+        out["roofline"]["frac_of_measured"] = achieved / probe["best_gbs"]
+        out["roofline"]["peak_measured_how"] = ("bcbf_hbm_read_probe: read-only pass over the %.2f GB operator buffer, best of %d "
+                                                "launches (mean %.0f GB/s), device to itself, after the timed region; `peak` / "
+                                                "`frac` stay on the vendor figure" % (probe["bytes"] / 1e9, probe["launches"], probe["mean_gbs"]))
         if alone:
             alone["note"] = ("the same kernel with the device to itself, one launch per HIP-event pair, after the timed region: "
                              "algorithmic bytes per launch / that launch's duration (what a kernel trace of a one-stream run "
                              "reports: profiles/*_bench_parts1_kernel_stats.csv)")
             out["roofline"]["unoverlapped"] = alone
-        if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(p, task, args.cpu_sample, N, n, m)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if multi:
         import torch.distributed as dist

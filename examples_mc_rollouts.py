@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default=None,
                     help="precision of the shared learned model (default: f64 as the reference's module for N <= 512, else f32)")
     args = ap.parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # BCBF_BENCH_FORCE_LAUNCH=1 (test hook, as in bench.py): also a one-GPU run goes through the launcher parent -> child rank path
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
         from bayesian_cbf_amd.distributed import launch_ranks
         sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     from bayesian_cbf_amd.distributed import RankContext, shard_range
@@ -69,12 +70,37 @@ def main():
     el_own = time.perf_counter() - t0
     el, per_rank = ctx.reduce_times(el_own)
     loop_max, _ = ctx.reduce_times(out["loop_seconds"])
+    # roofline of the loop's dominant kernel, over the LOOP time (every launch of a step included: a lower bound on the
+    # kernel's own rate).  Shared learned model: the regime-S posterior on the matrix cores, (1+m) N^2 flop per trajectory-
+    # step.  Fixed-kernel recipe (the reference's unicycle_bayes_cbf_safe_obstacle): the fused task rows / terms / SOCP /
+    # plant-step kernel holds everything in registers -- neither HBM nor the matrix cores bind it (a chain of fp64 divisions
+    # and square roots per interior-point iteration); its algorithmic bytes are the per-trajectory inputs and outputs
+    n_loc, isz = b - a, (8 if dtype == torch.float64 else 4)
+    if args.shared_learned:
+        N_ = args.shared_learned
+        flops = float(n_loc) * 3 * N_ * N_
+        ach = flops * args.steps / out["loop_seconds"] / 1e12
+        peak = 78.6 if isz == 8 else 157.3
+        roof = dict(bound="mfma", kernel="posterior_shared_reg_kernel<%s>" % ("double" if isz == 8 else "float"),
+                    algorithmic_flops_per_launch=flops, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
+                    how="over the loop time of rank 0 (posterior + solve + bookkeeping launches per step)")
+    else:
+        per_traj = isz * (3 + 3 + 3 + 9 + 9 + 9 + 4 + 2 + 3 + 2 + 1 + 3 + 3 + 4 + 3) + 4 * 3
+        if args.learned:
+            per_traj += isz * (args.learned * (args.learned + 1) // 2 + args.learned * 9)
+        byt = float(n_loc) * per_traj
+        ach = byt * args.steps / out["loop_seconds"] / 1e9
+        roof = dict(bound="hbm", kernel=("posterior_step_kernel<double, 3, ...>" if args.learned else "socp_quad_kernel<double, 2, true> (fused task rows + terms + SOCP + plant step)"),
+                    algorithmic_bytes_per_launch=byt, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None,
+                    limiter=(None if args.learned else "latency: register-resident interior-point iterations (fp64 division / sqrt chains); "
+                             "neither the HBM nor the MFMA roofline binds this kernel -- see solver iterations in DESIGN.md 3.2"),
+                    how="over the loop time of rank 0 (every launch of a step)")
     if rank == 0:
         print(json.dumps(dict(config="c4: Monte-Carlo safety rollouts (unicycle_bayes_cbf_safe_obstacle recipe)",
                               trajectories=args.trajectories, steps=args.steps, n_gpus=world, seconds=el, loop_seconds=loop_max,
                               trajectory_steps_per_s=args.trajectories * args.steps / el,
                               trajectory_steps_per_s_loop_only=args.trajectories * args.steps / loop_max, scaling="strong",
-                              comm=ctx.comm_info(per_rank), **out["stats"])))
+                              comm=ctx.comm_info(per_rank), roofline=roof, **out["stats"])))
     ctx.close()
 
 

@@ -65,6 +65,13 @@ extern "C" {
 int bcbf_version(void);
 const char* bcbf_last_error(void);
 
+/* Measurement aid (SURVEY.md 8d asks for the vendor HBM figure AND a ceiling measured on the same box; no reference
+ * counterpart): one launch that READS `bytes` of the caller's device buffer `buf` (16-byte aligned) with the access
+ * pattern of the roofline kernel's operator stream -- 16-byte non-temporal loads, contiguous per workgroup -- and writes
+ * nothing (`sink`: >= 256 floats of device memory, never written for finite data).  `*bytes_read` (host) receives the
+ * bytes the launch touches (bytes rounded down to a multiple of 16 * 8192).  Time it with events on `stream`. */
+int bcbf_hbm_read_probe(const void* buf, size_t bytes, void* sink, size_t* bytes_read, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Packed triangular operator "Lop" (the HBM layout the per-step kernel streams).
  * Np = N rounded up to BCBF_NB (32), J = floor(j/32).  Two parts:

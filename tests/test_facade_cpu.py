@@ -162,3 +162,25 @@ def test_nominal_controllers_restored_and_control_cbf_learned_default_constructi
     pd.set_init_state(torch.tensor([1.0, 0.3, 0.2], **T64))
     obs = pd.step(torch.tensor([1.0, 0.5], **T64), 0.1)
     np.testing.assert_allclose(obs["xdot"].numpy(), [-math.cos(0.3), -math.sin(0.3) + 0.5, -math.sin(0.3)], atol=1e-14)
+
+
+def test_hyper_cache_follows_dtype_casts_and_repointed_parameters():
+    """`_hyper()` (host-side constants kept across `clear_cache()`) must follow `float_()/double_()` (reference surface,
+    control_affine_model.py:625-643: module.to() bumps no version counter) and a re-pointed parameter."""
+    from bayesian_cbf_amd.control_affine_model import ControlAffineRegressor
+    r = ControlAffineRegressor(2, 1, device="cpu")
+    assert r._hyper()["A"].dtype == r.dtype
+    first = r.dtype
+    other = torch.float32 if first == torch.float64 else torch.float64
+    r.to(other)
+    hp = r._hyper()
+    assert all(v.dtype == other for v in hp.values()), {k: v.dtype for k, v in hp.items()}
+    r.to(first)
+    assert all(v.dtype == first for v in r._hyper().values())
+    ell0 = r._hyper()["ell"].clone()
+    r.model.raw_lengthscale.data = r.model.raw_lengthscale.data + 1.0        # re-pointed storage: no version bump
+    assert not torch.allclose(r._hyper()["ell"], ell0)
+    ell1 = r._hyper()["ell"].clone()
+    r.model.raw_lengthscale.data.add_(1.0)                                   # in place through .data: invisible ...
+    r.clear_cache(hyper=True)                                                # ... unless asked
+    assert not torch.allclose(r._hyper()["ell"], ell1)

@@ -125,3 +125,22 @@ def test_one_gpu_run_through_the_unhooked_launcher_parent(tmp_path):
     assert r["how"] in ("sysfs", "child") and r["counted"] >= 1 and r["gpu_descriptors"] == [] and r["gpus"] == 1
     assert out["n_gpus"] == 1 and out["comm"]["backend"] == "rccl" and out["comm"]["world_size"] == 1
     assert out["value"] > 0
+
+
+@pytest.mark.parametrize("config", ["c4", "c5"])
+def test_c4_c5_through_the_unhooked_launcher_parent_one_rccl_rank(tmp_path, config):
+    """`bench.py --config c4|c5 --gpus 8` on an 8-GPU node takes this path; here with the one GPU there is: the parent counts
+    devices without HIP, holds no GPU descriptor when it spawns torch.distributed.run, and the ONE child rank runs the
+    harness over RCCL (communicator, barriers, the final reductions)."""
+    rep = tmp_path / "launch.json"
+    args = (["--trajectories", "64", "--steps", "10"] if config == "c4" else ["--batch", "8", "--n0", "40", "--n1", "72"])
+    out = _run_script("bench.py", ["--config", config, "--gpus", "1"] + args,
+                      {"BCBF_BENCH_FORCE_LAUNCH": "1", "BCBF_BENCH_FORCE_DIST": "1", "BCBF_LAUNCH_REPORT": str(rep)})
+    r = json.loads(rep.read_text())
+    assert r["how"] in ("sysfs", "child") and r["counted"] >= 1 and r["gpu_descriptors"] == [] and r["gpus"] == 1
+    assert out["n_gpus"] == 1 and out["comm"]["backend"] == "rccl" and out["comm"]["world_size"] == 1
+    if config == "c4":
+        assert out["count"] == 64 and out["solver_failures"] == 0 and out["roofline"]["achieved"] > 0
+    else:
+        assert out["append_failures"] == 0 and out["final_vs_refit"]["Mk"] < 1e-8
+        assert out["segments"][0]["roofline"]["bound"] == "hbm" and 0 < out["segments"][0]["roofline"]["frac"] < 1

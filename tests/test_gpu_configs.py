@@ -32,11 +32,7 @@ def host(t):
     return t.detach().cpu().double().numpy()
 
 
-def rel_close(actual, desired, rtol, scale=None, what=""):
-    actual, desired = np.asarray(actual), np.asarray(desired)
-    sc = np.abs(desired).max() if scale is None else scale
-    err = np.abs(actual - desired).max()
-    assert err <= rtol * max(sc, 1e-300), "%s: max abs err %.3e > %.1e * scale %.3e" % (what, err, rtol, sc)
+from _tolreport import rel_close, all_close  # noqa: E402,F401
 
 
 def _refit_with_retry(ops, p):
@@ -91,6 +87,9 @@ def test_c3_fused_control_step_vs_oracle_end_to_end(ops, dtype):
         prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
         rel_close(Mk_d[i], Mk_o[0], tol_post, scale=max(1.0, np.abs(Mk_o).max()), what="Mk[%d]" % i)
         rel_close(Bk_d[i], Bk_o[0], tol_post, scale=prior, what="Bk[%d]" % i)
+        # ... and relative to B_k's OWN magnitude (north_star's tolerance as written; B_k is a difference of nearly equal
+        # numbers near training data, so this is the harder bound)
+        rel_close(Bk_d[i], Bk_o[0], tol_post, scale=float(np.abs(Bk_o[0]).max()), what="Bk own-relative[%d]" % i)
         o = ostep.control_step(h["x"][i], h["plan"][i], h["dot_plan"][i], Mk_o[0], Bk_o[0], h["A"][i], h["Kp"], 10.0,
                                h["centers"][i], h["radii"][i], h["tw"], h["gammas"], L_mean, h["w"][i], h["r"][i],
                                h["rho"][i], h["relax_mask"], dt=dt_plant, L_true=L_true)
@@ -448,8 +447,8 @@ def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
                                                  uh_new.contiguous(), xd_new.contiguous(), jit_new)
         pk = ops.posterior_step(L2, Vw2, X2, UHB2, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
         for a, b in zip(after, pk):
-            np.testing.assert_allclose(host(a), host(b), rtol=1e-9 if dtype == torch.float64 else 2e-3,
-                                       atol=1e-9 if dtype == torch.float64 else 2e-3)
+            all_close(host(a), host(b), 1e-9 if dtype == torch.float64 else 1e-3, 1e-9 if dtype == torch.float64 else 1e-3,
+                      what="reserved vs packed append")
         if cap == N + 1:
             with pytest.raises(RuntimeError):
                 g.append(x_new.contiguous(), uh_new.contiguous(), xd_new.contiguous(), jit_new)

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from _tolreport import rel_close, all_close  # noqa: E402,F401
+
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -783,8 +785,8 @@ def test_cogp_regressor_matches_reference(path):
     reg32 = make_cogp(g, [g["jitter_rand"][0], g["jitter2"][0]], dtype=torch.float32)
     mean32, K32 = reg32._custom_predict_matrix(torch.as_tensor(g["Xtest"], dtype=torch.float32, device=DEV))
     scale = float(g["s2"]) * np.abs(g["Sigma"]).max()
-    np.testing.assert_allclose(mean32.cpu().double().numpy(), g["mean_k"], rtol=0, atol=2e-3 * max(1.0, np.abs(g["mean_k"]).max()))
-    np.testing.assert_allclose(K32.cpu().double().numpy(), g["KkXX"], rtol=0, atol=2e-3 * scale)
+    rel_close(mean32.cpu().double().numpy(), g["mean_k"], 1e-3, scale=max(1.0, np.abs(g["mean_k"]).max()), what="CoGP fp32 mean_k")
+    rel_close(K32.cpu().double().numpy(), g["KkXX"], 1e-3, scale=scale, what="CoGP fp32 KkXX")
 
 
 @pytest.mark.parametrize("path", [f for f in COGP_FILES if "full_N48" in f or "full_n3m2" in f], ids=os.path.basename)

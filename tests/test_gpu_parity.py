@@ -37,11 +37,7 @@ def host(t):
     return t.detach().cpu().double().numpy()
 
 
-def rel_close(actual, desired, rtol, scale=None, what=""):
-    actual, desired = np.asarray(actual), np.asarray(desired)
-    sc = np.abs(desired).max() if scale is None else scale
-    err = np.abs(actual - desired).max()
-    assert err <= rtol * max(sc, 1e-300), "%s: max abs err %.3e > %.1e * scale %.3e" % (what, err, rtol, sc)
+from _tolreport import rel_close, all_close  # noqa: E402,F401
 
 
 TOL = {torch.float64: 1e-8, torch.float32: 1e-3}
@@ -150,7 +146,7 @@ def test_cholesky_failure_is_reported_per_instance(ops):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_chol_append_equals_refit(ops, dtype):
     from bayesian_cbf_amd.synthetic import make_instances
-    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    tol = 1e-9 if dtype == torch.float64 else 1e-3      # (fp32 measured: 4.9e-7, tools/tol_report.py)
     for N in (31, 32, 45, 64):     # append inside a block, across a block boundary
         p = make_instances(4, N + 1, 3, 2, dtype=dtype, device=DEV, seed=N)
         full = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
@@ -261,10 +257,8 @@ def test_socp_vs_oracle(ops, dtype, m, K):
     for i in range(Bt):
         sol = osocp.clf_cbf_socp(w[i], r[i], [(A[i, k], b[i, k], c[i, k], d[i, k]) for k in range(K)], rho, relax_mask)
         assert sol["status"] == "optimal"
-        # fp32 iterates (reduced KKT solve in fp64): 1e-3 on well-posed programs; this random family
-        # contains near-degenerate cones (scale 1e-3) where ~0.1% of instances reach 2e-3
-        np.testing.assert_allclose(yh[i], sol["x"], rtol=1e-6 if dtype == torch.float64 else 3e-3,
-                                   atol=1e-7 if dtype == torch.float64 else 3e-3)
+        # fp32 entry point: the iterates are fp64 behind it, measured 1.7e-7 over this family
+        all_close(yh[i], sol["x"], 1e-6 if dtype == torch.float64 else 1e-3, 1e-7 if dtype == torch.float64 else 1e-3, what="y vs oracle socp")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -289,8 +283,7 @@ def test_fused_cbc_socp_equals_two_step_path(ops, dtype):
     assert torch.equal(cstatus, cstatus2) and torch.equal(st1, st2)
     ok = (st1 == 0).cpu().numpy()
     assert ok.sum() >= 10          # (this small-N synthetic task leaves many programs infeasible)
-    np.testing.assert_allclose(host(y2)[ok], host(y1)[ok], rtol=1e-6 if dtype == torch.float64 else 2e-3,
-                               atol=1e-7 if dtype == torch.float64 else 2e-3)
+    all_close(host(y2)[ok], host(y1)[ok], 1e-6 if dtype == torch.float64 else 1e-3, 1e-7 if dtype == torch.float64 else 1e-3, what="fused y vs two-step y")
 
 
 def test_socp_flags_infeasible_instances_without_disturbing_others(ops):
@@ -363,7 +356,9 @@ def test_saved_run_controls_end_to_end(ops, name):
                                 cones, dev(np.array([1.0, 0, 0]), dt), dev(np.full(S, rho), dt))
     assert (status == 0).all()
     yh = host(y)
-    np.testing.assert_allclose(yh[:, :2], g["uopt"], rtol=2e-3, atol=2e-3)
+    # (fp64 here; the bound is the RECORD's precision: GUROBI's barrier tolerance and the float32 event file it was logged
+    #  to -- measured 1.55e-3; the oracle's solver agrees with the device to 1e-7, test_socp_vs_oracle)
+    all_close(yh[:, :2], g["uopt"], 2e-3, 2e-3, what="uopt vs GUROBI run")
     value = (g["cost_weights"] * yh ** 2).sum(axis=1)
     np.testing.assert_allclose(value, g["opt_value"], rtol=1e-4, atol=1e-5)
     xs = x.clone()
@@ -440,7 +435,7 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
                                        rep(g["M0"]), xs)
     st = ogp.refit_state(X, U, Xdot, g["B"], g["ell"], float(g["s2"]), g["M0"], g["jitter_rand"])
     C = m + 1
-    tol = 1e-8 if dtype == torch.float64 else 2e-3
+    tol = 1e-8 if dtype == torch.float64 else 1e-3      # (fp32 measured: <= 7e-6 on every golden file)
     for i in range(S):
         jets = oc2.posterior_jets(st["L"], st["Y"], X, st["UHB"], g["ell"], float(g["s2"]), g["B"], g["M0"], g["xs"][i])
         rel_close(host(Mk)[i], jets["Mk"], tol, scale=max(1.0, np.abs(jets["Mk"]).max()), what="Mk")
@@ -456,7 +451,7 @@ def test_reldeg2_jets_and_terms_vs_reference_golden(ops, path, dtype):
                          dev(g["k_alpha"], dtype), dev(g["u0s"], dtype))
     (mA, mb), (Q, p, r), mean, var, status = out
     assert (status == 0).all()
-    ttol = 1e-7 if dtype == torch.float64 else 5e-3
+    ttol = 1e-7 if dtype == torch.float64 else 1e-3     # (fp32 measured: <= 3.4e-5)
     for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
         ref = g["t_" + name].reshape(host(val).shape)
         rel_close(host(val), ref, ttol, scale=max(np.abs(ref).max(), 1e-2), what=name)
@@ -557,7 +552,7 @@ def test_reldeg2_terms_with_cleanup_branch_firing_vs_reference_golden(ops, path,
     """bcbf_posterior_jets + bcbf_cbc2_terms against cbc2_quadratic_terms(cbc2_gp(...)) of the executed reference in the
     state where GradientGP.knl's clean-up FIRES in every record: the factor is the one cached at output scale `s2_L`, the
     query runs at `s2_q[i]` (control_affine_model.py:379-385).  status == 4 (branch ran, reference formula) everywhere,
-    terms within 1e-7 (fp64) / 5e-3 (fp32); the projection mode gives different terms."""
+    terms within 1e-7 (fp64) / 1e-3 (fp32; measured <= 4.1e-5); the projection mode gives different terms."""
     g = np.load(path)
     X, U, Xdot = g["X"], g["U"], g["Xdot"]
     N, n = X.shape
@@ -576,7 +571,7 @@ def test_reldeg2_terms_with_cleanup_branch_firing_vs_reference_golden(ops, path,
             dev(g["t_hess"], dtype), dev(g["k_alpha"], dtype), dev(g["u0s"], dtype))
     (mA, mb), (Q, p, r), mean, var, status = ops.cbc2_terms(*args)
     assert (status == 4).all(), status
-    ttol = 1e-7 if dtype == torch.float64 else 5e-3
+    ttol = 1e-7 if dtype == torch.float64 else 1e-3
     for name, val in (("mean_A", mA), ("mean_b", mb), ("Q", Q), ("p", p), ("r", r), ("mean", mean), ("var", var)):
         ref = g["t_" + name].reshape(host(val).shape)
         rel_close(host(val), ref, ttol, scale=max(np.abs(ref).max(), 1e-2), what=name)
@@ -766,9 +761,9 @@ def test_control_step_shared_model_equals_replicated_model(ops, dtype):
     rel_close(host(ws1["Bk"]), host(ws2["Bk"]), tol, scale=prior, what="Bk")
     ok = ((ws1["status"] == 0) & (ws2["status"] == 0)).cpu().numpy()
     assert ok.sum() >= Bt // 2
-    ytol = 1e-6 if dtype == torch.float64 else 5e-3
-    np.testing.assert_allclose(host(ws1["y"])[ok], host(ws2["y"])[ok], rtol=ytol, atol=ytol)
-    np.testing.assert_allclose(host(x1)[ok], host(x2)[ok], rtol=ytol, atol=ytol)
+    ytol = 1e-6 if dtype == torch.float64 else 1e-3      # (fp32 measured: 2.1e-6)
+    all_close(host(ws1["y"])[ok], host(ws2["y"])[ok], ytol, ytol, what="shared-vs-instance y")
+    all_close(host(x1)[ok], host(x2)[ok], ytol, ytol, what="shared-vs-instance x")
     # composed path on the same inputs
     Mk, Bk, _ = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], t["x"], shared=True)
     grad, cst, fhat, ghat = ops.unicycle_constraints(t["x"], t["plan"], t["dot_plan"], t["Kp"], 10.0, t["centers"],
@@ -778,8 +773,8 @@ def test_control_step_shared_model_equals_replicated_model(ops, dtype):
     # (the composed path evaluates the task rows in another kernel: same source, but the compiler may contract
     #  multiply-adds differently, so agreement is to rounding, not bitwise)
     assert int((st != ws1["status"]).sum()) <= 1
-    ctol = 1e-9 if dtype == torch.float64 else 2e-3
-    np.testing.assert_allclose(host(y)[ok], host(ws1["y"])[ok], rtol=ctol, atol=ctol)
+    ctol = 1e-9 if dtype == torch.float64 else 1e-3      # (fp32 measured: 3.2e-7)
+    all_close(host(y)[ok], host(ws1["y"])[ok], ctol, ctol, what="composed y")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -832,6 +827,7 @@ def test_potri_dense_inverse(ops, dtype, N, gemm):
     res = (Kb.double() @ Kinv.double() - eye).abs().max()
     # K_b is ill conditioned (cond ~ 1e5..1e8 with the 1e-5 jitter): residual relative to |K_b| |K_b^-1|
     scale = float(Kb.double().abs().max() * Kinv.double().abs().max())
+    # (K_b K_b^-1 - I relative to |K_b| |K_b^-1|: the likelihood gradient's intermediate, fit runs it in fp64 -- FIT_DTYPE)
     assert float(res) <= (1e-10 if dtype == torch.float64 else 2e-3) * max(scale, 1.0), (float(res), scale)
     assert float((Kinv - Kinv.transpose(1, 2)).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-1) * float(Kinv.abs().max())
 
@@ -862,7 +858,7 @@ def test_edge_cases_empty_batch_single_point_and_maximum_size(ops):
         rel_close(host(Mk)[i], Mk_o[0], 1e-10, scale=max(1.0, np.abs(Mk_o).max()), what="Mk N=1")
         rel_close(host(Bk)[i], Bk_o[0], 1e-10, scale=h["s2"][i] * np.abs(h["Bm"][i]).max(), what="Bk N=1")
     # ---- N = 2048: well-conditioned inputs (wide box) so that fp32 factors too
-    for dtype, tol in ((torch.float64, 1e-8), (torch.float32, 2e-3)):
+    for dtype, tol in ((torch.float64, 1e-8), (torch.float32, 1e-3)):      # (fp32 measured: 6e-8)
         r = make_instances(2, 2048, 3, 2, dtype=torch.float64, device=DEV, seed=3)
         r["X"] = (r["X"] * 6.0).contiguous()                 # spread the points: K_b stays positive definite in fp32
         r["xq"] = (r["xq"] * 6.0).contiguous()
@@ -987,10 +983,12 @@ def test_rbf_plus_linear_data_kernel_entry_points(ops, dtype, tol):
         Phi = ogp.rbf_linear_kernel(X[b], xq[b:b + 1], ell[b], s2[b], lin[b]) * UHB[b]
         Wr = np.linalg.solve(L, Phi)
         Vr = np.linalg.solve(L, Y[b] - UH[b] @ M0[b])
-        rel_close(host(W[b, :N]), Wr, 20 * tol, what="W")
-        rel_close(host(Mk[b]), M0[b].T + Vr.T @ Wr, 20 * tol, what="Mk")
+        rel_close(host(W[b, :N]), Wr, 5 * tol, what="W")                     # (fp32: 1e-3; measured 5.6e-5)
+        # (the posterior mean is a weighted sum of the TARGETS, here white noise of scale |Y| ~ 3.5: error relative to that
+        #  scale, as B_k's is relative to the prior scale; fp32 measured 1.5e-3 of |Mk| = 4e-4 of |Y|)
+        rel_close(host(Mk[b]), M0[b].T + Vr.T @ Wr, 5 * tol, scale=max(1.0, np.abs(Y[b]).max()), what="Mk")
         kss = s2[b] * (1 + lin[b] * xq[b] @ xq[b])
-        rel_close(host(Bk[b]), kss * Bm[b] - Wr.T @ Wr, 50 * tol, scale=kss * np.abs(Bm[b]).max(), what="Bk")
+        rel_close(host(Bk[b]), kss * Bm[b] - Wr.T @ Wr, 5 * tol, scale=kss * np.abs(Bm[b]).max(), what="Bk")   # (measured 1.8e-6)
 
 
 @pytest.mark.parametrize("m", [1, 2])
@@ -1035,7 +1033,9 @@ def test_refit_one_wave_per_instance_vs_oracle_and_workgroup_form(ops, N, n, m, 
     from bayesian_cbf_amd.synthetic import make_instances
     Bt = 70                                    # odd number of workgroups' worth of waves + a ragged tail
     f64 = dtype == torch.float64
-    tL, tW, tP = (1e-8, 1e-9, 1e-8) if f64 else (1e-3, 1e-3, 2e-3)     # (fp32: two factorizations of K_b with cond ~1e5)
+    # (fp32 tP: two fp32 factorizations of a K_b with cond ~1e5 compared entry by entry -- an internal representation, forward
+    #  bound cond * eps = 6e-3, measured 7.8e-4; every reference-exposed output derived from it is held to 1e-3)
+    tL, tW, tP = (1e-8, 1e-9, 1e-8) if f64 else (1e-3, 1e-3, 2e-3)
     p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=100 + N)
     p["X"] = (p["X"] * 2.0).contiguous()
     jit = p["jitter"].clone()
@@ -1127,7 +1127,7 @@ def test_refit_two_waves_per_instance_vs_one_wave_form_and_oracle(ops, form, Bt,
     # (fp32: two factorizations of K_b with cond ~1e5 and the inverses of its diagonal blocks; the forms round K_b's entries
     #  differently since the one-wave form's interior tiles skip the jitter / padding selects: cond x eps = 6e-3)
     for i in np.nonzero(good)[0][:8]:
-        rel_close(host(Lop_p[i]), host(Lop_w[i]), 1e-8 if f64 else 5e-3, what="Lop vs one-wave form [%d]" % i)
+        rel_close(host(Lop_p[i]), host(Lop_w[i]), 1e-8 if f64 else 1e-3, what="Lop vs one-wave form [%d]" % i)   # (fp32 measured: 2.6e-6)
     Vw, _ = ops.potrs(Lop_p, p["Xdot"], UH, p["M0"], want_alpha=False)
     Mk, Bk = ops.posterior_step(Lop_p, Vw, X, UHB_p, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
     h = {k: host(v) for k, v in dict(X=X, U=p["U"], Xdot=p["Xdot"], Bm=p["Bm"], ell=p["ell"], s2=p["s2"], M0=p["M0"], jit=jit).items()}
@@ -1162,7 +1162,9 @@ def test_refit_super_panel_form_equals_plain_form(ops, dtype, N, n, m, monkeypat
     assert torch.equal(UHB_s, UHB_p)
     for i in torch.nonzero(info_s == 0).flatten().tolist():
         # (fp64: both forms accumulate the same products in a different order; fp32: cond x eps, as between the other forms)
-        rel_close(host(Lop_s[i]), host(Lop_p[i]), 1e-9 if f64 else 5e-3, what="super-panel vs plain form [%d]" % i)
+        # (fp32: two different fp32 factorisations of a K_b with cond ~1e5 -- the factor is an internal representation, not
+        #  a reference-exposed output; forward bound cond * eps = 6e-3, measured 4.4e-4; the posterior from it: 1e-3 below)
+        rel_close(host(Lop_s[i]), host(Lop_p[i]), 1e-9 if f64 else 2e-3, what="super-panel vs plain form [%d]" % i)
     if not f64:
         # fp32 again with a jitter of order 1 on the diagonal: K_b is then well conditioned, the two forms agree to rounding, and
         # a jitter entry that went missing or to the wrong row would stand out
@@ -1269,7 +1271,7 @@ def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
                                         one(p["M0"]), p["xq"], shared=True, kernel="matern52")
     h = {k: host(v) for k, v in p.items()}
     hj = host(jit)
-    tol = 1e-9 if f64 else 2e-3
+    tol = 1e-9 if f64 else 1e-3          # (fp32 measured: 3.6e-7)
     for i in range(Bt):
         UH = h["UH"][i]
         K_o = ogp.matern52_ard_kernel(h["X"][i], h["X"][i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
@@ -1411,14 +1413,14 @@ def test_matern52_fused_refit_equals_build_then_factor_and_jets_vs_oracle(ops, d
         Vw2, _ = ops.potrs(Lop2, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
         q = lambda L_, V_: ops.posterior_query(L_, V_, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, shared=False, kernel="matern52")
         (Mk1, Bk1, _), (Mk2, Bk2, _) = q(Lop, Vw), q(Lop2, Vw2)
-        tol = 1e-9 if f64 else 2e-3
+        tol = 1e-9 if f64 else 1e-3      # (fp32 measured: 1.9e-7)
         rel_close(host(Mk1), host(Mk2), tol, scale=max(1.0, float(Mk2.abs().max())), what="Mk fused vs build+factor")
         rel_close(host(Bk1), host(Bk2), tol, scale=float((p["s2"][:, None, None] * p["Bm"]).abs().max()), what="Bk fused vs build+factor")
         Mk, Bk, G, Mj = ops.posterior_jets(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, kernel="matern52")
         h = {k: host(v) for k, v in p.items()}
         hX, hxq, hj = host(X), host(xq), host(jit)
         C = m + 1
-        jt = 1e-8 if f64 else 3e-3
+        jt = 1e-8 if f64 else 1e-3       # (fp32 measured: 3.8e-7)
         for i in range(Bt):
             UH = h["UH"][i]
             K = ogp.matern52_ard_kernel(hX[i], hX[i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
@@ -1506,7 +1508,7 @@ def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n
         Mk, Bk, G, Mj, Wj = ops.posterior_jets(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, want_W=True)
         h = {k: host(v) for k, v in p.items()}
         hX, hxq, hj = host(X), host(xq), host(jit)
-        tol = 1e-8 if f64 else 2e-3
+        tol = 1e-8 if f64 else 1e-3      # (fp32 measured: values 1e-4, d/dx columns 2.6e-4, Gram blocks 1.1e-5)
         for i in range(Bt):
             st = ogp.refit_state(hX[i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i], hj[i][None] / 1e-5)
             jets = oc2.posterior_jets(st["L"], st["Y"], hX[i], st["UHB"], h["ell"][i], float(h["s2"][i]), h["Bm"][i], h["M0"][i], hxq[i])
@@ -1545,7 +1547,7 @@ def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n
             st = ogp.refit_state(hX[i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i], hj[i][None] / 1e-5)
             jets = oc2.posterior_jets(st["L"], st["Y"], hX[i], st["UHB"], h["ell"][i], float(h["s2"][i]), h["Bm"][i], h["M0"][i], hxq[i])
             if not f64:
-                # fp32: the jets were held to 2e-3 of their scale above; the terms are differences of products of them, so
+                # fp32: the jets were held to 1e-3 of their scale above; the terms are differences of products of them, so
                 # the terms KERNEL is checked on the jets it was given (the device's, widened to fp64)
                 Gh, Mjh = host(G)[i], host(Mj)[i]
                 blk = lambda d: slice((1 + d) * C, (2 + d) * C)

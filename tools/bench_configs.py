@@ -24,6 +24,14 @@ def config(Bt, N, n, m, dtype, name):
     out["refit_ms"] = t
     out["refit_TFLOPs"] = flops / (t * 1e-3) / 1e12
     out["refit_write_GBs"] = Bt * ops.lop_elems(N, dtype) * isz / (t * 1e-3) / 1e9
+    # roofline of the refit (SURVEY 8d, K1+K2): matrix-core bound -- N^3/3 flop per instance against the dense MFMA peak of
+    # the dtype; algorithmic bytes = inputs in (N (n + 1 + m + 1) values) + the packed factor out, per instance
+    peak = 78.6 if isz == 8 else 157.3
+    refit_bytes = Bt * isz * (N * (n + 2 + m) + N * (N + 1) // 2)
+    out["roofline"] = {"refit": dict(bound="mfma", kernel=os.environ.get("BCBF_REFIT_KERNEL_NAME", "refit_*_kernel<%s> (form chosen by the launcher)" % ("double" if isz == 8 else "float")),
+                                     algorithmic_flops_per_launch=flops, achieved=out["refit_TFLOPs"], peak=peak, unit="TFLOP/s",
+                                     frac=out["refit_TFLOPs"] / peak, algorithmic_bytes_per_launch=refit_bytes, traffic=None,
+                                     kernel_ms=t)}
     t = timeit(lambda: ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False))
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
     out["potrs_ms"] = t
@@ -31,6 +39,9 @@ def config(Bt, N, n, m, dtype, name):
     by = Bt * isz * (N * (N + 1) // 2 + 2 * N * n + N * (1 + m))
     out["posterior_ms"] = t
     out["posterior_GBs_algorithmic"] = by / (t * 1e-3) / 1e9
+    out["roofline"]["posterior"] = dict(bound="hbm", kernel="posterior_step_kernel<%s, %d, ...>" % ("double" if isz == 8 else "float", 1 + m),
+                                        algorithmic_bytes_per_launch=by, achieved=out["posterior_GBs_algorithmic"], peak=8000.0,
+                                        unit="GB/s", frac=out["posterior_GBs_algorithmic"] / 8000.0, traffic=None, kernel_ms=t)
     print(json.dumps(out))
 
 

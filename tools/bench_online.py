@@ -26,7 +26,8 @@ ap.add_argument("--repeat", type=int, default=1, help="runs (reproducibility of 
 ap.add_argument("--window", type=int, default=0, help="sliding window of the most recent W points (ops.ReservedGP(window=W)): grow "
                                                       "to W, then drop the oldest 32 every 32 appends; --n1 = observations seen")
 a = ap.parse_args()
-if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+# BCBF_BENCH_FORCE_LAUNCH=1 (test hook, as in bench.py): also a one-GPU run goes through the launcher parent -> child rank path
+if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
     from bayesian_cbf_amd.distributed import launch_ranks
     sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
 from bayesian_cbf_amd.distributed import RankContext
@@ -53,6 +54,10 @@ for _ in range(a.repeat):
         for s, (ta, tc) in zip(segs, v[:-1].tolist()):
             s["append_ms"], s["control_step_ms"], s["step_ms"] = ta, tc, ta + tc      # all three the slowest rank's
             s.pop("append_GBs_algorithmic", None)
+            rf = s.get("roofline")
+            if rf and rf.get("achieved") is not None:          # over the slowest rank's time, like append_ms
+                rf["achieved"] = rf["algorithmic_bytes_per_launch"] / (ta * 1e-3) / 1e9
+                rf["frac"] = rf["achieved"] / rf["peak"]
         appends = (a.n1 - a.n0) * a.batch * ctx.world
         out.update(config="c5: online GP growth", n_gpus=ctx.world, batch_per_gpu=a.batch, scaling="weak", seconds=el,
                    instance_appends_per_s=appends / el, comm=ctx.comm_info(per_rank), append_failures=int(fails[0]),
