@@ -458,18 +458,17 @@ BCBF_HD inline int clean_hessian(int n, double H[NMAX][NMAX], double eps, int mo
         }
         if (pd) return 0;
     }
-    project_psd(n, S, w, Vs);                              // eigenvalues of the symmetric part decide which branch runs
-    bool neg = false, bad = false;
-    for (int i = 0; i < n; ++i) { if (w[i] <= -eps) bad = true; if (w[i] < 0.0) neg = true; }
-    if (bad) return 1;
-    if (!neg) return 0;
+    // Which branch runs is decided as the reference decides it (gp_algebra.py:385-387): from the real parts of xGEEV's
+    // eigenvalues of H ITSELF -- `assert (evalz > -EPS).all()`, then `if (evalz < 0).any()` -- not from the symmetric part
+    // (for an H that is non-symmetric by rounding the two can differ next to 0 and next to -EPS).
     if (mode == 0) {
         double Acp[NMAX][NMAX], wr[NMAX], V[NMAX][NMAX];
         for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Acp[i][j] = H[i][j];
         if (geev_real(n, Acp, wr, V) == 0) {
-            bool any = false;
-            for (int k = 0; k < n; ++k) if (wr[k] < 0.0) { any = true; wr[k] = 0.0; }
-            if (!any) return 0;                            // (the general solver sees no negative eigenvalue: H stays)
+            bool any = false, bad = false;
+            for (int k = 0; k < n; ++k) { if (wr[k] <= -eps) bad = true; if (wr[k] < 0.0) { any = true; wr[k] = 0.0; } }
+            if (bad) return 1;
+            if (!any) return 0;
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < n; ++j) {
                     double t = 0.0;
@@ -479,6 +478,12 @@ BCBF_HD inline int clean_hessian(int n, double H[NMAX][NMAX], double eps, int mo
             return 4;
         }
     }
+    // mode 1 (spectral projection), or the general solver saw a complex pair / did not converge: the symmetric part decides
+    project_psd(n, S, w, Vs);
+    bool neg = false, bad = false;
+    for (int i = 0; i < n; ++i) { if (w[i] <= -eps) bad = true; if (w[i] < 0.0) neg = true; }
+    if (bad) return 1;
+    if (!neg) return 0;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             double t = 0.0;

@@ -46,13 +46,43 @@ def reduce_rollout_stats(collisions, min_h, cost_sum, solver_failures, count):
 KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
 
 
-def _visible_list():
-    """Entries of the runtime's device filter, or None when there is none (HIP / ROCr / the CUDA spelling torch honours)."""
-    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
-        v = os.environ.get(k)
-        if v is not None:
-            return [e for e in v.split(",") if e.strip() != ""]
-    return None
+def _filter_indices(value, have):
+    """Device indices one *_VISIBLE_DEVICES value keeps out of `have` devices, as the runtimes read it: a comma list of
+    indices (or UUIDs, which count as present), cut at the first negative or unparsable entry, out-of-range and repeated
+    indices dropped."""
+    keep = []
+    for e in value.split(","):
+        e = e.strip()
+        if e == "":
+            break
+        if e.upper().startswith("GPU-"):          # a UUID: cannot be resolved without the runtime; assume it names a device
+            keep.append(("uuid", e))
+            continue
+        try:
+            i = int(e)
+        except ValueError:
+            break
+        if i < 0:
+            break
+        if i < have and i not in keep:
+            keep.append(i)
+    return keep
+
+
+def _visible_count(have):
+    """Devices left of `have` after the runtime's filters, or None when no filter is set.  ROCR_VISIBLE_DEVICES narrows the
+    devices the HSA runtime enumerates; HIP_VISIBLE_DEVICES (or the CUDA spelling torch honours; HIP wins when both are set)
+    then indexes INTO that narrowed list -- both apply when both are set."""
+    rocr = os.environ.get("ROCR_VISIBLE_DEVICES")
+    hip = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
+    if rocr is None and hip is None:
+        return None
+    n = have
+    if rocr is not None:
+        n = len(_filter_indices(rocr, n))
+    if hip is not None:
+        n = len(_filter_indices(hip, n))
+    return n
 
 
 def visible_gpu_count(nodes_dir=None, dev_dir="/dev"):
@@ -93,9 +123,9 @@ def visible_gpu_count(nodes_dir=None, dev_dir="/dev"):
         except Exception:
             return 0, "unknown"
         return n, how                      # (the child applied the *_VISIBLE_DEVICES filter itself)
-    vis = _visible_list()
+    vis = _visible_count(n)
     if vis is not None:
-        n = min(n, len(vis))
+        n = min(n, vis)
     return n, how
 
 

@@ -212,11 +212,19 @@ class ReservedGP:
     N = 512, latency bound, plus re-inverting every diagonal block of the packed layout), the refit is N^3 / 3 = 45 MFLOP on
     the matrix cores at 18-50 TFLOP/s -- 0.5 ms for 256 windows of 512 points in fp64, once per 32 appends of 0.47 ms each --
     and it leaves EXACTLY the factor a from-scratch refit of the window gives (no accumulation over wrap-arounds).
-    Needs capacity >= W + 32."""
+    Needs capacity >= W + 32.  `drop` = k (default 32) forgets the k oldest points at a time instead (the live size then
+    runs between W and W + k - 1, capacity >= W + k): the reference's refit cadence `train_every_n_steps` = 40
+    (unicycle_move_to_pose.py:340-386) is `drop=40`.  What this is and is not: a REFIT SCHEDULE on in-place storage, not a
+    down-date kernel -- between two drops the appends are true rank-one updates in place, the drop itself recomputes the
+    window's factor from the data.
+    A failed factorisation of the window (after `max_tries` jitter levels) is reported: `drop_info[Bt]` holds the last
+    drop's per-instance pivot index, `drop_failures` counts instances over all drops, and the next `append` returns an
+    `info` that carries it (OR-ed in as a negative value) so a caller that only watches `append`'s result sees it."""
 
     BLOCK = 32
 
-    def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None):
+    def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None,
+                 drop=None):
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
         self.Bt, self.N, self.n = X.shape
         self.C = UHB.shape[2]
@@ -224,13 +232,16 @@ class ReservedGP:
         self.capacity = 0
         self.window = None if window is None else int(window)
         self.drops = 0
+        self.drop = self.BLOCK if drop is None else int(drop)
+        self.drop_failures = 0
+        self.drop_info = None
         self._fill(Lop, Vw, X, UHB, self.N, int(capacity))
         if self.window is not None:
             if UH is None or Xdot is None:
                 raise ValueError("a sliding window refits from the data: pass UH and Xdot (and the jitter) of the initial points")
-            if self.capacity < self.window + self.BLOCK or self.N > self.window + self.BLOCK - 1:
-                raise ValueError("window %d needs capacity >= %d and at most %d initial points" % (self.window, self.window + self.BLOCK,
-                                                                                                   self.window + self.BLOCK - 1))
+            if self.drop < 1 or self.capacity < self.window + self.drop or self.N > self.window + self.drop - 1:
+                raise ValueError("window %d needs capacity >= %d and at most %d initial points" % (self.window, self.window + self.drop,
+                                                                                                   self.window + self.drop - 1))
             _chk(UH, Xdot, jitter)
             f = dict(dtype=X.dtype, device=X.device)
             # raw rows of the live points (the reserved arrays hold derived quantities: UH B, L^-1 (Xdot - UH M0))
@@ -269,13 +280,13 @@ class ReservedGP:
         return self
 
     def drop_oldest_block(self, max_tries=10):
-        """Window mode: forget the 32 oldest points.  The raw rows move up, the window's factor and whitened targets are
+        """Window mode: forget the `drop` (default 32) oldest points.  The raw rows move up, the window's factor and whitened targets are
         recomputed from them (`refit` with the jitter every point ENTERED with -- an instance whose factorisation fails
         retries with its jitter x10, as make_psd does, control_affine_model.py:903-919) and laid out into the reserved
         buffers this object already owns.  Returns info[Bt] of the last factorisation (0 = fine)."""
         if self.window is None:
             raise RuntimeError("drop_oldest_block needs a ReservedGP built with window=...")
-        k = self.BLOCK
+        k = self.drop
         N2 = self.N - k
         if N2 < 1:
             raise RuntimeError("nothing would be left")
@@ -284,9 +295,15 @@ class ReservedGP:
         for ntry in range(max_tries):
             Lop, UHB, info, _ = refit(X, UH, self.Bm, self.ell, self.s2, J)
             bad = info != 0
-            if not bool(bad.any()):                   # (one host round trip per 32 appends)
-                break
-            J = torch.where(bad[:, None], J * 10, J)
+            if not bool(bad.any()):                   # (one host round trip per drop: ~30 us against the refit's milliseconds;
+                break                                 #  speculative jitter levels would cost two more refits per drop instead)
+            if ntry + 1 < max_tries:
+                J = torch.where(bad[:, None], J * 10, J)
+        else:
+            # still failing after max_tries levels: the instance's window is laid out as the (garbage) factor the kernel left;
+            # say so where callers look -- drop_info, the failure count, and the next append's info
+            self.drop_failures += int(bad.sum())
+        self.drop_info = info
         Vw, _ = potrs(Lop, Y, UH, self.M0, want_alpha=False)
         self._rUH[:, :N2], self._rY[:, :N2], self._rJ[:, :N2] = UH, Y, J
         self._fill(Lop, Vw, X, UHB, N2, self.capacity, reuse=True)
@@ -315,8 +332,8 @@ class ReservedGP:
         query[Bt,n] (with out = (Mk, Bk), or allocated): the posterior at `query` on the points BEFORE the append, computed
         on the same pass over the factors as the append's forward solve -- a "posterior, then append" step for the traffic
         of one; then returns (info, Mk, Bk)."""
-        if self.window is not None and self.N >= self.window + self.BLOCK:
-            raise RuntimeError("window mode: the live size is already window + 32 (drop_oldest_block failed?)")
+        if self.window is not None and self.N >= self.window + self.drop:
+            raise RuntimeError("window mode: the live size is already window + %d (drop_oldest_block failed?)" % self.drop)
         if self.N >= self.capacity:
             raise RuntimeError("ReservedGP is full (%d points): reserve a larger capacity" % self.capacity)
         _chk(self.X, x_new, uh_new, xdot_new, jitter_new, query)
@@ -337,9 +354,19 @@ class ReservedGP:
             _p(query), _p(Mk), _p(Bk), self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)),
             "bcbf_gp_append_reserved")
         self.N += 1
-        if self.window is not None and self.N >= self.window + self.BLOCK:
-            self.drop_oldest_block()                  # AFTER the append: the posterior the caller asked for saw every point
-        return self.info if query is None else (self.info, Mk, Bk)
+        info = self.info
+        if self.window is not None:
+            # an instance whose pivot failed holds a NEUTRAL point in place (zero rows): the window refit must see the same,
+            # so its raw row is zeroed too (UH = 0 makes K_b's row / column vanish but for the jitter on the diagonal)
+            failed = (info != 0)[:, None]
+            self._rUH[:, self.N - 1] = torch.where(failed, torch.zeros_like(uh_new), self._rUH[:, self.N - 1])
+            self._rY[:, self.N - 1] = torch.where(failed, torch.zeros_like(xdot_new), self._rY[:, self.N - 1])
+            self._rJ[:, self.N - 1] = torch.where(failed[:, 0], torch.ones_like(self._rJ[:, 0]), self._rJ[:, self.N - 1])   # (unit pivot)
+            if self.N >= self.window + self.drop:
+                dinfo = self.drop_oldest_block()      # AFTER the append: the posterior the caller asked for saw every point
+                if self.drop_failures:                # a window that could not be factored: carried in the returned info (< 0)
+                    info = torch.where(dinfo != 0, -dinfo.abs() - 1, info)
+        return info if query is None else (info, Mk, Bk)
 
     def live(self):
         """Views of the live rows: (Vw[Bt,N,n], X[Bt,N,n], UHB[Bt,N,C]) (strided: not inputs of the packed-layout kernels)."""

@@ -245,3 +245,187 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
         out["final_vs_refit"] = dict(Mk=float((Mk - Mr).abs().max() / max(1.0, float(Mr.abs().max()))),
                                      Bk=float((Bk - Br).abs().max() / prior))
     return out
+
+
+def learning_closed_loop(Bt=4096, window=512, steps=200, refit_every=40, warmup=40, dtype=torch.float32, device="cuda",
+                         seed=1234, schedule="online", n=3, m=2, barrier=None):
+    """The reference's REAL workload at BASELINE configs[2] scale: a control loop that keeps learning
+    (`LearnedShiftInvariantDynamics.train`, unicycle_move_to_pose.py:340-386: buffer (x, u) every step, refit every
+    `train_every_n_steps` = 40 on at most `max_train` points) -- Bt independent instances, each with its own GP over a window
+    of the `window` most recent observations.
+
+    schedule = "online" (default): every step ONE pass over every instance's factor answers the control step's posterior
+        query AND the forward solve of the new observation's in-place append (`ReservedGP.append(query=...)`), then the fused
+        task rows / terms / SOCP / plant-step launch; when `refit_every` new points have entered, the oldest `refit_every`
+        leave and the window is refactored from the data (`ReservedGP(window, drop=refit_every)`): the model the controller
+        queries is never more than zero steps old.
+    schedule = "reference": the reference's cadence -- the GP is STATIC between refits (the headline control step,
+        `bcbf_unicycle_control_step`: posterior pass + solve), observations only land in a buffer, every `refit_every`-th step
+        the last `window` buffered points are refactored (`bcbf_refit` + `bcbf_potrs`).
+
+    `warmup` untimed steps (rounded up to whole refit periods so that the timed region starts right after a refit), then
+    `steps` timed steps (a multiple of refit_every: every timed period holds exactly one refit) between two device
+    synchronisations.  Returns the timings (wall clock for the total; HIP events for the shares), a roofline entry per
+    kernel, and the final state for the parity checks: `final` = dict(rgp | gp tensors, raw window rows, query states)."""
+    import time
+    from .synthetic import make_instances, make_unicycle_task
+    dev = torch.device(device)
+    if steps % refit_every or steps <= 0:
+        raise ValueError("steps must be a positive multiple of refit_every")
+    warmup = -(-warmup // refit_every) * refit_every
+    total = warmup + steps
+    p = make_instances(Bt, window + total, n, m, dtype=dtype, device=dev, seed=seed)
+    task = make_unicycle_task(Bt, dtype=dtype, device=dev, seed=seed + 99)
+    cut = lambda t, N: t[:, :N].contiguous()
+    jit0 = cut(p["jitter"], window)
+    for attempt in range(4):                                   # make_psd's retry (control_affine_model.py:899-921)
+        Lop, UHB, info, _ = ops.refit(cut(p["X"], window), cut(p["UH"], window), p["Bm"], p["ell"], p["s2"], jit0)
+        bad = info != 0
+        if not bool(bad.any()):
+            break
+        jit0 = torch.where(bad[:, None], jit0 * 10, jit0).contiguous()
+    assert int((info != 0).sum()) == 0, "initial refit failed"
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], window), cut(p["UH"], window), p["M0"], want_alpha=False)
+    isz = p["X"].element_size()
+    A = p["A"]
+    ws = ops.control_workspace(Bt, 2, dtype, dev)
+    x = task["x"].clone()
+    dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
+    obs = [t.transpose(0, 1).contiguous() for t in (p["X"], p["UH"], p["Xdot"], p["jitter"])]     # [N][Bt, .]
+    fails = torch.zeros((), dtype=torch.int64, device=dev)
+    online = schedule == "online"
+    if online:
+        rgp = ops.ReservedGP(Lop, Vw, cut(p["X"], window), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + refit_every,
+                             window=window, drop=refit_every, UH=cut(p["UH"], window), Xdot=cut(p["Xdot"], window), jitter=jit0)
+        del Lop, Vw, UHB
+        solve = ops.unicycle_control_step_prepare(dict(A=A), task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
+                                                  clf_gamma=10.0, max_iters=20)
+    elif schedule == "reference":
+        gp = dict(Lop=Lop, Vw=Vw, X=cut(p["X"], window), UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=A)
+        jit_w = jit0
+        lo = 0
+        step_fn = ops.unicycle_control_step_prepare(gp, task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
+                                                    clf_gamma=10.0, max_iters=20)
+    else:
+        raise ValueError("schedule: 'online' or 'reference'")
+    E = lambda: torch.cuda.Event(enable_timing=True)
+    ev = [[E(), E(), E(), E()] for _ in range(total)]          # step start / pass end / solve end / (refit end)
+    refit_steps = []
+    t0 = None
+    for t in range(total):
+        if t == warmup:
+            if barrier is not None:
+                barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        N_obs = window + t
+        e = ev[t]
+        e[0].record()
+        if online:
+            drops_before = rgp.drops
+            info, _, _ = rgp.append(obs[0][N_obs], obs[1][N_obs], obs[2][N_obs], obs[3][N_obs], query=x, out=(ws["Mk"], ws["Bk"]))
+            # (the window's drop + refit, when this append filled it, ran inside append -- timed below as its own share)
+            e[1].record()
+            solve()
+            e[2].record()
+            fails += (info != 0).sum()
+            if rgp.drops != drops_before:
+                refit_steps.append(t)
+        else:
+            step_fn(e[0], e[1])                                  # (events around the posterior launch, on its stream)
+            e[2].record()
+            if (t + 1) % refit_every == 0:
+                lo = t + 1
+                sl = slice(lo, lo + window)
+                Xw, UHw, Yw = (p[k][:, sl].contiguous() for k in ("X", "UH", "Xdot"))
+                jit_w = p["jitter"][:, sl].contiguous()
+                for attempt in range(4):
+                    ops.refit(Xw, UHw, p["Bm"], p["ell"], p["s2"], jit_w, out=(gp["Lop"], gp["UHB"], info))
+                    bad = info != 0
+                    if not bool(bad.any()):
+                        break
+                    jit_w = torch.where(bad[:, None], jit_w * 10, jit_w).contiguous()
+                ops.potrs(gp["Lop"], Yw, UHw, p["M0"], want_alpha=False, out_Vw=gp["Vw"])
+                gp["X"].copy_(Xw)
+                fails += (info != 0).sum()
+                e[3].record()
+                refit_steps.append(t)
+    torch.cuda.synchronize(dev)
+    if barrier is not None:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    timed = range(warmup, total)
+    if online:
+        # the append (+ the drop/refit on refit steps) sits between e[0] and e[1]; a refit step's own share = its interval minus
+        # the mean interval of the other steps at a comparable N
+        tr = set(refit_steps)
+        plain = [ev[t][0].elapsed_time(ev[t][1]) for t in timed if t not in tr]
+        withr = [ev[t][0].elapsed_time(ev[t][1]) for t in timed if t in tr]
+        pass_ms = sum(plain) / max(1, len(plain))
+        refit_ms = (sum(withr) / max(1, len(withr)) - pass_ms) if withr else 0.0
+        n_refits = len(withr)
+    else:
+        pass_ms = sum(ev[t][0].elapsed_time(ev[t][1]) for t in timed) / steps
+        rs = [t for t in refit_steps if t >= warmup]
+        refit_ms = sum(ev[t][2].elapsed_time(ev[t][3]) for t in rs) / max(1, len(rs))
+        n_refits = len(rs)
+    solve_ms = sum(ev[t][1].elapsed_time(ev[t][2]) for t in timed) / steps
+    ms_step = elapsed / steps * 1e3
+    # roofline entries.  pass: every instance's packed factor + whitened targets + inputs + UH B rows read once at the live N
+    if online:
+        live = [window + (t % refit_every) for t in timed if t not in set(refit_steps)]
+        pass_bytes = sum(online_pass_bytes(N, n, m, isz) for N in live) / max(1, len(live)) * Bt
+        pass_kernel = "posterior_step_kernel<%s, %d, 4, 0, 1, false, 1> + gp_append_inplace_kernel" % ("float" if isz == 4 else "double", 1 + m)
+    else:
+        pass_bytes = isz * (window * (window + 1) // 2 + 2 * window * n + window * (1 + m)) * Bt
+        pass_kernel = "posterior_step_kernel<%s, %d, 4, 0, 1, false, 0>" % ("float" if isz == 4 else "double", 1 + m)
+    peak_t = 157.3 if isz == 4 else 78.6
+    refit_flops = Bt * window ** 3 / 3.0
+    roof = {"pass": dict(bound="hbm", kernel=pass_kernel, algorithmic_bytes_per_launch=pass_bytes,
+                         achieved=pass_bytes / (pass_ms * 1e-3) / 1e9, peak=8000.0, unit="GB/s",
+                         frac=pass_bytes / (pass_ms * 1e-3) / 1e9 / 8000.0, kernel_ms=pass_ms, traffic=None),
+            "refit": dict(bound="mfma", kernel="refit_wave_kernel<%s, ...> (+ bcbf_potrs%s)" % ("float" if isz == 4 else "double",
+                                                                                                ", row moves, bcbf_gp_reserve" if online else ""),
+                          algorithmic_flops_per_launch=refit_flops, achieved=refit_flops / (refit_ms * 1e-3) / 1e12 if refit_ms > 0 else None,
+                          peak=peak_t, unit="TFLOP/s", frac=refit_flops / (refit_ms * 1e-3) / 1e12 / peak_t if refit_ms > 0 else None,
+                          kernel_ms=refit_ms, traffic=None,
+                          note="over the WHOLE refit share of a refit step (every launch of it), a lower bound on the kernel's own rate")}
+    out = dict(schedule=schedule, batch=Bt, window=window, steps=steps, warmup=warmup, refit_every=refit_every, dtype=str(dtype),
+               seconds=elapsed, ms_per_step=ms_step, instance_steps_per_s=Bt * steps / elapsed,
+               shares=dict(pass_ms_per_step=pass_ms, solve_ms_per_step=solve_ms, refit_ms_per_refit=refit_ms,
+                           refit_ms_per_step=refit_ms * n_refits / steps, refits_in_timed_region=n_refits,
+                           other_ms_per_step=ms_step - pass_ms - solve_ms - refit_ms * n_refits / steps),
+               roofline=roof, append_or_refit_failures=int(fails), solver_optimal_fraction=float((ws["status"] == 0).float().mean()))
+    if online:
+        out["drop_failures"] = rgp.drop_failures
+        lo = window + total - rgp.N
+        final = dict(rgp=rgp, lo=lo, N=rgp.N, jitter=rgp._rJ[:, :rgp.N])
+    else:
+        final = dict(gp=gp, lo=lo, N=window, jitter=jit_w)
+    final.update(p=p, x=x, ws=ws)
+    return out, final
+
+
+def final_window_vs_device_refit(final, sample=64):
+    """Self-check of a learning loop's final model (any dtype) against a from-scratch fp64 refit ON THE DEVICE of the same
+    window rows with the jitter every point ended up with: max deviation of the posterior at the instances' query points over
+    `sample` instances spread over the batch, relative to max(1, |M_k|) and to the prior scale.  (The parity check against
+    the CPU oracle lives in tests/.)"""
+    p, lo, N = final["p"], final["lo"], final["N"]
+    Bt = p["X"].shape[0]
+    idx = torch.linspace(0, Bt - 1, min(sample, Bt), device=p["X"].device).long()
+    f64 = lambda t: t.double().contiguous()
+    sel = lambda k: f64(p[k][idx, lo:lo + N])
+    hp = {k: f64(p[k][idx]) for k in ("Bm", "ell", "s2", "M0", "xq")}
+    Lr, UHBr, info, _ = ops.refit(sel("X"), sel("UH"), hp["Bm"], hp["ell"], hp["s2"], f64(final["jitter"][idx]))
+    Vr, _ = ops.potrs(Lr, sel("Xdot"), sel("UH"), hp["M0"], want_alpha=False)
+    Mr, Br = ops.posterior_step(Lr, Vr, sel("X"), UHBr, hp["ell"], hp["s2"], hp["Bm"], hp["M0"], hp["xq"])
+    if "rgp" in final:
+        Mk, Bk = final["rgp"].posterior(p["xq"])
+    else:
+        g = final["gp"]
+        Mk, Bk = ops.posterior_step(g["Lop"], g["Vw"], g["X"], g["UHB"], g["ell"], g["s2"], g["Bm"], g["M0"], p["xq"])
+    prior = (hp["s2"][:, None, None] * hp["Bm"]).abs().amax(dim=(1, 2))
+    return dict(instances=int(idx.numel()), refit_failures=int((info != 0).sum()),
+                Mk=float(((f64(Mk[idx]) - Mr).abs().amax(dim=(1, 2)) / Mr.abs().amax(dim=(1, 2)).clamp(min=1.0)).max()),
+                Bk=float(((f64(Bk[idx]) - Br).abs().amax(dim=(1, 2)) / prior).max()))

@@ -398,6 +398,10 @@ int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X
  * (gp_algebra.py:384-392): hessian_mode 0 = the reference's formula `eigenvectors.T @ diag(evalz) @ eigenvectors` on the
  * eigenvectors of the GENERAL solver (xGEEV's order and signs, csrc/geev_small.h); 1 = the spectral projection
  * V max(L,0) V' of the symmetric part (what rounds 1-3 did; differs from the reference whenever the branch runs).
+ * WHICH branch runs (mode 0) is decided as the reference decides it, from the real parts of the general solver's
+ * eigenvalues of H itself (`evalz > -EPS`, `evalz < 0`); only a symmetric part that is positive definite by a wide margin
+ * (unpivoted Cholesky, every pivot > 1e-10 of the trace) skips the solver, and only a complex pair / non-convergence falls
+ * back to the eigenvalues of the symmetric part (status 6).
  * kernel_kind: the data kernel the jets came from, 0 = RBF (the reference's), 1 = Matern-5/2 (its prior term
  * d2 k / dx_d dx'_d at x' = x is (5/3) s2 / ell_d^2 instead of s2 / ell_d^2).
  * status[Bt] (optional): 0 = nothing to clean, 1 = an eigenvalue <= -2e-3 (the reference asserts), 4 = eigenvalues in

@@ -96,6 +96,21 @@ def test_visible_gpu_count_reads_the_driver_topology_not_hip(tmp_path, monkeypat
     assert D.visible_gpu_count(nodes, dev) == (8, "sysfs")
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3")
     assert D.visible_gpu_count(nodes, dev) == (2, "sysfs")
+    # both filters apply: ROCr narrows the enumeration to 4 devices, HIP then indexes into THAT list (index 5 is out of range)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2,3")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3,5")
+    assert D.visible_gpu_count(nodes, dev) == (2, "sysfs")
+    # a negative entry hides everything after it; an unparsable one likewise; repeats count once
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,-1,2,3")
+    assert D.visible_gpu_count(nodes, dev) == (1, "sysfs")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "-1")
+    assert D.visible_gpu_count(nodes, dev) == (0, "sysfs")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,2,x,4")
+    assert D.visible_gpu_count(nodes, dev) == (1, "sysfs")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "0,1,2,9")
+    assert D.visible_gpu_count(nodes, dev) == (3, "sysfs")
 
 
 _RANK_SCRIPT = """import os, sys

@@ -155,3 +155,58 @@ def test_eigenpairs_are_eigenpairs_and_status_codes(host):
     assert rc == 4 and np.allclose(H, np.diag([1.0, 0.0, 2.0]))
     rot = np.array([[0.0, 1.0], [-1.0, 0.0]])                      # complex pair: the general solver's path is refused
     assert host.eig(rot)[0] == 2
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_branch_decision_on_the_boundaries_follows_the_general_eigenvalues(host, n):
+    """Which branch runs (status 0 untouched / 4 cleaned / 1 the reference's assert) is decided from the real parts of the
+    GENERAL eigen-solver's eigenvalues of H itself, as gp_algebra.py:385-387 does -- also for an H that is non-symmetric by
+    rounding, right next to the -EPS assert boundary and with an eigenvalue within 1e-15 of zero (where the eigenvalues of the
+    symmetric part can land on the other side).  Compared with the reference's statements on torch.linalg.eig; cases on which
+    torch's and numpy's LAPACK builds themselves put an eigenvalue on different sides are skipped (nothing is defined)."""
+    rng = np.random.RandomState(900 + n)
+    EPS = 2e-3
+    checked = dict(assert_=0, fired=0, untouched=0, skipped=0)
+    for t in range(1200):
+        Q, _ = np.linalg.qr(rng.randn(n, n))
+        w = np.abs(rng.randn(n)) + 0.05 * (1 + np.arange(n))
+        kind = t % 6
+        if kind == 0:
+            w[0] = -EPS * (1 + rng.uniform(1e-9, 1e-3))            # just beyond the assert boundary
+        elif kind == 1:
+            w[0] = -EPS * (1 - rng.uniform(1e-9, 1e-3))            # just inside it: cleaned
+        elif kind == 2:
+            w[0] = rng.uniform(-1e-15, 1e-15)                       # an eigenvalue that rounds to either side of zero
+        elif kind == 3:
+            w[0] = -rng.uniform(1e-14, 1e-12)
+        elif kind == 4:
+            w[0] = rng.uniform(1e-14, 1e-12)
+        else:
+            w[0] = -rng.uniform(1e-6, 1.9e-3)
+        M = (Q * w) @ Q.T
+        if t % 2:
+            M = M + 1e-16 * np.abs(M).max() * rng.randn(n, n)      # asymmetric by rounding (what autograd leaves)
+        ev_t = np.real(torch_eig(M)[0])
+        ev_n = np.real(np.linalg.eig(M)[0])
+        side = lambda ev: ((ev <= -EPS).any(), (ev < 0).any())
+        if side(ev_t) != side(ev_n):
+            checked["skipped"] += 1
+            continue
+        rc, H = host.clean(M)
+        bad, neg = side(ev_t)
+        # (any solver's eigenvalues carry a rounding error of a few eps |M|: a case whose deciding eigenvalue is within
+        #  5e-16 |M| of the boundary may legitimately land on the other side -- only then is a disagreement accepted; the
+        #  1e-14 .. 1e-12 kinds and both sides of -EPS at relative distance >= 1e-9 are asserted strictly)
+        margin = min(np.abs(ev_t + EPS).min(), np.abs(ev_t).min())
+        if bad:
+            ok = rc == 1 and np.array_equal(H, M)
+            checked["assert_"] += 1
+        elif neg:
+            ok = rc in (4, 6)
+            checked["fired"] += 1
+        else:
+            ok = rc == 0 and np.array_equal(H, M)
+            checked["untouched"] += 1
+        assert ok or margin < 5e-16 * max(1.0, np.abs(M).max()), (kind, rc, ev_t, M)
+    print(n, checked)
+    assert checked["assert_"] > 100 and checked["fired"] > 300 and checked["untouched"] > 100

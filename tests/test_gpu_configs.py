@@ -454,6 +454,65 @@ def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
                 g.append(x_new.contiguous(), uh_new.contiguous(), xd_new.contiguous(), jit_new)
 
 
+# ------------------------------------------------------------------------------------------------ learning closed loop
+def _learning_loop_final_vs_oracle(final, idx, tol, ops):
+    p, lo, N = final["p"], final["lo"], final["N"]
+    if "rgp" in final:
+        Mk, Bk = final["rgp"].posterior(p["xq"])
+    else:
+        g = final["gp"]
+        Mk, Bk = ops.posterior_step(g["Lop"], g["Vw"], g["X"], g["UHB"], g["ell"], g["s2"], g["Bm"], g["M0"], p["xq"])
+    Mk, Bk, jit = host(Mk), host(Bk), host(final["jitter"])
+    h = {k: host(p[k][idx]) for k in ("X", "U", "Xdot", "Bm", "ell", "s2", "M0", "xq")}
+    worst = [0.0, 0.0]
+    for j, i in enumerate(idx):
+        st = ogp.refit_state(h["X"][j][lo:lo + N], h["U"][j][lo:lo + N], h["Xdot"][j][lo:lo + N], h["Bm"][j], h["ell"][j], h["s2"][j],
+                             h["M0"][j], jit[i][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][j][lo:lo + N][None], st["UHB"][None], h["ell"][j][None],
+                                        h["s2"][j][None], h["Bm"][j][None], h["M0"][j][None], h["xq"][j][None])
+        prior = float(h["s2"][j] * np.abs(h["Bm"][j]).max())
+        rel_close(Mk[i], Mk_o[0], tol, scale=max(1.0, np.abs(Mk_o).max()), what="learning loop Mk")
+        rel_close(Bk[i], Bk_o[0], tol, scale=prior, what="learning loop Bk")
+        worst = [max(worst[0], np.abs(Mk[i] - Mk_o[0]).max() / max(1.0, np.abs(Mk_o).max())), max(worst[1], np.abs(Bk[i] - Bk_o[0]).max() / prior)]
+    return worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("schedule", ["online", "reference"])
+def test_learning_closed_loop_final_model_vs_oracle_refit_of_the_final_window(ops, schedule, dtype):
+    """The learning closed loop (rollouts.learning_closed_loop; the reference's train(): buffer every step, refit every
+    `train_every_n_steps`, unicycle_move_to_pose.py:340-386) at a small size, both schedules: after 3 refit periods + 17
+    more steps' worth of warm-up rounding the model every instance queries equals the oracle's from-scratch refit of the same
+    window rows -- fp64 1e-7, fp32 1e-3 (north_star) -- and no append / refit failed."""
+    from bayesian_cbf_amd.rollouts import learning_closed_loop
+    out, final = learning_closed_loop(Bt=24, window=96, steps=48, refit_every=24, warmup=17, dtype=dtype, device=DEV, seed=7,
+                                      schedule=schedule)
+    assert out["append_or_refit_failures"] == 0 and out["warmup"] == 24 and out["shares"]["refits_in_timed_region"] == 2
+    assert final["N"] == (96 if schedule == "reference" else final["rgp"].N) and 96 <= final["N"] < 96 + 24
+    worst = _learning_loop_final_vs_oracle(final, list(range(24)), 1e-7 if dtype == torch.float64 else 1e-3, ops)
+    assert out["solver_optimal_fraction"] > 0.5 and out["instance_steps_per_s"] > 0
+    print("learning loop %s %s: worst |dMk| %.2e, |dBk| %.2e" % (schedule, dtype, worst[0], worst[1]))
+
+
+def test_learning_closed_loop_c3_scale_sampled_instances_vs_oracle(ops):
+    """The same at BASELINE configs[2] scale (4096 instances, window 512, fp32, refit every 40): one warm-up period + one
+    timed period, 64 instances spread over the batch against the oracle refit of their final window at 1e-3; the line the
+    bench tool prints carries a roofline entry per kernel."""
+    from bayesian_cbf_amd.rollouts import learning_closed_loop, final_window_vs_device_refit
+    out, final = learning_closed_loop(Bt=4096, window=512, steps=40, refit_every=40, warmup=40, dtype=torch.float32, device=DEV,
+                                      seed=1234, schedule="online")
+    assert out["append_or_refit_failures"] == 0 and out.get("drop_failures", 0) == 0
+    idx = [int(v) for v in np.linspace(0, 4095, 64)]
+    worst = _learning_loop_final_vs_oracle(final, idx, 1e-3, ops)
+    chk = final_window_vs_device_refit(final)
+    assert chk["Mk"] <= 1e-3 and chk["Bk"] <= 1e-3 and chk["refit_failures"] == 0
+    rf = out["roofline"]
+    assert rf["pass"]["bound"] == "hbm" and 0 < rf["pass"]["frac"] <= 1 and rf["refit"]["bound"] == "mfma" and 0 < rf["refit"]["frac"] <= 1
+    print("learning loop C3 scale: %.2f M instance-steps/s with learning, pass %.3f ms (%.0f%% HBM), solve %.3f, refit %.2f ms/refit; "
+          "worst |dMk| %.2e |dBk| %.2e" % (out["instance_steps_per_s"] / 1e6, out["shares"]["pass_ms_per_step"], 100 * rf["pass"]["frac"],
+                                          out["shares"]["solve_ms_per_step"], out["shares"]["refit_ms_per_refit"], worst[0], worst[1]))
+
+
 # ------------------------------------------------------------------------------------------------ C1
 def test_c1_pendulum_learn_dynamics_matrix_vector_N64(ops):
     """BASELINE config 1 (`pendulum.learn_dynamics_matrix_vector`, N_train = 64): the experiment runs end to end on the

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""The learning closed loop at BASELINE configs[2] scale (the reference's real workload,
+unicycle_move_to_pose.py:340-386): `--batch` independent control loops PER GPU, each with its own GP over a window of the
+`--window` most recent observations; every step = one control step + one new observation per instance, every
+`--refit-every`-th step the window is refactored.  `--schedule online` (default; the posterior query and the in-place append
+share one pass over the factor) or `reference` (static GP between refits, the headline control step).
+
+    python tools/bench_learning_loop.py                          # 4096 x 512, fp32, 200 timed steps, refit every 40
+    python tools/bench_learning_loop.py --gpus 8                 # starts its 8 ranks itself (weak scaling, no collective in the loop)
+    python bench.py --config learn [same flags]
+
+Rank 0 prints ONE JSON line: instance-steps/s WITH learning over all ranks (slowest rank's time), the shares of the pass /
+solve / refit, a roofline entry per kernel, and the self-check of the final model against a from-scratch fp64 refit of the
+final window on the device (the oracle parity of the same loop: tests/test_gpu_configs.py)."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+ap.add_argument("--window", type=int, default=512)
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--warmup", type=int, default=40)
+ap.add_argument("--refit-every", type=int, default=40)
+ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+ap.add_argument("--schedule", choices=["online", "reference"], default="online")
+a = ap.parse_args()
+if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
+    from bayesian_cbf_amd.distributed import launch_ranks
+    sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+from bayesian_cbf_amd.distributed import RankContext
+from bayesian_cbf_amd.rollouts import learning_closed_loop, final_window_vs_device_refit
+ctx = RankContext()
+out, final = learning_closed_loop(a.batch, a.window, a.steps, a.refit_every, warmup=a.warmup,
+                                  dtype=torch.float32 if a.dtype == "f32" else torch.float64, device=ctx.device,
+                                  seed=1234 + ctx.rank, schedule=a.schedule, barrier=ctx.barrier)
+chk = final_window_vs_device_refit(final)
+el, per_rank = ctx.reduce_times(out["seconds"])
+fails = ctx.reduce_sum([out["append_or_refit_failures"]])
+if ctx.rank == 0:
+    total = a.batch * ctx.world
+    out.update(metric="control steps/sec WITH learning (GP posterior + append + CBF-QP, window refit every %d steps) at "
+                      "N_train=%d, batch=%d" % (a.refit_every, a.window, a.batch),
+               value=total * a.steps / el, unit="control steps/s (instance-steps)", n_gpus=ctx.world, ms_per_step=el / a.steps * 1e3,
+               seconds=el, instance_steps_per_s=total * a.steps / el, higher_is_better=True, scaling="weak", data="synthetic",
+               comm=ctx.comm_info(per_rank), append_or_refit_failures=int(fails[0]), final_vs_fp64_refit_on_device=chk)
+    print(json.dumps(out), flush=True)
+ctx.close()
