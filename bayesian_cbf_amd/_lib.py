@@ -22,6 +22,8 @@ _SIGS = {
     "bcbf_lop_elems_f64": (c_size_t, [c_int]),
     "bcbf_posterior_shared_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_posterior_shared_f64": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
+    "bcbf_posterior_shared_matern52_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
+    "bcbf_posterior_shared_matern52_f64": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_rows": (c_int, [ctypes.POINTER(c_int), c_int, c_int, c_int]),
     "bcbf_controller_cones_f32": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_f64": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
@@ -65,6 +67,7 @@ _TSIGS = {
     "bcbf_unicycle_step": [P, P, "T", "T", c_int, P],
     "bcbf_rollout_stats": [P] * 8 + [c_int, c_int, c_int, P],
     "bcbf_unicycle_control_step": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "bcbf_unicycle_control_step_matern52": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
 }
 
 

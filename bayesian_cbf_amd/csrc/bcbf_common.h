@@ -53,7 +53,7 @@ bool posterior_shared_reg32_fits(int N, int n, int m);   // the same form in fp3
 template <typename T>
 int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                 const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk, T* W, int nq,
-                                int N, int n, int m, void* stream);
+                                int N, int n, int m, void* stream, int kind = 0);   // kind: 0 RBF, 1 Matern-5/2
 
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll

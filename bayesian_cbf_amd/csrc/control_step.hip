@@ -14,8 +14,8 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
 
 // Two launches per step: the posterior kernel, then ONE kernel that forms the task rows (CLC + obstacle CBCs) from the
 // state, the chance-constraint terms and cones from (M_k, B_k), solves the SOCP and advances the plant.
-#define BCBF_CTRL(T, SUF)                                                                                              \
-    extern "C" int bcbf_unicycle_control_step_##SUF(                                                                   \
+#define BCBF_CTRL(T, SUF, NAME, QUERY, STEP)                                                                           \
+    extern "C" int NAME##SUF(                                                                                          \
         const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0,     \
         const T* A, T* x, const T* plan, const T* dot_plan, const T* Kp, T clf_gamma, const T* centers,               \
         const T* radii, const T* tw, const T* gammas, T L_mean, const T* w, const T* r, const T* sign,                \
@@ -27,10 +27,9 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
         hipStream_t st = (hipStream_t)stream;                                                                          \
         if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);                                                  \
         /* Lop == NULL: no learned model in the loop -- (Mk, Bk) are the caller's (fixed-kernel model: 0 and I) */    \
-        int rc = !Lop ? BCBF_OK : shared_gp ? bcbf_posterior_query_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, \
+        int rc = !Lop ? BCBF_OK : shared_gp ? QUERY##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, \
                                                         1, Bt, N, 3, 2, stream)                                        \
-                           : bcbf_posterior_step_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, Bt, N, 3, \
-                                                       2, stream);                                                     \
+                           : STEP;                                                                                     \
         if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);                                                    \
         if (rc) return rc;                                                                                             \
         bcbf::UnicycleTask<T> task{x, plan, dot_plan, Kp, centers, radii, tw, gammas, clf_gamma, L_mean, dt, L_true,   \
@@ -38,5 +37,12 @@ int launch_unicycle_socp(const T* Mk, const T* Bk, const T* A, const T* sign, co
         return bcbf::launch_unicycle_socp<T>(Mk, Bk, A, sign, w, r, relax_mask, rho, cones, cstatus, y, status, iters, \
                                              Bt, max_iters, task, stream);                                             \
     }
-BCBF_CTRL(float, f32)
-BCBF_CTRL(double, f64)
+#define BCBF_STEP_RBF(SUF) bcbf_posterior_step_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, Bt, N, 3, 2, stream)
+#define BCBF_STEP_M52(SUF) bcbf_posterior_query_matern52_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, 0, Bt, N, 3, 2, stream)
+BCBF_CTRL(float, f32, bcbf_unicycle_control_step_, bcbf_posterior_query_, BCBF_STEP_RBF(f32))
+BCBF_CTRL(double, f64, bcbf_unicycle_control_step_, bcbf_posterior_query_, BCBF_STEP_RBF(f64))
+// The same step on a model learned with the opt-in Matern-5/2 data kernel (bcbf.h: *_matern52; parity unpinned -- the
+// reference has no Matern kernel): the posterior launch evaluates that kernel (one GP per instance: the streaming kernel;
+// shared_gp: the matrix-core query), everything behind it is the same launch
+BCBF_CTRL(float, f32, bcbf_unicycle_control_step_matern52_, bcbf_posterior_query_matern52_, BCBF_STEP_M52(f32))
+BCBF_CTRL(double, f64, bcbf_unicycle_control_step_matern52_, bcbf_posterior_query_matern52_, BCBF_STEP_M52(f64))

@@ -36,7 +36,8 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
                         const float* __restrict__ UHB, const float* __restrict__ ell, const float* __restrict__ s2p,
                         const float* __restrict__ Bm, const float* __restrict__ M0, const float* __restrict__ xq,
                         const float* __restrict__ jitter2, float* __restrict__ Mk, float* __restrict__ Bk,
-                        float* __restrict__ Wout, int nq, int N, int Np, int n) {
+                        float* __restrict__ Wout, int nq, int N, int Np, int n, int kind) {
+    // kind: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_posterior_shared_matern52; wave-uniform)
     constexpr int V = 4, QW = 4;                      // queries per wave
     extern __shared__ float smem[];
     const int nwave = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -120,7 +121,10 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
             float d2 = 0.f;
 #pragma unroll
             for (int d = 0; d < NS; ++d) { const float z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
-            const float kmine = s2 * __expf(-0.5f * d2);
+            float shape;
+            if (kind == 1) { const float a5 = sqrtf(5.f * d2); shape = (1.f + a5 + (5.f / 3.f) * d2) * __expf(-a5); }
+            else shape = __expf(-0.5f * d2);
+            const float kmine = s2 * shape;
             const float kk[4] = {dpp_q<0x00>(kmine), dpp_q<0x55>(kmine), dpp_q<0xAA>(kmine), dpp_q<0xFF>(kmine)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) phin[u * 4 + r] = kk[r] * Us[(I * NB + blk_row(u, g, r)) * C + cc] * cmask;
@@ -291,7 +295,7 @@ template <int C, int NS>
 static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Lop, const float* Vw,
                           const float* X, const float* UHB, const float* ell, const float* s2, const float* Bm,
                           const float* M0, const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
-                          int nq, int N, int Np, int n) {
+                          int nq, int N, int Np, int n, int kind) {
     if (W != nullptr) {
         static int lds_opt_in_dev[64] = {0};          // largest dynamic LDS size opted into, per device
         int dev_ = 0;
@@ -303,7 +307,7 @@ static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, con
             lds_opt_in = (int)lds;
         }
         hipLaunchKernelGGL((posterior_shared_kernel<C, NS, true>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
-                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind);
     } else {
         static int lds_opt_in_dev[64] = {0};          // largest dynamic LDS size opted into, per device
         int dev_ = 0;
@@ -315,7 +319,7 @@ static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, con
             lds_opt_in = (int)lds;
         }
         hipLaunchKernelGGL((posterior_shared_kernel<C, NS, false>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
-                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind);
     }
 }
 
@@ -323,8 +327,8 @@ template <int C>
 static void launch_shared_c(int NSp, dim3 grid, dim3 block, size_t lds, hipStream_t st, const float* Lop,
                             const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
                             const float* Bm, const float* M0, const float* xq, const float* jitter2, float* Mk,
-                            float* Bk, float* W, int nq, int N, int Np, int n) {
-#define BCBF_PSH(NSV) launch_shared<C, NSV>(grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
+                            float* Bk, float* W, int nq, int N, int Np, int n, int kind) {
+#define BCBF_PSH(NSV) launch_shared<C, NSV>(grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind)
     switch (NSp) {
         case 1: BCBF_PSH(1); break;
         case 2: BCBF_PSH(2); break;
@@ -338,10 +342,10 @@ static void launch_shared_c(int NSp, dim3 grid, dim3 block, size_t lds, hipStrea
 
 }  // namespace bcbf
 
-extern "C" int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
-                                         const float* ell, const float* s2, const float* Bm, const float* M0,
-                                         const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
-                                         int nq, int N, int n, int m, void* stream) {
+static int posterior_shared_f32_impl(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                     const float* ell, const float* s2, const float* Bm, const float* M0,
+                                     const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                     int nq, int N, int n, int m, void* stream, int kind) {
     using namespace bcbf;
     if (nq <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
@@ -350,7 +354,7 @@ extern "C" int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, cons
     // file's kernel (W slab in LDS) for comparisons
     static const int use_reg = [] { const char* e = getenv("BCBF_SHARED_REG"); return e ? atoi(e) : 1; }();
     if (use_reg && posterior_shared_reg32_fits(N, n, m))
-        return launch_posterior_shared_reg<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream);
+        return launch_posterior_shared_reg<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, kind);
     const int Np = round_up(N, NB), C = m + 1, NSp = padded_state_dim(n);
     if (!posterior_shared_fits(N, n, m)) return BCBF_EINVAL;      // the W slab of a wave lives in LDS
     const size_t stage = (size_t)Np * (2 * NSp + C) * sizeof(float), slab = (size_t)Np * 16 * sizeof(float);
@@ -363,9 +367,22 @@ extern "C" int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, cons
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((waves + nwave - 1) / nwave), block(64 * nwave);
     switch (m) {
-        case 1: launch_shared_c<2>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
-        case 2: launch_shared_c<3>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
-        default: launch_shared_c<4>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 1: launch_shared_c<2>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
+        case 2: launch_shared_c<3>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
+        default: launch_shared_c<4>(NSp, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
     }
     return check_launch("posterior_shared");
+}
+extern "C" int bcbf_posterior_shared_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                         const float* ell, const float* s2, const float* Bm, const float* M0,
+                                         const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                         int nq, int N, int n, int m, void* stream) {
+    return posterior_shared_f32_impl(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 0);
+}
+// ... with the opt-in Matern-5/2 data kernel (parity unpinned: the reference has no Matern kernel)
+extern "C" int bcbf_posterior_shared_matern52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                                  const float* ell, const float* s2, const float* Bm, const float* M0,
+                                                  const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                                  int nq, int N, int n, int m, void* stream) {
+    return posterior_shared_f32_impl(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 1);
 }

@@ -149,7 +149,8 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
                             const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                             const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                             const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
-                            T* __restrict__ Wout, int nq, int N, int Np, int n) {
+                            T* __restrict__ Wout, int nq, int N, int Np, int n, int kind) {
+    // kind: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_posterior_shared_matern52; wave-uniform)
     using P = PSR<T>;
     using acc_t = typename P::acc_t;
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
@@ -287,6 +288,14 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     // evaluates the row that register 4u + c holds.  It does not depend on the accumulation, so it is formed during the
     // LAST off-diagonal tile of the row, beside that tile's MFMAs (in the diagonal step every MFMA waits for it)
     T phi[8];
+    // shape of the data kernel at squared scaled distance d2: exp(-d2 / 2), or Matern-5/2 (1 + a + a^2 / 3) exp(-a), a = sqrt(5 d2)
+    auto kshape = [&](T d2) -> T {
+        if (kind == 1) {
+            const T a5 = (T)sqrt((double)(T(5) * d2));
+            return (T(1) + a5 + T(5) / T(3) * d2) * P::exp_(-a5);
+        }
+        return P::exp_(T(-0.5) * d2);
+    };
     auto phi_tile = [&](auto Ic_) {
         constexpr int I = decltype(Ic_)::value;
         if constexpr (QW != 4) {
@@ -300,7 +309,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
                 T d2 = T(0);
 #pragma unroll
                 for (int d = 0; d < NS; ++d) { const T z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
-                km[i] = s2 * P::exp_(T(-0.5) * d2);
+                km[i] = s2 * kshape(d2);
             }
             static_for<0, 8>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
@@ -314,7 +323,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
             T d2 = T(0);
 #pragma unroll
             for (int d = 0; d < NS; ++d) { const T z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
-            const T kmine = s2 * P::exp_(T(-0.5) * d2);
+            const T kmine = s2 * kshape(d2);
             const T kk[4] = {dpp_bc<0x00>(kmine), dpp_bc<0x55>(kmine), dpp_bc<0xAA>(kmine), dpp_bc<0xFF>(kmine)};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -449,7 +458,7 @@ template <typename T> static bool psr_fits(int N, int n, int m) {
 template <typename T, int C, int NS>
 static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X, const T* UHB,
                        const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
-                       T* W, int nq, int N, int Np, int n) {
+                       T* W, int nq, int N, int Np, int n, int kind) {
     // fp32 with enough queries for two waves per SIMD (more than 16 per CU-SIMD: > 4096 on 256 CUs): the 256-register
     // allocation, two workgroups per CU, each wave's stalls under the other's MFMAs.  fp64 needs the full file.
     int dev_ = 0, cus = 256;
@@ -484,7 +493,7 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
             lds_opt_in = (int)lds;
         }
         hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, OCC, QW>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
-                           xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+                           xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind);
     };
     auto go = [&](auto occ) {
         if constexpr (QWD != 4 && BCBF_PSR_QW5) { if (five) { go5(occ, Ic<QWD>{}); return; } }
@@ -504,13 +513,13 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
 template <typename T, int C>
 void launch_psr_c(int NSp, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
                   const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
-                  T* Mk, T* Bk, T* W, int nq, int N, int Np, int n);
+                  T* Mk, T* Bk, T* W, int nq, int N, int Np, int n, int kind);
 #ifndef BCBF_PSR_PART_BASE
 template <typename T, int C>
 void launch_psr_c(int NSp, size_t lds, hipStream_t st, const T* Lop, const T* Vw, const T* X,
                   const T* UHB, const T* ell, const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,
-                  T* Mk, T* Bk, T* W, int nq, int N, int Np, int n) {
-#define BCBF_PSR(NSV) launch_psr<T, C, NSV>(lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n)
+                  T* Mk, T* Bk, T* W, int nq, int N, int Np, int n, int kind) {
+#define BCBF_PSR(NSV) launch_psr<T, C, NSV>(lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind)
     switch (NSp) {
 #ifndef BCBF_PSR_DEV              // (development: the C = 3, NS = 3 instantiations only)
         case 2: BCBF_PSR(2); break;
@@ -531,7 +540,7 @@ void launch_psr_c(int NSp, size_t lds, hipStream_t st, const T* Lop, const T* Vw
 template void launch_psr_c<BCBF_PSR_PT, BCBF_PSR_PART_C>(int, size_t, hipStream_t, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
                                                          const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
                                                          const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*, const BCBF_PSR_PT*,
-                                                         BCBF_PSR_PT*, BCBF_PSR_PT*, BCBF_PSR_PT*, int, int, int, int);
+                                                         BCBF_PSR_PT*, BCBF_PSR_PT*, BCBF_PSR_PT*, int, int, int, int, int);
 #endif
 
 #if !(defined(BCBF_PSR_PART_T) && defined(BCBF_PSR_PART_C))
@@ -541,7 +550,7 @@ bool posterior_shared_reg32_fits(int N, int n, int m) { return psr_fits<float>(N
 template <typename T>
 int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                 const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk, T* W, int nq,
-                                int N, int n, int m, void* stream) {
+                                int N, int n, int m, void* stream, int kind) {
     if (nq <= 0) return BCBF_OK;
     if (!Lop || !Vw || !X || !UHB || !ell || !s2 || !Bm || !M0 || !xq || !Mk || !Bk) return BCBF_EINVAL;
     if (N < 1 || n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > 3) return BCBF_EINVAL;
@@ -551,19 +560,19 @@ int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* 
     hipStream_t st = (hipStream_t)stream;
     switch (m) {
 #ifdef BCBF_PSR_DEV
-        case 2: launch_psr_c<T, 3>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 2: launch_psr_c<T, 3>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
         default: break;
 #else
-        case 1: launch_psr_c<T, 2>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
-        case 2: launch_psr_c<T, 3>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
-        default: launch_psr_c<T, 4>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n); break;
+        case 1: launch_psr_c<T, 2>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
+        case 2: launch_psr_c<T, 3>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
+        default: launch_psr_c<T, 4>(NSp, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind); break;
 #endif
     }
     return check_launch("posterior_shared_reg");
 }
 template int launch_posterior_shared_reg<float>(const float*, const float*, const float*, const float*, const float*, const float*,
                                                 const float*, const float*, const float*, const float*, float*, float*, float*,
-                                                int, int, int, int, void*);
+                                                int, int, int, int, void*, int);
 
 #endif
 }  // namespace bcbf
@@ -573,6 +582,14 @@ extern "C" int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, co
                                          const double* ell, const double* s2, const double* Bm, const double* M0,
                                          const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                          int nq, int N, int n, int m, void* stream) {
-    return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream);
+    return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 0);
+}
+// The same matrix-core query with the opt-in Matern-5/2 data kernel (bcbf_posterior_query_matern52; parity unpinned: the
+// reference has no Matern kernel)
+extern "C" int bcbf_posterior_shared_matern52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                                  const double* ell, const double* s2, const double* Bm, const double* M0,
+                                                  const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                                  int nq, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 1);
 }
 #endif

@@ -970,6 +970,9 @@ extern "C" int bcbf_posterior_query_matern52_f32(const float* Lop, const float* 
                                                  const float* ell, const float* s2, const float* Bm, const float* M0,
                                                  const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                                                  int shared, int Bt, int N, int n, int m, void* stream) {
+    // many queries of one model: the matrix-core kernels (as bcbf_posterior_query does for the RBF kernel)
+    if (shared && Bt >= 16 && bcbf::posterior_shared_fits(N, n, m))
+        return bcbf_posterior_shared_matern52_f32(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, Bt, N, n, m, stream);
     return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream,
                                               nullptr, nullptr, nullptr, 0, 1);
 }
@@ -977,6 +980,8 @@ extern "C" int bcbf_posterior_query_matern52_f64(const double* Lop, const double
                                                  const double* ell, const double* s2, const double* Bm, const double* M0,
                                                  const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                                  int shared, int Bt, int N, int n, int m, void* stream) {
+    if (shared && Bt >= 16 && bcbf::posterior_shared64_fits(N, n, m))
+        return bcbf_posterior_shared_matern52_f64(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, Bt, N, n, m, stream);
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream,
                                                nullptr, nullptr, nullptr, 0, 1);
 }

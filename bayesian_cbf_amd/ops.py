@@ -485,9 +485,12 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
     return Mk, Bk, W
 
 
-def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=False):
+def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=False, kernel="rbf"):
     """b queries against one GP on the matrix cores (GP tensors carry a leading axis of 1; fp64: N <= 512, n <= 4).
-    posterior_query(shared=True) routes here for b >= 16; this entry forces the MFMA kernel for any b."""
+    posterior_query(shared=True) routes here for b >= 16; this entry forces the MFMA kernel for any b.
+    kernel="matern52": the opt-in Matern-5/2 data kernel (bcbf_posterior_shared_matern52)."""
+    if kernel not in DATA_KERNELS:
+        raise ValueError("kernel must be one of %s" % (DATA_KERNELS,))
     _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2)
     if X.dtype == torch.float64 and (X.shape[1] > 512 or X.shape[2] > 4):
         raise ValueError("posterior_shared in fp64 holds the solution in registers: N <= 512, n <= 4 (posterior_query streams the rest)")
@@ -500,7 +503,7 @@ def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=
     Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
     Np = (N + 31) // 32 * 32
     W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
-    fn = lib.bcbf_posterior_shared_f64 if X.dtype == torch.float64 else lib.bcbf_posterior_shared_f32
+    fn = getattr(lib, "bcbf_posterior_shared" + ("_matern52" if kernel == "matern52" else "") + _suf(X))
     check(fn(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq),
              _p(jitter2), _p(Mk), _p(Bk), _p(W), b, N, n, C - 1, _stream(X)), "bcbf_posterior_shared")
     return Mk, Bk, W
@@ -830,10 +833,11 @@ def _unicycle_control_step_composed(gp, task, ws, x, dt, L_true, L_mean, clf_gam
     gp, A, N, shared = _control_step_args(gp, task, ws, x)
     unicycle_constraints(x, task["plan"], task["dot_plan"], task["Kp"], clf_gamma, task["centers"], task["radii"],
                          task["tw"], task["gammas"], L_mean, out=(ws["grad"], ws["cst"], ws["fhat"], ws["ghat"]))
+    kernel = gp.get("kernel", "rbf")
     if gp["Lop"] is not None:
-        if shared:
+        if shared or kernel != "rbf":
             Mk, Bk, _ = posterior_query(gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], gp["ell"], gp["s2"], gp["Bm"], gp["M0"], x,
-                                        shared=True)
+                                        shared=shared, kernel=kernel)
             ws["Mk"].copy_(Mk); ws["Bk"].copy_(Bk)
         else:
             posterior_step(gp["Lop"], gp["Vw"], gp["X"], gp["UHB"], gp["ell"], gp["s2"], gp["Bm"], gp["M0"], x,
@@ -859,7 +863,10 @@ def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.
     gp, A, N, shared = _control_step_args(gp, task, ws, x)
     Bt = x.shape[0]
     Kob = task["centers"].shape[1]
-    fn = getattr(lib, "bcbf_unicycle_control_step" + _suf(x))
+    kernel = gp.get("kernel", "rbf")                       # data kernel of the learned model: "rbf" (the reference's) | "matern52"
+    if kernel not in DATA_KERNELS:
+        raise ValueError("gp['kernel'] must be one of %s" % (DATA_KERNELS,))
+    fn = getattr(lib, "bcbf_unicycle_control_step" + ("_matern52" if kernel == "matern52" else "") + _suf(x))
     head = (_p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
             _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
             _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),

@@ -247,21 +247,23 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
     return out
 
 
-def learning_closed_loop(Bt=4096, window=512, steps=200, refit_every=40, warmup=40, dtype=torch.float32, device="cuda",
+def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warmup=40, dtype=torch.float32, device="cuda",
                          seed=1234, schedule="online", n=3, m=2, barrier=None):
     """The reference's REAL workload at BASELINE configs[2] scale: a control loop that keeps learning
     (`LearnedShiftInvariantDynamics.train`, unicycle_move_to_pose.py:340-386: buffer (x, u) every step, refit every
-    `train_every_n_steps` = 40 on at most `max_train` points) -- Bt independent instances, each with its own GP over a window
-    of the `window` most recent observations.
+    `train_every_n_steps` = 40 on at most `max_train` points) -- Bt independent instances, each with its own GP over the most
+    recent observations, never more than `max_train` of them.
 
     schedule = "online" (default): every step ONE pass over every instance's factor answers the control step's posterior
         query AND the forward solve of the new observation's in-place append (`ReservedGP.append(query=...)`), then the fused
-        task rows / terms / SOCP / plant-step launch; when `refit_every` new points have entered, the oldest `refit_every`
-        leave and the window is refactored from the data (`ReservedGP(window, drop=refit_every)`): the model the controller
-        queries is never more than zero steps old.
+        task rows / terms / SOCP / plant-step launch; when the model holds `max_train` points the oldest `refit_every` leave
+        and the remaining window is refactored from the data (`ReservedGP(window=max_train - refit_every, drop=refit_every)`:
+        the live size runs from max_train - refit_every to max_train - 1, so the padded size -- and with it the workgroup
+        shape of the streaming kernel -- never exceeds max_train's): the model the controller queries is never more than zero
+        steps old.
     schedule = "reference": the reference's cadence -- the GP is STATIC between refits (the headline control step,
         `bcbf_unicycle_control_step`: posterior pass + solve), observations only land in a buffer, every `refit_every`-th step
-        the last `window` buffered points are refactored (`bcbf_refit` + `bcbf_potrs`).
+        the last `max_train` buffered points are refactored (`bcbf_refit` + `bcbf_potrs`).
 
     `warmup` untimed steps (rounded up to whole refit periods so that the timed region starts right after a refit), then
     `steps` timed steps (a multiple of refit_every: every timed period holds exactly one refit) between two device
@@ -274,6 +276,9 @@ def learning_closed_loop(Bt=4096, window=512, steps=200, refit_every=40, warmup=
         raise ValueError("steps must be a positive multiple of refit_every")
     warmup = -(-warmup // refit_every) * refit_every
     total = warmup + steps
+    window = max_train - refit_every if schedule == "online" else max_train      # points the model holds right after a refit
+    if window < 1:
+        raise ValueError("max_train must exceed refit_every")
     p = make_instances(Bt, window + total, n, m, dtype=dtype, device=dev, seed=seed)
     task = make_unicycle_task(Bt, dtype=dtype, device=dev, seed=seed + 99)
     cut = lambda t, N: t[:, :N].contiguous()
@@ -310,6 +315,9 @@ def learning_closed_loop(Bt=4096, window=512, steps=200, refit_every=40, warmup=
         raise ValueError("schedule: 'online' or 'reference'")
     E = lambda: torch.cuda.Event(enable_timing=True)
     ev = [[E(), E(), E(), E()] for _ in range(total)]          # step start / pass end / solve end / (refit end)
+    for row in ev:                                             # (torch creates the hipEvent handle at the first record; the
+        for e_ in row:                                         #  reference schedule hands raw handles to the C entry point)
+            e_.record()
     refit_steps = []
     t0 = None
     for t in range(total):
@@ -390,7 +398,7 @@ def learning_closed_loop(Bt=4096, window=512, steps=200, refit_every=40, warmup=
                           peak=peak_t, unit="TFLOP/s", frac=refit_flops / (refit_ms * 1e-3) / 1e12 / peak_t if refit_ms > 0 else None,
                           kernel_ms=refit_ms, traffic=None,
                           note="over the WHOLE refit share of a refit step (every launch of it), a lower bound on the kernel's own rate")}
-    out = dict(schedule=schedule, batch=Bt, window=window, steps=steps, warmup=warmup, refit_every=refit_every, dtype=str(dtype),
+    out = dict(schedule=schedule, batch=Bt, max_train=max_train, points_after_refit=window, steps=steps, warmup=warmup, refit_every=refit_every, dtype=str(dtype),
                seconds=elapsed, ms_per_step=ms_step, instance_steps_per_s=Bt * steps / elapsed,
                shares=dict(pass_ms_per_step=pass_ms, solve_ms_per_step=solve_ms, refit_ms_per_refit=refit_ms,
                            refit_ms_per_step=refit_ms * n_refits / steps, refits_in_timed_region=n_refits,

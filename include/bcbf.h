@@ -354,6 +354,17 @@ int bcbf_posterior_shared_f64(const double* Lop, const double* Vw, const double*
                               const double* ell, const double* s2, const double* Bm, const double* M0,
                               const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                               int Bt, int N, int n, int m, void* stream);
+/* The two matrix-core queries above with the opt-in Matern-5/2 data kernel (see bcbf_posterior_query_matern52; same ranges;
+ * bcbf_posterior_query_matern52(shared=1) routes here for Bt >= 16).  No reference counterpart: the reference has no Matern
+ * kernel -- BASELINE.json's north_star names one; parity unpinned, formula held to the CPU oracle. */
+int bcbf_posterior_shared_matern52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                       const float* ell, const float* s2, const float* Bm, const float* M0,
+                                       const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                       int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_shared_matern52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                       const double* ell, const double* s2, const double* Bm, const double* M0,
+                                       const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                       int Bt, int N, int n, int m, void* stream);
 
 /* Full predictive covariance of a query SET against one GP in one launch, from the Gram G[b, b', 1+m, 1+m] = W_b' Wp_b' of the
  * whitened cross-covariances of its points (W = L^-1 Phi: the W output of bcbf_posterior_query / _shared; the Gram is a plain
@@ -561,6 +572,26 @@ int bcbf_unicycle_control_step_f32(
     float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
     void* ev_start, void* ev_stop, void* stream);
 int bcbf_unicycle_control_step_f64(
+    const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
+    const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
+    const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,
+    const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
+    const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
+    double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
+    int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream);
+/* The same control step on a model learned with the opt-in Matern-5/2 data kernel (bcbf_refit_matern52 /
+ * bcbf_gp_append_matern52 states): identical arguments; the posterior launch evaluates the Matern kernel (one GP per
+ * instance: the streaming kernel; shared_gp: the matrix-core query bcbf_posterior_shared_matern52), the fused task rows /
+ * terms / SOCP / plant-step launch behind it is the same.  No reference counterpart (the reference has no Matern kernel). */
+int bcbf_unicycle_control_step_matern52_f32(
+    const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+    const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
+    const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
+    float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
+    float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
+    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
+    void* ev_start, void* ev_stop, void* stream);
+int bcbf_unicycle_control_step_matern52_f64(
     const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
     const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
     const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,

@@ -1563,3 +1563,97 @@ def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n
                 vs = max(np.abs(oQ).max(), np.abs(op_).max(), abs(float(or_)), abs(float(ovar)), 1e-2)
                 ms = max(np.abs(oA).max(), abs(float(ob)), abs(float(omean)), 1e-2)
                 rel_close(host(val)[i].reshape(ref.shape), ref, ttol, scale=ms if name.startswith("mean") else vs, what=name)
+
+
+# --------------------------------------------------------------------------------------------
+# The opt-in Matern-5/2 data kernel in regime S (matrix-core query) and in the fused control step
+@pytest.mark.parametrize("N,n,m,b,dtype", [(512, 3, 2, 203, torch.float32), (100, 3, 2, 21, torch.float32), (256, 2, 1, 64, torch.float32),
+                                           (1024, 3, 2, 37, torch.float32), (512, 3, 2, 5200, torch.float32),
+                                           (512, 3, 2, 203, torch.float64), (100, 2, 1, 19, torch.float64), (480, 4, 3, 37, torch.float64)])
+def test_matern52_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
+    """bcbf_posterior_shared_matern52 (the regime-S matrix-core kernels with the Matern-5/2 value in the prologue; register-
+    resident form N <= 512, the fp32 LDS-slab form beyond; 5200 queries: the five-queries-per-wave packing) against the oracle's
+    Matern posterior, ragged b and N; `posterior_query(shared=True, kernel="matern52")` routes to the same kernel; the RBF
+    result on the same factor differs (the switch is not ignored)."""
+    import scipy.linalg as sla
+    from bayesian_cbf_amd.synthetic import make_instances
+    f64 = dtype == torch.float64
+    p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=40 + N + m)
+    p["X"] = (p["X"] * (1.0 if f64 else 2.0)).contiguous()
+    jit = p["jitter"] if f64 else (p["jitter"] * 100).contiguous()
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+    assert int(info[0]) == 0
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lo, hi = p["X"][0].amin(dim=0), p["X"][0].amax(dim=0)
+    xq = (lo + (hi - lo) * torch.rand(b, n, generator=g, dtype=dtype, device=DEV)).contiguous()
+    args = (Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq)
+    Mk, Bk, W = ops.posterior_shared(*args, want_W=True, kernel="matern52")
+    Mq, Bq, _ = ops.posterior_query(*args, shared=True, kernel="matern52")
+    assert torch.equal(Mk, Mq) and torch.equal(Bk, Bq)
+    Mr, Br, _ = ops.posterior_shared(*args)
+    assert float((Br - Bk).abs().max()) > 1e-4
+    h = {k: host(v)[0] for k, v in p.items()}
+    UH = h["UH"]
+    K_o = ogp.matern52_ard_kernel(h["X"], h["X"], h["ell"], h["s2"]) * (UH @ h["Bm"] @ UH.T) + np.diag(host(jit)[0])
+    L = np.linalg.cholesky(K_o)
+    V_o = sla.solve_triangular(L, h["Xdot"] - UH @ h["M0"], lower=True)
+    prior = float(h["s2"] * np.abs(h["Bm"]).max())
+    tol = 1e-8 if f64 else 1e-3
+    hx = host(xq)
+    for i in sorted(set(np.linspace(0, b - 1, min(b, 40)).astype(int))):
+        Phi = ogp.matern52_ard_kernel(h["X"], hx[i][None], h["ell"], h["s2"])[:, :1] * (UH @ h["Bm"])
+        W_o = sla.solve_triangular(L, Phi, lower=True)
+        rel_close(host(Mk)[i], h["M0"].T + V_o.T @ W_o, tol, scale=max(1.0, np.abs(V_o.T @ W_o).max()), what="Mk matern shared")
+        rel_close(host(Bk)[i], h["s2"] * h["Bm"] - W_o.T @ W_o, tol, scale=prior, what="Bk matern shared")
+        rel_close(host(W)[i, :N], W_o, tol, scale=max(np.abs(W_o).max(), 1e-3), what="W matern shared")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("shared", [False, True], ids=["instance-gps", "shared-gp"])
+def test_matern52_fused_control_step_vs_composed_path_and_oracle(ops, dtype, shared):
+    """bcbf_unicycle_control_step_matern52 (gp["kernel"] = "matern52"): posterior of a Matern-5/2 model + the fused task rows /
+    terms / SOCP / plant step in one host call == the composed entry points on the same model, and the posterior it leaves in the
+    workspace is the oracle's Matern posterior; the RBF step on the same tensors gives a different posterior."""
+    import scipy.linalg as sla
+    from bayesian_cbf_amd.synthetic import make_instances, make_unicycle_task
+    f64 = dtype == torch.float64
+    Bt, N, n, m = 70, 96, 3, 2
+    p = make_instances(1 if shared else Bt, N, n, m, dtype=dtype, device=DEV, seed=61)
+    t = make_unicycle_task(Bt, dtype=dtype, device=DEV, seed=62)
+    jit = p["jitter"] if f64 else (p["jitter"] * 100).contiguous()
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+    gp = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=p["A"], kernel="matern52")
+    x1, x2 = t["x"].clone(), t["x"].clone()
+    ws1, ws2 = ops.control_workspace(Bt, 2, dtype, DEV), ops.control_workspace(Bt, 2, dtype, DEV)
+    ops.unicycle_control_step(gp, t, ws1, x1, dt=0.01, L_true=1.0, L_mean=4.0, clf_gamma=10.0, max_iters=40)
+    ops._unicycle_control_step_composed(gp, t, ws2, x2, 0.01, 1.0, 4.0, 10.0, 40)
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    tol = 1e-9 if f64 else 1e-4
+    rel_close(host(ws1["Mk"]), host(ws2["Mk"]), tol, scale=max(1.0, float(ws2["Mk"].abs().max())), what="Mk fused vs composed")
+    rel_close(host(ws1["Bk"]), host(ws2["Bk"]), tol, scale=prior, what="Bk fused vs composed")
+    ok = ((ws1["status"] == 0) & (ws2["status"] == 0)).cpu().numpy()
+    assert ok.sum() >= Bt // 3 and int((ws1["status"] != ws2["status"]).sum()) <= 1
+    ytol = 1e-6 if f64 else 1e-3
+    all_close(host(ws1["y"])[ok], host(ws2["y"])[ok], ytol, ytol, what="matern control y fused vs composed")
+    all_close(host(x1)[ok], host(x2)[ok], ytol, ytol, what="matern control x fused vs composed")
+    # posterior vs the oracle's Matern formula
+    h = {k: host(v) for k, v in p.items()}
+    hx, hj = host(t["x"]), host(jit)
+    ptol = 1e-8 if f64 else 1e-3
+    for i in (0, 1, 17, 69):
+        gi = 0 if shared else i
+        UH = h["UH"][gi]
+        K_o = ogp.matern52_ard_kernel(h["X"][gi], h["X"][gi], h["ell"][gi], h["s2"][gi]) * (UH @ h["Bm"][gi] @ UH.T) + np.diag(hj[gi])
+        L = np.linalg.cholesky(K_o)
+        Phi = ogp.matern52_ard_kernel(h["X"][gi], hx[i][None], h["ell"][gi], h["s2"][gi])[:, :1] * (UH @ h["Bm"][gi])
+        W_o = sla.solve_triangular(L, Phi, lower=True)
+        Mk_o = h["M0"][gi].T + sla.solve_triangular(L, h["Xdot"][gi] - UH @ h["M0"][gi], lower=True).T @ W_o
+        rel_close(host(ws1["Mk"])[i], Mk_o, ptol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk matern control step")
+        rel_close(host(ws1["Bk"])[i], h["s2"][gi] * h["Bm"][gi] - W_o.T @ W_o, ptol, scale=float(h["s2"][gi] * np.abs(h["Bm"][gi]).max()),
+                  what="Bk matern control step")
+    ws3, x3 = ops.control_workspace(Bt, 2, dtype, DEV), t["x"].clone()
+    ops.unicycle_control_step(dict(gp, kernel="rbf"), t, ws3, x3, dt=0.01, L_true=1.0, L_mean=4.0, clf_gamma=10.0, max_iters=40)
+    assert float((ws3["Bk"] - ws1["Bk"]).abs().max()) > 1e-4

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The learning closed loop at BASELINE configs[2] scale (the reference's real workload,
-unicycle_move_to_pose.py:340-386): `--batch` independent control loops PER GPU, each with its own GP over a window of the
-`--window` most recent observations; every step = one control step + one new observation per instance, every
+unicycle_move_to_pose.py:340-386): `--batch` independent control loops PER GPU, each with its own GP over its most recent
+observations (at most `--max-train`); every step = one control step + one new observation per instance, every
 `--refit-every`-th step the window is refactored.  `--schedule online` (default; the posterior query and the in-place append
 share one pass over the factor) or `reference` (static GP between refits, the headline control step).
 
@@ -20,7 +20,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-ap.add_argument("--window", type=int, default=512)
+ap.add_argument("--max-train", type=int, default=512, help="most points a model ever holds (the reference's max_train)")
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--warmup", type=int, default=40)
 ap.add_argument("--refit-every", type=int, default=40)
@@ -33,7 +33,7 @@ if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_
 from bayesian_cbf_amd.distributed import RankContext
 from bayesian_cbf_amd.rollouts import learning_closed_loop, final_window_vs_device_refit
 ctx = RankContext()
-out, final = learning_closed_loop(a.batch, a.window, a.steps, a.refit_every, warmup=a.warmup,
+out, final = learning_closed_loop(a.batch, a.max_train, a.steps, a.refit_every, warmup=a.warmup,
                                   dtype=torch.float32 if a.dtype == "f32" else torch.float64, device=ctx.device,
                                   seed=1234 + ctx.rank, schedule=a.schedule, barrier=ctx.barrier)
 chk = final_window_vs_device_refit(final)
@@ -42,7 +42,7 @@ fails = ctx.reduce_sum([out["append_or_refit_failures"]])
 if ctx.rank == 0:
     total = a.batch * ctx.world
     out.update(metric="control steps/sec WITH learning (GP posterior + append + CBF-QP, window refit every %d steps) at "
-                      "N_train=%d, batch=%d" % (a.refit_every, a.window, a.batch),
+                      "N_train<=%d, batch=%d" % (a.refit_every, a.max_train, a.batch),
                value=total * a.steps / el, unit="control steps/s (instance-steps)", n_gpus=ctx.world, ms_per_step=el / a.steps * 1e3,
                seconds=el, instance_steps_per_s=total * a.steps / el, higher_is_better=True, scaling="weak", data="synthetic",
                comm=ctx.comm_info(per_rank), append_or_refit_failures=int(fails[0]), final_vs_fp64_refit_on_device=chk)
