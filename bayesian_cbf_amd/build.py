@@ -118,10 +118,10 @@ def _compile(item, force):
         import re
         names = re.findall(r"Function Name: (\S+)", res.stderr)
         sizes = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res.stderr)]
-        # (the last two template arguments are the occupancy the kernel is compiled for and its queries per wave: only the
-        # one-wave-per-SIMD form, `Li1E`, carries the explicit read / wait pairs)
-        bad = [(n_, z) for n_, z in zip(names, sizes) if z and re.search(r"ELi1ELi\dEEEv", n_)]
-        if not any(re.search(r"ELi1ELi\dEEEv", n_) for n_ in names) and any("posterior_shared_reg_kernel" in n_ for n_ in names):
+        # (the last three template arguments are the occupancy the kernel is compiled for, its queries per wave and the data
+        # kernel: only the one-wave-per-SIMD form, `Li1E`, carries the explicit read / wait pairs)
+        bad = [(n_, z) for n_, z in zip(names, sizes) if z and re.search(r"ELi1ELi\dELi\dEEEv", n_)]
+        if not any(re.search(r"ELi1ELi\dELi\dEEEv", n_) for n_ in names) and any("posterior_shared_reg_kernel" in n_ for n_ in names):
             raise RuntimeError("%s: no one-wave-per-SIMD kernel name matched the scratch guard (%s)" % (src, names[:2]))
         if not sizes or len(names) != len(sizes) or bad:
             os.remove(obj)

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) hbm_read_probe_kernel(const probe_f4* __r
 
 extern "C" int bcbf_hbm_read_probe(const void* buf, size_t bytes, void* sink, size_t* bytes_read, void* stream) {
     if (!buf || !sink || !bytes_read || ((uintptr_t)buf & 15)) return BCBF_EINVAL;
-    const int wgs = 8192;                               // 32 workgroups per CU: tools/probe/read_bw.hip's best grid
+    const int wgs = 8192;                               // 32 workgroups per CU: tools/dev/probe/read_bw.hip's best grid
     const size_t per_wg = bytes / 16 / wgs;
     *bytes_read = per_wg * 16 * wgs;
     if (per_wg == 0) return BCBF_EINVAL;

@@ -55,7 +55,7 @@ __device__ inline float rsqrt_nr2(float p) {        // hardware estimate (1 ulp)
 }
 __device__ inline float2 halves64(float v) {
     // (the builtin form of this swap, fine in the double overload above, came back with BOTH results equal to the lower
-    // half's value here -- ROCm 7.2 clang, tools/micro/halves_test.hip -- so the instruction is written out; the s_nop
+    // half's value here -- ROCm 7.2 clang, tools/dev/micro/halves_test.hip -- so the instruction is written out; the s_nop
     // covers the VALU-write -> permlane read hazard the compiler cannot see inside the asm)
     unsigned a = __builtin_bit_cast(unsigned, v), b = a;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));

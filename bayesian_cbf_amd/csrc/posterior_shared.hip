@@ -30,14 +30,14 @@ __device__ inline int blk_row(int u, int g, int r) { return 8 * g + 2 * r + u; }
 
 constexpr int PSH_DEPTH = 4;      // L tiles in flight per wave
 
-template <int C, int NS, bool WANTW>
+template <int C, int NS, bool WANTW, int KIND = 0>
 __global__ void __launch_bounds__(256)
 posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__ Vw, const float* __restrict__ X,
                         const float* __restrict__ UHB, const float* __restrict__ ell, const float* __restrict__ s2p,
                         const float* __restrict__ Bm, const float* __restrict__ M0, const float* __restrict__ xq,
                         const float* __restrict__ jitter2, float* __restrict__ Mk, float* __restrict__ Bk,
-                        float* __restrict__ Wout, int nq, int N, int Np, int n, int kind) {
-    // kind: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_posterior_shared_matern52; wave-uniform)
+                        float* __restrict__ Wout, int nq, int N, int Np, int n) {
+    // KIND: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_posterior_shared_matern52)
     constexpr int V = 4, QW = 4;                      // queries per wave
     extern __shared__ float smem[];
     const int nwave = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -122,7 +122,7 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
 #pragma unroll
             for (int d = 0; d < NS; ++d) { const float z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
             float shape;
-            if (kind == 1) { const float a5 = sqrtf(5.f * d2); shape = (1.f + a5 + (5.f / 3.f) * d2) * __expf(-a5); }
+            if constexpr (KIND == 1) { const float a5 = sqrtf(5.f * d2); shape = (1.f + a5 + (5.f / 3.f) * d2) * __expf(-a5); }
             else shape = __expf(-0.5f * d2);
             const float kmine = s2 * shape;
             const float kk[4] = {dpp_q<0x00>(kmine), dpp_q<0x55>(kmine), dpp_q<0xAA>(kmine), dpp_q<0xFF>(kmine)};
@@ -232,7 +232,7 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
             const float v = (e >> 2) ? w1[e & 3] : w0[e & 3];
             pend[e] = v;
             wi[(e * 4 + g) * 16 + j] = v;                                      // k-ordered: position u*4+r, then g
-            if (WANTW && qok && cok) Wout[((size_t)q * Np + I * NB + blk_row(e >> 2, g, e & 3)) * C + c] = v;
+            if (WANTW && (KIND == 0 || Wout != nullptr) && qok && cok) Wout[((size_t)q * Np + I * NB + blk_row(e >> 2, g, e & 3)) * C + c] = v;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -296,31 +296,22 @@ static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, con
                           const float* X, const float* UHB, const float* ell, const float* s2, const float* Bm,
                           const float* M0, const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                           int nq, int N, int Np, int n, int kind) {
-    if (W != nullptr) {
-        static int lds_opt_in_dev[64] = {0};          // largest dynamic LDS size opted into, per device
+    // one launch body per (W wanted?, data kernel): the Matern-5/2 form always writes W-capable code (WANTW = true) to halve
+    // its instantiations -- the opt-in kernel's extra stores are skipped at run time when W is NULL
+    auto go = [&](auto kern, int slot) {
+        static int lds_opt_in_dev[4][64] = {{0}};     // largest dynamic LDS size opted into, per kernel form and device
         int dev_ = 0;
         (void)hipGetDevice(&dev_);
-        int& lds_opt_in = lds_opt_in_dev[dev_ & 63];
+        int& lds_opt_in = lds_opt_in_dev[slot][dev_ & 63];
         if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
-            (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<C, NS, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             lds_opt_in = (int)lds;
         }
-        hipLaunchKernelGGL((posterior_shared_kernel<C, NS, true>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
-                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind);
-    } else {
-        static int lds_opt_in_dev[64] = {0};          // largest dynamic LDS size opted into, per device
-        int dev_ = 0;
-        (void)hipGetDevice(&dev_);
-        int& lds_opt_in = lds_opt_in_dev[dev_ & 63];
-        if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
-            (void)hipFuncSetAttribute((const void*)posterior_shared_kernel<C, NS, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_opt_in = (int)lds;
-        }
-        hipLaunchKernelGGL((posterior_shared_kernel<C, NS, false>), grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm,
-                           M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind);
-    }
+        hipLaunchKernelGGL(kern, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+    };
+    if (kind == 1) go(posterior_shared_kernel<C, NS, true, 1>, 2);
+    else if (W != nullptr) go(posterior_shared_kernel<C, NS, true>, 0);
+    else go(posterior_shared_kernel<C, NS, false>, 1);
 }
 
 template <int C>

@@ -143,14 +143,16 @@ template <int CTRL> __device__ inline double dpp_bc(double v) {
 // MFMA columns carry a query instead of 12), 8 for C = 2 (16 instead of 8).  Chosen by the launcher when the queries no longer
 // fit one wave per SIMD at QW = 4 (a fifth / half fewer waves for the same queries; with one round of waves either way the
 // quads' cheaper broadcasts win).
-template <typename T, int C, int NS, int OCC, int QW = 4>
+template <typename T, int C, int NS, int OCC, int QW = 4, int KIND = 0>
 __global__ void __launch_bounds__(256, OCC)
 posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                             const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                             const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
                             const T* __restrict__ jitter2, T* __restrict__ Mk, T* __restrict__ Bk,
-                            T* __restrict__ Wout, int nq, int N, int Np, int n, int kind) {
-    // kind: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_posterior_shared_matern52; wave-uniform)
+                            T* __restrict__ Wout, int nq, int N, int Np, int n) {
+    // KIND: data kernel -- 0 = RBF (the reference's), 1 = Matern-5/2 (opt-in, bcbf_posterior_shared_matern52).  A template
+    // parameter: as a run-time switch it cost the RBF instantiations 6-10 % (fp64 4096 queries 0.0846 -> 0.0895 ms); the Matern
+    // form is compiled for the base packing only (one wave per SIMD, four queries per wave)
     using P = PSR<T>;
     using acc_t = typename P::acc_t;
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
@@ -290,7 +292,7 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     T phi[8];
     // shape of the data kernel at squared scaled distance d2: exp(-d2 / 2), or Matern-5/2 (1 + a + a^2 / 3) exp(-a), a = sqrt(5 d2)
     auto kshape = [&](T d2) -> T {
-        if (kind == 1) {
+        if constexpr (KIND == 1) {
             const T a5 = (T)sqrt((double)(T(5) * d2));
             return (T(1) + a5 + T(5) / T(3) * d2) * P::exp_(-a5);
         }
@@ -482,8 +484,20 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
             const double cost = (double)((w + slots - 1) / slots) * (f ? 1.05 : 1.0) * (t ? 1.7 : 1.0);
             if (cost < best) { best = cost; five = f; two = t; }
         }
+    if (kind == 1) { five = false; two = false; }      // Matern: the base packing only
     const int waves = five ? (nq + QWD - 1) / QWD : (nq + 3) / 4;
     const dim3 grid((waves + 3) / 4);                  // 256 threads per workgroup, four waves
+    if (kind == 1) {
+        static int opt_in_m[64] = {0};
+        int& lds_opt_in = opt_in_m[dev_ & 63];
+        if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
+            (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, 1, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_opt_in = (int)lds;
+        }
+        hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, 1, 4, 1>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
+                           xq, jitter2, Mk, Bk, W, nq, N, Np, n);
+        return;
+    }
     auto go5 = [&](auto occ, auto qw) {
         constexpr int OCC = decltype(occ)::value, QW = decltype(qw)::value;
         static int opt_in[2][64] = {{0}};           // largest dynamic LDS size opted into, per device
@@ -493,7 +507,7 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
             lds_opt_in = (int)lds;
         }
         hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, OCC, QW>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
-                           xq, jitter2, Mk, Bk, W, nq, N, Np, n, kind);
+                           xq, jitter2, Mk, Bk, W, nq, N, Np, n);
     };
     auto go = [&](auto occ) {
         if constexpr (QWD != 4 && BCBF_PSR_QW5) { if (five) { go5(occ, Ic<QWD>{}); return; } }

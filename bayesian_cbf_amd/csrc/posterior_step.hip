@@ -102,7 +102,7 @@ template <> struct BufLoad<double> {
 
 // One 16x16 matrix-core accumulator: acc += a(16x4) b(4x16); lane l supplies a[l % 16][l / 16] and b[l / 16][l % 16]
 // and holds acc[row(l / 16, r)][l % 16], r = 0..3, with row(g, r) = 4 g + r in fp32 and g + 4 r in fp64
-// (tools/probe/mfma64_layout.hip).  Exact IEEE arithmetic in both precisions.
+// (tools/dev/probe/mfma64_layout.hip).  Exact IEEE arithmetic in both precisions.
 template <typename T> struct Mfma16;
 template <> struct Mfma16<float> {
     using acc_t = __attribute__((__vector_size__(4 * sizeof(float)))) float;

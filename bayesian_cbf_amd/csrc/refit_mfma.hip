@@ -368,14 +368,14 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     // 0.070 / 0.058, 4096 x 128: 0.67 / 0.20 / 0.22, 1024 x 256: 0.441 / 0.220 / 0.186, 4096 x 256: 1.76 / 0.69 / 0.84,
     // 256 x 512: 1.17 / 0.90 / 0.85, 512 x 512: 1.31 / 0.93 / 0.93, 1024 x 512: 1.69 / 1.04 / 1.18, 4096 x 512: 6.6 / 3.7 / 5.4,
     // 64 x 512: 0.72 / 0.87 / 0.75, 256 x 1024: 5.5 / 5.3 / -
-    // (ONE model, tools/time_refit_one.py, us workgroup / two waves / team: N = 128: 105 / 41 / 44, 256: 236 / 131 / 96, 512:
+    // (ONE model, tools/dev/time_refit_one.py, us workgroup / two waves / team: N = 128: 105 / 41 / 44, 256: 236 / 131 / 96, 512:
     // 705 / 741 / 264, 1024: 2820 / - / 1311.)
     bool pair = Bt <= 1024 && (Np <= 256 || (Np <= 512 && Bt >= 128 && Bt <= 256));
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     // A team of eight waves per instance (refit_wave64.hip: one chain wave, seven bulk waves; one workgroup per CU at a
     // time) while ONE round of workgroups holds the batch, two rounds from N = 512 on, four from 1024 (1024 x 1024 fp32: 6.57 / 6.90)
     // -- measured on 256 CUs
-    // (tools/check_refit_team.py, ms team / best other form), fp32: 1 x 512: 0.27 / 0.71, 256 x 512: 0.30 / 0.86, 512 x 512:
+    // (tools/dev/check_refit_team.py, ms team / best other form), fp32: 1 x 512: 0.27 / 0.71, 256 x 512: 0.30 / 0.86, 512 x 512:
     // 0.61 / 0.93, 1024 x 512: 1.22 / 1.04, 1 x 1024: 1.31 / 2.81, 512 x 1024: 3.32 / 5.89, 256 x 256: 0.108 / 0.140,
     // 512 x 256: 0.21 / 0.16, 256 x 128: 0.047 / 0.045; fp64: 1 x 512: 0.43 / 0.90, 256 x 512: 0.52 / 1.12, 512 x 512:
     // 1.04 / 1.55, 1 x 1024: 2.31 / 3.57, 1 x 2048: 16.8 / 19.3, 256 x 256: 0.173 / 0.219.  BCBF_REFIT_TEAM=0/1 forces the

@@ -373,14 +373,14 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     // 0.104 / 0.100, 64 x 128: 0.132 / 0.093 / 0.066; a tie at 4096 (x 256: 3.24 / 1.367 / 1.390) -- and loses at N = 512
     // (256 x 512: 1.12 / 1.50 / 1.40, 1024 x 512: 3.06 / 1.88 / 2.26), where the one-wave form (512 registers) keeps more of the
     // update stream in flight.  BCBF_REFIT_PAIR=0/1 forces the choice (N <= 512).
-    // (ONE model, tools/time_refit_one.py, us workgroup / two waves / team: N = 128: 133 / 61 / 65, 256: 308 / 199 / 147, 512:
+    // (ONE model, tools/dev/time_refit_one.py, us workgroup / two waves / team: N = 128: 133 / 61 / 65, 256: 308 / 199 / 147, 512:
     // 901 / 1193 / 423, 1024: 3565 / - / 2311.)
     bool pair = Bt <= 1024 && Np <= 256;
     if (const char* e = getenv("BCBF_REFIT_PAIR")) pair = e[0] == '1' && Np / NB <= 16;
     // A team of eight waves per instance (refit_wave64.hip: one chain wave, seven bulk waves; one workgroup per CU at a
     // time) while ONE round of workgroups holds the batch, two rounds from N = 512 on, four from 1024 (1024 x 1024 fp32: 6.57 / 6.90)
     // -- measured on 256 CUs
-    // (tools/check_refit_team.py, ms team / best other form), fp32: 1 x 512: 0.27 / 0.71, 256 x 512: 0.30 / 0.86, 512 x 512:
+    // (tools/dev/check_refit_team.py, ms team / best other form), fp32: 1 x 512: 0.27 / 0.71, 256 x 512: 0.30 / 0.86, 512 x 512:
     // 0.61 / 0.93, 1024 x 512: 1.22 / 1.04, 1 x 1024: 1.31 / 2.81, 512 x 1024: 3.32 / 5.89, 256 x 256: 0.108 / 0.140,
     // 512 x 256: 0.21 / 0.16, 256 x 128: 0.047 / 0.045; fp64: 1 x 512: 0.43 / 0.90, 256 x 512: 0.52 / 1.12, 512 x 512:
     // 1.04 / 1.55, 1 x 1024: 2.31 / 3.57, 1 x 2048: 16.8 / 19.3, 256 x 256: 0.173 / 0.219.  BCBF_REFIT_TEAM=0/1 forces the

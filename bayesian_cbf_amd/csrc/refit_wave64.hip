@@ -1252,7 +1252,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #ifndef BCBF_RP_KS32
 #define BCBF_RP_KS32 4           // ... fp32
 #endif
-// -DBCBF_RP_TRACE (development, tools/trace_refit_pair.py): 100 MHz time stamps of workgroup 0's two waves at every hand-off
+// -DBCBF_RP_TRACE (development, tools/dev/trace_refit_pair.py): 100 MHz time stamps of workgroup 0's two waves at every hand-off
 #ifdef BCBF_RP_TRACE
 extern "C" __attribute__((visibility("default"))) int bcbf_debug_rp_trace(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rp_trace_buf), sizeof(rp_trace_buf));

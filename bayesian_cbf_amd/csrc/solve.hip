@@ -501,17 +501,26 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
                          const T* __restrict__ x_new, const T* __restrict__ uh_new, const T* __restrict__ xdot_new,
                          const T* __restrict__ jitter_new, const T* __restrict__ W, int* __restrict__ info,
                          int N, int Ncap, int n, int C, int wq, const T* __restrict__ Mk2, const T* __restrict__ Bk2,
-                         T* __restrict__ Mk_out, T* __restrict__ Bk_out, const T* __restrict__ lsum = nullptr) {
+                         T* __restrict__ Mk_out, T* __restrict__ Bk_out, const T* __restrict__ lsum = nullptr,
+                         T* __restrict__ rawUH = nullptr, T* __restrict__ rawY = nullptr, T* __restrict__ rawJ = nullptr) {
+    // rawUH / rawY / rawJ (optional, [Bt, Ncap, C] / [Bt, Ncap, n] / [Bt, Ncap]): the caller's store of the RAW rows (uh, xdot,
+    // jitter) a later refit of a sliding window is made from -- row N is written here, neutral (0, 0, unit pivot) where the
+    // new pivot failed, so that a refit sees exactly what the in-place path holds (ops.ReservedGP(window=...))
     // wq = 2: W / Mk2 / Bk2 hold TWO queries per instance (slot 0 = the caller's posterior query, slot 1 = x_new, both
     // from one pass over the factor); slot 0's posterior is handed to Mk_out / Bk_out here
     // wq = 3: W IS the column l [Bt, Np] (posterior_step_kernel<.., XC = 1>) and lsum[Bt, 1 + n] = (l'l, Vw'l) came with it
     constexpr int V = Vec<T>::V;
     __shared__ T lrow[ST * SMAXR];
     __shared__ T scratch[4 * SC];
+    __shared__ T dinv_s[LOP_DB];                                // the inverted diagonal block the new row extends
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Np = round_up(N, NB), Nl = round_up(Ncap, NB);
     T* lop = Lop + (size_t)b * lop_elems<V>(Nl);
     T* Vwb = Vw + (size_t)b * Ncap * n;
+    // (fetched by the whole workgroup up front: the new row of inv(L_JJ) is a chain of up to 31 multiply-adds per lane, and
+    //  with the operands in global memory every term waited out a memory round trip -- a quarter of the online step at
+    //  4096 instances)
+    for (int k = tid; k < LOP_DB; k += ST) dinv_s[k] = lop[lop_dinv_block(N / NB, Nl) + k];
     T uh[BCBF_MAX_CTRL_DIM + 1];
 #pragma unroll
     for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c) uh[c] = c < C ? uh_new[(size_t)b * C + c] : T(0);
@@ -564,7 +573,7 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
             if (jj == rr) val = T(1) / d;
             else {
                 T a2 = T(0);
-                for (int ii = jj; ii < rr; ++ii) a2 += lrow[col0 + ii] * lop[lop_dinv(Js, ii, jj, Nl)];
+                for (int ii = jj; ii < rr; ++ii) a2 += lrow[col0 + ii] * dinv_s[lop_dinv_col(jj) + ii];
                 val = -a2 / d;
             }
             lop[lop_dinv(Js, rr, jj, Nl)] = val;
@@ -581,7 +590,10 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
         T sacc = T(0);
         for (int a = 0; a < C; ++a) sacc += uh[a] * Bm[((size_t)b * C + a) * C + tid];
         UHB[((size_t)b * Ncap + N) * C + tid] = ok ? sacc : T(0);
+        if (rawUH != nullptr) rawUH[((size_t)b * Ncap + N) * C + tid] = ok ? uh[tid] : T(0);
     }
+    if (rawY != nullptr && tid < n) rawY[((size_t)b * Ncap + N) * n + tid] = ok ? xdot_new[(size_t)b * n + tid] : T(0);
+    if (rawJ != nullptr && tid == 0) rawJ[(size_t)b * Ncap + N] = ok ? (jitter_new ? jitter_new[b] : T(0)) : T(1);
     if (wq == 2 && Mk_out != nullptr) {
         if (tid < n * C) Mk_out[(size_t)b * n * C + tid] = Mk2[(size_t)(2 * b) * n * C + tid];
         else if (tid >= 64 && tid < 64 + C * C) Bk_out[(size_t)b * C * C + tid - 64] = Bk2[(size_t)(2 * b) * C * C + tid - 64];
@@ -615,9 +627,11 @@ template <typename T>
 static int launch_gp_append_inplace(T* Lop, T* Vw, T* X, T* UHB, const T* s2, const T* Bm, const T* M0, const T* x_new,
                                     const T* uh_new, const T* xdot_new, const T* jitter_new, const T* W, int* info, int Bt,
                                     int N, int Ncap, int n, int m, void* stream, int wq = 1, const T* Mk2 = nullptr,
-                                    const T* Bk2 = nullptr, T* Mk_out = nullptr, T* Bk_out = nullptr, const T* lsum = nullptr) {
+                                    const T* Bk2 = nullptr, T* Mk_out = nullptr, T* Bk_out = nullptr, const T* lsum = nullptr,
+                                    T* const* raw = nullptr) {
     hipLaunchKernelGGL((gp_append_inplace_kernel<T>), dim3(Bt), dim3(ST), 0, (hipStream_t)stream, Lop, Vw, X, UHB, s2, Bm, M0,
-                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1, wq, Mk2, Bk2, Mk_out, Bk_out, lsum);
+                       x_new, uh_new, xdot_new, jitter_new, W, info, N, Ncap, n, m + 1, wq, Mk2, Bk2, Mk_out, Bk_out, lsum,
+                       raw ? raw[0] : (T*)nullptr, raw ? raw[1] : (T*)nullptr, raw ? raw[2] : (T*)nullptr);
     return check_launch("gp_append_reserved");
 }
 }  // namespace bcbf
@@ -720,10 +734,10 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
         return bcbf::launch_gp_reserve<T>(Lop_in, Vw_in, X_in, UHB_in, Lop_r, Vw_r, X_r, UHB_r, Bt, N, Ncap_in, Ncap, n, m,  \
                                           stream);                                                                       \
     }                                                                                                                    \
-    int bcbf_gp_append_reserved_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,         \
+    static int gp_append_reserved_impl_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,   \
                                       const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,                   \
                                       const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, const T* xq,     \
-                                      T* Mk, T* Bk, int Bt, int N, int Ncap, int n, int m, void* stream) {               \
+                                      T* Mk, T* Bk, int Bt, int N, int Ncap, int n, int m, void* stream, T* const* raw) { \
         if (Bt <= 0) return BCBF_OK;                                                                                     \
         if (!Lop_r || !Vw_r || !X_r || !UHB_r || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !info ||  \
             !Wwork || !Mk_work || !Bk_work || (xq && (!Mk || !Bk)))                                                      \
@@ -739,7 +753,7 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
             if (rc != BCBF_OK) return rc;                                                                                \
             return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new,        \
                                                      jitter_new, Wwork, info, Bt, N, Ncap, n, m, stream, 3, nullptr,      \
-                                                     nullptr, nullptr, nullptr, Mk_work);                                \
+                                                     nullptr, nullptr, nullptr, Mk_work, raw);                           \
         }                                                                                                                \
         if (xq != nullptr && n <= 4 && m <= 2) {                                                                         \
             /* (round 3's form, BCBF_APPEND_PAIR=1: two full queries per instance on one pass) */                        \
@@ -748,7 +762,7 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
             if (rc != BCBF_OK) return rc;                                                                                \
             return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new,        \
                                                      jitter_new, Wwork, info, Bt, N, Ncap, n, m, stream, 2, Mk_work,      \
-                                                     Bk_work, Mk, Bk);                                                   \
+                                                     Bk_work, Mk, Bk, nullptr, raw);                                     \
         }                                                                                                                \
         if (xq != nullptr) {                                                                                             \
             const int rq = bcbf_posterior_query_reserved_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, nullptr, Mk,  \
@@ -759,7 +773,26 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
                                                            Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);          \
         if (rc != BCBF_OK) return rc;                                                                                    \
         return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
-                                                 Wwork, info, Bt, N, Ncap, n, m, stream);                                \
+                                                 Wwork, info, Bt, N, Ncap, n, m, stream, 1, nullptr, nullptr, nullptr,   \
+                                                 nullptr, nullptr, raw);                                                 \
+    }                                                                                                                    \
+    int bcbf_gp_append_reserved_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,         \
+                                      const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,                   \
+                                      const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, const T* xq,     \
+                                      T* Mk, T* Bk, int Bt, int N, int Ncap, int n, int m, void* stream) {               \
+        return gp_append_reserved_impl_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
+                                             info, Wwork, Mk_work, Bk_work, xq, Mk, Bk, Bt, N, Ncap, n, m, stream, nullptr); \
+    }                                                                                                                    \
+    /* ... that also records the RAW rows of the new point (what a sliding window's refit is made from) */              \
+    int bcbf_gp_append_reserved_raw_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,     \
+                                          const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,               \
+                                          const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, const T* xq, \
+                                          T* Mk, T* Bk, T* rawUH, T* rawY, T* rawJ, int Bt, int N, int Ncap, int n,      \
+                                          int m, void* stream) {                                                         \
+        if (!rawUH || !rawY || !rawJ) return BCBF_EINVAL;                                                                \
+        T* const raw[3] = {rawUH, rawY, rawJ};                                                                           \
+        return gp_append_reserved_impl_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
+                                             info, Wwork, Mk_work, Bk_work, xq, Mk, Bk, Bt, N, Ncap, n, m, stream, raw);  \
     }
 BCBF_RESERVED_ENTRY(f32, float)
 BCBF_RESERVED_ENTRY(f64, double)

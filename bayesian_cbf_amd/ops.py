@@ -337,10 +337,6 @@ class ReservedGP:
         if self.N >= self.capacity:
             raise RuntimeError("ReservedGP is full (%d points): reserve a larger capacity" % self.capacity)
         _chk(self.X, x_new, uh_new, xdot_new, jitter_new, query)
-        if self.window is not None:                   # raw row of the new point (row N of the raw arrays)
-            self._rUH[:, self.N], self._rY[:, self.N] = uh_new, xdot_new
-            if jitter_new is not None:
-                self._rJ[:, self.N] = jitter_new
         Mk = Bk = None
         if query is not None:
             f = dict(dtype=self.X.dtype, device=self.X.device)
@@ -348,24 +344,23 @@ class ReservedGP:
             if self._Ww.shape[0] != 2 * self.Bt:                      # work buffers for two queries per instance
                 self._Ww = torch.empty(2 * self.Bt, *self._Ww.shape[1:], **f)
                 self._Mkw, self._Bkw = torch.empty(2 * self.Bt, self.n, self.C, **f), torch.empty(2 * self.Bt, self.C, self.C, **f)
-        check(getattr(lib, "bcbf_gp_append_reserved" + _suf(self.X))(
-            _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0),
-            _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self.info), _p(self._Ww), _p(self._Mkw), _p(self._Bkw),
-            _p(query), _p(Mk), _p(Bk), self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)),
-            "bcbf_gp_append_reserved")
+        head = (_p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0),
+                _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self.info), _p(self._Ww), _p(self._Mkw), _p(self._Bkw),
+                _p(query), _p(Mk), _p(Bk))
+        tail = (self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X))
+        if self.window is not None:
+            # window mode: the same launches also record the point's RAW row (uh, xdot, jitter) -- neutral (0, 0, unit pivot)
+            # where the new pivot failed, which is what the in-place path holds -- for the next refit of the window
+            check(getattr(lib, "bcbf_gp_append_reserved_raw" + _suf(self.X))(*head, _p(self._rUH), _p(self._rY), _p(self._rJ), *tail),
+                  "bcbf_gp_append_reserved_raw")
+        else:
+            check(getattr(lib, "bcbf_gp_append_reserved" + _suf(self.X))(*head, *tail), "bcbf_gp_append_reserved")
         self.N += 1
         info = self.info
-        if self.window is not None:
-            # an instance whose pivot failed holds a NEUTRAL point in place (zero rows): the window refit must see the same,
-            # so its raw row is zeroed too (UH = 0 makes K_b's row / column vanish but for the jitter on the diagonal)
-            failed = (info != 0)[:, None]
-            self._rUH[:, self.N - 1] = torch.where(failed, torch.zeros_like(uh_new), self._rUH[:, self.N - 1])
-            self._rY[:, self.N - 1] = torch.where(failed, torch.zeros_like(xdot_new), self._rY[:, self.N - 1])
-            self._rJ[:, self.N - 1] = torch.where(failed[:, 0], torch.ones_like(self._rJ[:, 0]), self._rJ[:, self.N - 1])   # (unit pivot)
-            if self.N >= self.window + self.drop:
-                dinfo = self.drop_oldest_block()      # AFTER the append: the posterior the caller asked for saw every point
-                if self.drop_failures:                # a window that could not be factored: carried in the returned info (< 0)
-                    info = torch.where(dinfo != 0, -dinfo.abs() - 1, info)
+        if self.window is not None and self.N >= self.window + self.drop:
+            dinfo = self.drop_oldest_block()          # AFTER the append: the posterior the caller asked for saw every point
+            if self.drop_failures:                    # a window that could not be factored: carried in the returned info (< 0)
+                info = torch.where(dinfo != 0, -dinfo.abs() - 1, info)
         return info if query is None else (info, Mk, Bk)
 
     def live(self):

@@ -248,7 +248,7 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
 
 
 def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warmup=40, dtype=torch.float32, device="cuda",
-                         seed=1234, schedule="online", n=3, m=2, barrier=None):
+                         seed=1234, schedule="online", n=3, m=2, barrier=None, parts=1):
     """The reference's REAL workload at BASELINE configs[2] scale: a control loop that keeps learning
     (`LearnedShiftInvariantDynamics.train`, unicycle_move_to_pose.py:340-386: buffer (x, u) every step, refit every
     `train_every_n_steps` = 40 on at most `max_train` points) -- Bt independent instances, each with its own GP over the most
@@ -263,7 +263,10 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         steps old.
     schedule = "reference": the reference's cadence -- the GP is STATIC between refits (the headline control step,
         `bcbf_unicycle_control_step`: posterior pass + solve), observations only land in a buffer, every `refit_every`-th step
-        the last `max_train` buffered points are refactored (`bcbf_refit` + `bcbf_potrs`).
+        the last `max_train` buffered points are refactored (`bcbf_refit` + `bcbf_potrs`).  `parts` > 1: the control steps
+        run as `ops.ConcurrentControlLoop(parts=...)` (part batches on their own HIP streams, bench.py's default schedule: one
+        part's latency-bound solve beside another part's HBM-bound posterior); a refit waits for all part streams (one host
+        synchronisation per refit) and the part streams wait for it.
 
     `warmup` untimed steps (rounded up to whole refit periods so that the timed region starts right after a refit), then
     `steps` timed steps (a multiple of refit_every: every timed period holds exactly one refit) between two device
@@ -298,6 +301,7 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     dt_plant, L_true, L_mean = 1e-3, 1.0, 4.0
     obs = [t.transpose(0, 1).contiguous() for t in (p["X"], p["UH"], p["Xdot"], p["jitter"])]     # [N][Bt, .]
     fails = torch.zeros((), dtype=torch.int64, device=dev)
+    fails_vec = torch.zeros(Bt, dtype=torch.int32, device=dev)
     online = schedule == "online"
     if online:
         rgp = ops.ReservedGP(Lop, Vw, cut(p["X"], window), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + refit_every,
@@ -309,8 +313,13 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         gp = dict(Lop=Lop, Vw=Vw, X=cut(p["X"], window), UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=A)
         jit_w = jit0
         lo = 0
-        step_fn = ops.unicycle_control_step_prepare(gp, task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
-                                                    clf_gamma=10.0, max_iters=20)
+        if parts > 1:
+            loop = ops.ConcurrentControlLoop(gp, task, x, parts=parts, dt=dt_plant, L_true=L_true, L_mean=L_mean, clf_gamma=10.0,
+                                             max_iters=20)
+            ws = loop.ws
+        else:
+            step_fn = ops.unicycle_control_step_prepare(gp, task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
+                                                        clf_gamma=10.0, max_iters=20)
     else:
         raise ValueError("schedule: 'online' or 'reference'")
     E = lambda: torch.cuda.Event(enable_timing=True)
@@ -318,6 +327,14 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     for row in ev:                                             # (torch creates the hipEvent handle at the first record; the
         for e_ in row:                                         #  reference schedule hands raw handles to the C entry point)
             e_.record()
+    concurrent = (not online) and parts > 1
+    evp = None
+    if concurrent:                                             # per part: events around its posterior launch, on its stream
+        evp = [[(E(), E()) for _ in range(parts)] for _ in range(total)]
+        for row in evp:
+            for c, (a_, b_) in enumerate(row):
+                a_.record(loop.streams[c]); b_.record(loop.streams[c])
+        ev_base = E()
     refit_steps = []
     t0 = None
     for t in range(total):
@@ -325,6 +342,8 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
             if barrier is not None:
                 barrier()
             torch.cuda.synchronize(dev)
+            if concurrent:
+                ev_base.record(loop.streams[0])
             t0 = time.perf_counter()
         N_obs = window + t
         e = ev[t]
@@ -336,13 +355,19 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
             e[1].record()
             solve()
             e[2].record()
-            fails += (info != 0).sum()
+            fails_vec += info != 0                       # (stays on the device: the loop never waits for the host)
             if rgp.drops != drops_before:
                 refit_steps.append(t)
         else:
-            step_fn(e[0], e[1])                                  # (events around the posterior launch, on its stream)
-            e[2].record()
+            if concurrent:
+                loop.step(evp[t])
+            else:
+                step_fn(e[0], e[1])                              # (events around the posterior launch, on its stream)
+                e[2].record()
             if (t + 1) % refit_every == 0:
+                if concurrent:
+                    loop.synchronize()                           # the refit overwrites what the part streams read
+                    e[2].record()
                 lo = t + 1
                 sl = slice(lo, lo + window)
                 Xw, UHw, Yw = (p[k][:, sl].contiguous() for k in ("X", "UH", "Xdot"))
@@ -357,6 +382,9 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
                 gp["X"].copy_(Xw)
                 fails += (info != 0).sum()
                 e[3].record()
+                if concurrent:
+                    for st_ in loop.streams:
+                        st_.wait_stream(torch.cuda.current_stream(dev))
                 refit_steps.append(t)
     torch.cuda.synchronize(dev)
     if barrier is not None:
@@ -372,12 +400,26 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         pass_ms = sum(plain) / max(1, len(plain))
         refit_ms = (sum(withr) / max(1, len(withr)) - pass_ms) if withr else 0.0
         n_refits = len(withr)
+    elif concurrent:
+        # the part batches' posterior launches overlap one another: the time during which at least one of them ran (bench.py)
+        spans = sorted((ev_base.elapsed_time(a_), ev_base.elapsed_time(b_)) for t in timed for a_, b_ in evp[t])
+        busy, ca, cb = 0.0, spans[0][0], spans[0][1]
+        for a_, b_ in spans[1:]:
+            if a_ > cb:
+                busy += cb - ca
+                ca, cb = a_, b_
+            else:
+                cb = max(cb, b_)
+        pass_ms = (busy + cb - ca) / steps
+        rs = [t for t in refit_steps if t >= warmup]
+        refit_ms = sum(ev[t][2].elapsed_time(ev[t][3]) for t in rs) / max(1, len(rs))
+        n_refits = len(rs)
     else:
         pass_ms = sum(ev[t][0].elapsed_time(ev[t][1]) for t in timed) / steps
         rs = [t for t in refit_steps if t >= warmup]
         refit_ms = sum(ev[t][2].elapsed_time(ev[t][3]) for t in rs) / max(1, len(rs))
         n_refits = len(rs)
-    solve_ms = sum(ev[t][1].elapsed_time(ev[t][2]) for t in timed) / steps
+    solve_ms = 0.0 if concurrent else sum(ev[t][1].elapsed_time(ev[t][2]) for t in timed) / steps     # (concurrent: hidden beside the passes)
     ms_step = elapsed / steps * 1e3
     # roofline entries.  pass: every instance's packed factor + whitened targets + inputs + UH B rows read once at the live N
     if online:
@@ -403,7 +445,7 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
                shares=dict(pass_ms_per_step=pass_ms, solve_ms_per_step=solve_ms, refit_ms_per_refit=refit_ms,
                            refit_ms_per_step=refit_ms * n_refits / steps, refits_in_timed_region=n_refits,
                            other_ms_per_step=ms_step - pass_ms - solve_ms - refit_ms * n_refits / steps),
-               roofline=roof, append_or_refit_failures=int(fails), solver_optimal_fraction=float((ws["status"] == 0).float().mean()))
+               roofline=roof, append_or_refit_failures=int(fails) + int((fails_vec != 0).sum()), parts=parts, solver_optimal_fraction=float((ws["status"] == 0).float().mean()))
     if online:
         out["drop_failures"] = rgp.drop_failures
         lo = window + total - rgp.N

@@ -275,6 +275,21 @@ int bcbf_gp_append_reserved_f64(double* Lop_r, double* Vw_r, double* X_r, double
                                 const double* xdot_new, const double* jitter_new, int* info, double* Wwork, double* Mk_work,
                                 double* Bk_work, const double* xq, double* Mk, double* Bk, int Bt, int N, int Ncap, int n,
                                 int m, void* stream);
+/* bcbf_gp_append_reserved that also records the RAW rows of the new point in the caller's store -- rawUH[Bt,Ncap,1+m],
+ * rawY[Bt,Ncap,n], rawJ[Bt,Ncap]: row N receives (uh_new, xdot_new, jitter_new), or the neutral (0, 0, 1) where the new pivot
+ * failed -- the rows a later from-the-data refit of a sliding window is made from (ops.ReservedGP(window=...); the
+ * reference keeps its buffer in Python lists, unicycle_move_to_pose.py:340-386).  Same launches, no extra one. */
+int bcbf_gp_append_reserved_raw_f32(float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
+                                    const float* Bm, const float* M0, const float* x_new, const float* uh_new,
+                                    const float* xdot_new, const float* jitter_new, int* info, float* Wwork, float* Mk_work,
+                                    float* Bk_work, const float* xq, float* Mk, float* Bk, float* rawUH, float* rawY,
+                                    float* rawJ, int Bt, int N, int Ncap, int n, int m, void* stream);
+int bcbf_gp_append_reserved_raw_f64(double* Lop_r, double* Vw_r, double* X_r, double* UHB_r, const double* ell,
+                                    const double* s2, const double* Bm, const double* M0, const double* x_new,
+                                    const double* uh_new, const double* xdot_new, const double* jitter_new, int* info,
+                                    double* Wwork, double* Mk_work, double* Bk_work, const double* xq, double* Mk, double* Bk,
+                                    double* rawUH, double* rawY, double* rawJ, int Bt, int N, int Ncap, int n, int m,
+                                    void* stream);
 
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */

@@ -26,6 +26,7 @@ ap.add_argument("--warmup", type=int, default=40)
 ap.add_argument("--refit-every", type=int, default=40)
 ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
 ap.add_argument("--schedule", choices=["online", "reference"], default="online")
+ap.add_argument("--parts", type=int, default=1, help="reference schedule: part batches on their own streams (bench.py's default is 4)")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
     from bayesian_cbf_amd.distributed import launch_ranks
@@ -35,7 +36,7 @@ from bayesian_cbf_amd.rollouts import learning_closed_loop, final_window_vs_devi
 ctx = RankContext()
 out, final = learning_closed_loop(a.batch, a.max_train, a.steps, a.refit_every, warmup=a.warmup,
                                   dtype=torch.float32 if a.dtype == "f32" else torch.float64, device=ctx.device,
-                                  seed=1234 + ctx.rank, schedule=a.schedule, barrier=ctx.barrier)
+                                  seed=1234 + ctx.rank, schedule=a.schedule, barrier=ctx.barrier, parts=a.parts)
 chk = final_window_vs_device_refit(final)
 el, per_rank = ctx.reduce_times(out["seconds"])
 fails = ctx.reduce_sum([out["append_or_refit_failures"]])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timing of the MFMA refit kernel (development tool): build / run."""
 import ctypes, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 VARIANTS = {"full": []}

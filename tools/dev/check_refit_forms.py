@@ -2,7 +2,7 @@
 """The two-waves-per-instance form of the refit (BCBF_REFIT_PAIR=1) against the one-wave form, element by element (development):
 the packed operator incl. the inverted diagonal blocks, relative to its largest element."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances

@@ -2,7 +2,7 @@
 """The team-of-waves form of the refit (BCBF_REFIT_TEAM=1) against the library's default choice without it, element by
 element, and its time against the other forms for a few large systems (development)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from _timing import timeit
 from bayesian_cbf_amd import ops

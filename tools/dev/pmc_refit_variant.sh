@@ -1,4 +1,4 @@
-# tools/pmc_refit_variant.sh <lib> <occ> <tag>: FETCH_SIZE / WRITE_SIZE / MFMA-busy of the fp32 one-wave refit at 4096 x 512 for one
+# tools/dev/pmc_refit_variant.sh <lib> <occ> <tag>: FETCH_SIZE / WRITE_SIZE / MFMA-busy of the fp32 one-wave refit at 4096 x 512 for one
 # library (development; one counter set per pass, counters + kernel trace only)
 LIB=$1; OCC=$2; TAG=$3
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 """Development soak: regime-S queries over random shapes, the launcher's choice of queries per wave against four per wave
 (BCBF_PSR_QW=4 in a second process), fp64 (differences must be at rounding level) and fp32."""
 import os, sys, subprocess, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 if len(sys.argv) > 1:
     from bayesian_cbf_amd import ops
     from bayesian_cbf_amd.synthetic import make_instances

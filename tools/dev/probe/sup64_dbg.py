@@ -1,5 +1,5 @@
 import os, sys, torch, numpy as np, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 if len(sys.argv) > 1:
     from bayesian_cbf_amd import ops
     from bayesian_cbf_amd.synthetic import make_instances

@@ -1,7 +1,7 @@
 """Development soak: one-wave refit, super-panel instantiation against the plain one over random shapes, with an order-1 jitter
 (well conditioned: the two must agree to rounding in both precisions)."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
 os.environ["BCBF_REFIT_WAVE"] = "1"

@@ -1,5 +1,5 @@
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExact
 import math

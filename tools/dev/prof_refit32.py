@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Development: per-section cycle counts of the fp32 one-wave refit (plain and super-panel form) from a -DBCBF_RW64_PROF build.
-   build: bash tools/build_variant.sh prof refit_wave64.hip -DBCBF_RW64_PROF      run (GPU box): python tools/prof_refit32.py"""
+   build: bash tools/build_variant.sh prof refit_wave64.hip -DBCBF_RW64_PROF      run (GPU box): python tools/dev/prof_refit32.py"""
 import os, sys, json
-os.environ["BCBF_LIB_PATH"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_variants", "libbcbf_prof.so")
+os.environ["BCBF_LIB_PATH"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_variants", "libbcbf_prof.so")
 os.environ["BCBF_REFIT_WAVE"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances

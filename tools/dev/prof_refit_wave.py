@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Development: per-section cycle counts / timings of the one-wave-per-instance fp64 refit for a set of -D variants.
 
-  build : python tools/prof_refit_wave.py build     (here; hipcc cross-compiles into tools/_variants/)
-  run   : python tools/prof_refit_wave.py run       (on the GPU box)
+  build : python tools/dev/prof_refit_wave.py build     (here; hipcc cross-compiles into tools/_variants/)
+  run   : python tools/dev/prof_refit_wave.py run       (on the GPU box)
 
 Variants named *_prof carry -DBCBF_RW64_PROF (cycle counters in Ldense[b][0][1..6])."""
 import ctypes, json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 VARIANTS = {

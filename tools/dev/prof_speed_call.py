@@ -1,6 +1,6 @@
 """Where one `custom_predict_fullmat(Xtest); clear_cache()` call of the published speed test goes (development)."""
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from bayesian_cbf_amd.control_affine_model import ControlAffineRegressorExact, ControlAffineRegressorVector
 import math

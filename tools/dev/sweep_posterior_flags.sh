@@ -1,4 +1,4 @@
-# A/B sweeps of the posterior kernel's tuning macros on the GPU box:  bash tools/sweep_posterior_flags.sh "<flags>" ...
+# A/B sweeps of the posterior kernel's tuning macros on the GPU box:  bash tools/dev/sweep_posterior_flags.sh "<flags>" ...
 for flags in "$@"; do
   touch bayesian_cbf_amd/csrc/posterior_step.hip
   BCBF_EXTRA_HIPCC_FLAGS="$flags" python -m bayesian_cbf_amd.build > /dev/null 2>&1 || { echo "$flags BUILD FAILED"; continue; }

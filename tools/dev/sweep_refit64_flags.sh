@@ -1,4 +1,4 @@
-# A/B / ablation sweeps of the fp64 refit kernel on the GPU box:  bash tools/sweep_refit64_flags.sh "<flags>" ...
+# A/B / ablation sweeps of the fp64 refit kernel on the GPU box:  bash tools/dev/sweep_refit64_flags.sh "<flags>" ...
 for flags in "$@"; do
   touch bayesian_cbf_amd/csrc/refit_mfma64.hip
   BCBF_EXTRA_HIPCC_FLAGS="$flags" python -m bayesian_cbf_amd.build > /dev/null 2>&1 || { echo "$flags BUILD FAILED"; continue; }

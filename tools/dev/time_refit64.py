@@ -1,8 +1,8 @@
 import sys, os, torch, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from _timing import timeit
 os.environ["BCBF_REFIT_WAVE"] = "1"
 out = {}

@@ -1,9 +1,9 @@
 """Latency of ONE model's refit (the facade's fit / clear_cache path), fp32 and fp64 (development)."""
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from _timing import timeit
 for dtype in (torch.float32, torch.float64):
     out = []

@@ -2,9 +2,9 @@
 """Time line of the two waves of one instance in the two-waves-per-instance refit (development).
 
     tools/build_variant.sh rptrace refit_wave64.hip -DBCBF_RP_TRACE
-    BCBF_LIB_PATH=tools/_variants/libbcbf_rptrace.so python tools/trace_refit_pair.py [f32|f64] [batch] [N]"""
+    BCBF_LIB_PATH=tools/_variants/libbcbf_rptrace.so python tools/dev/trace_refit_pair.py [f32|f64] [batch] [N]"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from bayesian_cbf_amd import ops, _lib

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Tuning harness of the jets instantiations of the posterior kernel (rel-degree-2 path; development tool).
 
-  build : python tools/tune_jets.py build      (here; hipcc cross-compiles; prints registers / scratch per variant)
-  run   : python tools/tune_jets.py run [f64]  (on the GPU box; interleaved rounds in one process)
+  build : python tools/dev/tune_jets.py build      (here; hipcc cross-compiles; prints registers / scratch per variant)
+  run   : python tools/dev/tune_jets.py run [f64]  (on the GPU box; interleaved rounds in one process)
 
 Variants = columns per pipeline stage x occupancy target (-DBCBF_PJ_UNR32/64, -DBCBF_PJ_WAVES32/64) in tools/_variants/jets_*.so;
 results are checked against the fp64 jets of the shipped library."""
 import ctypes, os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 VARIANTS = {"u%d_w%d" % (u, w): ["-DBCBF_PJ_UNR32=%d" % u, "-DBCBF_PJ_WAVES32=%d" % w, "-DBCBF_PJ_UNR64=%d" % u, "-DBCBF_PJ_WAVES64=%d" % w]

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Kernel-tuning harness for the posterior-step kernel (development tool, not product code).
 
-  build : python tools/tune_posterior.py build          (here; hipcc cross-compiles)
-  run   : python tools/tune_posterior.py run            (on the GPU box; interleaved rounds, one process)
+  build : python tools/dev/tune_posterior.py build          (here; hipcc cross-compiles)
+  run   : python tools/dev/tune_posterior.py run            (on the GPU box; interleaved rounds, one process)
 
 Each variant is the same source compiled with different -D knobs into tools/_variants/<name>.so.
 """
@@ -12,7 +12,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 VDIR = os.path.join(ROOT, "tools", "_variants")
 CSRC = os.path.join(ROOT, "bayesian_cbf_amd", "csrc")
 
