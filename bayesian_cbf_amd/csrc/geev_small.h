@@ -161,7 +161,8 @@ BCBF_HD inline int geev_real(int n, double A[NMAX][NMAX], double wr[NMAX], doubl
         // ... and balance the norms of the rows / columns of the active block by powers of two
         const double sclfac = 2.0, factor = 0.95;
         const double sfmin1 = SAFMIN / ULP, sfmax1 = 1.0 / sfmin1, sfmin2 = sfmin1 * sclfac, sfmax2 = 1.0 / sfmin2;
-        for (bool again = true; again;) {
+        int passes = 0;
+        for (bool again = true; again && passes < 64; ++passes) {     // (bounded: no input may spin a device thread forever)
             again = false;
             for (int i = k; i <= l; ++i) {
                 double c = 0.0, r = 0.0, ca = 0.0, ra = 0.0;
@@ -436,6 +437,10 @@ BCBF_HD inline void project_psd(int n, double H[NMAX][NMAX], double w[NMAX], dou
 
 BCBF_HD inline int clean_hessian(int n, double H[NMAX][NMAX], double eps, int mode) {
     double w[NMAX], Vs[NMAX][NMAX], S[NMAX][NMAX];
+    // a non-finite entry: the reference's eigenvalues are NaN there and its `assert (evalz > -EPS).all()` fails (status 1, H
+    // untouched).  Decided HERE: xGEBAL's balancing loop does not terminate on NaN input (every comparison is false; newer
+    // LAPACK releases test DISNAN at that spot for the same reason)
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (!(fabs(H[i][j]) <= 1.7976931348623157e308)) return 1;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) S[i][j] = 0.5 * (H[i][j] + H[j][i]);
     {   // The common case first: a symmetric part that is positive definite by a wide margin has no eigenvalue < 0 and the
         // matrix stays as it is (status 0) -- decided by an unpivoted Cholesky whose pivots all exceed 1e-10 of the trace

@@ -63,6 +63,18 @@
 #ifndef BCBF_PJ_WAVES64
 #define BCBF_PJ_WAVES64 1
 #endif
+#ifndef BCBF_PJ_ONE
+#define BCBF_PJ_ONE 1        // fp32 jets with 12 right-hand-side columns (unicycle shape): ONE row block per thread (see ONE below)
+#endif
+#ifndef BCBF_PJ_ONE_UNR
+#define BCBF_PJ_ONE_UNR 8
+#endif
+#ifndef BCBF_PJ_ONE_WAVES
+#define BCBF_PJ_ONE_WAVES 3
+#endif
+#ifndef BCBF_PX_VALU32
+#define BCBF_PX_VALU32 1     // fp32 query + append column: per-lane Gram / mean sums instead of the matrix-core accumulator
+#endif
 
 namespace bcbf {
 
@@ -130,9 +142,18 @@ template <> struct Mfma16<double> {
 // sqrt(kappa - l'l), the new whitened target (y - Vw'l) / d (gp_append_inplace_kernel).  Round 3 answered the control query and
 // the append on one pass with TWO full queries (2 C = 6 columns at the unicycle shape): in fp64 that form fits two columns
 // per pipeline stage and streamed at 4.0 TB/s at N >= 1024; C + 1 = 4 columns run the plain kernel's schedule.
-template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false, int XC = 0>
+// ONE row block per thread (instead of the mirrored pair): half the residual accumulators and half the bytes per load
+// instruction per thread, twice the threads -- for the form whose 12 right-hand-side columns leave the pair form 256 registers,
+// two waves per SIMD and four columns per pipeline stage: three waves per SIMD with eight columns per stage each put 1.5 x the
+// bytes in flight per CU.  Lane l of wave w holds row block p = 32 w + (l & 31) (l < 32) or its mirror nrb - 1 - p (l >= 32): every
+// wave keeps the pair form's balance between long and short columns.
+template <typename T, int C, int NJ> __host__ __device__ constexpr bool ps_one_rowblock() {
+    return BCBF_PJ_ONE && sizeof(T) == 4 && NJ == 3 && C == 3;
+}
+
+template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false, int XC = 0, bool ONEP = false>
 __global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256),
-                                   (NJ > 0 ? (sizeof(T) == 8 || C * (1 + NJ) > 12 || NJ > 3 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
+                                   (NJ > 0 ? (ONEP ? BCBF_PJ_ONE_WAVES : sizeof(T) == 8 || C * (1 + NJ) > 12 || NJ > 3 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
                       const T* __restrict__ UHB, const T* __restrict__ ell, const T* __restrict__ s2p,
                       const T* __restrict__ Bm, const T* __restrict__ M0, const T* __restrict__ xq,
@@ -156,7 +177,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     constexpr int RPB = NB / V;          // row blocks per diagonal block
     constexpr int CP = (CT + 3) / 4 * 4; // padded RHS count in LDS
     constexpr int CQ = (CT - XC) / NQ;                         // columns of one query
-    constexpr int NG = NQ * (CQ * (CQ + 1) / 2);               // Gram entries kept: per query, upper triangle
+    constexpr int NGQ = NQ * (CQ * (CQ + 1) / 2);              // Gram entries kept: per query, upper triangle
+    constexpr int NG = NGQ + XC;                               // (+ l'l of the append's column)
     // (a <= c, same query) -> slot; with NQ = 1 this is the upper triangle of the full CT x CT Gram
     auto gidx = [](int a, int c) {
         const int qi = a / CQ, a_ = a - qi * CQ, c_ = c - qi * CQ;
@@ -164,8 +186,11 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     };
     // jets: a w_J row is widened to 16 entries [w (CT), Vw row (n), zeros]: the 32 x 16 tile is both operands of the
     // matrix-core product of step 2b
-    constexpr bool MG = NJ > 0 || NQ > 1 || XC > 0;            // Gram / mean sums on the matrix cores (the forms with
-                                                               // many right-hand-side columns: jets, several queries)
+    // Gram / mean sums on the matrix cores: the forms with many right-hand-side columns (jets, several queries), and the
+    // query + append column in fp64 (128-register cap at 512 threads).  In fp32 that form (4 columns, one wave per instance
+    // at N <= 512) keeps the plain kernel's per-lane sums: the eight MFMAs + LDS reads per block sat in the one wave's serial
+    // chain (4096 x 512: 442 us against the plain kernel's 331)
+    constexpr bool MG = NJ > 0 || NQ > 1 || (XC > 0 && (sizeof(T) == 8 || !BCBF_PX_VALU32));
     // ... in one 16-column tile when CT + n <= 16 (every shape up to the unicycle's n=3, m=2), in two otherwise
     // (n=3 m=3, n=4 m=2, n=4 m=3: CT = 16, 15, 20): the product is then 2 x 2 accumulators
     constexpr int NEEDW = CT + (NJ > 0 ? NJ : NS);
@@ -180,8 +205,12 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const int tid = threadIdx.x;
     const int nrb = Np / V;
     const int npairs = nrb / 2;
-    const bool live = tid < npairs;
-    const int rbA = tid, rbB = nrb - 1 - tid;
+    constexpr bool ONE = ONEP;
+    static_assert(!ONEP || (NQ == 1 && !RHS && XC == 0 && ps_one_rowblock<T, C, NJ>()), "one row block per thread: the fp32 unicycle jets");
+    constexpr int NR = ONE ? 1 : 2;     // row blocks per thread
+    const int pidx = ONE ? ((tid >> 6) * 32 + (tid & 31)) : tid;
+    const bool live = pidx < npairs;
+    const int rbA = ONE ? (((tid >> 5) & 1) ? nrb - 1 - pidx : pidx) : tid, rbB = nrb - 1 - tid;
     const T* __restrict__ lop = Lop + (size_t)gb * lop_elems<V>(Nl);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(lop), 0, (int)(lop_elems<V>(Nl) * sizeof(T)), 0x00020000);
@@ -224,8 +253,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // column-pairs and pays ~0.9 v_mov per packed multiply-add to shuffle the pairs (47 % of the loop's VALU issue).
     constexpr bool PK = BCBF_PS_PKASM && std::is_same<T, float>::value;
     using f32x2 = __attribute__((__vector_size__(2 * sizeof(float)))) float;
-    T acc[PK ? 1 : 2][PK ? 1 : V][PK ? 1 : CT];
-    f32x2 accp[PK ? 2 : 1][PK ? V / 2 : 1][PK ? CT : 1];
+    T acc[PK ? 1 : NR][PK ? 1 : V][PK ? 1 : CT];
+    f32x2 accp[PK ? NR : 1][PK ? V / 2 : 1][PK ? CT : 1];
 #define BCBF_ACC(r, v, c) (*(PK ? reinterpret_cast<T*>(&accp[r][(v) >> 1][c]) + ((v) & 1) : &acc[PK ? 0 : (r)][PK ? 0 : (v)][PK ? 0 : (c)]))
     // The training-input loads of a row set (V rows) are issued together, bounds-checked (rows >= N, state dimensions
     // >= n and idle lanes read zeros without a branch), then the kernel values are formed: one exposed load latency
@@ -235,7 +264,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(UHBb), 0, (int)((size_t)N * (RHS ? cu : C) * sizeof(T)), 0x00020000);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int rb = r == 0 ? rbA : rbB;
         if constexpr (RHS) {
             // given right-hand sides: r_i = Xdot_i - M0' uh_i  (rows >= N, columns >= n and idle lanes: zeros)
@@ -337,7 +366,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // loads of the next group (also across a block boundary) and the diagonal-block values of the
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
-    constexpr int UNR = NJ > 0 ? (CT > 12 ? 2 : sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
+    constexpr int UNR = ONE ? BCBF_PJ_ONE_UNR : NJ > 0 ? (CT > 12 ? 2 : sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
                                : (NQ > 1 ? (sizeof(T) == 8 ? BCBF_PQ_UNR64 : BCBF_PQ_UNR) : (PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
@@ -353,7 +382,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         for (int u = 0; u < UNR; ++u) {
             const int soff = (lop_base<V>(J * NB + g * UNR + u, Nl) + (J + 1) * NB) * (int)sizeof(T);
             la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
-            lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
+            if constexpr (!ONE) lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
         }
     };
     auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
@@ -368,7 +397,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     wp[2 * q] = __builtin_shufflevector(w4, w4, 0, 1);
                     wp[2 * q + 1] = __builtin_shufflevector(w4, w4, 2, 3);
                 }
-                const f32x4 a4 = __builtin_bit_cast(f32x4, la[u]), b4 = __builtin_bit_cast(f32x4, lb[u]);
+                const f32x4 a4 = __builtin_bit_cast(f32x4, la[u]), b4 = __builtin_bit_cast(f32x4, lb[ONE ? 0 : u]);
                 const f32x2 pa2[2] = {__builtin_shufflevector(a4, a4, 0, 1), __builtin_shufflevector(a4, a4, 2, 3)};
                 const f32x2 pb2[2] = {__builtin_shufflevector(b4, b4, 0, 1), __builtin_shufflevector(b4, b4, 2, 3)};
 #pragma unroll
@@ -379,13 +408,15 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         if (c & 1) {
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
                                 : "+v"(accp[0][vp][c]) : "v"(pa2[vp]), "v"(wp[c >> 1]));
+                            if constexpr (!ONE)
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
-                                : "+v"(accp[1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
+                                : "+v"(accp[NR - 1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
                         } else {
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
                                 : "+v"(accp[0][vp][c]) : "v"(pa2[vp]), "v"(wp[c >> 1]));
+                            if constexpr (!ONE)
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
-                                : "+v"(accp[1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
+                                : "+v"(accp[NR - 1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
                         }
                     }
             } else {
@@ -399,7 +430,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
                         acc[0][v][c] -= pa[v] * wj[c];
-                        acc[1][v][c] -= pb[v] * wj[c];
+                        if constexpr (!ONE) acc[NR - 1][v][c] -= pb[v] * wj[c];
                     }
             }
         }
@@ -435,7 +466,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         const int row0 = J * NB;
         // 1. publish r_J
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int rb = r == 0 ? rbA : rbB;
             if (live && rb / RPB == J) {
 #pragma unroll
@@ -486,6 +517,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     for (int a = 0; a < CQ; ++a)
 #pragma unroll
                         for (int c = a; c < CQ; ++c) gram[g++] += w[qi * CQ + a] * w[qi * CQ + c];
+                if constexpr (XC > 0) gram[NGQ] += w[CT - 1] * w[CT - 1];
                 }
                 (void)g;
                 if constexpr (MG) {
@@ -615,7 +647,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         }
         return;
     }
-    if constexpr (XC > 0) {
+    if constexpr (MG && XC > 0) {
         // query + one column: the query's Gram block / mean as usual; row / column C of the accumulator is the column l:
         // (C, C) = l'l, (CT + d, C) = (Vw'l)_d -> Gfull[b][1 + n]
         if (tid < 64) {
@@ -707,6 +739,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         for (int c = 0; c < CT; ++c) Mb[d * CT + c] = mk[d][c];
                     }
             }
+            if constexpr (XC > 0) {                              // the append's column: l'l and Vw'l -> Gfull[b][1 + n]
+                if (Gfull != nullptr) {
+                    Gfull[(size_t)b * (1 + n)] = (T)gsum[NGQ];
+#pragma unroll
+                    for (int d = 0; d < NS; ++d)
+                        if (d < n) Gfull[(size_t)b * (1 + n) + 1 + d] = mk[d][CT - 1];
+                }
+            }
             const T* M0b = M0 + (size_t)gb * C * n;
             const T* Bmb = Bm + (size_t)gb * C * C;
 #pragma unroll
@@ -785,7 +825,18 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
             case 22: BCBF_PJ_LAUNCH(3, 2); break;
             case 23: BCBF_PJ_LAUNCH(4, 2); break;
             case 31: BCBF_PJ_LAUNCH(2, 3); break;
-            case 32: BCBF_PJ_LAUNCH(3, 3); break;
+            case 32:
+                if constexpr (ps_one_rowblock<T, 3, 3>()) {
+                    if (2 * npairs <= 256) {            // (N <= 1024: one row block per thread, twice the threads)
+                        block = dim3(round_up(2 * npairs, 64));
+                        hipLaunchKernelGGL((posterior_step_kernel<T, 3, 4, 3, 1, false, 0, true>), grid, block, 0, st, Lop, Vw, X, UHB, ell,
+                                           s2, Bm, M0, xq, jitter2, Mk, Bk, Wout, Gfull, Mfull, shared, N, Np, n, (const T*)nullptr, Bt,
+                                           Nl, ldN, kind, (const T*)nullptr);
+                        break;
+                    }
+                }
+                BCBF_PJ_LAUNCH(3, 3);
+                break;
             case 33: BCBF_PJ_LAUNCH(4, 3); break;
             case 41: BCBF_PJ_LAUNCH(2, 4); break;
             case 42: BCBF_PJ_LAUNCH(3, 4); break;

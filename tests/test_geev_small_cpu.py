@@ -210,3 +210,20 @@ def test_branch_decision_on_the_boundaries_follows_the_general_eigenvalues(host,
         assert ok or margin < 5e-16 * max(1.0, np.abs(M).max()), (kind, rc, ev_t, M)
     print(n, checked)
     assert checked["assert_"] > 100 and checked["fired"] > 300 and checked["untouched"] > 100
+
+
+def test_non_finite_input_terminates_with_the_assert_status(host):
+    """A NaN / Inf entry: the reference's eigenvalues are NaN and its assert fails -> status 1, matrix untouched -- and the
+    port RETURNS (xGEBAL's balancing loop spins forever on NaN: every comparison is false; on the device that is a hung GPU)."""
+    import multiprocessing as mp
+    for bad in (np.nan, np.inf, -np.inf):
+        for n in (1, 2, 3, 4):
+            M = np.eye(n) + 0.1
+            M[n - 1, 0] = bad
+            M[0, n - 1] = bad
+            rc, H = host.clean(M)
+            assert rc == 1
+            np.testing.assert_array_equal(H, M)
+            rc, H = host.clean(M, mode=1)
+            assert rc == 1
+            assert host.eig(M)[0] in (0, 1, 2)        # (whatever it reports, it comes back)

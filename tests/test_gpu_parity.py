@@ -496,6 +496,23 @@ def test_hessian_cleanup_on_device_vs_executed_reference(ops, dtype):
     assert same >= 76 and same + explained == 80 and differs_proj >= 50, (same, explained, differs_proj)
 
 
+@pytest.mark.timeout(120)
+def test_hessian_cleanup_on_device_non_finite_input_returns(ops):
+    """NaN / Inf entries: status 1 (the reference's assert fails on NaN eigenvalues), the matrix handed back as it came -- and
+    the kernel RETURNS (the general solver's balancing loop would spin forever on NaN)."""
+    for n in (1, 2, 3, 4):
+        M = np.tile(np.eye(n) + 0.1, (6, 1, 1))
+        M[1, n - 1, 0] = np.nan
+        M[3, 0, n - 1] = np.inf
+        M[4, 0, 0] = -np.inf
+        for dtype in (torch.float64, torch.float32):
+            H, status = ops.clean_hessian(dev(M, dtype))
+            torch.cuda.synchronize()
+            st = status.cpu().numpy()
+            assert list(st) == [0, 1, 0, 1, 1, 0], (n, st)
+            np.testing.assert_array_equal(host(H)[[0, 2, 5]], M[[0, 2, 5]].astype(np.float32 if dtype == torch.float32 else np.float64))
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4])
 def test_hessian_cleanup_on_device_random_vs_general_eigensolver(ops, n):
     """4000 random near-PSD matrices per size against the reference's own statements run on torch.linalg.eig (= the
