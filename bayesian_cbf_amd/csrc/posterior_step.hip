@@ -64,7 +64,11 @@
 #define BCBF_PJ_WAVES64 1
 #endif
 #ifndef BCBF_PJ_ONE
-#define BCBF_PJ_ONE 1        // fp32 jets with 12 right-hand-side columns (unicycle shape): ONE row block per thread (see ONE below)
+#define BCBF_PJ_ONE 0        // fp32 jets with 12 right-hand-side columns (unicycle shape): ONE row block per thread (see ONE below).
+                             // OFF -- measured round 5, 4096 x 512, n=3, m=2 (columns per stage, waves/SIMD): pair form (4,2) 0.438 ms;
+                             // one row block per thread (8,2) 0.506, (4,2) 0.552, (16,2) 0.555 (36 B scratch), (16,1) 0.598, (8,3) 0.694
+                             // (148 B scratch): two waves per instance meet at two barriers per block and both wait for wave 0's
+                             // diagonal step -- the bytes in flight gained are lost to that chain
 #endif
 #ifndef BCBF_PJ_ONE_UNR
 #define BCBF_PJ_ONE_UNR 8
