@@ -23,7 +23,9 @@ _SIGS = {
     "bcbf_posterior_shared_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_posterior_shared_f64": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_posterior_shared_matern52_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
+    "bcbf_posterior_shared_rbfm52_f32": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_posterior_shared_matern52_f64": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
+    "bcbf_posterior_shared_rbfm52_f64": (c_int, [P] * 13 + [c_int, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_rows": (c_int, [ctypes.POINTER(c_int), c_int, c_int, c_int]),
     "bcbf_controller_cones_f32": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_f64": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
@@ -33,7 +35,9 @@ _SIGS = {
 _TSIGS = {
     "bcbf_kb_build": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_kb_build_matern52": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_kb_build_rbfm52": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query_matern52": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_query_rbfm52": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_refit": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_potrf": [P, P, P, P, c_int, c_int, P],
     "bcbf_potrs": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
@@ -56,9 +60,13 @@ _TSIGS = {
     "bcbf_posterior_jets": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_cbc2_terms": [P] * 15 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_refit_matern52": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bcbf_refit_rbfm52": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_jets_matern52": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_jets_rbfm52": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_mll_grad_matern52": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],
+    "bcbf_mll_grad_rbfm52": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],
     "bcbf_gp_append_matern52": [P] * 17 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_gp_append_rbfm52": [P] * 17 + [c_int, c_int, c_int, c_int, P],
     "bcbf_clean_hessian": [P, P, P, c_int, c_int, c_double, c_int, P],
     "bcbf_predict_assemble": [P] * 10 + [c_int] * 5 + [P],
     "bcbf_cbc_terms": [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
@@ -69,6 +77,7 @@ _TSIGS = {
     "bcbf_rollout_stats": [P] * 8 + [c_int, c_int, c_int, P],
     "bcbf_unicycle_control_step": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
     "bcbf_unicycle_control_step_matern52": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "bcbf_unicycle_control_step_rbfm52": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int, P, P, P],
 }
 
 

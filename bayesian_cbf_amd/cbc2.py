@@ -245,7 +245,8 @@ def lie1_gradient(model, grad_gp, x, eigeps=2e-3):
     idx = [(1 + i) * C for i in range(n)]
     Gm = G[0]
     s00, s_i = Bk[0, 0, 0], -Gm[idx, 0]
-    kxx = 5.0 / 3.0 if getattr(reg, "data_kernel", "rbf") == "matern52" else 1.0     # d2 k / dx dx' at x' = x, in units of s2 / ell^2
+    from .data_kernels import kxx as _kxx
+    kxx = _kxx(getattr(reg, "data_kernel", "rbf"))     # d2 k / dx dx' at x' = x, in units of s2 / ell^2 (1 | 5/3 | 8/3)
     sij = torch.diag(kxx * s2 / (ell * ell) * B00) - Gm[idx][:, idx]
     Agh = A @ gh
     HAg = Hh @ Agh

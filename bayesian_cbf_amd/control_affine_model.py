@@ -24,7 +24,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import data_kernels, ops
 from .gp_algebra import GaussianProcess
 from .matrix_variate_multitask_model import HetergeneousMatrixVariateMean, SharedConstantMeans
 
@@ -115,10 +115,10 @@ class ControlAffineRegressor:
     def __init__(self, x_dim, u_dim, device=None, default_device=default_device,
                  gamma_length_scale_prior=None, model_class=None, rank=None, dtype=None, generator=None,
                  data_kernel="rbf"):
-        """data_kernel: "rbf" (the reference's ScaleKernel(RBFKernel(ard)), :164-171) or the OPT-IN "matern52"
-        (ScaleKernel(MaternKernel(nu=2.5, ard)); no reference counterpart, parity unpinned, bcbf.h): prediction, `fit`,
-        `append_data` and the derivative GP (rel-degree-2 conditions, expression trees) run on it; the matrix-core regime-S
-        query and the fused unicycle control step stay with the RBF."""
+        """data_kernel: "rbf" (the reference's ScaleKernel(RBFKernel(ard)), :164-171), or OPT-IN "matern52"
+        (ScaleKernel(MaternKernel(nu=2.5, ard))) or "rbf_matern52" (the product of the two on one set of length scales) --
+        no reference counterpart, parity unpinned (bcbf.h): prediction (incl. the matrix-core regime-S query), `fit`,
+        `append_data`, the derivative GP (rel-degree-2 conditions, expression trees) and the fused control step run on them."""
         if data_kernel not in ops.DATA_KERNELS:
             raise ValueError("data_kernel %r: one of %s" % (data_kernel, ops.DATA_KERNELS))
         self.data_kernel = data_kernel
@@ -632,10 +632,7 @@ class ControlAffineRegressor:
         ell, s2 = hp["ell"].reshape(1, 1, -1), hp["s2"].reshape(())
         with torch.no_grad():
             d = (X1[:, None, :] - X2[None, :, :]) / ell
-            if self.data_kernel == "matern52":
-                a = torch.sqrt(5.0 * (d * d).sum(-1))
-                return s2 * (1.0 + a + a * a / 3.0) * torch.exp(-a)
-            return s2 * torch.exp(-0.5 * (d * d).sum(-1))
+            return s2 * data_kernels.shape_terms(self.data_kernel, (d * d).sum(-1))[0]
 
     def custom_predict(self, Xtest_in, Utest_in=None, UHfill=1, Xtestp_in=None, Utestp_in=None, UHfillp=1,
                        compute_cov=True, grad_gp=False, grad_check=False, scalar_var_only=False):

@@ -55,6 +55,26 @@ int launch_posterior_shared_reg(const T* Lop, const T* Vw, const T* X, const T* 
                                 const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk, T* W, int nq,
                                 int N, int n, int m, void* stream, int kind = 0);   // kind: 0 RBF, 1 Matern-5/2
 
+// Data kernels: k(x, x') = s2 * shape(d2), d2 = sum_d ((x_d - x'_d) / ell_d)^2.
+//   0  RBF               exp(-d2 / 2)                                   -- the reference's (ScaleKernel(RBFKernel(ard)))
+//   1  Matern-5/2        (1 + a + a^2 / 3) exp(-a),  a = sqrt(5 d2)      -- opt-in
+//   2  RBF x Matern-5/2  the PRODUCT of the two, one set of ARD length scales ("RBF x Matern", BASELINE.json north_star) -- opt-in
+// The opt-in kinds have no reference counterpart (no Matern in the reference); parity unpinned, formulas held to
+// the CPU oracle and to finite differences.  `dshape` = -2 d shape / d(d2): d shape / d x_d = dshape (x'_d - x_d) / ell_d^2,
+// d shape / d ell_d = dshape z_d^2 / ell_d; at x' = x: d2 shape / dx_d dx'_d = kernel_kxx(kind) / ell_d^2.
+constexpr int BCBF_KIND_RBF = 0, BCBF_KIND_MATERN52 = 1, BCBF_KIND_RBF_MATERN52 = 2, BCBF_KINDS = 3;
+template <typename T, typename EXPF>
+__host__ __device__ inline void kernel_shape(int kind, T d2, EXPF expf_, T& shape, T& dshape) {
+    if (kind == BCBF_KIND_RBF) { shape = expf_(T(-0.5) * d2); dshape = shape; return; }
+    const T a5 = (T)sqrt((double)(T(5) * d2));
+    const T poly = T(1) + a5 + T(5) / T(3) * d2, dpoly = T(5) / T(3) * (T(1) + a5);
+    if (kind == BCBF_KIND_MATERN52) { const T e5 = expf_(-a5); shape = poly * e5; dshape = dpoly * e5; return; }
+    const T e = expf_(-a5 - T(0.5) * d2);
+    shape = poly * e;
+    dshape = shape + dpoly * e;
+}
+__host__ __device__ inline double kernel_kxx(int kind) { return kind == BCBF_KIND_RBF ? 1.0 : kind == BCBF_KIND_MATERN52 ? 5.0 / 3.0 : 8.0 / 3.0; }
+
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -156,7 +156,7 @@ __global__ void cbc2_terms_kernel(const T* __restrict__ Mk, const T* __restrict_
     double e0[CC];
     for (int a = 0; a < CC; ++a) e0[a] = a == 0 ? 1.0 : 0.0;
     const double s00 = Bkd[0][0];
-    const double kxx = kernel_kind == 1 ? 5.0 / 3.0 : 1.0;      // d2 k / dx_d dx'_d at x' = x in units of s2 / ell_d^2: RBF 1, Matern-5/2 5/3
+    const double kxx = kernel_kxx(kernel_kind);      // d2 k / dx_d dx'_d at x' = x in units of s2 / ell_d^2: RBF 1, Matern-5/2 5/3, product 8/3
     double s_i[NN], H[NN][NN];
     for (int i = 0; i < NN; ++i) s_i[i] = i < n ? -Gat(1 + i, 0, 0, 0) : 0.0;
     for (int i = 0; i < NN; ++i)
@@ -261,7 +261,7 @@ static int launch_cbc2_terms(const T* Mk, const T* Bk, const T* G, const T* Mj, 
                              const T* s2, const T* h, const T* gh, const T* Hh, const T* kalpha, const T* u0, T* out,
                              int* status, int Bt, int n, int m, int hessian_mode, int kernel_kind, void* stream) {
     if (Bt <= 0) return BCBF_OK;
-    if ((hessian_mode != 0 && hessian_mode != 1) || (kernel_kind != 0 && kernel_kind != 1)) return BCBF_EINVAL;
+    if ((hessian_mode != 0 && hessian_mode != 1) || kernel_kind < 0 || kernel_kind >= BCBF_KINDS) return BCBF_EINVAL;
     if (!Mk || !Bk || !G || !Mj || !A || !Bm || !ell || !s2 || !h || !gh || !Hh || !kalpha || !u0 || !out) return BCBF_EINVAL;
     if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
     hipLaunchKernelGGL((cbc2_terms_kernel<T>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, Mk, Bk, G, Mj, A,

@@ -46,3 +46,6 @@ BCBF_CTRL(double, f64, bcbf_unicycle_control_step_, bcbf_posterior_query_, BCBF_
 // shared_gp: the matrix-core query), everything behind it is the same launch
 BCBF_CTRL(float, f32, bcbf_unicycle_control_step_matern52_, bcbf_posterior_query_matern52_, BCBF_STEP_M52(f32))
 BCBF_CTRL(double, f64, bcbf_unicycle_control_step_matern52_, bcbf_posterior_query_matern52_, BCBF_STEP_M52(f64))
+#define BCBF_STEP_RM52(SUF) bcbf_posterior_query_rbfm52_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, x, nullptr, Mk, Bk, nullptr, 0, Bt, N, 3, 2, stream)
+BCBF_CTRL(float, f32, bcbf_unicycle_control_step_rbfm52_, bcbf_posterior_query_rbfm52_, BCBF_STEP_RM52(f32))
+BCBF_CTRL(double, f64, bcbf_unicycle_control_step_rbfm52_, bcbf_posterior_query_rbfm52_, BCBF_STEP_RM52(f64))

@@ -92,11 +92,7 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
             dot += xi * xj;
         }
         double krbf, kder;                                   // kernel shape; its d / d ell_d is kder * z_d^2 / ell_d
-        if (kind == 1) {                                     // Matern-5/2 (opt-in)
-            const double a5 = sqrt(5.0 * d2), e5 = exp(-a5);
-            krbf = (1.0 + a5 + 5.0 / 3.0 * d2) * e5;
-            kder = 5.0 / 3.0 * (1.0 + a5) * e5;
-        } else { krbf = exp(-0.5 * d2); kder = krbf; }
+        kernel_shape(kind, d2, [](double v) { return exp(v); }, krbf, kder);      // (RBF | Matern-5/2 | their product)
         const double kij = krbf + linv * dot;
         double ui[CM], uj[CM], uij = 0.0;
 #pragma unroll
@@ -251,6 +247,20 @@ int bcbf_mll_grad_matern52_f64(const double* Lop, const double* alpha, const dou
                                int n, int m, void* work, void* stream) {
     return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
                                          UHtA, Bt, N, n, m, stream, work, -1, nullptr, nullptr, 1);
+}
+int bcbf_mll_grad_rbfm52_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                             const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
+                             float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
+                             void* work, void* stream) {
+    return bcbf::launch_mll_grad<float>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                        UHtA, Bt, N, n, m, stream, work, -1, nullptr, nullptr, 2);
+}
+int bcbf_mll_grad_rbfm52_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
+                             const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
+                             double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
+                             int n, int m, void* work, void* stream) {
+    return bcbf::launch_mll_grad<double>(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, g_ell, g_s2, g_B, logdetK, RtA,
+                                         UHtA, Bt, N, n, m, stream, work, -1, nullptr, nullptr, 2);
 }
 // Same sums for the data kernel s2 (exp(..) + lin x'x') and nt target columns (R, alpha [Bt,N,nt], Ainv [Bt,nt,nt],
 // RtA [Bt,nt,nt], UHtA [Bt,C,nt]); g_lin[Bt] = d log p / d lin.  nt = 1 with expanded inputs is the CoGP comparator

@@ -122,7 +122,7 @@ posterior_shared_kernel(const float* __restrict__ Lop, const float* __restrict__
 #pragma unroll
             for (int d = 0; d < NS; ++d) { const float z = (Xs[row_m * NS + d] - xqr[d]) * iell[d]; d2 += z * z; }
             float shape;
-            if constexpr (KIND == 1) { const float a5 = sqrtf(5.f * d2); shape = (1.f + a5 + (5.f / 3.f) * d2) * __expf(-a5); }
+            if constexpr (KIND != 0) { float dshape_; kernel_shape(KIND, d2, [](float q_) { return __expf(q_); }, shape, dshape_); }
             else shape = __expf(-0.5f * d2);
             const float kmine = s2 * shape;
             const float kk[4] = {dpp_q<0x00>(kmine), dpp_q<0x55>(kmine), dpp_q<0xAA>(kmine), dpp_q<0xFF>(kmine)};
@@ -310,6 +310,7 @@ static void launch_shared(dim3 grid, dim3 block, size_t lds, hipStream_t st, con
         hipLaunchKernelGGL(kern, grid, block, lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, Np, n);
     };
     if (kind == 1) go(posterior_shared_kernel<C, NS, true, 1>, 2);
+    else if (kind == 2) go(posterior_shared_kernel<C, NS, true, 2>, 3);
     else if (W != nullptr) go(posterior_shared_kernel<C, NS, true>, 0);
     else go(posterior_shared_kernel<C, NS, false>, 1);
 }
@@ -376,4 +377,10 @@ extern "C" int bcbf_posterior_shared_matern52_f32(const float* Lop, const float*
                                                   const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
                                                   int nq, int N, int n, int m, void* stream) {
     return posterior_shared_f32_impl(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 1);
+}
+extern "C" int bcbf_posterior_shared_rbfm52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                                const float* ell, const float* s2, const float* Bm, const float* M0,
+                                                const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                                int nq, int N, int n, int m, void* stream) {
+    return posterior_shared_f32_impl(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 2);
 }

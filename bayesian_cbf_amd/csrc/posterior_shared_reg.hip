@@ -292,9 +292,10 @@ posterior_shared_reg_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw,
     T phi[8];
     // shape of the data kernel at squared scaled distance d2: exp(-d2 / 2), or Matern-5/2 (1 + a + a^2 / 3) exp(-a), a = sqrt(5 d2)
     auto kshape = [&](T d2) -> T {
-        if constexpr (KIND == 1) {
-            const T a5 = (T)sqrt((double)(T(5) * d2));
-            return (T(1) + a5 + T(5) / T(3) * d2) * P::exp_(-a5);
+        if constexpr (KIND != 0) {                     // Matern-5/2 (1), RBF x Matern-5/2 (2): bcbf_common.h
+            T shape, dshape_;
+            kernel_shape(KIND, d2, [](T q_) { return P::exp_(q_); }, shape, dshape_);
+            return shape;
         }
         return P::exp_(T(-0.5) * d2);
     };
@@ -484,20 +485,22 @@ static void launch_psr(size_t lds, hipStream_t st, const T* Lop, const T* Vw, co
             const double cost = (double)((w + slots - 1) / slots) * (f ? 1.05 : 1.0) * (t ? 1.7 : 1.0);
             if (cost < best) { best = cost; five = f; two = t; }
         }
-    if (kind == 1) { five = false; two = false; }      // Matern: the base packing only
+    if (kind != 0) { five = false; two = false; }      // opt-in kernels: the base packing only
     const int waves = five ? (nq + QWD - 1) / QWD : (nq + 3) / 4;
     const dim3 grid((waves + 3) / 4);                  // 256 threads per workgroup, four waves
-    if (kind == 1) {
+    auto go_kind = [&](auto kc) {
+        constexpr int KD = decltype(kc)::value;
         static int opt_in_m[64] = {0};
         int& lds_opt_in = opt_in_m[dev_ & 63];
         if (lds > 64 * 1024 && (int)lds > lds_opt_in) {
-            (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, 1, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)posterior_shared_reg_kernel<T, C, NS, 1, 4, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             lds_opt_in = (int)lds;
         }
-        hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, 1, 4, 1>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
+        hipLaunchKernelGGL((posterior_shared_reg_kernel<T, C, NS, 1, 4, KD>), grid, dim3(256), lds, st, Lop, Vw, X, UHB, ell, s2, Bm, M0,
                            xq, jitter2, Mk, Bk, W, nq, N, Np, n);
-        return;
-    }
+    };
+    if (kind == 1) { go_kind(Ic<1>{}); return; }
+    if (kind == 2) { go_kind(Ic<2>{}); return; }
     auto go5 = [&](auto occ, auto qw) {
         constexpr int OCC = decltype(occ)::value, QW = decltype(qw)::value;
         static int opt_in[2][64] = {{0}};           // largest dynamic LDS size opted into, per device
@@ -605,5 +608,12 @@ extern "C" int bcbf_posterior_shared_matern52_f64(const double* Lop, const doubl
                                                   const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
                                                   int nq, int N, int n, int m, void* stream) {
     return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 1);
+}
+// ... and with the product kernel RBF x Matern-5/2 (kind 2)
+extern "C" int bcbf_posterior_shared_rbfm52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                                const double* ell, const double* s2, const double* Bm, const double* M0,
+                                                const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                                int nq, int N, int n, int m, void* stream) {
+    return bcbf::launch_posterior_shared_reg<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, nq, N, n, m, stream, 2);
 }
 #endif

@@ -317,11 +317,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     dot += xv[v][d] * xqr[qi][d];
                 }
                 T shape, dshape;                       // dshape: d shape / d x_q,d = dshape * (X_id - x_q,d) / ell_d^2
-                if (kind == 1) {                       // Matern-5/2: (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r), r^2 = d2
-                    const T a5 = (T)sqrt((double)(T(5) * d2));
-                    const T e5 = texp<T>(-a5);
-                    shape = (T(1) + a5 + T(5) / T(3) * d2) * e5;
-                    dshape = T(5) / T(3) * (T(1) + a5) * e5;
+                if (kind != 0) {                       // opt-in: Matern-5/2 (1), RBF x Matern-5/2 (2) -- bcbf_common.h
+                    kernel_shape(kind, d2, [](T q_) { return texp<T>(q_); }, shape, dshape);
                 } else { shape = texp<T>(T(-0.5) * d2); dshape = shape; }
                 const T k = s2 * (shape + linv * dot);
                 const T kd = s2 * dshape;              // (jets: no linear part)
@@ -819,7 +816,7 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
         return check_launch("posterior_pair");
     }
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
-        if (!Mfull || lin || (kind != 0 && kind != 1)) return BCBF_EINVAL;
+        if (!Mfull || lin || kind < 0 || kind >= BCBF_KINDS) return BCBF_EINVAL;
         if (n > 4) return BCBF_EINVAL;                  // (the rel-degree-2 terms kernel holds n <= 4 too)
         switch (10 * n + m) {                           // every (n <= 4, m <= 3): C = 1 + m columns x (1 + n) jets
             case 11: BCBF_PJ_LAUNCH(2, 1); break;
@@ -1040,6 +1037,29 @@ extern "C" int bcbf_posterior_query_matern52_f64(const double* Lop, const double
     return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m, stream,
                                                nullptr, nullptr, nullptr, 0, 1);
 }
+
+// The same two entry points for the PRODUCT kernel RBF x Matern-5/2 (kind 2 of bcbf_common.h: kernel_shape; opt-in, no
+// reference counterpart)
+#define BCBF_RBFM52_ENTRIES(T, SUF)                                                                                              \
+    extern "C" int bcbf_posterior_jets_rbfm52_##SUF(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, \
+                                                    const T* Bm, const T* M0, const T* xq, T* Mk, T* Bk, T* G, T* Mj, T* Wj,     \
+                                                    int shared, int Bt, int N, int n, int m, void* stream) {                   \
+        if (Bt <= 0) return BCBF_OK;                                                                                           \
+        if (!G || !Mj) return BCBF_EINVAL;                                                                                     \
+        return bcbf::launch_posterior_step<T>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk, Bk, Wj, shared, Bt, N, n, m,    \
+                                              stream, G, Mj, nullptr, 0, 2);                                                   \
+    }                                                                                                                          \
+    extern "C" int bcbf_posterior_query_rbfm52_##SUF(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell,          \
+                                                     const T* s2, const T* Bm, const T* M0, const T* xq, const T* jitter2,      \
+                                                     T* Mk, T* Bk, T* W, int shared, int Bt, int N, int n, int m, void* stream) { \
+        if (shared && Bt >= 16 && (sizeof(T) == 8 ? bcbf::posterior_shared64_fits(N, n, m) : bcbf::posterior_shared_fits(N, n, m))) \
+            return bcbf_posterior_shared_rbfm52_##SUF(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, Bt, N, n, m, stream); \
+        return bcbf::launch_posterior_step<T>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, shared, Bt, N, n, m,     \
+                                              stream, nullptr, nullptr, nullptr, 0, 2);                                        \
+    }
+BCBF_RBFM52_ENTRIES(float, f32)
+BCBF_RBFM52_ENTRIES(double, f64)
+#undef BCBF_RBFM52_ENTRIES
 
 // Two queries per instance on ONE pass over its factor (reserved storage): xq[Bt,n] and xq2[Bt,n] -> Mk2[Bt,2,n,1+m],
 // Bk2[Bt,2,1+m,1+m], W2[Bt,2,Np,1+m] (slot 0 = xq, slot 1 = xq2).  Internal to bcbf_gp_append_reserved (solve.hip).

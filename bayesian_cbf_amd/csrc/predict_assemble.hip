@@ -28,9 +28,9 @@ predict_assemble_kernel(const T* __restrict__ G, const T* __restrict__ Xq, const
     // data kernel at (x_qa, x'_qb): RBF (the reference's) or the opt-in Matern-5/2 (kind 1)
     T d2 = T(0);
     for (int e = 0; e < n; ++e) { const T z = (Xq[(size_t)qa * n + e] - Xqp[(size_t)qb * n + e]) / ell[e]; d2 += z * z; }
-    T k;
-    if (kind == 1) { const T a5 = (T)sqrt((double)(T(5) * d2)); k = s2p[0] * (T(1) + a5 + a5 * a5 / T(3)) * (T)exp(-(double)a5); }
-    else k = s2p[0] * (T)exp((double)(T(-0.5) * d2));
+    double shp, dshp_;
+    kernel_shape(kind, (double)d2, [](double q_) { return exp(q_); }, shp, dshp_);      // RBF | Matern-5/2 | their product
+    const T k = s2p[0] * (T)shp;
     T v = k * Bm[c * C + d] - G[(((size_t)qa * bp + qb) * C + c) * C + d];
     if (jitter != nullptr && qa == qb && c == d) v += jitter[(size_t)qa * C + c];
     if (Kron != nullptr) Kron[idx] = v * A[i * n + j];
@@ -42,7 +42,7 @@ static int launch_predict_assemble(const T* G, const T* Xq, const T* Xqp, const 
                                    const T* jitter, T* BkXX, T* Kron, int b, int bp, int n, int m, int kind, void* stream) {
     if (b <= 0 || bp <= 0) return BCBF_OK;
     if (!G || !Xq || !Xqp || !ell || !s2 || !Bm || (Kron && !A) || (!BkXX && !Kron)) return BCBF_EINVAL;
-    if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM || kind < 0 || kind > 1) return BCBF_EINVAL;
+    if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM || kind < 0 || kind >= BCBF_KINDS) return BCBF_EINVAL;
     if (jitter && b != bp) return BCBF_EINVAL;
     const int C = m + 1, nk = Kron ? n : 1;
     const size_t total = (size_t)b * C * nk * (size_t)bp * C * nk;

@@ -41,9 +41,8 @@ __global__ void kb_build_kernel(const T* __restrict__ X, const T* __restrict__ U
 #pragma unroll
         for (int a = 0; a < BCBF_MAX_TASK_DIM; ++a)
             if (a < C) uu += ub[a] * UHb[(size_t)j * C + a];
-        // kind 0: RBF exp(-d2 / 2) (the reference's data kernel);  kind 1: Matern-5/2 (opt-in, bcbf.h)
-        const T a5 = (T)sqrt((double)(T(5) * d2));
-        const T shape = kind == 1 ? (T(1) + a5 + T(5) / T(3) * d2) * texp2<T>(-a5) : texp2<T>(T(-0.5) * d2);
+        T shape, dshape_;                                   // (bcbf_common.h: kernel_shape -- RBF | Matern-5/2 | their product)
+        kernel_shape(kind, d2, [](T v) { return texp2<T>(v); }, shape, dshape_);
         T val = s2 * (shape + linv * dot) * uu;
         if (i == j && jitter) val += jitter[(size_t)b * N + i];
         Kb[((size_t)b * N + i) * N + j] = val;
@@ -91,6 +90,14 @@ int bcbf_kb_build_matern52_f32(const float* X, const float* UH, const float* Bm,
 int bcbf_kb_build_matern52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                                const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream) {
     return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, nullptr, 1);
+}
+int bcbf_kb_build_rbfm52_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                             const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_kb_build<float>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, nullptr, 2);
+}
+int bcbf_kb_build_rbfm52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                             const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_kb_build<double>(X, UH, Bm, ell, s2, jitter, Kb, Bt, N, n, m, stream, nullptr, 2);
 }
 // both precisions factor on the matrix cores (refit_mfma.hip, refit_mfma64.hip)
 extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,

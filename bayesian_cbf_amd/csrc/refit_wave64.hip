@@ -1900,9 +1900,9 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
                     for (int a = 0; a < 4; ++a) uu += ru[ib][a] * cu[a];
                     T shape;
-                    if constexpr (KIND == 1) {                     // Matern-5/2: (1 + a + a^2 / 3) exp(-a), a = sqrt(5 d2)
-                        const T a5 = (T)__builtin_sqrt((double)(T(5.0) * d2));
-                        shape = (T(1.0) + a5 + T(5.0) / T(3.0) * d2) * P::exp_neg(a5);
+                    if constexpr (KIND != 0) {                     // Matern-5/2 (1), RBF x Matern-5/2 (2): bcbf_common.h
+                        T dshape_;
+                        kernel_shape(KIND, d2, [](T q_) { return P::exp_neg(-q_); }, shape, dshape_);
                     } else shape = P::exp_neg(T(T(0.5)) * d2);
                     T val = s2 * shape * uu + (i == j ? rj[ib] : T(0.0));
                     val = (i >= N || j >= N) ? ((i == j) ? T(1.0) : T(0.0)) : val;
@@ -2123,9 +2123,13 @@ static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell,
                              T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int Np, int n, int C, int nw, hipStream_t st,
                              int kind = 0) {
     if (Np / NB > RT_MAXBLK) return -1;
-    if (kind == 1) {
+    if (kind != 0) {
         if (Kdense || (unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;
-        hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 1>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        if (kind == 1)
+            hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 1>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        else if (kind == 2)
+            hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 2>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        else return -1;
         return 0;
     }
     // the kernel addresses one instance's operator with 32-bit byte offsets (buffer resource size, scalar + lane offsets)
@@ -2151,20 +2155,22 @@ int launch_refit_team64(const double* X, const double* UH, const double* Bm, con
 
 // Fused K_b build + jittered Cholesky + packing with the OPT-IN Matern-5/2 data kernel (the reference has no Matern kernel;
 // BASELINE.json's north_star names one): arguments of bcbf_refit.  One form -- a team of eight waves per instance.
-#define BCBF_REFIT_MATERN(SUF, T)                                                                                           \
-    extern "C" int bcbf_refit_matern52_##SUF(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,   \
+#define BCBF_REFIT_MATERN(SUF, T, NAME, KINDV)                                                                              \
+    extern "C" int NAME##SUF(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2, const T* jitter,                   \
                                              T* Lop, T* UHB, T* Ldense, int* info, int Bt, int N, int n, int m, void* stream) { \
         using namespace bcbf;                                                                                                \
         if (Bt <= 0) return BCBF_OK;                                                                                         \
         if (!X || !UH || !Bm || !ell || !s2 || !Lop || !UHB || !info || N < 1) return BCBF_EINVAL;                            \
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;                            \
         if (launch_refit_team<T>(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, round_up(N, NB), n,      \
-                                 m + 1, 8, (hipStream_t)stream, 1) != 0)                                                     \
+                                 m + 1, 8, (hipStream_t)stream, KINDV) != 0)                                                 \
             return BCBF_EINVAL;                                                                                              \
         return check_launch("refit_matern52");                                                                               \
     }
-BCBF_REFIT_MATERN(f32, float)
-BCBF_REFIT_MATERN(f64, double)
+BCBF_REFIT_MATERN(f32, float, bcbf_refit_matern52_, 1)
+BCBF_REFIT_MATERN(f64, double, bcbf_refit_matern52_, 1)
+BCBF_REFIT_MATERN(f32, float, bcbf_refit_rbfm52_, 2)          // the product kernel RBF x Matern-5/2
+BCBF_REFIT_MATERN(f64, double, bcbf_refit_rbfm52_, 2)
 #undef BCBF_REFIT_MATERN
 namespace bcbf {
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,

@@ -322,10 +322,9 @@ chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict
 #pragma unroll
                 for (int c = 0; c < BCBF_MAX_CTRL_DIM + 1; ++c)
                     if (c < C) uu += f.UHB_in[((size_t)b * N + i) * C + c] * f.uh_new[(size_t)b * C + c];
-                if (f.kind == 1) {
-                    const double a5 = sqrt(5.0 * (double)d2);
-                    v = s2v * (T)((1.0 + a5 + 5.0 / 3.0 * (double)d2) * exp(-a5)) * uu;
-                } else v = s2v * (T)exp((double)(T(-0.5) * d2)) * uu;
+                double shp, dshp_;
+                kernel_shape(f.kind, (double)d2, [](double q) { return exp(q); }, shp, dshp_);
+                v = s2v * (T)shp * uu;
             }
             y[r] = v;
         }
@@ -717,6 +716,21 @@ int bcbf_gp_append_matern52_f64(const double* Lop_in, const double* Vw_in, const
                                 void* stream) {
     return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
                                           jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, nullptr, 1);
+}
+int bcbf_gp_append_rbfm52_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                              const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                              const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                              float* Vw_out, float* X_out, float* UHB_out, int* info, int Bt, int N, int n, int m, void* stream) {
+    return bcbf::launch_gp_append<float>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                         jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, nullptr, 2);
+}
+int bcbf_gp_append_rbfm52_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                              const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                              const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                              double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
+                              void* stream) {
+    return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
+                                          jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, nullptr, 2);
 }
 int bcbf_chol_append_f32(const float* Lop_in, const float* knew, const float* kappa, float* Lop_out,
                          int* info, int Bt, int N, void* stream) {

@@ -105,19 +105,14 @@ class _ModelJets:
         d = (pts[0] - pts[1]) / (ell * ell)                          # (x - x') / ell^2
         if fixed:
             k, kx, kp, kxp = s2, pts.new_zeros(n), pts.new_zeros(n), pts.new_zeros(n, n)
-        elif kernel == "matern52":
-            # k = s2 (1 + a + a^2/3) e^-a, a = sqrt5 r;  dk/dx = -g d with g = (5/3) s2 (1 + a) e^-a;
-            # d2k / dx_d dx'_e = g delta_de / ell_d^2 - (25/3) s2 e^-a d_d d_e
-            a = torch.sqrt(5.0 * ((pts[0] - pts[1]) ** 2 / (ell * ell)).sum())
-            ea = torch.exp(-a)
-            k = s2 * (1.0 + a + a * a / 3.0) * ea
-            g_ = 5.0 / 3.0 * s2 * (1.0 + a) * ea
-            kx, kp = -d * g_, d * g_
-            kxp = torch.diag(1.0 / (ell * ell)) * g_ - (25.0 / 3.0) * s2 * ea * torch.outer(d, d)
         else:
-            k = s2 * torch.exp(-0.5 * ((pts[0] - pts[1]) ** 2 / (ell * ell)).sum())
-            kx, kp = -d * k, d * k
-            kxp = (torch.diag(1.0 / (ell * ell)) - torch.outer(d, d)) * k
+            # k = s2 shape(d2);  dk/dx = -s2 dshape d;  d2k / dx_d dx'_e = s2 (dshape delta_de / ell_d^2 + ddshape d_d d_e)
+            # (data_kernels.shape_terms: RBF, or the opt-in Matern-5/2 / RBF x Matern-5/2)
+            from .data_kernels import shape_terms
+            sh, dsh, ddsh = shape_terms(kernel, ((pts[0] - pts[1]) ** 2 / (ell * ell)).sum())
+            k = s2 * sh
+            kx, kp = -d * (s2 * dsh), d * (s2 * dsh)
+            kxp = s2 * (torch.diag(1.0 / (ell * ell)) * dsh + ddsh * torch.outer(d, d))
         self.B00 = k * B
         self.Bx = kx[:, None, None] * B
         self.Bp = kp[:, None, None] * B

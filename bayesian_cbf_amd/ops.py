@@ -68,7 +68,8 @@ def hbm_read_probe(buf, launches=10, warm=2):
                 bytes=int(got.value), launches=launches)
 
 
-DATA_KERNELS = ("rbf", "matern52")
+DATA_KERNELS = ("rbf", "matern52", "rbf_matern52")       # (index = the library's kernel_kind; the last two are opt-in)
+_KSUF = {"rbf": "", "matern52": "_matern52", "rbf_matern52": "_rbfm52"}    # entry-point suffix of a data kernel
 
 
 def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None, kernel="rbf"):
@@ -81,11 +82,11 @@ def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None, kernel="rbf"):
     Kb = torch.empty(Bt, N, N, dtype=X.dtype, device=X.device)
     if kernel not in DATA_KERNELS:
         raise ValueError("data kernel %r: one of %s" % (kernel, DATA_KERNELS))
-    if kernel == "matern52":
+    if kernel != "rbf":
         if lin is not None:
-            raise ValueError("the Matern-5/2 option has no linear part")
-        check(getattr(lib, "bcbf_kb_build_matern52" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Kb),
-                                                               Bt, N, n, m, _stream(X)), "bcbf_kb_build_matern52")
+            raise ValueError("the opt-in data kernels have no linear part")
+        check(getattr(lib, "bcbf_kb_build" + _KSUF[kernel] + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Kb),
+                                                                      Bt, N, n, m, _stream(X)), "bcbf_kb_build" + _KSUF[kernel])
         return Kb
     if lin is not None:
         check(getattr(lib, "bcbf_kb_build_rbflin" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(lin), _p(jitter),
@@ -99,7 +100,7 @@ def kb_build(X, UH, Bm, ell, s2, jitter=None, lin=None, kernel="rbf"):
 def _kern(base, kernel):
     if kernel not in DATA_KERNELS:
         raise ValueError("kernel %r: one of %s" % (kernel, DATA_KERNELS))
-    return base + ("_matern52" if kernel == "matern52" else "")
+    return base + _KSUF[kernel]
 
 
 def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None, kernel="rbf"):
@@ -459,15 +460,15 @@ def posterior_query(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, shared=T
     Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
     Np = (N + 31) // 32 * 32
     W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
-    if kernel == "matern52":
-        if lin is not None:
-            raise ValueError("the Matern-5/2 option has no linear part")
-        check(getattr(lib, "bcbf_posterior_query_matern52" + _suf(X))(
-            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk), _p(W),
-            1 if shared else 0, b, N, n, C - 1, _stream(X)), "bcbf_posterior_query_matern52")
-        return Mk, Bk, W
-    if kernel != "rbf":
+    if kernel not in DATA_KERNELS:
         raise ValueError("data kernel %r: one of %s" % (kernel, DATA_KERNELS))
+    if kernel != "rbf":
+        if lin is not None:
+            raise ValueError("the opt-in data kernels have no linear part")
+        check(getattr(lib, "bcbf_posterior_query" + _KSUF[kernel] + _suf(X))(
+            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk), _p(W),
+            1 if shared else 0, b, N, n, C - 1, _stream(X)), "bcbf_posterior_query" + _KSUF[kernel])
+        return Mk, Bk, W
     if lin is not None:
         check(getattr(lib, "bcbf_posterior_query_rbflin" + _suf(X))(
             _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(lin), _p(Bm), _p(M0), _p(xq), _p(jitter2), _p(Mk), _p(Bk),
@@ -498,7 +499,7 @@ def posterior_shared(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, want_W=
     Bk = torch.empty(b, C, C, dtype=X.dtype, device=X.device)
     Np = (N + 31) // 32 * 32
     W = torch.empty(b, Np, C, dtype=X.dtype, device=X.device) if want_W else None
-    fn = getattr(lib, "bcbf_posterior_shared" + ("_matern52" if kernel == "matern52" else "") + _suf(X))
+    fn = getattr(lib, "bcbf_posterior_shared" + _KSUF[kernel] + _suf(X))
     check(fn(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(xq),
              _p(jitter2), _p(Mk), _p(Bk), _p(W), b, N, n, C - 1, _stream(X)), "bcbf_posterior_shared")
     return Mk, Bk, W
@@ -861,7 +862,7 @@ def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.
     kernel = gp.get("kernel", "rbf")                       # data kernel of the learned model: "rbf" (the reference's) | "matern52"
     if kernel not in DATA_KERNELS:
         raise ValueError("gp['kernel'] must be one of %s" % (DATA_KERNELS,))
-    fn = getattr(lib, "bcbf_unicycle_control_step" + ("_matern52" if kernel == "matern52" else "") + _suf(x))
+    fn = getattr(lib, "bcbf_unicycle_control_step" + _KSUF[kernel] + _suf(x))
     head = (_p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
             _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
             _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),

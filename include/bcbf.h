@@ -428,7 +428,7 @@ int bcbf_posterior_jets_f64(const double* Lop, const double* Vw, const double* X
  * eigenvalues of H itself (`evalz > -EPS`, `evalz < 0`); only a symmetric part that is positive definite by a wide margin
  * (unpivoted Cholesky, every pivot > 1e-10 of the trace) skips the solver, and only a complex pair / non-convergence falls
  * back to the eigenvalues of the symmetric part (status 6).
- * kernel_kind: the data kernel the jets came from, 0 = RBF (the reference's), 1 = Matern-5/2 (its prior term
+ * kernel_kind: the data kernel the jets came from, 0 = RBF (the reference's), 1 = Matern-5/2, 2 = RBF x Matern-5/2 (the prior term
  * d2 k / dx_d dx'_d at x' = x is (5/3) s2 / ell_d^2 instead of s2 / ell_d^2).
  * status[Bt] (optional): 0 = nothing to clean, 1 = an eigenvalue <= -2e-3 (the reference asserts), 4 = eigenvalues in
  * (-2e-3, 0) were zeroed, 6 = zeroed through the projection because xGEEV's path met a complex pair. */
@@ -607,6 +607,81 @@ int bcbf_unicycle_control_step_matern52_f32(
     float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
     void* ev_start, void* ev_stop, void* stream);
 int bcbf_unicycle_control_step_matern52_f64(
+    const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
+    const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
+    const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,
+    const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
+    const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
+    double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
+    int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The PRODUCT data kernel RBF x Matern-5/2 (BASELINE.json north_star: "RBF x Matern kernel-block build"):
+ *   k(x, x') = s2 exp(-d2 / 2) (1 + a + a^2 / 3) exp(-a),  d2 = sum_d ((x_d - x'_d) / ell_d)^2,  a = sqrt(5 d2)
+ * -- one set of ARD length scales for both factors.  Opt-in, like the Matern-5/2 kernel above, and like it without a
+ * reference counterpart (the reference's only data kernel is the RBF): parity unpinned; the formula, its
+ * derivative jets and its likelihood gradient are held to the CPU oracle and to finite differences.  Every `*_matern52` entry
+ * point has a `*_rbfm52` twin with the same arguments; `kernel_kind` = 2 in bcbf_cbc2_terms / bcbf_predict_assemble. */
+int bcbf_refit_rbfm52_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                            const float* jitter, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N, int n, int m,
+                            void* stream);
+int bcbf_refit_rbfm52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                            const double* jitter, double* Lop, double* UHB, double* Ldense, int* info, int Bt, int N, int n, int m,
+                            void* stream);
+int bcbf_posterior_jets_rbfm52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                     const float* ell, const float* s2, const float* Bm, const float* M0,
+                                     const float* xq, float* Mk, float* Bk, float* G, float* Mj, float* Wj, int shared,
+                                     int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_jets_rbfm52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                     const double* ell, const double* s2, const double* Bm, const double* M0,
+                                     const double* xq, double* Mk, double* Bk, double* G, double* Mj, double* Wj, int shared,
+                                     int Bt, int N, int n, int m, void* stream);
+int bcbf_mll_grad_rbfm52_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
+                               const float* R, const float* Ainv, const float* Bm, const float* ell, const float* s2, float* g_ell,
+                               float* g_s2, float* g_B, float* logdetK, float* RtA, float* UHtA, int Bt, int N, int n, int m,
+                               void* work, void* stream);
+int bcbf_mll_grad_rbfm52_f64(const double* Lop, const double* alpha, const double* Kinv, const double* X, const double* UH,
+                               const double* R, const double* Ainv, const double* Bm, const double* ell, const double* s2,
+                               double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
+                               int n, int m, void* work, void* stream);
+int bcbf_gp_append_rbfm52_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                                const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                                const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                                float* Vw_out, float* X_out, float* UHB_out, int* info, int Bt, int N, int n, int m, void* stream);
+int bcbf_gp_append_rbfm52_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                                const double* ell, const double* s2, const double* Bm, const double* M0, const double* x_new,
+                                const double* uh_new, const double* xdot_new, const double* jitter_new, double* Lop_out,
+                                double* Vw_out, double* X_out, double* UHB_out, int* info, int Bt, int N, int n, int m,
+                                void* stream);
+int bcbf_kb_build_rbfm52_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                               const float* jitter, float* Kb, int Bt, int N, int n, int m, void* stream);
+int bcbf_kb_build_rbfm52_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                               const double* jitter, double* Kb, int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_query_rbfm52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                      const float* ell, const float* s2, const float* Bm, const float* M0, const float* xq,
+                                      const float* jitter2, float* Mk, float* Bk, float* W, int shared, int Bt, int N,
+                                      int n, int m, void* stream);
+int bcbf_posterior_query_rbfm52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                      const double* ell, const double* s2, const double* Bm, const double* M0,
+                                      const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                      int shared, int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_shared_rbfm52_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                       const float* ell, const float* s2, const float* Bm, const float* M0,
+                                       const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                       int Bt, int N, int n, int m, void* stream);
+int bcbf_posterior_shared_rbfm52_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                       const double* ell, const double* s2, const double* Bm, const double* M0,
+                                       const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                       int Bt, int N, int n, int m, void* stream);
+int bcbf_unicycle_control_step_rbfm52_f32(
+    const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+    const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
+    const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
+    float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
+    float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
+    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
+    void* ev_start, void* ev_stop, void* stream);
+int bcbf_unicycle_control_step_rbfm52_f64(
     const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
     const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
     const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,

@@ -10,7 +10,8 @@ misc.py:268-285).  Everything is a function of the *jet* of the posterior at x:
 import numpy as np
 import scipy.linalg as sla
 
-from .gp_posterior import rbf_ard_kernel, matern52_ard_kernel, matern52_ard_grad
+from .gp_posterior import (rbf_ard_kernel, matern52_ard_kernel, matern52_ard_grad, rbf_matern52_ard_kernel,
+                           rbf_matern52_ard_grad, KERNEL_KXX)
 
 EIG_EPS = 2e-3   # gp_algebra.py:317: eigenvalues of the kernel Hessian in (-EPS, 0) are treated as rounding
 
@@ -54,9 +55,12 @@ def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x, kernel="rbf"):
     through k(X, x), :442-443.)
     """
     n = X.shape[1]
-    if kernel == "matern52":                  # the opt-in data kernel (no reference counterpart)
+    if kernel == "matern52":                  # the opt-in data kernels (no reference counterpart)
         kstar = matern52_ard_kernel(X, x[None], ell, s2)[:, 0]
         dkm = matern52_ard_grad(X, x, ell, s2)
+    elif kernel == "rbf_matern52":
+        kstar = rbf_matern52_ard_kernel(X, x[None], ell, s2)[:, 0]
+        dkm = rbf_matern52_ard_grad(X, x, ell, s2)
     else:
         kstar = rbf_ard_kernel(X, x[None], ell, s2)[:, 0]
     Phi = kstar[:, None] * UHB
@@ -64,7 +68,7 @@ def posterior_jets(L, Y, X, UHB, ell, s2, Bm, M0, x, kernel="rbf"):
     Vw = sla.solve_triangular(L, Y, lower=True)
     dW = []
     for d in range(n):
-        dk = dkm[:, d] if kernel == "matern52" else -(x[d] - X[:, d]) / ell[d] ** 2 * kstar
+        dk = dkm[:, d] if kernel != "rbf" else -(x[d] - X[:, d]) / ell[d] ** 2 * kstar
         dW.append(sla.solve_triangular(L, dk[:, None] * UHB, lower=True))
     Mk = M0.T + Vw.T @ W
     dMk = np.stack([Vw.T @ dW[d] for d in range(n)])
@@ -98,7 +102,7 @@ def cbc2_terms(jets, A, Bm, ell, s2, h, gh, Hh, k_alpha, u0, hessian_mode="refer
     # H_ij = d2/dx_i dx'_j [ gh(x)'A gh(x') s(x,e0;x',e0) ] at x' = x
     s00 = Bk[0, 0]
     s_i = np.array([-G10[i][0, 0] for i in range(n)])                 # ds/dx_i (= ds/dx'_i by symmetry)
-    kxx = 5.0 / 3.0 if kernel == "matern52" else 1.0        # d2 k / dx_d dx'_d at x' = x in units of s2 / ell_d^2
+    kxx = KERNEL_KXX[kernel]                                # d2 k / dx_d dx'_d at x' = x in units of s2 / ell_d^2
     s_ij = np.array([[(kxx * s2 / ell[i] ** 2 * Bm[0, 0] if i == j else 0.0) - G11[i][j][0, 0] for j in range(n)]
                      for i in range(n)])
     HAg = Hh @ Agh

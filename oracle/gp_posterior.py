@@ -55,6 +55,27 @@ def matern52_ard_grad(X, x, ell, s2):
     return -(5.0 / 3.0) * s2 * ((1.0 + a) * np.exp(-a))[:, None] * z / ell
 
 
+def rbf_matern52_ard_kernel(X1, X2, ell, s2):
+    """OPT-IN data kernel, the PRODUCT RBF x Matern-5/2 on one set of ARD length scales (BASELINE.json north_star's
+    "RBF x Matern"; no reference counterpart, PARITY UNPINNED): by definition the elementwise product of the two kernels
+    above over s2 -- k = s2 exp(-r^2 / 2) (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)."""
+    return rbf_ard_kernel(X1, X2, ell, 1.0) * matern52_ard_kernel(X1, X2, ell, s2)
+
+
+def rbf_matern52_ard_grad(X, x, ell, s2):
+    """d k(X_i, x) / d x_d [N, n] of the product kernel by the product rule from the two factors' own gradients."""
+    ell = np.asarray(ell, dtype=np.float64)
+    kr = rbf_ard_kernel(X, np.asarray(x)[None], ell, 1.0)[:, 0]
+    km = matern52_ard_kernel(X, np.asarray(x)[None], ell, s2)[:, 0]
+    z = (np.asarray(x)[None, :] - np.atleast_2d(X)) / ell
+    dkr = -(z / ell) * kr[:, None]
+    return dkr * km[:, None] + kr[:, None] * matern52_ard_grad(X, x, ell, s2)
+
+
+DATA_KERNELS = {"rbf": rbf_ard_kernel, "matern52": matern52_ard_kernel, "rbf_matern52": rbf_matern52_ard_kernel}
+KERNEL_KXX = {"rbf": 1.0, "matern52": 5.0 / 3.0, "rbf_matern52": 8.0 / 3.0}     # d2 k / dx_d dx'_d at x' = x, units of s2 / ell_d^2
+
+
 def index_kernel_covar(covar_factor, raw_var):
     """gpytorch IndexKernel.covar_matrix = F F^T + diag(softplus(raw_var)); used for A and B
     (bayes_cbf/matrix_variate_multitask_kernel.py:37-41, control_affine_model.py:158-163)."""
@@ -70,8 +91,8 @@ def homogeneous_controls(U, fill=1.0):
 
 # --------------------------------------------------------------------------- refit state
 def kb_matrix(X, UH, Bm, ell, s2, kernel="rbf"):
-    """K_b = k(X,X) o (UH Bm UH^T)   (control_affine_model.py:370-372).  kernel="matern52": the opt-in data kernel."""
-    k = matern52_ard_kernel if kernel == "matern52" else rbf_ard_kernel
+    """K_b = k(X,X) o (UH Bm UH^T)   (control_affine_model.py:370-372).  kernel="matern52" / "rbf_matern52": the opt-in data kernels."""
+    k = DATA_KERNELS[kernel]
     return k(X, X, ell, s2) * (UH @ Bm @ UH.T)
 
 

@@ -144,3 +144,19 @@ def test_c4_c5_through_the_unhooked_launcher_parent_one_rccl_rank(tmp_path, conf
     else:
         assert out["append_failures"] == 0 and out["final_vs_refit"]["Mk"] < 1e-8
         assert out["segments"][0]["roofline"]["bound"] == "hbm" and 0 < out["segments"][0]["roofline"]["frac"] < 1
+
+
+def test_learning_loop_two_ranks_and_through_bench_py():
+    """The learning closed loop harness (`bench.py --config learn` = tools/bench_learning_loop.py) with two ranks (weak scaling:
+    `--batch` instances per rank, no collective inside the loop, times = the slowest rank's) and with one rank through bench.py;
+    both schedules; the line carries the shares and a roofline entry per kernel."""
+    args = ["--batch", "16", "--max-train", "96", "--steps", "16", "--warmup", "8", "--refit-every", "8", "--dtype", "f64"]
+    two = _run_script(os.path.join("tools", "bench_learning_loop.py"), ["--gpus", "2"] + args, TWO_RANKS_ONE_DEVICE)
+    assert two["n_gpus"] == 2 and two["comm"]["world_size"] == 2 and two["scaling"] == "weak" and two["batch"] == 16
+    assert two["append_or_refit_failures"] == 0 and two["shares"]["refits_in_timed_region"] == 2
+    assert abs(two["value"] - 2 * 16 * 16 / two["seconds"]) < 1e-6 * two["value"]
+    assert two["final_vs_fp64_refit_on_device"]["Mk"] < 1e-8 and two["final_vs_fp64_refit_on_device"]["Bk"] < 1e-8
+    one = _run_script("bench.py", ["--config", "learn", "--schedule", "reference", "--parts", "2"] + args, {})
+    assert one["n_gpus"] == 1 and one["schedule"] == "reference" and one["parts"] == 2 and one["max_train"] == 96
+    assert one["roofline"]["pass"]["bound"] == "hbm" and one["roofline"]["refit"]["bound"] == "mfma"
+    assert one["final_vs_fp64_refit_on_device"]["Mk"] < 1e-8

@@ -647,7 +647,8 @@ def test_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("N,n,m,b,bp,kernel", [(100, 2, 1, 37, 37, "rbf"), (64, 3, 2, 50, 21, "rbf"), (33, 4, 3, 16, 16, "rbf"),
-                                               (130, 2, 1, 5, 70, "rbf"), (96, 3, 2, 40, 40, "matern52")])
+                                               (130, 2, 1, 5, 70, "rbf"), (96, 3, 2, 40, 40, "matern52"),
+                                               (96, 3, 2, 40, 40, "rbf_matern52")])
 def test_predict_assemble_vs_oracle_formula(ops, dtype, N, n, m, b, bp, kernel):
     """bcbf_predict_assemble (the one-launch tail of _custom_predict_matrix / custom_predict_fullmat, control_affine_model.py:
     1051-1091, 963-980): from the Gram G = W'W', BkXX = k(X*, X*') B - G (+ the make_psd jitter on its diagonal when b == b') and kron(Bk2, A),
@@ -672,7 +673,7 @@ def test_predict_assemble_vs_oracle_formula(ops, dtype, N, n, m, b, bp, kernel):
     BkXX, Kron = ops.predict_assemble(G, Xq, Xqp, p["ell"][0].contiguous(), p["s2"], p["Bm"][0].contiguous(), A, jit,
                                       want_BkXX=True, want_kron=True, kernel=kernel)
     h = lambda t: host(t).astype(np.float64)
-    knl = ogp.matern52_ard_kernel if kernel == "matern52" else ogp.rbf_ard_kernel
+    knl = ogp.DATA_KERNELS[kernel]
     KB = knl(h(Xq), h(Xqp), h(p["ell"][0]), float(p["s2"][0]))[:, :, None, None] * h(p["Bm"][0])[None, None]
     ref = KB - np.einsum("bic,pid->bpcd", h(W)[:, :N], h(Wp)[:, :N])                    # (:1079-1088 on the device's W)
     if jit is not None:
@@ -1266,7 +1267,8 @@ def test_programs_with_more_than_four_cones_vs_oracle(ops, dtype, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
+@pytest.mark.parametrize("kernel", ["matern52", "rbf_matern52"])
+def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, kernel, dtype):
     """The OPT-IN Matern-5/2 data kernel (bcbf_kb_build_matern52 -> bcbf_potrf -> bcbf_potrs ->
     bcbf_posterior_query_matern52) against the oracle's formula (which is checked against scikit-learn's Matern):
     dense K_b, and posterior M_k / B_k / W for per-instance queries and for queries of one shared model."""
@@ -1276,29 +1278,29 @@ def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
     p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=12)
     f64 = dtype == torch.float64
     jit = p["jitter"] if f64 else (p["jitter"] * 100).contiguous()
-    Kb = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+    Kb = ops.kb_build(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel=kernel)
     Lop, info, _ = ops.potrf(Kb)
     assert (info == 0).all()
     UHB = (p["UH"] @ p["Bm"]).contiguous()
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
     Mk, Bk, W = ops.posterior_query(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"], shared=False,
-                                    want_W=True, kernel="matern52")
+                                    want_W=True, kernel=kernel)
     one = lambda t: t[:1].contiguous()
     Mk_s, Bk_s, _ = ops.posterior_query(one(Lop), one(Vw), one(p["X"]), one(UHB), one(p["ell"]), one(p["s2"]), one(p["Bm"]),
-                                        one(p["M0"]), p["xq"], shared=True, kernel="matern52")
+                                        one(p["M0"]), p["xq"], shared=True, kernel=kernel)
     h = {k: host(v) for k, v in p.items()}
     hj = host(jit)
     tol = 1e-9 if f64 else 1e-3          # (fp32 measured: 3.6e-7)
     for i in range(Bt):
         UH = h["UH"][i]
-        K_o = ogp.matern52_ard_kernel(h["X"][i], h["X"][i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
+        K_o = ogp.DATA_KERNELS[kernel](h["X"][i], h["X"][i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
         rel_close(host(Kb)[i], K_o, 1e-12 if f64 else 1e-5, what="Kb")
         L = np.linalg.cholesky(K_o)
         Y = h["Xdot"][i] - UH @ h["M0"][i]
         cases = [(host(Mk)[i], host(Bk)[i])] + ([(host(Mk_s)[j], host(Bk_s)[j]) for j in range(Bt)] if i == 0 else [])
         for qi, (Mk_d, Bk_d) in enumerate(cases):
             xq = h["xq"][i] if qi == 0 else h["xq"][qi - 1]
-            Phi = ogp.matern52_ard_kernel(h["X"][i], xq[None], h["ell"][i], h["s2"][i])[:, :1] * (UH @ h["Bm"][i])
+            Phi = ogp.DATA_KERNELS[kernel](h["X"][i], xq[None], h["ell"][i], h["s2"][i])[:, :1] * (UH @ h["Bm"][i])
             W_o = sla.solve_triangular(L, Phi, lower=True)
             Mk_o = h["M0"][i].T + sla.solve_triangular(L, Y, lower=True).T @ W_o
             Bk_o = h["s2"][i] * h["Bm"][i] - W_o.T @ W_o
@@ -1313,8 +1315,9 @@ def test_matern52_option_kb_build_and_posterior_vs_oracle(ops, dtype):
     assert float((Br - Bk).abs().max()) > 1e-3
 
 
-def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
-    """`ControlAffineRegressor(data_kernel="matern52")` (opt-in; no reference counterpart, formulas pinned in
+@pytest.mark.parametrize("kernel", ["matern52", "rbf_matern52"])
+def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops, kernel):
+    """`ControlAffineRegressor(data_kernel=kernel)` (opt-in; no reference counterpart, formulas pinned in
     tests/test_oracle_formulas.py): custom_predict against the oracle; the likelihood gradient of fit() against central
     differences of the oracle's Matern likelihood; fit() lowers the loss; append_data equals a from-scratch state on all the
     points; the rel-degree-2 terms (derivative GP on the Matern jets) against the oracle's closed form."""
@@ -1329,7 +1332,7 @@ def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
     ell, s2, M0 = np.array([0.9, 1.3]), 0.7, rng.normal(size=(1 + m, n)) * 0.1
     f = dict(dtype=torch.float64, device=DEV)
     T_ = lambda a: torch.as_tensor(np.ascontiguousarray(a), **f)
-    reg = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel="matern52")
+    reg = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel=kernel)
     reg.set_kernel_params(A=A, B=B, lengthscale=ell, scalefactor=s2, M0=M0)
     reg.fit(T_(X), T_(U), T_(Y), training_iter=0)
     draws = []
@@ -1339,12 +1342,12 @@ def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
     mean, cov = reg.custom_predict(T_(Xt), T_(Ut))
     UH, UHt = np.c_[np.ones(N), U], np.c_[np.ones(b), Ut]
     jit0 = 1e-5 * host(draws[0])
-    K = ogp.matern52_ard_kernel(X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(jit0)
+    K = ogp.DATA_KERNELS[kernel](X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(jit0)
     L = np.linalg.cholesky(K)
-    ks = ogp.matern52_ard_kernel(X, Xt, ell, s2) * (UH @ B @ UHt.T)
+    ks = ogp.DATA_KERNELS[kernel](X, Xt, ell, s2) * (UH @ B @ UHt.T)
     v = sla.solve_triangular(L, ks, lower=True)
     mean_o = UHt @ M0 + ks.T @ sla.cho_solve((L, True), Y - UH @ M0)
-    sv_o = ogp.matern52_ard_kernel(Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v.T @ v
+    sv_o = ogp.DATA_KERNELS[kernel](Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v.T @ v
     rel_close(host(mean), mean_o, 1e-9, scale=max(1.0, np.abs(mean_o).max()), what="mean")
     rel_close(host(cov)[0], np.kron(sv_o, A), 1e-9, what="cov")
     # ---- rel-degree-2 terms through the facade (bcbf_posterior_jets_matern52 + bcbf_cbc2_terms(kernel_kind = 1))
@@ -1356,15 +1359,15 @@ def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
     x0, u0, ka = Xt[0], rng.random(m), np.array([1.0, 3.0])
     (mA, mb), (Q, pp, r), mean2, var2 = cbc2_quadratic_terms(reg, hfun, gfun, Hfun, T_(x0), T_(u0), ka)
     Yr = Y - UH @ M0
-    jets = oc2.posterior_jets(L, Yr, X, UH @ B, ell, s2, B, M0, x0, kernel="matern52")
+    jets = oc2.posterior_jets(L, Yr, X, UH @ B, ell, s2, B, M0, x0, kernel=kernel)
     (oA, ob), (oQ, op_, or_), omean, ovar = oc2.cbc2_terms(jets, A, B, ell, s2, float(0.5 * x0 @ Pm @ x0 + qv @ x0 - 1.0), Pm @ x0 + qv,
-                                                           Pm, ka, u0, kernel="matern52")
+                                                           Pm, ka, u0, kernel=kernel)
     for name, val, ref in (("mean_A", mA, oA), ("mean_b", mb, ob), ("Q", Q, oQ), ("p", pp, op_), ("r", r, or_), ("mean", mean2, omean),
                            ("var", var2, ovar)):
         ref = np.asarray(ref)
         rel_close(host(val).reshape(ref.shape), ref, 1e-7, scale=max(np.abs(ref).max(), abs(float(ovar)), 1e-2), what=name)
     # ---- append_data: the last 6 points enter one by one == a state fitted on all the points (same jitter draws)
-    reg2 = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel="matern52")
+    reg2 = ControlAffineRegressor(n, m, device=DEV, dtype=torch.float64, data_kernel=kernel)
     reg2.set_kernel_params(A=A, B=B, lengthscale=ell, scalefactor=s2, M0=M0)
     jall = rng.random(N)
     seq = iter([jall[:N - 6]] + [jall[N - 6 + k:N - 5 + k] for k in range(6)])
@@ -1375,11 +1378,11 @@ def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
     assert reg2.Xtrain.shape[0] == N
     reg2.rand_fn = lambda k: T_(np.zeros(k))
     m2, c2 = reg2.custom_predict(T_(Xt), T_(Ut))
-    K2 = ogp.matern52_ard_kernel(X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(1e-5 * jall)
+    K2 = ogp.DATA_KERNELS[kernel](X, X, ell, s2) * (UH @ B @ UH.T) + np.diag(1e-5 * jall)
     L2 = np.linalg.cholesky(K2)
     v2 = sla.solve_triangular(L2, ks, lower=True)
     rel_close(host(m2), UHt @ M0 + ks.T @ sla.cho_solve((L2, True), Y - UH @ M0), 1e-8, scale=max(1.0, np.abs(mean_o).max()), what="mean after append")
-    rel_close(host(c2)[0], np.kron(ogp.matern52_ard_kernel(Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v2.T @ v2, A), 1e-7, what="cov after append")
+    rel_close(host(c2)[0], np.kron(ogp.DATA_KERNELS[kernel](Xt, Xt, ell, s2) * (UHt @ B @ UHt.T) - v2.T @ v2, A), 1e-7, what="cov after append")
     # ---- the likelihood gradient against central differences of the oracle's Matern likelihood, then a short fit
     jfix = 1e-5 * np.linspace(0.1, 0.9, N)
     reg.rand_fn = lambda k: T_(np.linspace(0.1, 0.9, N)[:k])
@@ -1388,7 +1391,7 @@ def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
         mm = reg.model
         with torch.no_grad():
             return -ogp.marginal_log_likelihood(X, UH, Y, mm.A.cpu().numpy(), mm.B.cpu().numpy(), mm.lengthscale.cpu().numpy().ravel(),
-                                                float(mm.outputscale), mm.M0.cpu().numpy(), jfix, kernel="matern52") / (N * n)
+                                                float(mm.outputscale), mm.M0.cpu().numpy(), jfix, kernel=kernel) / (N * n)
     for p_ in reg.model.parameters():
         p_.grad = None
     loss = reg.neg_mll_backward()
@@ -1409,7 +1412,8 @@ def test_matern52_option_facade_prediction_fit_append_and_derivative_gp(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-def test_matern52_fused_refit_equals_build_then_factor_and_jets_vs_oracle(ops, dtype):
+@pytest.mark.parametrize("kernel", ["matern52", "rbf_matern52"])
+def test_matern52_fused_refit_equals_build_then_factor_and_jets_vs_oracle(ops, kernel, dtype):
     """bcbf_refit_matern52 (fused values + jittered Cholesky + packing, the team form) gives the factor of
     bcbf_kb_build_matern52 -> bcbf_potrf (posterior through either within rounding); bcbf_posterior_jets_matern52 against the
     oracle's Matern jets for batches of instances, two shapes, ragged N."""
@@ -1421,29 +1425,29 @@ def test_matern52_fused_refit_equals_build_then_factor_and_jets_vs_oracle(ops, d
         p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=40 + N)
         X, xq = (p["X"] * 2.0).contiguous(), (p["xq"] * 2.0).contiguous()
         jit = (p["jitter"] * (1 if f64 else 1e2)).contiguous()
-        Lop, UHB, info, _ = ops.refit(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+        Lop, UHB, info, _ = ops.refit(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel=kernel)
         assert (info == 0).all()
-        Kb = ops.kb_build(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+        Kb = ops.kb_build(X, p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel=kernel)
         Lop2, info2, _ = ops.potrf(Kb)
         assert (info2 == 0).all()
         Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
         Vw2, _ = ops.potrs(Lop2, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
-        q = lambda L_, V_: ops.posterior_query(L_, V_, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, shared=False, kernel="matern52")
+        q = lambda L_, V_: ops.posterior_query(L_, V_, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, shared=False, kernel=kernel)
         (Mk1, Bk1, _), (Mk2, Bk2, _) = q(Lop, Vw), q(Lop2, Vw2)
         tol = 1e-9 if f64 else 1e-3      # (fp32 measured: 1.9e-7)
         rel_close(host(Mk1), host(Mk2), tol, scale=max(1.0, float(Mk2.abs().max())), what="Mk fused vs build+factor")
         rel_close(host(Bk1), host(Bk2), tol, scale=float((p["s2"][:, None, None] * p["Bm"]).abs().max()), what="Bk fused vs build+factor")
-        Mk, Bk, G, Mj = ops.posterior_jets(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, kernel="matern52")
+        Mk, Bk, G, Mj = ops.posterior_jets(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, kernel=kernel)
         h = {k: host(v) for k, v in p.items()}
         hX, hxq, hj = host(X), host(xq), host(jit)
         C = m + 1
         jt = 1e-8 if f64 else 1e-3       # (fp32 measured: 3.8e-7)
         for i in range(Bt):
             UH = h["UH"][i]
-            K = ogp.matern52_ard_kernel(hX[i], hX[i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
+            K = ogp.DATA_KERNELS[kernel](hX[i], hX[i], h["ell"][i], h["s2"][i]) * (UH @ h["Bm"][i] @ UH.T) + np.diag(hj[i])
             L = np.linalg.cholesky(K)
             jets = oc2.posterior_jets(L, h["Xdot"][i] - UH @ h["M0"][i], hX[i], UH @ h["Bm"][i], h["ell"][i], float(h["s2"][i]), h["Bm"][i],
-                                      h["M0"][i], hxq[i], kernel="matern52")
+                                      h["M0"][i], hxq[i], kernel=kernel)
             prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
             rel_close(host(Mk)[i], jets["Mk"], jt, scale=max(1.0, np.abs(jets["Mk"]).max()), what="Mk")
             rel_close(host(Bk)[i], jets["Bk"], jt, scale=prior, what="Bk")
@@ -1587,10 +1591,11 @@ def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n
 @pytest.mark.parametrize("N,n,m,b,dtype", [(512, 3, 2, 203, torch.float32), (100, 3, 2, 21, torch.float32), (256, 2, 1, 64, torch.float32),
                                            (1024, 3, 2, 37, torch.float32), (512, 3, 2, 5200, torch.float32),
                                            (512, 3, 2, 203, torch.float64), (100, 2, 1, 19, torch.float64), (480, 4, 3, 37, torch.float64)])
-def test_matern52_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype):
+@pytest.mark.parametrize("kernel", ["matern52", "rbf_matern52"])
+def test_matern52_shared_gp_matrix_core_queries_vs_oracle(ops, kernel, N, n, m, b, dtype):
     """bcbf_posterior_shared_matern52 (the regime-S matrix-core kernels with the Matern-5/2 value in the prologue; register-
     resident form N <= 512, the fp32 LDS-slab form beyond; 5200 queries: the five-queries-per-wave packing) against the oracle's
-    Matern posterior, ragged b and N; `posterior_query(shared=True, kernel="matern52")` routes to the same kernel; the RBF
+    Matern posterior, ragged b and N; `posterior_query(shared=True, kernel=kernel)` routes to the same kernel; the RBF
     result on the same factor differs (the switch is not ignored)."""
     import scipy.linalg as sla
     from bayesian_cbf_amd.synthetic import make_instances
@@ -1598,28 +1603,28 @@ def test_matern52_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype
     p = make_instances(1, N, n, m, dtype=dtype, device=DEV, seed=40 + N + m)
     p["X"] = (p["X"] * (1.0 if f64 else 2.0)).contiguous()
     jit = p["jitter"] if f64 else (p["jitter"] * 100).contiguous()
-    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel=kernel)
     assert int(info[0]) == 0
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
     g = torch.Generator(device=DEV).manual_seed(5)
     lo, hi = p["X"][0].amin(dim=0), p["X"][0].amax(dim=0)
     xq = (lo + (hi - lo) * torch.rand(b, n, generator=g, dtype=dtype, device=DEV)).contiguous()
     args = (Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq)
-    Mk, Bk, W = ops.posterior_shared(*args, want_W=True, kernel="matern52")
-    Mq, Bq, _ = ops.posterior_query(*args, shared=True, kernel="matern52")
+    Mk, Bk, W = ops.posterior_shared(*args, want_W=True, kernel=kernel)
+    Mq, Bq, _ = ops.posterior_query(*args, shared=True, kernel=kernel)
     assert torch.equal(Mk, Mq) and torch.equal(Bk, Bq)
     Mr, Br, _ = ops.posterior_shared(*args)
     assert float((Br - Bk).abs().max()) > 1e-4
     h = {k: host(v)[0] for k, v in p.items()}
     UH = h["UH"]
-    K_o = ogp.matern52_ard_kernel(h["X"], h["X"], h["ell"], h["s2"]) * (UH @ h["Bm"] @ UH.T) + np.diag(host(jit)[0])
+    K_o = ogp.DATA_KERNELS[kernel](h["X"], h["X"], h["ell"], h["s2"]) * (UH @ h["Bm"] @ UH.T) + np.diag(host(jit)[0])
     L = np.linalg.cholesky(K_o)
     V_o = sla.solve_triangular(L, h["Xdot"] - UH @ h["M0"], lower=True)
     prior = float(h["s2"] * np.abs(h["Bm"]).max())
     tol = 1e-8 if f64 else 1e-3
     hx = host(xq)
     for i in sorted(set(np.linspace(0, b - 1, min(b, 40)).astype(int))):
-        Phi = ogp.matern52_ard_kernel(h["X"], hx[i][None], h["ell"], h["s2"])[:, :1] * (UH @ h["Bm"])
+        Phi = ogp.DATA_KERNELS[kernel](h["X"], hx[i][None], h["ell"], h["s2"])[:, :1] * (UH @ h["Bm"])
         W_o = sla.solve_triangular(L, Phi, lower=True)
         rel_close(host(Mk)[i], h["M0"].T + V_o.T @ W_o, tol, scale=max(1.0, np.abs(V_o.T @ W_o).max()), what="Mk matern shared")
         rel_close(host(Bk)[i], h["s2"] * h["Bm"] - W_o.T @ W_o, tol, scale=prior, what="Bk matern shared")
@@ -1628,7 +1633,8 @@ def test_matern52_shared_gp_matrix_core_queries_vs_oracle(ops, N, n, m, b, dtype
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("shared", [False, True], ids=["instance-gps", "shared-gp"])
-def test_matern52_fused_control_step_vs_composed_path_and_oracle(ops, dtype, shared):
+@pytest.mark.parametrize("kernel", ["matern52", "rbf_matern52"])
+def test_matern52_fused_control_step_vs_composed_path_and_oracle(ops, kernel, dtype, shared):
     """bcbf_unicycle_control_step_matern52 (gp["kernel"] = "matern52"): posterior of a Matern-5/2 model + the fused task rows /
     terms / SOCP / plant step in one host call == the composed entry points on the same model, and the posterior it leaves in the
     workspace is the oracle's Matern posterior; the RBF step on the same tensors gives a different posterior."""
@@ -1639,10 +1645,10 @@ def test_matern52_fused_control_step_vs_composed_path_and_oracle(ops, dtype, sha
     p = make_instances(1 if shared else Bt, N, n, m, dtype=dtype, device=DEV, seed=61)
     t = make_unicycle_task(Bt, dtype=dtype, device=DEV, seed=62)
     jit = p["jitter"] if f64 else (p["jitter"] * 100).contiguous()
-    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel="matern52")
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel=kernel)
     assert (info == 0).all()
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
-    gp = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=p["A"], kernel="matern52")
+    gp = dict(Lop=Lop, Vw=Vw, X=p["X"], UHB=UHB, ell=p["ell"], s2=p["s2"], Bm=p["Bm"], M0=p["M0"], A=p["A"], kernel=kernel)
     x1, x2 = t["x"].clone(), t["x"].clone()
     ws1, ws2 = ops.control_workspace(Bt, 2, dtype, DEV), ops.control_workspace(Bt, 2, dtype, DEV)
     ops.unicycle_control_step(gp, t, ws1, x1, dt=0.01, L_true=1.0, L_mean=4.0, clf_gamma=10.0, max_iters=40)
@@ -1664,9 +1670,9 @@ def test_matern52_fused_control_step_vs_composed_path_and_oracle(ops, dtype, sha
     for i in (0, 1, 17, 69):
         gi = 0 if shared else i
         UH = h["UH"][gi]
-        K_o = ogp.matern52_ard_kernel(h["X"][gi], h["X"][gi], h["ell"][gi], h["s2"][gi]) * (UH @ h["Bm"][gi] @ UH.T) + np.diag(hj[gi])
+        K_o = ogp.DATA_KERNELS[kernel](h["X"][gi], h["X"][gi], h["ell"][gi], h["s2"][gi]) * (UH @ h["Bm"][gi] @ UH.T) + np.diag(hj[gi])
         L = np.linalg.cholesky(K_o)
-        Phi = ogp.matern52_ard_kernel(h["X"][gi], hx[i][None], h["ell"][gi], h["s2"][gi])[:, :1] * (UH @ h["Bm"][gi])
+        Phi = ogp.DATA_KERNELS[kernel](h["X"][gi], hx[i][None], h["ell"][gi], h["s2"][gi])[:, :1] * (UH @ h["Bm"][gi])
         W_o = sla.solve_triangular(L, Phi, lower=True)
         Mk_o = h["M0"][gi].T + sla.solve_triangular(L, h["Xdot"][gi] - UH @ h["M0"][gi], lower=True).T @ W_o
         rel_close(host(ws1["Mk"])[i], Mk_o, ptol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk matern control step")

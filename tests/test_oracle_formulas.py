@@ -145,3 +145,25 @@ def test_matern52_derivatives_of_the_option_against_central_differences():
         k0 = ogp.matern52_ard_kernel(x[None], x[None], ell, s2)[0, 0]
         k2 = ogp.matern52_ard_kernel((x + e)[None], (x - e)[None], ell, s2)[0, 0]
         np.testing.assert_allclose(-(2 * k2 - 2 * k0) / (2 * hh) ** 2, (5.0 / 3.0) * s2 / ell[d] ** 2, rtol=2e-3)
+
+
+def test_product_kernel_option_is_the_product_and_its_gradient_matches_central_differences():
+    """The opt-in RBF x Matern-5/2 kernel (no reference counterpart): the product of the two factor kernels by definition;
+    its gradient (product rule) against central differences; the curvature at x' = x is (1 + 5/3) s2 / ell_d^2."""
+    rng = np.random.default_rng(5)
+    X, x = rng.normal(size=(9, 3)), rng.normal(size=3)
+    ell, s2 = np.array([0.7, 1.3, 0.9]), 1.7
+    K = ogp.rbf_matern52_ard_kernel(X, x[None], ell, s2)[:, 0]
+    np.testing.assert_allclose(K, ogp.rbf_ard_kernel(X, x[None], ell, s2)[:, 0] * ogp.matern52_ard_kernel(X, x[None], ell, s2)[:, 0] / s2, rtol=1e-14)
+    g = ogp.rbf_matern52_ard_grad(X, x, ell, s2)
+    h = 1e-6
+    for d in range(3):
+        e = np.zeros(3); e[d] = h
+        fd = (ogp.rbf_matern52_ard_kernel(X, (x + e)[None], ell, s2)[:, 0] - ogp.rbf_matern52_ard_kernel(X, (x - e)[None], ell, s2)[:, 0]) / (2 * h)
+        np.testing.assert_allclose(g[:, d], fd, rtol=1e-7, atol=1e-9)
+        hh = 1e-4
+        e2 = np.zeros(3); e2[d] = hh
+        k0 = ogp.rbf_matern52_ard_kernel(x[None], x[None], ell, s2)[0, 0]
+        k2 = ogp.rbf_matern52_ard_kernel((x + e2)[None], (x - e2)[None], ell, s2)[0, 0]
+        # k(x + e, x - e) = k0 - (1/2) kxx s2 (2 hh)^2 / ell^2 + O(h^3): d2k/dx dx' at x' = x  =  (k0 - k2) / (2 hh^2)
+        np.testing.assert_allclose((k0 - k2) / (2 * hh * hh), ogp.KERNEL_KXX["rbf_matern52"] * s2 / ell[d] ** 2, rtol=2e-3)
