@@ -1,6 +1,6 @@
 # One GPU call that produces everything tools/collect_profiles.py copies into profiles/ (ROUND tag = $1, default r03).
 # Counters are collected in their own passes (--pmc + --kernel-trace only), as MI355X_MICROARCH.md prescribes.
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # the setting bench.py gives itself; under rocprofv3 the runtime is up before Python runs
 cd $GRAFT_REPO_ROOT
@@ -63,6 +63,18 @@ python tools/learn_dynamics_matrix_vector.py /tmp/learn_matrix_vector > /dev/nul
 python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -1 > $O/mc_rollouts.txt
 python examples_mc_rollouts.py --trajectories 32768 2>/dev/null | tail -1 >> $O/mc_rollouts.txt
 bash tools/run_pmc_refit_traffic.sh $R > /dev/null 2>&1      # refit traffic past L2 -> $O/pmc_traffic_refit.json
+# the learning closed loop at C3 scale (round 5): reference cadence on four part batches, on one stream, and the online schedule
+python tools/bench_learning_loop.py --schedule reference --parts 4 2>/dev/null > $O/learn_reference_parts4.json
+python tools/bench_learning_loop.py --schedule reference 2>/dev/null > $O/learn_reference.json
+python tools/bench_learning_loop.py 2>/dev/null > $O/learn_online.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_reference -- python3 tools/bench_learning_loop.py --schedule reference --steps 80 --warmup 40 > $O/learn_reference_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online -- python3 tools/bench_learning_loop.py --steps 80 --warmup 40 > $O/learn_online_prof.json 2>/dev/null
+# C5 append: counters + kernel trace (round 5) -> $O/pmc_traffic_append.json, online_b*_n*.json
+bash tools/run_pmc_append_traffic.sh $R > /dev/null 2>&1
+# fp32 online growth at the C3 batch
+python tools/bench_online.py --dtype f32 --batch 4096 --n0 256 --n1 512 2>/dev/null | tail -1 > $O/online_f32_b4096.json
+# measured deviation behind every asserted tolerance of the GPU suite
+BCBF_TOL_REPORT=$PWD/$O/tol.jsonl python -m pytest tests -m gpu -q -x > $O/gputest.log 2>&1; python tools/tol_report.py $O/tol.jsonl 0 > $O/tol_report.txt 2>/dev/null
 du -sh $O; ls $O | head -50
 # keep the merge small: the raw traces are not needed, only the csv summaries
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*_kernel_trace.csv" -size +2M -delete 2>/dev/null

@@ -21,8 +21,8 @@ for tag, (Bt, n0, n1) in {"b256_n1024_2048": (256, 1024, 2048), "b1024_n1024_128
     for f in glob.glob(os.path.join(O, "pmc_append_%s_*" % tag, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "false, 1>" in k and "posterior_step_kernel" in k:
-                name = "posterior_step_kernel<double, 3, 4, 0, 1, false, 1>"
+            if "posterior_step_kernel" in k and ", false, 1" in k.split("(")[0]:
+                name = k.split("(")[0].replace("void bcbf::", "")
             elif "gp_append_inplace_kernel" in k:
                 name = "gp_append_inplace_kernel<double>"
             else:
@@ -45,7 +45,7 @@ for tag, (Bt, n0, n1) in {"b256_n1024_2048": (256, 1024, 2048), "b1024_n1024_128
     for f in glob.glob(os.path.join(O, "prof_append_%s" % tag, "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Name"]
-            if ("false, 1>" in k and "posterior_step_kernel" in k) or "gp_append_inplace_kernel" in k:
+            if ("posterior_step_kernel" in k and ", false, 1" in k.split("(")[0]) or "gp_append_inplace_kernel" in k:
                 dur[k.split("(")[0]] = dict(calls=int(r["Calls"]), total_ns=float(r["TotalDurationNs"]), avg_ns=float(r["AverageNs"]))
     if dur:
         tot = sum(v["total_ns"] for v in dur.values())
