@@ -30,7 +30,16 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.
 # fp32 batch form at two waves per SIMD runs 4096 x 256 in 0.63 instead of 0.71 ms, everything else within 1 %
 EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "refit_wave64.hip": ["-fno-slp-vectorize"],
-               "posterior_shared_reg.hip": ["-Rpass-analysis=kernel-resource-usage"]}
+               "posterior_shared_reg.hip": ["-Rpass-analysis=kernel-resource-usage"],
+               "posterior_step.hip": ["-Rpass-analysis=kernel-resource-usage"]}
+# instantiations of the streaming kernel whose measured figures assume ZERO scratch (a spill in the streaming loop is fatal
+# there: DESIGN.md 3.1 -- 1373 us against 470): the headline (fp32 / fp64 values-only, C = 2..3), the fp32 jets of the pendulum and
+# unicycle shapes, the fp32 fused query + append column.  Demangled-name prefixes; the build fails when one of them reports scratch.
+ZERO_SCRATCH_KERNELS = {"posterior_step.hip": [
+    "posterior_step_kernel<float, 2, 4, 0, 1, false, 0,", "posterior_step_kernel<float, 3, 4, 0, 1, false, 0,",
+    "posterior_step_kernel<double, 2, 4, 0, 1, false, 0,", "posterior_step_kernel<double, 3, 4, 0, 1, false, 0,",
+    "posterior_step_kernel<float, 2, 4, 2, 1, false, 0,", "posterior_step_kernel<float, 3, 4, 3, 1, false, 0,",
+    "posterior_step_kernel<float, 3, 4, 0, 1, false, 1,", "posterior_step_kernel<float, 3, 4, 0, 1, true, 0,"]}
 # kernels that must not touch scratch memory (posterior_shared_reg: an operand spilled between its explicit LDS read and
 # the explicit wait for it would be stored before it has arrived).  Their device assembly is also linted: no instruction may
 # name the destination of an LDS read that has not been waited for (check_lds_waits.py)
@@ -114,6 +123,22 @@ def _compile(item, force):
             shutil.move(os.path.join(tmpdir, os.path.basename(obj)), obj)
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
+    if src in ZERO_SCRATCH_KERNELS and not ASAN and not tuning:
+        import re
+        names = re.findall(r"Function Name: (\S+)", res.stderr)
+        sizes = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res.stderr)]
+        dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines() if names else []
+        seen = set()
+        for full, z in zip(dem, sizes):
+            for want in ZERO_SCRATCH_KERNELS[src]:
+                if want in full:
+                    seen.add(want)
+                    if z:
+                        os.remove(obj)
+                        raise RuntimeError("%s: %s uses %d bytes of scratch per lane (its measured figures assume none)" % (src, want, z))
+        missing = [w for w in ZERO_SCRATCH_KERNELS[src] if w not in seen]
+        if missing or len(names) != len(sizes):
+            raise RuntimeError("%s: the scratch guard found no resource remark for %s" % (src, missing or "the kernels"))
     if guard:
         import re
         names = re.findall(r"Function Name: (\S+)", res.stderr)
