@@ -7,7 +7,8 @@ from bayesian_cbf_amd import ops
 from bayesian_cbf_amd.synthetic import make_instances
 from _timing import timeit
 Bt, dt = 4096, torch.float32
-for N, m in ((512, 2), (512, 3), (480, 2), (496, 2)):
+CASES = [(int(a.split(",")[0]), int(a.split(",")[1])) for a in sys.argv[1:]] or [(512, 2), (512, 3), (480, 2), (496, 2)]
+for N, m in CASES:
     p = make_instances(Bt, N + 1, 3, m, dtype=dt, device="cuda", seed=3)
     cut = lambda t: t[:, :N].contiguous()
     Lop, UHB, info, _ = ops.refit(cut(p["X"]), cut(p["UH"]), p["Bm"], p["ell"], p["s2"], cut(p["jitter"]))
