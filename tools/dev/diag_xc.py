@@ -17,7 +17,9 @@ for N, m in CASES:
     t_plain = timeit(lambda: ops.posterior_step(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"]))
     out = dict(N=N, m=m, plain_ms=t_plain)
     if m == 2:
-        rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], 512 if N < 512 else 544)
+        cap = int(os.environ.get("DIAG_CAP", "0")) or (512 if N < 512 else 544)
+        rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], cap)
+        out["capacity"] = cap
         t_res = timeit(lambda: rgp.posterior(p["xq"]))
         xn, uhn, xdn, jn = (p[k][:, N].contiguous() for k in ("X", "UH", "Xdot", "jitter"))
         def fused():
