@@ -7,6 +7,7 @@ closed loops from perturbed start states: `sample_generator_trajectory` (samplin
 every trajectory at once, sharded over GPUs by `distributed.shard_range`, statistics reduced once
 at the end."""
 import math
+import os
 
 import torch
 
@@ -419,6 +420,10 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         rs = [t for t in refit_steps if t >= warmup]
         refit_ms = sum(ev[t][2].elapsed_time(ev[t][3]) for t in rs) / max(1, len(rs))
         n_refits = len(rs)
+    if os.environ.get("BCBF_LEARN_DUMP"):          # development: per-step pass / solve intervals with the live size
+        import json as _json
+        _json.dump([dict(t=t, N=(window + (t % refit_every)) if online else window, pass_ms=ev[t][0].elapsed_time(ev[t][1]),
+                         solve_ms=ev[t][1].elapsed_time(ev[t][2])) for t in timed], open(os.environ["BCBF_LEARN_DUMP"], "w"))
     solve_ms = 0.0 if concurrent else sum(ev[t][1].elapsed_time(ev[t][2]) for t in timed) / steps     # (concurrent: hidden beside the passes)
     ms_step = elapsed / steps * 1e3
     # roofline entries.  pass: every instance's packed factor + whitened targets + inputs + UH B rows read once at the live N
