@@ -10,7 +10,7 @@ out, final = learning_closed_loop(4096, 512, 40, 40, warmup=0, dtype=torch.float
 rgp, p = final["rgp"], final["p"]
 print("loop pass_ms", out["shares"]["pass_ms_per_step"], "N", rgp.N, flush=True)
 N = rgp.N
-xn, uhn, xdn, jn = (p[k][:, 600].contiguous() for k in ("X", "UH", "Xdot", "jitter"))
+xn, uhn, xdn, jn = (p[k][:, 500].contiguous() for k in ("X", "UH", "Xdot", "jitter"))
 def fused(g):
     n0 = g.N
     g.append(xn, uhn, xdn, jn, query=p["xq"])
