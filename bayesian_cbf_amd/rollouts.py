@@ -351,12 +351,22 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         e[0].record()
         if online:
             drops_before = rgp.drops
-            info, _, _ = rgp.append(obs[0][N_obs], obs[1][N_obs], obs[2][N_obs], obs[3][N_obs], query=x, out=(ws["Mk"], ws["Bk"]))
+            _exp = os.environ.get("BCBF_LEARN_EXPERIMENT", "")           # development switches (tools/dev/diag_online.sh)
+            if "plainquery" in _exp:
+                rgp.posterior(x, out=(ws["Mk"], ws["Bk"]))
+                info = rgp.info
+            else:
+                _n0 = rgp.N
+                info, _, _ = rgp.append(obs[0][N_obs], obs[1][N_obs], obs[2][N_obs], obs[3][N_obs], query=x, out=(ws["Mk"], ws["Bk"]))
+                if "fixedN" in _exp and rgp.drops == drops_before:
+                    rgp.N = _n0
             # (the window's drop + refit, when this append filled it, ran inside append -- timed below as its own share)
             e[1].record()
-            solve()
+            if "nosolve" not in _exp:
+                solve()
             e[2].record()
-            fails_vec += info != 0                       # (stays on the device: the loop never waits for the host)
+            if "nofails" not in _exp:
+                fails_vec += info != 0                   # (stays on the device: the loop never waits for the host)
             if rgp.drops != drops_before:
                 refit_steps.append(t)
         else:
