@@ -31,7 +31,22 @@ def growing(t):
     if t % 39 == 0:
         rgp.N = N0
     rgp.append(obs[0][k], obs[1][k], obs[2][k], obs[3][k], query=x, out=(ws["Mk"], ws["Bk"]))
+E = lambda: torch.cuda.Event(enable_timing=True)
+evs = [[E(), E(), E()] for _ in range(200)]
+def with_events(t):
+    e = evs[t]
+    e[0].record()
+    varying_row(t)
+    e[1].record()
+    e[2].record()
+solve = ops.unicycle_control_step_prepare(dict(A=p["A"]), {k: v for k, v in final.items() if False} or None, ws, x) if False else None
+def with_bool_accumulate(t):
+    varying_row(t)
+    acc.__iadd__(rgp.info != 0)
+acc = torch.zeros(4096, dtype=torch.int32, device="cuda")
 run("fixed obs row, fixed N", fixed_row)
+run("varying obs row + 3 event records per call", with_events)
+run("varying obs row + (info != 0) accumulate", with_bool_accumulate)
 run("varying obs row, fixed N", varying_row)
 run("varying obs row, N growing 472..510 (no drop)", growing)
 rgp.N = N0
