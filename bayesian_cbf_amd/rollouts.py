@@ -338,7 +338,6 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         ev_base = E()
     refit_steps = []
     t0 = None
-    per_step_events = "noevents" not in os.environ.get("BCBF_LEARN_EXPERIMENT", "")
     for t in range(total):
         if t == warmup:
             if barrier is not None:
@@ -349,28 +348,15 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
             t0 = time.perf_counter()
         N_obs = window + t
         e = ev[t]
-        if per_step_events:
-            e[0].record()
+        e[0].record()
         if online:
             drops_before = rgp.drops
-            _exp = os.environ.get("BCBF_LEARN_EXPERIMENT", "")           # development switches (tools/dev/diag_online.sh)
-            if "plainquery" in _exp:
-                rgp.posterior(x, out=(ws["Mk"], ws["Bk"]))
-                info = rgp.info
-            else:
-                _n0 = rgp.N
-                info, _, _ = rgp.append(obs[0][N_obs], obs[1][N_obs], obs[2][N_obs], obs[3][N_obs], query=x, out=(ws["Mk"], ws["Bk"]))
-                if "fixedN" in _exp and rgp.drops == drops_before:
-                    rgp.N = _n0
+            info, _, _ = rgp.append(obs[0][N_obs], obs[1][N_obs], obs[2][N_obs], obs[3][N_obs], query=x, out=(ws["Mk"], ws["Bk"]))
             # (the window's drop + refit, when this append filled it, ran inside append -- timed below as its own share)
-            if per_step_events:
-                e[1].record()
-            if "nosolve" not in _exp:
-                solve()
-            if per_step_events:
-                e[2].record()
-            if "nofails" not in _exp:
-                fails_vec += info != 0                   # (stays on the device: the loop never waits for the host)
+            e[1].record()
+            solve()
+            e[2].record()
+            fails_vec += info != 0                       # (stays on the device: the loop never waits for the host)
             if rgp.drops != drops_before:
                 refit_steps.append(t)
         else:
