@@ -76,6 +76,9 @@
 #ifndef BCBF_PJ_ONE_WAVES
 #define BCBF_PJ_ONE_WAVES 3
 #endif
+#ifndef BCBF_PS_UNR64_WIDE
+#define BCBF_PS_UNR64_WIDE 2
+#endif
 #ifndef BCBF_PX_UNR32
 #define BCBF_PX_UNR32 8      // fp32 query + append column (4 right-hand-side columns): columns per pipeline stage
 #endif
@@ -371,7 +374,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     // next block are in flight while the current group / the barriers / the diagonal mat-vec run.
     // fp32 with the packed update has registers to spare: 8 columns per stage (16-32 KB in flight per wave), +2.5 %
     constexpr int UNR = ONE ? BCBF_PJ_ONE_UNR : NJ > 0 ? (CT > 12 ? 2 : sizeof(T) == 8 ? BCBF_PJ_UNR64 : (CT <= 6 ? BCBF_PJ_UNR32_NARROW : BCBF_PJ_UNR32))
-                               : (NQ > 1 ? (sizeof(T) == 8 ? BCBF_PQ_UNR64 : BCBF_PQ_UNR) : (XC > 0 && PK ? BCBF_PX_UNR32 : PK && C <= BCBF_PS_UNR8_MAXC ? 8 : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
+                               : (NQ > 1 ? (sizeof(T) == 8 ? BCBF_PQ_UNR64 : BCBF_PQ_UNR) : (XC > 0 && PK ? BCBF_PX_UNR32 : PK && C <= BCBF_PS_UNR8_MAXC ? 8
+                                  // (fp64 with four columns or a wide state: two columns per stage -- at four the 256-register form spills
+                                  //  108-268 B per lane and streams at 0.32-0.46 of HBM, round 5)
+                                  : (sizeof(T) == 8 && XC == 0 && (C >= 4 || NS > 4)) ? BCBF_PS_UNR64_WIDE : BCBF_PS_UNR)), NGRP = NB / UNR, HALF = NB / 2;
     static_assert(NGRP % 2 == 0, "pipeline processes two groups per trip");
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
