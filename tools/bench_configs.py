@@ -47,11 +47,11 @@ def config(Bt, N, n, m, dtype, name):
 
 CONFIGS = {"C2": (1024, 256, 2, 1, torch.float64, "C2"), "C3f64": (4096, 512, 3, 2, torch.float64, "C3 in fp64"),
            "C3": (4096, 512, 3, 2, torch.float32, "C3"), "N1024f64": (1024, 1024, 3, 2, torch.float64, "N=1024 fp64"),
-           # the fp64 instantiations of the streaming kernel that use scratch (m = 3: <double, 4, 4>; n > 4: <double, 3, 8>,
-           # <double, 4, 8>): what the spills cost, next to the same sizes at (n, m) = (3, 2) in "C3 in fp64"
-           "m3f64": (4096, 512, 3, 3, torch.float64, "fp64, m = 3 (posterior_step_kernel<double, 4, 4>: 108 B scratch)"),
-           "n6f64": (4096, 512, 6, 2, torch.float64, "fp64, n = 6 (posterior_step_kernel<double, 3, 8>: 108 B scratch)"),
-           "n6m3f64": (4096, 512, 6, 3, torch.float64, "fp64, n = 6, m = 3 (posterior_step_kernel<double, 4, 8>: 268 B scratch)")}
+           # the wide fp64 instantiations of the streaming kernel (m = 3: <double, 4, 4>; n > 4: <double, 3, 8>, <double, 4, 8>), next
+           # to the same sizes at (n, m) = (3, 2) in "C3 in fp64": two columns per pipeline stage since round 5 (at four they spilled)
+           "m3f64": (4096, 512, 3, 3, torch.float64, "fp64, m = 3 (posterior_step_kernel<double, 4, 4>)"),
+           "n6f64": (4096, 512, 6, 2, torch.float64, "fp64, n = 6 (posterior_step_kernel<double, 3, 8>)"),
+           "n6m3f64": (4096, 512, 6, 3, torch.float64, "fp64, n = 6, m = 3 (posterior_step_kernel<double, 4, 8>: 28 B scratch)")}
 DEFAULT = ("C2", "C3f64", "C3", "N1024f64")
 
 if __name__ == "__main__":
