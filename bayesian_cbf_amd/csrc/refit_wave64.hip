@@ -1252,6 +1252,10 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #ifndef BCBF_RP_KS32
 #define BCBF_RP_KS32 4           // ... fp32
 #endif
+#ifndef BCBF_RP_ACACHE
+#define BCBF_RP_ACACHE 1         // fp64: the bulk wave keeps the two left-most tiles of block row J (the A operand every tile of column J
+                                 // shares) in LDS for the column -- the launch is bound by the bandwidth of its own re-reads
+#endif
 // -DBCBF_RP_TRACE (development, tools/dev/trace_refit_pair.py): 100 MHz time stamps of workgroup 0's two waves at every hand-off
 #ifdef BCBF_RP_TRACE
 extern "C" __attribute__((visibility("default"))) int bcbf_debug_rp_trace(long long* out) {
@@ -1286,8 +1290,11 @@ constexpr int RA_MAXBLK = 16;          // block columns the look-ahead form hand
 #else
 #define RA_T(w) do {} while (0)
 #endif
+constexpr int RP_ACACHE_GROUPS = 16;          // cached k-groups of 4 columns: two 32-column tiles
 template <typename T> struct RAShared {
-    DiagTile<T> d;                            // wave 0's
+    DiagTile<T> d;                            // wave 0's (d.tile is NOT used by this kernel's diagonal-tile routine: with the A-operand
+                                              //  cache on it holds the cache's first tile)
+    T arow1[BCBF_RP_ACACHE && sizeof(T) == 8 ? 8 : 1][64][2] __attribute__((aligned(16)));    // ... its second tile
     T colX[2][NB][BCBF_MAX_STATE_DIM];        // [wave]: each wave stages the column block it is forming values for
     T colUH[2][NB][BCBF_MAX_CTRL_DIM + 1];
     unsigned pack_rc[LOP_DB / 2];             // (row, column) of the entries of a packed inverted diagonal block, two per word
@@ -1307,11 +1314,17 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     using P = RW<T>;
     using acc_t = typename P::acc_t;
     using T2 = typename P::vec2;
-    __shared__ RAShared<T> shm;
+    __shared__ __attribute__((aligned(16))) RAShared<T> shm;
     __attribute__((address_space(3))) RAShared<T>& sp = *(__attribute__((address_space(3))) RAShared<T>*)&shm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x;
     const int j16 = lane & 15, g = lane >> 4;
+    constexpr bool ACACHE = BCBF_RP_ACACHE && sizeof(T) == 8;
+    static_assert(!ACACHE || sizeof(T) * NB * DT_LS >= 8 * 64 * sizeof(T2), "the cache's first tile lives in d.tile");
+    // k-group grp (4 columns) of the cached A operand: this lane's two rows (the layout `update` loads them in)
+    auto acache = [&](int grp) -> __attribute__((address_space(3))) T* {
+        return grp < 8 ? &sp.d.tile[0][0] + (grp * 64 + lane) * 2 : &sp.arow1[ACACHE ? grp - 8 : 0][lane][0];
+    };
     T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
     const T* Xb = X + (size_t)b * N * n;
     const T* UHb = UH + (size_t)b * N * C;
@@ -1473,6 +1486,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     // multiply-adds per fetch instead of the full column-offset polynomial per load (the VALU work of this loop was
     // a third of its time: the wave issues in order, address arithmetic does not hide behind its own MFMAs)
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(lop, 0, (int)(lop_elems<V>(Np) * ES), 0x00020000);
+    int kc = 0;                       // bulk wave, A-operand cache: columns [0, kc) of block row J sit in LDS for this column
     auto update = [&](acc_t (&acc)[2][2], int I, int J, int k0, int k1) {
         constexpr int KS = sizeof(T) == 8 ? BCBF_RP_KS64 : BCBF_RP_KS32;
         const int col0 = J * NB, irow = I * NB + 2 * j16;
@@ -1487,7 +1501,10 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #pragma unroll
             for (int s_ = 0; s_ < KS; ++s_) {
                 const int so = (base + 4 * s_ * stride) * ES;
-                a_nxt[s_] = P::bload2(rsL, va, so);
+                if (ACACHE && kk + 4 * s_ < kc) {                      // (wave-uniform)
+                    const __attribute__((address_space(3))) T* cp = acache((kk >> 2) + s_);
+                    a_nxt[s_].x = cp[0]; a_nxt[s_].y = cp[1];
+                } else a_nxt[s_] = P::bload2(rsL, va, so);
                 b_nxt[s_] = P::bload2(rsL, vb, so);
             }
         };
@@ -1611,6 +1628,24 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
         T ainv[2][2][4];
         RA_T(1);                                                   // 0: column starts
         if (!EARLY) { load_rows(J + 1); stage_issue(J); stage_commit(); }
+        if constexpr (ACACHE) {
+            // block row J, columns [0, kc): the tiles L_{J,0}, L_{J,1} this wave stored in earlier columns (behind its own column
+            // fences), in the per-lane layout `update` loads its A operand in -- one read for the nblk - J - 1 tiles of the column
+            // (the first tile below, formed before the chain's inverse arrives, included).  Nothing else touches d.tile / arow1.
+            kc = (J + 2 < nblk) ? min(col0, 4 * RP_ACACHE_GROUPS) : 0;            // (a column with one tile has nothing to share)
+            for (int kk = 0; kk < kc; kk += 16) {
+                T2 v[4];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const int k_ = kk + 4 * s_, K = k_ / NB, stride = Np - NB * (K + 1);
+                    const int base = lop_base<V>(K * NB, Np) + NB * (K + 1) + (k_ - K * NB) * stride;
+                    v[s_] = P::bload2(rsL, (g * stride + col0 + 2 * j16 - NB * (K + 1)) * ES, base * ES);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) { __attribute__((address_space(3))) T* cp = acache((kk >> 2) + s_); cp[0] = v[s_].x; cp[1] = v[s_].y; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         for (int I = J + 1; I < nblk; ++I) {
             const int irow = I * NB + 2 * j16;
             acc_t acc[2][2];
