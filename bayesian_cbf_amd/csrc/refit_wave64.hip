@@ -1253,8 +1253,11 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 #define BCBF_RP_KS32 4           // ... fp32
 #endif
 #ifndef BCBF_RP_ACACHE
-#define BCBF_RP_ACACHE 1         // fp64: the bulk wave keeps the two left-most tiles of block row J (the A operand every tile of column J
-                                 // shares) in LDS for the column -- the launch is bound by the bandwidth of its own re-reads
+#define BCBF_RP_ACACHE 0         // fp64: the bulk wave keeps the two left-most tiles of block row J (the A operand every tile of column J
+                                 // shares) in LDS for the column: 25 of the 168 panel-tile reads of a C2 instance gone.  OFF -- measured
+                                 // (round 5, 1024 x 256 fp64, same box): 0.324 ms with the cache against 0.289 without; the fill at the head
+                                 // of a column and the LDS reads inside the stream cost the bulk wave more than the L2 / fabric reads they
+                                 // replace -- the re-reads are not what the launch waits for, whatever the byte count says
 #endif
 // -DBCBF_RP_TRACE (development, tools/dev/trace_refit_pair.py): 100 MHz time stamps of workgroup 0's two waves at every hand-off
 #ifdef BCBF_RP_TRACE
