@@ -221,7 +221,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     using acc_t = typename P::acc_t;
     using T2 = typename P::vec2;
     static_assert(!SUP || sizeof(T) == 8 || BCBF_RW32_PAIRS, "the super-panel form lives in the pair path");
-    __shared__ __attribute__((aligned(16))) RWShared<T, SUP> shm[RW_WPB];
+    __shared__ RWShared<T, SUP> shm[RW_WPB];
     // wave-uniform instance index: the per-instance pointers and hyper-parameters then live in SGPRs (scalar loads)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x * RW_WPB + wave;
