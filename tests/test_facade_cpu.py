@@ -184,3 +184,46 @@ def test_hyper_cache_follows_dtype_casts_and_repointed_parameters():
     r.model.raw_lengthscale.data.add_(1.0)                                   # in place through .data: invisible ...
     r.clear_cache(hyper=True)                                                # ... unless asked
     assert not torch.allclose(r._hyper()["ell"], ell1)
+
+
+def test_host_side_data_kernel_shapes_match_the_oracle_and_finite_differences():
+    """bayesian_cbf_amd/data_kernels.py (the prior-kernel values and derivatives the facade evaluates on the host: `_prior_knl`,
+    gp_eval, the rel-degree-2 prior curvature) against the oracle's kernels and central differences, all three data kernels."""
+    from bayesian_cbf_amd import data_kernels as dk
+    from oracle import gp_posterior as ogp
+    rng = np.random.default_rng(11)
+    ell, s2 = np.array([0.7, 1.3, 0.9]), 1.6
+    for kernel in dk.KINDS:
+        assert kernel in ogp.DATA_KERNELS and abs(dk.kxx(kernel) - ogp.KERNEL_KXX[kernel]) < 1e-15
+        for _ in range(5):
+            x, xp = rng.normal(size=3), rng.normal(size=3)
+            d2 = float((((x - xp) / ell) ** 2).sum())
+            sh, dsh, ddsh = (float(v) for v in dk.shape_terms(kernel, torch.tensor(d2, dtype=torch.float64)))
+            np.testing.assert_allclose(s2 * sh, ogp.DATA_KERNELS[kernel](x[None], xp[None], ell, s2)[0, 0], rtol=1e-13)
+            d = (x - xp) / ell ** 2
+            h = 1e-5
+            for a in range(3):
+                e = np.zeros(3); e[a] = h
+                k = lambda u, v: ogp.DATA_KERNELS[kernel](u[None], v[None], ell, s2)[0, 0]
+                np.testing.assert_allclose(-s2 * dsh * d[a], (k(x + e, xp) - k(x - e, xp)) / (2 * h), rtol=1e-6, atol=1e-9)   # dk/dx_a
+                for b_ in range(3):
+                    f = np.zeros(3); f[b_] = h
+                    fd = (k(x + e, xp + f) - k(x + e, xp - f) - k(x - e, xp + f) + k(x - e, xp - f)) / (4 * h * h)
+                    want = s2 * (dsh * (a == b_) / ell[a] ** 2 + ddsh * d[a] * d[b_])                                       # d2k/dx_a dx'_b
+                    np.testing.assert_allclose(want, fd, rtol=2e-4, atol=2e-6)
+        assert abs(float(dk.shape_terms(kernel, torch.tensor(0.0, dtype=torch.float64))[1]) - dk.kxx(kernel)) < 1e-14
+
+
+def test_every_data_kernel_has_every_entry_point_the_wrappers_ask_for():
+    """ops maps a data-kernel name to an entry-point suffix (`_KSUF`); every (base, kernel, dtype) the wrappers can ask for must be
+    an exported, declared symbol of libbcbf (a missing twin would only show up as an AttributeError on the GPU box)."""
+    from bayesian_cbf_amd import _lib, ops
+    bases = ["bcbf_kb_build", "bcbf_refit", "bcbf_posterior_query", "bcbf_posterior_shared", "bcbf_posterior_jets", "bcbf_mll_grad",
+             "bcbf_gp_append", "bcbf_unicycle_control_step"]
+    declared = set(_lib.declared_symbols())
+    for kernel in ops.DATA_KERNELS:
+        for base in bases:
+            for suf in ("_f32", "_f64"):
+                name = base + ops._KSUF[kernel] + suf
+                assert name in declared and hasattr(_lib.lib, name), name
+    assert ops.DATA_KERNELS.index("rbf") == 0 and ops.DATA_KERNELS.index("matern52") == 1 and ops.DATA_KERNELS.index("rbf_matern52") == 2
