@@ -494,6 +494,24 @@ def test_learning_closed_loop_final_model_vs_oracle_refit_of_the_final_window(op
     print("learning loop %s %s: worst |dMk| %.2e, |dBk| %.2e" % (schedule, dtype, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_learning_closed_loop_reference_schedule_on_part_batches_vs_oracle(ops, dtype):
+    """The reference cadence with the control steps as `ConcurrentControlLoop` part batches on their own streams (what
+    `bench.py --config learn --schedule reference --parts 4` times): every refit waits for the part streams and they wait for it --
+    a missing edge would let a part batch read a half-written factor.  Final model of every instance == the oracle's refit of the
+    final window; the controls of the last step agree with a one-stream run of the same loop."""
+    from bayesian_cbf_amd.rollouts import learning_closed_loop
+    kw = dict(Bt=30, max_train=120, steps=48, refit_every=24, warmup=24, dtype=dtype, device=DEV, seed=9, schedule="reference")
+    out3, final3 = learning_closed_loop(parts=3, **kw)
+    out1, final1 = learning_closed_loop(parts=1, **kw)
+    assert out3["parts"] == 3 and out3["append_or_refit_failures"] == 0 and out3["shares"]["refits_in_timed_region"] == 2
+    _learning_loop_final_vs_oracle(final3, list(range(30)), 1e-7 if dtype == torch.float64 else 1e-3, ops)
+    # same loop, one stream: identical states and controls (instances never interact; the refits are the same launches)
+    np.testing.assert_array_equal(host(final3["x"]), host(final1["x"]))
+    np.testing.assert_array_equal(host(final3["ws"]["y"]), host(final1["ws"]["y"]))
+    assert torch.equal(final3["ws"]["status"], final1["ws"]["status"])
+
+
 def test_learning_closed_loop_c3_scale_sampled_instances_vs_oracle(ops):
     """The same at BASELINE configs[2] scale (4096 instances, at most 512 points each, fp32, refit every 40): one warm-up period + one
     timed period, 64 instances spread over the batch against the oracle refit of their final window at 1e-3; the line the
