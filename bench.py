@@ -233,9 +233,21 @@ def cpu_baseline(sample, N, n, m, seed=1234, task_seed=99):
             procs = [ctx.Process(target=_cpu_worker, args=(w * per, (w + 1) * per, reps, barrier, queue)) for w in range(nw)]
             for pr in procs:
                 pr.start()
-            res = [queue.get() for _ in procs]
+            res = []
+            try:                                   # (a worker that never reports -- a fork of a threaded parent can in principle
+                for _ in procs:                    #  inherit a held lock -- must not hang the benchmark: bounded wait, then give up)
+                    res.append(queue.get(timeout=600))
+            except Exception:
+                res = None
             for pr in procs:
-                pr.join()
+                if res is None and pr.is_alive():
+                    pr.terminate()
+                pr.join(30)
+            if res is None:
+                variants.append(dict(name="scalar loop, one process per core: ABANDONED (a worker did not report within 600 s)",
+                                     cores=0, value=0.0, instances=0, seconds=0.0))
+                _CPU_SHARED.clear()
+                continue
             el = max(r[1] for r in res) - min(r[0] for r in res)
             done = sum(r[2] for r in res)
             pw = sorted(r[2] / (r[1] - r[0]) for r in res)
