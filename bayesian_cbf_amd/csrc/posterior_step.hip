@@ -209,6 +209,11 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     static_assert(NT <= 2, "[W, Vw] must fit 32 tile columns");
     __shared__ __attribute__((aligned(16))) T rbuf[NB][CP];
     __shared__ __attribute__((aligned(16))) T wbuf[NB][CW];
+    // (XC: the solved column l [Np] and -- tail step -- all solved columns [Np][CT], kept for one burst of stores after the last block;
+    //  dynamic shared memory, sized by launch_posterior_query_column_reserved)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_dyn_smem[];
+    T* const xc_l = reinterpret_cast<T*>(ps_dyn_smem);
+    T* const xc_w = xc_l + (XC > 0 && Wout != nullptr ? Np : 0);
 
     const int b = blockIdx.x;
     const int gb = shared ? 0 : b;      // regime S: every query reads the one shared GP (instance 0)
@@ -507,7 +512,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                         for (int c = 0; c < C; ++c) if (c < n) Wout[((size_t)b * ldN + row0 + di) * n + c] = w[c];
                     }
                 } else if (XC > 0) {                            // the append's column l, a vector [Np] per instance
-                    if (Wout != nullptr) Wout[(size_t)b * Np + row0 + di] = w[CT - 1];
+                    // (into LDS here, to memory after the last block: a global store in the diagonal step sits in the chain the whole
+                    //  workgroup waits for -- stores and loads retire through ONE in-order counter, so every load issued after it
+                    //  waited out the store's acknowledgement: 4096 x 472 fp32, 375 us with the stores here, 317 without)
+                    if (Wout != nullptr) xc_l[row0 + di] = w[CT - 1];
+                    if (Mfull != nullptr) {                     // ... and all CT solved columns [Np, CT] (the tail step, tail.hip)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) xc_w[(row0 + di) * CT + c] = w[c];
+                    }
                 } else if (NJ > 0 && Wout != nullptr) {        // jets: all CT columns [Phi, dPhi/dx_1 ..] of this row
 #pragma unroll
                     for (int c = 0; c < CT; ++c) Wout[((size_t)b * Np + row0 + di) * CT + c] = w[c];
@@ -600,6 +612,17 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         }
     }
 
+    if constexpr (XC > 0) {
+        // the append's column (and, for the tail step, every solved column): LDS -> memory, 16 bytes per lane, nothing waits for it
+        __syncthreads();
+        using VecT_ = typename Vec<T>::type;
+        if (Wout != nullptr)
+            for (int i = tid; i < Np / V; i += blockDim.x)
+                reinterpret_cast<VecT_*>(Wout + (size_t)b * Np)[i] = reinterpret_cast<const VecT_*>(xc_l)[i];
+        if (Mfull != nullptr)
+            for (int i = tid; i < Np * CT / V; i += blockDim.x)
+                reinterpret_cast<VecT_*>(Mfull + (size_t)b * Np * CT)[i] = reinterpret_cast<const VecT_*>(xc_w)[i];
+    }
     // ---- epilogue: wave 0 reduces the Gram and Vw'W and writes Mk, Bk
     if constexpr (RHS) return;
     if constexpr (MG) {
@@ -1085,16 +1108,20 @@ int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const 
 template <typename T>
 int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                            const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
-                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream) {
+                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream, T* Wfull, int Lcap) {
+    // Wfull (optional, [Bt, Np, 1 + m + 1]): every solved column of the pass, row-major per row (what the tail step continues from)
+    // Lcap (0: Ncap): the capacity the OPERATOR is laid out for where it differs from the arrays' -- a packed operator of exactly N
+    // points (bcbf_refit's output) beside arrays of Ncap rows: the tail step's window, which never grows in place
     if (Bt <= 0) return BCBF_OK;
     if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM || Ncap < N) return BCBF_EINVAL;
     constexpr int V = Vec<T>::V;
-    const int Np = round_up(N, NB), Nl = round_up(Ncap, NB);
+    const int Np = round_up(N, NB), Nl = round_up(Lcap ? Lcap : Ncap, NB);
     const int threads = round_up(Np / V / 2, 64);
-    if (threads > (sizeof(T) == 8 ? 512 : 256)) return BCBF_EINVAL;
+    if (threads > (sizeof(T) == 8 ? 512 : 256) || Nl < Np) return BCBF_EINVAL;
+    if (((lvec ? Np : 0) + (Wfull ? (size_t)Np * (m + 2) : 0)) * sizeof(T) > 48 * 1024) return BCBF_EINVAL;      // (the columns kept in LDS until the pass ends)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PX_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1>), grid, block, 0, st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, (T*)nullptr, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, 0, x_new, uh_new)
+#define BCBF_PX_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1>), grid, block, ((lvec ? Np : 0) + (Wfull ? (size_t)Np * (CC + 1) : 0)) * sizeof(T), st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, Wfull, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, 0, x_new, uh_new)
     switch (m) {
         case 1: BCBF_PX_LAUNCH(2); break;
         case 2: BCBF_PX_LAUNCH(3); break;
@@ -1103,8 +1130,8 @@ int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X
 #undef BCBF_PX_LAUNCH
     return check_launch("posterior_query_column");
 }
-template int launch_posterior_query_column_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, int, int, int, void*);
-template int launch_posterior_query_column_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int, int, int, int, int, void*);
+template int launch_posterior_query_column_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, int, int, int, void*, float*, int);
+template int launch_posterior_query_column_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int, int, int, int, int, void*, double*, int);
 template int launch_posterior_pair_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int, void*);
 template int launch_posterior_pair_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, int, int, int, int, int, void*);
 }  // namespace bcbf

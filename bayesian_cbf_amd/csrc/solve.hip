@@ -620,7 +620,8 @@ int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const 
 template <typename T>
 int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                            const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
-                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream);   // posterior_step.hip
+                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream,
+                                           T* Wfull = nullptr, int Lcap = 0);   // posterior_step.hip
 
 template <typename T>
 static int launch_gp_append_inplace(T* Lop, T* Vw, T* X, T* UHB, const T* s2, const T* Bm, const T* M0, const T* x_new,

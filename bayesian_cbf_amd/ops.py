@@ -224,8 +224,10 @@ class ReservedGP:
 
     BLOCK = 32
 
+    TAIL_MAX = 64            # tail rows the tail step holds (bcbf_gp_tail_step: tcap <= 64)
+
     def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None,
-                 drop=None):
+                 drop=None, tail=False):
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
         self.Bt, self.N, self.n = X.shape
         self.C = UHB.shape[2]
@@ -251,6 +253,24 @@ class ReservedGP:
             self._rUH[:, :self.N], self._rY[:, :self.N] = UH, Xdot
             if jitter is not None:
                 self._rJ[:, :self.N] = jitter
+        # tail=True (window mode): the points observed since the last window refit are kept as contiguous ROWS of a bordered factor
+        # beside the window's own (bcbf_gp_tail_step) instead of being written into the operator's columns one element at a time
+        self.tail = bool(tail)
+        self.N0, self.t = self.N, 0
+        if self.tail:
+            if self.window is None:
+                raise ValueError("tail=True is a form of the sliding window: pass window=...")
+            if self.window + self.drop - self.N > self.TAIL_MAX or self.n > 4:
+                raise ValueError("tail=True holds at most %d points between two window refits (and n <= 4)" % self.TAIL_MAX)
+            f = dict(dtype=X.dtype, device=X.device)
+            Npc = (self.capacity + 31) // 32 * 32
+            self._tcap = min(self.TAIL_MAX, self.window + self.drop - self.N)
+            self._Rb = torch.zeros(self.Bt, self._tcap, Npc, **f)
+            self._Rinv = torch.zeros(self.Bt, self._tcap, self._tcap, **f)
+            self._Wfull = torch.empty(self.Bt, Npc, self.C + 1, **f)
+            self._sw = torch.empty(self.Bt, 1 + self.n, **f)
+            self._ones = torch.ones(self.Bt, self.C, **f)
+            self._Lcap = self.capacity           # what the operator is laid out for: the reservation now, the window after a refit
 
     def _fill(self, Lop, Vw, X, UHB, N, capacity, cap_in=0, reuse=False):
         if capacity < N:
@@ -307,10 +327,25 @@ class ReservedGP:
         self.drop_info = info
         Vw, _ = potrs(Lop, Y, UH, self.M0, want_alpha=False)
         self._rUH[:, :N2], self._rY[:, :N2], self._rJ[:, :N2] = UH, Y, J
-        self._fill(Lop, Vw, X, UHB, N2, self.capacity, reuse=True)
-        self.N = N2
+        if self.tail:
+            # the window's operator is only read until the next refit: the packed one the refit wrote serves as it is (no re-layout
+            # into the reservation, 1.3 ms of a 4.9 ms window refit at 4096 x 472); the arrays keep their reserved rows
+            self.Lop, self._Lcap = Lop, N2
+            self.Vw[:, :N2], self.X[:, :N2], self.UHB[:, :N2] = Vw, X, UHB
+        else:
+            self._fill(Lop, Vw, X, UHB, N2, self.capacity, reuse=True)
+        self.N = self.N0 = N2
+        self.t = 0
         self.drops += 1
         return info
+
+    def _tail_step(self, xq, x_new, uh_new, xdot_new, jitter_new, Mk, Bk, do_append):
+        check(getattr(lib, "bcbf_gp_tail_step" + _suf(self.X))(
+            _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2),
+            _p(self.Bm), _p(self.M0), _p(xq), _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self._Rb), _p(self._Rinv),
+            _p(self.info), _p(self._Wfull), _p(self._sw), _p(Mk), _p(Bk), _p(self._rUH), _p(self._rY), _p(self._rJ), self.Bt,
+            self.N0, self.t, self._tcap, self.capacity, self._Lcap, self.n, self.C - 1, int(do_append), _stream(self.X)),
+            "bcbf_gp_tail_step")
 
     def posterior(self, xq, jitter2=None, want_W=False, out=None):
         """(Mk[Bt,n,C], Bk[Bt,C,C]) (+ W[Bt,Np,C]) at one query per instance on the live points."""
@@ -320,6 +355,11 @@ class ReservedGP:
             Mk, Bk = torch.empty(self.Bt, self.n, self.C, **f), torch.empty(self.Bt, self.C, self.C, **f)
         else:
             Mk, Bk = out
+        if self.tail:
+            if jitter2 is not None or want_W:
+                raise NotImplementedError("tail=True: the posterior at one query per instance, no jitter, no W")
+            self._tail_step(xq, xq, self._ones, None, None, Mk, Bk, False)
+            return Mk, Bk
         W = torch.empty(self.Bt, (self.N + 31) // 32 * 32, self.C, **f) if want_W else None
         check(getattr(lib, "bcbf_posterior_query_reserved" + _suf(self.X))(
             _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0), _p(xq),
@@ -338,6 +378,17 @@ class ReservedGP:
         if self.N >= self.capacity:
             raise RuntimeError("ReservedGP is full (%d points): reserve a larger capacity" % self.capacity)
         _chk(self.X, x_new, uh_new, xdot_new, jitter_new, query)
+        if self.tail:
+            if self.t >= self._tcap:
+                raise RuntimeError("tail=True: %d points since the last window refit -- drop_oldest_block first" % self.t)
+            f = dict(dtype=self.X.dtype, device=self.X.device)
+            if query is not None:
+                Mk, Bk = out if out is not None else (torch.empty(self.Bt, self.n, self.C, **f), torch.empty(self.Bt, self.C, self.C, **f))
+            else:
+                Mk, Bk = self._Mkw, self._Bkw
+            self._tail_step(x_new if query is None else query, x_new, uh_new, xdot_new, jitter_new, Mk, Bk, True)
+            self.t += 1
+            return self._appended(query, Mk, Bk)
         Mk = Bk = None
         if query is not None:
             f = dict(dtype=self.X.dtype, device=self.X.device)
@@ -356,6 +407,9 @@ class ReservedGP:
                   "bcbf_gp_append_reserved_raw")
         else:
             check(getattr(lib, "bcbf_gp_append_reserved" + _suf(self.X))(*head, *tail), "bcbf_gp_append_reserved")
+        return self._appended(query, Mk, Bk)
+
+    def _appended(self, query, Mk, Bk):
         self.N += 1
         info = self.info
         if self.window is not None and self.N >= self.window + self.drop:

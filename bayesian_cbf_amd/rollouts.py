@@ -262,6 +262,10 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         the live size runs from max_train - refit_every to max_train - 1, so the padded size -- and with it the workgroup
         shape of the streaming kernel -- never exceeds max_train's): the model the controller queries is never more than zero
         steps old.
+    schedule = "online_tail": the same schedule with the points observed since the last window refit kept as contiguous ROWS beside
+        the window's factor (`ReservedGP(tail=True)`, `bcbf_gp_tail_step`): the streaming pass runs over the static window, a small
+        tail kernel finishes the posterior over the newer points and appends the observation as one contiguous row -- no
+        element-per-column writes into the operator, whose dirty lines cost the next pass a quarter of its time.
     schedule = "reference": the reference's cadence -- the GP is STATIC between refits (the headline control step,
         `bcbf_unicycle_control_step`: posterior pass + solve), observations only land in a buffer, every `refit_every`-th step
         the last `max_train` buffered points are refactored (`bcbf_refit` + `bcbf_potrs`).  `parts` > 1: the control steps
@@ -280,7 +284,7 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         raise ValueError("steps must be a positive multiple of refit_every")
     warmup = -(-warmup // refit_every) * refit_every
     total = warmup + steps
-    window = max_train - refit_every if schedule == "online" else max_train      # points the model holds right after a refit
+    window = max_train - refit_every if schedule in ("online", "online_tail") else max_train      # points the model holds right after a refit
     if window < 1:
         raise ValueError("max_train must exceed refit_every")
     p = make_instances(Bt, window + total, n, m, dtype=dtype, device=dev, seed=seed)
@@ -303,10 +307,11 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     obs = [t.transpose(0, 1).contiguous() for t in (p["X"], p["UH"], p["Xdot"], p["jitter"])]     # [N][Bt, .]
     fails = torch.zeros((), dtype=torch.int64, device=dev)
     fails_vec = torch.zeros(Bt, dtype=torch.int32, device=dev)
-    online = schedule == "online"
+    online = schedule in ("online", "online_tail")
     if online:
         rgp = ops.ReservedGP(Lop, Vw, cut(p["X"], window), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + refit_every,
-                             window=window, drop=refit_every, UH=cut(p["UH"], window), Xdot=cut(p["Xdot"], window), jitter=jit0)
+                             window=window, drop=refit_every, UH=cut(p["UH"], window), Xdot=cut(p["Xdot"], window), jitter=jit0,
+                             tail=schedule == "online_tail")
         del Lop, Vw, UHB
         solve = ops.unicycle_control_step_prepare(dict(A=A), task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
                                                   clf_gamma=10.0, max_iters=20)
@@ -322,7 +327,7 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
             step_fn = ops.unicycle_control_step_prepare(gp, task, ws, x, dt=dt_plant, L_true=L_true, L_mean=L_mean,
                                                         clf_gamma=10.0, max_iters=20)
     else:
-        raise ValueError("schedule: 'online' or 'reference'")
+        raise ValueError("schedule: 'online', 'online_tail' or 'reference'")
     E = lambda: torch.cuda.Event(enable_timing=True)
     ev = [[E(), E(), E(), E()] for _ in range(total)]          # step start / pass end / solve end / (refit end)
     for row in ev:                                             # (torch creates the hipEvent handle at the first record; the
@@ -430,7 +435,8 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     if online:
         live = [window + (t % refit_every) for t in timed if t not in set(refit_steps)]
         pass_bytes = sum(online_pass_bytes(N, n, m, isz) for N in live) / max(1, len(live)) * Bt
-        pass_kernel = "posterior_step_kernel<%s, %d, 4, 0, 1, false, 1> + gp_append_inplace_kernel" % ("float" if isz == 4 else "double", 1 + m)
+        pass_kernel = "posterior_step_kernel<%s, %d, 4, 0, 1, false, 1> + %s" % ("float" if isz == 4 else "double", 1 + m,
+                                                                                   "gp_tail_step_kernel" if rgp.tail else "gp_append_inplace_kernel")
     else:
         pass_bytes = isz * (window * (window + 1) // 2 + 2 * window * n + window * (1 + m)) * Bt
         pass_kernel = "posterior_step_kernel<%s, %d, 4, 0, 1, false, 0>" % ("float" if isz == 4 else "double", 1 + m)

@@ -291,6 +291,31 @@ int bcbf_gp_append_reserved_raw_f64(double* Lop_r, double* Vw_r, double* X_r, do
                                     double* rawUH, double* rawY, double* rawJ, int Bt, int N, int Ncap, int n, int m,
                                     void* stream);
 
+/* Window mode with a row-major tail (csrc/tail.hip): the factor of the window's N0 points stays as bcbf_gp_reserve laid it out
+ * (Lop_r is only READ; Lcap = the capacity it is laid out for: Ncap for bcbf_gp_reserve's output, N0 for the packed operator of
+ * exactly N0 points that bcbf_refit writes -- the window never grows in place, so a window refit needs no re-layout) and the t points observed since the last window refit are rows of a bordered factor kept beside it --
+ * Rb[Bt,tcap,round_up(Ncap,32)] (row p: the new point's row over the N0 columns, contiguous), Rinv[Bt,tcap,tcap] (the inverse of the
+ * tail's own lower-triangular block), and rows N0+p of X_r / UHB_r / Vw_r (and of the raw store, as in bcbf_gp_append_reserved_raw;
+ * rawUH = rawY = rawJ = NULL: none).  One call = one "posterior, then append" step of the online schedule: (Mk[Bt,n,1+m],
+ * Bk[Bt,1+m,1+m]) at xq[Bt,n] over all N0 + t points, then (do_append) the observation (x_new, uh_new, xdot_new, jitter_new) enters as
+ * tail row t -- one contiguous row written per instance instead of one element in each of the operator's columns, whose ~N dirty
+ * 128-byte lines per instance cost the NEXT streaming pass a quarter of its time.  info[Bt] = 0, or N0+t+1 where the new
+ * pivot was not positive (a neutral point enters, as in bcbf_gp_append).  do_append = 0: the posterior only (x_new / uh_new still
+ * name a valid point; nothing is written but Mk, Bk and the work buffers).  Work buffers: Wwork[Bt,round_up(N0,32),2+m],
+ * swork[Bt,1+n].  tcap <= 64, n <= 4, m <= 3; round_up(N0,32) (2+m) + tcap^2 elements must fit 40 KB of LDS.  The caller counts t and rebuilds the
+ * window (refit of the raw rows + bcbf_gp_reserve) before t reaches tcap.  Follows the reference's refit-every-k loop
+ * (unicycle_move_to_pose.py:340-386) with k = 1 between refits; posterior: control_affine_model.py:1051-1059. */
+int bcbf_gp_tail_step_f32(const float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
+                          const float* Bm, const float* M0, const float* xq, const float* x_new, const float* uh_new,
+                          const float* xdot_new, const float* jitter_new, float* Rb, float* Rinv, int* info, float* Wwork,
+                          float* swork, float* Mk, float* Bk, float* rawUH, float* rawY, float* rawJ, int Bt, int N0, int t,
+                          int tcap, int Ncap, int Lcap, int n, int m, int do_append, void* stream);
+int bcbf_gp_tail_step_f64(const double* Lop_r, double* Vw_r, double* X_r, double* UHB_r, const double* ell, const double* s2,
+                          const double* Bm, const double* M0, const double* xq, const double* x_new, const double* uh_new,
+                          const double* xdot_new, const double* jitter_new, double* Rb, double* Rinv, int* info, double* Wwork,
+                          double* swork, double* Mk, double* Bk, double* rawUH, double* rawY, double* rawJ, int Bt, int N0, int t,
+                          int tcap, int Ncap, int Lcap, int n, int m, int do_append, void* stream);
+
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */
 int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream);

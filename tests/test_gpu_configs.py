@@ -401,6 +401,73 @@ def test_c5_reserved_storage_growth_128_to_2048_vs_oracle(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_window_with_row_major_tail_vs_oracle_and_vs_in_place_appends(ops, dtype):
+    """`ReservedGP(window=..., tail=True)` (bcbf_gp_tail_step): the points observed since the last window refit are rows of a
+    bordered factor beside the window's own.  Every step's posterior (at the query, BEFORE the step's append) against the ORACLE's
+    from-scratch refactorisation of the points held at that step, and against the in-place form (`tail=False`) run on the same
+    stream of observations -- through two window refits; a non-positive pivot enters a neutral tail row (the instance's posterior
+    stays what it was, the others learn); the tail refuses a 65th point; `posterior()` answers without appending."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, n, m, W, D = 4, 3, 2, 72, 24
+    steps = 2 * D + 7
+    p = make_instances(Bt, W + steps + 1, n, m, dtype=dtype, device=DEV, seed=77)
+    p["X"] = (p["X"] * 2.0).contiguous()
+    p["xq"] = (p["xq"] * 2.0).contiguous()
+    cut = lambda t, N: t[:, :N].contiguous()
+    jit0 = cut(p["jitter"], W)
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], W), cut(p["UH"], W), p["Bm"], p["ell"], p["s2"], jit0)
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], W), cut(p["UH"], W), p["M0"], want_alpha=False)
+    mk = lambda tail: ops.ReservedGP(Lop, Vw, cut(p["X"], W), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D,
+                                     UH=cut(p["UH"], W), Xdot=cut(p["Xdot"], W), jitter=jit0, tail=tail)
+    gt, gi = mk(True), mk(False)
+    h = {k: host(v) for k, v in p.items()}
+    tol = 1e-3 if dtype == torch.float32 else 1e-8
+    lo = 0                                                   # first observation the window still holds
+    bad_step = D + 3                                         # instance 2's observation of this step duplicates a live point
+    for t in range(steps):
+        N = W + t
+        xq = (p["xq"] + 0.01 * t).contiguous()
+        x_new, uh_new, xd_new, j_new = (p[k][:, N].clone().contiguous() for k in ("X", "UH", "Xdot", "jitter"))
+        if t == bad_step:
+            x_new[2], uh_new[2] = p["X"][2, N - 5], p["UH"][2, N - 5]
+            j_new[2] = -j_new[2].abs()
+        n_before, jit_before = gt.N, host(gt._rJ[:, :gt.N])
+        it, Mt, Bt_ = gt.append(x_new, uh_new, xd_new, j_new, query=xq)
+        ii, Mi, Bi = gi.append(x_new, uh_new, xd_new, j_new, query=xq)
+        assert it.cpu().tolist() == ii.cpu().tolist()
+        assert it.cpu().tolist() == ([0, 0, n_before + 1, 0] if t == bad_step else [0] * Bt)
+        rel_close(host(Mt), host(Mi), tol, scale=max(1.0, float(Mi.abs().max())), what="Mk tail vs in place, step %d" % t)
+        rel_close(host(Bt_), host(Bi), tol, scale=float((p["s2"][:, None, None] * p["Bm"]).abs().max()), what="Bk tail vs in place")
+        if t % 5 == 0 or t in (D - 1, D, bad_step + 1):
+            sl = slice(lo, lo + n_before)                     # the observations held BEFORE this append, oldest first
+            for i in (0, 1):                                  # (instance 2 holds a neutral point after bad_step: checked against the in-place form)
+                stt = ogp.refit_state(h["X"][i, sl], h["U"][i, sl], h["Xdot"][i, sl], h["Bm"][i], h["ell"][i], h["s2"][i],
+                                      h["M0"][i], jit_before[i][None] / 1e-5)
+                Mk_o, Bk_o = ogp.posterior_step(stt["L"][None], stt["alpha"][None], h["X"][i, sl][None], stt["UHB"][None],
+                                                h["ell"][i][None], h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None],
+                                                host(xq)[i][None])
+                prior = float(h["s2"][i] * np.abs(h["Bm"][i]).max())
+                rel_close(host(Mt)[i], Mk_o[0], tol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk tail vs oracle, step %d" % t)
+                rel_close(host(Bt_)[i], Bk_o[0], tol, scale=prior, what="Bk tail vs oracle, step %d" % t)
+        assert gt.N == gi.N and gt.N == gt.N0 + gt.t
+        if gt.N == W:                                         # the append filled the window: D points left, the tail is empty again
+            lo += D
+            assert gt.t == 0 and gt.N0 == W
+    assert gt.drops == 2 and gt.t == 7 and gt.N == W + 7 and gt.drop_failures == 0
+    # posterior() = the same step without the append
+    xq = p["xq"]
+    Mq, Bq = gt.posterior(xq)
+    Mi, Bi = gi.posterior(xq)
+    rel_close(host(Mq), host(Mi), tol, scale=max(1.0, float(Mi.abs().max())), what="Mk posterior() tail vs in place")
+    rel_close(host(Bq), host(Bi), tol, scale=float((p["s2"][:, None, None] * p["Bm"]).abs().max()), what="Bk posterior()")
+    assert gt.t == 7
+    with pytest.raises(ValueError):                           # more points between two refits than the tail holds
+        ops.ReservedGP(Lop, Vw, cut(p["X"], W), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + 80, window=W, drop=80,
+                       UH=cut(p["UH"], W), Xdot=cut(p["Xdot"], W), jitter=jit0, tail=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
     """Reserved storage holds the same GP as the packed layout: queries agree bit for bit with `posterior_step` on the
     packed state at several live sizes / capacities (incl. a capacity that is no multiple of 32); a non-positive pivot
@@ -478,7 +545,7 @@ def _learning_loop_final_vs_oracle(final, idx, tol, ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("schedule", ["online", "reference"])
+@pytest.mark.parametrize("schedule", ["online", "online_tail", "reference"])
 def test_learning_closed_loop_final_model_vs_oracle_refit_of_the_final_window(ops, schedule, dtype):
     """The learning closed loop (rollouts.learning_closed_loop; the reference's train(): buffer every step, refit every
     `train_every_n_steps`, unicycle_move_to_pose.py:340-386) at a small size, both schedules: after 3 refit periods + 17
