@@ -22,7 +22,7 @@ def last_json_line(path):
 
 
 # ---- kernel-trace summaries (libbcbf kernels only; the torch kernels of the synthetic-data generator are dropped)
-for tag in ("default", "parts1", "shared", "shared_f64", "reldeg2", "learn_reference", "learn_online", "append_b256_n1024_2048", "append_b1024_n1024_1280"):
+for tag in ("default", "parts1", "shared", "shared_f64", "reldeg2", "learn_reference", "learn_online", "learn_online_tail", "append_b256_n1024_2048", "append_b1024_n1024_1280"):
     f = latest("prof_%s/*/*_kernel_stats.csv" % tag)
     if not f:
         continue
@@ -41,7 +41,7 @@ for a in ("bench_default", "bench_driver_form", "bench_default_prof", "bench_par
               "busy/step", round(rf.get("kernel_busy_ms_per_step", 0), 4), d.get("cpu_baseline", {}).get("value"))
 for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online_growth_f64.json", "online_growth_f64_unfused.json", "online_growth_f64_unfused3.json", "online_growth_f64_packed.json", "online_growth_f64_batch1024.json", "online_growth_f64_pairform.json", "online_window512_f64.json", "online_window1024_f64.json", "speed_call_host.txt", "reldeg2.jsonl", "speed_test.jsonl", "speed_test_unicycle.jsonl",
           "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "shared_sweep.jsonl", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt", "pmc_traffic_refit.json",
-          "refit_pair_timeline.txt", "learn_reference_parts4.json", "learn_reference.json", "learn_online.json", "learn_reference_prof.json",
+          "refit_pair_timeline.txt", "learn_reference_parts4.json", "learn_reference.json", "learn_online.json", "learn_online_tail.json", "learn_online_tail_prof.json", "learn_reference_prof.json",
           "learn_online_prof.json", "pmc_traffic_append.json", "online_b256_n1024_2048.json", "online_b1024_n1024_1280.json",
           "online_f32_b4096.json", "tol_report.txt"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
