@@ -248,6 +248,23 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
     return out
 
 
+class _PartsReserved:
+    """The part batches' `ops.ReservedGP` objects of `learning_closed_loop(parts > 1)` seen as one (what the parity checks read)."""
+
+    def __init__(self, rgps, bounds):
+        self.rgps, self.bounds = rgps, bounds
+
+    N = property(lambda self: self.rgps[0].N)
+    tail = property(lambda self: self.rgps[0].tail)
+    drops = property(lambda self: self.rgps[0].drops)
+    drop_failures = property(lambda self: sum(g.drop_failures for g in self.rgps))
+    _rJ = property(lambda self: torch.cat([g._rJ for g in self.rgps], 0))
+
+    def posterior(self, xq):
+        out = [g.posterior(xq[lo:hi].contiguous()) for g, (lo, hi) in zip(self.rgps, self.bounds)]
+        return torch.cat([o[0] for o in out], 0), torch.cat([o[1] for o in out], 0)
+
+
 def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warmup=40, dtype=torch.float32, device="cuda",
                          seed=1234, schedule="online", n=3, m=2, barrier=None, parts=1):
     """The reference's REAL workload at BASELINE configs[2] scale: a control loop that keeps learning
@@ -308,7 +325,34 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     fails = torch.zeros((), dtype=torch.int64, device=dev)
     fails_vec = torch.zeros(Bt, dtype=torch.int32, device=dev)
     online = schedule in ("online", "online_tail")
-    if online:
+    if online and parts > 1:
+        # part batches on their own streams (instances never interact): one part's latency-bound solve and its small tail / row
+        # kernels run beside another part's streaming pass, as ops.ConcurrentControlLoop does for the static model; a part's window
+        # refit runs on its own stream too (its jitter-retry check waits for that stream only)
+        base, rem = divmod(Bt, parts)
+        bounds = [(c * base + min(c, rem), (c + 1) * base + min(c + 1, rem)) for c in range(parts)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(parts)]
+        cur = torch.cuda.current_stream(dev)
+        X0, UH0, Y0 = cut(p["X"], window), cut(p["UH"], window), cut(p["Xdot"], window)
+        tkeys = ops.ConcurrentControlLoop.TASK_INSTANCE_KEYS
+        rgps, solves = [], []
+        for c in range(parts):
+            sl = slice(*bounds[c])
+            streams[c].wait_stream(cur)
+            with torch.cuda.stream(streams[c]):
+                rgps.append(ops.ReservedGP(Lop[sl], Vw[sl], X0[sl], UHB[sl], p["ell"][sl], p["s2"][sl], p["Bm"][sl], p["M0"][sl],
+                                           window + refit_every, window=window, drop=refit_every, UH=UH0[sl], Xdot=Y0[sl],
+                                           jitter=jit0[sl], tail=schedule == "online_tail"))
+            taskc = {k: (v[sl] if (torch.is_tensor(v) and k in tkeys) else v) for k, v in task.items()}
+            Ac = A[sl] if (A.dim() == 3 and A.shape[0] == Bt and Bt > 1) else A
+            solves.append(ops.unicycle_control_step_prepare(dict(A=Ac), taskc, {k: v[sl] for k, v in ws.items()}, x[sl], dt=dt_plant,
+                                                            L_true=L_true, L_mean=L_mean, clf_gamma=10.0, max_iters=20,
+                                                            stream=streams[c]))
+        for s_ in streams:
+            s_.synchronize()
+        del Lop, Vw, UHB, X0, UH0, Y0
+        rgp = _PartsReserved(rgps, bounds)
+    elif online:
         rgp = ops.ReservedGP(Lop, Vw, cut(p["X"], window), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + refit_every,
                              window=window, drop=refit_every, UH=cut(p["UH"], window), Xdot=cut(p["Xdot"], window), jitter=jit0,
                              tail=schedule == "online_tail")
@@ -333,13 +377,15 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     for row in ev:                                             # (torch creates the hipEvent handle at the first record; the
         for e_ in row:                                         #  reference schedule hands raw handles to the C entry point)
             e_.record()
-    concurrent = (not online) and parts > 1
+    concurrent = parts > 1
     evp = None
     if concurrent:                                             # per part: events around its posterior launch, on its stream
+        if not online:
+            streams = loop.streams
         evp = [[(E(), E()) for _ in range(parts)] for _ in range(total)]
         for row in evp:
             for c, (a_, b_) in enumerate(row):
-                a_.record(loop.streams[c]); b_.record(loop.streams[c])
+                a_.record(streams[c]); b_.record(streams[c])
         ev_base = E()
     refit_steps = []
     t0 = None
@@ -349,12 +395,27 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
                 barrier()
             torch.cuda.synchronize(dev)
             if concurrent:
-                ev_base.record(loop.streams[0])
+                for s_ in streams:
+                    s_.synchronize()
+                ev_base.record(streams[0])
             t0 = time.perf_counter()
         N_obs = window + t
         e = ev[t]
         e[0].record()
-        if online:
+        if online and concurrent:
+            drops_before = rgp.drops
+            for c in range(parts):
+                sl = slice(*bounds[c])
+                with torch.cuda.stream(streams[c]):
+                    evp[t][c][0].record(streams[c])
+                    info, _, _ = rgps[c].append(obs[0][N_obs][sl], obs[1][N_obs][sl], obs[2][N_obs][sl], obs[3][N_obs][sl], query=x[sl],
+                                                out=(ws["Mk"][sl], ws["Bk"][sl]))
+                    evp[t][c][1].record(streams[c])
+                    solves[c]()
+                    fails_vec[sl] += info != 0
+            if rgp.drops != drops_before:
+                refit_steps.append(t)
+        elif online:
             drops_before = rgp.drops
             info, _, _ = rgp.append(obs[0][N_obs], obs[1][N_obs], obs[2][N_obs], obs[3][N_obs], query=x, out=(ws["Mk"], ws["Bk"]))
             # (the window's drop + refit, when this append filled it, ran inside append -- timed below as its own share)
@@ -397,7 +458,27 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         barrier()
     elapsed = time.perf_counter() - t0
     timed = range(warmup, total)
-    if online:
+    if online and concurrent:
+        # the parts drift apart, so shares are taken over the whole timed region: the time during which at least one part's pass
+        # (on a refit step: pass + window refit) ran, and a refit's own share from each part's refit-step interval minus that part's
+        # mean plain interval
+        spans = sorted((ev_base.elapsed_time(a_), ev_base.elapsed_time(b_)) for t in timed for a_, b_ in evp[t])
+        busy, ca, cb = 0.0, spans[0][0], spans[0][1]
+        for a_, b_ in spans[1:]:
+            if a_ > cb:
+                busy += cb - ca
+                ca, cb = a_, b_
+            else:
+                cb = max(cb, b_)
+        busy += cb - ca
+        tr = set(refit_steps)
+        dur = lambda t, c: evp[t][c][0].elapsed_time(evp[t][c][1])
+        plain_c = [sum(dur(t, c) for t in timed if t not in tr) / max(1, sum(1 for t in timed if t not in tr)) for c in range(parts)]
+        rs = [t for t in timed if t in tr]
+        n_refits = len(rs)
+        refit_ms = (sum(dur(t, c) - plain_c[c] for t in rs for c in range(parts)) / (n_refits * parts)) if rs else 0.0
+        pass_ms = busy / steps - refit_ms * n_refits / steps / parts      # (a part's refit occupies the device for ~1/parts of the batch)
+    elif online:
         # the append (+ the drop/refit on refit steps) sits between e[0] and e[1]; a refit step's own share = its interval minus
         # the mean interval of the other steps at a comparable N
         tr = set(refit_steps)
@@ -441,7 +522,7 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         pass_bytes = isz * (window * (window + 1) // 2 + 2 * window * n + window * (1 + m)) * Bt
         pass_kernel = "posterior_step_kernel<%s, %d, 4, 0, 1, false, 0>" % ("float" if isz == 4 else "double", 1 + m)
     peak_t = 157.3 if isz == 4 else 78.6
-    refit_flops = Bt * window ** 3 / 3.0
+    refit_flops = (Bt / parts if (online and concurrent) else Bt) * window ** 3 / 3.0     # (online on part batches: a refit is one part's)
     roof = {"pass": dict(bound="hbm", kernel=pass_kernel, algorithmic_bytes_per_launch=pass_bytes,
                          achieved=pass_bytes / (pass_ms * 1e-3) / 1e9, peak=8000.0, unit="GB/s",
                          frac=pass_bytes / (pass_ms * 1e-3) / 1e9 / 8000.0, kernel_ms=pass_ms, traffic=None),

@@ -579,6 +579,25 @@ def test_learning_closed_loop_reference_schedule_on_part_batches_vs_oracle(ops, 
     assert torch.equal(final3["ws"]["status"], final1["ws"]["status"])
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("schedule", ["online_tail", "online"])
+def test_learning_closed_loop_online_schedules_on_part_batches_vs_oracle(ops, schedule, dtype):
+    """The online schedules with the batch split into part batches, each with its own `ReservedGP` on its own stream (what
+    `bench.py --config learn --schedule online_tail --parts 4` times): the final model of every instance == the oracle's refit of
+    the final window, and states / controls of the last step are those of the one-stream run of the same loop (instances never
+    interact; a part's appends, tail steps and window refits are the same launches on a slice of the batch)."""
+    from bayesian_cbf_amd.rollouts import learning_closed_loop
+    kw = dict(Bt=30, max_train=120, steps=48, refit_every=24, warmup=24, dtype=dtype, device=DEV, seed=9, schedule=schedule)
+    out3, final3 = learning_closed_loop(parts=3, **kw)
+    out1, final1 = learning_closed_loop(parts=1, **kw)
+    assert out3["parts"] == 3 and out3["append_or_refit_failures"] == 0 and out3["shares"]["refits_in_timed_region"] == 2
+    assert final3["N"] == final1["N"] and final3["rgp"].drops == final1["rgp"].drops
+    _learning_loop_final_vs_oracle(final3, list(range(30)), 1e-7 if dtype == torch.float64 else 1e-3, ops)
+    np.testing.assert_array_equal(host(final3["x"]), host(final1["x"]))
+    np.testing.assert_array_equal(host(final3["ws"]["y"]), host(final1["ws"]["y"]))
+    assert torch.equal(final3["ws"]["status"], final1["ws"]["status"])
+
+
 def test_learning_closed_loop_c3_scale_sampled_instances_vs_oracle(ops):
     """The same at BASELINE configs[2] scale (4096 instances, at most 512 points each, fp32, refit every 40): one warm-up period + one
     timed period, 64 instances spread over the batch against the oracle refit of their final window at 1e-3; the line the

@@ -27,7 +27,7 @@ ap.add_argument("--warmup", type=int, default=40)
 ap.add_argument("--refit-every", type=int, default=40)
 ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
 ap.add_argument("--schedule", choices=["online", "online_tail", "reference"], default="online")
-ap.add_argument("--parts", type=int, default=1, help="reference schedule: part batches on their own streams (bench.py's default is 4)")
+ap.add_argument("--parts", type=int, default=1, help="part batches on their own streams (reference schedule: 4 is bench.py's default; online schedules: 2 -- more are host-bound)")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
     from bayesian_cbf_amd.distributed import launch_ranks
