@@ -34,7 +34,9 @@ EXTRA_FLAGS = {"posterior_shared.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "posterior_step.hip": ["-Rpass-analysis=kernel-resource-usage"]}
 # instantiations of the streaming kernel whose measured figures assume ZERO scratch (a spill in the streaming loop is fatal
 # there: DESIGN.md 3.1 -- 1373 us against 470): the headline (fp32 / fp64 values-only, C = 2..3), the fp32 jets of the pendulum and
-# unicycle shapes, the fp32 fused query + append column.  Demangled-name prefixes; the build fails when one of them reports scratch.
+# unicycle shapes, the fp32 fused query + append column.  Demangled-name prefixes; the build fails when one of them reports scratch
+# beyond its allowance (SCRATCH_ALLOWANCE: the unicycle jets spill 40 B per lane since the block loop exists twice -- A side live /
+# dead, BCBF_PS_SKIP_DEAD_A -- and run 0.444 ms with them against 0.455 without the second loop and without scratch).
 ZERO_SCRATCH_KERNELS = {"posterior_step.hip": [
     "posterior_step_kernel<float, 2, 4, 0, 1, false, 0,", "posterior_step_kernel<float, 3, 4, 0, 1, false, 0,",
     "posterior_step_kernel<double, 2, 4, 0, 1, false, 0,", "posterior_step_kernel<double, 3, 4, 0, 1, false, 0,",
@@ -44,6 +46,7 @@ ZERO_SCRATCH_KERNELS = {"posterior_step.hip": [
 # kernels that must not touch scratch memory (posterior_shared_reg: an operand spilled between its explicit LDS read and
 # the explicit wait for it would be stored before it has arrived).  Their device assembly is also linted: no instruction may
 # name the destination of an LDS read that has not been waited for (check_lds_waits.py)
+SCRATCH_ALLOWANCE = {"posterior_step_kernel<float, 3, 4, 3, 1, false, 0,": 40}
 NO_SCRATCH = {"posterior_shared_reg.hip"}
 
 
@@ -134,7 +137,7 @@ def _compile(item, force):
             for want in ZERO_SCRATCH_KERNELS[src]:
                 if want in full:
                     seen.add(want)
-                    if z:
+                    if z > SCRATCH_ALLOWANCE.get(want, 0):
                         os.remove(obj)
                         raise RuntimeError("%s: %s uses %d bytes of scratch per lane (its measured figures assume none)" % (src, want, z))
         missing = [w for w in ZERO_SCRATCH_KERNELS[src] if w not in seen]

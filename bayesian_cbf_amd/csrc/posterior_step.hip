@@ -79,6 +79,9 @@
 #ifndef BCBF_PS_UNR64_WIDE
 #define BCBF_PS_UNR64_WIDE 2
 #endif
+#ifndef BCBF_PS_SKIP_DEAD_A
+#define BCBF_PS_SKIP_DEAD_A 1
+#endif
 #ifndef BCBF_PX_UNR32
 #define BCBF_PX_UNR32 8      // fp32 query + append column (4 right-hand-side columns): columns per pipeline stage
 #endif
@@ -387,7 +390,8 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     VecT la0[UNR], lb0[UNR], la1[UNR], lb1[UNR];
     T dval[HALF];
     const int di = tid & 31, dh = (tid >> 5) & 1;
-    auto issue = [&](VecT* la, VecT* lb, int J, int g) {
+    // AL (compile-time): the wave still owns live A-side rows (its low row blocks); false: loads and updates of the A side are skipped
+    auto issue = [&](VecT* la, VecT* lb, int J, int g, auto AL) __attribute__((always_inline)) {
         // column j of block column J stores rows 32 (J+1) .. Np-1: per-lane offset relative to the first stored row,
         // scalar offset = start of the column (lop_base(j) + 32 (J+1) >= 0: buffer offsets are unsigned)
         const int rbmin = (J + 1) * RPB;
@@ -396,11 +400,12 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int soff = (lop_base<V>(J * NB + g * UNR + u, Nl) + (J + 1) * NB) * (int)sizeof(T);
-            la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
+            if constexpr (decltype(AL)::value) la[u] = BufLoad<T>::vec(rsrc, voffA, soff);
             if constexpr (!ONE) lb[u] = BufLoad<T>::vec(rsrc, voffB, soff);
         }
     };
-    auto consume = [&](const VecT* la, const VecT* lb, int jj0) {
+    auto consume = [&](const VecT* la, const VecT* lb, int jj0, auto AL) __attribute__((always_inline)) {
+        constexpr bool ALV = decltype(AL)::value;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             if constexpr (PK) {
@@ -412,7 +417,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     wp[2 * q] = __builtin_shufflevector(w4, w4, 0, 1);
                     wp[2 * q + 1] = __builtin_shufflevector(w4, w4, 2, 3);
                 }
-                const f32x4 a4 = __builtin_bit_cast(f32x4, la[u]), b4 = __builtin_bit_cast(f32x4, lb[ONE ? 0 : u]);
+                const f32x4 a4 = (ALV || ONE) ? __builtin_bit_cast(f32x4, la[u]) : f32x4{}, b4 = __builtin_bit_cast(f32x4, lb[ONE ? 0 : u]);
                 const f32x2 pa2[2] = {__builtin_shufflevector(a4, a4, 0, 1), __builtin_shufflevector(a4, a4, 2, 3)};
                 const f32x2 pb2[2] = {__builtin_shufflevector(b4, b4, 0, 1), __builtin_shufflevector(b4, b4, 2, 3)};
 #pragma unroll
@@ -421,12 +426,14 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     for (int c = 0; c < CT; ++c) {
                         // acc.{lo,hi} -= p.{lo,hi} * w[c]  (w[c] = low or high half of its pair, broadcast by op_sel)
                         if (c & 1) {
+                            if constexpr (ALV || ONE)
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
                                 : "+v"(accp[0][vp][c]) : "v"(pa2[vp]), "v"(wp[c >> 1]));
                             if constexpr (!ONE)
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
                                 : "+v"(accp[NR - 1][vp][c]) : "v"(pb2[vp]), "v"(wp[c >> 1]));
                         } else {
+                            if constexpr (ALV || ONE)
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
                                 : "+v"(accp[0][vp][c]) : "v"(pa2[vp]), "v"(wp[c >> 1]));
                             if constexpr (!ONE)
@@ -444,7 +451,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 for (int v = 0; v < V; ++v)
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
-                        acc[0][v][c] -= pa[v] * wj[c];
+                        if constexpr (ALV || ONE) acc[0][v][c] -= pa[v] * wj[c];
                         if constexpr (!ONE) acc[NR - 1][v][c] -= pb[v] * wj[c];
                     }
             }
@@ -476,8 +483,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     issue_vw(0);
 #endif
     issue_diag(0);
-    if (nblk > 1) issue(la0, lb0, 0, 0);
-    for (int J = 0; J < nblk; ++J) {
+    if (nblk > 1) issue(la0, lb0, 0, 0, std::true_type{});
+    // One block of the forward substitution.  AL (compile-time): this wave still owns live A-side rows; the blocks after its last live
+    // one run the B side only (BCBF_PS_SKIP_DEAD_A) -- in a SECOND loop, so that the A side's registers are dead there
+    auto block_body = [&](const int J, auto AL) __attribute__((always_inline)) {
         const int row0 = J * NB;
         // 1. publish r_J
 #pragma unroll
@@ -601,15 +610,28 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 #if BCBF_PS_VWPF
             issue_vw(J + 1);
 #endif
+            // the block's column groups; a wave whose A-side row blocks all lie above the rows this block column still touches runs
+            // the B side only (BCBF_PS_SKIP_DEAD_A: the dead half cost its loads' issue slots and its multiply-adds -- a quarter of
+            // the kernel's instructions over a pass, which the forms near their issue limit feel: jets, the append's column)
+            auto stream_block = [&](auto AL) __attribute__((always_inline)) {
 #pragma unroll 1
-            for (int g = 0; g < NGRP; g += 2) {
-                issue(la1, lb1, J, g + 1);
-                consume(la0, lb0, g * UNR);
-                if (g + 2 < NGRP) issue(la0, lb0, J, g + 2);
-                else if (J + 2 < nblk) issue(la0, lb0, J + 1, 0);
-                consume(la1, lb1, (g + 1) * UNR);
-            }
+                for (int g = 0; g < NGRP; g += 2) {
+                    issue(la1, lb1, J, g + 1, AL);
+                    consume(la0, lb0, g * UNR, AL);
+                    if (g + 2 < NGRP) issue(la0, lb0, J, g + 2, AL);
+                    else if (J + 2 < nblk) issue(la0, lb0, J + 1, 0, AL);
+                    consume(la1, lb1, (g + 1) * UNR, AL);
+                }
+            };
+            stream_block(AL);
         }
+    };
+    {
+        // a wave's A-side row blocks are [64 w, 64 w + 63]: live in block J while (J + 1) RPB <= the largest of them
+        const int rbA_wave_max = __builtin_amdgcn_readfirstlane(tid) | 63;
+        const int Jsplit = (BCBF_PS_SKIP_DEAD_A && !ONE) ? min(nblk, rbA_wave_max / RPB) : nblk;
+        for (int J = 0; J < Jsplit; ++J) block_body(J, std::true_type{});
+        for (int J = Jsplit; J < nblk; ++J) block_body(J, std::false_type{});
     }
 
     if constexpr (XC > 0) {
