@@ -340,12 +340,17 @@ class ReservedGP:
         return info
 
     def _tail_step(self, xq, x_new, uh_new, xdot_new, jitter_new, Mk, Bk, do_append):
-        check(getattr(lib, "bcbf_gp_tail_step" + _suf(self.X))(
-            _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2),
-            _p(self.Bm), _p(self.M0), _p(xq), _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self._Rb), _p(self._Rinv),
-            _p(self.info), _p(self._Wfull), _p(self._sw), _p(Mk), _p(Bk), _p(self._rUH), _p(self._rY), _p(self._rJ), self.Bt,
-            self.N0, self.t, self._tcap, self.capacity, self._Lcap, self.n, self.C - 1, int(do_append), _stream(self.X)),
-            "bcbf_gp_tail_step")
+        # (the pointers of this object's own buffers are converted once per window: a closed loop on part batches makes this call
+        #  thousands of times and the host side of it is what bounds four part batches)
+        st = self.__dict__.get("_tail_static")
+        if st is None or st[0] is not self.Lop:
+            st = self._tail_static = (self.Lop, getattr(lib, "bcbf_gp_tail_step" + _suf(self.X)),
+                                      (_p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0)),
+                                      (_p(self._Rb), _p(self._Rinv), _p(self.info), _p(self._Wfull), _p(self._sw)),
+                                      (_p(self._rUH), _p(self._rY), _p(self._rJ)))
+        check(st[1](*st[2], _p(xq), _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), *st[3], _p(Mk), _p(Bk), *st[4], self.Bt,
+                    self.N0, self.t, self._tcap, self.capacity, self._Lcap, self.n, self.C - 1, int(do_append), _stream(self.X)),
+              "bcbf_gp_tail_step")
 
     def posterior(self, xq, jitter2=None, want_W=False, out=None):
         """(Mk[Bt,n,C], Bk[Bt,C,C]) (+ W[Bt,Np,C]) at one query per instance on the live points."""

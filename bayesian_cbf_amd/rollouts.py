@@ -352,6 +352,11 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
             s_.synchronize()
         del Lop, Vw, UHB, X0, UH0, Y0
         rgp = _PartsReserved(rgps, bounds)
+        # per-part views, made once (the loop's host side is what bounds three and four part batches)
+        obs_c = [[o[:, slice(*bounds[c])] for o in obs] for c in range(parts)]
+        x_c = [x[slice(*bounds[c])] for c in range(parts)]
+        out_c = [(ws["Mk"][slice(*bounds[c])], ws["Bk"][slice(*bounds[c])]) for c in range(parts)]
+        fails_c = [fails_vec[slice(*bounds[c])] for c in range(parts)]
     elif online:
         rgp = ops.ReservedGP(Lop, Vw, cut(p["X"], window), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + refit_every,
                              window=window, drop=refit_every, UH=cut(p["UH"], window), Xdot=cut(p["Xdot"], window), jitter=jit0,
@@ -405,14 +410,13 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         if online and concurrent:
             drops_before = rgp.drops
             for c in range(parts):
-                sl = slice(*bounds[c])
+                oc = obs_c[c]
                 with torch.cuda.stream(streams[c]):
                     evp[t][c][0].record(streams[c])
-                    info, _, _ = rgps[c].append(obs[0][N_obs][sl], obs[1][N_obs][sl], obs[2][N_obs][sl], obs[3][N_obs][sl], query=x[sl],
-                                                out=(ws["Mk"][sl], ws["Bk"][sl]))
+                    info, _, _ = rgps[c].append(oc[0][N_obs], oc[1][N_obs], oc[2][N_obs], oc[3][N_obs], query=x_c[c], out=out_c[c])
                     evp[t][c][1].record(streams[c])
                     solves[c]()
-                    fails_vec[sl] += info != 0
+                    fails_c[c] += info != 0
             if rgp.drops != drops_before:
                 refit_steps.append(t)
         elif online:
