@@ -160,3 +160,7 @@ def test_learning_loop_two_ranks_and_through_bench_py():
     assert one["n_gpus"] == 1 and one["schedule"] == "reference" and one["parts"] == 2 and one["max_train"] == 96
     assert one["roofline"]["pass"]["bound"] == "hbm" and one["roofline"]["refit"]["bound"] == "mfma"
     assert one["final_vs_fp64_refit_on_device"]["Mk"] < 1e-8
+    assert two["schedule"] == "online_tail"                       # (the tool's default)
+    inp = _run_script(os.path.join("tools", "bench_learning_loop.py"), ["--schedule", "online", "--parts", "2"] + args, {})
+    assert inp["schedule"] == "online" and inp["parts"] == 2 and inp["append_or_refit_failures"] == 0
+    assert inp["final_vs_fp64_refit_on_device"]["Mk"] < 1e-8 and inp["final_vs_fp64_refit_on_device"]["Bk"] < 1e-8

@@ -467,6 +467,46 @@ def test_window_with_row_major_tail_vs_oracle_and_vs_in_place_appends(ops, dtype
                        UH=cut(p["UH"], W), Xdot=cut(p["Xdot"], W), jitter=jit0, tail=True)
 
 
+@pytest.mark.parametrize("n,m,W", [(2, 1, 40), (4, 3, 70), (3, 2, 250)], ids=["pendulum-n2m1", "n4m3", "unicycle-8-blocks"])
+def test_row_major_tail_other_shapes_vs_in_place_appends(ops, n, m, W):
+    """The tail step at the other compiled shapes (C + 1 = 3 and 5 right-hand-side columns; a window of 8 diagonal blocks, where the
+    streaming pass runs its B-side-only loop): every step's posterior and info equal the in-place form's on the same observations, fp64
+    to 1e-9, through one window refit; and the entry point refuses what it cannot hold."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    from bayesian_cbf_amd._lib import lib
+    Bt, D, dtype = 5, 12, torch.float64
+    p = make_instances(Bt, W + D + 6, n, m, dtype=dtype, device=DEV, seed=100 + n)
+    cut = lambda t, N: t[:, :N].contiguous()
+    jit0 = cut(p["jitter"], W)
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], W), cut(p["UH"], W), p["Bm"], p["ell"], p["s2"], jit0)
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], W), cut(p["UH"], W), p["M0"], want_alpha=False)
+    mk = lambda tail: ops.ReservedGP(Lop, Vw, cut(p["X"], W), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D,
+                                     UH=cut(p["UH"], W), Xdot=cut(p["Xdot"], W), jitter=jit0, tail=tail)
+    gt, gi = mk(True), mk(False)
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    for t in range(D + 5):
+        N = W + t
+        row = lambda k: p[k][:, N].contiguous()
+        xq = (p["xq"] + 0.02 * t).contiguous()
+        it, Mt, Bt_ = gt.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq)
+        ii, Mi, Bi = gi.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq)
+        assert it.cpu().tolist() == ii.cpu().tolist() == [0] * Bt
+        rel_close(host(Mt), host(Mi), 1e-9, scale=max(1.0, float(Mi.abs().max())), what="Mk tail vs in place n=%d m=%d" % (n, m))
+        rel_close(host(Bt_), host(Bi), 1e-9, scale=prior, what="Bk tail vs in place n=%d m=%d" % (n, m))
+    assert gt.drops == 1 and gt.t == 5 and gt.N == gi.N == W + 5
+    # refusals: a tail beyond its capacity, an operator laid out for fewer points than it is said to hold
+    f = lambda *a: getattr(lib, "bcbf_gp_tail_step_f64")(*a)
+    P = ops._p
+    args = lambda t, tcap, Lcap: (P(gt.Lop), P(gt.Vw), P(gt.X), P(gt.UHB), P(gt.ell), P(gt.s2), P(gt.Bm), P(gt.M0), P(xq), P(xq), P(gt._ones),
+                                  P(row("Xdot")), None, P(gt._Rb), P(gt._Rinv), P(gt.info), P(gt._Wfull), P(gt._sw), P(Mt), P(Bt_), None, None, None,
+                                  Bt, gt.N0, t, tcap, gt.capacity, Lcap, n, m, 1, None)
+    assert f(*args(gt._tcap, gt._tcap, gt._Lcap)) != 0              # no room for one more row
+    assert f(*args(0, 65, gt._Lcap)) != 0                            # tcap beyond what the kernel holds
+    assert f(*args(0, gt._tcap, gt.N0 - 1)) != 0                     # operator smaller than the window
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
     """Reserved storage holds the same GP as the packed layout: queries agree bit for bit with `posterior_step` on the

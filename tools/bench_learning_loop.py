@@ -2,9 +2,9 @@
 """The learning closed loop at BASELINE configs[2] scale (the reference's real workload,
 unicycle_move_to_pose.py:340-386): `--batch` independent control loops PER GPU, each with its own GP over its most recent
 observations (at most `--max-train`); every step = one control step + one new observation per instance, every
-`--refit-every`-th step the window is refactored.  `--schedule online` (default; the posterior query and the in-place append
-share one pass over the factor), `online_tail` (the same, the points since the last window refit kept as contiguous rows beside the
-window's factor: `bcbf_gp_tail_step`) or `reference` (static GP between refits, the headline control step).
+`--refit-every`-th step the window is refactored.  `--schedule online_tail` (default: the posterior query and the new observation's
+column share one pass over the window's factor, the points since the last window refit are contiguous rows beside it:
+`bcbf_gp_tail_step`), `online` (the same with in-place appends into the operator) or `reference` (static GP between refits, the headline control step).
 
     python tools/bench_learning_loop.py                          # 4096 x 512, fp32, 200 timed steps, refit every 40
     python tools/bench_learning_loop.py --gpus 8                 # starts its 8 ranks itself (weak scaling, no collective in the loop)
@@ -26,7 +26,7 @@ ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--warmup", type=int, default=40)
 ap.add_argument("--refit-every", type=int, default=40)
 ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-ap.add_argument("--schedule", choices=["online", "online_tail", "reference"], default="online")
+ap.add_argument("--schedule", choices=["online", "online_tail", "reference"], default="online_tail")
 ap.add_argument("--parts", type=int, default=1, help="part batches on their own streams (reference schedule: 4 is bench.py's default; online schedules: 2 -- more are host-bound)")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):

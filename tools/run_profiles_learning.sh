@@ -7,10 +7,10 @@ O=gpurun_out/$R
 mkdir -p $O
 python tools/bench_learning_loop.py --schedule reference --parts 4 2>/dev/null > $O/learn_reference_parts4.json
 python tools/bench_learning_loop.py --schedule reference 2>/dev/null > $O/learn_reference.json
-python tools/bench_learning_loop.py 2>/dev/null > $O/learn_online.json
+python tools/bench_learning_loop.py --schedule online 2>/dev/null > $O/learn_online.json
 python tools/bench_learning_loop.py --schedule online_tail 2>/dev/null > $O/learn_online_tail.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_reference -- python3 tools/bench_learning_loop.py --schedule reference --steps 80 --warmup 40 > $O/learn_reference_prof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online -- python3 tools/bench_learning_loop.py --steps 80 --warmup 40 > $O/learn_online_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online -- python3 tools/bench_learning_loop.py --schedule online --steps 80 --warmup 40 > $O/learn_online_prof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online_tail -- python3 tools/bench_learning_loop.py --schedule online_tail --steps 80 --warmup 40 > $O/learn_online_tail_prof.json 2>/dev/null
 bash tools/run_pmc_append_traffic.sh $R > /dev/null 2>&1
 python tools/bench_online.py --repeat 3 2>/dev/null > $O/online_growth_f64.json
