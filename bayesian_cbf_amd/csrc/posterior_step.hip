@@ -102,6 +102,16 @@ using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned;
 using u32x2 = __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned;
 constexpr int OOB = 0x40000000;   // > any operator size; voffset + soffset stays below 2^31
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire over EVERY address space:
+// hipcc waits for all outstanding global loads (s_waitcnt vmcnt(0)) in front of each barrier -- in this kernel that drained the loads
+// of the next column group and the next diagonal block, which are issued a block ahead precisely so that they fly across the block's
+// two barriers.  Nothing here passes data between threads through global memory; the threads meet in rbuf / wbuf only.
+__device__ inline void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <typename T> struct BufLoad;
 template <> struct BufLoad<float> {
     static __device__ inline float4 vec(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -499,7 +509,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                     for (int c = 0; c < CT; ++c) rbuf[rb * V + v - row0][c] = BCBF_ACC(r, v, c);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // 2. diagonal block: w_J = inv(L_JJ) r_J  (wave 0; lane = (row di, column half dh))
         if (tid < 64) {
             T w[CT];
@@ -583,7 +593,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if constexpr (MG) {
             // 2b. Gram and mean sums of the block on the matrix cores: with T_J = [w_J, Vw_J, 0] (32 x 16, in wbuf),
             // gacc += T_J' T_J -- rows / columns < CT: the Gram Wj'Wj, rows CT .. CT+n-1: Vw'Wj.  A and B operand of
@@ -636,7 +646,7 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
 
     if constexpr (XC > 0) {
         // the append's column (and, for the tail step, every solved column): LDS -> memory, 16 bytes per lane, nothing waits for it
-        __syncthreads();
+        lds_barrier();
         using VecT_ = typename Vec<T>::type;
         if (Wout != nullptr)
             for (int i = tid; i < Np / V; i += blockDim.x)
@@ -659,9 +669,9 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        __syncthreads();
+                        lds_barrier();
                         if (tid >= 64) red[tid] = gacc[ti][tj][r];
-                        __syncthreads();
+                        lds_barrier();
                         if (tid < 64) {
                             T sum = gacc[ti][tj][r];
                             for (int w_ = 1; w_ < nw; ++w_) sum += red[w_ * 64 + tid];
