@@ -565,7 +565,9 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
     __syncthreads();                                            // lrow complete for every thread
     const int Js = N / NB, col0 = Js * NB, rr = N - col0;
     if (ok) {
-        for (int j = tid; j < col0; j += ST) lop[lop_base<V>(j, Nl) + N] = lrow[j];
+        // (non-temporal: one element per 128-byte line of every column -- written through instead of left dirty in L2, where the
+        //  partial lines drained while the NEXT streaming pass ran and cost it far more than their bytes)
+        for (int j = tid; j < col0; j += ST) __builtin_nontemporal_store(lrow[j], &lop[lop_base<V>(j, Nl) + N]);
         if (tid <= rr) {
             const int jj = tid;                                 // column inside the diagonal block
             T val;
