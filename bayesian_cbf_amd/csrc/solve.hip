@@ -577,8 +577,8 @@ gp_append_inplace_kernel(T* __restrict__ Lop, T* __restrict__ Vw, T* __restrict_
                 for (int ii = jj; ii < rr; ++ii) a2 += lrow[col0 + ii] * dinv_s[lop_dinv_col(jj) + ii];
                 val = -a2 / d;
             }
-            lop[lop_dinv(Js, rr, jj, Nl)] = val;
-            lop[lop_dfull(Js, rr, jj, Nl)] = val;
+            __builtin_nontemporal_store(val, &lop[lop_dinv(Js, rr, jj, Nl)]);
+            __builtin_nontemporal_store(val, &lop[lop_dfull(Js, rr, jj, Nl)]);      // (a row of a column-major tile: 32 lines)
         }
     }
     if (tid < n) {

@@ -222,7 +222,7 @@ gp_tail_step_kernel(const T* __restrict__ W0, T* __restrict__ Rb, T* __restrict_
     const int N = N0 + t;
     if (tid == 0) info[b] = ok ? 0 : N + 1;
     T* nrow = Rbb + (size_t)t * ldR;
-    for (int j = tid; j < N0; j += TT) nrow[j] = ok ? Wl[j * CT + C] : T(0);
+    for (int j = tid; j < N0; j += TT) __builtin_nontemporal_store(ok ? Wl[j * CT + C] : T(0), &nrow[j]);     // (read next by another step's kernel, from memory)
     if (tid <= t) {
         T val;
         if (tid == t) val = ok ? T(1) / dv : T(1);
