@@ -28,7 +28,7 @@ constexpr int TT = 256;                 // threads per instance
 constexpr int TMAXT = 64;               // tail rows held in LDS
 
 template <typename T> __device__ inline T tail_exp(T x);
-template <> __device__ inline float tail_exp<float>(float x) { return __expf(x); }
+template <> __device__ inline float tail_exp<float>(float x) { return expf(x); }        // (as the streaming pass: the tail rows are rows of the same solve)
 template <> __device__ inline double tail_exp<double>(double x) { return exp(x); }
 
 // global -> LDS, count elements, 8 independent loads in flight per thread (a plain copy loop waits out one round trip per element)
