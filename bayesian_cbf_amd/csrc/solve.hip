@@ -237,14 +237,28 @@ template <typename T>
 __device__ inline void relayout_operator(const T* __restrict__ lin, T* __restrict__ lout, int NpI, int NpO, int tid) {
     constexpr int V = Vec<T>::V;
     // off-diagonal part: column j keeps its rows below its diagonal block; rows / columns of the new padding are zero
-    for (int j = 0; j < NpO; ++j) {
-        const int first = (j / NB + 1) * NB;
-        const int bo = lop_base<V>(j, NpO);
-        if (j < NpI) {
-            const int bi = lop_base<V>(j, NpI);
-            for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = i < NpI ? lin[bi + i] : T(0);
-        } else {
-            for (int i = first + tid; i < NpO; i += ST) lout[bo + i] = T(0);
+    // (16-byte vectors -- every column starts on a 128-byte line and NpI, NpO, `first` are multiples of 32 --, four columns per trip so
+    //  that a thread has four loads in flight: one 4-byte element of one column per trip moved 4.2 GB in 1.3 ms at 4096 x 512)
+    using VT = typename Vec<T>::type;
+    for (int j0 = 0; j0 < NpO; j0 += 4) {
+        VT v[4];
+        int io[4], bo[4];
+        bool ok[4];
+        const int first = (j0 / NB + 1) * NB;                   // (j0 .. j0 + 3 lie in one block column: NB is a multiple of 4)
+        const int nv = (NpO - first) / V;                        // vectors per column of this block column
+        for (int k0 = 0; k0 < nv; k0 += ST) {
+            const int k = k0 + tid;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u, i = first + k * V;
+                ok[u] = k < nv;
+                io[u] = i;
+                bo[u] = lop_base<V>(j, NpO);
+                v[u] = (ok[u] && j < NpI && i < NpI) ? *reinterpret_cast<const VT*>(lin + lop_base<V>(j, NpI) + i) : VT{};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) *reinterpret_cast<VT*>(lout + bo[u] + io[u]) = v[u];
         }
     }
     // inverted diagonal blocks: copied; a new padding block is the identity
