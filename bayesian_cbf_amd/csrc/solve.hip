@@ -396,7 +396,7 @@ chol_append_kernel(const T* Lin, const T* __restrict__ knew, const T* __restrict
     // was (in place) or has just become (re-packed), so the operator still describes the old N points exactly and
     // the caller can retry with a larger jitter (make_psd's schedule, control_affine_model.py:905-919)
     const int Js = N / NB, col0 = Js * NB, rr = N - col0;
-    if (ok) for (int j = tid; j < col0; j += ST) lout[lop_base<V>(j, NpO) + N] = lrow[j];
+    if (ok) for (int j = tid; j < col0; j += ST) __builtin_nontemporal_store(lrow[j], &lout[lop_base<V>(j, NpO) + N]);   // (one element per line: see gp_append_inplace_kernel)
     if (ok && tid <= rr) {
         const int jj = tid;          // column inside the diagonal block
         T val;
