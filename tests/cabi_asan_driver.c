@@ -39,6 +39,7 @@ int main(void) {
     EXPECT(bcbf_posterior_query_matern52_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_query_reserved_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_gp_append_reserved_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 16, 3, 2, 0), BCBF_OK);
+    EXPECT(bcbf_gp_tail_step_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 8, 16, 16, 3, 2, 1, 0), BCBF_OK);
     EXPECT(bcbf_posterior_step_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_query_f64(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 8, 3, 2, 0), BCBF_OK);
     EXPECT(bcbf_posterior_shared_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 3, 2, 0), BCBF_OK);
@@ -67,6 +68,10 @@ int main(void) {
     EXPECT(bcbf_gp_append_reserved_f64(d, d, d, d, d, d, d, d, d, d, d, 0, i, d, d, d, 0, 0, 0, 1, 16, 16, 3, 2, 0), BCBF_EINVAL);  /* full */
     EXPECT(bcbf_gp_append_reserved_f64(d, d, d, d, d, d, d, d, d, d, d, 0, i, d, d, d, d, 0, 0, 1, 8, 16, 3, 2, 0), BCBF_EINVAL);   /* xq without Mk */
     EXPECT(bcbf_posterior_query_reserved_f64(d, d, d, d, d, d, d, d, d, 0, d, d, 0, 1, 16, 8, 3, 2, 0), BCBF_EINVAL);     /* Ncap < N */
+    EXPECT(bcbf_gp_tail_step_f64(d, d, d, d, d, d, d, d, d, d, d, d, 0, d, d, i, d, d, d, d, 0, 0, 0, 1, 8, 8, 8, 32, 32, 3, 2, 1, 0), BCBF_EINVAL);   /* the tail is full */
+    EXPECT(bcbf_gp_tail_step_f64(d, d, d, d, d, d, d, d, d, d, d, d, 0, d, d, i, d, d, d, d, 0, 0, 0, 1, 8, 0, 65, 128, 128, 3, 2, 1, 0), BCBF_EINVAL); /* tcap > 64 */
+    EXPECT(bcbf_gp_tail_step_f64(d, d, d, d, d, d, d, d, d, d, d, d, 0, d, d, i, d, d, d, d, 0, 0, 0, 1, 8, 0, 8, 32, 4, 3, 2, 1, 0), BCBF_EINVAL);    /* operator laid out for fewer points than it holds */
+    EXPECT(bcbf_gp_tail_step_f64(d, d, d, d, d, d, d, d, d, d, d, d, 0, d, d, i, d, d, d, d, d, 0, 0, 1, 8, 0, 8, 32, 32, 3, 2, 1, 0), BCBF_EINVAL);   /* one raw store without the others */
     {   /* the row-count helper is pure host logic */
         int kinds[4] = {1, 2, 0, 1};
         EXPECT(bcbf_controller_cones_rows(kinds, 4, 2, 1) == 1 + 4 + 3 * 4 ? 0 : 1, 0);
