@@ -18,6 +18,8 @@ Exact class draws a second b(1+m)-vector per covariance prediction, :1089); pass
 """
 from functools import partial
 
+from collections import OrderedDict
+
 import numpy as np
 import math
 
@@ -257,19 +259,88 @@ class ControlAffineRegressor:
         self.clear_cache()
         return self
 
-    def state_dict(self):
-        return dict(model=self.model.state_dict(), train=(self.Xtrain, self.Utrain, self.XdotTrain))
+    # ---- checkpoint: the reference's layout (ControlAffineRegressor.state_dict, control_affine_model.py:862-874, over
+    # ControlAffineExactGP.state_dict, :201-218).  `model` holds matshape, decoder, mean_module, task_covar, input_covar,
+    # covar_module (gpytorch parameter names), train_inputs = (MXU,), train_targets = vec(Xdot); `likelihood` is the
+    # (parameter-free) IdentityLikelihood.  Two additions the reference's loader ignores: `mean_module["base_means"]` --
+    # the reference's HetergeneousMatrixVariateMean.state_dict (matrix_variate_multitask_model.py:68-76) drops the prior-mean
+    # constants, so its own checkpoints lose them -- and a top-level `bcbf` dict (data-kernel kind of the opt-in kernels).
+    _REF_PARAM_NAMES = (      # (attribute of the parameter container, key in task_covar / input_covar)
+        ("task_covar", "U.covar_factor", "A_covar_factor"), ("task_covar", "U.raw_var", "A_raw_var"),
+        ("task_covar", "V.covar_factor", "B_covar_factor"), ("task_covar", "V.raw_var", "B_raw_var"),
+        ("input_covar", "raw_outputscale", "raw_outputscale"),
+        ("input_covar", "base_kernel.raw_lengthscale", "raw_lengthscale"))
 
-    def load_state_dict(self, sd):
-        self.model.load_state_dict(sd["model"])
-        self.Xtrain, self.Utrain, self.XdotTrain = sd["train"]
-        self.clear_cache()
+    def state_dict(self):
+        m = self.model
+        mods = dict(task_covar=OrderedDict(), input_covar=OrderedDict())
+        for mod, key, attr in self._REF_PARAM_NAMES:
+            mods[mod][key] = getattr(m, attr).detach().clone()
+        covar = OrderedDict([("task_covar_module." + k, v) for k, v in mods["task_covar"].items()]
+                            + [("data_covar_module." + k, v) for k, v in mods["input_covar"].items()])
+        consts = m.mean_constants.detach().clone()
+        mean = dict(matshape=tuple(self.matshape), decoder=self.decoder.state_dict(),
+                    base_means=OrderedDict(("%d.constant" % i, consts[i:i + 1]) for i in range(consts.numel())))
+        detach = lambda t: None if t is None else t.detach().clone()
+        ti = self.train_inputs
+        model = dict(matshape=tuple(self.matshape), decoder=self.decoder.state_dict(), mean_module=mean,
+                     task_covar=mods["task_covar"], input_covar=mods["input_covar"], covar_module=covar,
+                     train_inputs=None if ti is None else (detach(ti[0]),), train_targets=detach(self.train_targets))
+        return dict(model=model, likelihood=OrderedDict(), bcbf=dict(layout=2, data_kernel=self.data_kernel))
+
+    def load_state_dict(self, state_dict):
+        """Accepts the reference's layout (a pickle its `save` wrote -- also one from real gpytorch, whose modules add
+        constraint buffers: keys this container has no use for are skipped) and this package's round-1..5 layout
+        `dict(model=<container state>, train=(X, U, Xdot))`.  The argument is not modified (the reference's loader pops)."""
+        sd = state_dict
+        if "train" in sd:                                        # layout of rounds 1-5
+            self.model.load_state_dict(sd["model"])
+            self.Xtrain, self.Utrain, self.XdotTrain = sd["train"]
+            self.clear_cache(hyper=True)
+            return self
+        ms = sd["model"]
+        if tuple(ms["matshape"]) != tuple(self.matshape):
+            raise ValueError("checkpoint matshape %s, model %s" % (tuple(ms["matshape"]), tuple(self.matshape)))
+        kind = sd.get("bcbf", {}).get("data_kernel", "rbf")
+        if kind != self.data_kernel:
+            raise ValueError("checkpoint of data kernel %r loaded into a %r model" % (kind, self.data_kernel))
+        self.decoder.load_state_dict(ms["decoder"])
+        m = self.model
+        with torch.no_grad():
+            prefix = dict(task_covar="task_covar_module.", input_covar="data_covar_module.")
+            for mod, key, attr in self._REF_PARAM_NAMES:
+                if key in ms.get(mod, ()):
+                    val = ms[mod][key]
+                else:                                             # (the same tensors, as the covar_module holds them)
+                    val = ms["covar_module"][prefix[mod] + key]
+                par = getattr(m, attr)
+                if tuple(val.shape) != tuple(par.shape):          # (an IndexKernel of another rank)
+                    setattr(m, attr, torch.nn.Parameter(torch.empty(val.shape, dtype=par.dtype, device=par.device)))
+                    par = getattr(m, attr)
+                par.copy_(val.to(par))
+            bm = ms.get("mean_module", {}).get("base_means")
+            if bm is not None:       # (absent from the reference's own files: constants stay as they are, as in the reference)
+                for k, v in bm.items():
+                    i, name = k.split(".", 1)
+                    if name in ("constant", "raw_constant"):
+                        m.mean_constants[int(i)] = v.reshape(()).to(m.mean_constants)
+        ti, tt = ms.get("train_inputs"), ms.get("train_targets")
+        if ti is not None and tt is not None:
+            _, X, UH = self.decoder.decode(ti[0])
+            self.Xtrain = self._ensure_device_dtype(X).contiguous()
+            self.Utrain = self._ensure_device_dtype(UH[..., 1:]).contiguous()
+            self.XdotTrain = self._ensure_device_dtype(tt).reshape(-1, self.x_dim).contiguous()
+        else:
+            self.Xtrain = self.Utrain = self.XdotTrain = None
+        self.clear_cache(hyper=True)
+        return self
 
     def save(self, path="/tmp/saved.pickle"):
         torch.save(self.state_dict(), path)
 
     def load(self, path="/tmp/saved.pickle"):
-        self.load_state_dict(torch.load(path))
+        # (plain containers and tensors only: the default safe unpickler reads it)
+        self.load_state_dict(torch.load(path, map_location=self.device))
 
     # ---------------------------------------------------------------- training data
     def encode_from_XU(self, Xtrain, Utrain=None, M=0):
@@ -963,6 +1034,12 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         if (1 + u_dim) * x_dim > 12:
             raise NotImplementedError("the CoGP comparator takes (1+m) n <= 12 task outputs (BCBF_MAX_TASK_DIM)")
         self.model = VectorKernelParams(x_dim, u_dim, rank=rank, dtype=dtype).to(self.device)
+
+    _REF_PARAM_NAMES = (      # ControlAffineVectorGP's modules (:1106-1126): one IndexKernel, ScaleKernel(RBF + Linear)
+        ("task_covar", "covar_factor", "task_covar_factor"), ("task_covar", "raw_var", "task_raw_var"),
+        ("input_covar", "raw_outputscale", "raw_outputscale"),
+        ("input_covar", "base_kernel.kernels.0.raw_lengthscale", "raw_lengthscale"),
+        ("input_covar", "base_kernel.kernels.1.raw_variance", "raw_variance"))
 
     def get_kernel_param(self, name):
         if name == "Sigma":

@@ -828,7 +828,58 @@ def gen_facade():
     print('facade_surfaces:', {k: v.shape for k, v in out.items() if hasattr(v, 'shape')})
 
 
+def gen_checkpoint():
+    """The reference's checkpoint layout (ControlAffineRegressor.save / state_dict, control_affine_model.py:862-874 over
+    ControlAffineExactGP.state_dict, :201-218), written by the executed reference:
+      reference_checkpoint_n3m2_N24.pt    the pickle `reg.save(path)` wrote (plain dicts / OrderedDicts of tensors)
+      reference_checkpoint_n3m2_N24.npz   what a FRESH reference regressor predicts after `load(path)` (its loader leaves the
+                                          prior-mean constants at their initial zeros: the mean module's state_dict drops
+                                          them, matrix_variate_multitask_model.py:68-76), what the SAVING regressor predicts
+                                          (constants recorded beside it), and the recorded jitter draws of both.
+    Vector-variate comparator: reference_checkpoint_vector_n2m1_N10.{pt,npz} the same way."""
+    for tag, cls, n, m, N, seed in (("n3m2_N24", cam.ControlAffineRegressor, 3, 2, 24, 31),
+                                    ("vector_n2m1_N10", cam.ControlAffineRegressorVector, 2, 1, 10, 32)):
+        if cls is cam.ControlAffineRegressorVector:
+            torch.manual_seed(seed)
+            reg = cls(n, m, device='cpu')
+            with torch.no_grad():
+                rbf, linear = reg.model.input_covar.base_kernel.kernels
+                rbf.raw_lengthscale.copy_(0.3 * torch.randn(1, 1))
+                linear.raw_variance.copy_(0.3 * torch.randn(1, 1) - 2.0)
+                reg.model.input_covar.raw_outputscale.copy_(0.3 * torch.randn(()))
+                for bm in reg.model.mean_module.base_means:
+                    bm.constant.copy_(0.2 * torch.randn(1))
+            X, U = 1.5 * (2 * torch.rand(N, n) - 1), torch.randn(N, m)
+            Xdot = torch.sin(X @ torch.randn(n, n).t()) + 0.5 * torch.cos(X) * U + 1e-3 * torch.randn(N, n)
+            reg.model.set_train_data(X, U, Xdot)
+        else:
+            reg, X, U, Xdot = make_regressor(cls, n, m, N, seed)
+        path = os.path.join(HERE, "reference_checkpoint_%s.pt" % tag)
+        reg.save(path)
+        consts = np.array([float(bm.constant.detach()) for bm in reg.model.mean_module.base_means])
+        torch.manual_seed(seed + 1)
+        Xtest = 1.2 * (2 * torch.rand(5, n) - 1)
+        Utest = torch.randn(5, m)
+        out = dict(Xtest=t2n(Xtest), Utest=t2n(Utest), mean_constants=consts, X=t2n(X), U=t2n(U), Xdot=t2n(Xdot))
+        with RandRecorder() as rr:
+            mean, cov = reg.custom_predict(Xtest, Utest)
+        out.update(saver_mean=t2n(mean), saver_cov=t2n(cov), saver_draws=np.stack(rr.draws))
+        fresh = cls(n, m, device='cpu')
+        fresh.load(path)
+        sd = fresh.state_dict()
+        assert torch.equal(sd['model']['train_targets'], Xdot.reshape(-1))
+        with RandRecorder() as rr:
+            mean, cov = fresh.custom_predict(Xtest, Utest)
+        out.update(loaded_mean=t2n(mean), loaded_cov=t2n(cov), loaded_draws=np.stack(rr.draws))
+        np.savez_compressed(os.path.join(HERE, "reference_checkpoint_%s.npz" % tag), **out)
+        print("reference_checkpoint_%s:" % tag, sorted(torch.load(path)['model']), "constants lost on load:",
+              bool(np.abs(out['saver_mean'] - out['loaded_mean']).max() > 1e-6))
+
+
 if __name__ == '__main__':
+    if 'checkpoint' in sys.argv:
+        gen_checkpoint()
+        sys.exit(0)
     if 'facade' in sys.argv:
         gen_facade()
     elif 'eigfired' in sys.argv:

@@ -227,3 +227,95 @@ def test_every_data_kernel_has_every_entry_point_the_wrappers_ask_for():
                 name = base + ops._KSUF[kernel] + suf
                 assert name in declared and hasattr(_lib.lib, name), name
     assert ops.DATA_KERNELS.index("rbf") == 0 and ops.DATA_KERNELS.index("matern52") == 1 and ops.DATA_KERNELS.index("rbf_matern52") == 2
+
+
+# ---- checkpoint layout (ControlAffineRegressor.state_dict / save / load, control_affine_model.py:201-218, 862-874):
+# the pickles were written by the executed reference's `save` (tests/golden/gen_golden.py checkpoint)
+CKPT = [("n3m2_N24", "ControlAffineRegressor", 3, 2), ("vector_n2m1_N10", "ControlAffineRegressorVector", 2, 1)]
+REF_MODEL_KEYS = ["matshape", "decoder", "mean_module", "task_covar", "input_covar", "covar_module", "train_inputs",
+                  "train_targets"]
+
+
+def _ckpt(tag):
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    return os.path.join(here, "reference_checkpoint_%s.pt" % tag), np.load(os.path.join(here, "reference_checkpoint_%s.npz" % tag))
+
+
+@pytest.mark.parametrize("tag,cls,n,m", CKPT)
+def test_reference_checkpoint_loads_and_is_rewritten_key_for_key(tag, cls, n, m, tmp_path):
+    import bayesian_cbf_amd.control_affine_model as cam
+    path, g = _ckpt(tag)
+    ref = torch.load(path)
+    reg = getattr(cam, cls)(n, m, device="cpu", dtype=torch.float64)
+    with torch.no_grad():
+        reg.model.mean_constants.fill_(0.25)
+    reg.load(path)
+    np.testing.assert_array_equal(reg.Xtrain.numpy(), g["X"])
+    np.testing.assert_array_equal(reg.Utrain.numpy(), g["U"])
+    np.testing.assert_array_equal(reg.XdotTrain.numpy(), g["Xdot"])
+    # the reference's file carries no prior-mean constants: they stay what they were (as in the reference's loader)
+    assert float((reg.model.mean_constants - 0.25).abs().max()) == 0
+    sd = reg.state_dict()
+    assert list(sd["model"]) == REF_MODEL_KEYS and list(ref["model"]) == REF_MODEL_KEYS
+    assert sorted(sd)[:2] == ["bcbf", "likelihood"] and "model" in sd and len(sd["likelihood"]) == 0 == len(ref["likelihood"])
+    for mod in ("task_covar", "input_covar", "covar_module"):
+        assert list(sd["model"][mod]) == list(ref["model"][mod]), mod
+        for k in ref["model"][mod]:
+            assert torch.equal(sd["model"][mod][k], ref["model"][mod][k]), (mod, k)
+    assert sd["model"]["matshape"] == ref["model"]["matshape"] and sd["model"]["decoder"] == ref["model"]["decoder"]
+    assert {k: sd["model"]["mean_module"][k] for k in ("matshape", "decoder")} == ref["model"]["mean_module"]
+    assert torch.equal(sd["model"]["train_inputs"][0], ref["model"]["train_inputs"][0])
+    assert torch.equal(sd["model"]["train_targets"], ref["model"]["train_targets"])
+    # save -> load round trip of the façade's own file keeps the constants too
+    p2 = str(tmp_path / "saved.pickle")
+    reg.save(p2)
+    reg2 = getattr(cam, cls)(n, m, device="cpu", dtype=torch.float64)
+    reg2.load(p2)
+    for (k, a), (k2, b) in zip(reg.model.state_dict().items(), reg2.model.state_dict().items()):
+        assert k == k2 and torch.equal(a, b), k
+    assert torch.equal(reg2.Xtrain, reg.Xtrain) and torch.equal(reg2.Utrain, reg.Utrain) and torch.equal(reg2.XdotTrain, reg.XdotTrain)
+    # the layout of rounds 1-5 still loads
+    reg3 = getattr(cam, cls)(n, m, device="cpu", dtype=torch.float64)
+    reg3.load_state_dict(dict(model=reg.model.state_dict(), train=(reg.Xtrain, reg.Utrain, reg.XdotTrain)))
+    assert torch.equal(reg3.model.mean_constants, reg.model.mean_constants) and torch.equal(reg3.Xtrain, reg.Xtrain)
+    # a model of another shape or data kernel refuses the file
+    with pytest.raises(ValueError):
+        getattr(cam, cls)(n + 1, m, device="cpu", dtype=torch.float64).load(path)
+    if cls == "ControlAffineRegressor":
+        with pytest.raises(ValueError):
+            cam.ControlAffineRegressor(n, m, device="cpu", dtype=torch.float64, data_kernel="matern52").load(p2)
+
+
+def test_facade_checkpoint_loads_into_the_executed_reference(tmp_path):
+    """Container-only (needs /root/reference): a file the façade's `save` wrote goes through the reference's own
+    `load_state_dict`.  The reference runs in a child process (its harness patches torch for the old API it expects)."""
+    import subprocess
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if not os.path.isdir("/root/reference/bayes_cbf"):
+        pytest.skip("reference tree not present")
+    import bayesian_cbf_amd.control_affine_model as cam
+    path, g = _ckpt("n3m2_N24")
+    reg = cam.ControlAffineRegressor(3, 2, device="cpu", dtype=torch.float64)
+    reg.load(path)
+    p2 = str(tmp_path / "saved.pickle")
+    reg.save(p2)
+    child = """
+import sys, torch
+sys.path.insert(0, %r)
+import _refenv
+_refenv.setup()
+torch.set_default_dtype(torch.float64)
+import bayes_cbf.control_affine_model as rcam
+ref = rcam.ControlAffineRegressor(3, 2, device="cpu")
+ref.load_state_dict(torch.load(%r))
+want = torch.load(%r)["model"]
+got = ref.state_dict()["model"]
+for mod in ("task_covar", "input_covar", "covar_module"):
+    for k in want[mod]:
+        assert torch.equal(got[mod][k], want[mod][k]), (mod, k)
+assert torch.equal(got["train_inputs"][0], want["train_inputs"][0]) and torch.equal(got["train_targets"], want["train_targets"])
+print("reference loaded the facade checkpoint")
+""" % (golden, p2, path)
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "reference loaded the facade checkpoint" in out.stdout, out.stderr[-2000:]

@@ -1455,3 +1455,37 @@ def test_speculative_jitter_levels_leave_the_sequential_random_stream(own_genera
     assert level > 1e-4, "one of the first two levels succeeded: the interesting paths did not run (%g)" % level
     for k in ("jit0", "jit1", "fm0", "fm1", "fv0", "fv1", "next"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("tag,cls,n,m", [("n3m2_N24", "ControlAffineRegressor", 3, 2),
+                                         ("vector_n2m1_N10", "ControlAffineRegressorVector", 2, 1)])
+def test_reference_checkpoint_loads_and_reproduces_custom_predict(tag, cls, n, m, tmp_path):
+    """A pickle the executed reference's `save` wrote (control_affine_model.py:862-874; layout :201-218) goes through the
+    façade's `load`; `custom_predict` then equals what a fresh reference regressor predicts after ITS `load` (1e-9; the
+    reference's file drops the prior-mean constants, so both predict with zeros), and -- with the constants restored by
+    value -- what the saving regressor predicted.  Also after a `save` / `load` round trip of the façade's own file."""
+    import bayesian_cbf_amd.control_affine_model as cam
+    path = os.path.join(GOLDEN, "reference_checkpoint_%s.pt" % tag)
+    g = np.load(os.path.join(GOLDEN, "reference_checkpoint_%s.npz" % tag))
+    reg = getattr(cam, cls)(n, m, device=DEV, dtype=torch.float64)
+    reg.load(path)
+    assert reg.Xtrain.device.type == "cuda" and reg.model.raw_outputscale.device.type == "cuda"
+    Xt, Ut = t(g["Xtest"]), t(g["Utest"])
+
+    def predict(r, draws):
+        it = iter(draws)
+        r.rand_fn = lambda k: t(next(it)[:k])
+        r.clear_cache()
+        return r.custom_predict(Xt, Ut)
+    mean, cov = predict(reg, g["loaded_draws"])
+    close(mean, g["loaded_mean"], rtol=1e-9, atol=1e-11); close(cov, g["loaded_cov"], rtol=1e-9, atol=1e-11)
+    with torch.no_grad():
+        reg.model.mean_constants.copy_(t(g["mean_constants"]))
+    mean, cov = predict(reg, g["saver_draws"])
+    close(mean, g["saver_mean"], rtol=1e-9, atol=1e-11); close(cov, g["saver_cov"], rtol=1e-9, atol=1e-11)
+    p2 = str(tmp_path / "saved.pickle")
+    reg.save(p2)
+    reg2 = getattr(cam, cls)(n, m, device=DEV, dtype=torch.float64)
+    reg2.load(p2)
+    mean, cov = predict(reg2, g["saver_draws"])
+    close(mean, g["saver_mean"], rtol=1e-9, atol=1e-11); close(cov, g["saver_cov"], rtol=1e-9, atol=1e-11)
