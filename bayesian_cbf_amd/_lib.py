@@ -30,6 +30,7 @@ _SIGS = {
     "bcbf_controller_cones_f32": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "bcbf_controller_cones_f64": (c_int, [P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "bcbf_mll_grad_work_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "bcbf_fit_param_count": (c_int, [c_int, c_int, c_int, c_int]),
     "bcbf_coneqp_f64": (c_int, [P, P, P, P, c_int, c_int, ctypes.POINTER(c_int), c_int, P, P, P, c_int, c_int, P]),
 }
 _TSIGS = {
@@ -53,6 +54,9 @@ _TSIGS = {
     "bcbf_trtri": [P, P, c_int, c_int, P],
     "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],
     "bcbf_syrk_lt": [P, P, c_int, c_int, P],
+    "bcbf_fit_derive": [P] * 8 + [c_int] * 5 + [P],
+    "bcbf_fit_adam_step": [P] * 14 + [c_int] * 7 + [c_double] * 4 + [ctypes.POINTER(c_double), P],
+    "bcbf_kinv_apply": [P, P, P, c_int, c_int, c_int, P],
     "bcbf_kb_build_rbflin": [P] * 8 + [c_int, c_int, c_int, c_int, P],
     "bcbf_posterior_query_rbflin": [P] * 14 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_mll_grad_rbflin": [P] * 18 + [c_int, c_int, c_int, c_int, c_int, P, P],

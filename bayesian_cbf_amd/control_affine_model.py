@@ -133,6 +133,7 @@ class ControlAffineRegressor:
         # order; tests replace it to replay recorded draws
         self.rand_fn = lambda k: torch.rand(k, dtype=self.dtype, device=self.device, generator=self.generator)
         self._default_rand_fn = self.rand_fn
+        self.target_rand_fn = torch.rand_like      # the fit's 1 + 1e-6 rand target perturbation (:318-321), same hook idea
         self.Xtrain = self.Utrain = self.XdotTrain = None
         self._cache = dict()
         self._derived = dict()       # host-side constants that survive clear_cache(): keyed by what they were derived from
@@ -466,7 +467,7 @@ class ControlAffineRegressor:
         N, n = self.Xtrain.shape
         Y = self.XdotTrain
         if perturb_targets:
-            Y = Y * (1 + 1e-6 * torch.rand_like(Y))                                # :318-321
+            Y = Y * (1 + 1e-6 * self.target_rand_fn(Y))                            # :318-321
         Y = Y.to(wd)[None].contiguous()
         # jitter schedule of make_psd (1e-5 rand, x10 on a failed pivot).  Inside one fit() an iteration starts ONE level
         # below the level that last worked, never below 1e-5 (`_fit_jitter`): in fp32 the first level fails at every
@@ -486,7 +487,7 @@ class ControlAffineRegressor:
             self._fit_jitter = factor
         R = (Y - UH @ hp["M0"]).contiguous()
         Kinv = ops.kb_inverse(Lop, N)
-        alpha = (Kinv @ R).contiguous()          # K_b^-1 R from the inverse the gradient needs anyway (the two triangular
+        alpha = ops.kinv_apply(Kinv, R)          # K_b^-1 R from the inverse the gradient needs anyway (the two triangular
                                                  # solves of bcbf_potrs on one workgroup were a third of an iteration)
         Ad = hp["A"][0]
         # n x n (n <= 8) inverse and log-determinant on the host: not worth pulling the device solver library in
@@ -1240,7 +1241,7 @@ class ControlAffineRegressorVector(ControlAffineRegressor):
         if getattr(self, "_fit_jitter", None) is not None:
             self._fit_jitter = factor
         Kinv = ops.kb_inverse(Lop, Ne)
-        alpha = (Kinv @ Ye).contiguous()
+        alpha = ops.kinv_apply(Kinv, Ye.contiguous())
         one = Xe.new_ones(1, 1, 1)
         g_ell, g_s2, g_B, logdetK, RtA, UHtA, g_lin = ops.mll_grad(Lop, alpha, Kinv, Xe[None], UHe[None], Ye, one, hp["Bm"],
                                                                     hp["ell"], hp["s2"], lin=hp["lin"])

@@ -260,11 +260,14 @@ class ReservedGP:
         if self.tail:
             if self.window is None:
                 raise ValueError("tail=True is a form of the sliding window: pass window=...")
-            if self.window + self.drop - self.N > self.TAIL_MAX or self.n > 4:
-                raise ValueError("tail=True holds at most %d points between two window refits (and n <= 4)" % self.TAIL_MAX)
+            # rows the tail must hold: until the first window refit window + drop - N_init of them, `drop` after every refit
+            # (N0 = window, t = 0 there) -- whichever is larger (N_init > window makes the first period the shorter one)
+            self._tcap = max(self.drop, self.window + self.drop - self.N)
+            if self._tcap > self.TAIL_MAX or self.n > 4:
+                raise ValueError("tail=True holds at most %d points between two window refits (needs %d here) and n <= 4"
+                                 % (self.TAIL_MAX, self._tcap))
             f = dict(dtype=X.dtype, device=X.device)
             Npc = (self.capacity + 31) // 32 * 32
-            self._tcap = min(self.TAIL_MAX, self.window + self.drop - self.N)
             self._Rb = torch.zeros(self.Bt, self._tcap, Npc, **f)
             self._Rinv = torch.zeros(self.Bt, self._tcap, self._tcap, **f)
             self._Wfull = torch.empty(self.Bt, Npc, self.C + 1, **f)
@@ -487,6 +490,56 @@ def mll_grad(Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell, s2, lin=None, kernel="rb
                                                   _p(UHtA), Bt, N, n, C - 1, _p(_mll_work(Bt, N, C - 1, X.device)),
                                                   _stream(X)), "bcbf_mll_grad")
     return g_ell, g_s2, g_B, logdet, RtA, UHtA
+
+
+def kinv_apply(Kinv, R, out=None):
+    """alpha[Bt,N,nt] = Kinv R for the dense symmetric K_b^-1 (bcbf_kinv_apply: the fit iteration's `Kinv @ R` without a
+    library GEMM)."""
+    _chk(Kinv, R, out)
+    Bt, N, nt = R.shape
+    alpha = torch.empty_like(R) if out is None else out
+    check(getattr(lib, "bcbf_kinv_apply" + _suf(R))(_p(Kinv), _p(R), _p(alpha), Bt, N, nt, _stream(R)), "bcbf_kinv_apply")
+    return alpha
+
+
+def fit_param_count(n, m, rA=None, rB=None):
+    """Raw parameters per model of the batched fit (bcbf.h: theta's layout)."""
+    P = int(lib.bcbf_fit_param_count(n, m, n if rA is None else rA, 1 + m if rB is None else rB))
+    if P < 0:
+        raise ValueError("unsupported fit shape n=%d m=%d ranks %s %s" % (n, m, rA, rB))
+    return P
+
+
+def fit_derive(theta, n, m, rA, rB, want_Ainv=True):
+    """theta[Bt,P] -> dict(ell, s2, A, Bm, M0[, Ainv, logdetA]) (bcbf_fit_derive)."""
+    _chk(theta)
+    Bt, C = theta.shape[0], 1 + m
+    f = dict(dtype=theta.dtype, device=theta.device)
+    out = dict(ell=torch.empty(Bt, n, **f), s2=torch.empty(Bt, **f), A=torch.empty(Bt, n, n, **f), Bm=torch.empty(Bt, C, C, **f),
+               M0=torch.empty(Bt, C, n, **f))
+    if want_Ainv:
+        out.update(Ainv=torch.empty(Bt, n, n, **f), logdetA=torch.empty(Bt, **f))
+    check(getattr(lib, "bcbf_fit_derive" + _suf(theta))(_p(theta), _p(out["ell"]), _p(out["s2"]), _p(out["A"]), _p(out["Bm"]),
+                                                        _p(out["M0"]), _p(out.get("Ainv")), _p(out.get("logdetA")), Bt, n, m, rA, rB,
+                                                        _stream(theta)), "bcbf_fit_derive")
+    return out
+
+
+def fit_adam_step(theta, mom1, mom2, sums, Ainv, logdetA, N, n, m, rA, rB, step, lr, betas=(0.9, 0.999), eps=1e-8, skip=None,
+                  gamma_prior=None, want_grad=False):
+    """One Adam update of every model from mll_grad's `sums` = (g_ell, g_s2, g_B, logdetK, RtA, UHtA) (bcbf_fit_adam_step).
+    Returns (loss[Bt], grad[Bt,P] | None); step = 0: value and gradient only."""
+    g_ell, g_s2, g_B, logdetK, RtA, UHtA = sums[:6]
+    _chk(theta, mom1, mom2, g_ell, g_s2, g_B, logdetK, RtA, UHtA, Ainv, logdetA, skip)
+    Bt = theta.shape[0]
+    loss = torch.empty(Bt, dtype=theta.dtype, device=theta.device)
+    grad = torch.empty_like(theta) if want_grad else None
+    prior = None if gamma_prior is None else (ctypes.c_double * 2)(float(gamma_prior[0]), float(gamma_prior[1]))
+    check(getattr(lib, "bcbf_fit_adam_step" + _suf(theta))(
+        _p(theta), _p(mom1), _p(mom2), _p(g_ell), _p(g_s2), _p(g_B), _p(logdetK), _p(RtA), _p(UHtA), _p(Ainv), _p(logdetA), _p(skip),
+        _p(loss), _p(grad), Bt, N, n, m, rA, rB, int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), prior,
+        _stream(theta)), "bcbf_fit_adam_step")
+    return loss, grad
 
 
 def posterior_step(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2=None, out=None):

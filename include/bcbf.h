@@ -350,6 +350,39 @@ int bcbf_mll_grad_f64(const double* Lop, const double* alpha, const double* Kinv
                       double* g_ell, double* g_s2, double* g_B, double* logdetK, double* RtA, double* UHtA, int Bt, int N,
                       int n, int m, void* work, void* stream);
 
+/* Batched hyper-parameter fit (SURVEY 8f #1 for MANY models; ControlAffineRegressor.fit, control_affine_model.py:268-335 of the
+ * reference: ExactMarginalLogLikelihood + autograd through gpytorch's softplus / IndexKernel parameterisation + torch.optim.Adam
+ * under MultiStepLR, one model at a time).  theta[Bt,P] holds the reference's RAW parameters of every model,
+ *   [ base_kernel.raw_lengthscale (n) | raw_outputscale (1) | task_covar.U.covar_factor (n x rA, row-major) | U.raw_var (n)
+ *     | task_covar.V.covar_factor (C x rB) | V.raw_var (C) | mean_module constants (C x n) ],  C = 1 + m,
+ *   P = bcbf_fit_param_count(n, m, rA, rB)   (rA, rB = the IndexKernel ranks: n and C by default, 1 "RankOne", 0 "Diag").
+ * bcbf_fit_derive: ell[Bt,n] = softplus, s2[Bt] = softplus, A[Bt,n,n] = Wa Wa' + diag softplus(va), Bm[Bt,C,C] likewise,
+ *   M0[Bt,C,n], and (optional, NULL to skip) Ainv[Bt,n,n], logdetA[Bt] -- the inputs of bcbf_refit / bcbf_mll_grad.
+ * bcbf_fit_adam_step: from bcbf_mll_grad's outputs (g_ell, g_s2, g_B, logdetK, RtA, UHtA) and Ainv / logdetA:
+ *   loss[b] = (-log p(Y_b) - log GammaPrior(ell_b)) / (N n)  (gamma_prior = {concentration, rate} or NULL),
+ *   grad_out[Bt,P] (optional) = d loss / d theta by the chain rule (:164-171, :268-335), and -- step >= 1 -- ONE update of
+ *   torch.optim.Adam(lr, betas = (beta1, beta2), eps) on theta with the moment buffers mom1, mom2 [Bt,P] (zero before step 1);
+ *   step = 0: value and gradient only.  skip[b] != 0 (optional): model b is left untouched, loss[b] = NaN.
+ * bcbf_kinv_apply: alpha[Bt,N,nt] = Kinv[Bt,N,N] R[Bt,N,nt] for the dense SYMMETRIC K_b^-1 of bcbf_trtri + bcbf_syrk_lt
+ *   (nt <= 8) -- replaces the library GEMM `Kinv @ R` of a fit iteration.
+ * One iteration = derive, bcbf_refit, bcbf_trtri, bcbf_syrk_lt, bcbf_kinv_apply, bcbf_mll_grad, adam_step: no host round trip
+ * except the caller's look at bcbf_refit's info (make_psd's x10 jitter retry, :899-921). */
+int bcbf_fit_param_count(int n, int m, int rA, int rB);
+int bcbf_fit_derive_f32(const float* theta, float* ell, float* s2, float* A, float* Bm, float* M0, float* Ainv, float* logdetA,
+                        int Bt, int n, int m, int rA, int rB, void* stream);
+int bcbf_fit_derive_f64(const double* theta, double* ell, double* s2, double* A, double* Bm, double* M0, double* Ainv,
+                        double* logdetA, int Bt, int n, int m, int rA, int rB, void* stream);
+int bcbf_fit_adam_step_f32(float* theta, float* mom1, float* mom2, const float* g_ell, const float* g_s2, const float* g_B,
+                           const float* logdetK, const float* RtA, const float* UHtA, const float* Ainv, const float* logdetA,
+                           const int* skip, float* loss, float* grad_out, int Bt, int N, int n, int m, int rA, int rB, int step,
+                           double lr, double beta1, double beta2, double eps, const double* gamma_prior, void* stream);
+int bcbf_fit_adam_step_f64(double* theta, double* mom1, double* mom2, const double* g_ell, const double* g_s2, const double* g_B,
+                           const double* logdetK, const double* RtA, const double* UHtA, const double* Ainv, const double* logdetA,
+                           const int* skip, double* loss, double* grad_out, int Bt, int N, int n, int m, int rA, int rB, int step,
+                           double lr, double beta1, double beta2, double eps, const double* gamma_prior, void* stream);
+int bcbf_kinv_apply_f32(const float* Kinv, const float* R, float* alpha, int Bt, int N, int nt, void* stream);
+int bcbf_kinv_apply_f64(const double* Kinv, const double* R, double* alpha, int Bt, int N, int nt, void* stream);
+
 /* K4+K5+K6+K7: one posterior query per instance (the HBM-bound hot kernel).
  *   Phi = diag(k(X, xq)) UHB;  W = L^-1 Phi;  Mk = M0' + Vw' W;  Bk = s2*Bm - W'W (+ diag(jitter2))
  * Replaces ControlAffineRegressorExact._custom_predict_matrix with b = 1

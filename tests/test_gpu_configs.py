@@ -507,6 +507,37 @@ def test_row_major_tail_other_shapes_vs_in_place_appends(ops, n, m, W):
     torch.cuda.synchronize()
 
 
+def test_row_major_tail_started_beyond_the_window_keeps_going_after_the_first_refit(ops):
+    """A tail-mode window built from MORE than `window` points (N_init = window + 5): the first period is the shorter one
+    (drop - 5 appends), every later one takes `drop` rows -- the tail is sized for the longer (ops.ReservedGP: `_tcap`).  Equal
+    to the in-place form step by step through three window refits, fp64 1e-9."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, n, m, W, D, extra, dtype = 3, 3, 2, 64, 16, 5, torch.float64
+    N0 = W + extra
+    steps = (D - extra) + 2 * D + 3
+    p = make_instances(Bt, N0 + steps + 1, n, m, dtype=dtype, device=DEV, seed=91)
+    cut = lambda t, N: t[:, :N].contiguous()
+    jit0 = cut(p["jitter"], N0)
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], N0), cut(p["UH"], N0), p["Bm"], p["ell"], p["s2"], jit0)
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N0), cut(p["UH"], N0), p["M0"], want_alpha=False)
+    mk = lambda tail: ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D,
+                                     UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=jit0, tail=tail)
+    gt, gi = mk(True), mk(False)
+    assert gt._tcap == D
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    for t in range(steps):
+        row = lambda k: p[k][:, N0 + t].contiguous()
+        xq = (p["xq"] + 0.02 * t).contiguous()
+        it, Mt, Bt_ = gt.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq)
+        ii, Mi, Bi = gi.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq)
+        assert it.cpu().tolist() == ii.cpu().tolist() == [0] * Bt
+        rel_close(host(Mt), host(Mi), 1e-9, scale=max(1.0, float(Mi.abs().max())), what="Mk tail (N_init > window) vs in place")
+        rel_close(host(Bt_), host(Bi), 1e-9, scale=prior, what="Bk tail (N_init > window) vs in place")
+        assert gt.N == gi.N
+    assert gt.drops == gi.drops == 3 and gt.t == 3 and gt.N == W + 3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 def test_reserved_storage_queries_and_failed_pivot(ops, dtype):
     """Reserved storage holds the same GP as the packed layout: queries agree bit for bit with `posterior_step` on the
