@@ -172,6 +172,9 @@ class BatchedHyperFit:
             raise ValueError("data [%d, %d, %d] / [.., %d] does not fit %d models of n=%d m=%d" % (Bt, N, n, U.shape[2], self.theta.shape[0], self.n, self.m))
         UH = torch.cat([torch.ones_like(U[..., :1]), U], dim=-1).contiguous()
         self.jitter_level = None
+        self.mom1.zero_()                                   # a fit() is a NEW optimiser, as in the reference (:290-300)
+        self.mom2.zero_()
+        self.steps_done = 0
         losses = torch.empty(training_iter, Bt, dtype=self.theta.dtype, device=self.theta.device)
         skipped = torch.zeros(Bt, dtype=torch.int32, device=self.theta.device)
         for it, lr_it in enumerate(lr_schedule(lr, training_iter)):

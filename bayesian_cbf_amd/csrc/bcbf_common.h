@@ -46,6 +46,9 @@ template <int V>
 __host__ __device__ inline size_t lop_elems(int Np) { return (size_t)Np * (Np + 2) / 2 + (size_t)NB * Np; }
 
 void set_error(const char* what, hipError_t err);
+// bcbf_refit_retry: the previous attempt's info[Bt] while the retry's launch is being set up on this host thread (NULL otherwise).
+// Every refit kernel takes it as its last argument: an instance whose entry is 0 returns at once (info[b] = 0 again).
+extern thread_local const int* g_refit_only_bad;
 int check_launch(const char* what);
 bool posterior_shared_fits(int N, int n, int m);   // regime-S MFMA kernel: staging + one W slab fit in LDS
 bool posterior_shared64_fits(int N, int n, int m); // solution in registers (posterior_shared_reg.hip), fp64: N <= 512, n <= 4

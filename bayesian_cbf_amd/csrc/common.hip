@@ -5,6 +5,7 @@
 
 namespace bcbf {
 static thread_local char g_err[256] = "";
+thread_local const int* g_refit_only_bad = nullptr;
 
 void set_error(const char* what, hipError_t err) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(err));

@@ -120,6 +120,29 @@ int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const do
     if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
     return bcbf_refit_mfma_f64(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, Ldense, info, Bt, N, n, m, stream);
 }
+// The x10 jitter retry of make_psd (control_affine_model.py:903-919) WITHOUT a host round trip: factor again, with the caller's
+// (raised) jitter, only the instances whose previous attempt failed (prev_info[b] != 0); the others return at once and report 0.
+// A caller launches it unconditionally after bcbf_refit -- a launch in which nothing failed costs microseconds.
+int bcbf_refit_retry_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                         const float* jitter, float* Lop, float* UHB, const int* prev_info, int* info,
+                         int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!X || !UH || !Bm || !ell || !s2 || !UHB || !prev_info || prev_info == info) return BCBF_EINVAL;
+    bcbf::g_refit_only_bad = prev_info;
+    const int rc = bcbf_refit_mfma_f32(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, nullptr, info, Bt, N, n, m, stream);
+    bcbf::g_refit_only_bad = nullptr;
+    return rc;
+}
+int bcbf_refit_retry_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                         const double* jitter, double* Lop, double* UHB, const int* prev_info, int* info,
+                         int Bt, int N, int n, int m, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!X || !UH || !Bm || !ell || !s2 || !UHB || !prev_info || prev_info == info) return BCBF_EINVAL;
+    bcbf::g_refit_only_bad = prev_info;
+    const int rc = bcbf_refit_mfma_f64(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, nullptr, info, Bt, N, n, m, stream);
+    bcbf::g_refit_only_bad = nullptr;
+    return rc;
+}
 int bcbf_potrf_f32(const float* Kb, float* Lop, float* Ldense, int* info, int Bt, int N, void* stream) {
     if (Bt <= 0) return BCBF_OK;
     if (!Kb) return BCBF_EINVAL;

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? BCBF_R32_OCC : 1))
 refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, const float* __restrict__ Bm,
                   const float* __restrict__ ell, const float* __restrict__ s2p, const float* __restrict__ jitter,
                   const float* __restrict__ Kdense, float* __restrict__ Lop, float* __restrict__ UHBout,
-                  float* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C) {
+                  float* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C, const int* only_bad) {
     constexpr int V = 4;
     __shared__ DiagTile<float> dt;                           // the diagonal tile's working set (diag_tile64.h)
     float (&dS)[NB][NB + 1] = dt.tile;                       // diagonal tile S_JJ (row c, col i); after the factorisation: L
@@ -65,6 +65,7 @@ refit_mfma_kernel(const float* __restrict__ X, const float* __restrict__ UH, con
 
     constexpr int MTT = 64 * NW;                              // threads
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (only_bad != nullptr && only_bad[b] == 0) { if (tid == 0) info[b] = 0; return; }     // bcbf_refit_retry: factored already
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
     const float* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
@@ -430,12 +431,12 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     } while (0)
     if (Kdense) {
         BCBF_REFIT_LAUNCH(true, 0, st, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
+                           nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0, g_refit_only_bad);
     } else {
         if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
         if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
         BCBF_REFIT_LAUNCH(false, 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
-                           Lop, UHB, Ldense, info, N, Np, n, m + 1);
+                           Lop, UHB, Ldense, info, N, Np, n, m + 1, g_refit_only_bad);
     }
     return check_launch("refit_mfma");
 }

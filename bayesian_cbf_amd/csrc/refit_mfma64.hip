@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 4 ? BCBF_R64_OCC : 2))
 refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH, const double* __restrict__ Bm,
                     const double* __restrict__ ell, const double* __restrict__ s2p, const double* __restrict__ jitter,
                     const double* __restrict__ Kdense, double* __restrict__ Lop, double* __restrict__ UHBout,
-                    double* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C) {
+                    double* __restrict__ Ldense, int* __restrict__ info, int N, int Np, int n, int C, const int* only_bad) {
     constexpr int V = 2;
     __shared__ double dS[NB][NB + 1];                        // diagonal tile S_JJ (row c, col i)
     __shared__ double dinv[NB][NB + 1];                      // inv(L_JJ)[c'][c]
@@ -74,6 +74,7 @@ refit_mfma64_kernel(const double* __restrict__ X, const double* __restrict__ UH,
 
     constexpr int MTT = 64 * NW;                              // threads
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (only_bad != nullptr && only_bad[b] == 0) { if (tid == 0) info[b] = 0; return; }     // bcbf_refit_retry: factored already
     const int wave = tid >> 6, lane = tid & 63, j16 = lane & 15, g = lane >> 4;
     double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
     const double* Xb = FROM_DENSE ? nullptr : X + (size_t)b * N * n;
@@ -424,10 +425,10 @@ extern "C" int bcbf_refit_mfma_f64(const double* X, const double* UH, const doub
     } while (0)
     if (Kdense) {
         BCBF_REFIT_LAUNCH(true, 0, st, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0);
+                           nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, N, Np, 0, 0, g_refit_only_bad);
     } else {
         BCBF_REFIT_LAUNCH(false, 0, st, X, UH, Bm, ell, s2, jitter, nullptr,
-                           Lop, UHB, Ldense, info, N, Np, n, m + 1);
+                           Lop, UHB, Ldense, info, N, Np, n, m + 1, g_refit_only_bad);
     }
     return check_launch("refit_mfma64");
 }

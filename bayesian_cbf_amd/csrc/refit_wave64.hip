@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64 * RW_WPB, OCC)
 refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                     const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
                     const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout,
-                    T* __restrict__ Ldense, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+                    T* __restrict__ Ldense, int* __restrict__ info, int Bt, int N, int Np, int n, int C, const int* only_bad) {
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
     using P = RW<T>;
     using acc_t = typename P::acc_t;
@@ -226,6 +226,7 @@ refit_wave_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x * RW_WPB + wave;
     if (b >= Bt) return;                                      // whole wave: no workgroup barrier anywhere below
+    if (only_bad != nullptr && only_bad[b] == 0) { if (lane == 0) info[b] = 0; return; }     // bcbf_refit_retry: factored already
     __attribute__((address_space(3))) RWShared<T, SUP>& sh = *(__attribute__((address_space(3))) RWShared<T, SUP>*)&shm[wave];   // keep ds_* ops
     const int j16 = lane & 15, g = lane >> 4;                 // MFMA roles
 
@@ -1312,7 +1313,7 @@ template <typename T>
 __global__ void __launch_bounds__(128, 2)
 refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
-                   T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+                   T* __restrict__ Lop, T* __restrict__ UHBout, int* __restrict__ info, int Bt, int N, int Np, int n, int C, const int* only_bad) {
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
     using P = RW<T>;
     using acc_t = typename P::acc_t;
@@ -1321,6 +1322,7 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     __attribute__((address_space(3))) RAShared<T>& sp = *(__attribute__((address_space(3))) RAShared<T>*)&shm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x;
+    if (only_bad != nullptr && only_bad[b] == 0) { if (threadIdx.x == 0) info[b] = 0; return; }     // bcbf_refit_retry: factored already
     const int j16 = lane & 15, g = lane >> 4;
     constexpr bool ACACHE = BCBF_RP_ACACHE && sizeof(T) == 8;
     static_assert(!ACACHE || sizeof(T) * NB * DT_LS >= 8 * 64 * sizeof(T2), "the cache's first tile lives in d.tile");
@@ -1713,7 +1715,7 @@ static int launch_refit_pair(const T* X, const T* UH, const T* Bm, const T* ell,
                               int* info, int Bt, int N, int Np, int n, int C, hipStream_t st) {
     if (Np / NB > RA_MAXBLK) return -1;
     if ((unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;    // 32-bit byte offsets
-    hipLaunchKernelGGL((refit_pair_kernel<T>), dim3(Bt), dim3(128), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C);
+    hipLaunchKernelGGL((refit_pair_kernel<T>), dim3(Bt), dim3(128), 0, st, X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, C, g_refit_only_bad);
     return 0;
 }
 int launch_refit_pair64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
@@ -1756,7 +1758,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW)
 refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ Bm,
                    const T* __restrict__ ell, const T* __restrict__ s2p, const T* __restrict__ jitter,
                    const T* __restrict__ Kdense, T* __restrict__ Lop, T* __restrict__ UHBout, T* __restrict__ Ldense,
-                   int* __restrict__ info, int Bt, int N, int Np, int n, int C) {
+                   int* __restrict__ info, int Bt, int N, int Np, int n, int C, const int* only_bad) {
     constexpr int V = Vec<T>::V, ES = (int)sizeof(T);
     using P = RW<T>;
     using acc_t = typename P::acc_t;
@@ -1765,6 +1767,7 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
     __attribute__((address_space(3))) RTShared<T, NW>& sp = *(__attribute__((address_space(3))) RTShared<T, NW>*)&shm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x;
+    if (only_bad != nullptr && only_bad[b] == 0) { if (threadIdx.x == 0) info[b] = 0; return; }     // bcbf_refit_retry: factored already
     const int j16 = lane & 15, g = lane >> 4;
     T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
     // (FROM_DENSE: K_b is given -- bcbf_potrf -- and the kernel values are read, not formed; no X / UH / UH B)
@@ -2164,9 +2167,9 @@ static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell,
     if (kind != 0) {
         if (Kdense || (unsigned long long)lop_elems<16 / (int)sizeof(T)>(Np) * sizeof(T) >= (1ull << 31)) return -1;
         if (kind == 1)
-            hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 1>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+            hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 1>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, g_refit_only_bad);
         else if (kind == 2)
-            hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 2>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+            hipLaunchKernelGGL((refit_team_kernel<T, 8, false, 2>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, g_refit_only_bad);
         else return -1;
         return 0;
     }
@@ -2175,13 +2178,13 @@ static int launch_refit_team(const T* X, const T* UH, const T* Bm, const T* ell,
     // four waves per instance (two workgroups per CU) when the batch needs more than one workgroup per CU but not more than
     // two: 512 x 256 fp64 0.259 (two waves per instance) / 0.330 (team of eight, two rounds) / 0.210 ms
     if (nw == 4 && !Kdense) {
-        hipLaunchKernelGGL((refit_team_kernel<T, 4, false>), dim3(Bt), dim3(256), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        hipLaunchKernelGGL((refit_team_kernel<T, 4, false>), dim3(Bt), dim3(256), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, g_refit_only_bad);
         return 0;
     }
     if (Kdense)
-        hipLaunchKernelGGL((refit_team_kernel<T, 8, true>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, true>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, g_refit_only_bad);
     else
-        hipLaunchKernelGGL((refit_team_kernel<T, 8, false>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C);
+        hipLaunchKernelGGL((refit_team_kernel<T, 8, false>), dim3(Bt), dim3(512), 0, st, X, UH, Bm, ell, s2, jitter, Kdense, Lop, UHB, Ldense, info, Bt, N, Np, n, C, g_refit_only_bad);
     return 0;
 }
 int launch_refit_team64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
@@ -2233,10 +2236,10 @@ static int launch_refit_wave(const T* X, const T* UH, const T* Bm, const T* ell,
     do {                                                                                                                  \
         if (Kdense)                                                                                                       \
             hipLaunchKernelGGL((refit_wave_kernel<T, true, OCC_>), grid, block, 0, st, nullptr, nullptr, nullptr, nullptr,  \
-                               nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, Bt, N, Np, 0, 0);                    \
+                               nullptr, nullptr, Kdense, Lop, nullptr, Ldense, info, Bt, N, Np, 0, 0, g_refit_only_bad);                    \
         else                                                                                                              \
             hipLaunchKernelGGL((refit_wave_kernel<T, false, OCC_, ##__VA_ARGS__>), grid, block, 0, st, X, UH, Bm, ell, s2, jitter,        \
-                               nullptr, Lop, UHB, Ldense, info, Bt, N, Np, n, C);                                         \
+                               nullptr, Lop, UHB, Ldense, info, Bt, N, Np, n, C, g_refit_only_bad);                                         \
     } while (0)
     if constexpr (sizeof(T) == 4) {
         // super-panels from N = 512 on (BCBF_RW32_SUPER; never for a given dense K_b or a dense output: those are the

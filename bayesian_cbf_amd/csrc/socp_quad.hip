@@ -658,12 +658,18 @@ socp_quad_kernel(const T* __restrict__ w, const T* __restrict__ r, const T* __re
         for (int i = 0; i < NV; ++i) y[(size_t)b * NV + i] = (T)x[i];
         status[b] = st_code;
         if (iters) iters[b] = it;
-        if (UNI && task.dt > T(0) && st_code == BCBF_SOCP_OPTIMAL) {   // plant step with y = [u0, u1, relax] as stored
-            T* xs = task.x + (size_t)b * 3;      // (rounded to T).  An instance whose program was not solved keeps its state:
-            const T th = xs[2], u0 = (T)x[0], u1 = (T)x[1];   // the reference raises there (unicycle_move_to_pose.py:954-964),
-            xs[0] += cos(th) * u0 * task.dt;                  // a batch freezes the instance and reports it in status[]
-            xs[1] += sin(th) * u0 * task.dt;
-            xs[2] += u1 / task.L_true * task.dt;
+        if (UNI && task.dt > T(0)) {             // plant step with y = [u0, u1, relax] as stored (rounded to T)
+            T* xs = task.x + (size_t)b * 3;
+            const T x0 = xs[0], x1 = xs[1], th = xs[2];
+            T n0 = x0, n1 = x1, n2 = th, u0 = T(0), u1 = T(0);
+            if (st_code == BCBF_SOCP_OPTIMAL) {  // An instance whose program was not solved keeps its state: the reference raises
+                u0 = (T)x[0]; u1 = (T)x[1];      // there (unicycle_move_to_pose.py:954-964), a batch freezes the instance and
+                n0 = x0 + cos(th) * u0 * task.dt;                 // reports it in status[]
+                n1 = x1 + sin(th) * u0 * task.dt;
+                n2 = th + u1 / task.L_true * task.dt;
+                xs[0] = n0; xs[1] = n1; xs[2] = n2;
+            }
+            unicycle_observe<T>(task, b, x0, x1, th, n0, n1, n2, u0, u1);
         }
     }
 }

@@ -103,7 +103,48 @@ struct UnicycleTask {
     T clf_gamma, L_mean, dt, L_true;
     T *grad, *cst, *fhat, *ghat;             // workspaces that expose the rows (may be NULL)
     int Kob;
+    // Observation of THIS step for the learner (LearnedShiftInvariantDynamics.train / fit, unicycle_move_to_pose.py:326-386),
+    // written with the plant step (dt > 0; all NULL = not wanted): row b * obs_ld of
+    //   obs_x  [.,3]  the regressor's input: the state BEFORE the step, (0, 0, theta) when shift_invariant (:326-330)
+    //   obs_uh [.,3]  (1, u)  -- u = 0 for an instance whose program was not solved (its state is frozen: a unicycle at rest)
+    //   obs_y  [.,3]  (x_{t+1} - x_t) / dt  -  (f_mean + g_mean(L_mean) u)(input)   finite difference of the STORED states
+    //                 minus the prior-mean dynamics (:364-372)
+    // xq_next [Bt,3] (optional): the regressor's input at the NEW state -- the next step's posterior query.
+    // advance_plan: the planner's target moves on with the step, plan += dot_plan dt (PiecewiseLinearPlanner.plan(t + 1),
+    //               planner.py:54-64: a straight line at constant speed) -- `plan` is then written.
+    T *obs_x = nullptr, *obs_uh = nullptr, *obs_y = nullptr, *xq_next = nullptr;
+    int obs_ld = 1, shift_invariant = 1, advance_plan = 0;
 };
+
+// the observation row of one instance (see UnicycleTask): old state (x0, x1, th), new state (n0, n1, n2), applied u
+template <typename T>
+__device__ inline void unicycle_observe(const UnicycleTask<T>& task, int b, T x0, T x1, T th, T n0, T n1, T n2, T u0, T u1) {
+    const bool si = task.shift_invariant != 0;
+    if (task.obs_x != nullptr) {
+        const size_t row = (size_t)b * task.obs_ld * 3;
+        task.obs_x[row] = si ? T(0) : x0;
+        task.obs_x[row + 1] = si ? T(0) : x1;
+        task.obs_x[row + 2] = th;
+        task.obs_uh[row] = T(1);
+        task.obs_uh[row + 1] = u0;
+        task.obs_uh[row + 2] = u1;
+        T G[3][2];
+        ackermann_g<T>(th, task.L_mean, G);                    // (g_mean depends on theta only: the same at the shifted input)
+        task.obs_y[row] = (n0 - x0) / task.dt - (G[0][0] * u0 + G[0][1] * u1);
+        task.obs_y[row + 1] = (n1 - x1) / task.dt - (G[1][0] * u0 + G[1][1] * u1);
+        task.obs_y[row + 2] = (n2 - th) / task.dt - (G[2][0] * u0 + G[2][1] * u1);
+    }
+    if (task.advance_plan) {
+        T* pl = const_cast<T*>(task.plan) + (size_t)b * 3;
+        const T* dp = task.dot_plan + (size_t)b * 3;
+        pl[0] += dp[0] * task.dt; pl[1] += dp[1] * task.dt; pl[2] += dp[2] * task.dt;
+    }
+    if (task.xq_next != nullptr) {
+        task.xq_next[(size_t)b * 3] = si ? T(0) : n0;
+        task.xq_next[(size_t)b * 3 + 1] = si ? T(0) : n1;
+        task.xq_next[(size_t)b * 3 + 2] = n2;
+    }
+}
 
 }  // namespace bcbf
 #endif

@@ -124,6 +124,74 @@ def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None, kernel="r
     return Lop, UHB, info, Ld
 
 
+def refit_retry(X, UH, Bm, ell, s2, jitter, Lop, UHB, prev_info, info):
+    """Factor again ONLY the instances with prev_info[b] != 0 (bcbf_refit_retry; no host round trip), with the jitter the
+    caller has raised for them; writes `info` (a different buffer than prev_info)."""
+    _chk(X, UH, Bm, ell, s2, jitter, Lop, UHB, prev_info, info)
+    Bt, N, n = X.shape
+    check(getattr(lib, "bcbf_refit_retry" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
+                                                     _p(prev_info), _p(info), Bt, N, n, UH.shape[2] - 1, _stream(X)), "bcbf_refit_retry")
+    return info
+
+
+def refit_with_retries(X, UH, Bm, ell, s2, jitter, out, levels=3, scratch=None, level=None, counts=None):
+    """bcbf_refit followed by `levels` unconditional retry launches (x10 jitter on the instances that failed: make_psd's
+    schedule, control_affine_model.py:903-919) -- nothing waits for the host.  out = (Lop, UHB, info); `jitter` is raised IN
+    PLACE for the failed instances (it is the record of what every point was factored with), and so is `level[Bt]` (the
+    instance's jitter level, kept by callers that start the next refit near the level that worked).  counts[levels + 1]
+    (optional, int64 on the device): += the instances each launch had to factor.  Returns info (0, or the pivot of an instance
+    that failed every level)."""
+    Lop, UHB, info = out
+    refit(X, UH, Bm, ell, s2, jitter, out=(Lop, UHB, info))
+    if counts is not None:
+        counts[0] += X.shape[0]
+    other = torch.empty_like(info) if scratch is None else scratch
+    cur, nxt = info, other
+    for k in range(levels):
+        fac = torch.where(cur != 0, 10.0, 1.0).to(jitter.dtype)
+        jitter.mul_(fac[:, None])
+        if level is not None:
+            level.mul_(fac)
+        if counts is not None:
+            counts[k + 1] += (cur != 0).sum()
+        refit_retry(X, UH, Bm, ell, s2, jitter, Lop, UHB, cur, nxt)
+        cur, nxt = nxt, cur
+    if cur is not info:
+        info.copy_(cur)
+    return info
+
+
+def gram(W, Wp=None, out=None):
+    """G[b,bp,C,C] = einsum("bkc,pkd->bpcd", W, Wp) on the matrix cores (bcbf_gram); Wp None = W (symmetric: half the tiles)."""
+    Wp = W if Wp is None else Wp
+    _chk(W, Wp, out)
+    b, Np, C = W.shape
+    bp = Wp.shape[0]
+    if Wp.shape[1] != Np or Wp.shape[2] != C:
+        raise ValueError("gram: W %s vs Wp %s" % (tuple(W.shape), tuple(Wp.shape)))
+    G = torch.empty(b, bp, C, C, dtype=W.dtype, device=W.device) if out is None else out
+    check(getattr(lib, "bcbf_gram" + _suf(W))(_p(W), _p(Wp), _p(G), b, bp, Np, C, _stream(W)), "bcbf_gram")
+    return G
+
+
+def predict_fullmat(Lop, Vw, X, UHB, ell, s2, Bm, M0, A, Xq, jitter=None, want_BkXX=False, want_kron=True, kernel="rbf"):
+    """query -> Gram -> assembly in ONE host call (bcbf_predict_fullmat).  Returns (Mk[b,n,C], BkXX | None, Kron | None)."""
+    _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0, A, Xq, jitter)
+    if X.shape[0] != 1:
+        raise ValueError("predict_fullmat: GP tensors of ONE model (leading axis 1)")
+    N, n = X.shape[1], X.shape[2]
+    C, b = UHB.shape[2], Xq.shape[0]
+    f = dict(dtype=X.dtype, device=X.device)
+    Np = (N + 31) // 32 * 32
+    Mk, Bk, W, G = torch.empty(b, n, C, **f), torch.empty(b, C, C, **f), torch.empty(b, Np, C, **f), torch.empty(b, b, C, C, **f)
+    BkXX = torch.empty(b, b, C, C, **f) if want_BkXX else None
+    Kron = torch.empty(b * C * n, b * C * n, **f) if want_kron else None
+    check(getattr(lib, "bcbf_predict_fullmat" + _suf(X))(_p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(A), _p(Xq),
+                                                         _p(jitter), _p(Mk), _p(Bk), _p(W), _p(G), _p(BkXX), _p(Kron), b, N, n, C - 1,
+                                                         DATA_KERNELS.index(kernel), _stream(X)), "bcbf_predict_fullmat")
+    return Mk, BkXX, Kron
+
+
 def potrf(Kb, want_dense=False):
     """Cholesky of caller-supplied SPD matrices (torch.linalg.cholesky, control_affine_model.py:911)."""
     _chk(Kb)
@@ -227,8 +295,18 @@ class ReservedGP:
     TAIL_MAX = 64            # tail rows the tail step holds (bcbf_gp_tail_step: tcap <= 64)
 
     def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None,
-                 drop=None, tail=False):
+                 drop=None, tail=False, retry_levels=None):
+        """retry_levels = k (window mode): the window refit of a drop never waits for the host -- bcbf_refit followed by k
+        unconditional bcbf_refit_retry launches (x10 jitter on the instances that failed), into a second operator buffer that
+        is swapped in (no allocation per drop).  `drop_info` then holds the last level's info; `drop_failures` is counted only
+        when asked for (`count_drop_failures()`: one host read).  None: ten levels with a look at the device per level."""
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
+        self.retry_levels = retry_levels
+        self._alt = None
+        # retry_levels mode: the jitter LEVEL of every instance (make_psd starts at 1e-5 and goes x10 per failure; a window refit here
+        # starts one level below the one that last worked) -- `jitter_level` is also what a caller scales a new point's draw with
+        self.jitter_level = torch.full((X.shape[0],), 1e-5, dtype=X.dtype, device=X.device)
+        self.retry_counts = torch.zeros((retry_levels or 0) + 1, dtype=torch.int64, device=X.device)
         self.Bt, self.N, self.n = X.shape
         self.C = UHB.shape[2]
         self.ell, self.s2, self.Bm, self.M0, self.A = ell, s2, Bm, M0, A
@@ -316,17 +394,39 @@ class ReservedGP:
             raise RuntimeError("nothing would be left")
         X = self.X[:, k:self.N].contiguous()
         UH, Y, J = self._rUH[:, k:self.N].contiguous(), self._rY[:, k:self.N].contiguous(), self._rJ[:, k:self.N].contiguous()
-        for ntry in range(max_tries):
-            Lop, UHB, info, _ = refit(X, UH, self.Bm, self.ell, self.s2, J)
-            bad = info != 0
-            if not bool(bad.any()):                   # (one host round trip per drop: ~30 us against the refit's milliseconds;
-                break                                 #  speculative jitter levels would cost two more refits per drop instead)
-            if ntry + 1 < max_tries:
-                J = torch.where(bad[:, None], J * 10, J)
+        if self.retry_levels is not None:
+            # no host round trip, no allocation: the refit and its retries write the operator buffer that is NOT being read
+            f = dict(dtype=X.dtype, device=X.device)
+            if self._alt is None or self._alt[0].shape[1] != lop_elems(N2, X.dtype):
+                self._alt = (torch.empty(self.Bt, lop_elems(N2, X.dtype), **f), torch.empty(self.Bt, N2, self.C, **f),
+                             torch.empty(self.Bt, dtype=torch.int32, device=X.device), torch.empty(self.Bt, dtype=torch.int32, device=X.device))
+            Lop, UHB, info, scratch = self._alt
+            # a FRESH draw for every point of the window at the instance's level, as make_psd draws one per factorisation (:907-910)
+            # (raising the points' stored jitter x10 per failed refit instead would compound from window to window)
+            # (starting at the level that last worked; one level down every `level_decay_every`-th refit -- 1: make_psd's restart, one
+            #  level below, at every refit)
+            every = getattr(self, "level_decay_every", 1)
+            if every and (self.drops + 1) % every == 0:
+                self.jitter_level.div_(10).clamp_(min=1e-5)
+            J = (self.jitter_level[:, None] * torch.rand(self.Bt, N2, **f)).contiguous()
+            refit_with_retries(X, UH, self.Bm, self.ell, self.s2, J, (Lop, UHB, info), levels=self.retry_levels, scratch=scratch,
+                               level=self.jitter_level, counts=self.retry_counts)
+            if self.tail:
+                self._alt = (self.Lop if self.Lop.shape == Lop.shape else None, UHB, info, scratch)    # the buffer now read is the next drop's target
+                if self._alt[0] is None:
+                    self._alt = None
         else:
-            # still failing after max_tries levels: the instance's window is laid out as the (garbage) factor the kernel left;
-            # say so where callers look -- drop_info, the failure count, and the next append's info
-            self.drop_failures += int(bad.sum())
+            for ntry in range(max_tries):
+                Lop, UHB, info, _ = refit(X, UH, self.Bm, self.ell, self.s2, J)
+                bad = info != 0
+                if not bool(bad.any()):                   # (one host round trip per drop: ~30 us against the refit's milliseconds;
+                    break                                 #  speculative jitter levels would cost two more refits per drop instead)
+                if ntry + 1 < max_tries:
+                    J = torch.where(bad[:, None], J * 10, J)
+            else:
+                # still failing after max_tries levels: the instance's window is laid out as the (garbage) factor the kernel left;
+                # say so where callers look -- drop_info, the failure count, and the next append's info
+                self.drop_failures += int(bad.sum())
         self.drop_info = info
         Vw, _ = potrs(Lop, Y, UH, self.M0, want_alpha=False)
         self._rUH[:, :N2], self._rY[:, :N2], self._rJ[:, :N2] = UH, Y, J
@@ -341,6 +441,10 @@ class ReservedGP:
         self.t = 0
         self.drops += 1
         return info
+
+    def count_drop_failures(self):
+        """Host read of the last window refit's info (retry_levels mode keeps it on the device): instances still failing."""
+        return 0 if self.drop_info is None else int((self.drop_info != 0).sum())
 
     def _tail_step(self, xq, x_new, uh_new, xdot_new, jitter_new, Mk, Bk, do_append):
         # (the pointers of this object's own buffers are converted once per window: a closed loop on part batches makes this call
@@ -962,28 +1066,55 @@ def _unicycle_control_step_composed(gp, task, ws, x, dt, L_true, L_mean, clf_gam
 
 
 def unicycle_control_step_prepare(gp, task, ws, x, dt=0.0, L_true=1.0, L_mean=1.0, clf_gamma=10.0, max_iters=100,
-                                  stream=None):
+                                  stream=None, observe=None):
     """Bind every argument of `unicycle_control_step` once and return `step(ev_start=None, ev_stop=None)`.
     A closed loop calls the same entry point with the same buffers thousands of times; converting ~40 tensors to
     pointers per call costs more host time than the two launches take on the device for small batches.  The tensors
     must keep their storage (update them in place); the closure keeps them alive.
-    stream: a fixed torch stream for both launches (default: the current stream at call time)."""
+    stream: a fixed torch stream for both launches (default: the current stream at call time).
+    observe = dict(xq=[Bt,3] | None, xq_next=[Bt,3] | None, shift_invariant=True, advance_plan=False): the loop LEARNS FROM ITSELF
+    (bcbf_unicycle_control_step_observe; RBF models): the posterior is queried at `xq`, and the solve / plant launch writes this
+    step's observation row where the call says -- `step(ev_start, ev_stop, obs=(obs_x, obs_uh, obs_y, ld))`, three-column
+    tensors whose row b * ld is instance b's (ld = 1: [Bt,3] tensors) -- and the next query into `xq_next`."""
     gp, A, N, shared = _control_step_args(gp, task, ws, x)
     Bt = x.shape[0]
     Kob = task["centers"].shape[1]
     kernel = gp.get("kernel", "rbf")                       # data kernel of the learned model: "rbf" (the reference's) | "matern52"
     if kernel not in DATA_KERNELS:
         raise ValueError("gp['kernel'] must be one of %s" % (DATA_KERNELS,))
-    fn = getattr(lib, "bcbf_unicycle_control_step" + _KSUF[kernel] + _suf(x))
+    if observe is not None and kernel != "rbf":
+        raise NotImplementedError("the observing control step is built for the reference's RBF data kernel")
+    fn = getattr(lib, ("bcbf_unicycle_control_step_observe" if observe is not None else "bcbf_unicycle_control_step" + _KSUF[kernel]) + _suf(x))
     head = (_p(gp["Lop"]), _p(gp["Vw"]), _p(gp["X"]), _p(gp["UHB"]), _p(gp["ell"]), _p(gp["s2"]), _p(gp["Bm"]),
             _p(gp["M0"]), _p(A), _p(x), _p(task["plan"]), _p(task["dot_plan"]), _p(task["Kp"]), clf_gamma,
             _p(task["centers"]), _p(task["radii"]), _p(task["tw"]), _p(task["gammas"]), L_mean, _p(task["w"]),
             _p(task["r"]), _p(task["sign"]), _p(task["relax_mask"]), _p(task["rho"]), _p(ws["grad"]), _p(ws["cst"]),
             _p(ws["fhat"]), _p(ws["ghat"]), _p(ws["Mk"]), _p(ws["Bk"]), _p(ws["cones"]), _p(ws["cstatus"]), _p(ws["y"]),
             _p(ws["status"]), _p(ws["iters"]), dt, L_true, Bt, N, Kob, max_iters, 1 if shared else 0)
-    keep = (dict(gp), dict(task), dict(ws), x, A, stream)      # the pointers above are only valid while these live
+    keep = (dict(gp), dict(task), dict(ws), x, A, stream, observe)      # the pointers above are only valid while these live
     dev, y = x.device, ws["y"]
     fixed = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+
+    if observe is not None:
+        xq, xq_next = observe.get("xq"), observe.get("xq_next")
+        _chk(x, xq, xq_next)
+        p_xq, p_next = _p(xq), _p(xq_next)
+        si = (1 if observe.get("shift_invariant", True) else 0) | (2 if observe.get("advance_plan", False) else 0)   # the entry's `flags`
+
+        def step(ev_start=None, ev_stop=None, obs=None):
+            ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None
+            ev1 = ctypes.c_void_p(ev_stop.cuda_event) if ev_stop is not None else None
+            if obs is None:
+                o = (None, None, None, 1)
+            else:
+                o = (_p(obs[0]), _p(obs[1]), _p(obs[2]), int(obs[3]))
+            rc = fn(*head, p_xq, *o, p_next, si, ev0, ev1,
+                    fixed if fixed is not None else ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if rc:
+                check(rc, "bcbf_unicycle_control_step_observe")
+            return y
+        step.keep = keep
+        return step
 
     def step(ev_start=None, ev_stop=None):
         ev0 = ctypes.c_void_p(ev_start.cuda_event) if ev_start is not None else None

@@ -266,7 +266,7 @@ class _PartsReserved:
 
 
 def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warmup=40, dtype=torch.float32, device="cuda",
-                         seed=1234, schedule="online", n=3, m=2, barrier=None, parts=1):
+                         seed=1234, schedule="online", n=3, m=2, barrier=None, parts=1, mid_period_steps=0):
     """The reference's REAL workload at BASELINE configs[2] scale: a control loop that keeps learning
     (`LearnedShiftInvariantDynamics.train`, unicycle_move_to_pose.py:340-386: buffer (x, u) every step, refit every
     `train_every_n_steps` = 40 on at most `max_train` points) -- Bt independent instances, each with its own GP over the most
@@ -290,6 +290,11 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
         part's latency-bound solve beside another part's HBM-bound posterior); a refit waits for all part streams (one host
         synchronisation per refit) and the part streams wait for it.
 
+    Observations are PRE-DRAWN synthetic rows (`synthetic.make_instances`: well-conditioned random inputs) -- the cost of the
+    learning loop on data that does not depend on the loop; `self_learning_closed_loop` below is the loop that learns from its own
+    (x_t, u_t, x_{t+1}).  mid_period_steps: untimed extra steps after the timed region (fewer than refit_every), so that the final
+    model the parity checks look at is MID-PERIOD -- a window plus appended / tail rows, not a model that was just refitted.
+
     `warmup` untimed steps (rounded up to whole refit periods so that the timed region starts right after a refit), then
     `steps` timed steps (a multiple of refit_every: every timed period holds exactly one refit) between two device
     synchronisations.  Returns the timings (wall clock for the total; HIP events for the shares), a roofline entry per
@@ -300,7 +305,9 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
     if steps % refit_every or steps <= 0:
         raise ValueError("steps must be a positive multiple of refit_every")
     warmup = -(-warmup // refit_every) * refit_every
-    total = warmup + steps
+    if not 0 <= mid_period_steps < refit_every:
+        raise ValueError("mid_period_steps must be in [0, refit_every)")
+    total = warmup + steps + int(mid_period_steps)
     window = max_train - refit_every if schedule in ("online", "online_tail") else max_train      # points the model holds right after a refit
     if window < 1:
         raise ValueError("max_train must exceed refit_every")
@@ -393,7 +400,7 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
                 a_.record(streams[c]); b_.record(streams[c])
         ev_base = E()
     refit_steps = []
-    t0 = None
+    t0 = elapsed = None
     for t in range(total):
         if t == warmup:
             if barrier is not None:
@@ -404,6 +411,11 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
                     s_.synchronize()
                 ev_base.record(streams[0])
             t0 = time.perf_counter()
+        if t == warmup + steps:                                  # (mid_period_steps > 0: the timed region ends here)
+            torch.cuda.synchronize(dev)
+            if barrier is not None:
+                barrier()
+            elapsed = time.perf_counter() - t0
         N_obs = window + t
         e = ev[t]
         e[0].record()
@@ -458,10 +470,11 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
                         st_.wait_stream(torch.cuda.current_stream(dev))
                 refit_steps.append(t)
     torch.cuda.synchronize(dev)
-    if barrier is not None:
-        barrier()
-    elapsed = time.perf_counter() - t0
-    timed = range(warmup, total)
+    if elapsed is None:
+        if barrier is not None:
+            barrier()
+        elapsed = time.perf_counter() - t0
+    timed = range(warmup, warmup + steps)
     if online and concurrent:
         # the parts drift apart, so shares are taken over the whole timed region: the time during which at least one part's pass
         # (on a refit step: pass + window refit) ran, and a refit's own share from each part's refit-step interval minus that part's
@@ -502,12 +515,12 @@ def learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warm
             else:
                 cb = max(cb, b_)
         pass_ms = (busy + cb - ca) / steps
-        rs = [t for t in refit_steps if t >= warmup]
+        rs = [t for t in refit_steps if warmup <= t < warmup + steps]
         refit_ms = sum(ev[t][2].elapsed_time(ev[t][3]) for t in rs) / max(1, len(rs))
         n_refits = len(rs)
     else:
         pass_ms = sum(ev[t][0].elapsed_time(ev[t][1]) for t in timed) / steps
-        rs = [t for t in refit_steps if t >= warmup]
+        rs = [t for t in refit_steps if warmup <= t < warmup + steps]
         refit_ms = sum(ev[t][2].elapsed_time(ev[t][3]) for t in rs) / max(1, len(rs))
         n_refits = len(rs)
     if os.environ.get("BCBF_LEARN_DUMP"):          # development: per-step pass / solve intervals with the live size
@@ -575,3 +588,335 @@ def final_window_vs_device_refit(final, sample=64):
     return dict(instances=int(idx.numel()), refit_failures=int((info != 0).sum()),
                 Mk=float(((f64(Mk[idx]) - Mr).abs().amax(dim=(1, 2)) / Mr.abs().amax(dim=(1, 2)).clamp(min=1.0)).max()),
                 Bk=float(((f64(Bk[idx]) - Br).abs().amax(dim=(1, 2)) / prior).max()))
+
+
+def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warmup=None, dtype=torch.float32, device="cuda",
+                              seed=1234, schedule="reference", parts=4, stagger=True, shift_invariant=True, dt=0.01,
+                              retry_levels=3, fit_iters=0, fit_lr=0.1, fit_dtype=torch.float64, record_states=False, barrier=None,
+                              mid_period_steps=0, query_shift_invariant=True, level_decay_every=4):
+    """The reference's learning loop for MANY instances, fed BY ITSELF (LearnedShiftInvariantDynamics.train / fit,
+    unicycle_move_to_pose.py:326-386): every control step's observation row is built on the device from the loop's own
+    (x_t, u_t, x_{t+1}) -- inside the solve / plant launch (`bcbf_unicycle_control_step_observe`): regressor input = the state
+    before the step, shift invariant (0, 0, theta) (:326-330), target = (x_{t+1} - x_t) / dt minus the mean model
+    `AckermannDrive(L_mean)` (:364-372) -- and is what the next refit / append learns from.  query_shift_invariant (default):
+    the controller queries the learned model at the shift-invariant input of the current state too, which the kernel keeps in
+    `xq` (xq_next).  The reference's `fu_func_gp` (:388-397) does NOT go through the wrapper -- its controller queries a model
+    trained on (0, 0, theta) at the raw (x, y, theta), far from every training input, so the posterior is the prior and most
+    chance constraints are infeasible (measured here: 13 % of the programs solve, against 87 % with consistent inputs);
+    query_shift_invariant=False reproduces that.
+    Jitter (make_psd, :899-921): every factorisation draws level * rand per point, x10 per failed attempt; an instance starts a
+    refit at the level that last worked and goes one level down every `level_decay_every`-th refit (the reference restarts at
+    1e-5 every time; in fp32 on a trajectory's near-collinear rows that level fails for three instances in four, each failure
+    a whole factorisation).
+
+    Bt instances in `parts` part batches, each on its own HIP stream with its own model buffers; NOTHING waits for the host:
+    a refit is `bcbf_refit` + `retry_levels` unconditional `bcbf_refit_retry` launches (make_psd's x10 schedule on the failed
+    instances) + `bcbf_potrs` into the operator buffer that is not being read, then the buffers swap.  `stagger`: part c refits
+    at steps = c * refit_every / parts (mod refit_every), so one part's matrix-core refit runs beside the other parts' HBM-bound
+    passes instead of stopping the device.
+      schedule "reference":   the model is static between refits (posterior pass + solve); every `refit_every` steps the last
+                              `max_train` observations are refactored -- the reference's cadence (train_every_n_steps).
+      schedule "online_tail": every observation enters the model the step after it was made (`ReservedGP(tail=True)`:
+                              streaming pass over the window + tail kernel), window refit every `refit_every` appends.
+    The windows start filled with synthetic rows (the model the run starts from); `warmup` (default: enough periods to flush
+    them, >= window + refit_every steps) makes the timed region learn from the loop's own rows only.
+    fit_iters > 0 (schedule "reference"): every refit first runs `fit_iters` Adam iterations of the marginal likelihood on the
+    part's window for every instance (`BatchedHyperFit`, in `fit_dtype`) -- the reference's `fit(..., training_iter=100)`;
+    the hyper-parameters the control path reads are updated in place.
+    mid_period_steps: untimed extra steps after the timed region, so that the final model is mid-period (tail / window not
+    just refitted) for the parity checks.
+
+    Returns (report, final): final = dict(rows = the raw observation rows each instance's model holds, oldest first
+    (X, UH, Y, jitter [Bt, N, .]), posterior = (Mk, Bk) of the final model at `xq_check`, xq_check, hyper-parameters; states
+    (record_states): the visited (x_t, u_t) of every step)."""
+    import time
+    from .synthetic import make_instances, make_unicycle_task
+    dev = torch.device(device)
+    n, m = 3, 2
+    if schedule not in ("reference", "online_tail"):
+        raise ValueError("schedule: 'reference' or 'online_tail'")
+    if steps % refit_every or steps <= 0:
+        raise ValueError("steps must be a positive multiple of refit_every")
+    if fit_iters and schedule != "reference":
+        raise ValueError("fit_iters: the hyper-parameter fit rides on the reference schedule's refits")
+    online = schedule == "online_tail"
+    window = max_train - refit_every if online else max_train
+    if window < 1:
+        raise ValueError("max_train must exceed refit_every")
+    if warmup is None:
+        warmup = window + refit_every
+    warmup = -(-warmup // refit_every) * refit_every
+    total = warmup + steps + int(mid_period_steps)
+    Ntot = window + total + 1
+    p = make_instances(Bt, window, n, m, dtype=dtype, device=dev, seed=seed, variant="theta" if shift_invariant else "dense")
+    task = make_unicycle_task(Bt, dtype=dtype, device=dev, seed=seed + 99)
+    f = dict(dtype=dtype, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 7)
+    # the observation stream of every instance: rows 0 .. window-1 = the synthetic start, row window + t = step t's observation
+    Xall, UHall, Yall = torch.zeros(Bt, Ntot, n, **f), torch.zeros(Bt, Ntot, 1 + m, **f), torch.zeros(Bt, Ntot, n, **f)
+    # make_psd's draws (:907-910): reference schedule -- the jitter every row was last factored with (filled in per refit); online --
+    # one rand per step, scaled by the instance's level when the point enters
+    Jall = torch.rand(Bt, Ntot, generator=gen, **f).contiguous()
+    Jall[:, :window] = p["jitter"]
+    Xall[:, :window], UHall[:, :window], Yall[:, :window] = p["X"], p["UH"], p["Xdot"]
+    x = task["x"].clone()
+    # the planner's target moves along the straight line start -> goal at constant speed and reaches the goal when the run ends
+    # (PiecewiseLinearPlanner, planner.py:54-64); the solve / plant launch advances it (flags bit 1)
+    task["dot_plan"] = ((task["xg"] - task["x"]) / (total * dt)).contiguous()
+    task["plan"] = (task["x"] + 20 * dt * task["dot_plan"]).contiguous()        # (a look-ahead: at the state itself the CLF's polar terms are singular)
+    L_true, L_mean = 1.0, 4.0
+    base, rem = divmod(Bt, parts)
+    bounds = [(c * base + min(c, rem), (c + 1) * base + min(c + 1, rem)) for c in range(parts)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(parts)]
+    cur = torch.cuda.current_stream(dev)
+    ws = ops.control_workspace(Bt, 2, dtype, dev)
+    rnd = lambda *shape: torch.rand(*shape, generator=gen, **f)
+    tkeys = ops.ConcurrentControlLoop.TASK_INSTANCE_KEYS
+    offsets = [(c * refit_every) // parts if stagger else 0 for c in range(parts)]
+    hyper = {k: p[k] for k in ("ell", "s2", "Bm", "M0", "A")}                       # updated in place by the fit
+    xs_log, us_log = ([], []) if record_states else (None, None)
+
+    class Part:
+        pass
+    P = []
+    for c in range(parts):
+        lo, hi = bounds[c]
+        sl = slice(lo, hi)
+        pt = Part()
+        pt.sl, pt.Bt = sl, hi - lo
+        pt.X, pt.UH, pt.Y, pt.J = Xall[sl], UHall[sl], Yall[sl], Jall[sl]             # contiguous [Bt_c, Ntot, .] views
+        pt.hp = {k: v[sl] for k, v in hyper.items()}
+        pt.x = x[sl]
+        pt.n_refits = 0
+        # the learned model's query: the shift-invariant input of the current state, kept by the solve / plant launch (xq_next)
+        pt.xq = None
+        if query_shift_invariant and shift_invariant:
+            pt.xq = pt.x.clone()
+            pt.xq[:, :2] = 0
+        obs_kw = dict(xq=pt.xq, xq_next=pt.xq, shift_invariant=shift_invariant, advance_plan=True)
+        taskc = {k: (v[sl] if (torch.is_tensor(v) and k in tkeys) else v) for k, v in task.items()}
+        wsc = {k: v[sl] for k, v in ws.items()}
+        pt.ws = wsc
+        streams[c].wait_stream(cur)
+        with torch.cuda.stream(streams[c]):
+            cutw = lambda t_: t_[:, :window].contiguous()
+            Xw, UHw, Yw, Jw = cutw(pt.X), cutw(pt.UH), cutw(pt.Y), cutw(pt.J)
+            E = ops.lop_elems(window, dtype)
+            mk = lambda: dict(Lop=torch.empty(pt.Bt, E, **f), UHB=torch.empty(pt.Bt, window, 1 + m, **f), Vw=torch.empty(pt.Bt, window, n, **f),
+                              X=torch.empty(pt.Bt, window, n, **f))
+            pt.info, pt.info2 = torch.zeros(pt.Bt, dtype=torch.int32, device=dev), torch.zeros(pt.Bt, dtype=torch.int32, device=dev)
+            pt.fail_count = torch.zeros((), dtype=torch.int64, device=dev)
+            pt.level = torch.full((pt.Bt,), 1e-5, **f)                 # make_psd's level per instance (x10 per failed attempt)
+            pt.retry_counts = torch.zeros(retry_levels + 1, dtype=torch.int64, device=dev)
+
+            def factor_into(buf, Xw, UHw, Yw, Jw, pt=pt):
+                ops.refit_with_retries(Xw, UHw, pt.hp["Bm"], pt.hp["ell"], pt.hp["s2"], Jw, (buf["Lop"], buf["UHB"], pt.info),
+                                       levels=retry_levels, scratch=pt.info2, level=pt.level, counts=pt.retry_counts)
+                ops.potrs(buf["Lop"], Yw, UHw, pt.hp["M0"], want_alpha=False, out_Vw=buf["Vw"])
+                buf["X"].copy_(Xw)
+                pt.fail_count += (pt.info != 0).sum()
+            pt.factor_into = factor_into
+            if online:
+                b0 = mk()
+                factor_into(b0, Xw, UHw, Yw, Jw)
+                # stagger: part c starts `offset` rows into its period (N_init = window + offset): its drops come that much earlier
+                pt.rgp = ops.ReservedGP(b0["Lop"], b0["Vw"], Xw, b0["UHB"], pt.hp["ell"], pt.hp["s2"], pt.hp["Bm"], pt.hp["M0"],
+                                        window + refit_every, window=window, drop=refit_every, UH=UHw, Xdot=Yw, jitter=Jw, tail=True,
+                                        retry_levels=retry_levels)
+                pt.rgp.level_decay_every = level_decay_every
+                pt.obs = [tuple(torch.zeros(pt.Bt, 3, **f) for _ in range(3)) for _ in range(2)]
+                pt.solve = ops.unicycle_control_step_prepare(dict(A=pt.hp["A"]), taskc, wsc, pt.x, dt=dt, L_true=L_true, L_mean=L_mean,
+                                                             clf_gamma=10.0, max_iters=20, stream=streams[c],
+                                                             observe=obs_kw)
+            else:
+                pt.bufs = [mk(), mk()]
+                factor_into(pt.bufs[0], Xw, UHw, Yw, Jw)
+                pt.cur = 0
+                pt.step = [ops.unicycle_control_step_prepare(dict(b_, **pt.hp), taskc, wsc, pt.x, dt=dt, L_true=L_true, L_mean=L_mean,
+                                                             clf_gamma=10.0, max_iters=20, stream=streams[c],
+                                                             observe=obs_kw)
+                           for b_ in pt.bufs]
+                pt.lo = 0
+                if fit_iters:
+                    from .batched_fit import BatchedHyperFit
+                    pt.bf = BatchedHyperFit.from_values(pt.hp["A"], pt.hp["Bm"], pt.hp["ell"], pt.hp["s2"], pt.hp["M0"], dtype=fit_dtype)
+        P.append(pt)
+    for s_ in streams:
+        s_.synchronize()
+    if online:
+        # bootstrap: the first append needs an observation -- one control step on the start model (posterior, solve + observe)
+        for c, pt in enumerate(P):
+            with torch.cuda.stream(streams[c]):
+                pt.q = pt.xq if pt.xq is not None else pt.x
+                pt.rgp.posterior(pt.q, out=(pt.ws["Mk"], pt.ws["Bk"]))
+                pt.solve(obs=(*pt.obs[0], 1))
+                # stagger the parts' drops: part c enters `offset` more observations before the loop (untimed)
+                for k in range(offsets[c]):
+                    o = pt.obs[k % 2]
+                    pt.rgp.append(o[0], o[1], o[2], pt.rgp.jitter_level * pt.J[:, window + total - 1 - k], query=pt.q, out=(pt.ws["Mk"], pt.ws["Bk"]))
+                    pt.solve(obs=(*pt.obs[(k + 1) % 2], 1))
+                pt.k0 = offsets[c]
+        for s_ in streams:
+            s_.synchronize()
+    E_ = lambda: torch.cuda.Event(enable_timing=True)
+    evp = [[(E_(), E_()) for _ in range(parts)] for _ in range(total)]
+    evr = {}
+    for row in evp:
+        for c, (a_, b_) in enumerate(row):
+            a_.record(streams[c]); b_.record(streams[c])
+    ev_base = E_()
+    refit_log = []
+
+    def do_refit(c, pt, t):
+        """Part c, after step t: refactor the last `window` observations into the buffer that is not being read; swap."""
+        lo = t + 1
+        cutw = lambda t_: t_[:, lo:lo + window].contiguous()
+        Xw, UHw, Yw = cutw(pt.X), cutw(pt.UH), cutw(pt.Y)
+        # a fresh jitter draw per factorisation, at the instance's level: one below the one that last worked (make_psd, :903-919)
+        pt.n_refits += 1
+        if level_decay_every and pt.n_refits % level_decay_every == 0:
+            pt.level.div_(10).clamp_(min=1e-5)
+        Jw = (pt.level[:, None] * rnd(pt.Bt, window)).contiguous()
+        if fit_iters:
+            wd = fit_dtype
+            pt.bf.fit(Xw.to(wd), UHw[:, :, 1:].to(wd).contiguous(), Yw.to(wd), training_iter=fit_iters, lr=fit_lr)
+            hp = pt.bf.derive()
+            for k in ("ell", "s2", "Bm", "M0", "A"):
+                pt.hp[k].copy_(hp[k].to(dtype))
+        nxt = 1 - pt.cur
+        pt.factor_into(pt.bufs[nxt], Xw, UHw, Yw, Jw)
+        pt.J[:, lo:lo + window] = Jw                                  # the level every point was finally factored with
+        pt.cur, pt.lo = nxt, lo
+
+    t0 = None
+    for t in range(total):
+        if t == warmup:
+            if barrier is not None:
+                barrier()
+            torch.cuda.synchronize(dev)
+            ev_base.record(streams[0])
+            t0 = time.perf_counter()
+        if t == warmup + steps:
+            torch.cuda.synchronize(dev)
+            if barrier is not None:
+                barrier()
+            elapsed = time.perf_counter() - t0
+        if record_states:
+            torch.cuda.synchronize(dev)
+            xs_log.append(x.clone())
+        for c, pt in enumerate(P):
+            row = window + t
+            if online:
+                with torch.cuda.stream(streams[c]):
+                    k = pt.k0 + t
+                    o_prev, o_next = pt.obs[k % 2], pt.obs[(k + 1) % 2]
+                    drops_before = pt.rgp.drops
+                    evp[t][c][0].record(streams[c])
+                    jit = pt.rgp.jitter_level * pt.J[:, row]                  # (J holds rand draws here: the new point's jitter at the instance's level)
+                    pt.rgp.append(o_prev[0], o_prev[1], o_prev[2], jit, query=pt.q, out=(pt.ws["Mk"], pt.ws["Bk"]))
+                    evp[t][c][1].record(streams[c])
+                    pt.solve(obs=(*o_next, 1))
+                    if pt.rgp.drops != drops_before:
+                        refit_log.append((t, c))
+            else:
+                pt.step[pt.cur](evp[t][c][0], evp[t][c][1], obs=(pt.X[:, row], pt.UH[:, row], pt.Y[:, row], Ntot))
+                if (t + 1 - offsets[c]) % refit_every == 0 and t + 1 >= refit_every:
+                    with torch.cuda.stream(streams[c]):
+                        a_, b_ = E_(), E_()
+                        a_.record(streams[c])
+                        do_refit(c, pt, t)
+                        b_.record(streams[c])
+                        evr[(t, c)] = (a_, b_)
+                    refit_log.append((t, c))
+        if record_states:
+            torch.cuda.synchronize(dev)
+            # the control that was APPLIED: the program's solution, or zero for an instance whose program was not solved (frozen)
+            us_log.append(torch.where((ws["status"] == 0)[:, None], ws["y"][:, :2], torch.zeros_like(ws["y"][:, :2])))
+    torch.cuda.synchronize(dev)
+    if total == warmup + steps:
+        if barrier is not None:
+            barrier()
+        elapsed = time.perf_counter() - t0
+    timed = range(warmup, warmup + steps)
+    spans = sorted((ev_base.elapsed_time(a_), ev_base.elapsed_time(b_)) for t in timed for a_, b_ in evp[t])
+    busy, ca, cb = 0.0, spans[0][0], spans[0][1]
+    for a_, b_ in spans[1:]:
+        if a_ > cb:
+            busy += cb - ca
+            ca, cb = a_, b_
+        else:
+            cb = max(cb, b_)
+    busy += cb - ca
+    rts = [evr[k][0].elapsed_time(evr[k][1]) for k in evr if warmup <= k[0] < warmup + steps]
+    isz = p["X"].element_size()
+    n_refits = sum(1 for (t, c) in refit_log if warmup <= t < warmup + steps)
+    report = dict(schedule=schedule, data="loop", batch=Bt, parts=parts, stagger=bool(stagger), max_train=max_train, points_after_refit=window,
+                  steps=steps, warmup=warmup, refit_every=refit_every, dt=dt, shift_invariant=bool(shift_invariant), dtype=str(dtype),
+                  retry_levels=retry_levels, query_shift_invariant=bool(query_shift_invariant and shift_invariant), fit_iters=fit_iters, seconds=elapsed, ms_per_step=elapsed / steps * 1e3,
+                  instance_steps_per_s=Bt * steps / elapsed, part_refits_in_timed_region=n_refits,
+                  pass_busy_ms_per_step=busy / steps, refit_ms_per_part_refit=(sum(rts) / len(rts)) if rts else None,
+                  refit_failures_after_retries=int(sum(int(pt.fail_count) for pt in P)) + (sum(g.rgp.count_drop_failures() for g in P) if online else 0),
+                  instances_factored_per_retry_level=[int(v) for v in sum((pt.rgp.retry_counts if online else pt.retry_counts) for pt in P).tolist()],
+                  jitter_level_max=float(max(float((pt.rgp.jitter_level if online else pt.level).max()) for pt in P)),
+                  solver_optimal_fraction=float((ws["status"] == 0).float().mean()))
+    if not online:
+        pass_bytes = isz * (window * (window + 1) // 2 + 2 * window * n + window * (1 + m)) * Bt
+        report["roofline"] = {"pass": dict(bound="hbm", kernel="posterior_step_kernel<%s, 3, 4, 0, 1, false, 0>" % ("float" if isz == 4 else "double"),
+                                           algorithmic_bytes_per_step=pass_bytes, achieved=pass_bytes / (busy / steps * 1e-3) / 1e9, peak=8000.0,
+                                           unit="GB/s", frac=pass_bytes / (busy / steps * 1e-3) / 1e9 / 8000.0, traffic=None,
+                                           note="union of the part batches' pass intervals (HIP events on their streams); a part's refit on its own "
+                                                "stream runs beside the other parts' passes and slows them -- this is the loop's rate, not the kernel's alone")}
+    # ---- the final model, for the parity checks
+    final = dict(hyper={k: v.clone() for k, v in hyper.items()}, xq_check=p["xq"], x=x, ws=ws)
+    rowsX, rowsUH, rowsY, rowsJ, Mks, Bks = [], [], [], [], [], []
+    for c, pt in enumerate(P):
+        xqc = p["xq"][pt.sl].contiguous()
+        with torch.cuda.stream(streams[c]):
+            if online:
+                g = pt.rgp
+                rowsX.append(g.X[:, :g.N].clone()); rowsUH.append(g._rUH[:, :g.N].clone())
+                rowsY.append(g._rY[:, :g.N].clone()); rowsJ.append(g._rJ[:, :g.N].clone())
+                Mk, Bk = g.posterior(xqc)
+            else:
+                sl_ = slice(pt.lo, pt.lo + window)
+                rowsX.append(pt.X[:, sl_].clone()); rowsUH.append(pt.UH[:, sl_].clone())
+                rowsY.append(pt.Y[:, sl_].clone()); rowsJ.append(pt.J[:, sl_].clone())
+                b_ = pt.bufs[pt.cur]
+                Mk, Bk = ops.posterior_step(b_["Lop"], b_["Vw"], b_["X"], b_["UHB"], pt.hp["ell"], pt.hp["s2"], pt.hp["Bm"], pt.hp["M0"], xqc)
+            Mks.append(Mk); Bks.append(Bk)
+    torch.cuda.synchronize(dev)
+    final["rows"] = [dict(X=rowsX[c], UH=rowsUH[c], Y=rowsY[c], jitter=rowsJ[c]) for c in range(parts)]   # (parts may hold different N)
+    final["bounds"] = bounds
+    final["posterior"] = (torch.cat(Mks, 0), torch.cat(Bks, 0))
+    final["stream_rows"] = dict(X=Xall, UH=UHall, Y=Yall, jitter=Jall, window=window)
+    if record_states:
+        final["states"] = dict(x=torch.stack(xs_log, 1), u=torch.stack(us_log, 1))
+    return report, final
+
+
+def final_model_vs_fp64_refit(final, sample=64):
+    """Self-check of `self_learning_closed_loop`'s final model: per part, a from-scratch fp64 refit ON THE DEVICE of the rows the
+    model holds (with the jitter every point ended up with) against the model's own posterior at `xq_check`; max deviation over
+    `sample` instances per part, relative to max(1, |M_k|) and the prior scale.  (The CPU-oracle check lives in tests/.)"""
+    hyper, xq = final["hyper"], final["xq_check"]
+    Mk_all, Bk_all = final["posterior"]
+    worst = dict(Mk=0.0, Bk=0.0, refit_failures=0, instances=0)
+    f64 = lambda t: t.double().contiguous()
+    for (lo, hi), rows in zip(final["bounds"], final["rows"]):
+        Bt = hi - lo
+        idx = torch.linspace(0, Bt - 1, min(sample, Bt), device=xq.device).long()
+        hp = {k: f64(hyper[k][lo:hi][idx]) for k in ("Bm", "ell", "s2", "M0")}
+        X, UH, Y, J = (f64(rows[k][idx]) for k in ("X", "UH", "Y", "jitter"))
+        Lr, UHBr, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], J)
+        Vr, _ = ops.potrs(Lr, Y, UH, hp["M0"], want_alpha=False)
+        Mr, Br = ops.posterior_step(Lr, Vr, X, UHBr, hp["ell"], hp["s2"], hp["Bm"], hp["M0"], f64(xq[lo:hi][idx]))
+        prior = (hp["s2"][:, None, None] * hp["Bm"]).abs().amax(dim=(1, 2))
+        ok = info == 0
+        worst["refit_failures"] += int((~ok).sum())
+        worst["instances"] += int(idx.numel())
+        if bool(ok.any()):
+            dM = ((f64(Mk_all[lo:hi][idx]) - Mr).abs().amax(dim=(1, 2)) / Mr.abs().amax(dim=(1, 2)).clamp(min=1.0))[ok].max()
+            dB = ((f64(Bk_all[lo:hi][idx]) - Br).abs().amax(dim=(1, 2)) / prior)[ok].max()
+            worst["Mk"], worst["Bk"] = max(worst["Mk"], float(dM)), max(worst["Bk"], float(dB))
+    return worst

@@ -108,6 +108,18 @@ int bcbf_refit_f32(const float* X, const float* UH, const float* Bm, const float
 int bcbf_refit_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                    const double* jitter, double* Lop, double* UHB, double* Ldense, int* info,
                    int Bt, int N, int n, int m, void* stream);
+/* make_psd's x10 jitter retry (control_affine_model.py:903-919) without a host round trip: arguments of bcbf_refit (no dense
+ * output) plus prev_info[Bt] = the info of the previous attempt (a different buffer than info).  Only instances with
+ * prev_info[b] != 0 are factored again -- with the jitter the caller has raised for them -- the others return at once and
+ * report info[b] = 0; their Lop / UHB are left as the successful attempt wrote them.  Launch it unconditionally after
+ * bcbf_refit (and again, ping-ponging the two info buffers, for further levels): a launch in which nothing failed costs
+ * microseconds, and no stream waits for the host. */
+int bcbf_refit_retry_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                         const float* jitter, float* Lop, float* UHB, const int* prev_info, int* info,
+                         int Bt, int N, int n, int m, void* stream);
+int bcbf_refit_retry_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                         const double* jitter, double* Lop, double* UHB, const int* prev_info, int* info,
+                         int Bt, int N, int n, int m, void* stream);
 
 /* K2 on a caller-supplied dense SPD matrix (lower triangle of Kb[Bt,N,N] is read): same outputs.
  * Replaces torch.linalg.cholesky (control_affine_model.py:911). */
@@ -456,6 +468,25 @@ int bcbf_predict_assemble_f64(const double* G, const double* Xq, const double* X
                               const double* Bm, const double* A, const double* jitter, double* BkXX, double* Kron, int b, int bp,
                               int n, int m, int kernel_kind, void* stream);
 
+/* Gram of whitened cross-covariances on the matrix cores: G[b,bp,C,C] = einsum("bkc,pkd->bpcd", W, Wp) for W[b,Np,C],
+ * Wp[bp,Np,C] (the W output of bcbf_posterior_query / bcbf_posterior_shared; Np = N rounded up to 32; C <= 12).  Replaces the
+ * library GEMMs `v.t() @ vp` (C = 1, control_affine_model.py:586) and `kb_star' Bdagger` (:1079-1088) of the reference's
+ * prediction path.  W == Wp (and b == bp): the symmetric half is computed once and mirrored. */
+int bcbf_gram_f32(const float* W, const float* Wp, float* G, int b, int bp, int Np, int C, void* stream);
+int bcbf_gram_f64(const double* W, const double* Wp, double* G, int b, int bp, int Np, int C, void* stream);
+/* ControlAffineRegressorExact.custom_predict_fullmat (control_affine_model.py:963-980) behind a cached factor, ONE host call:
+ * bcbf_posterior_query(shared = 1, W) -> bcbf_gram -> bcbf_predict_assemble on `stream`.  GP tensors of one model (leading axis
+ * 1), A[n,n], Xq[b,n], jitter[b(1+m)] (the make_psd draw, may be NULL) -> Mk[b,n,1+m], and BkXX[b,b,1+m,1+m] and / or
+ * Kron[b(1+m)n, b(1+m)n]; Bk[b,1+m,1+m], W[b,Np,1+m], G[b,b,1+m,1+m] are caller-provided work arrays (kept as outputs). */
+int bcbf_predict_fullmat_f32(const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell,
+                             const float* s2, const float* Bm, const float* M0, const float* A, const float* Xq,
+                             const float* jitter, float* Mk, float* Bk, float* W, float* G, float* BkXX, float* Kron, int b,
+                             int N, int n, int m, int kernel_kind, void* stream);
+int bcbf_predict_fullmat_f64(const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell,
+                             const double* s2, const double* Bm, const double* M0, const double* A, const double* Xq,
+                             const double* jitter, double* Mk, double* Bk, double* W, double* G, double* BkXX, double* Kron,
+                             int b, int N, int n, int m, int kernel_kind, void* stream);
+
 /* Posterior jets: value and first x-derivatives of the posterior factors (one query per instance, or per
  * query of a shared GP).  CT = (1+m)(1+n) right-hand sides [Phi, dPhi/dx_1 .. dPhi/dx_n] of the same stream:
  *   G[Bt,CT,CT] = Wj'Wj,  Mj[Bt,n,CT] = Vw'Wj   (Mk = M0' + Mj[:, :C]; dMk/dx_d = Mj[:, (1+d)C:(2+d)C]),
@@ -652,6 +683,39 @@ int bcbf_unicycle_control_step_f64(
     const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
     double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
     int N, int Kob, int max_iters, int shared_gp, void* ev_start, void* ev_stop, void* stream);
+/* The control step of a loop that LEARNS FROM ITSELF (LearnedShiftInvariantDynamics.train / fit,
+ * unicycle_move_to_pose.py:326-386: every visited (x_t, u_t) is buffered; targets are the finite differences
+ * (x_{t+1} - x_t) / dt of the visited states minus the mean model f_mean + g_mean u; inputs go through
+ * `_make_trans_invariant`, :326-330).  Arguments of bcbf_unicycle_control_step, plus
+ *   xq[Bt,3]      where the posterior is queried (NULL: at x) -- the shift-invariant input (0, 0, theta) of the current state;
+ *   obs_x, obs_uh, obs_y  (all three or none; need dt > 0): THIS step's observation, row b * obs_ld of three-column arrays
+ *                 (obs_ld = 1: a [Bt,3] array; obs_ld = rows per instance: a column of a [Bt,obs_ld,3] buffer) --
+ *                 obs_x = the state BEFORE the step ((0, 0, theta) when shift_invariant != 0), obs_uh = (1, u) (u = 0 where the
+ *                 program was not solved: that instance's state is frozen), obs_y = (x_new - x_old) / dt - g_mean(L_mean) u
+ *                 computed from the STORED (rounded) states as the reference's buffer does;
+ *   xq_next[Bt,3] (optional): the regressor input at the NEW state = the next step's xq (may be the same buffer as xq);
+ *   flags         bit 0: shift-invariant regressor inputs (obs_x, xq_next); bit 1: the planner's target moves on with the step,
+ *                 plan[b] += dot_plan[b] dt (PiecewiseLinearPlanner, planner.py:54-64: a straight line at constant speed) --
+ *                 `plan` is then written, although it is declared const for the entry points that only read it.
+ * The rows go to bcbf_gp_append_reserved[_raw] / bcbf_gp_tail_step / the next bcbf_refit as they are. */
+int bcbf_unicycle_control_step_observe_f32(
+    const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+    const float* Bm, const float* M0, const float* A, float* x, const float* plan, const float* dot_plan,
+    const float* Kp, float clf_gamma, const float* centers, const float* radii, const float* tw, const float* gammas,
+    float L_mean, const float* w, const float* r, const float* sign, const float* relax_mask, const float* rho,
+    float* grad, float* cst, float* fhat, float* ghat, float* Mk, float* Bk, float* cones, int* cstatus,
+    float* y, int* status, int* iters, float dt, float L_true, int Bt, int N, int Kob, int max_iters, int shared_gp,
+    const float* xq, float* obs_x, float* obs_uh, float* obs_y, int obs_ld, float* xq_next, int flags,
+    void* ev_start, void* ev_stop, void* stream);
+int bcbf_unicycle_control_step_observe_f64(
+    const double* Lop, const double* Vw, const double* X, const double* UHB, const double* ell, const double* s2,
+    const double* Bm, const double* M0, const double* A, double* x, const double* plan, const double* dot_plan,
+    const double* Kp, double clf_gamma, const double* centers, const double* radii, const double* tw,
+    const double* gammas, double L_mean, const double* w, const double* r, const double* sign,
+    const double* relax_mask, const double* rho, double* grad, double* cst, double* fhat, double* ghat, double* Mk,
+    double* Bk, double* cones, int* cstatus, double* y, int* status, int* iters, double dt, double L_true, int Bt,
+    int N, int Kob, int max_iters, int shared_gp, const double* xq, double* obs_x, double* obs_uh, double* obs_y,
+    int obs_ld, double* xq_next, int flags, void* ev_start, void* ev_stop, void* stream);
 /* The same control step on a model learned with the opt-in Matern-5/2 data kernel (bcbf_refit_matern52 /
  * bcbf_gp_append_matern52 states): identical arguments; the posterior launch evaluates the Matern kernel (one GP per
  * instance: the streaming kernel; shared_gp: the matrix-core query bcbf_posterior_shared_matern52), the fused task rows /
