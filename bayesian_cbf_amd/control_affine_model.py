@@ -736,7 +736,9 @@ class ControlAffineRegressor:
             Wp = W
         v = torch.einsum("bnc,bc->bn", W, UHtest)            # L^-1 kb*(x, u)
         vp = torch.einsum("bnc,bc->bn", Wp, UHtestp)
-        sv = self._prior_knl(Xtest, Xtestp) * (UHtest @ B @ UHtestp.t()) - v @ vp.t()
+        # v' vp on the matrix cores (bcbf_gram with one column per query; the reference's `v.t() @ vp`, :586)
+        vtv = ops.gram(v.contiguous()[:, :, None], vp.contiguous()[:, :, None]).reshape(v.shape[0], vp.shape[0])
+        sv = self._prior_knl(Xtest, Xtestp) * (UHtest @ B @ UHtestp.t()) - vtv
         return mean, (sv if scalar_var_only else torch_kron(sv, A)[None])
 
     def predict(self, Xtest_in, return_cov=True):
@@ -755,7 +757,7 @@ class ControlAffineRegressor:
             _, Mk, _, W = self._query(Xtest, want_W=return_cov)
             mean = Mk.transpose(-2, -1)
             if return_cov:
-                Bk = self._prior_knl(Xtest, Xtest)[:, :, None, None] * B - torch.einsum("bnc,pnd->bpcd", W, W)
+                Bk = self._prior_knl(Xtest, Xtest)[:, :, None, None] * B - ops.gram(W)
         mean = mean.to(device=Xtest_in.device, dtype=Xtest_in.dtype) if isinstance(Xtest_in, torch.Tensor) else mean
         if not return_cov:
             return mean
@@ -868,21 +870,15 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
             return mean, A, B * self._prior_knl(Xtest, Xtestp)[:, :, None, None]
         # (deferred: the refit's jitter level is chosen on the device; the host only needs it for the random stream, which the
         #  make_psd draw below is the next to touch -- everything up to there is queued without waiting for the factorisation)
-        st, Mk, Bk, W = self._query(Xtest, want_W=compute_cov, defer=True)
-        if not compute_cov:
-            if not self._resolve_pending(st):
-                return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov)
-            return Mk, A, Xtest.new_zeros(b, bp, C, C)
-        Wp = W if Xtestp_in is None else self._query(Xtestp, want_W=True, defer=True)[3]
-        if fused_kron and b == bp and b * C > 32:
-            # query sets beyond one 32 x 32 tile (the first make_psd draw is kept unchecked there, see below): prior kernel, the
-            # subtraction of W'W and the Kronecker product with A in ONE launch (bcbf_predict_assemble) instead of ~20, queued behind the query
-            # without waiting for the factorisation; the jitter diagonal follows once the pending level is known (the draw is
-            # the next use of the random stream after it)
-            G = torch.einsum("bnc,pnd->bpcd", W, Wp).contiguous()
-            _, kron = ops.predict_assemble(G, Xtest.contiguous(), Xtestp.contiguous(), hp["ell"].reshape(-1), hp["s2"],
-                                           B.contiguous(), A.contiguous(), None, want_BkXX=False, want_kron=True,
-                                           kernel=self.data_kernel)
+        if compute_cov and fused_kron and Xtestp_in is None and b * C > 32:
+            # query sets beyond one 32 x 32 tile (the first make_psd draw is kept unchecked there, see below): the shared-model query,
+            # the Gram of its whitened cross-covariances on the matrix cores, prior kernel, subtraction and the Kronecker product with A
+            # in ONE host call (bcbf_predict_fullmat: three launches) instead of ~25 torch launches, queued behind the refit without
+            # waiting for the factorisation; the jitter diagonal follows once the pending level is known (the draw is the next use
+            # of the random stream after it)
+            st = self._state(defer=True)
+            Mk, _, kron = ops.predict_fullmat(st["Lop"], st["Vw"], st["X"], st["UHB"], st["ell"], st["s2"], st["Bm"], st["M0"],
+                                              A.contiguous(), Xtest.contiguous(), None, want_kron=True, kernel=self.data_kernel)
             if not self._resolve_pending(st):
                 return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov, fused_kron)
             jit = 1e-5 * self.rand_fn(b * C)
@@ -890,8 +886,13 @@ class ControlAffineRegressorExact(ControlAffineRegressor):
             blocks = kron.view(b * C, n, b * C, n).diagonal(dim1=0, dim2=2)        # [n, n, b C]: the diagonal n x n blocks (a view)
             blocks += A[:, :, None] * jit[None, None, :]
             return Mk, A, kron
-        BkXX = (self._prior_knl(Xtest, Xtestp)[:, :, None, None] * B
-                - torch.einsum("bnc,pnd->bpcd", W, Wp))
+        st, Mk, Bk, W = self._query(Xtest, want_W=compute_cov, defer=True)
+        if not compute_cov:
+            if not self._resolve_pending(st):
+                return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov)
+            return Mk, A, Xtest.new_zeros(b, bp, C, C)
+        Wp = W if Xtestp_in is None else self._query(Xtestp, want_W=True, defer=True)[3]
+        BkXX = self._prior_knl(Xtest, Xtestp)[:, :, None, None] * B - ops.gram(W, None if Wp is W else Wp)
         if not self._resolve_pending(st):                 # all speculative levels failed (rare): start over on the rebuilt state
             return self._custom_predict_matrix(Xtest_in, Xtestp_in, compute_cov)
         # make_psd(BkXX) on the [b(1+m)] x [b'(1+m)] matrix: 1e-5 * rand on its diagonal (:1089, :907-910)
