@@ -107,10 +107,11 @@ class BatchedHyperFit:
         C = Bm.shape[1]
 
         def fac(S):
-            S = S.double()
+            dev = S.device
+            S = S.double().cpu()                          # (k x k factorisations, k <= 8: on the host, like set_kernel_params)
             eps = 1e-10 * S.diagonal(dim1=1, dim2=2).mean(dim=1)
-            L = torch.linalg.cholesky(S - eps[:, None, None] * torch.eye(S.shape[1], dtype=S.dtype, device=S.device))
-            return L.reshape(Bt, -1), _inv_softplus(eps[:, None].expand(Bt, S.shape[1]))
+            L = torch.linalg.cholesky(S - eps[:, None, None] * torch.eye(S.shape[1], dtype=S.dtype))
+            return L.reshape(Bt, -1).to(dev), _inv_softplus(eps[:, None].expand(Bt, S.shape[1])).to(dev)
         Wa, va = fac(A)
         Wb, vb = fac(Bm)
         theta = torch.cat([_inv_softplus(ell), _inv_softplus(s2).reshape(Bt, 1), Wa, va, Wb, vb, M0.double().reshape(Bt, -1)], dim=1)

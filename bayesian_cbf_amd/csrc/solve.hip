@@ -199,6 +199,9 @@ static int launch_potrs(const T* Lop, const T* Xdot, const T* UH, const T* M0, T
     return check_launch("potrs");
 }
 
+int launch_trtri_mfma_f32(const float* Lop, float* Linv, int Bt, int N, void* stream);       // trtri.hip
+int launch_trtri_mfma_f64(const double* Lop, double* Linv, int Bt, int N, void* stream);
+
 template <typename T>
 static int launch_potri(const T* Lop, T* Kinv, int Bt, int N, void* stream, int forward_only = 0) {
     if (Bt <= 0) return BCBF_OK;
@@ -667,13 +670,23 @@ int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream) {
 int bcbf_potri_f64(const double* Lop, double* Kinv, int Bt, int N, void* stream) {
     return bcbf::launch_potri<double>(Lop, Kinv, Bt, N, stream);
 }
-// Dense inverse of the factor itself, Linv[Bt,N,N] = L^-1 (lower triangular): the forward half of bcbf_potri (whose
-// backward half is 32 workgroup reductions per block: 2 ms at N = 512).  K_b^-1 = Linv' Linv is then one GEMM.
+// Dense inverse of the factor itself, Linv[Bt,N,N] = L^-1 (lower triangular).  Batches: the blocked matrix-core form (trtri.hip:
+// one wave per block column, N^3 / 3 flops per model on 32 x 32 tiles).  A handful of models: the forward half of bcbf_potri
+// (N / 8 workgroups per model, each a forward solve of 8 identity columns -- more parallel for ONE model, N / 8 passes over the
+// factor each).  K_b^-1 = Linv' Linv is then bcbf_syrk_lt.  BCBF_TRTRI_SOLVE=1 forces the solve form (development).
 int bcbf_trtri_f32(const float* Lop, float* Linv, int Bt, int N, void* stream) {
-    return bcbf::launch_potri<float>(Lop, Linv, Bt, N, stream, 1);
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !Linv || N < 1) return BCBF_EINVAL;
+    static const bool solve = [] { const char* e = getenv("BCBF_TRTRI_SOLVE"); return e && e[0] == '1'; }();
+    if (Bt < 4 || solve) return bcbf::launch_potri<float>(Lop, Linv, Bt, N, stream, 1);
+    return bcbf::launch_trtri_mfma_f32(Lop, Linv, Bt, N, stream);
 }
 int bcbf_trtri_f64(const double* Lop, double* Linv, int Bt, int N, void* stream) {
-    return bcbf::launch_potri<double>(Lop, Linv, Bt, N, stream, 1);
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop || !Linv || N < 1) return BCBF_EINVAL;
+    static const bool solve = [] { const char* e = getenv("BCBF_TRTRI_SOLVE"); return e && e[0] == '1'; }();
+    if (Bt < 4 || solve) return bcbf::launch_potri<double>(Lop, Linv, Bt, N, stream, 1);
+    return bcbf::launch_trtri_mfma_f64(Lop, Linv, Bt, N, stream);
 }
 int bcbf_gp_append_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
                        const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,

@@ -150,7 +150,7 @@ def test_learning_loop_two_ranks_and_through_bench_py():
     """The learning closed loop harness (`bench.py --config learn` = tools/bench_learning_loop.py) with two ranks (weak scaling:
     `--batch` instances per rank, no collective inside the loop, times = the slowest rank's) and with one rank through bench.py;
     both schedules; the line carries the shares and a roofline entry per kernel."""
-    args = ["--batch", "16", "--max-train", "96", "--steps", "16", "--warmup", "8", "--refit-every", "8", "--dtype", "f64"]
+    args = ["--data", "synthetic", "--batch", "16", "--max-train", "96", "--steps", "16", "--warmup", "8", "--refit-every", "8", "--dtype", "f64"]
     two = _run_script(os.path.join("tools", "bench_learning_loop.py"), ["--gpus", "2"] + args, TWO_RANKS_ONE_DEVICE)
     assert two["n_gpus"] == 2 and two["comm"]["world_size"] == 2 and two["scaling"] == "weak" and two["batch"] == 16
     assert two["append_or_refit_failures"] == 0 and two["shares"]["refits_in_timed_region"] == 2
@@ -164,3 +164,13 @@ def test_learning_loop_two_ranks_and_through_bench_py():
     inp = _run_script(os.path.join("tools", "bench_learning_loop.py"), ["--schedule", "online", "--parts", "2"] + args, {})
     assert inp["schedule"] == "online" and inp["parts"] == 2 and inp["append_or_refit_failures"] == 0
     assert inp["final_vs_fp64_refit_on_device"]["Mk"] < 1e-8 and inp["final_vs_fp64_refit_on_device"]["Bk"] < 1e-8
+    # the loop that learns from ITSELF (the tool's default data): two ranks, and one rank through bench.py with a hyper-parameter fit
+    largs = ["--batch", "16", "--max-train", "96", "--steps", "16", "--refit-every", "8", "--dtype", "f64", "--parts", "2"]
+    two = _run_script(os.path.join("tools", "bench_learning_loop.py"), ["--gpus", "2", "--schedule", "reference"] + largs, TWO_RANKS_ONE_DEVICE)
+    assert two["n_gpus"] == 2 and two["data"].endswith("(x_t, u_t, x_t+1)") and two["schedule"] == "reference" and two["stagger"]
+    assert two["append_or_refit_failures"] == 0 and two["warmup"] >= 96 and two["final_vs_fp64_refit_on_device"]["Mk"] < 1e-8
+    one = _run_script("bench.py", ["--config", "learn", "--schedule", "online_tail"] + largs, {})
+    assert one["schedule"] == "online_tail" and one["append_or_refit_failures"] == 0 and one["final_vs_fp64_refit_on_device"]["Mk"] < 1e-7
+    fit = _run_script("bench.py", ["--config", "learn", "--schedule", "reference", "--fit-iters", "3"] + largs, {})
+    assert fit["fit_iters"] == 3 and "3 Adam iterations" in fit["metric"] and fit["append_or_refit_failures"] == 0
+    assert fit["final_vs_fp64_refit_on_device"]["Mk"] < 1e-7

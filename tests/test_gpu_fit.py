@@ -175,3 +175,30 @@ def test_kinv_apply_is_the_symmetric_product():
             got = ops.kinv_apply(S, R)
             want = (S.double() @ R.double())
             assert float((got.double() - want).abs().max() / want.abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)], ids=["f64", "f32"])
+def test_trtri_on_the_matrix_cores_is_the_inverse_of_the_factor(dtype, tol):
+    """bcbf_trtri for batches (trtri.hip: one wave per block column, MFMA tiles) against the dense factor the refit hands out:
+    L Linv = I, zeros above the diagonal, and the same numbers as the solve-based form a single model takes (Bt < 4); N not a
+    multiple of 32, one block, many blocks."""
+    from bayesian_cbf_amd import ops
+    from bayesian_cbf_amd._lib import lib
+    from bayesian_cbf_amd.synthetic import make_instances
+    for Bt, N in ((5, 70), (6, 32), (4, 17), (9, 512), (7, 300)):
+        p = make_instances(Bt, N, 3, 2, dtype=dtype, device=DEV, seed=N)
+        jit = (p["jitter"] * (100 if dtype == torch.float32 else 1)).contiguous()
+        Lop, _, info, Ld = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, want_dense=True)
+        assert int((info != 0).sum()) == 0
+        Linv = torch.full((Bt, N, N), float("nan"), dtype=dtype, device=DEV)
+        ops.check(getattr(lib, "bcbf_trtri" + ops._suf(Lop))(ops._p(Lop), ops._p(Linv), Bt, N, ops._stream(Lop)), "bcbf_trtri")
+        assert bool(torch.isfinite(Linv).all())
+        assert float(torch.triu(Linv, diagonal=1).abs().max()) == 0.0
+        eye = torch.eye(N, dtype=torch.float64, device=DEV)
+        res = (Ld.double() @ Linv.double() - eye).abs().amax(dim=(1, 2))
+        cond_scale = (Linv.double().abs().amax(dim=(1, 2)) * Ld.double().abs().amax(dim=(1, 2)))
+        assert float((res / cond_scale).max()) < tol, (Bt, N, float((res / cond_scale).max()))
+        one = torch.empty(1, N, N, dtype=dtype, device=DEV)          # the solve-based form (a single model)
+        ops.check(getattr(lib, "bcbf_trtri" + ops._suf(Lop))(ops._p(Lop[2:3].contiguous()), ops._p(one), 1, N, ops._stream(Lop)), "bcbf_trtri")
+        scale = float(one.abs().max())
+        assert float((one[0] - Linv[2]).abs().max()) <= (1e-10 if dtype == torch.float64 else 2e-3) * scale
