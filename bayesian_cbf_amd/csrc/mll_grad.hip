@@ -8,6 +8,7 @@
 // plus the two small products R' alpha [n,n] and UH' alpha [C,n] the host needs for d/dA, d/dM0 and the value.
 // One workgroup per GP (a fit is one model at a time; N^2 pair terms, nothing to tile).
 #include "bcbf_common.h"
+#include <stdlib.h>
 
 namespace bcbf {
 
@@ -166,6 +167,170 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
     }
 }
 
+// Batches (round 6): the same sums with one THREAD PER ROW i and the columns j streamed through LDS in tiles.  The form above spends
+// ~300 fp64 operations per pair (every loop unrolled over the compile-time maxima -- 8 state dimensions, an 8 x 8 product with
+// A^-1 and a 4 x 4 one with B PER PAIR) and reads K_b^-1 row-wise per thread; 4096 models of 512 points took 27 ms (fp64) / 51 ms
+// (fp32 inputs), more than the factorisation.  Here the per-ROW quantities are formed once per tile -- t_j = A^-1 alpha_j,
+// v_j = B uh_j -- so a pair costs  q = alpha_i . t_j,  u_ij = uh_i . v_j,  the kernel value and  w_i += G k uh_j  (g_B = s2
+// sum_i uh_i w_i' afterwards); K_b^-1 is read through its symmetry, element (j, i), so consecutive threads read consecutive
+// addresses.  Grid (Bt, RC * JS): RC = ceil(N / 256) row chunks times JS column slices (JS > 1 only for a handful of models);
+// partial sums go to the caller's workspace and mll_reduce_kernel adds them in a fixed order (bit-identical run to run).
+// n, nt <= 4 and C <= 4 (every matrix-variate model the device path takes); no linear kernel part.
+constexpr int MR_TJ = 128;
+template <typename T>
+__global__ void __launch_bounds__(MG_T)
+mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T* __restrict__ Kinv,
+                     const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ R, const T* __restrict__ Ainv,
+                     const T* __restrict__ Bm, const T* __restrict__ ell, const T* __restrict__ s2p,
+                     T* __restrict__ logdetK, T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C, int nt,
+                     double* __restrict__ work, int kind, int RC) {
+    constexpr int V = Vec<T>::V;
+    constexpr int NS = 4, CM = BCBF_MAX_CTRL_DIM + 1;
+    constexpr int NR = BCBF_MAX_STATE_DIM + 2 + CM * CM;
+    __shared__ double xj[MR_TJ][NS], uj[MR_TJ][CM], vj[MR_TJ][CM], tj[MR_TJ][NS];
+    __shared__ double red[4][NR];
+    const int b = blockIdx.x, tid = threadIdx.x, part = blockIdx.y, G = gridDim.y;
+    const int rc = part % RC, js = part / RC, JS = G / RC;
+    const T* Xb = X + (size_t)b * N * n;
+    const T* UHb = UH + (size_t)b * N * C;
+    const T* Rb = R + (size_t)b * N * nt;
+    const T* al = alpha + (size_t)b * N * nt;
+    const T* Kib = Kinv + (size_t)b * N * N;
+    const T* lop = Lop + (size_t)b * lop_elems<V>(Np);
+    double iell[NS], Ai[NS][NS], Bl[CM][CM];
+    const double s2 = (double)s2p[b];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) {
+        iell[d] = d < n ? 1.0 / (double)ell[(size_t)b * n + d] : 0.0;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) Ai[d][e] = (d < nt && e < nt) ? (double)Ainv[((size_t)b * nt + d) * nt + e] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < CM; ++a)
+#pragma unroll
+        for (int c = 0; c < CM; ++c) Bl[a][c] = (a < C && c < C) ? (double)Bm[((size_t)b * C + a) * C + c] : 0.0;
+    // this thread's row
+    const int i = rc * MG_T + tid;
+    const bool vi = i < N;
+    double xi[NS], ui[CM], ai[NS];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) {
+        xi[d] = (vi && d < n) ? (double)Xb[(size_t)i * n + d] : 0.0;
+        ai[d] = (vi && d < nt) ? (double)al[(size_t)i * nt + d] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < CM; ++a) ui[a] = (vi && a < C) ? (double)UHb[(size_t)i * C + a] : 0.0;
+    double gl[NS], w[CM], gs = 0.0;
+#pragma unroll
+    for (int d = 0; d < NS; ++d) gl[d] = 0.0;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) w[c] = 0.0;
+    // this workgroup's columns: slice js of JS, in tiles of MR_TJ
+    const int per = ((N + JS - 1) / JS + MR_TJ - 1) / MR_TJ * MR_TJ;
+    const int jbeg = js * per, jend = min(N, jbeg + per);
+    for (int j0 = jbeg; j0 < jend; j0 += MR_TJ) {
+        __syncthreads();
+        if (tid < MR_TJ) {
+            const int j = j0 + tid;
+            const bool vj_ = j < jend;
+            double a_[NS], u_[CM];
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                xj[tid][d] = (vj_ && d < n) ? (double)Xb[(size_t)j * n + d] : 0.0;
+                a_[d] = (vj_ && d < nt) ? (double)al[(size_t)j * nt + d] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < CM; ++a) u_[a] = (vj_ && a < C) ? (double)UHb[(size_t)j * C + a] : 0.0;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                double t = 0.0;
+#pragma unroll
+                for (int e = 0; e < NS; ++e) t += Ai[d][e] * a_[e];
+                tj[tid][d] = t;
+            }
+#pragma unroll
+            for (int a = 0; a < CM; ++a) {
+                double t = 0.0;
+#pragma unroll
+                for (int c = 0; c < CM; ++c) t += Bl[a][c] * u_[c];
+                vj[tid][a] = t;
+                uj[tid][a] = u_[a];
+            }
+        }
+        __syncthreads();
+        const int cnt = min(MR_TJ, jend - j0);
+        if (vi)
+            for (int jj = 0; jj < cnt; ++jj) {
+                const double kinv = (double)Kib[(size_t)(j0 + jj) * N + i];        // K_b^-1 [j][i] = [i][j]
+                double d2 = 0.0, dz2[NS];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) {
+                    const double z = (xi[d] - xj[jj][d]) * iell[d];
+                    dz2[d] = z * z;
+                    d2 += z * z;
+                }
+                double krbf, kder;
+                kernel_shape(kind, d2, [](double v) { return exp(v); }, krbf, kder);
+                double uij = 0.0, q = 0.0;
+#pragma unroll
+                for (int a = 0; a < CM; ++a) uij += ui[a] * vj[jj][a];
+#pragma unroll
+                for (int d = 0; d < NS; ++d) q += ai[d] * tj[jj][d];
+                const double Gm = 0.5 * (q - (double)nt * kinv);
+                const double Gk = Gm * krbf;
+                gs += Gk * uij;
+                const double GK = Gm * kder * s2 * uij;
+#pragma unroll
+                for (int d = 0; d < NS; ++d) gl[d] += GK * dz2[d] * iell[d];
+#pragma unroll
+                for (int c = 0; c < CM; ++c) w[c] += Gk * uj[jj][c];
+            }
+    }
+    // workgroup sums into the NR slots of mll_store's layout
+    const bool lead = (tid & 63) == 0;
+    auto put = [&](int o, double v) { v = wave_sum(v); if (lead) red[tid >> 6][o] = v; };
+#pragma unroll
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) put(d, d < NS ? gl[d < NS ? d : 0] : 0.0);
+    put(BCBF_MAX_STATE_DIM, gs);
+#pragma unroll
+    for (int a = 0; a < CM; ++a)
+#pragma unroll
+        for (int c = 0; c < CM; ++c) put(BCBF_MAX_STATE_DIM + 1 + a * CM + c, s2 * ui[a] * w[c]);
+    put(NR - 1, 0.0);
+    __syncthreads();
+    if (tid < NR) work[((size_t)b * G + part) * NR + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (part != 0) return;
+    // ---- the small products and logdet (as in the form above)
+    if (tid < nt * nt) {
+        const int d = tid / nt, e = tid - d * nt;
+        double v = 0.0;
+        for (int r = 0; r < N; ++r) v += (double)Rb[(size_t)r * nt + d] * (double)al[(size_t)r * nt + e];
+        RtA[(size_t)b * nt * nt + tid] = (T)v;
+    } else if (tid >= 64 && tid < 64 + C * nt) {
+        const int o = tid - 64, a = o / nt, d = o - a * nt;
+        double v = 0.0;
+        for (int r = 0; r < N; ++r) v += (double)UHb[(size_t)r * C + a] * (double)al[(size_t)r * nt + d];
+        UHtA[(size_t)b * C * nt + o] = (T)v;
+    } else if (tid >= 192) {
+        double v = 0.0;
+        for (int r = tid - 192; r < N; r += 64) v -= 2.0 * log((double)lop[lop_dinv(r / NB, r % NB, r % NB, Np)]);
+        v = wave_sum(v);
+        if (tid == 192) logdetK[b] = (T)v;
+    }
+}
+
+// the row form's grid: RC row chunks x JS column slices (JS > 1 for a handful of models only)
+static void mll_rows_split(int Bt, int N, int& RC, int& JS) {
+    RC = (N + MG_T - 1) / MG_T;
+    JS = 1;
+    if (Bt < 64) {
+        const int tiles = (N + MR_TJ - 1) / MR_TJ;
+        JS = 128 / RC;
+        if (JS > tiles) JS = tiles;
+        if (JS < 1) JS = 1;
+    }
+}
+
 // workgroups per model of the split form (0 < Bt < 64 models: ~32 pair terms per thread, at most 128 workgroups)
 static int mll_split(int Bt, int N) {
     if (Bt >= 64) return 1;
@@ -189,8 +354,19 @@ static int launch_mll_grad(const T* Lop, const T* alpha, const T* Kinv, const T*
     if ((m + 1) * nt > 128) return BCBF_EINVAL;                    // phase 2: one thread per entry of UH' alpha
     // few models: spread each one's pair terms over G workgroups (needs the caller's workspace for the partial sums;
     // without one the model stays on one workgroup)
-    const int G = work != nullptr ? mll_split(Bt, N) : 1;
     hipStream_t st = (hipStream_t)stream;
+    static const bool pairs_form = [] { const char* e = getenv("BCBF_MLL_PAIRS"); return e && e[0] == '1'; }();   // (development)
+    if (work != nullptr && lin == nullptr && n <= 4 && nt <= 4 && m <= BCBF_MAX_CTRL_DIM && !pairs_form) {
+        constexpr int CM = BCBF_MAX_CTRL_DIM + 1;
+        int RC, JS;
+        mll_rows_split(Bt, N, RC, JS);
+        hipLaunchKernelGGL((mll_grad_rows_kernel<T>), dim3(Bt, RC * JS), dim3(MG_T), 0, st, Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell,
+                           s2, logdetK, RtA, UHtA, N, round_up(N, NB), n, m + 1, nt, (double*)work, kind, RC);
+        hipLaunchKernelGGL((mll_reduce_kernel<T, CM>), dim3(Bt), dim3(64), 0, st, (const double*)work, RC * JS, n, m + 1, g_ell,
+                           g_s2, g_B, g_lin);
+        return check_launch("mll_grad");
+    }
+    const int G = work != nullptr ? mll_split(Bt, N) : 1;
     if (m <= BCBF_MAX_CTRL_DIM) {
         constexpr int CM = BCBF_MAX_CTRL_DIM + 1;
         hipLaunchKernelGGL((mll_grad_kernel<T, CM>), dim3(Bt, G), dim3(MG_T), 0, st, Lop, alpha, Kinv, X, UH, R, Ainv, Bm, ell,
@@ -215,8 +391,14 @@ extern "C" {
 // bytes of the workspace `work` of bcbf_mll_grad* (partial sums of the split form; 0 = one workgroup per model anyway)
 size_t bcbf_mll_grad_work_bytes(int Bt, int N, int m) {
     if (Bt <= 0 || N < 1 || m < 1) return 0;
-    const int G = bcbf::mll_split(Bt, N);
+    int G = bcbf::mll_split(Bt, N);
     const int CM = m <= BCBF_MAX_CTRL_DIM ? BCBF_MAX_CTRL_DIM + 1 : BCBF_MAX_TASK_DIM;
+    if (m <= BCBF_MAX_CTRL_DIM) {                       // the row form (batches; n <= 4): one slot set per row chunk x column slice
+        int RC, JS;
+        bcbf::mll_rows_split(Bt, N, RC, JS);
+        if (RC * JS > G) G = RC * JS;
+        return sizeof(double) * (size_t)Bt * G * (BCBF_MAX_STATE_DIM + 2 + CM * CM);
+    }
     return G > 1 ? sizeof(double) * (size_t)Bt * G * (BCBF_MAX_STATE_DIM + 2 + CM * CM) : 0;
 }
 int bcbf_mll_grad_f32(const float* Lop, const float* alpha, const float* Kinv, const float* X, const float* UH,
