@@ -142,6 +142,7 @@ def _compile(item, force):
                         raise RuntimeError("%s: %s uses %d bytes of scratch per lane (its measured figures assume none)" % (src, want, z))
         missing = [w for w in ZERO_SCRATCH_KERNELS[src] if w not in seen]
         if missing or len(names) != len(sizes):
+            os.remove(obj)          # (an unchecked object must not pass for "up to date" on the next build)
             raise RuntimeError("%s: the scratch guard found no resource remark for %s" % (src, missing or "the kernels"))
     if guard:
         import re

@@ -55,7 +55,7 @@ gp_tail_step_kernel(const T* __restrict__ W0, T* __restrict__ Rb, T* __restrict_
                     int Ncap, int n, int do_append) {
     // Everything small is staged in LDS with coalesced loads up front (the first form read Rinv / Vw / X rows from global memory
     // inside its short loops: a chain of exposed load latencies, 158 us per launch at 4096 x 472 + <= 40 where the bytes take 30)
-    constexpr int CTM = BCBF_MAX_CTRL_DIM + 2, NSM = BCBF_MAX_STATE_DIM, C = CT - 1;
+    constexpr int CTM = BCBF_MAX_CTRL_DIM + 2, NSM = 4, C = CT - 1;        // NSM: the entry point takes n <= 4 (gp_tail_step below)
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
     T* Wl = reinterpret_cast<T*>(tail_smem);                    // [Np0][CT]  the prefix's solved columns
     T* Ri = Wl + (size_t)Np0 * (C + 1);                         // [tcap][tcap] inv(Lt)
@@ -266,11 +266,17 @@ static int gp_tail_step(const T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell,
     if (n < 1 || n > 4 || m < 1 || m > 3 || Lcap < N0) return BCBF_EINVAL;
     const int Np0 = round_up(N0, NB), CT = m + 2;
     const size_t smem = ((size_t)Np0 * CT + (size_t)tcap * tcap) * sizeof(T);
-    if (smem > 40 * 1024) return BCBF_EINVAL;                   // (+ up to 22 KB of static LDS)
+    // the window's W0 [Np0 x CT] and the tail's inverse [tcap x tcap] live in LDS beside ~14 KB (fp64) of static arrays: gfx950 gives a
+    // workgroup 160 KB.  What bounds the window in practice is the streaming pass in front (posterior_step.hip: its solved columns
+    // stay in LDS, Np0 (m + 2) sizeof(T) <= 48 KB, and its workgroup covers Np0 <= 2048): fp64 N0 <= 1536 (m <= 2) / 1216 (m = 3),
+    // fp32 N0 <= 2048 (bcbf.h: size table).  The tail rows are evaluated with the RBF kernel only (tail_exp): ReservedGP has no
+    // data-kernel option.
+    if (smem > 120 * 1024) return BCBF_EINVAL;
     const int rc = launch_posterior_query_column_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new, uh_new, Mk, Bk,
                                                              (T*)nullptr, swork, Bt, N0, Ncap, n, m, stream, Wwork, Lcap);
     if (rc != BCBF_OK) return rc;
 #define BCBF_TAIL_LAUNCH(CTV)                                                                                                      \
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)gp_tail_step_kernel<T, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((gp_tail_step_kernel<T, CTV>), dim3(Bt), dim3(TT), smem, (hipStream_t)stream, Wwork, Rb, Rinv, X_r, UHB_r,     \
                        Vw_r, ell, s2, Bm, M0, xq, x_new, uh_new, xdot_new, jitter_new, swork, Mk, Bk, info, rawUH, rawY, rawJ, N0,   \
                        Np0, t, tcap, round_up(Ncap, NB), Ncap, n, do_append)

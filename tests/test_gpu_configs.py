@@ -905,3 +905,28 @@ def test_c4_full_size_monte_carlo_rollouts_properties():
     err = np.abs(z["traj"].cpu().numpy()[:int(g["numSteps"]), 0] - g["state"]).max(axis=1)
     assert err[:50].max() < 5e-3 and err.max() < 5e-2
 
+
+
+def test_row_major_tail_on_a_large_fp64_window(ops):
+    """The tail step beyond the 40 KB of dynamic LDS it was limited to in round 5 (fp64 window of 1200 points, m = 2: 38 KB of W0 +
+    the tail's inverse): equal to the in-place form, 1e-9, over a few steps."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, n, m, W, D, dtype = 3, 3, 2, 1200, 40, torch.float64
+    p = make_instances(Bt, W + 8, n, m, dtype=dtype, device=DEV, seed=12)
+    cut = lambda t, N: t[:, :N].contiguous()
+    jit0 = cut(p["jitter"], W)
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], W), cut(p["UH"], W), p["Bm"], p["ell"], p["s2"], jit0)
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], W), cut(p["UH"], W), p["M0"], want_alpha=False)
+    mk = lambda tail: ops.ReservedGP(Lop, Vw, cut(p["X"], W), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D,
+                                     UH=cut(p["UH"], W), Xdot=cut(p["Xdot"], W), jitter=jit0, tail=tail)
+    gt, gi = mk(True), mk(False)
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    for t in range(6):
+        row = lambda k: p[k][:, W + t].contiguous()
+        xq = (p["xq"] + 0.02 * t).contiguous()
+        it, Mt, Bt_ = gt.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq)
+        ii, Mi, Bi = gi.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq)
+        assert it.cpu().tolist() == ii.cpu().tolist() == [0] * Bt
+        rel_close(host(Mt), host(Mi), 1e-9, scale=max(1.0, float(Mi.abs().max())), what="Mk tail fp64 W=1200 vs in place")
+        rel_close(host(Bt_), host(Bi), 1e-9, scale=prior, what="Bk tail fp64 W=1200 vs in place")

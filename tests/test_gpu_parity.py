@@ -72,11 +72,16 @@ def test_refit_and_posterior_vs_reference_golden(ops, path, dtype):
     Vw, alpha = ops.potrs(Lop, dev(Xdot[None], dtype), args[1], dev(g["M0"][None], dtype))
     Y = ogp.residual_targets(Xdot, UH, g["M0"])
     import scipy.linalg as sla
-    # Vw / alpha are internal, ill-conditioned quantities (the reference only exposes mean / cov):
-    # fp32 is held to the north-star tolerance on the posterior outputs below, loosely here
+    # Vw = L^-1 Y and alpha = K_b^-1 Y are outputs of the C ABI (bcbf_potrs).  Entry by entry they carry cond(K_b) eps (the
+    # reference only exposes mean / cov); fp64 is held to the oracle's values, fp32 through what DEFINES them -- the residuals
+    # L Vw = Y and K_b alpha = Y at north_star's 1e-3 (of |Y|) -- and loosely entry by entry
     itol = tol if dtype == torch.float64 else 2e-2
     rel_close(host(Vw)[0], sla.solve_triangular(g["L"], Y, lower=True), itol, what="Vw")
-    rel_close(host(alpha)[0], ogp.cholesky_solve(Y, g["L"]), itol * 50, what="alpha")
+    if dtype == torch.float64:
+        rel_close(host(alpha)[0], ogp.cholesky_solve(Y, g["L"]), tol, what="alpha")
+    Kb_j = Kb_ref
+    rel_close(g["L"] @ host(Vw)[0], Y, 1e-9 if dtype == torch.float64 else 1e-3, scale=np.abs(Y).max(), what="L Vw = Y")
+    rel_close(Kb_j @ host(alpha)[0], Y, 1e-7 if dtype == torch.float64 else 1e-3, scale=np.abs(Y).max(), what="K_b alpha = Y")
     # per-step posterior at the golden single query, explicit second jitter
     xq = g["Xtest"][:1]
     j2 = 1e-5 * g["one_jitter2"][None]
