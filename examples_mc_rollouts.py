@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the closed-loop step from a captured HIP graph")
     ap.add_argument("--shared-learned", type=int, default=0,
                     help="N_train of ONE learned GP queried by every trajectory (matrix-core posterior; N <= 512 in fp64)")
+    ap.add_argument("--predict-8gpu", action="store_true",
+                    help="one GPU only: also time the per-GPU shape of the 8-way strong split (trajectories / 8) and print "
+                         "predicted_strong_scaling_8gpu = loop(trajectories) / loop(trajectories / 8) -- what an 8-GPU node could gain")
     ap.add_argument("--dtype", choices=["f32", "f64"], default=None,
                     help="precision of the shared learned model (default: f64 as the reference's module for N <= 512, else f32)")
     args = ap.parse_args()
@@ -95,8 +98,23 @@ def main():
                     limiter=(None if args.learned else "latency: register-resident interior-point iterations (fp64 division / sqrt chains); "
                              "neither the HBM nor the MFMA roofline binds this kernel -- see solver iterations in DESIGN.md 3.2"),
                     how="over the loop time of rank 0 (every launch of a step)")
+    extra = dict(setup_and_capture_seconds=el - loop_max, setup_share_of_wall=(el - loop_max) / el if el > 0 else None)
+    if args.predict_8gpu and world == 1:
+        # the per-GPU shape of the strong split on THIS GPU: an eighth of the trajectories (same recipe, same graph option)
+        n8 = max(1, args.trajectories // 8)
+        gp8 = gp if (gp is None or args.shared_learned) else {k: (v[:n8].contiguous() if torch.is_tensor(v) and v.shape[0] == n_loc else v) for k, v in gp.items()}
+        torch.cuda.synchronize()
+        out8 = monte_carlo_safety_rollouts(n8, numSteps=args.steps, gp=gp8, max_risk=args.max_risk, seed=rank, dtype=dtype,
+                                           device=ctx.device, use_graph=args.graph)
+        torch.cuda.synchronize()
+        extra.update(loop_seconds_at_one_eighth=out8["loop_seconds"], trajectories_at_one_eighth=n8,
+                     us_per_step_full=out["loop_seconds"] / args.steps * 1e6, us_per_step_at_one_eighth=out8["loop_seconds"] / args.steps * 1e6,
+                     predicted_strong_scaling_8gpu=out["loop_seconds"] / out8["loop_seconds"],
+                     note="the loop is latency bound (four lanes per trajectory, one wave per CU at 4096 trajectories): an eighth of the "
+                          "trajectories takes nearly the same time per step, so 8 GPUs cannot give 8x on a FIXED 32768-trajectory job; "
+                          "C4 is reported weak-scaled (trajectories per GPU fixed)")
     if rank == 0:
-        print(json.dumps(dict(config="c4: Monte-Carlo safety rollouts (unicycle_bayes_cbf_safe_obstacle recipe)",
+        print(json.dumps(dict(config="c4: Monte-Carlo safety rollouts (unicycle_bayes_cbf_safe_obstacle recipe)", **extra,
                               trajectories=args.trajectories, steps=args.steps, n_gpus=world, seconds=el, loop_seconds=loop_max,
                               trajectory_steps_per_s=args.trajectories * args.steps / el,
                               trajectory_steps_per_s_loop_only=args.trajectories * args.steps / loop_max, scaling="strong",

@@ -669,6 +669,38 @@ def test_learning_closed_loop_online_schedules_on_part_batches_vs_oracle(ops, sc
     assert torch.equal(final3["ws"]["status"], final1["ws"]["status"])
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("schedule", ["online", "online_tail"])
+def test_learning_closed_loop_mid_period_model_vs_oracle(ops, schedule, dtype):
+    """The incremental paths THEMSELVES against the oracle (round-5 review: with steps a multiple of refit_every the final model of
+    the online schedules was always a fresh window refit -- a refit compared with a refit).  `mid_period_steps` extra steps after the
+    timed region: the final model is the window's factor PLUS 11 in-place appends (online) / 11 bordered tail rows (online_tail),
+    compared with the oracle's from-scratch refit of the window + 11 rows it holds; fp64 1e-7, fp32 1e-3."""
+    from bayesian_cbf_amd.rollouts import learning_closed_loop
+    out, final = learning_closed_loop(Bt=24, max_train=120, steps=48, refit_every=24, warmup=24, dtype=dtype, device=DEV, seed=11,
+                                      schedule=schedule, mid_period_steps=11)
+    assert out["append_or_refit_failures"] == 0 and out["shares"]["refits_in_timed_region"] == 2
+    assert final["N"] == 96 + 11 and final["rgp"].N == 107
+    if schedule == "online_tail":
+        assert final["rgp"].t == 11 and final["rgp"].N0 == 96
+    worst = _learning_loop_final_vs_oracle(final, list(range(24)), 1e-7 if dtype == torch.float64 else 1e-3, ops)
+    print("learning loop mid-period %s %s: worst |dMk| %.2e, |dBk| %.2e" % (schedule, dtype, worst[0], worst[1]))
+
+
+def test_learning_closed_loop_c3_scale_mid_period_tail_fp32_vs_oracle(ops):
+    """The same at BASELINE configs[2] scale for the tail form in fp32: 4096 instances, a window of 472 points + 39 bordered tail rows
+    (one short of the next window refit), 32 sampled instances against the oracle's refit of the 511 rows, 1e-3."""
+    from bayesian_cbf_amd.rollouts import learning_closed_loop, final_window_vs_device_refit
+    out, final = learning_closed_loop(Bt=4096, max_train=512, steps=40, refit_every=40, warmup=40, dtype=torch.float32, device=DEV,
+                                      seed=1234, schedule="online_tail", mid_period_steps=39)
+    assert out["append_or_refit_failures"] == 0 and final["rgp"].t == 39 and final["N"] == 511
+    idx = [int(v) for v in np.linspace(0, 4095, 32)]
+    worst = _learning_loop_final_vs_oracle(final, idx, 1e-3, ops)
+    chk = final_window_vs_device_refit(final)
+    assert chk["Mk"] <= 1e-3 and chk["Bk"] <= 1e-3 and chk["refit_failures"] == 0
+    print("learning loop C3 scale, mid-period tail fp32 (39 rows): worst |dMk| %.2e |dBk| %.2e vs oracle; vs fp64 device refit %s" % (worst[0], worst[1], chk))
+
+
 def test_learning_closed_loop_c3_scale_sampled_instances_vs_oracle(ops):
     """The same at BASELINE configs[2] scale (4096 instances, at most 512 points each, fp32, refit every 40): one warm-up period + one
     timed period, 64 instances spread over the batch against the oracle refit of their final window at 1e-3; the line the

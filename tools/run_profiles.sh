@@ -60,7 +60,8 @@ python tools/bench_reldeg2.py 2>/dev/null > $O/reldeg2.jsonl
 python tools/bench_speed_test.py --quick 2>/dev/null > $O/speed_test.jsonl
 python tools/bench_speed_test_unicycle.py --quick 2>/dev/null > $O/speed_test_unicycle.jsonl
 python tools/learn_dynamics_matrix_vector.py /tmp/learn_matrix_vector > /dev/null 2>&1; cp gpurun_out/learn_matrix_vector.jsonl $O/ 2>/dev/null
-python examples_mc_rollouts.py --trajectories 32768 --graph 2>/dev/null | tail -1 > $O/mc_rollouts.txt
+python examples_mc_rollouts.py --trajectories 32768 --graph --predict-8gpu 2>/dev/null | tail -1 > $O/mc_rollouts.txt
+for T in 4096 8192 16384; do python examples_mc_rollouts.py --trajectories $T --graph 2>/dev/null | tail -1 >> $O/mc_rollouts.txt; done
 python examples_mc_rollouts.py --trajectories 32768 2>/dev/null | tail -1 >> $O/mc_rollouts.txt
 bash tools/run_pmc_refit_traffic.sh $R > /dev/null 2>&1      # refit traffic past L2 -> $O/pmc_traffic_refit.json
 # the learning closed loop at C3 scale (round 5): reference cadence on four part batches, on one stream, and the online schedule
