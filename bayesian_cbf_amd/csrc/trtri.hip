@@ -108,22 +108,36 @@ trtri_mfma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv,
     trtri_own_writes_visible();
     for (int I = J + 1; I < nblk; ++I) {
         f64x4 acc[2][2] = {};
-        for (int K = J; K < I; ++K) {
+        // operands of block K + 1 are in flight while block K's MFMA chain runs (two register sets, as in the fp32 kernel)
+        double av[2][8][2], bv[2][8][2];
+        auto load = [&](int K, double (&a)[8][2], double (&bq)[8][2]) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                          // k = 4 s + g within the 32-wide tile
                 const int k = 4 * s + g, gk = K * NB + k;
-                double a[2], bb[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    a[h] = lop[lop_base<V>(gk, Np) + I * NB + 16 * h + c16];
+                    a[s][h] = lop[lop_base<V>(gk, Np) + I * NB + 16 * h + c16];
                     const int gc = J * NB + 16 * h + c16;
-                    bb[h] = (gc < N && gk < N) ? X[(size_t)gk * N + gc] : 0.0;
+                    bq[s][h] = (gc < N && gk < N) ? X[(size_t)gk * N + gc] : 0.0;
                 }
+            }
+        };
+        auto chain = [&](double (&a)[8][2], double (&bq)[8][2]) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int hi = 0; hi < 2; ++hi)
 #pragma unroll
                     for (int hj = 0; hj < 2; ++hj)
-                        acc[hi][hj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[hi], bb[hj], acc[hi][hj], 0, 0, 0);
+                        acc[hi][hj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][hi], bq[s][hj], acc[hi][hj], 0, 0, 0);
+        };
+        load(J, av[0], bv[0]);
+        for (int K = J; K < I; K += 2) {
+            if (K + 1 < I) load(K + 1, av[1], bv[1]);
+            chain(av[0], bv[0]);
+            if (K + 1 < I) {
+                if (K + 2 < I) load(K + 2, av[0], bv[0]);
+                chain(av[1], bv[1]);
             }
         }
         // X_IJ = -inv(L_II) S: register q of acc[hk][hj] = row 16 hk + 4 q + g of S in column 16 hj + c16
