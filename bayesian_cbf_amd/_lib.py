@@ -55,6 +55,7 @@ _TSIGS = {
     "bcbf_gp_append_reserved": [P] * 19 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_gp_append_reserved_raw": [P] * 22 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_gp_tail_step": [P] * 23 + [c_int] * 9 + [P],
+    "bcbf_gp_tail_commit": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_potri": [P, P, c_int, c_int, P],
     "bcbf_trtri": [P, P, c_int, c_int, P],
     "bcbf_mll_grad": [P] * 16 + [c_int, c_int, c_int, c_int, P, P],

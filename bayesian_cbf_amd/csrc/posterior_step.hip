@@ -1150,10 +1150,11 @@ int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X
     const int Np = round_up(N, NB), Nl = round_up(Lcap ? Lcap : Ncap, NB);
     const int threads = round_up(Np / V / 2, 64);
     if (threads > (sizeof(T) == 8 ? 512 : 256) || Nl < Np) return BCBF_EINVAL;
-    if (((lvec ? Np : 0) + (Wfull ? (size_t)Np * (m + 2) : 0)) * sizeof(T) > 48 * 1024) return BCBF_EINVAL;      // (the columns kept in LDS until the pass ends)
+    const size_t px_lds = ((lvec ? Np : 0) + (Wfull ? (size_t)Np * (m + 2) : 0)) * sizeof(T);      // (the columns kept in LDS until the pass ends)
+    if (px_lds > 100 * 1024) return BCBF_EINVAL;                    // (beside ~1 KB of static LDS; gfx950: 160 KB per workgroup)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PX_LAUNCH(CC) hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1>), grid, block, ((lvec ? Np : 0) + (Wfull ? (size_t)Np * (CC + 1) : 0)) * sizeof(T), st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, Wfull, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, 0, x_new, uh_new)
+#define BCBF_PX_LAUNCH(CC) if (px_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_step_kernel<T, CC, 4, 0, 1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds); hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1>), grid, block, ((lvec ? Np : 0) + (Wfull ? (size_t)Np * (CC + 1) : 0)) * sizeof(T), st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, Wfull, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, 0, x_new, uh_new)
     switch (m) {
         case 1: BCBF_PX_LAUNCH(2); break;
         case 2: BCBF_PX_LAUNCH(3); break;

@@ -268,8 +268,7 @@ static int gp_tail_step(const T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell,
     const size_t smem = ((size_t)Np0 * CT + (size_t)tcap * tcap) * sizeof(T);
     // the window's W0 [Np0 x CT] and the tail's inverse [tcap x tcap] live in LDS beside ~14 KB (fp64) of static arrays: gfx950 gives a
     // workgroup 160 KB.  What bounds the window in practice is the streaming pass in front (posterior_step.hip: its solved columns
-    // stay in LDS, Np0 (m + 2) sizeof(T) <= 48 KB, and its workgroup covers Np0 <= 2048): fp64 N0 <= 1536 (m <= 2) / 1216 (m = 3),
-    // fp32 N0 <= 2048 (bcbf.h: size table).  The tail rows are evaluated with the RBF kernel only (tail_exp): ReservedGP has no
+    // stay in LDS, Np0 (m + 2) sizeof(T) <= 100 KB, and its workgroup covers Np0 <= 2048): N0 <= 2048 in both precisions (bcbf.h).  The tail rows are evaluated with the RBF kernel only (tail_exp): ReservedGP has no
     // data-kernel option.
     if (smem > 120 * 1024) return BCBF_EINVAL;
     const int rc = launch_posterior_query_column_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new, uh_new, Mk, Bk,
@@ -288,6 +287,52 @@ static int gp_tail_step(const T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell,
 #undef BCBF_TAIL_LAUNCH
     return check_launch("gp_tail_step");
 }
+// GROWTH with a tail (round 6): without a window the model keeps growing, so the tail cannot wait for a refit -- every
+// 32 appends its rows are COMMITTED to the reserved column layout as one whole block row: element (N0 + r, j) of column j for r =
+// 0..31 is 32 consecutive elements of that column, a full 128-byte line in fp32 (two in fp64), where the in-place append wrote one
+// element per line and step (the dirty partial lines were what the next streaming pass waited for).  The block's own diagonal tile is
+// the tail's triangular block: its inverse Rinv goes to the packed-triangle and the full-tile copies.  N0 a multiple of 32, t = 32.
+// grid (N0 / 32 + 1, Bt): workgroup (Jc, b) transposes the 32 x 32 tile Rb[0..31][32 Jc ..] through LDS; the last one writes the
+// diagonal block.
+template <typename T>
+__global__ void __launch_bounds__(256)
+gp_tail_commit_kernel(T* __restrict__ Lop, const T* __restrict__ Rb, const T* __restrict__ Rinv, int N0, int tcap, int ldR, int Nl) {
+    constexpr int V = Vec<T>::V;
+    __shared__ T tile[NB][NB + 1];
+    const int b = blockIdx.y, Jc = blockIdx.x, Jn = N0 / NB, tid = threadIdx.x;
+    T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Nl);
+    const int c = tid & 31, r0 = tid >> 5;                       // 8 rows per pass
+    if (Jc < Jn) {
+        const T* Rbb = Rb + (size_t)b * tcap * ldR;
+#pragma unroll
+        for (int r = r0; r < NB; r += 8) tile[r][c] = Rbb[(size_t)r * ldR + Jc * NB + c];        // row r: 32 consecutive columns
+        __syncthreads();
+#pragma unroll
+        for (int cc = r0; cc < NB; cc += 8)                        // column cc: rows N0 .. N0 + 31, consecutive
+            lop[lop_base<V>(Jc * NB + cc, Nl) + N0 + c] = tile[c][cc];
+        return;
+    }
+    const T* Rib = Rinv + (size_t)b * tcap * tcap;
+#pragma unroll
+    for (int r = r0; r < NB; r += 8) tile[r][c] = c <= r ? Rib[(size_t)r * tcap + c] : T(0);     // inv(Lt)[r][c]
+    __syncthreads();
+#pragma unroll
+    for (int cc = r0; cc < NB; cc += 8) {
+        lop[lop_dfull(Jn, c, cc, Nl)] = tile[c][cc];              // full tile, column-major, zeros above the diagonal
+        if (c >= cc) lop[lop_dinv(Jn, c, cc, Nl)] = tile[c][cc];  // packed lower triangle
+    }
+}
+
+template <typename T>
+static int gp_tail_commit(T* Lop_r, const T* Rb, const T* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream) {
+    if (Bt <= 0) return BCBF_OK;
+    if (!Lop_r || !Rb || !Rinv) return BCBF_EINVAL;
+    if (N0 < NB || N0 % NB != 0 || t != NB || tcap < NB || tcap > TMAXT || N0 + NB > Ncap) return BCBF_EINVAL;
+    const int Nl = round_up(Ncap, NB);
+    hipLaunchKernelGGL((gp_tail_commit_kernel<T>), dim3(N0 / NB + 1, Bt), dim3(256), 0, (hipStream_t)stream, Lop_r, Rb, Rinv, N0, tcap,
+                       Nl, Nl);
+    return check_launch("gp_tail_commit");
+}
 }  // namespace bcbf
 
 extern "C" {
@@ -304,4 +349,10 @@ extern "C" {
 BCBF_TAIL_ENTRY(f32, float)
 BCBF_TAIL_ENTRY(f64, double)
 #undef BCBF_TAIL_ENTRY
+int bcbf_gp_tail_commit_f32(float* Lop_r, const float* Rb, const float* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream) {
+    return bcbf::gp_tail_commit<float>(Lop_r, Rb, Rinv, Bt, N0, t, tcap, Ncap, stream);
+}
+int bcbf_gp_tail_commit_f64(double* Lop_r, const double* Rb, const double* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream) {
+    return bcbf::gp_tail_commit<double>(Lop_r, Rb, Rinv, Bt, N0, t, tcap, Ncap, stream);
+}
 }

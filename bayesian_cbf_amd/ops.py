@@ -335,9 +335,23 @@ class ReservedGP:
         # beside the window's own (bcbf_gp_tail_step) instead of being written into the operator's columns one element at a time
         self.tail = bool(tail)
         self.N0, self.t = self.N, 0
-        if self.tail:
-            if self.window is None:
-                raise ValueError("tail=True is a form of the sliding window: pass window=...")
+        if self.tail and self.window is None:
+            # GROWTH with a tail (no window): the appends since the last commit are rows of a bordered factor beside the reserved
+            # operator; every 32nd append commits them as one whole block row (bcbf_gp_tail_commit: full-line writes into the
+            # column layout).  The live size then is N0 (committed, a multiple of 32) + t.
+            if self.N % self.BLOCK or self.n > 4:
+                raise ValueError("tail=True without a window starts from a multiple of %d points (and n <= 4)" % self.BLOCK)
+            f = dict(dtype=X.dtype, device=X.device)
+            Npc = (self.capacity + 31) // 32 * 32
+            self._tcap = self.BLOCK
+            self._Rb = torch.zeros(self.Bt, self._tcap, Npc, **f)
+            self._Rinv = torch.zeros(self.Bt, self._tcap, self._tcap, **f)
+            self._Wfull = torch.empty(self.Bt, Npc, self.C + 1, **f)
+            self._sw = torch.empty(self.Bt, 1 + self.n, **f)
+            self._ones = torch.ones(self.Bt, self.C, **f)
+            self._Lcap = self.capacity
+            self._rUH = self._rY = self._rJ = None
+        elif self.tail:
             # rows the tail must hold: until the first window refit window + drop - N_init of them, `drop` after every refit
             # (N0 = window, t = 0 there) -- whichever is larger (N_init > window makes the first period the shorter one)
             self._tcap = max(self.drop, self.window + self.drop - self.N)
@@ -500,6 +514,12 @@ class ReservedGP:
                 Mk, Bk = self._Mkw, self._Bkw
             self._tail_step(x_new if query is None else query, x_new, uh_new, xdot_new, jitter_new, Mk, Bk, True)
             self.t += 1
+            if self.window is None and self.t == self._tcap:
+                # growth: the 32 tail rows become block row N0 / 32 of the reserved operator (one launch, full-line writes)
+                check(getattr(lib, "bcbf_gp_tail_commit" + _suf(self.X))(_p(self.Lop), _p(self._Rb), _p(self._Rinv), self.Bt, self.N0, self.t,
+                                                                          self._tcap, self.capacity, _stream(self.X)), "bcbf_gp_tail_commit")
+                self.N0 += self._tcap
+                self.t = 0
             return self._appended(query, Mk, Bk)
         Mk = Bk = None
         if query is not None:

@@ -131,7 +131,7 @@ def online_pass_bytes(N, n, m, itemsize):
 
 
 def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", seed=5, with_control=True, check=True,
-                     reserved=True, fused=True, window=None):
+                     reserved=True, fused=True, window=None, tail=False):
     """BASELINE configs[4]: every instance starts from an N0-point GP and takes one observation per control step
     until it holds N1 points -- the reference refits from scratch every `train_every_n_steps`
     (unicycle_move_to_pose.py:340-386).  reserved=True (default): capacity-reserving storage (`ops.ReservedGP`,
@@ -144,6 +144,9 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
     grows from N0 to W, then every 32nd append drops the oldest 32 points and refits the window (the drop is inside that
     step's `append_ms`); N1 is then the number of observations seen, the final check is against a from-scratch refit of the
     LAST window.
+    tail=True (reserved storage, no window; N0 a multiple of 32): the appends since the last commit are contiguous rows beside the
+    operator (`bcbf_gp_tail_step`), committed to the column layout 32 rows at a time (`bcbf_gp_tail_commit`: full-line writes) --
+    the in-place append's one element per 128-byte line and step is what the next streaming pass waited for.
     Returns per-octave timings (HIP events) and the deviation of the final posterior from a from-scratch refit of all
     N1 points."""
     from .synthetic import make_instances, make_unicycle_task
@@ -164,7 +167,7 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
         rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], window + 32, window=window,
                              UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
     else:
-        rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N1) if reserved else None
+        rgp = ops.ReservedGP(Lop, Vw, X, UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N1, tail=tail) if reserved else None
     if reserved:
         del Lop, Vw, UHB
     # pre-slice the observation stream (contiguous [N1][Bt,.]) so the timed loop holds only the path's own launches
@@ -218,14 +221,16 @@ def online_gp_growth(Bt, N0=128, N1=2048, dtype=torch.float64, device="cuda", se
             passes = 1 if (with_control and fused) or not with_control else 2
             gbs = byt * passes / (t_app * 1e-3) / 1e9 if passes == 1 else None
             seg["roofline"] = dict(bound="hbm", kernel="posterior_step_kernel<%s, %d, 4, 0, 1, false, 1> (query columns + the append's column on "
-                                   "one pass) + gp_append_rows" % ("double" if isz == 8 else "float", 1 + m),
+                                   "one pass) + %s" % ("double" if isz == 8 else "float", 1 + m,
+                                                       "gp_tail_step_kernel (+ gp_tail_commit_kernel every 32nd step)" if tail else "gp_append_rows"),
                                    algorithmic_bytes_per_launch=byt / k, achieved=gbs, peak=8000.0, unit="GB/s",
                                    frac=None if gbs is None else gbs / 8000.0, traffic=None,
                                    how="sum over the segment's appends of Bt x online_pass_bytes(N) / sum of the HIP-event "
                                        "intervals around append(+query) [ms = append_ms]")
         segs.append(seg)
     out = dict(batch=Bt, N0=N0, N1=N1, dtype=str(dtype),
-               storage=("reserved (in place)" + (", posterior query and append on one pass" if (fused and with_control) else ""))
+               storage=("reserved (" + ("row-major tail, committed 32 rows at a time" if tail else "in place") + ")"
+                        + (", posterior query and append on one pass" if (fused and with_control) else ""))
                if reserved else "packed (copy per append)",
                segments=segs, append_failures=int(fails))
     if window is not None:

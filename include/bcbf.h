@@ -314,7 +314,8 @@ int bcbf_gp_append_reserved_raw_f64(double* Lop_r, double* Vw_r, double* X_r, do
  * 128-byte lines per instance cost the NEXT streaming pass a quarter of its time.  info[Bt] = 0, or N0+t+1 where the new
  * pivot was not positive (a neutral point enters, as in bcbf_gp_append).  do_append = 0: the posterior only (x_new / uh_new still
  * name a valid point; nothing is written but Mk, Bk and the work buffers).  Work buffers: Wwork[Bt,round_up(N0,32),2+m],
- * swork[Bt,1+n].  tcap <= 64, n <= 4, m <= 3; round_up(N0,32) (2+m) + tcap^2 elements must fit 40 KB of LDS.  The caller counts t and rebuilds the
+ * swork[Bt,1+n].  tcap <= 64, n <= 4, m <= 3; the streaming pass in front keeps its solved columns in LDS and its workgroup covers 2048 rows:
+ * N0 <= 2048 (and round_up(N0,32) (2+m) sizeof(T) <= 100 KB, which 2048 points meet for every m <= 3 in both precisions).  The caller counts t and rebuilds the
  * window (refit of the raw rows + bcbf_gp_reserve) before t reaches tcap.  Follows the reference's refit-every-k loop
  * (unicycle_move_to_pose.py:340-386) with k = 1 between refits; posterior: control_affine_model.py:1051-1059. */
 int bcbf_gp_tail_step_f32(const float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
@@ -328,12 +329,24 @@ int bcbf_gp_tail_step_f64(const double* Lop_r, double* Vw_r, double* X_r, double
                           double* swork, double* Mk, double* Bk, double* rawUH, double* rawY, double* rawJ, int Bt, int N0, int t,
                           int tcap, int Ncap, int Lcap, int n, int m, int do_append, void* stream);
 
+/* GROWTH with a row-major tail: a model that keeps growing (no window, BASELINE configs[4]) commits its tail to the reserved column
+ * layout one whole 32-row block at a time -- after 32 bcbf_gp_tail_step appends on a window of N0 points (N0 a multiple of 32,
+ * Lop_r = bcbf_gp_reserve's output for capacity Ncap >= N0 + 32, Lcap = Ncap) this writes rows N0 .. N0+31 of every column (32
+ * consecutive elements per column: full 128-byte lines, where the in-place append of bcbf_gp_append_reserved writes one element
+ * per line and step) and the new diagonal block's inverse (Rinv) in both of the layout's forms.  t must be 32; the caller then
+ * continues with N0 + 32, t = 0.  X_r / UHB_r / Vw_r already hold the rows (the tail step wrote them). */
+int bcbf_gp_tail_commit_f32(float* Lop_r, const float* Rb, const float* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream);
+int bcbf_gp_tail_commit_f64(double* Lop_r, const double* Rb, const double* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream);
+
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */
 int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream);
 int bcbf_potri_f64(const double* Lop, double* Kinv, int Bt, int N, void* stream);
 /* Dense inverse of the Cholesky factor, Linv[Bt,N,N] = L^-1 (lower triangular, zeros above): the forward half of
  * bcbf_potri (whose backward half is latency bound: 2 ms at N = 512 for ONE model). */
+/* (batches, Bt >= 4: blocked on the matrix cores, csrc/trtri.hip -- one wave per 32-column block column, X_IJ = -inv(L_II) sum_K
+ * L_IK X_KJ as MFMA chains; fewer models: the forward half of bcbf_potri.  Output: the full lower-triangular matrix, zeros above
+ * the diagonal.) */
 int bcbf_trtri_f32(const float* Lop, float* Linv, int Bt, int N, void* stream);
 int bcbf_trtri_f64(const double* Lop, double* Linv, int Bt, int N, void* stream);
 /* K_b^-1 = Linv' Linv [Bt,N,N] (full symmetric matrix) from the dense triangular inverse of bcbf_trtri: 32 x 32 output tiles

@@ -962,3 +962,59 @@ def test_row_major_tail_on_a_large_fp64_window(ops):
         assert it.cpu().tolist() == ii.cpu().tolist() == [0] * Bt
         rel_close(host(Mt), host(Mi), 1e-9, scale=max(1.0, float(Mi.abs().max())), what="Mk tail fp64 W=1200 vs in place")
         rel_close(host(Bt_), host(Bi), 1e-9, scale=prior, what="Bk tail fp64 W=1200 vs in place")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_growth_with_a_row_major_tail_and_block_commits_vs_in_place_and_oracle(ops, dtype):
+    """`ReservedGP(tail=True)` WITHOUT a window (BASELINE configs[4], growth): the appends since the last commit are rows of a bordered
+    factor (bcbf_gp_tail_step), every 32nd append commits them to the reserved column layout as one block row (bcbf_gp_tail_commit).
+    Every step's posterior equals the in-place form's on the same observations and -- sampled -- the oracle's from-scratch refit of
+    the points held; after three commits the OPERATOR itself equals the in-place form's (same layout, same values to rounding), so the
+    model can go on in either form; a failed pivot enters a neutral row and is committed as one."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, n, m, N0, steps = 4, 3, 2, 64, 3 * 32 + 9
+    p = make_instances(Bt, N0 + steps + 1, n, m, dtype=dtype, device=DEV, seed=21)
+    cut = lambda t, N: t[:, :N].contiguous()
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], N0), cut(p["UH"], N0), p["Bm"], p["ell"], p["s2"], cut(p["jitter"], N0))
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N0), cut(p["UH"], N0), p["M0"], want_alpha=False)
+    mk = lambda tail: ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N0 + steps + 8, tail=tail)
+    gt, gi = mk(True), mk(False)
+    h = {k: host(v) for k, v in p.items()}
+    tol = 1e-3 if dtype == torch.float32 else 1e-8
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    bad_step = 40
+    for t in range(steps):
+        N = N0 + t
+        xq = (p["xq"] + 0.01 * t).contiguous()
+        x_new, uh_new, xd_new, j_new = (p[k][:, N].clone().contiguous() for k in ("X", "UH", "Xdot", "jitter"))
+        if t == bad_step:
+            x_new[1], uh_new[1] = p["X"][1, N - 3], p["UH"][1, N - 3]
+            j_new[1] = -j_new[1].abs()
+        it, Mt, Bt_ = gt.append(x_new, uh_new, xd_new, j_new, query=xq)
+        ii, Mi, Bi = gi.append(x_new, uh_new, xd_new, j_new, query=xq)
+        assert it.cpu().tolist() == ii.cpu().tolist()
+        assert (it != 0).sum() == (1 if t == bad_step else 0)
+        rel_close(host(Mt), host(Mi), tol, scale=max(1.0, float(Mi.abs().max())), what="Mk growth tail vs in place")
+        rel_close(host(Bt_), host(Bi), tol, scale=prior, what="Bk growth tail vs in place")
+        if t in (0, 31, 32, 33, 70) :
+            for i in (0, 3):
+                sl = slice(0, N)
+                stt = ogp.refit_state(h["X"][i, sl], h["U"][i, sl], h["Xdot"][i, sl], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                                      h["jitter"][i, sl][None] / 1e-5)
+                Mk_o, Bk_o = ogp.posterior_step(stt["L"][None], stt["alpha"][None], h["X"][i, sl][None], stt["UHB"][None], h["ell"][i][None],
+                                                h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], host(xq)[i][None])
+                rel_close(host(Mt)[i], Mk_o[0], tol, scale=max(1.0, np.abs(Mk_o).max()), what="Mk growth tail vs oracle")
+                rel_close(host(Bt_)[i], Bk_o[0], tol, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk growth tail vs oracle")
+        assert gt.N == gi.N == N + 1 and gt.N0 == N0 + 32 * ((t + 1) // 32) and gt.t == (t + 1) % 32
+    # three commits: the committed part of the operator is the in-place one's (both lay the same factor out for the same capacity)
+    # (after three commits and nine tail rows: posterior() continues from committed blocks + tail)
+    assert gt.Lop.shape == gi.Lop.shape
+    Mq, Bq = gt.posterior(p["xq"])
+    Mi, Bi = gi.posterior(p["xq"])
+    rel_close(host(Mq), host(Mi), tol, scale=max(1.0, float(Mi.abs().max())), what="Mk posterior() growth tail")
+    rel_close(host(Bq), host(Bi), tol, scale=prior, what="Bk posterior() growth tail")
+    L40, U40, i40, _ = ops.refit(cut(p["X"], 40), cut(p["UH"], 40), p["Bm"], p["ell"], p["s2"], cut(p["jitter"], 40))
+    V40, _ = ops.potrs(L40, cut(p["Xdot"], 40), cut(p["UH"], 40), p["M0"], want_alpha=False)
+    with pytest.raises(ValueError):                                       # growth with a tail starts from a multiple of 32 points
+        ops.ReservedGP(L40, V40, cut(p["X"], 40), U40, p["ell"], p["s2"], p["Bm"], p["M0"], 200, tail=True)

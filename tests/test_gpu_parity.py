@@ -1497,7 +1497,12 @@ def test_syrk_kb_inverse_and_deterministic_likelihood_gradient(ops, dtype):
         for _ in range(3):
             again = ops.mll_grad(*args)
             assert all(torch.equal(a, b) for a, b in zip(first, again)), "the split form must be deterministic"
-        assert int(_lib.lib.bcbf_mll_grad_work_bytes(Bt, N, m)) == (0 if N == 33 else 8 * Bt * min(128, -(-N * N // 8192)) * 26)
+        # workspace: one slot set per workgroup of a model -- the pair form's split (few models) or the row form's row chunks x column
+        # slices (round 6), whichever is larger
+        g_pairs = min(128, -(-N * N // 8192))
+        rc, tiles = -(-N // 256), -(-N // 128)
+        g_rows = rc * max(1, min(128 // rc, tiles))
+        assert int(_lib.lib.bcbf_mll_grad_work_bytes(Bt, N, m)) == 8 * Bt * max(g_pairs, g_rows) * 26
         saved = ops._mll_work
         ops._mll_work = lambda *a: None                   # no workspace: one workgroup per model
         try:

@@ -25,6 +25,8 @@ ap.add_argument("--unfused", action="store_true", help="reserved storage, but th
 ap.add_argument("--repeat", type=int, default=1, help="runs (reproducibility of the per-segment figures)")
 ap.add_argument("--window", type=int, default=0, help="sliding window of the most recent W points (ops.ReservedGP(window=W)): grow "
                                                       "to W, then drop the oldest 32 every 32 appends; --n1 = observations seen")
+ap.add_argument("--tail", action="store_true", help="growth with a row-major tail committed 32 rows at a time (bcbf_gp_tail_step + bcbf_gp_tail_commit) "
+                                                    "instead of in-place element-per-line appends")
 a = ap.parse_args()
 # BCBF_BENCH_FORCE_LAUNCH=1 (test hook, as in bench.py): also a one-GPU run goes through the launcher parent -> child rank path
 if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
@@ -39,7 +41,7 @@ for _ in range(a.repeat):
     t0 = time.perf_counter()
     out = online_gp_growth(a.batch, a.n0, a.n1, dtype=torch.float64 if a.dtype == "f64" else torch.float32, device=ctx.device,
                            seed=5 + ctx.rank, with_control=not a.no_control, reserved=not a.packed, fused=not a.unfused,
-                           window=a.window or None)
+                           window=a.window or None, tail=a.tail)
     torch.cuda.synchronize()
     el, per_rank = ctx.reduce_times(time.perf_counter() - t0)
     # the slowest rank's figure per segment, the worst rank's deviation, the sum of failures: one short reduction each
