@@ -6,7 +6,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = R + "gpurun_out/%s/" % ROUND
 DST = R + "profiles/%s_" % ROUND
 
@@ -22,12 +22,22 @@ def last_json_line(path):
 
 
 # ---- kernel-trace summaries (libbcbf kernels only; the torch kernels of the synthetic-data generator are dropped)
-for tag in ("default", "parts1", "shared", "shared_f64", "reldeg2", "learn_reference", "learn_online", "learn_online_tail", "append_b256_n1024_2048", "append_b1024_n1024_1280"):
+for tag in ("default", "parts1", "shared", "shared_f64", "reldeg2", "learn_reference", "learn_online", "learn_online_tail", "learn_loop_reference", "fit_iter", "speed_call", "append_b256_n1024_2048", "append_b1024_n1024_1280"):
     f = latest("prof_%s/*/*_kernel_stats.csv" % tag)
     if not f:
         continue
     rows = list(csv.reader(open(f)))
-    out = [rows[0]] + [r for r in rows[1:] if "bcbf::" in r[0]]
+    own = [r for r in rows[1:] if "bcbf::" in r[0]]
+    # everything that is NOT a libbcbf kernel (torch's elementwise / copy / index launches, a library GEMM of the synthetic-data
+    # generator): one summed row, so that whatever the host path launches beside the library shows up in the share column
+    rest = [r for r in rows[1:] if "bcbf::" not in r[0]]
+    other = []
+    if rest:
+        calls, tot = sum(int(r[1]) for r in rest), sum(float(r[2]) for r in rest)
+        biggest = max(rest, key=lambda r: float(r[2]))
+        other = [["torch / other (%d kernels; largest: %s)" % (len(rest), biggest[0][:80]), calls, int(tot), tot / max(1, calls),
+                  sum(float(r[4]) for r in rest), min(float(r[5]) for r in rest), max(float(r[6]) for r in rest), ""]]
+    out = [rows[0]] + own + other
     csv.writer(open(DST + "bench_%s_kernel_stats.csv" % tag, "w")).writerows(out)
     print(tag, [(r[0].split("(")[0][-44:], r[1], round(float(r[3]) / 1e3, 1)) for r in out[1:]])
 
@@ -43,13 +53,24 @@ for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online
           "learn_matrix_vector.jsonl", "mc_rollouts.txt", "shared_queries.txt", "shared_sweep.jsonl", "bench_default_prof_union.json", "bench_parts1_prof_union.json", "ramp.txt", "pmc_traffic_refit.json",
           "refit_pair_timeline.txt", "learn_reference_parts4.json", "learn_reference.json", "learn_online.json", "learn_online_tail.json", "learn_online_tail_prof.json", "learn_reference_prof.json",
           "learn_online_prof.json", "pmc_traffic_append.json", "online_b256_n1024_2048.json", "online_b1024_n1024_1280.json",
-          "online_f32_b4096.json", "tol_report.txt"):
+          "online_f32_b4096.json", "tol_report.txt", "learn_loop_reference_f32.json", "learn_loop_reference_f64.json",
+          "learn_loop_reference_nostagger_f32.json", "learn_loop_reference_nostagger_f64.json", "learn_loop_online_tail_f32.json",
+          "learn_loop_online_tail_f64.json", "learn_loop_reference_fit100_f32.json", "learn_loop_reference_fit100_f32_b256.json",
+          "learn_loop_reference_prof.json", "fit_iteration.jsonl", "refit_footprint.jsonl", "online_growth_tail.jsonl"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
         shutil.copy(SRC + a, DST + a)
 
 # ---- HBM traffic of the roofline kernel from the three counter passes per schedule
 NOTE = ("FETCH_SIZE is in KiB and, on gfx950, counts 1/2 of the bytes of wide coalesced reads: bytes = FETCH_SIZE*1024*2; "
         "WRITE_SIZE*1024 exact.  Cross-check: TCC_MISS_sum * 128 B.  (MI355X_MICROARCH.md, HBM / rocprofv3 section)")
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("bayesian_cbf_amd/csrc/posterior_step.hip", "bayesian_cbf_amd/csrc/bcbf_common.h"):
+        h.update(open(R + f, "rb").read())
+    return h.hexdigest()
+
+
 def traffic_pass(tag, kernel_sub, per_instance_alg, command, out_name, sizes=None, dtype="f32", n=3, m=2):
     """Per-instance HBM traffic of one kernel from the three counter passes pmc_traffic_<tag>_{FETCH_SIZE,WRITE_SIZE,TCC..}."""
     per_inst = collections.defaultdict(list)
@@ -76,7 +97,9 @@ def traffic_pass(tag, kernel_sub, per_instance_alg, command, out_name, sizes=Non
                hbm_bytes_per_instance=fetch + write, hbm_bytes_per_launch=(fetch + write) * batch,
                tcc_miss_bytes_per_instance=(mean("TCC_MISS_sum") * 128 if "TCC_MISS_sum" in per_inst else None),
                algorithmic_bytes_per_instance=per_instance_alg, algorithmic_bytes_per_launch=per_instance_alg * batch,
-               traffic_over_algorithmic=(fetch + write) / per_instance_alg)
+               traffic_over_algorithmic=(fetch + write) / per_instance_alg,
+               # the kernel source these counters were taken from: bench.py attaches `traffic` only while the file still hashes to this
+               kernel_source=dict(file="bayesian_cbf_amd/csrc/posterior_step.hip", sha256=source_hash()))
     json.dump(out, open(DST + out_name, "w"), indent=1)
     print("traffic", tag, kernel_sub, round(fetch + write), "x algorithmic", round(out["traffic_over_algorithmic"], 4), "launches", out["launches"])
 
