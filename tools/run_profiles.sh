@@ -1,6 +1,6 @@
 # One GPU call that produces everything tools/collect_profiles.py copies into profiles/ (ROUND tag = $1, default r03).
 # Counters are collected in their own passes (--pmc + --kernel-trace only), as MI355X_MICROARCH.md prescribes.
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # the setting bench.py gives itself; under rocprofv3 the runtime is up before Python runs
 cd $GRAFT_REPO_ROOT
@@ -65,13 +65,30 @@ for T in 4096 8192 16384; do python examples_mc_rollouts.py --trajectories $T --
 python examples_mc_rollouts.py --trajectories 32768 2>/dev/null | tail -1 >> $O/mc_rollouts.txt
 bash tools/run_pmc_refit_traffic.sh $R > /dev/null 2>&1      # refit traffic past L2 -> $O/pmc_traffic_refit.json
 # the learning closed loop at C3 scale (round 5): reference cadence on four part batches, on one stream, and the online schedule
-python tools/bench_learning_loop.py --schedule reference --parts 4 2>/dev/null > $O/learn_reference_parts4.json
-python tools/bench_learning_loop.py --schedule reference 2>/dev/null > $O/learn_reference.json
-python tools/bench_learning_loop.py --schedule online 2>/dev/null > $O/learn_online.json
-python tools/bench_learning_loop.py --schedule online_tail 2>/dev/null > $O/learn_online_tail.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_reference -- python3 tools/bench_learning_loop.py --schedule reference --steps 80 --warmup 40 > $O/learn_reference_prof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online -- python3 tools/bench_learning_loop.py --schedule online --steps 80 --warmup 40 > $O/learn_online_prof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online_tail -- python3 tools/bench_learning_loop.py --schedule online_tail --steps 80 --warmup 40 > $O/learn_online_tail_prof.json 2>/dev/null
+python tools/bench_learning_loop.py --data synthetic --schedule reference --parts 4 2>/dev/null > $O/learn_reference_parts4.json
+python tools/bench_learning_loop.py --data synthetic --schedule reference 2>/dev/null > $O/learn_reference.json
+python tools/bench_learning_loop.py --data synthetic --schedule online 2>/dev/null > $O/learn_online.json
+python tools/bench_learning_loop.py --data synthetic --schedule online_tail 2>/dev/null > $O/learn_online_tail.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_reference -- python3 tools/bench_learning_loop.py --data synthetic --schedule reference --steps 80 --warmup 40 > $O/learn_reference_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online -- python3 tools/bench_learning_loop.py --data synthetic --schedule online --steps 80 --warmup 40 > $O/learn_online_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_online_tail -- python3 tools/bench_learning_loop.py --data synthetic --schedule online_tail --steps 80 --warmup 40 > $O/learn_online_tail_prof.json 2>/dev/null
+# round 6: the loop that learns from ITSELF (rows built on the device from its own x_t, u_t, x_t+1; host-free staggered refits)
+for dt in f32 f64; do
+python tools/bench_learning_loop.py --schedule reference --dtype $dt 2>/dev/null | tail -1 > $O/learn_loop_reference_$dt.json
+python tools/bench_learning_loop.py --schedule reference --no-stagger --dtype $dt 2>/dev/null | tail -1 > $O/learn_loop_reference_nostagger_$dt.json
+python tools/bench_learning_loop.py --schedule online_tail --dtype $dt 2>/dev/null | tail -1 > $O/learn_loop_online_tail_$dt.json
+done
+python tools/bench_learning_loop.py --schedule reference --dtype f32 --fit-iters 100 --steps 40 2>/dev/null | tail -1 > $O/learn_loop_reference_fit100_f32.json
+python tools/bench_learning_loop.py --schedule reference --dtype f32 --batch 256 --fit-iters 100 --steps 40 2>/dev/null | tail -1 > $O/learn_loop_reference_fit100_f32_b256.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_loop_reference -- python3 tools/bench_learning_loop.py --schedule reference --steps 80 > $O/learn_loop_reference_prof.json 2>/dev/null
+# round 6: one batched Adam iteration of the marginal likelihood (BatchedHyperFit), per-kernel shares
+python tools/dev/try_fit_scale.py 2>/dev/null > $O/fit_iteration.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fit_iter -- python3 tools/dev/try_fit_scale.py > /dev/null 2>&1
+python tools/dev/sweep_refit_footprint.py 2>/dev/null > $O/refit_footprint.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_speed_call -- python3 tools/prof_speed_host.py > /dev/null 2>&1
+# round 6: C5 growth with a row-major tail committed 32 rows at a time, next to the in-place form
+( for args in "--dtype f32 --batch 4096 --n0 256 --n1 512" "--dtype f64 --batch 1024 --n0 1024 --n1 1280" "--dtype f64"; do
+    python tools/bench_online.py $args 2>/dev/null | tail -1; python tools/bench_online.py --tail $args 2>/dev/null | tail -1; done ) > $O/online_growth_tail.jsonl
 # C5 append: counters + kernel trace (round 5) -> $O/pmc_traffic_append.json, online_b*_n*.json
 bash tools/run_pmc_append_traffic.sh $R > /dev/null 2>&1
 # fp32 online growth at the C3 batch
