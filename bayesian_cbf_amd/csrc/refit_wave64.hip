@@ -44,6 +44,9 @@ namespace bcbf {
 using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 
+#ifndef BCBF_RP_CHAIN_PRIO
+#define BCBF_RP_CHAIN_PRIO 1     // two-wave / team forms: the chain wave (diagonal tiles) issues with priority over co-resident bulk waves
+#endif
 #ifndef BCBF_RW64_WPB
 #define BCBF_RW64_WPB 1          // waves (= instances) per workgroup (measured: 1 beats 2 by 5 %, 3 loses 80 %: LDS)
 #endif
@@ -1561,6 +1564,9 @@ refit_pair_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
     if (wave == 0) {
         // =============================== the CHAIN ===============================
+#if BCBF_RP_CHAIN_PRIO
+        __builtin_amdgcn_s_setprio(3);        // the chain is the launch's critical path: issue ahead of the bulk waves sharing the SIMD
+#endif
         int fail = 0;
         if (EARLY) { load_rows(0); stage_issue(0); stage_commit(); }
         for (int J = 0; J < nblk; ++J) {
@@ -2027,6 +2033,9 @@ refit_team_kernel(const T* __restrict__ X, const T* __restrict__ UH, const T* __
 
     if (wave == 0) {
         // =============================== the CHAIN ===============================
+#if BCBF_RP_CHAIN_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         int fail = 0;
         for (int J = 0; J < nblk; ++J) {
             const int col0 = J * NB;
