@@ -45,7 +45,9 @@ using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
 using f32x4w = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 
 #ifndef BCBF_RP_CHAIN_PRIO
-#define BCBF_RP_CHAIN_PRIO 1     // two-wave / team forms: the chain wave (diagonal tiles) issues with priority over co-resident bulk waves
+#define BCBF_RP_CHAIN_PRIO 0     // two-wave / team forms: 1 = the chain wave (diagonal tiles) issues with priority over co-resident bulk waves
+                                 // (s_setprio 3).  Measured, round 6, fp64 N = 256: 1024 instances 0.295 -> 0.295 / 0.320 ms (two runs), 512: 0.205 -> 0.195,
+                                 // 768: 0.254 -> 0.281 -- no gain: the chain waits on LDS round trips and MFMA latencies, not on issue slots
 #endif
 #ifndef BCBF_RW64_WPB
 #define BCBF_RW64_WPB 1          // waves (= instances) per workgroup (measured: 1 beats 2 by 5 %, 3 loses 80 %: LDS)
