@@ -598,7 +598,8 @@ def final_window_vs_device_refit(final, sample=64):
 def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40, warmup=None, dtype=torch.float32, device="cuda",
                               seed=1234, schedule="reference", parts=4, stagger=True, shift_invariant=True, dt=0.01,
                               retry_levels=3, fit_iters=0, fit_lr=0.1, fit_dtype=torch.float64, record_states=False, barrier=None,
-                              mid_period_steps=0, query_shift_invariant=True, level_decay_every=4):
+                              mid_period_steps=0, query_shift_invariant=True, level_decay_every=4, factor_dtype=None,
+                              min_jitter_level=1e-5):
     """The reference's learning loop for MANY instances, fed BY ITSELF (LearnedShiftInvariantDynamics.train / fit,
     unicycle_move_to_pose.py:326-386): every control step's observation row is built on the device from the loop's own
     (x_t, u_t, x_{t+1}) -- inside the solve / plant launch (`bcbf_unicycle_control_step_observe`): regressor input = the state
@@ -630,6 +631,15 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
     the hyper-parameters the control path reads are updated in place.
     mid_period_steps: untimed extra steps after the timed region, so that the final model is mid-period (tail / window not
     just refitted) for the parity checks.
+    factor_dtype = torch.float64 with dtype = torch.float32 (schedule "reference"): MIXED precision -- the window is factored in
+    fp64 (`bcbf_refit` + `bcbf_potrs` on the rows cast up: cond(K_b) ~ N s2 / jitter is beyond fp32 on a trajectory's rows, the
+    fp64 factorisation succeeds at make_psd's base level with no retry) and the operator, `UH B`, `Vw` are ROUNDED to fp32 for
+    the streaming passes, which are HBM bound and move half the bytes.  The error the passes then add is cond(L) eps32 =
+    sqrt(cond K_b) eps32 ~ 1e-4, not cond(K_b) eps32: the loop runs at fp32's pass rate with models that agree with the fp64
+    refit of their rows to ~1e-3 (reported: final_vs_fp64_refit_on_device).
+    min_jitter_level (default make_psd's 1e-5): the floor of every instance's jitter level.  fp32 PASSES cannot resolve a posterior
+    variance below ~sqrt(cond K_b) eps32 of the prior: with fp64 factors at the 1e-5 level B_k = s2 B - W'W is rounding noise (it
+    goes indefinite and the cone conversion refuses the program); 1e-3 keeps it resolvable.
 
     Returns (report, final): final = dict(rows = the raw observation rows each instance's model holds, oldest first
     (X, UH, Y, jitter [Bt, N, .]), posterior = (Mk, Bk) of the final model at `xq_check`, xq_check, hyper-parameters; states
@@ -644,6 +654,8 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
         raise ValueError("steps must be a positive multiple of refit_every")
     if fit_iters and schedule != "reference":
         raise ValueError("fit_iters: the hyper-parameter fit rides on the reference schedule's refits")
+    if factor_dtype is not None and factor_dtype != dtype and schedule != "reference":
+        raise ValueError("factor_dtype: mixed precision is built for the reference schedule (the tail's bordered rows are fp32 pivots)")
     online = schedule == "online_tail"
     window = max_train - refit_every if online else max_train
     if window < 1:
@@ -712,13 +724,32 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
                               X=torch.empty(pt.Bt, window, n, **f))
             pt.info, pt.info2 = torch.zeros(pt.Bt, dtype=torch.int32, device=dev), torch.zeros(pt.Bt, dtype=torch.int32, device=dev)
             pt.fail_count = torch.zeros((), dtype=torch.int64, device=dev)
-            pt.level = torch.full((pt.Bt,), 1e-5, **f)                 # make_psd's level per instance (x10 per failed attempt)
+            pt.level = torch.full((pt.Bt,), float(min_jitter_level), **f)     # make_psd's level per instance (x10 per failed attempt)
             pt.retry_counts = torch.zeros(retry_levels + 1, dtype=torch.int64, device=dev)
 
-            def factor_into(buf, Xw, UHw, Yw, Jw, pt=pt):
-                ops.refit_with_retries(Xw, UHw, pt.hp["Bm"], pt.hp["ell"], pt.hp["s2"], Jw, (buf["Lop"], buf["UHB"], pt.info),
-                                       levels=retry_levels, scratch=pt.info2, level=pt.level, counts=pt.retry_counts)
-                ops.potrs(buf["Lop"], Yw, UHw, pt.hp["M0"], want_alpha=False, out_Vw=buf["Vw"])
+            mixed = factor_dtype is not None and factor_dtype != dtype
+            if mixed:
+                fw = dict(dtype=factor_dtype, device=dev)
+                pt.wide = dict(Lop=torch.empty(pt.Bt, ops.lop_elems(window, factor_dtype), **fw), UHB=torch.empty(pt.Bt, window, 1 + m, **fw),
+                               Vw=torch.empty(pt.Bt, window, n, **fw))
+
+            def factor_into(buf, Xw, UHw, Yw, Jw, pt=pt, mixed=mixed):
+                if mixed:
+                    # factor in the wide precision, round the results into the buffers the passes read (the packed layout is the
+                    # same element for element in both precisions: a cast, no re-layout)
+                    up = lambda t_: t_.to(factor_dtype)
+                    hpw = {k: up(v) for k, v in pt.hp.items()}
+                    Xd, UHd, Yd, Jd = up(Xw), up(UHw), up(Yw), up(Jw)
+                    w = pt.wide
+                    ops.refit_with_retries(Xd, UHd, hpw["Bm"], hpw["ell"], hpw["s2"], Jd, (w["Lop"], w["UHB"], pt.info),
+                                           levels=retry_levels, scratch=pt.info2, level=pt.level, counts=pt.retry_counts)
+                    ops.potrs(w["Lop"], Yd, UHd, hpw["M0"], want_alpha=False, out_Vw=w["Vw"])
+                    buf["Lop"].copy_(w["Lop"]); buf["UHB"].copy_(w["UHB"]); buf["Vw"].copy_(w["Vw"])
+                    Jw.copy_(Jd)
+                else:
+                    ops.refit_with_retries(Xw, UHw, pt.hp["Bm"], pt.hp["ell"], pt.hp["s2"], Jw, (buf["Lop"], buf["UHB"], pt.info),
+                                           levels=retry_levels, scratch=pt.info2, level=pt.level, counts=pt.retry_counts)
+                    ops.potrs(buf["Lop"], Yw, UHw, pt.hp["M0"], want_alpha=False, out_Vw=buf["Vw"])
                 buf["X"].copy_(Xw)
                 pt.fail_count += (pt.info != 0).sum()
             pt.factor_into = factor_into
@@ -781,7 +812,7 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
         # a fresh jitter draw per factorisation, at the instance's level: one below the one that last worked (make_psd, :903-919)
         pt.n_refits += 1
         if level_decay_every and pt.n_refits % level_decay_every == 0:
-            pt.level.div_(10).clamp_(min=1e-5)
+            pt.level.div_(10).clamp_(min=float(min_jitter_level))
         Jw = (pt.level[:, None] * rnd(pt.Bt, window)).contiguous()
         if fit_iters:
             wd = fit_dtype
@@ -858,7 +889,8 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
     n_refits = sum(1 for (t, c) in refit_log if warmup <= t < warmup + steps)
     report = dict(schedule=schedule, data="loop", batch=Bt, parts=parts, stagger=bool(stagger), max_train=max_train, points_after_refit=window,
                   steps=steps, warmup=warmup, refit_every=refit_every, dt=dt, shift_invariant=bool(shift_invariant), dtype=str(dtype),
-                  retry_levels=retry_levels, query_shift_invariant=bool(query_shift_invariant and shift_invariant), fit_iters=fit_iters, seconds=elapsed, ms_per_step=elapsed / steps * 1e3,
+                  retry_levels=retry_levels, query_shift_invariant=bool(query_shift_invariant and shift_invariant), fit_iters=fit_iters,
+                  factor_dtype=str(factor_dtype) if factor_dtype is not None else str(dtype), min_jitter_level=min_jitter_level, seconds=elapsed, ms_per_step=elapsed / steps * 1e3,
                   instance_steps_per_s=Bt * steps / elapsed, part_refits_in_timed_region=n_refits,
                   pass_busy_ms_per_step=busy / steps, refit_ms_per_part_refit=(sum(rts) / len(rts)) if rts else None,
                   refit_failures_after_retries=int(sum(int(pt.fail_count) for pt in P)) + (sum(g.rgp.count_drop_failures() for g in P) if online else 0),

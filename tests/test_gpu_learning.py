@@ -169,3 +169,22 @@ def test_refit_retry_factors_only_the_failed_instances():
         np.testing.assert_allclose(host(level[bad]), 1e-3, rtol=1e-5)
         np.testing.assert_allclose(host(level[~bad]), 1e-5, rtol=1e-5)
         assert torch.equal(out[0][~bad], L0[~bad])
+
+
+def test_self_learning_loop_mixed_precision_fp64_factors_fp32_passes_meets_1e_3():
+    """fp32 passes on fp64 FACTORS (`factor_dtype=torch.float64`, jitter floor 1e-3): the window of every instance is factored in fp64
+    on its (fp32) rows cast up -- no retry needed -- and the operator / `UH B` / `Vw` are rounded to fp32 for the HBM-bound passes.
+    The passes then add cond(L) eps32, not cond(K_b) eps32: every instance's final model (the fp32 buffers the passes read) equals the
+    ORACLE's fp64 refit of the rows it holds to north_star's fp32 tolerance 1e-3 -- which pure fp32 misses by two orders of magnitude
+    on the same rows (test above) -- and the programs solve."""
+    from bayesian_cbf_amd.rollouts import self_learning_closed_loop, final_model_vs_fp64_refit
+    rep, final = self_learning_closed_loop(Bt=24, max_train=120, steps=48, refit_every=24, parts=3, dtype=torch.float32, schedule="reference",
+                                           device=DEV, seed=5, factor_dtype=torch.float64, min_jitter_level=1e-3)
+    assert rep["refit_failures_after_retries"] == 0 and rep["factor_dtype"] == "torch.float64"
+    assert sum(rep["instances_factored_per_retry_level"][1:]) == 0            # fp64 factors at the floor level: no retry
+    assert rep["solver_optimal_fraction"] >= 0.9
+    assert final["posterior"][0].dtype == torch.float32
+    worst = _final_vs_oracle(final, 1e-3, "self-learning loop, fp64 factors + fp32 passes")
+    chk = final_model_vs_fp64_refit(final)
+    assert chk["Mk"] <= 1e-3 and chk["Bk"] <= 1e-3 and chk["refit_failures"] == 0, chk
+    print("self-learning mixed precision: worst |dMk| %.2e |dBk| %.2e vs oracle" % (worst[0], worst[1]))

@@ -41,6 +41,8 @@ ap.add_argument("--no-stagger", action="store_true", help="--data loop: every pa
 ap.add_argument("--raw-inputs", action="store_true", help="--data loop: regressor inputs = the raw state, not the shift-invariant (0, 0, theta)")
 ap.add_argument("--dt", type=float, default=0.01)
 ap.add_argument("--retry-levels", type=int, default=3)
+ap.add_argument("--min-jitter-level", type=float, default=1e-5, help="--data loop: floor of the per-instance jitter level (make_psd starts at 1e-5)")
+ap.add_argument("--factor-f64", action="store_true", help="--data loop --dtype f32 --schedule reference: factor the windows in fp64, round the operator to fp32 for the passes")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
     from bayesian_cbf_amd.distributed import launch_ranks
@@ -56,7 +58,8 @@ if a.data == "loop":
     out, final = self_learning_closed_loop(a.batch, a.max_train, a.steps, a.refit_every, warmup=None if a.warmup == 40 else a.warmup,
                                            dtype=dtype, device=ctx.device, seed=1234 + ctx.rank, schedule=a.schedule, parts=a.parts or 4,
                                            stagger=not a.no_stagger, shift_invariant=not a.raw_inputs, dt=a.dt, retry_levels=a.retry_levels,
-                                           fit_iters=a.fit_iters, barrier=ctx.barrier)
+                                           fit_iters=a.fit_iters, barrier=ctx.barrier,
+                                           factor_dtype=torch.float64 if (a.factor_f64 and a.dtype == "f32") else None, min_jitter_level=a.min_jitter_level)
     chk = final_model_vs_fp64_refit(final)
     nfail = out["refit_failures_after_retries"]
     what = "rows built on the device from the loop's own (x_t, u_t, x_t+1)"

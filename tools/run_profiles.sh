@@ -78,6 +78,10 @@ python tools/bench_learning_loop.py --schedule reference --dtype $dt 2>/dev/null
 python tools/bench_learning_loop.py --schedule reference --no-stagger --dtype $dt 2>/dev/null | tail -1 > $O/learn_loop_reference_nostagger_$dt.json
 python tools/bench_learning_loop.py --schedule online_tail --dtype $dt 2>/dev/null | tail -1 > $O/learn_loop_online_tail_$dt.json
 done
+# fp32 passes on fp64 factors (jitter floor 1e-3), next to pure fp32 / fp64 at the same floor
+python tools/bench_learning_loop.py --schedule reference --dtype f32 --factor-f64 --min-jitter-level 1e-3 2>/dev/null | tail -1 > $O/learn_loop_reference_mixed.json
+python tools/bench_learning_loop.py --schedule reference --dtype f32 --min-jitter-level 1e-3 2>/dev/null | tail -1 > $O/learn_loop_reference_f32_floor1e-3.json
+python tools/bench_learning_loop.py --schedule reference --dtype f64 --min-jitter-level 1e-3 2>/dev/null | tail -1 > $O/learn_loop_reference_f64_floor1e-3.json
 python tools/bench_learning_loop.py --schedule reference --dtype f32 --fit-iters 100 --steps 40 2>/dev/null | tail -1 > $O/learn_loop_reference_fit100_f32.json
 python tools/bench_learning_loop.py --schedule reference --dtype f32 --batch 256 --fit-iters 100 --steps 40 2>/dev/null | tail -1 > $O/learn_loop_reference_fit100_f32_b256.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learn_loop_reference -- python3 tools/bench_learning_loop.py --schedule reference --steps 80 > $O/learn_loop_reference_prof.json 2>/dev/null
