@@ -295,17 +295,25 @@ class ReservedGP:
     TAIL_MAX = 64            # tail rows the tail step holds (bcbf_gp_tail_step: tcap <= 64)
 
     def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None,
-                 drop=None, tail=False, retry_levels=None):
-        """retry_levels = k (window mode): the window refit of a drop never waits for the host -- bcbf_refit followed by k
+                 drop=None, tail=False, retry_levels=None, factor_dtype=None, min_jitter_level=1e-5):
+        """factor_dtype (retry_levels mode; e.g. float64 for an fp32 model): the window refits factor in that precision and ROUND the
+        operator / UH B / Vw into the buffers the passes read (the packed layout is the same element for element) -- the passes then
+        add cond(L) eps, not cond(K_b) eps.  min_jitter_level: floor of the per-instance level (fp32 passes cannot resolve a posterior
+        variance below ~ sqrt(cond K_b) eps32 of the prior: 1e-3 for fp32 passes on fp64 factors).
+        retry_levels = k (window mode): the window refit of a drop never waits for the host -- bcbf_refit followed by k
         unconditional bcbf_refit_retry launches (x10 jitter on the instances that failed), into a second operator buffer that
         is swapped in (no allocation per drop).  `drop_info` then holds the last level's info; `drop_failures` is counted only
         when asked for (`count_drop_failures()`: one host read).  None: ten levels with a look at the device per level."""
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
         self.retry_levels = retry_levels
+        self.factor_dtype = factor_dtype if (factor_dtype is not None and factor_dtype != X.dtype) else None
+        self.min_jitter_level = float(min_jitter_level)
+        if self.factor_dtype is not None and retry_levels is None:
+            raise ValueError("factor_dtype: mixed precision is built on the host-free window refit (retry_levels=...)")
         self._alt = None
         # retry_levels mode: the jitter LEVEL of every instance (make_psd starts at 1e-5 and goes x10 per failure; a window refit here
         # starts one level below the one that last worked) -- `jitter_level` is also what a caller scales a new point's draw with
-        self.jitter_level = torch.full((X.shape[0],), 1e-5, dtype=X.dtype, device=X.device)
+        self.jitter_level = torch.full((X.shape[0],), float(min_jitter_level), dtype=X.dtype, device=X.device)
         self.retry_counts = torch.zeros((retry_levels or 0) + 1, dtype=torch.int64, device=X.device)
         self.Bt, self.N, self.n = X.shape
         self.C = UHB.shape[2]
@@ -421,10 +429,24 @@ class ReservedGP:
             #  level below, at every refit)
             every = getattr(self, "level_decay_every", 1)
             if every and (self.drops + 1) % every == 0:
-                self.jitter_level.div_(10).clamp_(min=1e-5)
+                self.jitter_level.div_(10).clamp_(min=self.min_jitter_level)
             J = (self.jitter_level[:, None] * torch.rand(self.Bt, N2, **f)).contiguous()
-            refit_with_retries(X, UH, self.Bm, self.ell, self.s2, J, (Lop, UHB, info), levels=self.retry_levels, scratch=scratch,
-                               level=self.jitter_level, counts=self.retry_counts)
+            Vw_wide = None
+            if self.factor_dtype is not None:
+                # factor in the wide precision on the rows cast up; round the results into the buffers the passes read
+                wd = self.factor_dtype
+                fw = dict(dtype=wd, device=X.device)
+                if getattr(self, "_wide", None) is None or self._wide[0].shape[1] != lop_elems(N2, wd):
+                    self._wide = (torch.empty(self.Bt, lop_elems(N2, wd), **fw), torch.empty(self.Bt, N2, self.C, **fw))
+                up = lambda t_: t_.to(wd)
+                Xd, UHd, Yd, Jd, lvl = up(X), up(UH), up(Y), up(J), up(self.jitter_level)
+                refit_with_retries(Xd, UHd, up(self.Bm), up(self.ell), up(self.s2), Jd, (self._wide[0], self._wide[1], info),
+                                   levels=self.retry_levels, scratch=scratch, level=lvl, counts=self.retry_counts)
+                Vw_wide, _ = potrs(self._wide[0], Yd, UHd, up(self.M0), want_alpha=False)
+                Lop.copy_(self._wide[0]); UHB.copy_(self._wide[1]); J.copy_(Jd); self.jitter_level.copy_(lvl)
+            else:
+                refit_with_retries(X, UH, self.Bm, self.ell, self.s2, J, (Lop, UHB, info), levels=self.retry_levels, scratch=scratch,
+                                   level=self.jitter_level, counts=self.retry_counts)
             if self.tail:
                 self._alt = (self.Lop if self.Lop.shape == Lop.shape else None, UHB, info, scratch)    # the buffer now read is the next drop's target
                 if self._alt[0] is None:
@@ -442,7 +464,10 @@ class ReservedGP:
                 # say so where callers look -- drop_info, the failure count, and the next append's info
                 self.drop_failures += int(bad.sum())
         self.drop_info = info
-        Vw, _ = potrs(Lop, Y, UH, self.M0, want_alpha=False)
+        if self.retry_levels is not None and self.factor_dtype is not None:
+            Vw = Vw_wide.to(X.dtype)
+        else:
+            Vw, _ = potrs(Lop, Y, UH, self.M0, want_alpha=False)
         self._rUH[:, :N2], self._rY[:, :N2], self._rJ[:, :N2] = UH, Y, J
         if self.tail:
             # the window's operator is only read until the next refit: the packed one the refit wrote serves as it is (no re-layout

@@ -654,8 +654,6 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
         raise ValueError("steps must be a positive multiple of refit_every")
     if fit_iters and schedule != "reference":
         raise ValueError("fit_iters: the hyper-parameter fit rides on the reference schedule's refits")
-    if factor_dtype is not None and factor_dtype != dtype and schedule != "reference":
-        raise ValueError("factor_dtype: mixed precision is built for the reference schedule (the tail's bordered rows are fp32 pivots)")
     online = schedule == "online_tail"
     window = max_train - refit_every if online else max_train
     if window < 1:
@@ -759,7 +757,7 @@ def self_learning_closed_loop(Bt=4096, max_train=512, steps=200, refit_every=40,
                 # stagger: part c starts `offset` rows into its period (N_init = window + offset): its drops come that much earlier
                 pt.rgp = ops.ReservedGP(b0["Lop"], b0["Vw"], Xw, b0["UHB"], pt.hp["ell"], pt.hp["s2"], pt.hp["Bm"], pt.hp["M0"],
                                         window + refit_every, window=window, drop=refit_every, UH=UHw, Xdot=Yw, jitter=Jw, tail=True,
-                                        retry_levels=retry_levels)
+                                        retry_levels=retry_levels, factor_dtype=factor_dtype, min_jitter_level=min_jitter_level)
                 pt.rgp.level_decay_every = level_decay_every
                 pt.obs = [tuple(torch.zeros(pt.Bt, 3, **f) for _ in range(3)) for _ in range(2)]
                 pt.solve = ops.unicycle_control_step_prepare(dict(A=pt.hp["A"]), taskc, wsc, pt.x, dt=dt, L_true=L_true, L_mean=L_mean,

@@ -1018,3 +1018,38 @@ def test_growth_with_a_row_major_tail_and_block_commits_vs_in_place_and_oracle(o
     V40, _ = ops.potrs(L40, cut(p["Xdot"], 40), cut(p["UH"], 40), p["M0"], want_alpha=False)
     with pytest.raises(ValueError):                                       # growth with a tail starts from a multiple of 32 points
         ops.ReservedGP(L40, V40, cut(p["X"], 40), U40, p["ell"], p["s2"], p["Bm"], p["M0"], 200, tail=True)
+
+
+def test_window_refit_host_free_and_in_mixed_precision(ops):
+    """`ReservedGP(window, tail, retry_levels=k)`: the window refit of a drop is bcbf_refit + k unconditional bcbf_refit_retry launches into
+    a second operator buffer (no host round trip, no allocation per drop); `factor_dtype=float64` on an fp32 model factors the window in
+    fp64 and rounds the operator / UH B / Vw into the fp32 buffers the passes read.  Both against the default form (host-checked retries)
+    on the same stream of observations through two drops: the posteriors agree to the fp32 tolerance (the jitter of a refit window is a
+    FRESH draw at the instance's level in the host-free forms, so the models differ by their jitter, ~1e-5 of the prior, not more)."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    Bt, n, m, W, D, dtype = 6, 3, 2, 96, 16, torch.float32
+    steps = 2 * D + 5
+    p = make_instances(Bt, W + steps + 1, n, m, dtype=dtype, device=DEV, seed=33)
+    cut = lambda t, N: t[:, :N].contiguous()
+    jit0 = cut(p["jitter"], W)
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], W), cut(p["UH"], W), p["Bm"], p["ell"], p["s2"], jit0)
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], W), cut(p["UH"], W), p["M0"], want_alpha=False)
+    mk = lambda **kw: ops.ReservedGP(Lop, Vw, cut(p["X"], W), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D,
+                                     UH=cut(p["UH"], W), Xdot=cut(p["Xdot"], W), jitter=jit0, tail=True, **kw)
+    torch.manual_seed(0)
+    g_ref, g_free, g_mix = mk(), mk(retry_levels=2), mk(retry_levels=2, factor_dtype=torch.float64)
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    for t in range(steps):
+        row = lambda k: p[k][:, W + t].contiguous()
+        xq = (p["xq"] + 0.01 * t).contiguous()
+        outs = [g.append(row("X"), row("UH"), row("Xdot"), row("jitter"), query=xq) for g in (g_ref, g_free, g_mix)]
+        for (i_, M_, B_), name in zip(outs[1:], ("host-free", "mixed precision")):
+            assert int((i_ != 0).sum()) == 0
+            rel_close(host(M_), host(outs[0][1]), 1e-3, scale=max(1.0, float(outs[0][1].abs().max())), what="Mk window refit " + name)
+            rel_close(host(B_), host(outs[0][2]), 1e-3, scale=prior, what="Bk window refit " + name)
+    assert g_ref.drops == g_free.drops == g_mix.drops == 2
+    assert g_free.count_drop_failures() == 0 and g_mix.count_drop_failures() == 0
+    assert g_mix.Lop.dtype == torch.float32 and int(g_mix.retry_counts[0]) == 2 * Bt and int(g_mix.retry_counts[1:].sum()) == 0
+    with pytest.raises(ValueError):
+        mk(factor_dtype=torch.float64)                                   # mixed precision needs the host-free refit

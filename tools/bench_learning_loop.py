@@ -42,7 +42,7 @@ ap.add_argument("--raw-inputs", action="store_true", help="--data loop: regresso
 ap.add_argument("--dt", type=float, default=0.01)
 ap.add_argument("--retry-levels", type=int, default=3)
 ap.add_argument("--min-jitter-level", type=float, default=1e-5, help="--data loop: floor of the per-instance jitter level (make_psd starts at 1e-5)")
-ap.add_argument("--factor-f64", action="store_true", help="--data loop --dtype f32 --schedule reference: factor the windows in fp64, round the operator to fp32 for the passes")
+ap.add_argument("--factor-f64", action="store_true", help="--data loop --dtype f32: factor the windows in fp64, round the operator to fp32 for the passes")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("BCBF_BENCH_FORCE_LAUNCH") == "1"):
     from bayesian_cbf_amd.distributed import launch_ranks
