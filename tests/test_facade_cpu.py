@@ -319,3 +319,34 @@ print("reference loaded the facade checkpoint")
 """ % (golden, p2, path)
     out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "reference loaded the facade checkpoint" in out.stdout, out.stderr[-2000:]
+
+
+# ---- batched hyper-parameter fit: the host-side pieces that need no GPU
+def test_batched_fit_lr_schedule_is_torchs_multisteplr_and_param_layout_counts():
+    """`batched_fit.lr_schedule` == torch.optim.lr_scheduler.MultiStepLR(milestones = round(f T), gamma 0.1) stepped once per iteration
+    (the reference's schedule, control_affine_model.py:293-300), value for value incl. duplicate and zero milestones; the raw-parameter
+    row's length is the library's (`bcbf_fit_param_count`, pure host code) for the full-rank, rank-one and diagonal parameterisations."""
+    import warnings
+    from bayesian_cbf_amd import batched_fit, _lib
+    for T in (1, 2, 3, 4, 5, 7, 10, 33, 50, 100):
+        p_ = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p_], lr=0.1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(round(f * T)) for f in batched_fit.MILESTONES])
+            want = []
+            for _ in range(T):
+                want.append(opt.param_groups[0]["lr"])
+                opt.step()
+                sch.step()
+        assert batched_fit.lr_schedule(0.1, T) == want, T
+    n, m = 3, 2
+    C = 1 + m
+    assert _lib.lib.bcbf_fit_param_count(n, m, n, C) == n + 1 + n * n + n + C * C + C + C * n
+    assert _lib.lib.bcbf_fit_param_count(n, m, 1, 1) == n + 1 + n + n + C + C + C * n
+    assert _lib.lib.bcbf_fit_param_count(n, m, 0, 0) == n + 1 + n + C + C * n
+    assert _lib.lib.bcbf_fit_param_count(9, m, 1, 1) < 0 and _lib.lib.bcbf_fit_param_count(n, 4, 1, 1) < 0
+    with pytest.raises(RuntimeError):
+        batched_fit.BatchedHyperFit(torch.zeros(2, 37, dtype=torch.float64), n, m)          # a CPU tensor: there is no CPU path
+    with pytest.raises(ValueError):
+        batched_fit.BatchedHyperFit(torch.zeros(2, 36, dtype=torch.float64), n, m)          # wrong row length
