@@ -15,6 +15,8 @@
 // Flops N^3 / 3 per model; operator bytes ~ nblk^3 / 6 tiles per model, shared by the nblk waves of a model through L2 (they are
 // launched next to one another, heaviest block column first).
 #include "bcbf_common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace bcbf {
 
@@ -170,15 +172,233 @@ trtri_mfma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv,
     }
 }
 
+// RIGHT-LOOKING within a block column, N <= 512 (round 6, second form): the form above reads every X_KJ back from the dense output it has just written -- a
+// store, a fence and an exposed load round trip per block row, at ~220 registers (two waves per SIMD): 13 TFLOP/s.  Here a wave keeps the accumulators of ALL the
+// tiles below it in registers (up to 15 tiles x 16 registers, one wave per SIMD): as soon as X_KJ exists -- in the accumulator layout, which IS the B-operand
+// layout -- it is applied to every pending row I > K, `acc_I += L_IK X_KJ`, with the A operand gathered in the accumulator's row order straight from the packed
+// operator.  Nothing the wave loads depends on anything it computed: the operand loads of the next tile are in flight under the current tile's MFMA chain, there
+// is no read-back and no fence.  fp64 takes HALF a block column per wave (16 columns: 15 tiles x 16 registers again).
+constexpr int TR_MAXT = 15;
+constexpr int TR_RING = 3;          // operand sets in flight per wave (tiles ahead + 1); 4 x 16 loads exceed what s_waitcnt vmcnt can count (63): the compiler then waits for all but the newest set
+
+// compile-time loop: every index of the accumulator array is a constant, so the array lives in registers (with a run-time `break` in an unrolled loop the
+// compiler kept it in scratch: 1 KB per lane)
+template <int B, int E, typename F> __device__ inline void static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+
+__global__ void __launch_bounds__(64, 1)
+trtri_rl_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, int N, int Np, int nblk) {
+    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+    constexpr int V = 4;
+    const int b = blockIdx.x / nblk, J = blockIdx.x - b * nblk;
+    const float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    float* __restrict__ X = Linv + (size_t)b * N * N;
+    const int lane = threadIdx.x, col = lane & 31, g = lane >> 5;
+    const int gc = J * NB + col;
+    const bool vc = gc < N;
+    const int cnt = nblk - J - 1;                                  // tiles below the diagonal tile
+    for (int i = g; i < J * NB; i += 2)
+        if (vc && i < N) X[(size_t)i * N + gc] = 0.0f;
+    // register q of a lane <-> row rho(q) + 4 g of its column (the MFMA accumulator layout).  Every address below is a wave-uniform base (scalar registers)
+    // plus a 32-bit per-lane offset formed ONCE (per kernel: doff, xoff; per K: kb) -- formed per load, the index arithmetic of the packed layout (three
+    // quarter-rate integer multiplies and a 64-bit add each) was 20 vector instructions per load, more issue slots than the MFMA chain it feeds
+    unsigned doff[16], xoff[16], kb[16];
+    int rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        rr[q] = 8 * (q >> 2) + (q & 3) + 4 * g;
+        doff[q] = (unsigned)(NB * rr[q] + col);                    // inv(L_KK)[col][rr]  in the full-tile copy (column-major)
+        xoff[q] = (unsigned)(rr[q] * N + gc);                      // X[32 K + rr][gc]
+    }
+    f32x16 xk, acc[TR_MAXT];
+    {
+        const float* dj = lop + lop_dfull_block(J, Np);
+        float* xj = X + (size_t)J * NB * N;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            xk[q] = dj[(unsigned)(NB * col + rr[q])];              // inv(L_JJ)[rr][col] (zeros above the diagonal)
+            if (vc && J * NB + rr[q] < N) xj[xoff[q]] = xk[q];
+        }
+    }
+    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value] = f32x16{0}; });
+    // A operand of tile (I, K) in the accumulator's contraction order: L[32 I + col][32 K + rr]
+    int Kcur = J;
+    auto load_a = [&](int I, float (&av)[16]) {
+        const float* pi = lop + (I - Kcur - 1) * NB;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[q] = pi[kb[q]];
+    };
+    float ar[TR_RING][16];
+    static_for<0, TR_MAXT + 1>([&](auto kc) {                      // K = J + kk
+        constexpr int kk = decltype(kc)::value;
+        if (kk > cnt) return;
+        const int K = J + kk;
+        Kcur = K;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kb[q] = (unsigned)(lop_base<V>(K * NB + rr[q], Np) + (K + 1) * NB + col);     // (row 32 (K + 1): the first row a column of block K stores -- lop_base itself is negative for the first columns)
+        // the A operands of the first TR_RING - 1 pending tiles are issued BEFORE X_K is formed (they do not depend on it)
+        static_for<0, TR_RING - 1>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if (kk + r < cnt) load_a(J + 1 + kk + r, ar[r]);
+        });
+        if constexpr (kk > 0) {
+            f32x16 out = {0};
+            const float* dk = lop + lop_dfull_block(K, Np);
+            float di[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) di[q] = dk[doff[q]];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(di[q], acc[kk - 1][q], out, 0, 0, 0);
+            float* xkp = X + (size_t)K * NB * N;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                xk[q] = -out[q];
+                if (vc && K * NB + rr[q] < N) xkp[xoff[q]] = xk[q];
+            }
+        }
+        static_for<0, TR_MAXT - kk>([&](auto pc) {
+            constexpr int d = decltype(pc)::value, t = kk + d;     // tile t of this block column (I = J + 1 + t), ring slot d % TR_RING
+            if (t < cnt) {
+                if (t + TR_RING - 1 < cnt) load_a(J + 1 + t + TR_RING - 1, ar[(d + TR_RING - 1) % TR_RING]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d % TR_RING][q], xk[q], acc[t], 0, 0, 0);
+            }
+        });
+    });
+}
+
+__global__ void __launch_bounds__(64, 1)
+trtri_rl_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, int N, int Np, int nblk) {
+    using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    constexpr int V = 2;
+    const int w = blockIdx.x % (2 * nblk), b = blockIdx.x / (2 * nblk), J = w >> 1, half = w & 1;
+    const double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    double* __restrict__ X = Linv + (size_t)b * N * N;
+    const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
+    const int lc = 16 * half + c16, gc = J * NB + lc;              // this lane's column (within the block column / global)
+    const bool vc = gc < N;
+    const int cnt = nblk - J - 1;
+    for (int i = g; i < J * NB; i += 4)
+        if (vc && i < N) X[(size_t)i * N + gc] = 0.0;
+    // register q of acc[.][hk] <-> row rr[hk][q] = 16 hk + 4 q + g of the lane's column; per-lane offsets formed once (see the fp32 kernel)
+    int rr[2][4];
+    unsigned doff[2][4][2], xoff[2][4], kb[2][4];
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rr[hk][q] = 16 * hk + 4 * q + g;
+            xoff[hk][q] = (unsigned)(rr[hk][q] * N + gc);
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) doff[hk][q][hi] = (unsigned)(NB * rr[hk][q] + 16 * hi + c16);     // inv(L_KK)[16 hi + c16][rr]
+        }
+    f64x4 xk[2], acc[TR_MAXT][2];
+    {
+        const double* dj = lop + lop_dfull_block(J, Np);
+        double* xj = X + (size_t)J * NB * N;
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xk[hk][q] = dj[(unsigned)(NB * lc + rr[hk][q])];
+                if (vc && J * NB + rr[hk][q] < N) xj[xoff[hk][q]] = xk[hk][q];
+            }
+    }
+    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value][0] = f64x4{0}; acc[decltype(tc)::value][1] = f64x4{0}; });
+    // A operand: L[32 I + 16 hi + c16][32 K + rr]
+    int Kcur = J;
+    auto load_a = [&](int I, double (&av)[2][4][2]) {
+        const double* pi = lop + (I - Kcur - 1) * NB;
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                av[hk][q][0] = pi[kb[hk][q]];
+                av[hk][q][1] = pi[kb[hk][q] + 16u];
+            }
+    };
+    auto chain = [&](f64x4 (&ac)[2], const double (&av)[2][4][2]) {
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi)
+                    ac[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[hk][q][hi], xk[hk][q], ac[hi], 0, 0, 0);
+    };
+    double ar[TR_RING][2][4][2];
+    static_for<0, TR_MAXT + 1>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        if (kk > cnt) return;
+        const int K = J + kk;
+        Kcur = K;
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kb[hk][q] = (unsigned)(lop_base<V>(K * NB + rr[hk][q], Np) + (K + 1) * NB + c16);
+        static_for<0, TR_RING - 1>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if (kk + r < cnt) load_a(J + 1 + kk + r, ar[r]);
+        });
+        if constexpr (kk > 0) {
+            f64x4 out[2] = {f64x4{0}, f64x4{0}};
+            const double* dk = lop + lop_dfull_block(K, Np);
+            double di[2][4][2];
+#pragma unroll
+            for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int hi = 0; hi < 2; ++hi) di[hk][q][hi] = dk[doff[hk][q][hi]];
+#pragma unroll
+            for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int hi = 0; hi < 2; ++hi)
+                        out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(di[hk][q][hi], acc[kk - 1][hk][q], out[hi], 0, 0, 0);
+            double* xkp = X + (size_t)K * NB * N;
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xk[hi][q] = -out[hi][q];
+                    if (vc && K * NB + rr[hi][q] < N) xkp[xoff[hi][q]] = xk[hi][q];
+                }
+        }
+        static_for<0, TR_MAXT - kk>([&](auto pc) {
+            constexpr int d = decltype(pc)::value, t = kk + d;
+            if (t < cnt) {
+                if (t + TR_RING - 1 < cnt) load_a(J + 1 + t + TR_RING - 1, ar[(d + TR_RING - 1) % TR_RING]);
+                chain(acc[t], ar[d % TR_RING]);
+            }
+        });
+    });
+}
+
 int launch_trtri_mfma_f32(const float* Lop, float* Linv, int Bt, int N, void* stream) {
     const int Np = round_up(N, NB), nblk = Np / NB;
     if ((long long)Bt * nblk > 0x7fffffffLL) return BCBF_EINVAL;
+    static const bool ll = [] { const char* e = getenv("BCBF_TRTRI_LEFT"); return e && e[0] == '1'; }();      // (development: force the left-looking form)
+    if (nblk - 1 <= TR_MAXT && !ll) {
+        hipLaunchKernelGGL(trtri_rl_kernel_f32, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
+        return check_launch("trtri_rl");
+    }
     hipLaunchKernelGGL(trtri_mfma_kernel_f32, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
     return check_launch("trtri_mfma");
 }
 int launch_trtri_mfma_f64(const double* Lop, double* Linv, int Bt, int N, void* stream) {
     const int Np = round_up(N, NB), nblk = Np / NB;
     if ((long long)Bt * nblk > 0x7fffffffLL) return BCBF_EINVAL;
+    // fp64: the left-looking form stays the default (4096 x 512: 14.0 ms against 17.5 for the register-resident form, whose half-width tiles double the A-operand
+    // loads per flop); BCBF_TRTRI_RL64=1 selects it (development)
+    static const bool ll = [] { const char* e = getenv("BCBF_TRTRI_RL64"); return !(e && e[0] == '1'); }();
+    if (nblk - 1 <= TR_MAXT && !ll) {
+        if ((long long)Bt * nblk * 2 > 0x7fffffffLL) return BCBF_EINVAL;
+        hipLaunchKernelGGL(trtri_rl_kernel_f64, dim3(Bt * nblk * 2), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
+        return check_launch("trtri_rl");
+    }
     hipLaunchKernelGGL(trtri_mfma_kernel_f64, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
     return check_launch("trtri_mfma");
 }
