@@ -53,11 +53,15 @@ trtri_mfma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, i
         // operands of block K + 1 are in flight while block K's MFMA chain runs (two register sets, swapped by the unrolled pair)
         float av[2][16], bv[2][16];
         auto load = [&](int K, float (&a)[16], float (&bq)[16]) {
+            const int stride = Np - NB * (K + 1);
+            const float* pa = lop + (lop_base<V>(K * NB, Np) + NB * (K + 1)) + (I - K - 1) * NB;      // (scalar base + 32-bit lane offsets: see the fp64 kernel)
+            const float* pb = X + (size_t)K * NB * N + J * NB;
+            const bool krow = (K + 1) * NB <= N;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int k = 2 * s + g, gk = K * NB + k;          // column of L / row of X
-                a[s] = lop[lop_base<V>(gk, Np) + gr];
-                bq[s] = (vc && gk < N) ? X[(size_t)gk * N + gc] : 0.0f;
+                const int k = 2 * s + g;                           // column of L / row of X within block K
+                a[s] = pa[(unsigned)__builtin_amdgcn_mul_u24(k, stride) + col];
+                bq[s] = (vc && (krow || K * NB + k < N)) ? pb[(unsigned)__builtin_amdgcn_mul_u24(k, N) + col] : 0.0f;
             }
         };
         load(J, av[0], bv[0]);
@@ -112,15 +116,22 @@ trtri_mfma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv,
         f64x4 acc[2][2] = {};
         // operands of block K + 1 are in flight while block K's MFMA chain runs (two register sets, as in the fp32 kernel)
         double av[2][8][2], bv[2][8][2];
+        // addresses: wave-uniform bases (scalar registers) + 32-bit per-lane offsets.  Column c = 4 s + g of block K starts at lop_base(32 K) + c (Np - 32 (K + 1)):
+        // one 24-bit multiply-add per s and K instead of the layout's full index arithmetic per load (20 vector instructions each, measured in the fp32 kernel)
         auto load = [&](int K, double (&a)[8][2], double (&bq)[8][2]) {
+            const int stride = Np - NB * (K + 1);
+            const double* pa = lop + (lop_base<V>(K * NB, Np) + NB * (K + 1)) + (I - K - 1) * NB;     // row 32 I of column 32 K (>= 0: the column stores rows >= 32 (K + 1))
+            const double* pb = X + (size_t)K * NB * N + J * NB;
+            const bool krow = (K + 1) * NB <= N;                  // (a block row clear of the padding: no per-row test)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                          // k = 4 s + g within the 32-wide tile
-                const int k = 4 * s + g, gk = K * NB + k;
+                const unsigned ao = (unsigned)__builtin_amdgcn_mul_u24(4 * s + g, stride) + c16;
+                const unsigned bo = (unsigned)__builtin_amdgcn_mul_u24(4 * s + g, N) + c16;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    a[s][h] = lop[lop_base<V>(gk, Np) + I * NB + 16 * h + c16];
+                    a[s][h] = pa[ao + 16u * h];
                     const int gc = J * NB + 16 * h + c16;
-                    bq[s][h] = (gc < N && gk < N) ? X[(size_t)gk * N + gc] : 0.0;
+                    bq[s][h] = (gc < N && (krow || K * NB + 4 * s + g < N)) ? pb[bo + 16u * h] : 0.0;
                 }
             }
         };
