@@ -56,7 +56,7 @@ for a in ("configs.jsonl", "refit_forms.jsonl", "refit_forms_f32.jsonl", "online
           "online_f32_b4096.json", "tol_report.txt", "learn_loop_reference_f32.json", "learn_loop_reference_f64.json",
           "learn_loop_reference_nostagger_f32.json", "learn_loop_reference_nostagger_f64.json", "learn_loop_online_tail_f32.json",
           "learn_loop_online_tail_f64.json", "learn_loop_reference_fit100_f32.json", "learn_loop_reference_fit100_f32_b256.json",
-          "learn_loop_reference_prof.json", "learn_loop_reference_mixed.json", "learn_loop_reference_f32_floor1e-3.json", "learn_loop_reference_f64_floor1e-3.json", "fit_iteration.jsonl", "refit_footprint.jsonl", "online_growth_tail.jsonl"):
+          "learn_loop_reference_prof.json", "learn_loop_reference_mixed.json", "learn_loop_reference_f32_floor1e-3.json", "learn_loop_reference_f64_floor1e-3.json", "learn_loop_reference_fit100_mixed_b256.json", "trtri_syrk.jsonl", "fit_iteration.jsonl", "refit_footprint.jsonl", "online_growth_tail.jsonl"):
     if os.path.exists(SRC + a) and os.path.getsize(SRC + a):
         shutil.copy(SRC + a, DST + a)
 
