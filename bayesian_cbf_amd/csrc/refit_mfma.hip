@@ -348,6 +348,9 @@ int launch_refit_pair32(const float* X, const float* UH, const float* Bm, const 
                         hipStream_t st);                                               // refit_wave64.hip: two waves per instance
 
 
+int launch_refit_slab32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                        const float* jitter, float* Lop, float* UHB, int* info, int Bt, int N, int Np, int n, int C,
+                        hipStream_t st);                                               // refit_slab.hip: four waves per instance, operands staged through LDS
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                         const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N,
                         int Np, int n, int C, int nw, hipStream_t st);                 // refit_wave64.hip: a team of eight (four) waves per instance
@@ -396,6 +399,14 @@ extern "C" int bcbf_refit_mfma_f32(const float* X, const float* UH, const float*
     if (Np / NB <= 16 && Np >= 256 && Bt > cus_ && Bt <= 2 * cus_ && !Kdense) { team = true; team_nw = 4; }
     if (getenv("BCBF_REFIT_WAVE") || getenv("BCBF_REFIT_PAIR")) team = false;      // (another form is being forced)
     if (const char* e = getenv("BCBF_REFIT_TEAM")) { team = e[0] == '1' && Np / NB <= 256; if (e[0] == '1' && e[1] == '4') team_nw = 4; else if (e[0] == '1' && e[1] == '8') team_nw = 8; }
+    // Large batches of N = 384 .. 512 (refit_slab.hip): BCBF_REFIT_SLAB=0/1 forces the choice
+    bool slab = false;
+    if (const char* e = getenv("BCBF_REFIT_SLAB")) slab = e[0] == '1';
+    if (slab && !Kdense && !Ldense) {
+        if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;
+        if (n < 1 || n > BCBF_MAX_STATE_DIM || m < 1 || m > BCBF_MAX_CTRL_DIM) return BCBF_EINVAL;
+        if (launch_refit_slab32(X, UH, Bm, ell, s2, jitter, Lop, UHB, info, Bt, N, Np, n, m + 1, st) == 0) return check_launch("refit_slab32");
+    }
     if (team) {
         if (!Kdense) {
             if (!X || !UH || !Bm || !ell || !s2 || !UHB) return BCBF_EINVAL;

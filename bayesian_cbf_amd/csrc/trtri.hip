@@ -60,8 +60,8 @@ trtri_mfma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, i
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int k = 2 * s + g;                           // column of L / row of X within block K
-                a[s] = pa[(unsigned)__builtin_amdgcn_mul_u24(k, stride) + col];
-                bq[s] = (vc && (krow || K * NB + k < N)) ? pb[(unsigned)__builtin_amdgcn_mul_u24(k, N) + col] : 0.0f;
+                a[s] = pa[__umul24(k, stride) + col];
+                bq[s] = (vc && (krow || K * NB + k < N)) ? pb[__umul24(k, N) + col] : 0.0f;
             }
         };
         load(J, av[0], bv[0]);
@@ -125,8 +125,8 @@ trtri_mfma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv,
             const bool krow = (K + 1) * NB <= N;                  // (a block row clear of the padding: no per-row test)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                          // k = 4 s + g within the 32-wide tile
-                const unsigned ao = (unsigned)__builtin_amdgcn_mul_u24(4 * s + g, stride) + c16;
-                const unsigned bo = (unsigned)__builtin_amdgcn_mul_u24(4 * s + g, N) + c16;
+                const unsigned ao = __umul24(4 * s + g, stride) + c16;
+                const unsigned bo = __umul24(4 * s + g, N) + c16;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     a[s][h] = pa[ao + 16u * h];

@@ -1202,6 +1202,44 @@ def test_refit_super_panel_form_equals_plain_form(ops, dtype, N, n, m, monkeypat
             rel_close(host(Lb_s[i]), host(Lb_p[i]), 2e-5, what="super-panel vs plain form, large jitter [%d]" % i)
 
 
+@pytest.mark.parametrize("Bt,N,n,m", [(9, 512, 3, 2), (5, 500, 3, 2), (6, 448, 4, 2), (4, 130, 2, 1), (3, 490, 3, 3)])
+def test_refit_slab_form_vs_one_wave_form_and_oracle(ops, Bt, N, n, m, monkeypatch):
+    """The four-waves-per-instance form of the fp32 refit whose update operands are staged through LDS by `buffer_load ... lds`
+    (refit_slab.hip; experimental, BCBF_REFIT_SLAB=1 -- DESIGN_NOTES round 6: correct, slower than the one-wave form) against the
+    one-wave form on the same inputs: failure index (a failed pivot in one instance), UH*B, the packed operator to cond x eps, and
+    through potrs + the posterior kernel against the oracle.  Shapes: full super-panels, a ragged last block, n = 4, an odd count
+    of 32-row blocks padded to an even one, C = 4."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    p = make_instances(Bt, N, n, m, dtype=torch.float32, device=DEV, seed=700 + N)
+    jit = p["jitter"].clone()
+    X, UH = p["X"].clone(), p["UH"].clone()
+    X[2, 70], UH[2, 70] = X[2, 3], UH[2, 3]          # instance 2: a duplicated point with a negative shift -> pivot 71 fails
+    jit[2] = 0.0
+    jit[2, 70] = -1e-2
+    args = (X, UH, p["Bm"], p["ell"], p["s2"], jit)
+    monkeypatch.setenv("BCBF_REFIT_SLAB", "1")
+    Lop_s, UHB_s, info_s, _ = ops.refit(*args)
+    monkeypatch.delenv("BCBF_REFIT_SLAB")
+    monkeypatch.setenv("BCBF_REFIT_WAVE", "1")
+    Lop_w, UHB_w, info_w, _ = ops.refit(*args)
+    torch.cuda.synchronize()
+    is_ = info_s.cpu().numpy()
+    assert np.array_equal(is_, info_w.cpu().numpy()) and is_[2] == 71 and (is_ == 0).sum() == Bt - 1
+    assert torch.equal(UHB_s, UHB_w)
+    for i in np.nonzero(is_ == 0)[0]:
+        rel_close(host(Lop_s[i]), host(Lop_w[i]), 2e-3, what="Lop vs one-wave form [%d]" % i)
+    Vw, _ = ops.potrs(Lop_s, p["Xdot"], UH, p["M0"], want_alpha=False)
+    Mk, Bk = ops.posterior_step(Lop_s, Vw, X, UHB_s, p["ell"], p["s2"], p["Bm"], p["M0"], p["xq"])
+    h = {k: host(v) for k, v in dict(X=X, U=p["U"], Xdot=p["Xdot"], Bm=p["Bm"], ell=p["ell"], s2=p["s2"], M0=p["M0"], jit=jit).items()}
+    for i in (0, 1):                                   # (instance 2 is the failed one)
+        st = ogp.refit_state(h["X"][i], h["U"][i], h["Xdot"][i], h["Bm"][i], h["ell"][i], h["s2"][i], h["M0"][i],
+                             h["jit"][i][None] / 1e-5)
+        Mk_o, Bk_o = ogp.posterior_step(st["L"][None], st["alpha"][None], h["X"][i][None], st["UHB"][None], h["ell"][i][None],
+                                        h["s2"][i][None], h["Bm"][i][None], h["M0"][i][None], host(p["xq"])[i][None])
+        rel_close(host(Mk)[i], Mk_o[0], 1e-3, scale=max(1.0, np.abs(Mk_o).max()), what="Mk")
+        rel_close(host(Bk)[i], Bk_o[0], 1e-3, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk")
+
+
 @pytest.mark.timeout(180)
 def test_refit_handoff_protocols_soak(ops, monkeypatch):
     """The chain / bulk refit kernels hand work over through spin waits on LDS counters; a lost wake-up would be a hang.
