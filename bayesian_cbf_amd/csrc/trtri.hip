@@ -388,10 +388,245 @@ trtri_rl_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, i
     });
 }
 
+// The register-resident form again, its operand stream through LDS by `buffer_load ... lds` (round 6, third form, fp32).  What the form above lacks is
+// bytes in flight: its operand ring lives in registers beside 240 accumulator registers, and with every tile in a basic block of its own the compiler's
+// s_waitcnt placement drains the ring per tile -- a memory round trip per 16 MFMAs.  Nothing this wave reads depends on what it computes, so the WHOLE read
+// sequence is known up front: for K = J ..: [inv(L_KK) (K > J)], L_{K+1,K}, L_{K+2,K}, ...  -- every element a 4 KB tile.  A run-time cursor walks that sequence
+// TD_RING - 1 elements ahead of the (compile-time unrolled) consumption and copies each tile into a ring of LDS slots with four LDS-DMA instructions (no
+// registers, no s_waitcnt the compiler knows about); a consumer step issues the next element's copy, waits with a COUNTED vmcnt for its own element (the
+// TD_RING - 1 younger copies stay in flight; past the end of the sequence the cursor issues out-of-range dummies so that the count holds), reads its sixteen
+// A-operand registers from the slot and runs the MFMA chain.  The inverted diagonal tile is just another element of the stream (its full-tile copy is
+// column-major like an off-diagonal tile's LDS image: one fragment addressing for both).  Workgroup -> (model, block column) is XCD-aware: the block columns
+// of a model are dealt to ONE XCD (consecutive workgroups of that XCD), whose L2 then serves the K + 1 reads of tile (I, K).
+constexpr int TD_RING = 8;
+__global__ void __launch_bounds__(64, 1)
+trtri_dma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, int Bt, int N, int Np, int nblk) {
+    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+    constexpr int V = 4;
+    __shared__ __attribute__((aligned(16))) float ring[TD_RING][NB * NB];
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;         // (workgroups go to the XCDs round-robin)
+    const int J = pos % nblk, b = (pos / nblk) * 8 + xcd;
+    if (b >= Bt) return;
+    const float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    float* __restrict__ X = Linv + (size_t)b * N * N;
+    const int lane = threadIdx.x, col = lane & 31, g = lane >> 5;
+    const int gc = J * NB + col;
+    const bool vc = gc < N;
+    const int cnt = nblk - J - 1;                                  // tiles below the diagonal tile
+    for (int i = g; i < J * NB; i += 2)
+        if (vc && i < N) X[(size_t)i * N + gc] = 0.0f;
+    unsigned xoff[16];
+    int rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        rr[q] = 8 * (q >> 2) + (q & 3) + 4 * g;
+        xoff[q] = (unsigned)(rr[q] * N + gc);                      // X[32 K + rr][gc]
+    }
+    f32x16 xk, acc[TR_MAXT];
+    {
+        const float* dj = lop + lop_dfull_block(J, Np);
+        float* xj = X + (size_t)J * NB * N;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            xk[q] = dj[(unsigned)(NB * col + rr[q])];              // inv(L_JJ)[rr][col] (zeros above the diagonal)
+            if (vc && J * NB + rr[q] < N) xj[xoff[q]] = xk[q];
+        }
+    }
+    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value] = f32x16{0}; });
+
+    // ---- the read sequence: cursor (cK, cI); cI == cK: the inverted diagonal tile of cK, cI > cK: tile (cI, cK)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lop), 0, (unsigned)(lop_elems<V>(Np) * 4), 0x00020000);
+    int cK = J, cI = J + 1, wslot = 0;
+    if (cI >= nblk) { cK = J + 1; cI = cK; }
+    const int lq = lane >> 3, lr = lane & 7;                        // a copy instruction moves 8 columns x 32 rows: lane = (column lq, rows 4 lr ..)
+    auto issue_next = [&]() {
+        const bool valid = cK < nblk, diag = cI == cK;
+        const int cs = Np - NB * (cK + 1);
+        // per-lane source offset, scalar offset of the element, scalar step between its four pieces (bytes)
+        const int voff = !valid ? 0x7ffffff0 : diag ? 16 * lane : (lq * cs + 4 * lr) * 4;
+        const int soff = diag ? lop_dfull_block(cK, Np) * 4 : (lop_base<V>(cK * NB, Np) + NB * (cK + 1) + NB * (cI - cK - 1)) * 4;
+        const int step = diag ? 1024 : 32 * cs;
+        __attribute__((address_space(3))) float* dst = (__attribute__((address_space(3))) float*)&ring[wslot][0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 256 * j), 16, voff, valid ? soff + j * step : 0, 0, 0);
+        wslot = wslot + 1 == TD_RING ? 0 : wslot + 1;
+        ++cI;
+        if (cI >= nblk) { ++cK; cI = cK; }
+    };
+    for (int a = 0; a < TD_RING - 1; ++a) issue_next();
+    int rslot = 0;
+    // the next element of the sequence as sixteen A-operand registers: fr[q] = tile[row col][column rr[q]]  (the accumulator's contraction order)
+    auto next_frags = [&](float (&fr)[16]) {
+        issue_next();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (TD_RING - 1)) : "memory");
+        const __attribute__((address_space(3))) float* src = (const __attribute__((address_space(3))) float*)&ring[rslot][0] + (4 * g) * NB + col;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) fr[q] = src[(8 * (q >> 2) + (q & 3)) * NB];
+        rslot = rslot + 1 == TD_RING ? 0 : rslot + 1;
+    };
+    static_for<0, TR_MAXT + 1>([&](auto kc) {                      // K = J + kk
+        constexpr int kk = decltype(kc)::value;
+        if (kk > cnt) return;
+        const int K = J + kk;
+        if constexpr (kk > 0) {
+            float di[16];
+            next_frags(di);
+            f32x16 out = {0};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(di[q], acc[kk - 1][q], out, 0, 0, 0);
+            float* xkp = X + (size_t)K * NB * N;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                xk[q] = -out[q];
+                if (vc && K * NB + rr[q] < N) xkp[xoff[q]] = xk[q];
+            }
+        }
+        static_for<0, TR_MAXT - kk>([&](auto pc) {
+            constexpr int t = kk + decltype(pc)::value;           // tile t of this block column (I = J + 1 + t)
+            if (t < cnt) {
+                float ar[16];
+                next_frags(ar);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], xk[q], acc[t], 0, 0, 0);
+            }
+        });
+    });
+}
+
+// ... and in fp64: a wave holds the accumulators of HALF a block column (16 columns: 15 tiles x 16 registers), so the two waves of a block column form ONE
+// workgroup and share the ring -- each copies half of an element's eight 1 KB pieces, a workgroup barrier per element says that both halves have landed and
+// that the slot about to be refilled has been read by both (8 KB tiles: the stream crosses the fabric once per block column, not once per wave).
+constexpr int TD_RING64 = 8;
+__global__ void __launch_bounds__(128, 1)
+trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, int Bt, int N, int Np, int nblk) {
+    using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    constexpr int V = 2;
+    __shared__ __attribute__((aligned(16))) double ring[TD_RING64][NB * NB];
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int J = pos % nblk, b = (pos / nblk) * 8 + xcd;
+    if (b >= Bt) return;                                           // (both waves)
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    double* __restrict__ X = Linv + (size_t)b * N * N;
+    const int lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4;
+    const int lc = 16 * half + c16, gc = J * NB + lc;              // this lane's column (within the block column / global)
+    const bool vc = gc < N;
+    const int cnt = nblk - J - 1;
+    for (int i = g; i < J * NB; i += 4)
+        if (vc && i < N) X[(size_t)i * N + gc] = 0.0;
+    int rr[2][4];
+    unsigned xoff[2][4];
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rr[hk][q] = 16 * hk + 4 * q + g;
+            xoff[hk][q] = (unsigned)(rr[hk][q] * N + gc);
+        }
+    f64x4 xk[2], acc[TR_MAXT][2];
+    {
+        const double* dj = lop + lop_dfull_block(J, Np);
+        double* xj = X + (size_t)J * NB * N;
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xk[hk][q] = dj[(unsigned)(NB * lc + rr[hk][q])];
+                if (vc && J * NB + rr[hk][q] < N) xj[xoff[hk][q]] = xk[hk][q];
+            }
+    }
+    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value][0] = f64x4{0}; acc[decltype(tc)::value][1] = f64x4{0}; });
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(lop), 0, (unsigned)min((size_t)0xfffffff0u, lop_elems<V>(Np) * 8), 0x00020000);
+    int cK = J, cI = J + 1, wslot = 0;
+    if (cI >= nblk) { cK = J + 1; cI = cK; }
+    const int lq = lane >> 4, lr = lane & 15;                       // a copy instruction moves 4 columns x 32 rows: lane = (column lq, rows 2 lr, 2 lr + 1)
+    auto issue_next = [&]() {                                      // this wave's four pieces (half, half + 2, ..) of the next element
+        const bool valid = cK < nblk, diag = cI == cK;
+        const int cs = Np - NB * (cK + 1);
+        const int voff = !valid ? 0x7ffffff0 : diag ? 16 * lane : (lq * cs + 2 * lr) * 8;
+        const int soff = diag ? lop_dfull_block(cK, Np) * 8 : (lop_base<V>(cK * NB, Np) + NB * (cK + 1) + NB * (cI - cK - 1)) * 8;
+        const int step = diag ? 1024 : 32 * cs;
+        __attribute__((address_space(3))) double* dst = (__attribute__((address_space(3))) double*)&ring[wslot][0];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            const int j = half + 2 * j4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 128 * j), 16, voff, valid ? soff + j * step : 0, 0, 0);
+        }
+        wslot = wslot + 1 == TD_RING64 ? 0 : wslot + 1;
+        ++cI;
+        if (cI >= nblk) { ++cK; cI = cK; }
+    };
+    for (int a = 0; a < TD_RING64 - 1; ++a) issue_next();
+    int rslot = 0;
+    // the next element as A-operand registers: fr[hk][q][hi] = tile[row 16 hi + c16][column 16 hk + 4 q + g]
+    auto next_frags = [&](double (&fr)[2][4][2]) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (TD_RING64 - 2)) : "memory");      // this wave's pieces of the element have landed
+        __builtin_amdgcn_s_barrier();                                                    // ... the other wave's too; the slot refilled next has been read by both
+        asm volatile("" ::: "memory");
+        issue_next();
+        const __attribute__((address_space(3))) double* src = (const __attribute__((address_space(3))) double*)&ring[rslot][0] + g * NB + c16;
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi) fr[hk][q][hi] = src[(16 * hk + 4 * q) * NB + 16 * hi];
+        rslot = rslot + 1 == TD_RING64 ? 0 : rslot + 1;
+    };
+    static_for<0, TR_MAXT + 1>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        if (kk > cnt) return;
+        const int K = J + kk;
+        if constexpr (kk > 0) {
+            double di[2][4][2];
+            next_frags(di);
+            f64x4 out[2] = {f64x4{0}, f64x4{0}};
+#pragma unroll
+            for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int hi = 0; hi < 2; ++hi)
+                        out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(di[hk][q][hi], acc[kk - 1][hk][q], out[hi], 0, 0, 0);
+            double* xkp = X + (size_t)K * NB * N;
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xk[hi][q] = -out[hi][q];
+                    if (vc && K * NB + rr[hi][q] < N) xkp[xoff[hi][q]] = xk[hi][q];
+                }
+        }
+        static_for<0, TR_MAXT - kk>([&](auto pc) {
+            constexpr int t = kk + decltype(pc)::value;
+            if (t < cnt) {
+                double ar[2][4][2];
+                next_frags(ar);
+#pragma unroll
+                for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int hi = 0; hi < 2; ++hi)
+                            acc[t][hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[hk][q][hi], xk[hk][q], acc[t][hi], 0, 0, 0);
+            }
+        });
+    });
+}
+
 int launch_trtri_mfma_f32(const float* Lop, float* Linv, int Bt, int N, void* stream) {
     const int Np = round_up(N, NB), nblk = Np / NB;
     if ((long long)Bt * nblk > 0x7fffffffLL) return BCBF_EINVAL;
     static const bool ll = [] { const char* e = getenv("BCBF_TRTRI_LEFT"); return e && e[0] == '1'; }();      // (development: force the left-looking form)
+    static const int dma = [] { const char* e = getenv("BCBF_TRTRI_DMA"); return e ? atoi(e) : 1; }();         // (development: 0 = the register-ring form)
+    if (nblk - 1 <= TR_MAXT && !ll && dma) {
+        const long long groups = ((long long)Bt + 7) / 8;
+        if (groups * 8 * nblk > 0x7fffffffLL) return BCBF_EINVAL;
+        hipLaunchKernelGGL(trtri_dma_kernel_f32, dim3((unsigned)(groups * 8 * nblk)), dim3(64), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
+        return check_launch("trtri_dma");
+    }
     if (nblk - 1 <= TR_MAXT && !ll) {
         hipLaunchKernelGGL(trtri_rl_kernel_f32, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
         return check_launch("trtri_rl");
@@ -405,6 +640,13 @@ int launch_trtri_mfma_f64(const double* Lop, double* Linv, int Bt, int N, void* 
     // fp64: the left-looking form stays the default (4096 x 512: 14.0 ms against 17.5 for the register-resident form, whose half-width tiles double the A-operand
     // loads per flop); BCBF_TRTRI_RL64=1 selects it (development)
     static const bool ll = [] { const char* e = getenv("BCBF_TRTRI_RL64"); return !(e && e[0] == '1'); }();
+    static const int dma = [] { const char* e = getenv("BCBF_TRTRI_DMA"); return e ? atoi(e) : 1; }();         // (development: 0 = the forms below)
+    if (nblk - 1 <= TR_MAXT && dma) {
+        const long long groups = ((long long)Bt + 7) / 8;
+        if (groups * 8 * nblk > 0x7fffffffLL) return BCBF_EINVAL;
+        hipLaunchKernelGGL(trtri_dma_kernel_f64, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
+        return check_launch("trtri_dma");
+    }
     if (nblk - 1 <= TR_MAXT && !ll) {
         if ((long long)Bt * nblk * 2 > 0x7fffffffLL) return BCBF_EINVAL;
         hipLaunchKernelGGL(trtri_rl_kernel_f64, dim3(Bt * nblk * 2), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
