@@ -78,6 +78,28 @@ __host__ __device__ inline void kernel_shape(int kind, T d2, EXPF expf_, T& shap
 }
 __host__ __device__ inline double kernel_kxx(int kind) { return kind == BCBF_KIND_RBF ? 1.0 : kind == BCBF_KIND_MATERN52 ? 5.0 / 3.0 : 8.0 / 3.0; }
 
+// exp(-x) for x >= 0 in full double precision: k = rint(x log2 e), r = k ln2 - x in [-ln2/2, ln2/2] (two-part ln2),
+// degree-12 Taylor polynomial (truncation 1.7e-16), scaled by 2^-k.  Half the instructions of the library exp (no
+// special cases: the argument is a squared distance).
+__device__ inline double exp_neg64(double x) {
+    const double kf = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(kf, 0.6931471803691238, -x);
+    r = __builtin_fma(kf, 1.9082149292705877e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, -(int)kf);
+}
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -177,6 +177,8 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
 // partial sums go to the caller's workspace and mll_reduce_kernel adds them in a fixed order (bit-identical run to run).
 // n, nt <= 4 and C <= 4 (every matrix-variate model the device path takes); no linear kernel part.
 constexpr int MR_TJ = 128;
+__device__ inline float mll_exp(float v) { return __expf(v); }
+__device__ inline double mll_exp(double v) { return exp_neg64(-v); }     // (every data kernel's exponent is <= 0; bcbf_common.h: half the library exp's instructions)
 template <typename T>
 __global__ void __launch_bounds__(MG_T)
 mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T* __restrict__ Kinv,
@@ -187,7 +189,10 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
     constexpr int V = Vec<T>::V;
     constexpr int NS = 4, CM = BCBF_MAX_CTRL_DIM + 1;
     constexpr int NR = BCBF_MAX_STATE_DIM + 2 + CM * CM;
-    __shared__ double xj[MR_TJ][NS], uj[MR_TJ][CM], vj[MR_TJ][CM], tj[MR_TJ][NS];
+    // the pair loop's arithmetic type: fp32 inputs are summed in fp32 (K_b^-1 itself carries cond x 6e-8 there; an fp64 pair loop costs
+    // 4096 x 512: 5.5 ms against the fp64 kernel's 3.7 -- conversions and the double exp), fp64 inputs in fp64
+    using M = T;
+    __shared__ M xj[MR_TJ][NS], uj[MR_TJ][CM], vj[MR_TJ][CM], tj[MR_TJ][NS];
     __shared__ double red[4][NR];
     const int b = blockIdx.x, tid = threadIdx.x, part = blockIdx.y, G = gridDim.y;
     const int rc = part % RC, js = part / RC, JS = G / RC;
@@ -197,34 +202,34 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
     const T* al = alpha + (size_t)b * N * nt;
     const T* Kib = Kinv + (size_t)b * N * N;
     const T* lop = Lop + (size_t)b * lop_elems<V>(Np);
-    double iell[NS], Ai[NS][NS], Bl[CM][CM];
-    const double s2 = (double)s2p[b];
+    M iell[NS], Ai[NS][NS], Bl[CM][CM];
+    const M s2 = (M)s2p[b];
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
-        iell[d] = d < n ? 1.0 / (double)ell[(size_t)b * n + d] : 0.0;
+        iell[d] = d < n ? M(1.0) / (M)ell[(size_t)b * n + d] : M(0.0);
 #pragma unroll
-        for (int e = 0; e < NS; ++e) Ai[d][e] = (d < nt && e < nt) ? (double)Ainv[((size_t)b * nt + d) * nt + e] : 0.0;
+        for (int e = 0; e < NS; ++e) Ai[d][e] = (d < nt && e < nt) ? (M)Ainv[((size_t)b * nt + d) * nt + e] : M(0.0);
     }
 #pragma unroll
     for (int a = 0; a < CM; ++a)
 #pragma unroll
-        for (int c = 0; c < CM; ++c) Bl[a][c] = (a < C && c < C) ? (double)Bm[((size_t)b * C + a) * C + c] : 0.0;
+        for (int c = 0; c < CM; ++c) Bl[a][c] = (a < C && c < C) ? (M)Bm[((size_t)b * C + a) * C + c] : M(0.0);
     // this thread's row
     const int i = rc * MG_T + tid;
     const bool vi = i < N;
-    double xi[NS], ui[CM], ai[NS];
+    M xi[NS], ui[CM], ai[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
-        xi[d] = (vi && d < n) ? (double)Xb[(size_t)i * n + d] : 0.0;
-        ai[d] = (vi && d < nt) ? (double)al[(size_t)i * nt + d] : 0.0;
+        xi[d] = (vi && d < n) ? (M)Xb[(size_t)i * n + d] : M(0.0);
+        ai[d] = (vi && d < nt) ? (M)al[(size_t)i * nt + d] : M(0.0);
     }
 #pragma unroll
-    for (int a = 0; a < CM; ++a) ui[a] = (vi && a < C) ? (double)UHb[(size_t)i * C + a] : 0.0;
-    double gl[NS], w[CM], gs = 0.0;
+    for (int a = 0; a < CM; ++a) ui[a] = (vi && a < C) ? (M)UHb[(size_t)i * C + a] : M(0.0);
+    M gl[NS], w[CM], gs = M(0.0);
 #pragma unroll
-    for (int d = 0; d < NS; ++d) gl[d] = 0.0;
+    for (int d = 0; d < NS; ++d) gl[d] = M(0.0);
 #pragma unroll
-    for (int c = 0; c < CM; ++c) w[c] = 0.0;
+    for (int c = 0; c < CM; ++c) w[c] = M(0.0);
     // this workgroup's columns: slice js of JS, in tiles of MR_TJ
     const int per = ((N + JS - 1) / JS + MR_TJ - 1) / MR_TJ * MR_TJ;
     const int jbeg = js * per, jend = min(N, jbeg + per);
@@ -233,24 +238,24 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
         if (tid < MR_TJ) {
             const int j = j0 + tid;
             const bool vj_ = j < jend;
-            double a_[NS], u_[CM];
+            M a_[NS], u_[CM];
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                xj[tid][d] = (vj_ && d < n) ? (double)Xb[(size_t)j * n + d] : 0.0;
-                a_[d] = (vj_ && d < nt) ? (double)al[(size_t)j * nt + d] : 0.0;
+                xj[tid][d] = (vj_ && d < n) ? (M)Xb[(size_t)j * n + d] : M(0.0);
+                a_[d] = (vj_ && d < nt) ? (M)al[(size_t)j * nt + d] : M(0.0);
             }
 #pragma unroll
-            for (int a = 0; a < CM; ++a) u_[a] = (vj_ && a < C) ? (double)UHb[(size_t)j * C + a] : 0.0;
+            for (int a = 0; a < CM; ++a) u_[a] = (vj_ && a < C) ? (M)UHb[(size_t)j * C + a] : M(0.0);
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double t = 0.0;
+                M t = M(0.0);
 #pragma unroll
                 for (int e = 0; e < NS; ++e) t += Ai[d][e] * a_[e];
                 tj[tid][d] = t;
             }
 #pragma unroll
             for (int a = 0; a < CM; ++a) {
-                double t = 0.0;
+                M t = M(0.0);
 #pragma unroll
                 for (int c = 0; c < CM; ++c) t += Bl[a][c] * u_[c];
                 vj[tid][a] = t;
@@ -261,25 +266,25 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
         const int cnt = min(MR_TJ, jend - j0);
         if (vi)
             for (int jj = 0; jj < cnt; ++jj) {
-                const double kinv = (double)Kib[(size_t)(j0 + jj) * N + i];        // K_b^-1 [j][i] = [i][j]
-                double d2 = 0.0, dz2[NS];
+                const M kinv = (M)Kib[(size_t)(j0 + jj) * N + i];        // K_b^-1 [j][i] = [i][j]
+                M d2 = M(0.0), dz2[NS];
 #pragma unroll
                 for (int d = 0; d < NS; ++d) {
-                    const double z = (xi[d] - xj[jj][d]) * iell[d];
+                    const M z = (xi[d] - xj[jj][d]) * iell[d];
                     dz2[d] = z * z;
                     d2 += z * z;
                 }
-                double krbf, kder;
-                kernel_shape(kind, d2, [](double v) { return exp(v); }, krbf, kder);
-                double uij = 0.0, q = 0.0;
+                M krbf, kder;
+                kernel_shape(kind, d2, [](M v) { return mll_exp(v); }, krbf, kder);
+                M uij = M(0.0), q = M(0.0);
 #pragma unroll
                 for (int a = 0; a < CM; ++a) uij += ui[a] * vj[jj][a];
 #pragma unroll
                 for (int d = 0; d < NS; ++d) q += ai[d] * tj[jj][d];
-                const double Gm = 0.5 * (q - (double)nt * kinv);
-                const double Gk = Gm * krbf;
+                const M Gm = M(0.5) * (q - (M)nt * kinv);
+                const M Gk = Gm * krbf;
                 gs += Gk * uij;
-                const double GK = Gm * kder * s2 * uij;
+                const M GK = Gm * kder * s2 * uij;
 #pragma unroll
                 for (int d = 0; d < NS; ++d) gl[d] += GK * dz2[d] * iell[d];
 #pragma unroll
@@ -290,12 +295,12 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
     const bool lead = (tid & 63) == 0;
     auto put = [&](int o, double v) { v = wave_sum(v); if (lead) red[tid >> 6][o] = v; };
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) put(d, d < NS ? gl[d < NS ? d : 0] : 0.0);
-    put(BCBF_MAX_STATE_DIM, gs);
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) put(d, d < NS ? (double)gl[d < NS ? d : 0] : 0.0);
+    put(BCBF_MAX_STATE_DIM, (double)gs);
 #pragma unroll
     for (int a = 0; a < CM; ++a)
 #pragma unroll
-        for (int c = 0; c < CM; ++c) put(BCBF_MAX_STATE_DIM + 1 + a * CM + c, s2 * ui[a] * w[c]);
+        for (int c = 0; c < CM; ++c) put(BCBF_MAX_STATE_DIM + 1 + a * CM + c, (double)(s2 * ui[a] * w[c]));
     put(NR - 1, 0.0);
     __syncthreads();
     if (tid < NR) work[((size_t)b * G + part) * NR + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
