@@ -465,16 +465,27 @@ trtri_dma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, in
         for (int q = 0; q < 16; ++q) fr[q] = src[(8 * (q >> 2) + (q & 3)) * NB];
         rslot = rslot + 1 == TD_RING ? 0 : rslot + 1;
     };
+    // Software pipeline over the sequence: the element a consumer needs is fetched from the ring by its PREDECESSOR, between that one's MFMAs (a wave issues in
+    // order and stalls at an MFMA while the pipe is busy: the copy's scalar arithmetic, the counted wait and the sixteen LDS reads placed after the first
+    // four MFMAs of a chain run under the other twelve; behind the chain they are exposed -- 300 cycles per 1024 of MFMA issue).  The last consumer fetches a dummy.
+    float cur[16];
+    next_frags(cur);
     static_for<0, TR_MAXT + 1>([&](auto kc) {                      // K = J + kk
         constexpr int kk = decltype(kc)::value;
         if (kk > cnt) return;
         const int K = J + kk;
         if constexpr (kk > 0) {
-            float di[16];
-            next_frags(di);
+            float nxt[16];
             f32x16 out = {0};
 #pragma unroll
-            for (int q = 0; q < 16; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(di[q], acc[kk - 1][q], out, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], acc[kk - 1][q], out, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            next_frags(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 4; q < 16; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], acc[kk - 1][q], out, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
             float* xkp = X + (size_t)K * NB * N;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -485,10 +496,16 @@ trtri_dma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, in
         static_for<0, TR_MAXT - kk>([&](auto pc) {
             constexpr int t = kk + decltype(pc)::value;           // tile t of this block column (I = J + 1 + t)
             if (t < cnt) {
-                float ar[16];
-                next_frags(ar);
+                float nxt[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], xk[q], acc[t], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], xk[q], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                next_frags(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 4; q < 16; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], xk[q], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
             }
         });
     });
@@ -575,21 +592,37 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
                 for (int hi = 0; hi < 2; ++hi) fr[hk][q][hi] = src[(16 * hk + 4 * q) * NB + 16 * hi];
         rslot = rslot + 1 == TD_RING64 ? 0 : rslot + 1;
     };
+    // (software pipeline as in the fp32 kernel: a consumer fetches its successor's element between its own MFMAs)
+    double cur[2][4][2];
+    next_frags(cur);
+    auto copy_frags = [&](double (&d)[2][4][2], const double (&s_)[2][4][2]) {
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi) d[hk][q][hi] = s_[hk][q][hi];
+    };
     static_for<0, TR_MAXT + 1>([&](auto kc) {
         constexpr int kk = decltype(kc)::value;
         if (kk > cnt) return;
         const int K = J + kk;
         if constexpr (kk > 0) {
-            double di[2][4][2];
-            next_frags(di);
+            double nxt[2][4][2];
             f64x4 out[2] = {f64x4{0}, f64x4{0}};
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0][0][hi], acc[kk - 1][0][0], out[hi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            next_frags(nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int hk = 0; hk < 2; ++hk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int hi = 0; hi < 2; ++hi)
-                        out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(di[hk][q][hi], acc[kk - 1][hk][q], out[hi], 0, 0, 0);
+                        if (hk + q > 0) out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[hk][q][hi], acc[kk - 1][hk][q], out[hi], 0, 0, 0);
+            copy_frags(cur, nxt);
             double* xkp = X + (size_t)K * NB * N;
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi)
@@ -602,15 +635,20 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
         static_for<0, TR_MAXT - kk>([&](auto pc) {
             constexpr int t = kk + decltype(pc)::value;
             if (t < cnt) {
-                double ar[2][4][2];
-                next_frags(ar);
+                double nxt[2][4][2];
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi) acc[t][hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0][0][hi], xk[0][0], acc[t][hi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                next_frags(nxt);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int hk = 0; hk < 2; ++hk)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int hi = 0; hi < 2; ++hi)
-                            acc[t][hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[hk][q][hi], xk[hk][q], acc[t][hi], 0, 0, 0);
+                            if (hk + q > 0) acc[t][hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[hk][q][hi], xk[hk][q], acc[t][hi], 0, 0, 0);
+                copy_frags(cur, nxt);
             }
         });
     });
