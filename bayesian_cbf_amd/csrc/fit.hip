@@ -231,6 +231,63 @@ kinv_apply_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __rest
             alpha[((size_t)b * N + i) * nt + c] = (T)(part[0][col][c] + part[1][col][c] + part[2][col][c] + part[3][col][c]);
 }
 
+// ... the same product with 16 bytes per lane and eight rows of K_b^-1 in flight per lane (batches; N a multiple of the vector width, nt <= 4): the form above
+// issues one 4-byte load per multiply-add group and waits for it (4096 x 512: 2.6 ms fp32 / 3.0 ms fp64 for a 4.3 / 8.6 GB read).  A lane owns V consecutive
+// columns, a wave one of four row slices (its rows of R staged in LDS as doubles), sums in fp64 as above.
+template <typename T, int NT>
+__global__ void __launch_bounds__(256)
+kinv_apply_vec_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __restrict__ alpha, int N, int nt) {
+    constexpr int V = 16 / (int)sizeof(T), U = 8, PERMAX = 256;
+    using VecT = typename Vec<T>::type;
+    __shared__ double part[4][64][V][NT];
+    __shared__ double rs[4][PERMAX][NT];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * 64 + lane) * V;
+    const T* K = Kinv + (size_t)b * N * N;
+    const T* Rb = R + (size_t)b * N * nt;
+    const int per = (N + 3) / 4, j0 = sl * per, j1 = min(N, j0 + per), cnt = j1 - j0;
+    for (int e = lane; e < per * NT; e += 64) {
+        const int jj = e / NT, c = e - jj * NT;
+        rs[sl][jj][c] = (jj < cnt && c < nt) ? (double)Rb[(size_t)(j0 + jj) * nt + c] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();                              // (a wave reads its own slice only)
+    double acc[V][NT];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[v][c] = 0.0;
+    if (i0 < N)
+        for (int jj = 0; jj < cnt; jj += U) {
+            VecT k[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + min(jj + u, cnt - 1);                 // (a row past the slice repeats the last one and meets zeros below)
+                k[u] = *reinterpret_cast<const VecT*>(K + (size_t)j * N + i0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = jj + u < cnt;
+                const T* kv = reinterpret_cast<const T*>(&k[u]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const double r = in ? rs[sl][min(jj + u, PERMAX - 1)][c] : 0.0;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v][c] += (double)kv[v] * r;
+                }
+            }
+        }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) part[sl][lane][v][c] = acc[v][c];
+    __syncthreads();
+    if (sl == 0 && i0 < N)
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            for (int c = 0; c < nt; ++c)
+                alpha[((size_t)b * N + i0 + v) * nt + c] = (T)(part[0][lane][v][c] + part[1][lane][v][c] + part[2][lane][v][c] + part[3][lane][v][c]);
+}
+
 static bool fit_shape_ok(int Bt, int n, int m, int rA, int rB) {
     return Bt >= 0 && n >= 1 && n <= BCBF_MAX_STATE_DIM && m >= 1 && m <= BCBF_MAX_CTRL_DIM && rA >= 0 && rA <= n && rB >= 0 && rB <= m + 1;
 }
@@ -270,6 +327,11 @@ static int launch_kinv_apply(const T* Kinv, const T* R, T* alpha, int Bt, int N,
     if (Bt < 0 || N < 1 || nt < 1 || nt > KA_NT) return BCBF_EINVAL;
     if (Bt == 0) return BCBF_OK;
     if (!Kinv || !R || !alpha || (const void*)R == (const void*)alpha) return BCBF_EINVAL;
+    constexpr int V = 16 / (int)sizeof(T);
+    if (Bt >= 16 && N % V == 0 && nt <= 4 && (N + 3) / 4 <= 256) {      // batches: 16 bytes per lane, eight rows in flight
+        hipLaunchKernelGGL((kinv_apply_vec_kernel<T, 4>), dim3((N / V + 63) / 64, Bt), dim3(256), 0, (hipStream_t)stream, Kinv, R, alpha, N, nt);
+        return check_launch("bcbf_kinv_apply");
+    }
     hipLaunchKernelGGL((kinv_apply_kernel<T>), dim3((N + 63) / 64, Bt), dim3(256), 0, (hipStream_t)stream, Kinv, R, alpha, N, nt);
     return check_launch("bcbf_kinv_apply");
 }
