@@ -167,7 +167,8 @@ def test_batched_fit_retries_failed_factorisations_on_the_failed_models_only():
 def test_kinv_apply_is_the_symmetric_product():
     from bayesian_cbf_amd import ops
     for dtype, tol in ((torch.float64, 1e-13), (torch.float32, 2e-6)):
-        for Bt, N, nt in ((3, 70, 3), (1, 512, 1), (2, 33, 8)):
+        # (from 16 models on, N a multiple of the 16-byte vector and nt <= 4: the vector form -- 20 x 512, 17 x 256; 16 x 130 / 18 x 64 with nt = 5: the scalar form)
+        for Bt, N, nt in ((3, 70, 3), (1, 512, 1), (2, 33, 8), (20, 512, 3), (17, 256, 2), (16, 130, 3), (18, 64, 5), (16, 1024, 4)):
             g = torch.Generator(device=DEV).manual_seed(N)
             S = torch.randn(Bt, N, N, dtype=dtype, device=DEV, generator=g)
             S = (S + S.transpose(1, 2)).contiguous()
@@ -175,6 +176,26 @@ def test_kinv_apply_is_the_symmetric_product():
             got = ops.kinv_apply(S, R)
             want = (S.double() @ R.double())
             assert float((got.double() - want).abs().max() / want.abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-13), (torch.float32, 2e-6)], ids=["f64", "f32"])
+def test_syrk_lt_forms_against_the_plain_product(dtype, tol):
+    """bcbf_syrk_lt (K_b^-1 = Linv' Linv, Linv lower triangular: fit.hip's consumers read the full symmetric matrix) against torch's product in
+    fp64, every form: one tile per wave (few models), 2 x 2 tiles per wave (batches, N not a multiple of 128), and the 128 x 128 block per workgroup
+    whose operands go through an LDS ring (batches, N a multiple of 128; it skips the structurally zero part of Linv and writes the mirror image
+    through LDS) -- incl. batches that are not a multiple of the eight XCDs the workgroups are dealt to.  Exactly symmetric."""
+    from bayesian_cbf_amd import ops
+    from bayesian_cbf_amd._lib import lib
+    for Bt, N in ((2, 96), (3, 512), (16, 200), (20, 256), (17, 512), (16, 384), (33, 128)):
+        g = torch.Generator(device=DEV).manual_seed(100 + N)
+        Linv = torch.tril(torch.randn(Bt, N, N, dtype=dtype, device=DEV, generator=g)).contiguous()
+        Kinv = torch.full((Bt, N, N), float("nan"), dtype=dtype, device=DEV)
+        ops.check(getattr(lib, "bcbf_syrk_lt" + ops._suf(Linv))(ops._p(Linv), ops._p(Kinv), Bt, N, ops._stream(Linv)), "bcbf_syrk_lt")
+        want = Linv.double().transpose(1, 2) @ Linv.double()
+        assert bool(torch.isfinite(Kinv).all()), (Bt, N)
+        assert torch.equal(Kinv, Kinv.transpose(1, 2)), (Bt, N)
+        err = float((Kinv.double() - want).abs().max() / want.abs().max())
+        assert err < tol * (N / 32), (Bt, N, err)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)], ids=["f64", "f32"])
@@ -185,7 +206,7 @@ def test_trtri_on_the_matrix_cores_is_the_inverse_of_the_factor(dtype, tol):
     from bayesian_cbf_amd import ops
     from bayesian_cbf_amd._lib import lib
     from bayesian_cbf_amd.synthetic import make_instances
-    for Bt, N in ((5, 70), (6, 32), (4, 17), (9, 512), (7, 300)):
+    for Bt, N in ((5, 70), (6, 32), (4, 17), (9, 512), (7, 300), (19, 256), (8, 480)):        # (batches that are / are not a multiple of the eight XCDs)
         p = make_instances(Bt, N, 3, 2, dtype=dtype, device=DEV, seed=N)
         jit = (p["jitter"] * (100 if dtype == torch.float32 else 1)).contiguous()
         Lop, _, info, Ld = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, want_dense=True)
