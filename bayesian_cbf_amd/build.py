@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libbcbf.so")
 ARCH = "gfx950"
-SOURCES = ["common.hip", "posterior_step.hip", "posterior_shared.hip", "posterior_shared_reg.hip", "refit.hip", "refit_mfma.hip", "refit_mfma64.hip", "refit_wave64.hip", "refit_slab.hip", "solve.hip", "trtri.hip", "tail.hip", "syrk.hip", "mll_grad.hip", "fit.hip", "cbc_terms.hip", "predict_assemble.hip", "gram.hip", "controller_cones.hip", "socp.hip", "socp_quad.hip",
+SOURCES = ["common.hip", "posterior_step.hip", "jets_mfma.hip", "posterior_shared.hip", "posterior_shared_reg.hip", "refit.hip", "refit_mfma.hip", "refit_mfma64.hip", "refit_wave64.hip", "refit_slab.hip", "solve.hip", "trtri.hip", "tail.hip", "syrk.hip", "mll_grad.hip", "fit.hip", "cbc_terms.hip", "predict_assemble.hip", "gram.hip", "controller_cones.hip", "socp.hip", "socp_quad.hip",
            "unicycle.hip", "control_step.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]

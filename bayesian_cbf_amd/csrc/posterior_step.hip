@@ -849,6 +849,10 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
     }
 }
 
+int launch_posterior_jets_mfma(const float* Lop, const float* Vw, const float* X, const float* UHB, const float* ell, const float* s2,
+                               const float* Bm, const float* M0, const float* xq, float* Mk, float* Bk, float* Wout, float* Gfull, float* Mfull,
+                               int shared, int Bt, int N, int n, int m, int kind, hipStream_t st);       // jets_mfma.hip
+bool posterior_jets_mfma_preferred(int N, int n, int m);
 template <typename T>
 static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                  const T* Bm, const T* M0, const T* xq, const T* jitter2, T* Mk, T* Bk,
@@ -882,6 +886,14 @@ static int launch_posterior_step(const T* Lop, const T* Vw, const T* X, const T*
     if (Gfull != nullptr) {      // jets: (n, m) combinations compiled in
         if (!Mfull || lin || kind < 0 || kind >= BCBF_KINDS) return BCBF_EINVAL;
         if (n > 4) return BCBF_EINVAL;                  // (the rel-degree-2 terms kernel holds n <= 4 too)
+        if constexpr (sizeof(T) == 4) {
+            // fp32, N <= 512, twelve right-hand-side columns (n = 3, m = 2): on the matrix cores, the operator through an LDS-DMA ring (jets_mfma.hip).
+            // BCBF_JETS_MFMA=0: the streaming kernel; =2: every shape the form takes (n = 2 / 3, m = 1 / 2)
+            const char* e_ = getenv("BCBF_JETS_MFMA");
+            const int jm = e_ ? atoi(e_) : 1;
+            if (jm && (jm == 2 || posterior_jets_mfma_preferred(N, n, m)) && Ncap == 0 && launch_posterior_jets_mfma(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, Mk, Bk, Wout, Gfull, Mfull, shared, Bt, N, n, m, kind, st) == 0)
+                return check_launch("posterior_jets_mfma");
+        }
         switch (10 * n + m) {                           // every (n <= 4, m <= 3): C = 1 + m columns x (1 + n) jets
             case 11: BCBF_PJ_LAUNCH(2, 1); break;
             case 12: BCBF_PJ_LAUNCH(3, 1); break;

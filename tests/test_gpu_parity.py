@@ -1552,9 +1552,11 @@ def test_syrk_kb_inverse_and_deterministic_likelihood_gradient(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("n,m", [(n_, m_) for n_ in (1, 2, 3, 4) for m_ in (1, 2, 3)])
-def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n, m, dtype):
-    """The jets instantiations (Gram / mean sums on the matrix-core accumulators of wave 0) for EVERY (n <= 4, m <= 3) --
+@pytest.mark.parametrize("n,m,form", [(n_, m_, "default") for n_ in (1, 2, 3, 4) for m_ in (1, 2, 3)] + [(2, 1, "mfma"), (2, 2, "mfma"), (3, 1, "mfma"), (3, 2, "mfma")])
+def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n, m, form, dtype, monkeypatch):
+    """("mfma": the same with BCBF_JETS_MFMA=2 -- the matrix-core form of jets_mfma.hip, residual in MFMA accumulators and the operator through an
+    LDS-DMA ring, forced for every shape it takes (fp32, N <= 512; by default it runs for twelve right-hand-side columns only).)
+    The jets instantiations (Gram / mean sums on the matrix-core accumulators of wave 0) for EVERY (n <= 4, m <= 3) --
     wherever the value kernels and the rel-degree-2 terms kernel work (gp_algebra.py:319-402, cbc2.py:26-33 hold for any
     state / control dimension); (3,3), (4,2), (4,3) have more than 16 tile columns and run the 2 x 2 accumulator form --
     and for training sizes that take one wave, several waves and a ragged last block per workgroup, against the oracle's
@@ -1564,6 +1566,10 @@ def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n
     from oracle import cbc2 as oc2
     from bayesian_cbf_amd.synthetic import make_instances
     f64 = dtype == torch.float64
+    if form == "mfma":
+        if f64:
+            pytest.skip("the matrix-core jets form is fp32")
+        monkeypatch.setenv("BCBF_JETS_MFMA", "2")
     C = m + 1
     for N in (40, 300, 700):
         Bt = 3

@@ -10,7 +10,7 @@ from bayesian_cbf_amd.synthetic import make_instances
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _timing import timeit          # warms the clocks up first (tools/_timing.py)
 
-for (Bt, N, n, m, dtype) in ((4096, 512, 2, 1, torch.float32), (4096, 512, 3, 2, torch.float32), (1024, 256, 2, 1, torch.float64)):
+for (Bt, N, n, m, dtype) in ((4096, 512, 2, 1, torch.float32), (4096, 512, 3, 2, torch.float32), (1024, 256, 2, 1, torch.float64), (4096, 512, 2, 2, torch.float32), (4096, 512, 3, 1, torch.float32)):
     p = make_instances(Bt, N, n, m, dtype=dtype, device="cuda", seed=3)
     Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
     Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
