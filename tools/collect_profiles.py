@@ -113,7 +113,7 @@ except Exception:
 traffic_pass("default", HEAD, 543744, "bench.py --steps 5 --warmup 2 --cpu-sample 0", "pmc_traffic.json", sizes_default)
 traffic_pass("defaultparts1", HEAD, 543744, "bench.py --steps 5 --warmup 2 --cpu-sample 0 --parts 1", "pmc_traffic_parts1.json", {4096})
 # rel-degree-2 jets (tools/bench_reldeg2.py): the unicycle shape (12 right-hand sides) and the pendulum shape (6)
-traffic_pass("jets", "posterior_step_kernel<float, 3, 4, 3, 1, false", 543744, "tools/bench_reldeg2.py", "pmc_traffic_jets_n3m2.json", {4096})
+traffic_pass("jets", "posterior_jets_mfma_kernel<3, 3>", 543744, "tools/bench_reldeg2.py", "pmc_traffic_jets_n3m2.json", {4096})      # (round 6: twelve columns run jets_mfma.hip)
 traffic_pass("jets", "posterior_step_kernel<float, 2, 4, 2, 1, false", 4 * (512 * 513 // 2 + 2 * 512 * 2 + 512 * 2), "tools/bench_reldeg2.py",
              "pmc_traffic_jets_n2m1.json", {4096}, n=2, m=1)
 
