@@ -515,36 +515,59 @@ trtri_dma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, in
 // workgroup and share the ring -- each copies half of an element's eight 1 KB pieces, a workgroup barrier per element says that both halves have landed and
 // that the slot about to be refilled has been read by both (8 KB tiles: the stream crosses the fabric once per block column, not once per wave).
 constexpr int TD_RING64 = 8;
-__global__ void __launch_bounds__(128, 1)
-trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, int Bt, int N, int Np, int nblk) {
-    using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
-    constexpr int V = 2;
-    __shared__ __attribute__((aligned(16))) double ring[TD_RING64][NB * NB];
+// (the same kernel serves fp32 -- `trtri_pair_kernel<float>` -- with the 16x16x4 fp32 MFMA: half a block column is then 120 accumulator registers and TWO waves share a
+//  SIMD, which the copy path rewards: see launch_trtri_mfma_f32)
+template <typename T> struct TP;
+template <> struct TP<double> {
+    using acc_t = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    static constexpr int OCC = 1, PIECES = 8, LQS = 4, RING = TD_RING64;      // 1 KB pieces per tile; lane = (column lane >> LQS, 16 bytes of rows) of a piece
+    __device__ static acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static int row(int q, int g) { return 4 * q + g; }  // row (of 16) that accumulator register q holds in lane group g
+};
+template <> struct TP<float> {
+    using acc_t = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+#ifndef BCBF_TP32_OCC
+#define BCBF_TP32_OCC 3          // fp32 waves per SIMD (measured 4096 x 512, (waves, ring slots)): (2, 8) 3.56 ms, (2, 10) 3.60, (3, 6) 3.39 with 80 B of scratch -- the copy path rewards waves, not depth
+#endif
+#ifndef BCBF_TP32_RING
+#define BCBF_TP32_RING 6
+#endif
+    static constexpr int OCC = BCBF_TP32_OCC, PIECES = 4, LQS = 3, RING = BCBF_TP32_RING;
+    __device__ static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static int row(int q, int g) { return 4 * g + q; }
+};
+template <typename T>
+__global__ void __launch_bounds__(128, TP<T>::OCC)
+trtri_pair_kernel(const T* __restrict__ Lop, T* __restrict__ Linv, int Bt, int N, int Np, int nblk) {
+    using P = TP<T>;
+    using f64x4 = typename P::acc_t;
+    constexpr int V = Vec<T>::V, ES = (int)sizeof(T), RPL = 16 / ES;       // rows per lane and copy
+    __shared__ __attribute__((aligned(16))) T ring[P::RING][NB * NB];
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
     const int J = pos % nblk, b = (pos / nblk) * 8 + xcd;
     if (b >= Bt) return;                                           // (both waves)
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
-    double* __restrict__ X = Linv + (size_t)b * N * N;
+    const T* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
+    T* __restrict__ X = Linv + (size_t)b * N * N;
     const int lane = threadIdx.x & 63, c16 = lane & 15, g = lane >> 4;
     const int lc = 16 * half + c16, gc = J * NB + lc;              // this lane's column (within the block column / global)
     const bool vc = gc < N;
     const int cnt = nblk - J - 1;
     for (int i = g; i < J * NB; i += 4)
-        if (vc && i < N) X[(size_t)i * N + gc] = 0.0;
+        if (vc && i < N) X[(size_t)i * N + gc] = T(0.0);
     int rr[2][4];
     unsigned xoff[2][4];
 #pragma unroll
     for (int hk = 0; hk < 2; ++hk)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            rr[hk][q] = 16 * hk + 4 * q + g;
+            rr[hk][q] = 16 * hk + P::row(q, g);
             xoff[hk][q] = (unsigned)(rr[hk][q] * N + gc);
         }
     f64x4 xk[2], acc[TR_MAXT][2];
     {
-        const double* dj = lop + lop_dfull_block(J, Np);
-        double* xj = X + (size_t)J * NB * N;
+        const T* dj = lop + lop_dfull_block(J, Np);
+        T* xj = X + (size_t)J * NB * N;
 #pragma unroll
         for (int hk = 0; hk < 2; ++hk)
 #pragma unroll
@@ -555,47 +578,47 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
     }
     static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value][0] = f64x4{0}; acc[decltype(tc)::value][1] = f64x4{0}; });
 
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(lop), 0, (unsigned)min((size_t)0xfffffff0u, lop_elems<V>(Np) * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(lop), 0, (unsigned)min((size_t)0xfffffff0u, lop_elems<V>(Np) * ES), 0x00020000);
     int cK = J, cI = J + 1, wslot = 0;
     if (cI >= nblk) { cK = J + 1; cI = cK; }
-    const int lq = lane >> 4, lr = lane & 15;                       // a copy instruction moves 4 columns x 32 rows: lane = (column lq, rows 2 lr, 2 lr + 1)
+    const int lq = lane >> P::LQS, lr = lane & ((1 << P::LQS) - 1);      // a copy instruction moves 4 (fp32: 8) columns x 32 rows: lane = (column lq, rows RPL lr ..)
     auto issue_next = [&]() {                                      // this wave's four pieces (half, half + 2, ..) of the next element
         const bool valid = cK < nblk, diag = cI == cK;
         const int cs = Np - NB * (cK + 1);
-        const int voff = !valid ? 0x7ffffff0 : diag ? 16 * lane : (lq * cs + 2 * lr) * 8;
-        const int soff = diag ? lop_dfull_block(cK, Np) * 8 : (lop_base<V>(cK * NB, Np) + NB * (cK + 1) + NB * (cI - cK - 1)) * 8;
-        const int step = diag ? 1024 : 32 * cs;
-        __attribute__((address_space(3))) double* dst = (__attribute__((address_space(3))) double*)&ring[wslot][0];
+        const int voff = !valid ? 0x7ffffff0 : diag ? 16 * lane : (lq * cs + RPL * lr) * ES;
+        const int soff = diag ? lop_dfull_block(cK, Np) * ES : (lop_base<V>(cK * NB, Np) + NB * (cK + 1) + NB * (cI - cK - 1)) * ES;
+        const int step = diag ? 1024 : 32 * cs;                   // (bytes between pieces: 1 KB of the contiguous diagonal tile / 4 (fp32: 8) columns)
+        __attribute__((address_space(3))) T* dst = (__attribute__((address_space(3))) T*)&ring[wslot][0];
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
+        for (int j4 = 0; j4 < P::PIECES / 2; ++j4) {
             const int j = half + 2 * j4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 128 * j), 16, voff, valid ? soff + j * step : 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (1024 / ES) * j), 16, voff, valid ? soff + j * step : 0, 0, 0);
         }
-        wslot = wslot + 1 == TD_RING64 ? 0 : wslot + 1;
+        wslot = wslot + 1 == P::RING ? 0 : wslot + 1;
         ++cI;
         if (cI >= nblk) { ++cK; cI = cK; }
     };
-    for (int a = 0; a < TD_RING64 - 1; ++a) issue_next();
+    for (int a = 0; a < P::RING - 1; ++a) issue_next();
     int rslot = 0;
-    // the next element as A-operand registers: fr[hk][q][hi] = tile[row 16 hi + c16][column 16 hk + 4 q + g]
-    auto next_frags = [&](double (&fr)[2][4][2]) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (TD_RING64 - 2)) : "memory");      // this wave's pieces of the element have landed
+    // the next element as A-operand registers: fr[hk][q][hi] = tile[row 16 hi + c16][column rr[hk][q]]  (the accumulator's contraction order)
+    auto next_frags = [&](T (&fr)[2][4][2]) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((P::PIECES / 2) * (P::RING - 2)) : "memory");      // this wave's pieces of the element have landed
         __builtin_amdgcn_s_barrier();                                                    // ... the other wave's too; the slot refilled next has been read by both
         asm volatile("" ::: "memory");
         issue_next();
-        const __attribute__((address_space(3))) double* src = (const __attribute__((address_space(3))) double*)&ring[rslot][0] + g * NB + c16;
+        const __attribute__((address_space(3))) T* src = (const __attribute__((address_space(3))) T*)&ring[rslot][0] + P::row(0, g) * NB + c16;
 #pragma unroll
         for (int hk = 0; hk < 2; ++hk)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int hi = 0; hi < 2; ++hi) fr[hk][q][hi] = src[(16 * hk + 4 * q) * NB + 16 * hi];
-        rslot = rslot + 1 == TD_RING64 ? 0 : rslot + 1;
+                for (int hi = 0; hi < 2; ++hi) fr[hk][q][hi] = src[(16 * hk + P::row(q, 0)) * NB + 16 * hi];
+        rslot = rslot + 1 == P::RING ? 0 : rslot + 1;
     };
     // (software pipeline as in the fp32 kernel: a consumer fetches its successor's element between its own MFMAs)
-    double cur[2][4][2];
+    T cur[2][4][2];
     next_frags(cur);
-    auto copy_frags = [&](double (&d)[2][4][2], const double (&s_)[2][4][2]) {
+    auto copy_frags = [&](T (&d)[2][4][2], const T (&s_)[2][4][2]) {
 #pragma unroll
         for (int hk = 0; hk < 2; ++hk)
 #pragma unroll
@@ -608,10 +631,10 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
         if (kk > cnt) return;
         const int K = J + kk;
         if constexpr (kk > 0) {
-            double nxt[2][4][2];
+            T nxt[2][4][2];
             f64x4 out[2] = {f64x4{0}, f64x4{0}};
 #pragma unroll
-            for (int hi = 0; hi < 2; ++hi) out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0][0][hi], acc[kk - 1][0][0], out[hi], 0, 0, 0);
+            for (int hi = 0; hi < 2; ++hi) out[hi] = P::mfma(cur[0][0][hi], acc[kk - 1][0][0], out[hi]);
             __builtin_amdgcn_sched_barrier(0);
             next_frags(nxt);
             __builtin_amdgcn_sched_barrier(0);
@@ -621,9 +644,9 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int hi = 0; hi < 2; ++hi)
-                        if (hk + q > 0) out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[hk][q][hi], acc[kk - 1][hk][q], out[hi], 0, 0, 0);
+                        if (hk + q > 0) out[hi] = P::mfma(cur[hk][q][hi], acc[kk - 1][hk][q], out[hi]);
             copy_frags(cur, nxt);
-            double* xkp = X + (size_t)K * NB * N;
+            T* xkp = X + (size_t)K * NB * N;
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi)
 #pragma unroll
@@ -635,9 +658,9 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
         static_for<0, TR_MAXT - kk>([&](auto pc) {
             constexpr int t = kk + decltype(pc)::value;
             if (t < cnt) {
-                double nxt[2][4][2];
+                T nxt[2][4][2];
 #pragma unroll
-                for (int hi = 0; hi < 2; ++hi) acc[t][hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0][0][hi], xk[0][0], acc[t][hi], 0, 0, 0);
+                for (int hi = 0; hi < 2; ++hi) acc[t][hi] = P::mfma(cur[0][0][hi], xk[0][0], acc[t][hi]);
                 __builtin_amdgcn_sched_barrier(0);
                 next_frags(nxt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -647,7 +670,7 @@ trtri_dma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, 
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int hi = 0; hi < 2; ++hi)
-                            if (hk + q > 0) acc[t][hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[hk][q][hi], xk[hk][q], acc[t][hi], 0, 0, 0);
+                            if (hk + q > 0) acc[t][hi] = P::mfma(cur[hk][q][hi], xk[hk][q], acc[t][hi]);
                 copy_frags(cur, nxt);
             }
         });
@@ -662,7 +685,10 @@ int launch_trtri_mfma_f32(const float* Lop, float* Linv, int Bt, int N, void* st
     if (nblk - 1 <= TR_MAXT && !ll && dma) {
         const long long groups = ((long long)Bt + 7) / 8;
         if (groups * 8 * nblk > 0x7fffffffLL) return BCBF_EINVAL;
-        hipLaunchKernelGGL(trtri_dma_kernel_f32, dim3((unsigned)(groups * 8 * nblk)), dim3(64), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
+        // dma == 2: a whole block column per wave (32x32x2 MFMA, 240 accumulator registers, one wave per SIMD); default: the pair form the fp64 path uses -- half a
+        // block column per wave, two waves per SIMD (measured 4096 x 512: see DESIGN 3.4)
+        if (dma == 2) hipLaunchKernelGGL(trtri_dma_kernel_f32, dim3((unsigned)(groups * 8 * nblk)), dim3(64), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
+        else hipLaunchKernelGGL(trtri_pair_kernel<float>, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
         return check_launch("trtri_dma");
     }
     if (nblk - 1 <= TR_MAXT && !ll) {
@@ -682,7 +708,7 @@ int launch_trtri_mfma_f64(const double* Lop, double* Linv, int Bt, int N, void* 
     if (nblk - 1 <= TR_MAXT && dma) {
         const long long groups = ((long long)Bt + 7) / 8;
         if (groups * 8 * nblk > 0x7fffffffLL) return BCBF_EINVAL;
-        hipLaunchKernelGGL(trtri_dma_kernel_f64, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
+        hipLaunchKernelGGL(trtri_pair_kernel<double>, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
         return check_launch("trtri_dma");
     }
     if (nblk - 1 <= TR_MAXT && !ll) {
