@@ -1551,6 +1551,34 @@ def test_syrk_kb_inverse_and_deterministic_likelihood_gradient(ops, dtype):
             np.testing.assert_allclose(host(a), host(b), rtol=1e-10 if f64 else 2e-4, atol=(1e-10 if f64 else 2e-4) * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("kernel", ["rbf", "matern52", "rbf_matern52"])
+@pytest.mark.parametrize("n,m", [(3, 2), (2, 1)])
+def test_posterior_jets_matrix_core_form_equals_streaming_form(ops, n, m, kernel, monkeypatch):
+    """jets_mfma.hip (fp32; residual in MFMA accumulators, operator through an LDS-DMA ring) against the streaming kernel on the same inputs, output by
+    output -- one GP per query and ONE shared GP for all queries (`shared`), the opt-in data kernels, sizes with a ragged last block / a half-filled last
+    64-row group / the largest the form takes, with and without the W output."""
+    from bayesian_cbf_amd.synthetic import make_instances
+    for Bt, N, shared in ((5, 512, False), (3, 300, False), (37, 480, True), (4, 33, False), (2, 64, True)):
+        p = make_instances(1 if shared else Bt, N, n, m, dtype=torch.float32, device=DEV, seed=31 * n + m + N)
+        jit = (p["jitter"] * 1e3).contiguous()
+        Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], jit, kernel=kernel)
+        assert (info == 0).all()
+        Vw, _ = ops.potrs(Lop, p["Xdot"], p["UH"], p["M0"], want_alpha=False)
+        g = torch.Generator(device=DEV).manual_seed(N)
+        xq = (p["X"][0, :Bt] if shared else p["X"][:, 0]) + 0.3 * torch.randn(Bt, n, device=DEV, generator=g)
+        xq = xq.contiguous()
+        out = {}
+        for form in ("0", "2"):
+            monkeypatch.setenv("BCBF_JETS_MFMA", form)
+            out[form] = ops.posterior_jets(Lop, Vw, p["X"], UHB, p["ell"], p["s2"], p["Bm"], p["M0"], xq, shared=shared, want_W=True, kernel=kernel)
+        torch.cuda.synchronize()
+        for name, a, b in zip(("Mk", "Bk", "G", "Mj", "Wj"), out["0"], out["2"]):
+            sc = max(float(a.abs().max()), 1e-3)
+            if name == "Bk":                                   # (B_k = s2 B - W'W cancels: held to the prior's scale, as everywhere)
+                sc = max(sc, float((p["s2"].abs().max() * p["Bm"].abs().max())))
+            rel_close(host(b), host(a), 2e-4, scale=sc, what="%s %s N=%d shared=%s" % (kernel, name, N, shared))      # (fp32 sums in a different order; measured <= 3e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("n,m,form", [(n_, m_, "default") for n_ in (1, 2, 3, 4) for m_ in (1, 2, 3)] + [(2, 1, "mfma"), (2, 2, "mfma"), (3, 1, "mfma"), (3, 2, "mfma")])
 def test_posterior_jets_every_compiled_shape_and_workgroup_size_vs_oracle(ops, n, m, form, dtype, monkeypatch):
