@@ -49,7 +49,6 @@ trtri_mfma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, i
     trtri_own_writes_visible();
     for (int I = J + 1; I < nblk; ++I) {
         f32x16 acc = {0};
-        const int gr = I * NB + col;                               // this lane's A row (tile row I)
         // operands of block K + 1 are in flight while block K's MFMA chain runs (two register sets, swapped by the unrolled pair)
         float av[2][16], bv[2][16];
         auto load = [&](int K, float (&a)[16], float (&bq)[16]) {
@@ -183,14 +182,13 @@ trtri_mfma_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv,
     }
 }
 
-// RIGHT-LOOKING within a block column, N <= 512 (round 6, second form): the form above reads every X_KJ back from the dense output it has just written -- a
-// store, a fence and an exposed load round trip per block row, at ~220 registers (two waves per SIMD): 13 TFLOP/s.  Here a wave keeps the accumulators of ALL the
-// tiles below it in registers (up to 15 tiles x 16 registers, one wave per SIMD): as soon as X_KJ exists -- in the accumulator layout, which IS the B-operand
-// layout -- it is applied to every pending row I > K, `acc_I += L_IK X_KJ`, with the A operand gathered in the accumulator's row order straight from the packed
-// operator.  Nothing the wave loads depends on anything it computed: the operand loads of the next tile are in flight under the current tile's MFMA chain, there
-// is no read-back and no fence.  fp64 takes HALF a block column per wave (16 columns: 15 tiles x 16 registers again).
+// RIGHT-LOOKING within a block column, N <= 512 (round 6): the form above reads every X_KJ back from the dense output it has just written -- a store, a fence and
+// an exposed load round trip per block row, at ~220 registers (two waves per SIMD): 13 TFLOP/s.  In the forms below a wave keeps the accumulators of ALL the tiles
+// under its columns in registers: as soon as X_KJ exists -- in the accumulator layout, which IS the B-operand layout -- it is applied to every pending row I > K,
+// `acc_I += L_IK X_KJ`.  Nothing the wave loads depends on anything it computed: no read-back, no fence.  (Steps on the way, DESIGN 3.4 / DESIGN_NOTES: operands
+// gathered straight from memory into a register ring -- drained per tile by the compiler's waits across basic blocks, 9.2 ms fp32 at 4096 x 512; a whole block
+// column per wave with the LDS ring below, 4.2 ms; the pair form, 3.4 ms.)
 constexpr int TR_MAXT = 15;
-constexpr int TR_RING = 3;          // operand sets in flight per wave (tiles ahead + 1); 4 x 16 loads exceed what s_waitcnt vmcnt can count (63): the compiler then waits for all but the newest set
 
 // compile-time loop: every index of the accumulator array is a constant, so the array lives in registers (with a run-time `break` in an unrolled loop the
 // compiler kept it in scratch: 1 KB per lane)
@@ -198,320 +196,14 @@ template <int B, int E, typename F> __device__ inline void static_for(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
-__global__ void __launch_bounds__(64, 1)
-trtri_rl_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, int N, int Np, int nblk) {
-    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
-    constexpr int V = 4;
-    const int b = blockIdx.x / nblk, J = blockIdx.x - b * nblk;
-    const float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
-    float* __restrict__ X = Linv + (size_t)b * N * N;
-    const int lane = threadIdx.x, col = lane & 31, g = lane >> 5;
-    const int gc = J * NB + col;
-    const bool vc = gc < N;
-    const int cnt = nblk - J - 1;                                  // tiles below the diagonal tile
-    for (int i = g; i < J * NB; i += 2)
-        if (vc && i < N) X[(size_t)i * N + gc] = 0.0f;
-    // register q of a lane <-> row rho(q) + 4 g of its column (the MFMA accumulator layout).  Every address below is a wave-uniform base (scalar registers)
-    // plus a 32-bit per-lane offset formed ONCE (per kernel: doff, xoff; per K: kb) -- formed per load, the index arithmetic of the packed layout (three
-    // quarter-rate integer multiplies and a 64-bit add each) was 20 vector instructions per load, more issue slots than the MFMA chain it feeds
-    unsigned doff[16], xoff[16], kb[16];
-    int rr[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        rr[q] = 8 * (q >> 2) + (q & 3) + 4 * g;
-        doff[q] = (unsigned)(NB * rr[q] + col);                    // inv(L_KK)[col][rr]  in the full-tile copy (column-major)
-        xoff[q] = (unsigned)(rr[q] * N + gc);                      // X[32 K + rr][gc]
-    }
-    f32x16 xk, acc[TR_MAXT];
-    {
-        const float* dj = lop + lop_dfull_block(J, Np);
-        float* xj = X + (size_t)J * NB * N;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            xk[q] = dj[(unsigned)(NB * col + rr[q])];              // inv(L_JJ)[rr][col] (zeros above the diagonal)
-            if (vc && J * NB + rr[q] < N) xj[xoff[q]] = xk[q];
-        }
-    }
-    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value] = f32x16{0}; });
-    // A operand of tile (I, K) in the accumulator's contraction order: L[32 I + col][32 K + rr]
-    int Kcur = J;
-    auto load_a = [&](int I, float (&av)[16]) {
-        const float* pi = lop + (I - Kcur - 1) * NB;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) av[q] = pi[kb[q]];
-    };
-    float ar[TR_RING][16];
-    static_for<0, TR_MAXT + 1>([&](auto kc) {                      // K = J + kk
-        constexpr int kk = decltype(kc)::value;
-        if (kk > cnt) return;
-        const int K = J + kk;
-        Kcur = K;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) kb[q] = (unsigned)(lop_base<V>(K * NB + rr[q], Np) + (K + 1) * NB + col);     // (row 32 (K + 1): the first row a column of block K stores -- lop_base itself is negative for the first columns)
-        // the A operands of the first TR_RING - 1 pending tiles are issued BEFORE X_K is formed (they do not depend on it)
-        static_for<0, TR_RING - 1>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if (kk + r < cnt) load_a(J + 1 + kk + r, ar[r]);
-        });
-        if constexpr (kk > 0) {
-            f32x16 out = {0};
-            const float* dk = lop + lop_dfull_block(K, Np);
-            float di[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) di[q] = dk[doff[q]];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(di[q], acc[kk - 1][q], out, 0, 0, 0);
-            float* xkp = X + (size_t)K * NB * N;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                xk[q] = -out[q];
-                if (vc && K * NB + rr[q] < N) xkp[xoff[q]] = xk[q];
-            }
-        }
-        static_for<0, TR_MAXT - kk>([&](auto pc) {
-            constexpr int d = decltype(pc)::value, t = kk + d;     // tile t of this block column (I = J + 1 + t), ring slot d % TR_RING
-            if (t < cnt) {
-                if (t + TR_RING - 1 < cnt) load_a(J + 1 + t + TR_RING - 1, ar[(d + TR_RING - 1) % TR_RING]);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d % TR_RING][q], xk[q], acc[t], 0, 0, 0);
-            }
-        });
-    });
-}
-
-__global__ void __launch_bounds__(64, 1)
-trtri_rl_kernel_f64(const double* __restrict__ Lop, double* __restrict__ Linv, int N, int Np, int nblk) {
-    using f64x4 = __attribute__((__vector_size__(4 * sizeof(double)))) double;
-    constexpr int V = 2;
-    const int w = blockIdx.x % (2 * nblk), b = blockIdx.x / (2 * nblk), J = w >> 1, half = w & 1;
-    const double* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
-    double* __restrict__ X = Linv + (size_t)b * N * N;
-    const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
-    const int lc = 16 * half + c16, gc = J * NB + lc;              // this lane's column (within the block column / global)
-    const bool vc = gc < N;
-    const int cnt = nblk - J - 1;
-    for (int i = g; i < J * NB; i += 4)
-        if (vc && i < N) X[(size_t)i * N + gc] = 0.0;
-    // register q of acc[.][hk] <-> row rr[hk][q] = 16 hk + 4 q + g of the lane's column; per-lane offsets formed once (see the fp32 kernel)
-    int rr[2][4];
-    unsigned doff[2][4][2], xoff[2][4], kb[2][4];
-#pragma unroll
-    for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            rr[hk][q] = 16 * hk + 4 * q + g;
-            xoff[hk][q] = (unsigned)(rr[hk][q] * N + gc);
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi) doff[hk][q][hi] = (unsigned)(NB * rr[hk][q] + 16 * hi + c16);     // inv(L_KK)[16 hi + c16][rr]
-        }
-    f64x4 xk[2], acc[TR_MAXT][2];
-    {
-        const double* dj = lop + lop_dfull_block(J, Np);
-        double* xj = X + (size_t)J * NB * N;
-#pragma unroll
-        for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                xk[hk][q] = dj[(unsigned)(NB * lc + rr[hk][q])];
-                if (vc && J * NB + rr[hk][q] < N) xj[xoff[hk][q]] = xk[hk][q];
-            }
-    }
-    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value][0] = f64x4{0}; acc[decltype(tc)::value][1] = f64x4{0}; });
-    // A operand: L[32 I + 16 hi + c16][32 K + rr]
-    int Kcur = J;
-    auto load_a = [&](int I, double (&av)[2][4][2]) {
-        const double* pi = lop + (I - Kcur - 1) * NB;
-#pragma unroll
-        for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                av[hk][q][0] = pi[kb[hk][q]];
-                av[hk][q][1] = pi[kb[hk][q] + 16u];
-            }
-    };
-    auto chain = [&](f64x4 (&ac)[2], const double (&av)[2][4][2]) {
-#pragma unroll
-        for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int hi = 0; hi < 2; ++hi)
-                    ac[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[hk][q][hi], xk[hk][q], ac[hi], 0, 0, 0);
-    };
-    double ar[TR_RING][2][4][2];
-    static_for<0, TR_MAXT + 1>([&](auto kc) {
-        constexpr int kk = decltype(kc)::value;
-        if (kk > cnt) return;
-        const int K = J + kk;
-        Kcur = K;
-#pragma unroll
-        for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) kb[hk][q] = (unsigned)(lop_base<V>(K * NB + rr[hk][q], Np) + (K + 1) * NB + c16);
-        static_for<0, TR_RING - 1>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if (kk + r < cnt) load_a(J + 1 + kk + r, ar[r]);
-        });
-        if constexpr (kk > 0) {
-            f64x4 out[2] = {f64x4{0}, f64x4{0}};
-            const double* dk = lop + lop_dfull_block(K, Np);
-            double di[2][4][2];
-#pragma unroll
-            for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int hi = 0; hi < 2; ++hi) di[hk][q][hi] = dk[doff[hk][q][hi]];
-#pragma unroll
-            for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int hi = 0; hi < 2; ++hi)
-                        out[hi] = __builtin_amdgcn_mfma_f64_16x16x4f64(di[hk][q][hi], acc[kk - 1][hk][q], out[hi], 0, 0, 0);
-            double* xkp = X + (size_t)K * NB * N;
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    xk[hi][q] = -out[hi][q];
-                    if (vc && K * NB + rr[hi][q] < N) xkp[xoff[hi][q]] = xk[hi][q];
-                }
-        }
-        static_for<0, TR_MAXT - kk>([&](auto pc) {
-            constexpr int d = decltype(pc)::value, t = kk + d;
-            if (t < cnt) {
-                if (t + TR_RING - 1 < cnt) load_a(J + 1 + t + TR_RING - 1, ar[(d + TR_RING - 1) % TR_RING]);
-                chain(acc[t], ar[d % TR_RING]);
-            }
-        });
-    });
-}
-
-// The register-resident form again, its operand stream through LDS by `buffer_load ... lds` (round 6, third form, fp32).  What the form above lacks is
-// bytes in flight: its operand ring lives in registers beside 240 accumulator registers, and with every tile in a basic block of its own the compiler's
-// s_waitcnt placement drains the ring per tile -- a memory round trip per 16 MFMAs.  Nothing this wave reads depends on what it computes, so the WHOLE read
-// sequence is known up front: for K = J ..: [inv(L_KK) (K > J)], L_{K+1,K}, L_{K+2,K}, ...  -- every element a 4 KB tile.  A run-time cursor walks that sequence
-// TD_RING - 1 elements ahead of the (compile-time unrolled) consumption and copies each tile into a ring of LDS slots with four LDS-DMA instructions (no
-// registers, no s_waitcnt the compiler knows about); a consumer step issues the next element's copy, waits with a COUNTED vmcnt for its own element (the
-// TD_RING - 1 younger copies stay in flight; past the end of the sequence the cursor issues out-of-range dummies so that the count holds), reads its sixteen
-// A-operand registers from the slot and runs the MFMA chain.  The inverted diagonal tile is just another element of the stream (its full-tile copy is
-// column-major like an off-diagonal tile's LDS image: one fragment addressing for both).  Workgroup -> (model, block column) is XCD-aware: the block columns
-// of a model are dealt to ONE XCD (consecutive workgroups of that XCD), whose L2 then serves the K + 1 reads of tile (I, K).
-constexpr int TD_RING = 8;
-__global__ void __launch_bounds__(64, 1)
-trtri_dma_kernel_f32(const float* __restrict__ Lop, float* __restrict__ Linv, int Bt, int N, int Np, int nblk) {
-    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
-    constexpr int V = 4;
-    __shared__ __attribute__((aligned(16))) float ring[TD_RING][NB * NB];
-    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;         // (workgroups go to the XCDs round-robin)
-    const int J = pos % nblk, b = (pos / nblk) * 8 + xcd;
-    if (b >= Bt) return;
-    const float* __restrict__ lop = Lop + (size_t)b * lop_elems<V>(Np);
-    float* __restrict__ X = Linv + (size_t)b * N * N;
-    const int lane = threadIdx.x, col = lane & 31, g = lane >> 5;
-    const int gc = J * NB + col;
-    const bool vc = gc < N;
-    const int cnt = nblk - J - 1;                                  // tiles below the diagonal tile
-    for (int i = g; i < J * NB; i += 2)
-        if (vc && i < N) X[(size_t)i * N + gc] = 0.0f;
-    unsigned xoff[16];
-    int rr[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        rr[q] = 8 * (q >> 2) + (q & 3) + 4 * g;
-        xoff[q] = (unsigned)(rr[q] * N + gc);                      // X[32 K + rr][gc]
-    }
-    f32x16 xk, acc[TR_MAXT];
-    {
-        const float* dj = lop + lop_dfull_block(J, Np);
-        float* xj = X + (size_t)J * NB * N;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            xk[q] = dj[(unsigned)(NB * col + rr[q])];              // inv(L_JJ)[rr][col] (zeros above the diagonal)
-            if (vc && J * NB + rr[q] < N) xj[xoff[q]] = xk[q];
-        }
-    }
-    static_for<0, TR_MAXT>([&](auto tc) { acc[decltype(tc)::value] = f32x16{0}; });
-
-    // ---- the read sequence: cursor (cK, cI); cI == cK: the inverted diagonal tile of cK, cI > cK: tile (cI, cK)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lop), 0, (unsigned)(lop_elems<V>(Np) * 4), 0x00020000);
-    int cK = J, cI = J + 1, wslot = 0;
-    if (cI >= nblk) { cK = J + 1; cI = cK; }
-    const int lq = lane >> 3, lr = lane & 7;                        // a copy instruction moves 8 columns x 32 rows: lane = (column lq, rows 4 lr ..)
-    auto issue_next = [&]() {
-        const bool valid = cK < nblk, diag = cI == cK;
-        const int cs = Np - NB * (cK + 1);
-        // per-lane source offset, scalar offset of the element, scalar step between its four pieces (bytes)
-        const int voff = !valid ? 0x7ffffff0 : diag ? 16 * lane : (lq * cs + 4 * lr) * 4;
-        const int soff = diag ? lop_dfull_block(cK, Np) * 4 : (lop_base<V>(cK * NB, Np) + NB * (cK + 1) + NB * (cI - cK - 1)) * 4;
-        const int step = diag ? 1024 : 32 * cs;
-        __attribute__((address_space(3))) float* dst = (__attribute__((address_space(3))) float*)&ring[wslot][0];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 256 * j), 16, voff, valid ? soff + j * step : 0, 0, 0);
-        wslot = wslot + 1 == TD_RING ? 0 : wslot + 1;
-        ++cI;
-        if (cI >= nblk) { ++cK; cI = cK; }
-    };
-    for (int a = 0; a < TD_RING - 1; ++a) issue_next();
-    int rslot = 0;
-    // the next element of the sequence as sixteen A-operand registers: fr[q] = tile[row col][column rr[q]]  (the accumulator's contraction order)
-    auto next_frags = [&](float (&fr)[16]) {
-        issue_next();
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (TD_RING - 1)) : "memory");
-        const __attribute__((address_space(3))) float* src = (const __attribute__((address_space(3))) float*)&ring[rslot][0] + (4 * g) * NB + col;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) fr[q] = src[(8 * (q >> 2) + (q & 3)) * NB];
-        rslot = rslot + 1 == TD_RING ? 0 : rslot + 1;
-    };
-    // Software pipeline over the sequence: the element a consumer needs is fetched from the ring by its PREDECESSOR, between that one's MFMAs (a wave issues in
-    // order and stalls at an MFMA while the pipe is busy: the copy's scalar arithmetic, the counted wait and the sixteen LDS reads placed after the first
-    // four MFMAs of a chain run under the other twelve; behind the chain they are exposed -- 300 cycles per 1024 of MFMA issue).  The last consumer fetches a dummy.
-    float cur[16];
-    next_frags(cur);
-    static_for<0, TR_MAXT + 1>([&](auto kc) {                      // K = J + kk
-        constexpr int kk = decltype(kc)::value;
-        if (kk > cnt) return;
-        const int K = J + kk;
-        if constexpr (kk > 0) {
-            float nxt[16];
-            f32x16 out = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], acc[kk - 1][q], out, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            next_frags(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 4; q < 16; ++q) out = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], acc[kk - 1][q], out, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
-            float* xkp = X + (size_t)K * NB * N;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                xk[q] = -out[q];
-                if (vc && K * NB + rr[q] < N) xkp[xoff[q]] = xk[q];
-            }
-        }
-        static_for<0, TR_MAXT - kk>([&](auto pc) {
-            constexpr int t = kk + decltype(pc)::value;           // tile t of this block column (I = J + 1 + t)
-            if (t < cnt) {
-                float nxt[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], xk[q], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                next_frags(nxt);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 4; q < 16; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q], xk[q], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
-            }
-        });
-    });
-}
-
-// ... and in fp64: a wave holds the accumulators of HALF a block column (16 columns: 15 tiles x 16 registers), so the two waves of a block column form ONE
+// The operand stream goes through LDS by `buffer_load ... lds`.  Nothing a wave reads depends on what it computes, so the WHOLE read sequence is known up front:
+// for K = J ..: [inv(L_KK) (K > J)], L_{K+1,K}, L_{K+2,K}, ...  -- every element a 32 x 32 tile.  A run-time cursor walks that sequence RING - 1 elements ahead
+// of the (compile-time unrolled) consumption and copies each tile into a ring of LDS slots (no registers, no s_waitcnt the compiler places); a consumer step issues
+// the next element's copy, waits with a COUNTED vmcnt for its own element (the younger copies stay in flight; past the end of the sequence the cursor issues
+// out-of-range dummies so that the count holds), reads its A-operand registers from the slot and runs the MFMA chain.  The inverted diagonal tile is just another
+// element of the stream (its full-tile copy is column-major like an off-diagonal tile's LDS image: one fragment addressing for both).  Workgroup -> (model, block
+// column) is XCD-aware: the block columns of a model are dealt to ONE XCD (consecutive workgroups of that XCD), whose L2 then serves the K + 1 reads of tile (I, K).
+// A wave holds the accumulators of HALF a block column (16 columns: 15 tiles x 16 registers in fp64, x 8 in fp32), so the two waves of a block column form ONE
 // workgroup and share the ring -- each copies half of an element's eight 1 KB pieces, a workgroup barrier per element says that both halves have landed and
 // that the slot about to be refilled has been read by both (8 KB tiles: the stream crosses the fabric once per block column, not once per wave).
 constexpr int TD_RING64 = 8;
@@ -677,47 +369,23 @@ trtri_pair_kernel(const T* __restrict__ Lop, T* __restrict__ Linv, int Bt, int N
     });
 }
 
-int launch_trtri_mfma_f32(const float* Lop, float* Linv, int Bt, int N, void* stream) {
+// N <= 512: the pair form with the LDS ring (BCBF_TRTRI_DMA=0: the left-looking form, which every larger N takes)
+template <typename T>
+static int launch_trtri_mfma(const T* Lop, T* Linv, int Bt, int N, void* stream) {
     const int Np = round_up(N, NB), nblk = Np / NB;
     if ((long long)Bt * nblk > 0x7fffffffLL) return BCBF_EINVAL;
-    static const bool ll = [] { const char* e = getenv("BCBF_TRTRI_LEFT"); return e && e[0] == '1'; }();      // (development: force the left-looking form)
-    static const int dma = [] { const char* e = getenv("BCBF_TRTRI_DMA"); return e ? atoi(e) : 1; }();         // (development: 0 = the register-ring form)
-    if (nblk - 1 <= TR_MAXT && !ll && dma) {
-        const long long groups = ((long long)Bt + 7) / 8;
-        if (groups * 8 * nblk > 0x7fffffffLL) return BCBF_EINVAL;
-        // dma == 2: a whole block column per wave (32x32x2 MFMA, 240 accumulator registers, one wave per SIMD); default: the pair form the fp64 path uses -- half a
-        // block column per wave, two waves per SIMD (measured 4096 x 512: see DESIGN 3.4)
-        if (dma == 2) hipLaunchKernelGGL(trtri_dma_kernel_f32, dim3((unsigned)(groups * 8 * nblk)), dim3(64), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
-        else hipLaunchKernelGGL(trtri_pair_kernel<float>, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
-        return check_launch("trtri_dma");
-    }
-    if (nblk - 1 <= TR_MAXT && !ll) {
-        hipLaunchKernelGGL(trtri_rl_kernel_f32, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
-        return check_launch("trtri_rl");
-    }
-    hipLaunchKernelGGL(trtri_mfma_kernel_f32, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
-    return check_launch("trtri_mfma");
-}
-int launch_trtri_mfma_f64(const double* Lop, double* Linv, int Bt, int N, void* stream) {
-    const int Np = round_up(N, NB), nblk = Np / NB;
-    if ((long long)Bt * nblk > 0x7fffffffLL) return BCBF_EINVAL;
-    // fp64: the left-looking form stays the default (4096 x 512: 14.0 ms against 17.5 for the register-resident form, whose half-width tiles double the A-operand
-    // loads per flop); BCBF_TRTRI_RL64=1 selects it (development)
-    static const bool ll = [] { const char* e = getenv("BCBF_TRTRI_RL64"); return !(e && e[0] == '1'); }();
-    static const int dma = [] { const char* e = getenv("BCBF_TRTRI_DMA"); return e ? atoi(e) : 1; }();         // (development: 0 = the forms below)
+    static const int dma = [] { const char* e = getenv("BCBF_TRTRI_DMA"); return e ? atoi(e) : 1; }();         // (development)
     if (nblk - 1 <= TR_MAXT && dma) {
         const long long groups = ((long long)Bt + 7) / 8;
         if (groups * 8 * nblk > 0x7fffffffLL) return BCBF_EINVAL;
-        hipLaunchKernelGGL(trtri_pair_kernel<double>, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
-        return check_launch("trtri_dma");
+        hipLaunchKernelGGL(trtri_pair_kernel<T>, dim3((unsigned)(groups * 8 * nblk)), dim3(128), 0, (hipStream_t)stream, Lop, Linv, Bt, N, Np, nblk);
+        return check_launch("trtri_pair");
     }
-    if (nblk - 1 <= TR_MAXT && !ll) {
-        if ((long long)Bt * nblk * 2 > 0x7fffffffLL) return BCBF_EINVAL;
-        hipLaunchKernelGGL(trtri_rl_kernel_f64, dim3(Bt * nblk * 2), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
-        return check_launch("trtri_rl");
-    }
-    hipLaunchKernelGGL(trtri_mfma_kernel_f64, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(trtri_mfma_kernel_f32, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
+    else hipLaunchKernelGGL(trtri_mfma_kernel_f64, dim3(Bt * nblk), dim3(64), 0, (hipStream_t)stream, Lop, Linv, N, Np, nblk);
     return check_launch("trtri_mfma");
 }
+int launch_trtri_mfma_f32(const float* Lop, float* Linv, int Bt, int N, void* stream) { return launch_trtri_mfma<float>(Lop, Linv, Bt, N, stream); }
+int launch_trtri_mfma_f64(const double* Lop, double* Linv, int Bt, int N, void* stream) { return launch_trtri_mfma<double>(Lop, Linv, Bt, N, stream); }
 
 }  // namespace bcbf
