@@ -173,21 +173,40 @@ mll_grad_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T*
 // (fp32 inputs), more than the factorisation.  Here the per-ROW quantities are formed once per tile -- t_j = A^-1 alpha_j,
 // v_j = B uh_j -- so a pair costs  q = alpha_i . t_j,  u_ij = uh_i . v_j,  the kernel value and  w_i += G k uh_j  (g_B = s2
 // sum_i uh_i w_i' afterwards); K_b^-1 is read through its symmetry, element (j, i), so consecutive threads read consecutive
-// addresses.  Grid (Bt, RC * JS): RC = ceil(N / 256) row chunks times JS column slices (JS > 1 only for a handful of models);
+// addresses -- and, being symmetric in (i, j) term by term, only the pairs j <= i are visited (a wave of rows stops at its last row:
+// 0.56 of the pair work at N = 512, half of K_b^-1's bytes).  Grid (Bt, RC * JS): RC = ceil(N / 256) row chunks times JS column slices (JS > 1 only for a handful of models);
 // partial sums go to the caller's workspace and mll_reduce_kernel adds them in a fixed order (bit-identical run to run).
 // n, nt <= 4 and C <= 4 (every matrix-variate model the device path takes); no linear kernel part.
 constexpr int MR_TJ = 128;
+#ifndef BCBF_MR_U32
+#define BCBF_MR_U32 2
+#endif
+#ifndef BCBF_MR_U64
+#define BCBF_MR_U64 1
+#endif
+#ifndef BCBF_MR_OCC32
+#define BCBF_MR_OCC32 7
+#endif
+#ifndef BCBF_MR_OCC64
+#define BCBF_MR_OCC64 4
+#endif
+// pairs per group of the row form's loop (MR_TJ is a multiple) and the waves per SIMD its registers are held to.  The loop is a chain
+// of dependent operations per pair: waves, not unrolling, fill the SIMD.  4096 x 512, ms (U, waves): fp32 (4, 4) 1.42, (2, 5) 1.34,
+// (2, 6) 1.30, (2, 7) 1.24, (2, 8) 2.21 (spills), (1, 8) 1.30, (8, 4) 8.6; fp64 (1, 4) 2.63, (2, 3) 2.71, (4, 2) 3.14, (2, 4) 6.4 (spills),
+// (1, 5) 7.4.  Whatever the compiler picks without a bound: fp32 1.65, fp64 4.8 (256 registers, one wave per SIMD)
+template <typename T> struct MRows { static constexpr int U = BCBF_MR_U32, OCC = BCBF_MR_OCC32; };
+template <> struct MRows<double> { static constexpr int U = BCBF_MR_U64, OCC = BCBF_MR_OCC64; };
 __device__ inline float mll_exp(float v) { return __expf(v); }
 __device__ inline double mll_exp(double v) { return exp(v); }              // (exp_neg64 of bcbf_common.h measured SLOWER here: 4.5 against 3.75 ms)
 template <typename T>
-__global__ void __launch_bounds__(MG_T)
+__global__ void __launch_bounds__(MG_T, MRows<T>::OCC)
 mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, const T* __restrict__ Kinv,
                      const T* __restrict__ X, const T* __restrict__ UH, const T* __restrict__ R, const T* __restrict__ Ainv,
                      const T* __restrict__ Bm, const T* __restrict__ ell, const T* __restrict__ s2p,
                      T* __restrict__ logdetK, T* __restrict__ RtA, T* __restrict__ UHtA, int N, int Np, int n, int C, int nt,
                      double* __restrict__ work, int kind, int RC) {
     constexpr int V = Vec<T>::V;
-    constexpr int NS = 4, CM = BCBF_MAX_CTRL_DIM + 1;
+    constexpr int NS = 4, CM = BCBF_MAX_CTRL_DIM + 1, MR_U = MRows<T>::U;
     constexpr int NR = BCBF_MAX_STATE_DIM + 2 + CM * CM;
     // the pair loop's arithmetic type: fp32 inputs are summed in fp32 (K_b^-1 itself carries cond x 6e-8 there; an fp64 pair loop costs
     // 4096 x 512: 5.5 ms against the fp64 kernel's 3.7 -- conversions and the double exp), fp64 inputs in fp64
@@ -230,9 +249,12 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
     for (int d = 0; d < NS; ++d) gl[d] = M(0.0);
 #pragma unroll
     for (int c = 0; c < CM; ++c) w[c] = M(0.0);
-    // this workgroup's columns: slice js of JS, in tiles of MR_TJ
+    // this workgroup's columns: slice js of JS, in tiles of MR_TJ -- the pairs j <= i only: every term of the sums is the same for
+    // (i, j) and (j, i) up to the transposition of uh_i' B uh_j, so a pair below the diagonal carries both (weight 1 on the sum of
+    // the two), the diagonal half of that; a wave stops at its last row
     const int per = ((N + JS - 1) / JS + MR_TJ - 1) / MR_TJ * MR_TJ;
-    const int jbeg = js * per, jend = min(N, jbeg + per);
+    const int jbeg = js * per, jend = min(min(N, jbeg + per), rc * MG_T + MG_T);
+    const int jlast = rc * MG_T + (tid | 63);       // the wave's last row
     for (int j0 = jbeg; j0 < jend; j0 += MR_TJ) {
         __syncthreads();
         if (tid < MR_TJ) {
@@ -257,16 +279,29 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
             for (int a = 0; a < CM; ++a) {
                 M t = M(0.0);
 #pragma unroll
-                for (int c = 0; c < CM; ++c) t += Bl[a][c] * u_[c];
+                for (int c = 0; c < CM; ++c) t += (Bl[a][c] + Bl[c][a]) * u_[c];       // (B + B') uh_j: uh_i' B uh_j + uh_j' B uh_i in one product
                 vj[tid][a] = t;
                 uj[tid][a] = u_[a];
             }
         }
         __syncthreads();
-        const int cnt = min(MR_TJ, jend - j0);
-        if (vi)
-            for (int jj = 0; jj < cnt; ++jj) {
-                const M kinv = (M)Kib[(size_t)(j0 + jj) * N + i];        // K_b^-1 [j][i] = [i][j]
+        const int cnt = min(min(MR_TJ, jend - j0), jlast - j0 + 1);
+        // K_b^-1's elements are fetched MR_U pairs ahead (one load per pair, ~100 operations between its issue and its use otherwise).  The pairs of a group beyond `cnt` meet zero-filled
+        // columns or weight 0; their addresses are clamped into the tile
+        const int jcl = min(MR_TJ, jend - j0) - 1;
+        if (vi) {
+          M kv[MR_U], kn[MR_U];
+          const T* kp = Kib + (size_t)j0 * N + i;                      // K_b^-1 [j][i] = [i][j]
+#pragma unroll
+          for (int u = 0; u < MR_U; ++u) kv[u] = (M)kp[(size_t)min(u, jcl) * N];
+          for (int jg = 0; jg < cnt; jg += MR_U) {
+#pragma unroll
+            for (int u = 0; u < MR_U; ++u) kn[u] = (M)kp[(size_t)min(jg + MR_U + u, jcl) * N];
+#pragma unroll
+            for (int u = 0; u < MR_U; ++u) {
+                const int jj = jg + u, j = j0 + jj;
+                const M wgt = j < i ? M(1.0) : (j == i ? M(0.5) : M(0.0));
+                const M kinv = kv[u];
                 M d2 = M(0.0), dz2[NS];
 #pragma unroll
                 for (int d = 0; d < NS; ++d) {
@@ -278,29 +313,33 @@ mll_grad_rows_kernel(const T* __restrict__ Lop, const T* __restrict__ alpha, con
                 kernel_shape(kind, d2, [](M v) { return mll_exp(v); }, krbf, kder);
                 M uij = M(0.0), q = M(0.0);
 #pragma unroll
-                for (int a = 0; a < CM; ++a) uij += ui[a] * vj[jj][a];
+                for (int a = 0; a < CM; ++a) uij += ui[a] * vj[jj][a];                            // uh_i' B uh_j + uh_j' B uh_i
 #pragma unroll
                 for (int d = 0; d < NS; ++d) q += ai[d] * tj[jj][d];
-                const M Gm = M(0.5) * (q - (M)nt * kinv);
+                const M Gm = wgt * M(0.5) * (q - (M)nt * kinv);
                 const M Gk = Gm * krbf;
                 gs += Gk * uij;
                 const M GK = Gm * kder * s2 * uij;
 #pragma unroll
-                for (int d = 0; d < NS; ++d) gl[d] += GK * dz2[d] * iell[d];
+                for (int d = 0; d < NS; ++d) gl[d] += GK * dz2[d];                 // (x 1 / l_d after the loop)
 #pragma unroll
-                for (int c = 0; c < CM; ++c) w[c] += Gk * uj[jj][c];
+                for (int c = 0; c < CM; ++c) w[c] += Gk * uj[jj][c];              // M = sum_{j <= i} G k uh_i uh_j';  g_B = s2 (M + M')
             }
+#pragma unroll
+            for (int u = 0; u < MR_U; ++u) kv[u] = kn[u];
+          }
+        }
     }
     // workgroup sums into the NR slots of mll_store's layout
     const bool lead = (tid & 63) == 0;
     auto put = [&](int o, double v) { v = wave_sum(v); if (lead) red[tid >> 6][o] = v; };
 #pragma unroll
-    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) put(d, d < NS ? (double)gl[d < NS ? d : 0] : 0.0);
+    for (int d = 0; d < BCBF_MAX_STATE_DIM; ++d) put(d, d < NS ? (double)(gl[d < NS ? d : 0] * iell[d < NS ? d : 0]) : 0.0);
     put(BCBF_MAX_STATE_DIM, (double)gs);
 #pragma unroll
     for (int a = 0; a < CM; ++a)
 #pragma unroll
-        for (int c = 0; c < CM; ++c) put(BCBF_MAX_STATE_DIM + 1 + a * CM + c, (double)(s2 * ui[a] * w[c]));
+        for (int c = 0; c < CM; ++c) put(BCBF_MAX_STATE_DIM + 1 + a * CM + c, (double)(s2 * (ui[a] * w[c] + ui[c] * w[a])));
     put(NR - 1, 0.0);
     __syncthreads();
     if (tid < NR) work[((size_t)b * G + part) * NR + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
