@@ -55,6 +55,11 @@ _TSIGS = {
     "bcbf_gp_append_reserved": [P] * 19 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_gp_append_reserved_raw": [P] * 22 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_gp_tail_step": [P] * 23 + [c_int] * 9 + [P],
+    # the online entry points with kernel_kind (opt-in data kernels)
+    "bcbf_gp_append_stream_kind": [P] * 20 + [c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_posterior_query_reserved_kind": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_gp_append_reserved_kind": [P] * 22 + [c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "bcbf_gp_tail_step_kind": [P] * 23 + [c_int] * 10 + [P],
     "bcbf_gp_tail_commit": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_potri": [P, P, c_int, c_int, P],
     "bcbf_trtri": [P, P, c_int, c_int, P],

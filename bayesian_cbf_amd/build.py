@@ -41,7 +41,7 @@ ZERO_SCRATCH_KERNELS = {"posterior_step.hip": [
     "posterior_step_kernel<float, 2, 4, 0, 1, false, 0,", "posterior_step_kernel<float, 3, 4, 0, 1, false, 0,",
     "posterior_step_kernel<double, 2, 4, 0, 1, false, 0,", "posterior_step_kernel<double, 3, 4, 0, 1, false, 0,",
     "posterior_step_kernel<float, 2, 4, 2, 1, false, 0,", "posterior_step_kernel<float, 3, 4, 3, 1, false, 0,",
-    "posterior_step_kernel<float, 3, 4, 0, 1, false, 1,", "posterior_step_kernel<float, 3, 4, 0, 1, true, 0,",
+    "posterior_step_kernel<float, 3, 4, 0, 1, false, 1, false, false>", "posterior_step_kernel<float, 3, 4, 0, 1, true, 0,",
     "posterior_step_kernel<double, 4, 4, 0, 1, false, 0,", "posterior_step_kernel<double, 3, 8, 0, 1, false, 0,"]}
 # kernels that must not touch scratch memory (posterior_shared_reg: an operand spilled between its explicit LDS read and
 # the explicit wait for it would be stored before it has arrived).  Their device assembly is also linted: no instruction may

@@ -174,7 +174,7 @@ template <typename T, int C, int NJ> __host__ __device__ constexpr bool ps_one_r
     return BCBF_PJ_ONE && sizeof(T) == 4 && NJ == 3 && C == 3;
 }
 
-template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false, int XC = 0, bool ONEP = false>
+template <typename T, int C, int NS, int NJ, int NQ = 1, bool RHS = false, int XC = 0, bool ONEP = false, bool XK = false>
 __global__ void __launch_bounds__((sizeof(T) == 8 && NJ == 0 ? 512 : 256),
                                    (NJ > 0 ? (ONEP ? BCBF_PJ_ONE_WAVES : sizeof(T) == 8 || C * (1 + NJ) > 12 || NJ > 3 ? BCBF_PJ_WAVES64 : BCBF_PJ_WAVES32) : BCBF_PS_WAVES))
 posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const T* __restrict__ X,
@@ -333,6 +333,17 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
         for (int v = 0; v < V; ++v) {
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
+                if constexpr (XC > 0) {                // the extra column: k(X_i, x2) (UH B)_i . uh2 (first: nothing of the query's own columns is live yet)
+                    T e2 = T(0), ud = T(0);
+#pragma unroll
+                    for (int d = 0; d < NS; ++d) { const T z = (xv[v][d] - x2r[d]) * iell[d]; e2 += z * z; }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) ud += uv[v][c] * uh2r[c];
+                    T sh2, dsh2;                       // XK: the opt-in data kernels (its own instantiation: the RBF form keeps its registers)
+                    if constexpr (XK) kernel_shape(kind, e2, [](T q_) { return texp<T>(q_); }, sh2, dsh2);
+                    else sh2 = texp<T>(T(-0.5) * e2);
+                    BCBF_ACC(r, v, CT - 1) = s2 * sh2 * ud;
+                }
                 T d2 = T(0), dot = T(0);
 #pragma unroll
                 for (int d = 0; d < NS; ++d) {         // d >= n: xv = xqr = iell = 0
@@ -346,14 +357,6 @@ posterior_step_kernel(const T* __restrict__ Lop, const T* __restrict__ Vw, const
                 } else { shape = texp<T>(T(-0.5) * d2); dshape = shape; }
                 const T k = s2 * (shape + linv * dot);
                 const T kd = s2 * dshape;              // (jets: no linear part)
-                if constexpr (XC > 0) {                // the extra column: k(X_i, x2) (UH B)_i . uh2
-                    T e2 = T(0), ud = T(0);
-#pragma unroll
-                    for (int d = 0; d < NS; ++d) { const T z = (xv[v][d] - x2r[d]) * iell[d]; e2 += z * z; }
-#pragma unroll
-                    for (int c = 0; c < C; ++c) ud += uv[v][c] * uh2r[c];
-                    BCBF_ACC(r, v, CT - 1) = s2 * texp<T>(T(-0.5) * e2) * ud;
-                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const T ub = uv[v][c];             // 0 for rows >= N and idle lanes: the row contributes nothing
@@ -1071,6 +1074,25 @@ extern "C" int bcbf_posterior_query_reserved_f64(const double* Lop, const double
                                                nullptr, nullptr, nullptr, Ncap);
 }
 
+// ... with the opt-in data kernels (kernel_kind of bcbf_common.h: 0 RBF, 1 Matern-5/2, 2 RBF x Matern-5/2) -- states grown by
+// bcbf_gp_append_reserved_kind / bcbf_gp_tail_step_kind
+extern "C" int bcbf_posterior_query_reserved_kind_f32(const float* Lop, const float* Vw, const float* X, const float* UHB,
+                                                      const float* ell, const float* s2, const float* Bm, const float* M0,
+                                                      const float* xq, const float* jitter2, float* Mk, float* Bk, float* W,
+                                                      int Bt, int N, int Ncap, int n, int m, int kernel_kind, void* stream) {
+    if (Ncap < N || kernel_kind < 0 || kernel_kind >= bcbf::BCBF_KINDS) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<float>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, 0, Bt, N, n, m, stream,
+                                              nullptr, nullptr, nullptr, Ncap, kernel_kind);
+}
+extern "C" int bcbf_posterior_query_reserved_kind_f64(const double* Lop, const double* Vw, const double* X, const double* UHB,
+                                                      const double* ell, const double* s2, const double* Bm, const double* M0,
+                                                      const double* xq, const double* jitter2, double* Mk, double* Bk, double* W,
+                                                      int Bt, int N, int Ncap, int n, int m, int kernel_kind, void* stream) {
+    if (Ncap < N || kernel_kind < 0 || kernel_kind >= bcbf::BCBF_KINDS) return BCBF_EINVAL;
+    return bcbf::launch_posterior_step<double>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, jitter2, Mk, Bk, W, 0, Bt, N, n, m, stream,
+                                               nullptr, nullptr, nullptr, Ncap, kernel_kind);
+}
+
 // The same queries with the Matern-5/2 data kernel  k = s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r),  r^2 = sum_d ((x_d - x'_d) / ell_d)^2
 // (gpytorch MaternKernel(nu = 2.5, ard) under ScaleKernel).  OPT-IN and parity unpinned: the reference has no Matern
 // (and the derivative jets of the same kernel, bcbf_posterior_jets_matern52: d k / d x_d = -(5/3) s2 (1 + a) exp(-a) (x_d - x'_d) / ell_d^2)
@@ -1143,21 +1165,22 @@ namespace bcbf {
 template <typename T>
 int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm,
                                    const T* M0, const T* xq, const T* xq2, T* Mk2, T* Bk2, T* W2, int Bt, int N, int Ncap, int n,
-                                   int m, void* stream) {
+                                   int m, void* stream, int kind) {
     return launch_posterior_step<T>(Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, nullptr, Mk2, Bk2, W2, 0, Bt, N, n, m, stream, nullptr,
-                                    nullptr, nullptr, Ncap, 0, xq2);
+                                    nullptr, nullptr, Ncap, kind, xq2);
 }
 // The online path's fused pass: posterior (Mk, Bk) at xq AND the append's column l = L^-1 (k(X, x_new) o (UH B uh_new)) with its
 // sums (lsum[Bt, 1 + n] = l'l, Vw'l) on ONE pass over every instance's factor (reserved storage, capacity Ncap)
 template <typename T>
 int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                            const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
-                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream, T* Wfull, int Lcap) {
+                                           T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream, T* Wfull, int Lcap,
+                                           int kind) {
     // Wfull (optional, [Bt, Np, 1 + m + 1]): every solved column of the pass, row-major per row (what the tail step continues from)
     // Lcap (0: Ncap): the capacity the OPERATOR is laid out for where it differs from the arrays' -- a packed operator of exactly N
     // points (bcbf_refit's output) beside arrays of Ncap rows: the tail step's window, which never grows in place
     if (Bt <= 0) return BCBF_OK;
-    if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM || Ncap < N) return BCBF_EINVAL;
+    if (n < 1 || n > 4 || m < 1 || m > BCBF_MAX_CTRL_DIM || Ncap < N || kind < 0 || kind >= BCBF_KINDS) return BCBF_EINVAL;
     constexpr int V = Vec<T>::V;
     const int Np = round_up(N, NB), Nl = round_up(Lcap ? Lcap : Ncap, NB);
     const int threads = round_up(Np / V / 2, 64);
@@ -1166,17 +1189,19 @@ int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X
     if (px_lds > 100 * 1024) return BCBF_EINVAL;                    // (beside ~1 KB of static LDS; gfx950: 160 KB per workgroup)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(Bt), block(threads);
-#define BCBF_PX_LAUNCH(CC) if (px_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_step_kernel<T, CC, 4, 0, 1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds); hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1>), grid, block, ((lvec ? Np : 0) + (Wfull ? (size_t)Np * (CC + 1) : 0)) * sizeof(T), st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, Wfull, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, 0, x_new, uh_new)
+#define BCBF_PX_LAUNCH_(CC, XKV) do { if (px_lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)posterior_step_kernel<T, CC, 4, 0, 1, false, 1, false, XKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)px_lds); hipLaunchKernelGGL((posterior_step_kernel<T, CC, 4, 0, 1, false, 1, false, XKV>), grid, block, ((lvec ? Np : 0) + (Wfull ? (size_t)Np * (CC + 1) : 0)) * sizeof(T), st, Lop, Vw, X, UHB, ell, s2, Bm, M0, xq, (const T*)nullptr, Mk, Bk, lvec, lsum, Wfull, 0, N, Np, n, (const T*)nullptr, Bt, Nl, Ncap, kind, x_new, uh_new); } while (0)
+#define BCBF_PX_LAUNCH(CC) if (kind != 0) BCBF_PX_LAUNCH_(CC, true); else BCBF_PX_LAUNCH_(CC, false)
     switch (m) {
         case 1: BCBF_PX_LAUNCH(2); break;
         case 2: BCBF_PX_LAUNCH(3); break;
         default: BCBF_PX_LAUNCH(4); break;
     }
 #undef BCBF_PX_LAUNCH
+#undef BCBF_PX_LAUNCH_
     return check_launch("posterior_query_column");
 }
-template int launch_posterior_query_column_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, int, int, int, void*, float*, int);
-template int launch_posterior_query_column_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int, int, int, int, int, void*, double*, int);
-template int launch_posterior_pair_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int, void*);
-template int launch_posterior_pair_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, int, int, int, int, int, void*);
+template int launch_posterior_query_column_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, int, int, int, int, int, void*, float*, int, int);
+template int launch_posterior_query_column_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int, int, int, int, int, void*, double*, int, int);
+template int launch_posterior_pair_reserved<float>(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int, void*, int);
+template int launch_posterior_pair_reserved<double>(const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, double*, int, int, int, int, int, void*, int);
 }  // namespace bcbf

@@ -635,12 +635,12 @@ static int launch_gp_reserve(const T* Lin, const T* Vw_in, const T* X_in, const 
 template <typename T>
 int launch_posterior_pair_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2, const T* Bm,
                                    const T* M0, const T* xq, const T* xq2, T* Mk2, T* Bk2, T* W2, int Bt, int N, int Ncap, int n,
-                                   int m, void* stream);          // posterior_step.hip
+                                   int m, void* stream, int kind = 0);          // posterior_step.hip
 template <typename T>
 int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                            const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
                                            T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream,
-                                           T* Wfull = nullptr, int Lcap = 0);   // posterior_step.hip
+                                           T* Wfull = nullptr, int Lcap = 0, int kind = 0);   // posterior_step.hip
 
 template <typename T>
 static int launch_gp_append_inplace(T* Lop, T* Vw, T* X, T* UHB, const T* s2, const T* Bm, const T* M0, const T* x_new,
@@ -731,6 +731,30 @@ int bcbf_gp_append_stream_f64(const double* Lop_in, const double* Vw_in, const d
     return bcbf::launch_gp_append<double>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new,
                                           jitter_new, Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, Wwork);
 }
+// ... bcbf_gp_append_stream with the opt-in data kernels (kernel_kind 0 RBF, 1 Matern-5/2, 2 RBF x Matern-5/2): the forward solve on
+// the streaming kernel of that kind
+#define BCBF_STREAM_KIND_ENTRY(SUF, T)                                                                                       \
+    int bcbf_gp_append_stream_kind_##SUF(const T* Lop_in, const T* Vw_in, const T* X_in, const T* UHB_in, const T* ell,       \
+                                         const T* s2, const T* Bm, const T* M0, const T* x_new, const T* uh_new,             \
+                                         const T* xdot_new, const T* jitter_new, T* Lop_out, T* Vw_out, T* X_out,            \
+                                         T* UHB_out, int* info, T* Wwork, T* Mk_work, T* Bk_work, int Bt, int N, int n,       \
+                                         int m, int kernel_kind, void* stream) {                                             \
+        if (!Wwork || !Mk_work || !Bk_work || kernel_kind < 0 || kernel_kind >= bcbf::BCBF_KINDS) return BCBF_EINVAL;              \
+        const int rc = kernel_kind == 0 ? bcbf_posterior_query_##SUF(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new,      \
+                                                                     nullptr, Mk_work, Bk_work, Wwork, 0, Bt, N, n, m, stream) \
+                     : kernel_kind == 1 ? bcbf_posterior_query_matern52_##SUF(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0,   \
+                                                                              x_new, nullptr, Mk_work, Bk_work, Wwork, 0, Bt, \
+                                                                              N, n, m, stream)                              \
+                                        : bcbf_posterior_query_rbfm52_##SUF(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0,     \
+                                                                            x_new, nullptr, Mk_work, Bk_work, Wwork, 0, Bt,   \
+                                                                            N, n, m, stream);                               \
+        if (rc != BCBF_OK) return rc;                                                                                        \
+        return bcbf::launch_gp_append<T>(Lop_in, Vw_in, X_in, UHB_in, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new,   \
+                                         Lop_out, Vw_out, X_out, UHB_out, info, Bt, N, n, m, stream, Wwork);                 \
+    }
+BCBF_STREAM_KIND_ENTRY(f32, float)
+BCBF_STREAM_KIND_ENTRY(f64, double)
+#undef BCBF_STREAM_KIND_ENTRY
 // ... with the opt-in Matern-5/2 data kernel for the new column (the simple forward solve; no reference counterpart)
 int bcbf_gp_append_matern52_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
                                 const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
@@ -781,8 +805,10 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
     static int gp_append_reserved_impl_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,   \
                                       const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,                   \
                                       const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work, const T* xq,     \
-                                      T* Mk, T* Bk, int Bt, int N, int Ncap, int n, int m, void* stream, T* const* raw) { \
+                                      T* Mk, T* Bk, int Bt, int N, int Ncap, int n, int m, void* stream, T* const* raw,  \
+                                      int kind = 0) {                                                                    \
         if (Bt <= 0) return BCBF_OK;                                                                                     \
+        if (kind < 0 || kind >= bcbf::BCBF_KINDS) return BCBF_EINVAL;                                                    \
         if (!Lop_r || !Vw_r || !X_r || !UHB_r || !ell || !s2 || !Bm || !M0 || !x_new || !uh_new || !xdot_new || !info ||  \
             !Wwork || !Mk_work || !Bk_work || (xq && (!Mk || !Bk)))                                                      \
             return BCBF_EINVAL;                                                                                          \
@@ -793,7 +819,7 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
                the factor (Wwork: the column l [Bt, Np]; Mk_work: its sums [Bt, 1 + n]) */                               \
             const int rc = bcbf::launch_posterior_query_column_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq,  \
                                                                            x_new, uh_new, Mk, Bk, Wwork, Mk_work, Bt, N,  \
-                                                                           Ncap, n, m, stream);                          \
+                                                                           Ncap, n, m, stream, nullptr, 0, kind);        \
             if (rc != BCBF_OK) return rc;                                                                                \
             return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new,        \
                                                      jitter_new, Wwork, info, Bt, N, Ncap, n, m, stream, 3, nullptr,      \
@@ -802,19 +828,20 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
         if (xq != nullptr && n <= 4 && m <= 2) {                                                                         \
             /* (round 3's form, BCBF_APPEND_PAIR=1: two full queries per instance on one pass) */                        \
             const int rc = bcbf::launch_posterior_pair_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new,   \
-                                                                   Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);  \
+                                                                   Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream,   \
+                                                                   kind);                                                \
             if (rc != BCBF_OK) return rc;                                                                                \
             return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new,        \
                                                      jitter_new, Wwork, info, Bt, N, Ncap, n, m, stream, 2, Mk_work,      \
                                                      Bk_work, Mk, Bk, nullptr, raw);                                     \
         }                                                                                                                \
         if (xq != nullptr) {                                                                                             \
-            const int rq = bcbf_posterior_query_reserved_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, nullptr, Mk,  \
-                                                               Bk, nullptr, Bt, N, Ncap, n, m, stream);                  \
+            const int rq = bcbf_posterior_query_reserved_kind_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, nullptr, \
+                                                                    Mk, Bk, nullptr, Bt, N, Ncap, n, m, kind, stream);   \
             if (rq != BCBF_OK) return rq;                                                                                \
         }                                                                                                                \
-        const int rc = bcbf_posterior_query_reserved_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, nullptr,       \
-                                                           Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, stream);          \
+        const int rc = bcbf_posterior_query_reserved_kind_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, nullptr,  \
+                                                                Mk_work, Bk_work, Wwork, Bt, N, Ncap, n, m, kind, stream); \
         if (rc != BCBF_OK) return rc;                                                                                    \
         return bcbf::launch_gp_append_inplace<T>(Lop_r, Vw_r, X_r, UHB_r, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
                                                  Wwork, info, Bt, N, Ncap, n, m, stream, 1, nullptr, nullptr, nullptr,   \
@@ -837,6 +864,19 @@ int bcbf_chol_append_f64(const double* Lop_in, const double* knew, const double*
         T* const raw[3] = {rawUH, rawY, rawJ};                                                                           \
         return gp_append_reserved_impl_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
                                              info, Wwork, Mk_work, Bk_work, xq, Mk, Bk, Bt, N, Ncap, n, m, stream, raw);  \
+    }                                                                                                                    \
+    /* ... with the opt-in data kernels (kernel_kind 0 RBF, 1 Matern-5/2, 2 RBF x Matern-5/2; a state built by the matching \
+       bcbf_refit_* and bcbf_gp_reserve); rawUH = rawY = rawJ = NULL: no raw store */                                    \
+    int bcbf_gp_append_reserved_kind_##SUF(T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,    \
+                                           const T* M0, const T* x_new, const T* uh_new, const T* xdot_new,              \
+                                           const T* jitter_new, int* info, T* Wwork, T* Mk_work, T* Bk_work,             \
+                                           const T* xq, T* Mk, T* Bk, T* rawUH, T* rawY, T* rawJ, int Bt, int N, int Ncap, \
+                                           int n, int m, int kernel_kind, void* stream) {                                \
+        if ((rawUH || rawY || rawJ) && !(rawUH && rawY && rawJ)) return BCBF_EINVAL;                                     \
+        T* const raw[3] = {rawUH, rawY, rawJ};                                                                           \
+        return gp_append_reserved_impl_##SUF(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_new, \
+                                             info, Wwork, Mk_work, Bk_work, xq, Mk, Bk, Bt, N, Ncap, n, m, stream,        \
+                                             rawUH ? raw : nullptr, kernel_kind);                                        \
     }
 BCBF_RESERVED_ENTRY(f32, float)
 BCBF_RESERVED_ENTRY(f64, double)

@@ -22,7 +22,7 @@ template <typename T>
 int launch_posterior_query_column_reserved(const T* Lop, const T* Vw, const T* X, const T* UHB, const T* ell, const T* s2,
                                            const T* Bm, const T* M0, const T* xq, const T* x_new, const T* uh_new, T* Mk, T* Bk,
                                            T* lvec, T* lsum, int Bt, int N, int Ncap, int n, int m, void* stream,
-                                           T* Wfull, int Lcap);   // posterior_step.hip
+                                           T* Wfull, int Lcap, int kind);   // posterior_step.hip
 
 constexpr int TT = 256;                 // threads per instance
 constexpr int TMAXT = 64;               // tail rows held in LDS
@@ -52,7 +52,7 @@ gp_tail_step_kernel(const T* __restrict__ W0, T* __restrict__ Rb, T* __restrict_
                     const T* __restrict__ uh_new, const T* __restrict__ xdot_new, const T* __restrict__ jitter_new,
                     const T* __restrict__ lsum, T* __restrict__ Mk, T* __restrict__ Bk, int* __restrict__ info,
                     T* __restrict__ rawUH, T* __restrict__ rawY, T* __restrict__ rawJ, int N0, int Np0, int t, int tcap, int ldR,
-                    int Ncap, int n, int do_append) {
+                    int Ncap, int n, int do_append, int kind) {
     // Everything small is staged in LDS with coalesced loads up front (the first form read Rinv / Vw / X rows from global memory
     // inside its short loops: a chain of exposed load latencies, 158 us per launch at 4096 x 472 + <= 40 where the bytes take 30)
     constexpr int CTM = BCBF_MAX_CTRL_DIM + 2, NSM = 4, C = CT - 1;        // NSM: the entry point takes n <= 4 (gp_tail_step below)
@@ -160,7 +160,13 @@ gp_tail_step_kernel(const T* __restrict__ W0, T* __restrict__ Rb, T* __restrict_
             e2 += z2 * z2;
         }
         const T s2 = s_sc[0];
-        const T k1 = s2 * tail_exp<T>(T(-0.5) * e1), k2 = s2 * tail_exp<T>(T(-0.5) * e2);
+        T k1, k2, dsh_;
+        if (kind != 0) {                                   // opt-in data kernels (bcbf_common.h), as the streaming pass in front
+            kernel_shape(kind, e1, [](T q_) { return tail_exp<T>(q_); }, k1, dsh_);
+            kernel_shape(kind, e2, [](T q_) { return tail_exp<T>(q_); }, k2, dsh_);
+            k1 *= s2;
+            k2 *= s2;
+        } else { k1 = s2 * tail_exp<T>(T(-0.5) * e1); k2 = s2 * tail_exp<T>(T(-0.5) * e2); }
         const int G = t <= 16 ? 4 : t <= 32 ? 2 : 1, R = 64 / G;
         for (int c = 0; c < CT; ++c) {
             T sub = T(0);
@@ -255,8 +261,9 @@ template <typename T>
 static int gp_tail_step(const T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm, const T* M0,
                         const T* xq, const T* x_new, const T* uh_new, const T* xdot_new, const T* jitter_new, T* Rb, T* Rinv,
                         int* info, T* Wwork, T* swork, T* Mk, T* Bk, T* rawUH, T* rawY, T* rawJ, int Bt, int N0, int t,
-                        int tcap, int Ncap, int Lcap, int n, int m, int do_append, void* stream) {
+                        int tcap, int Ncap, int Lcap, int n, int m, int do_append, void* stream, int kind = 0) {
     if (Bt <= 0) return BCBF_OK;
+    if (kind < 0 || kind >= BCBF_KINDS) return BCBF_EINVAL;
     if (!Lop_r || !Vw_r || !X_r || !UHB_r || !ell || !s2 || !Bm || !M0 || !xq || !x_new || !uh_new || !Rb || !Rinv || !Wwork ||
         !swork || !Mk || !Bk)
         return BCBF_EINVAL;
@@ -268,17 +275,16 @@ static int gp_tail_step(const T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell,
     const size_t smem = ((size_t)Np0 * CT + (size_t)tcap * tcap) * sizeof(T);
     // the window's W0 [Np0 x CT] and the tail's inverse [tcap x tcap] live in LDS beside ~14 KB (fp64) of static arrays: gfx950 gives a
     // workgroup 160 KB.  What bounds the window in practice is the streaming pass in front (posterior_step.hip: its solved columns
-    // stay in LDS, Np0 (m + 2) sizeof(T) <= 100 KB, and its workgroup covers Np0 <= 2048): N0 <= 2048 in both precisions (bcbf.h).  The tail rows are evaluated with the RBF kernel only (tail_exp): ReservedGP has no
-    // data-kernel option.
+    // stay in LDS, Np0 (m + 2) sizeof(T) <= 100 KB, and its workgroup covers Np0 <= 2048): N0 <= 2048 in both precisions (bcbf.h).
     if (smem > 120 * 1024) return BCBF_EINVAL;
     const int rc = launch_posterior_query_column_reserved<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new, uh_new, Mk, Bk,
-                                                             (T*)nullptr, swork, Bt, N0, Ncap, n, m, stream, Wwork, Lcap);
+                                                             (T*)nullptr, swork, Bt, N0, Ncap, n, m, stream, Wwork, Lcap, kind);
     if (rc != BCBF_OK) return rc;
 #define BCBF_TAIL_LAUNCH(CTV)                                                                                                      \
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)gp_tail_step_kernel<T, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL((gp_tail_step_kernel<T, CTV>), dim3(Bt), dim3(TT), smem, (hipStream_t)stream, Wwork, Rb, Rinv, X_r, UHB_r,     \
                        Vw_r, ell, s2, Bm, M0, xq, x_new, uh_new, xdot_new, jitter_new, swork, Mk, Bk, info, rawUH, rawY, rawJ, N0,   \
-                       Np0, t, tcap, round_up(Ncap, NB), Ncap, n, do_append)
+                       Np0, t, tcap, round_up(Ncap, NB), Ncap, n, do_append, kind)
     switch (m) {
         case 1: BCBF_TAIL_LAUNCH(3); break;
         case 2: BCBF_TAIL_LAUNCH(4); break;
@@ -345,6 +351,17 @@ extern "C" {
         return bcbf::gp_tail_step<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new, uh_new, xdot_new, jitter_new, Rb,    \
                                      Rinv, info, Wwork, swork, Mk, Bk, rawUH, rawY, rawJ, Bt, N0, t, tcap, Ncap, Lcap, n, m,   \
                                      do_append, stream);                                                                     \
+    }                                                                                                                        \
+    /* ... with the opt-in data kernels: kernel_kind 0 RBF, 1 Matern-5/2, 2 RBF x Matern-5/2 (the window's factor from the      \
+       matching bcbf_refit_*; the tail rows and the new point's row are evaluated with the same kernel) */                    \
+    int bcbf_gp_tail_step_kind_##SUF(const T* Lop_r, T* Vw_r, T* X_r, T* UHB_r, const T* ell, const T* s2, const T* Bm,        \
+                                     const T* M0, const T* xq, const T* x_new, const T* uh_new, const T* xdot_new,           \
+                                     const T* jitter_new, T* Rb, T* Rinv, int* info, T* Wwork, T* swork, T* Mk, T* Bk,        \
+                                     T* rawUH, T* rawY, T* rawJ, int Bt, int N0, int t, int tcap, int Ncap, int Lcap, int n,  \
+                                     int m, int do_append, int kernel_kind, void* stream) {                                  \
+        return bcbf::gp_tail_step<T>(Lop_r, Vw_r, X_r, UHB_r, ell, s2, Bm, M0, xq, x_new, uh_new, xdot_new, jitter_new, Rb,    \
+                                     Rinv, info, Wwork, swork, Mk, Bk, rawUH, rawY, rawJ, Bt, N0, t, tcap, Ncap, Lcap, n, m,   \
+                                     do_append, stream, kernel_kind);                                                        \
     }
 BCBF_TAIL_ENTRY(f32, float)
 BCBF_TAIL_ENTRY(f64, double)

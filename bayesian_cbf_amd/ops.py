@@ -243,6 +243,15 @@ def gp_append(Lop, Vw, X, UHB, ell, s2, Bm, M0, x_new, uh_new, xdot_new, jitter_
     Lout = Lop if same_pad else torch.empty(Bt, lop_elems(N + 1, X.dtype), **f)
     Vw2, X2, UHB2 = torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, n, **f), torch.empty(Bt, N + 1, C, **f)
     info = torch.empty(Bt, dtype=torch.int32, device=X.device)
+    if kernel != "rbf" and N >= GP_APPEND_STREAM_MIN_N:  # opt-in kernels, large N: the forward solve on that kind's streaming kernel
+        _kern("bcbf_gp_append", kernel)
+        Np = (N + 31) // 32 * 32
+        Ww, Mkw, Bkw = torch.empty(Bt, Np, C, **f), torch.empty(Bt, n, C, **f), torch.empty(Bt, C, C, **f)
+        check(getattr(lib, "bcbf_gp_append_stream_kind" + _suf(X))(
+            _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(x_new), _p(uh_new), _p(xdot_new),
+            _p(jitter_new), _p(Lout), _p(Vw2), _p(X2), _p(UHB2), _p(info), _p(Ww), _p(Mkw), _p(Bkw), Bt, N, n, C - 1,
+            DATA_KERNELS.index(kernel), _stream(X)), "bcbf_gp_append_stream_kind")
+        return Lout, Vw2, X2, UHB2, info
     if kernel != "rbf":                                # opt-in kernels: the simple forward solve
         check(getattr(lib, _kern("bcbf_gp_append", kernel) + _suf(X))(
             _p(Lop), _p(Vw), _p(X), _p(UHB), _p(ell), _p(s2), _p(Bm), _p(M0), _p(x_new), _p(uh_new), _p(xdot_new),
@@ -295,8 +304,10 @@ class ReservedGP:
     TAIL_MAX = 64            # tail rows the tail step holds (bcbf_gp_tail_step: tcap <= 64)
 
     def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None,
-                 drop=None, tail=False, retry_levels=None, factor_dtype=None, min_jitter_level=1e-5):
-        """factor_dtype (retry_levels mode; e.g. float64 for an fp32 model): the window refits factor in that precision and ROUND the
+                 drop=None, tail=False, retry_levels=None, factor_dtype=None, min_jitter_level=1e-5, kernel="rbf"):
+        """kernel: the data kernel of the state ("rbf"; opt-in "matern52", "rbf_matern52": the `*_kind` entry points of bcbf.h --
+        queries, appends, the tail step and the window refits evaluate it; not with retry_levels, whose retry launches are RBF).
+        factor_dtype (retry_levels mode; e.g. float64 for an fp32 model): the window refits factor in that precision and ROUND the
         operator / UH B / Vw into the buffers the passes read (the packed layout is the same element for element) -- the passes then
         add cond(L) eps, not cond(K_b) eps.  min_jitter_level: floor of the per-instance level (fp32 passes cannot resolve a posterior
         variance below ~ sqrt(cond K_b) eps32 of the prior: 1e-3 for fp32 passes on fp64 factors).
@@ -305,6 +316,10 @@ class ReservedGP:
         is swapped in (no allocation per drop).  `drop_info` then holds the last level's info; `drop_failures` is counted only
         when asked for (`count_drop_failures()`: one host read).  None: ten levels with a look at the device per level."""
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
+        _kern("", kernel)
+        self.kernel, self._kind = kernel, DATA_KERNELS.index(kernel)
+        if self._kind != 0 and retry_levels is not None:
+            raise NotImplementedError("kernel=%r with retry_levels: bcbf_refit_retry evaluates the RBF kernel only" % kernel)
         self.retry_levels = retry_levels
         self.factor_dtype = factor_dtype if (factor_dtype is not None and factor_dtype != X.dtype) else None
         self.min_jitter_level = float(min_jitter_level)
@@ -453,7 +468,7 @@ class ReservedGP:
                     self._alt = None
         else:
             for ntry in range(max_tries):
-                Lop, UHB, info, _ = refit(X, UH, self.Bm, self.ell, self.s2, J)
+                Lop, UHB, info, _ = refit(X, UH, self.Bm, self.ell, self.s2, J, kernel=self.kernel)
                 bad = info != 0
                 if not bool(bad.any()):                   # (one host round trip per drop: ~30 us against the refit's milliseconds;
                     break                                 #  speculative jitter levels would cost two more refits per drop instead)
@@ -490,12 +505,13 @@ class ReservedGP:
         #  thousands of times and the host side of it is what bounds four part batches)
         st = self.__dict__.get("_tail_static")
         if st is None or st[0] is not self.Lop:
-            st = self._tail_static = (self.Lop, getattr(lib, "bcbf_gp_tail_step" + _suf(self.X)),
+            st = self._tail_static = (self.Lop, getattr(lib, ("bcbf_gp_tail_step_kind" if self._kind else "bcbf_gp_tail_step") + _suf(self.X)),
                                       (_p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0)),
                                       (_p(self._Rb), _p(self._Rinv), _p(self.info), _p(self._Wfull), _p(self._sw)),
                                       (_p(self._rUH), _p(self._rY), _p(self._rJ)))
         check(st[1](*st[2], _p(xq), _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), *st[3], _p(Mk), _p(Bk), *st[4], self.Bt,
-                    self.N0, self.t, self._tcap, self.capacity, self._Lcap, self.n, self.C - 1, int(do_append), _stream(self.X)),
+                    self.N0, self.t, self._tcap, self.capacity, self._Lcap, self.n, self.C - 1, int(do_append),
+                    *((self._kind,) if self._kind else ()), _stream(self.X)),
               "bcbf_gp_tail_step")
 
     def posterior(self, xq, jitter2=None, want_W=False, out=None):
@@ -512,9 +528,10 @@ class ReservedGP:
             self._tail_step(xq, xq, self._ones, None, None, Mk, Bk, False)
             return Mk, Bk
         W = torch.empty(self.Bt, (self.N + 31) // 32 * 32, self.C, **f) if want_W else None
-        check(getattr(lib, "bcbf_posterior_query_reserved" + _suf(self.X))(
+        check(getattr(lib, ("bcbf_posterior_query_reserved_kind" if self._kind else "bcbf_posterior_query_reserved") + _suf(self.X))(
             _p(self.Lop), _p(self.Vw), _p(self.X), _p(self.UHB), _p(self.ell), _p(self.s2), _p(self.Bm), _p(self.M0), _p(xq),
-            _p(jitter2), _p(Mk), _p(Bk), _p(W), self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X)),
+            _p(jitter2), _p(Mk), _p(Bk), _p(W), self.Bt, self.N, self.capacity, self.n, self.C - 1,
+            *((self._kind,) if self._kind else ()), _stream(self.X)),
             "bcbf_posterior_query_reserved")
         return (Mk, Bk, W) if want_W else (Mk, Bk)
 
@@ -557,7 +574,11 @@ class ReservedGP:
                 _p(x_new), _p(uh_new), _p(xdot_new), _p(jitter_new), _p(self.info), _p(self._Ww), _p(self._Mkw), _p(self._Bkw),
                 _p(query), _p(Mk), _p(Bk))
         tail = (self.Bt, self.N, self.capacity, self.n, self.C - 1, _stream(self.X))
-        if self.window is not None:
+        if self._kind:
+            raw = (_p(self._rUH), _p(self._rY), _p(self._rJ)) if self.window is not None else (None, None, None)
+            check(getattr(lib, "bcbf_gp_append_reserved_kind" + _suf(self.X))(*head, *raw, *tail[:-1], self._kind, tail[-1]),
+                  "bcbf_gp_append_reserved_kind")
+        elif self.window is not None:
             # window mode: the same launches also record the point's RAW row (uh, xdot, jitter) -- neutral (0, 0, unit pivot)
             # where the new pivot failed, which is what the in-place path holds -- for the next refit of the window
             check(getattr(lib, "bcbf_gp_append_reserved_raw" + _suf(self.X))(*head, _p(self._rUH), _p(self._rY), _p(self._rJ), *tail),

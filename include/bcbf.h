@@ -338,6 +338,59 @@ int bcbf_gp_tail_step_f64(const double* Lop_r, double* Vw_r, double* X_r, double
 int bcbf_gp_tail_commit_f32(float* Lop_r, const float* Rb, const float* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream);
 int bcbf_gp_tail_commit_f64(double* Lop_r, const double* Rb, const double* Rinv, int Bt, int N0, int t, int tcap, int Ncap, void* stream);
 
+/* The online entry points above with the OPT-IN data kernels (no reference counterpart: the reference has no Matern kernel;
+ * BASELINE.json:north_star names an "RBF x Matern" kernel build): kernel_kind 0 = RBF (identical to the plain entry points),
+ * 1 = Matern-5/2, 2 = RBF x Matern-5/2 (bcbf_refit_matern52 / bcbf_refit_rbfm52 build the state).  Same arguments, argument
+ * checks, layouts and limits as their namesakes; BCBF_EINVAL for another kind.
+ *   bcbf_gp_append_stream_kind      bcbf_gp_append_stream: the forward solve W = L^-1 Phi(x_new) on that kind's streaming kernel;
+ *   bcbf_posterior_query_reserved_kind, bcbf_gp_append_reserved_kind (rawUH = rawY = rawJ = NULL: bcbf_gp_append_reserved,
+ *                                   else bcbf_gp_append_reserved_raw): the ride-along query, the append's own column and the
+ *                                   fallback passes all evaluate the kind;
+ *   bcbf_gp_tail_step_kind          bcbf_gp_tail_step: the streaming pass in front, the tail rows k(x_p, xq), k(x_p, x_new).
+ * bcbf_gp_reserve, bcbf_gp_tail_commit and bcbf_chol_append do not evaluate the data kernel. */
+int bcbf_gp_append_stream_kind_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
+                                   const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
+                                   const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,
+                                   float* Vw_out, float* X_out, float* UHB_out, int* info, float* Wwork, float* Mk_work,
+                                   float* Bk_work, int Bt, int N, int n, int m, int kernel_kind, void* stream);
+int bcbf_gp_append_stream_kind_f64(const double* Lop_in, const double* Vw_in, const double* X_in, const double* UHB_in,
+                                   const double* ell, const double* s2, const double* Bm, const double* M0,
+                                   const double* x_new, const double* uh_new, const double* xdot_new,
+                                   const double* jitter_new, double* Lop_out, double* Vw_out, double* X_out, double* UHB_out,
+                                   int* info, double* Wwork, double* Mk_work, double* Bk_work, int Bt, int N, int n, int m,
+                                   int kernel_kind, void* stream);
+int bcbf_posterior_query_reserved_kind_f32(const float* Lop_r, const float* Vw_r, const float* X_r, const float* UHB_r,
+                                           const float* ell, const float* s2, const float* Bm, const float* M0,
+                                           const float* xq, const float* jitter2, float* Mk, float* Bk, float* W, int Bt,
+                                           int N, int Ncap, int n, int m, int kernel_kind, void* stream);
+int bcbf_posterior_query_reserved_kind_f64(const double* Lop_r, const double* Vw_r, const double* X_r, const double* UHB_r,
+                                           const double* ell, const double* s2, const double* Bm, const double* M0,
+                                           const double* xq, const double* jitter2, double* Mk, double* Bk, double* W, int Bt,
+                                           int N, int Ncap, int n, int m, int kernel_kind, void* stream);
+int bcbf_gp_append_reserved_kind_f32(float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
+                                     const float* Bm, const float* M0, const float* x_new, const float* uh_new,
+                                     const float* xdot_new, const float* jitter_new, int* info, float* Wwork, float* Mk_work,
+                                     float* Bk_work, const float* xq, float* Mk, float* Bk, float* rawUH, float* rawY,
+                                     float* rawJ, int Bt, int N, int Ncap, int n, int m, int kernel_kind, void* stream);
+int bcbf_gp_append_reserved_kind_f64(double* Lop_r, double* Vw_r, double* X_r, double* UHB_r, const double* ell,
+                                     const double* s2, const double* Bm, const double* M0, const double* x_new,
+                                     const double* uh_new, const double* xdot_new, const double* jitter_new, int* info,
+                                     double* Wwork, double* Mk_work, double* Bk_work, const double* xq, double* Mk, double* Bk,
+                                     double* rawUH, double* rawY, double* rawJ, int Bt, int N, int Ncap, int n, int m,
+                                     int kernel_kind, void* stream);
+int bcbf_gp_tail_step_kind_f32(const float* Lop_r, float* Vw_r, float* X_r, float* UHB_r, const float* ell, const float* s2,
+                               const float* Bm, const float* M0, const float* xq, const float* x_new, const float* uh_new,
+                               const float* xdot_new, const float* jitter_new, float* Rb, float* Rinv, int* info,
+                               float* Wwork, float* swork, float* Mk, float* Bk, float* rawUH, float* rawY, float* rawJ, int Bt,
+                               int N0, int t, int tcap, int Ncap, int Lcap, int n, int m, int do_append, int kernel_kind,
+                               void* stream);
+int bcbf_gp_tail_step_kind_f64(const double* Lop_r, double* Vw_r, double* X_r, double* UHB_r, const double* ell,
+                               const double* s2, const double* Bm, const double* M0, const double* xq, const double* x_new,
+                               const double* uh_new, const double* xdot_new, const double* jitter_new, double* Rb,
+                               double* Rinv, int* info, double* Wwork, double* swork, double* Mk, double* Bk, double* rawUH,
+                               double* rawY, double* rawJ, int Bt, int N0, int t, int tcap, int Ncap, int Lcap, int n, int m,
+                               int do_append, int kernel_kind, void* stream);
+
 /* Dense K_b^-1 [Bt,N,N] from the packed factor (fit path): the potrs solve on identity columns, one workgroup per
  * 8 columns. */
 int bcbf_potri_f32(const float* Lop, float* Kinv, int Bt, int N, void* stream);

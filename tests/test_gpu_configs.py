@@ -1053,3 +1053,105 @@ def test_window_refit_host_free_and_in_mixed_precision(ops):
     assert g_mix.Lop.dtype == torch.float32 and int(g_mix.retry_counts[0]) == 2 * Bt and int(g_mix.retry_counts[1:].sum()) == 0
     with pytest.raises(ValueError):
         mk(factor_dtype=torch.float64)                                   # mixed precision needs the host-free refit
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("kernel", ["matern52", "rbf_matern52"])
+def test_opt_in_data_kernels_on_the_online_entry_points_vs_oracle(ops, kernel, dtype):
+    """The online entry points with `kernel_kind` (bcbf_gp_append_reserved_kind, bcbf_posterior_query_reserved_kind,
+    bcbf_gp_tail_step_kind, bcbf_gp_append_stream_kind; `ops.ReservedGP(kernel=...)`, `ops.gp_append(kernel=...)`): in place, with
+    the row-major tail + block commit, with a sliding window (whose refits evaluate the kernel too) and on the streaming append.
+    No reference counterpart (the reference has no Matern kernel): the oracle is the definition -- Cholesky of the kernel matrix of
+    the points held (oracle/gp_posterior.py: kb_matrix(kernel=...), itself checked against scikit-learn's Matern) -- and the two
+    device forms are compared with each other at every step."""
+    import scipy.linalg as sla
+    from bayesian_cbf_amd.synthetic import make_instances
+    from bayesian_cbf_amd._lib import BcbfError
+    Bt, n, m, N0, steps = 3, 3, 2, 64, 40
+    p = make_instances(Bt, N0 + steps + 1, n, m, dtype=dtype, device=DEV, seed=31)
+    cut = lambda t, N: t[:, :N].contiguous()
+    h = {k: host(v) for k, v in p.items()}
+    tol = 2e-3 if dtype == torch.float32 else 1e-8
+
+    def oracle_posterior(i, rows, xq):
+        X, UH, Xd, J = h["X"][i, rows], h["UH"][i, rows], h["Xdot"][i, rows], h["jitter"][i, rows]
+        K = ogp.kb_matrix(X, UH, h["Bm"][i], h["ell"][i], h["s2"][i], kernel=kernel) + np.diag(J)
+        L = np.linalg.cholesky(K)
+        Y = Xd - UH @ h["M0"][i]
+        Phi = ogp.DATA_KERNELS[kernel](X, xq[None], h["ell"][i], h["s2"][i])[:, :1] * (UH @ h["Bm"][i])
+        W = sla.solve_triangular(L, Phi, lower=True)
+        alpha = sla.cho_solve((L, True), Y)
+        return h["M0"][i].T + alpha.T @ Phi, h["s2"][i] * h["Bm"][i] - W.T @ W
+
+    def check(Mk, Bk, rows, xq, what):
+        for i in (0, Bt - 1):
+            Mo, Bo = oracle_posterior(i, rows, host(xq)[i])
+            rel_close(host(Mk)[i], Mo, tol, scale=max(1.0, np.abs(Mo).max()), what="Mk " + what)
+            rel_close(host(Bk)[i], Bo, tol, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk " + what)
+
+    Lop, UHB, info, _ = ops.refit(cut(p["X"], N0), cut(p["UH"], N0), p["Bm"], p["ell"], p["s2"], cut(p["jitter"], N0), kernel=kernel)
+    assert (info == 0).all()
+    Vw, _ = ops.potrs(Lop, cut(p["Xdot"], N0), cut(p["UH"], N0), p["M0"], want_alpha=False)
+    mk = lambda **kw: ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N0 + steps + 8, kernel=kernel, **kw)
+    gi, gt, gp = mk(), mk(tail=True), mk()
+    prior = float((p["s2"][:, None, None] * p["Bm"]).abs().max())
+    new = lambda N: tuple(p[k][:, N].contiguous() for k in ("X", "UH", "Xdot", "jitter"))
+    for t in range(steps):
+        N = N0 + t
+        xq = (p["xq"] + 0.01 * t).contiguous()
+        ii, Mi, Bi = gi.append(*new(N), query=xq)                    # the fused pass: query + the append's column
+        it, Mt, Bt_ = gt.append(*new(N), query=xq)                   # tail rows; commit at t = 31
+        assert (ii == 0).all() and (it == 0).all()
+        rel_close(host(Mt), host(Mi), tol, scale=max(1.0, float(Mi.abs().max())), what="Mk tail vs in place (%s)" % kernel)
+        rel_close(host(Bt_), host(Bi), tol, scale=prior, what="Bk tail vs in place (%s)" % kernel)
+        if t in (0, 31, 32, steps - 1):
+            check(Mi, Bi, slice(0, N), xq, "in place, step %d" % t)
+            check(Mt, Bt_, slice(0, N), xq, "tail, step %d" % t)
+        if t < 3:
+            assert (gp.append(*new(N)) == 0).all()                   # without a query: the plain forward pass
+    Mq, Bq = gp.posterior(p["xq"])
+    check(Mq, Bq, slice(0, N0 + 3), p["xq"], "append without a query, then posterior()")
+    Mq, Bq = gt.posterior(p["xq"])
+    check(Mq, Bq, slice(0, N0 + steps), p["xq"], "posterior() on committed blocks + tail")
+    # kernel_kind = 0 through the same entry point is the plain one, bit for bit; another kind is refused
+    g0 = ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], N0 + 8)      # (an RBF query on these arrays: any numbers do)
+    M0_, B0_ = g0.posterior(p["xq"])
+    M1_, B1_ = torch.empty_like(M0_), torch.empty_like(B0_)
+    from bayesian_cbf_amd.ops import _p, _suf, _stream
+    lib = ops.lib
+    fn = getattr(lib, "bcbf_posterior_query_reserved_kind" + _suf(g0.X))
+    args = lambda kind: (_p(g0.Lop), _p(g0.Vw), _p(g0.X), _p(g0.UHB), _p(g0.ell), _p(g0.s2), _p(g0.Bm), _p(g0.M0), _p(p["xq"]), None,
+                         _p(M1_), _p(B1_), None, Bt, g0.N, g0.capacity, n, m, kind, _stream(g0.X))
+    assert fn(*args(0)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(M0_, M1_) and torch.equal(B0_, B1_)
+    assert fn(*args(3)) != 0 and fn(*args(-1)) != 0
+    # sliding window: the drop's refit evaluates the kernel as well
+    W, D = 64, 8
+    gw = ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D, kernel=kernel,
+                        UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    for t in range(D + 2):
+        info = gw.append(*new(N0 + t))
+        assert (info == 0).all()
+    assert gw.drops == 1 and gw.N == W + 2
+    Mq, Bq = gw.posterior(p["xq"])
+    check(Mq, Bq, slice(D, N0 + D + 2), p["xq"], "window after a drop")
+    with pytest.raises(NotImplementedError):
+        mk(window=W, drop=D, retry_levels=2, UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    # the streaming append (N >= 384): the forward solve on that kind's streaming kernel
+    Ns = ops.GP_APPEND_STREAM_MIN_N
+    q = make_instances(2, Ns + 1, n, m, dtype=dtype, device=DEV, seed=32)
+    hq = {k: host(v) for k, v in q.items()}
+    Ls, Us, inf, _ = ops.refit(cut(q["X"], Ns), cut(q["UH"], Ns), q["Bm"], q["ell"], q["s2"], cut(q["jitter"], Ns), kernel=kernel)
+    assert (inf == 0).all()
+    Vs, _ = ops.potrs(Ls, cut(q["Xdot"], Ns), cut(q["UH"], Ns), q["M0"], want_alpha=False)
+    L2, V2, X2, U2, inf2 = ops.gp_append(Ls, Vs, cut(q["X"], Ns), Us, q["ell"], q["s2"], q["Bm"], q["M0"], q["X"][:, Ns].contiguous(),
+                                         q["UH"][:, Ns].contiguous(), q["Xdot"][:, Ns].contiguous(), q["jitter"][:, Ns].contiguous(), kernel=kernel)
+    assert (inf2 == 0).all() and X2.shape[1] == Ns + 1
+    Ms, Bs = ops.posterior_query(L2, V2, X2, U2, q["ell"], q["s2"], q["Bm"], q["M0"], q["xq"], shared=False, kernel=kernel)[:2]
+    Lf, Uf, inf, _ = ops.refit(q["X"], q["UH"], q["Bm"], q["ell"], q["s2"], q["jitter"], kernel=kernel)
+    Vf, _ = ops.potrs(Lf, q["Xdot"], q["UH"], q["M0"], want_alpha=False)
+    Mf, Bf = ops.posterior_query(Lf, Vf, q["X"], Uf, q["ell"], q["s2"], q["Bm"], q["M0"], q["xq"], shared=False, kernel=kernel)[:2]
+    tol_s = 5e-3 if dtype == torch.float32 else 1e-7
+    rel_close(host(Ms), host(Mf), tol_s, scale=max(1.0, float(Mf.abs().max())), what="Mk streaming append vs refit (%s)" % kernel)
+    rel_close(host(Bs), host(Bf), tol_s, scale=float((q["s2"][:, None, None] * q["Bm"]).abs().max()), what="Bk streaming append vs refit (%s)" % kernel)
