@@ -41,6 +41,7 @@ _TSIGS = {
     "bcbf_posterior_query_rbfm52": [P] * 13 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_refit": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_refit_retry": [P] * 10 + [c_int, c_int, c_int, c_int, P],
+    "bcbf_refit_retry_kind": [P] * 10 + [c_int, c_int, c_int, c_int, c_int, P],
     "bcbf_gram": [P, P, P, c_int, c_int, c_int, c_int, P],
     "bcbf_predict_fullmat": [P] * 17 + [c_int] * 5 + [P],
     "bcbf_unicycle_control_step_observe": [P] * 13 + ["T"] + [P] * 4 + ["T"] + [P] * 16 + ["T", "T", c_int, c_int, c_int, c_int, c_int,

@@ -2202,6 +2202,32 @@ BCBF_REFIT_MATERN(f64, double, bcbf_refit_matern52_, 1)
 BCBF_REFIT_MATERN(f32, float, bcbf_refit_rbfm52_, 2)          // the product kernel RBF x Matern-5/2
 BCBF_REFIT_MATERN(f64, double, bcbf_refit_rbfm52_, 2)
 #undef BCBF_REFIT_MATERN
+// bcbf_refit_retry (refit.hip) for a state of any data kernel: kernel_kind 0 = RBF (bcbf_refit_retry itself), 1 = Matern-5/2,
+// 2 = RBF x Matern-5/2 -- only the instances with prev_info[b] != 0 are factored again, the others report 0
+extern "C" int bcbf_refit_mfma_f32(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                                   float*, float*, float*, int*, int, int, int, int, void*);
+extern "C" int bcbf_refit_mfma_f64(const double*, const double*, const double*, const double*, const double*, const double*,
+                                   const double*, double*, double*, double*, int*, int, int, int, int, void*);
+#define BCBF_REFIT_RETRY_KIND(SUF, T)                                                                                        \
+    extern "C" int bcbf_refit_retry_kind_##SUF(const T* X, const T* UH, const T* Bm, const T* ell, const T* s2,               \
+                                               const T* jitter, T* Lop, T* UHB, const int* prev_info, int* info, int Bt,      \
+                                               int N, int n, int m, int kernel_kind, void* stream) {                         \
+        if (Bt <= 0) return BCBF_OK;                                                                                         \
+        if (!X || !UH || !Bm || !ell || !s2 || !UHB || !prev_info || prev_info == info) return BCBF_EINVAL;                  \
+        if (kernel_kind < 0 || kernel_kind >= bcbf::BCBF_KINDS) return BCBF_EINVAL;                                          \
+        bcbf::g_refit_only_bad = prev_info;                                                                                  \
+        const int rc = kernel_kind == 0 ? bcbf_refit_mfma_##SUF(X, UH, Bm, ell, s2, jitter, nullptr, Lop, UHB, nullptr, info, \
+                                                                Bt, N, n, m, stream)                                         \
+                     : kernel_kind == 1 ? bcbf_refit_matern52_##SUF(X, UH, Bm, ell, s2, jitter, Lop, UHB, nullptr, info, Bt,  \
+                                                                    N, n, m, stream)                                         \
+                                        : bcbf_refit_rbfm52_##SUF(X, UH, Bm, ell, s2, jitter, Lop, UHB, nullptr, info, Bt, N, \
+                                                                  n, m, stream);                                             \
+        bcbf::g_refit_only_bad = nullptr;                                                                                    \
+        return rc;                                                                                                           \
+    }
+BCBF_REFIT_RETRY_KIND(f32, float)
+BCBF_REFIT_RETRY_KIND(f64, double)
+#undef BCBF_REFIT_RETRY_KIND
 namespace bcbf {
 int launch_refit_team32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
                         const float* jitter, const float* Kdense, float* Lop, float* UHB, float* Ldense, int* info, int Bt, int N,

@@ -124,17 +124,23 @@ def refit(X, UH, Bm, ell, s2, jitter=None, want_dense=False, out=None, kernel="r
     return Lop, UHB, info, Ld
 
 
-def refit_retry(X, UH, Bm, ell, s2, jitter, Lop, UHB, prev_info, info):
+def refit_retry(X, UH, Bm, ell, s2, jitter, Lop, UHB, prev_info, info, kernel="rbf"):
     """Factor again ONLY the instances with prev_info[b] != 0 (bcbf_refit_retry; no host round trip), with the jitter the
     caller has raised for them; writes `info` (a different buffer than prev_info)."""
     _chk(X, UH, Bm, ell, s2, jitter, Lop, UHB, prev_info, info)
     Bt, N, n = X.shape
+    if kernel != "rbf":
+        _kern("", kernel)
+        check(getattr(lib, "bcbf_refit_retry_kind" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
+                                                              _p(prev_info), _p(info), Bt, N, n, UH.shape[2] - 1,
+                                                              DATA_KERNELS.index(kernel), _stream(X)), "bcbf_refit_retry_kind")
+        return info
     check(getattr(lib, "bcbf_refit_retry" + _suf(X))(_p(X), _p(UH), _p(Bm), _p(ell), _p(s2), _p(jitter), _p(Lop), _p(UHB),
                                                      _p(prev_info), _p(info), Bt, N, n, UH.shape[2] - 1, _stream(X)), "bcbf_refit_retry")
     return info
 
 
-def refit_with_retries(X, UH, Bm, ell, s2, jitter, out, levels=3, scratch=None, level=None, counts=None):
+def refit_with_retries(X, UH, Bm, ell, s2, jitter, out, levels=3, scratch=None, level=None, counts=None, kernel="rbf"):
     """bcbf_refit followed by `levels` unconditional retry launches (x10 jitter on the instances that failed: make_psd's
     schedule, control_affine_model.py:903-919) -- nothing waits for the host.  out = (Lop, UHB, info); `jitter` is raised IN
     PLACE for the failed instances (it is the record of what every point was factored with), and so is `level[Bt]` (the
@@ -142,7 +148,7 @@ def refit_with_retries(X, UH, Bm, ell, s2, jitter, out, levels=3, scratch=None, 
     (optional, int64 on the device): += the instances each launch had to factor.  Returns info (0, or the pivot of an instance
     that failed every level)."""
     Lop, UHB, info = out
-    refit(X, UH, Bm, ell, s2, jitter, out=(Lop, UHB, info))
+    refit(X, UH, Bm, ell, s2, jitter, out=(Lop, UHB, info), kernel=kernel)
     if counts is not None:
         counts[0] += X.shape[0]
     other = torch.empty_like(info) if scratch is None else scratch
@@ -154,7 +160,7 @@ def refit_with_retries(X, UH, Bm, ell, s2, jitter, out, levels=3, scratch=None, 
             level.mul_(fac)
         if counts is not None:
             counts[k + 1] += (cur != 0).sum()
-        refit_retry(X, UH, Bm, ell, s2, jitter, Lop, UHB, cur, nxt)
+        refit_retry(X, UH, Bm, ell, s2, jitter, Lop, UHB, cur, nxt, kernel=kernel)
         cur, nxt = nxt, cur
     if cur is not info:
         info.copy_(cur)
@@ -306,7 +312,7 @@ class ReservedGP:
     def __init__(self, Lop, Vw, X, UHB, ell, s2, Bm, M0, capacity, A=None, window=None, UH=None, Xdot=None, jitter=None,
                  drop=None, tail=False, retry_levels=None, factor_dtype=None, min_jitter_level=1e-5, kernel="rbf"):
         """kernel: the data kernel of the state ("rbf"; opt-in "matern52", "rbf_matern52": the `*_kind` entry points of bcbf.h --
-        queries, appends, the tail step and the window refits evaluate it; not with retry_levels, whose retry launches are RBF).
+        queries, appends, the tail step and the window refits -- bcbf_refit_retry_kind with retry_levels -- evaluate it).
         factor_dtype (retry_levels mode; e.g. float64 for an fp32 model): the window refits factor in that precision and ROUND the
         operator / UH B / Vw into the buffers the passes read (the packed layout is the same element for element) -- the passes then
         add cond(L) eps, not cond(K_b) eps.  min_jitter_level: floor of the per-instance level (fp32 passes cannot resolve a posterior
@@ -318,8 +324,6 @@ class ReservedGP:
         _chk(Lop, Vw, X, UHB, ell, s2, Bm, M0)
         _kern("", kernel)
         self.kernel, self._kind = kernel, DATA_KERNELS.index(kernel)
-        if self._kind != 0 and retry_levels is not None:
-            raise NotImplementedError("kernel=%r with retry_levels: bcbf_refit_retry evaluates the RBF kernel only" % kernel)
         self.retry_levels = retry_levels
         self.factor_dtype = factor_dtype if (factor_dtype is not None and factor_dtype != X.dtype) else None
         self.min_jitter_level = float(min_jitter_level)
@@ -456,12 +460,12 @@ class ReservedGP:
                 up = lambda t_: t_.to(wd)
                 Xd, UHd, Yd, Jd, lvl = up(X), up(UH), up(Y), up(J), up(self.jitter_level)
                 refit_with_retries(Xd, UHd, up(self.Bm), up(self.ell), up(self.s2), Jd, (self._wide[0], self._wide[1], info),
-                                   levels=self.retry_levels, scratch=scratch, level=lvl, counts=self.retry_counts)
+                                   levels=self.retry_levels, scratch=scratch, level=lvl, counts=self.retry_counts, kernel=self.kernel)
                 Vw_wide, _ = potrs(self._wide[0], Yd, UHd, up(self.M0), want_alpha=False)
                 Lop.copy_(self._wide[0]); UHB.copy_(self._wide[1]); J.copy_(Jd); self.jitter_level.copy_(lvl)
             else:
                 refit_with_retries(X, UH, self.Bm, self.ell, self.s2, J, (Lop, UHB, info), levels=self.retry_levels, scratch=scratch,
-                                   level=self.jitter_level, counts=self.retry_counts)
+                                   level=self.jitter_level, counts=self.retry_counts, kernel=self.kernel)
             if self.tail:
                 self._alt = (self.Lop if self.Lop.shape == Lop.shape else None, UHB, info, scratch)    # the buffer now read is the next drop's target
                 if self._alt[0] is None:

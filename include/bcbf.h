@@ -120,6 +120,14 @@ int bcbf_refit_retry_f32(const float* X, const float* UH, const float* Bm, const
 int bcbf_refit_retry_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
                          const double* jitter, double* Lop, double* UHB, const int* prev_info, int* info,
                          int Bt, int N, int n, int m, void* stream);
+/* ... for a state of any data kernel (kernel_kind 0 = RBF: bcbf_refit_retry itself; 1 = Matern-5/2, 2 = RBF x Matern-5/2: the
+ * retry of bcbf_refit_matern52 / bcbf_refit_rbfm52; opt-in, no reference counterpart) */
+int bcbf_refit_retry_kind_f32(const float* X, const float* UH, const float* Bm, const float* ell, const float* s2,
+                              const float* jitter, float* Lop, float* UHB, const int* prev_info, int* info,
+                              int Bt, int N, int n, int m, int kernel_kind, void* stream);
+int bcbf_refit_retry_kind_f64(const double* X, const double* UH, const double* Bm, const double* ell, const double* s2,
+                              const double* jitter, double* Lop, double* UHB, const int* prev_info, int* info,
+                              int Bt, int N, int n, int m, int kernel_kind, void* stream);
 
 /* K2 on a caller-supplied dense SPD matrix (lower triangle of Kb[Bt,N,N] is read): same outputs.
  * Replaces torch.linalg.cholesky (control_affine_model.py:911). */
@@ -347,7 +355,8 @@ int bcbf_gp_tail_commit_f64(double* Lop_r, const double* Rb, const double* Rinv,
  *                                   else bcbf_gp_append_reserved_raw): the ride-along query, the append's own column and the
  *                                   fallback passes all evaluate the kind;
  *   bcbf_gp_tail_step_kind          bcbf_gp_tail_step: the streaming pass in front, the tail rows k(x_p, xq), k(x_p, x_new).
- * bcbf_gp_reserve, bcbf_gp_tail_commit and bcbf_chol_append do not evaluate the data kernel. */
+ * bcbf_gp_reserve, bcbf_gp_tail_commit and bcbf_chol_append do not evaluate the data kernel; a window's host-free refit:
+ * bcbf_refit_matern52 / bcbf_refit_rbfm52 + bcbf_refit_retry_kind. */
 int bcbf_gp_append_stream_kind_f32(const float* Lop_in, const float* Vw_in, const float* X_in, const float* UHB_in,
                                    const float* ell, const float* s2, const float* Bm, const float* M0, const float* x_new,
                                    const float* uh_new, const float* xdot_new, const float* jitter_new, float* Lop_out,

@@ -1073,8 +1073,9 @@ def test_opt_in_data_kernels_on_the_online_entry_points_vs_oracle(ops, kernel, d
     h = {k: host(v) for k, v in p.items()}
     tol = 2e-3 if dtype == torch.float32 else 1e-8
 
-    def oracle_posterior(i, rows, xq):
-        X, UH, Xd, J = h["X"][i, rows], h["UH"][i, rows], h["Xdot"][i, rows], h["jitter"][i, rows]
+    def oracle_posterior(i, rows, xq, J=None):
+        X, UH, Xd = h["X"][i, rows], h["UH"][i, rows], h["Xdot"][i, rows]
+        J = h["jitter"][i, rows] if J is None else J[i]
         K = ogp.kb_matrix(X, UH, h["Bm"][i], h["ell"][i], h["s2"][i], kernel=kernel) + np.diag(J)
         L = np.linalg.cholesky(K)
         Y = Xd - UH @ h["M0"][i]
@@ -1083,9 +1084,9 @@ def test_opt_in_data_kernels_on_the_online_entry_points_vs_oracle(ops, kernel, d
         alpha = sla.cho_solve((L, True), Y)
         return h["M0"][i].T + alpha.T @ Phi, h["s2"][i] * h["Bm"][i] - W.T @ W
 
-    def check(Mk, Bk, rows, xq, what):
+    def check(Mk, Bk, rows, xq, what, J=None):
         for i in (0, Bt - 1):
-            Mo, Bo = oracle_posterior(i, rows, host(xq)[i])
+            Mo, Bo = oracle_posterior(i, rows, host(xq)[i], J)
             rel_close(host(Mk)[i], Mo, tol, scale=max(1.0, np.abs(Mo).max()), what="Mk " + what)
             rel_close(host(Bk)[i], Bo, tol, scale=float(h["s2"][i] * np.abs(h["Bm"][i]).max()), what="Bk " + what)
 
@@ -1136,8 +1137,25 @@ def test_opt_in_data_kernels_on_the_online_entry_points_vs_oracle(ops, kernel, d
     assert gw.drops == 1 and gw.N == W + 2
     Mq, Bq = gw.posterior(p["xq"])
     check(Mq, Bq, slice(D, N0 + D + 2), p["xq"], "window after a drop")
-    with pytest.raises(NotImplementedError):
-        mk(window=W, drop=D, retry_levels=2, UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    # ... and without a look at the device (retry_levels: bcbf_refit of the kind + unconditional bcbf_refit_retry_kind launches on a
+    # fresh draw at each instance's level); the jitter every point was factored with is what the raw store holds
+    gr = ops.ReservedGP(Lop, Vw, cut(p["X"], N0), UHB, p["ell"], p["s2"], p["Bm"], p["M0"], W + D, window=W, drop=D, kernel=kernel,
+                        retry_levels=2, UH=cut(p["UH"], N0), Xdot=cut(p["Xdot"], N0), jitter=cut(p["jitter"], N0))
+    for t in range(D + 2):
+        assert (gr.append(*new(N0 + t)) == 0).all()
+    assert gr.drops == 1 and gr.count_drop_failures() == 0
+    Mq, Bq = gr.posterior(p["xq"])
+    check(Mq, Bq, slice(D, N0 + D + 2), p["xq"], "window after a host-free drop", J=host(gr._rJ[:, :gr.N]))
+    # bcbf_refit_retry_kind alone: a failed instance (negative jitter) is factored again with the raised jitter, the others are left alone
+    Xr, UHr, Jr = cut(p["X"], N0), cut(p["UH"], N0), cut(p["jitter"], N0).clone()
+    Jr[1] = -1.0
+    L1, U1, i1, _ = ops.refit(Xr, UHr, p["Bm"], p["ell"], p["s2"], Jr, kernel=kernel)
+    assert i1.cpu().tolist()[1] != 0 and (i1.cpu()[[0, 2]] == 0).all()
+    keep = L1.clone()
+    Jr[1] = p["jitter"][1, :N0]
+    i2 = ops.refit_retry(Xr, UHr, p["Bm"], p["ell"], p["s2"], Jr, L1, U1, i1, torch.empty_like(i1), kernel=kernel)
+    assert (i2 == 0).all() and torch.equal(L1[[0, 2]], keep[[0, 2]])
+    rel_close(host(L1[1]), host(Lop[1]), 1e-5 if dtype == torch.float32 else 1e-12, scale=float(Lop[1].abs().max()), what="retried operator (%s)" % kernel)
     # the streaming append (N >= 384): the forward solve on that kind's streaming kernel
     Ns = ops.GP_APPEND_STREAM_MIN_N
     q = make_instances(2, Ns + 1, n, m, dtype=dtype, device=DEV, seed=32)
