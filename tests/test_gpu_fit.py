@@ -223,3 +223,38 @@ def test_trtri_on_the_matrix_cores_is_the_inverse_of_the_factor(dtype, tol):
         ops.check(getattr(lib, "bcbf_trtri" + ops._suf(Lop))(ops._p(Lop[2:3].contiguous()), ops._p(one), 1, N, ops._stream(Lop)), "bcbf_trtri")
         scale = float(one.abs().max())
         assert float((one[0] - Linv[2]).abs().max()) <= (1e-10 if dtype == torch.float64 else 2e-3) * scale
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)], ids=["f64", "f32"])
+@pytest.mark.parametrize("Bt,N", [(3, 300), (5, 512), (70, 300), (66, 512), (64, 129)])
+def test_mll_grad_row_form_on_half_the_pairs_equals_the_pair_form(Bt, N, dtype, tol):
+    """bcbf_mll_grad's row form visits the pairs j <= i only (weight 1 on the sum of a pair's two ordered terms, 1/2 on the
+    diagonal, (B + B') staged per tile, g_B = s2 (M + M')) across row chunks (N > 256), column tiles (N > 128) and column slices
+    (few models); the pair-per-thread form (the entry point without a workspace: one workgroup per model, every ordered pair) is
+    an independent evaluation of the same sums.  Also with a NON-symmetric B, where u_i' B u_j != u_j' B u_i."""
+    from bayesian_cbf_amd import ops
+    from bayesian_cbf_amd.ops import _p, _suf, _stream, lib
+    from bayesian_cbf_amd.synthetic import make_instances
+    n, m = 3, 2
+    p = make_instances(Bt, N, n, m, dtype=dtype, device=DEV, seed=4)
+    Lop, UHB, info, _ = ops.refit(p["X"], p["UH"], p["Bm"], p["ell"], p["s2"], p["jitter"])
+    assert (info == 0).all()
+    Kinv = ops.kb_inverse(Lop, N)
+    R = (p["Xdot"] - p["UH"] @ p["M0"]).contiguous()
+    alpha = ops.kinv_apply(Kinv, R)
+    Ainv = torch.linalg.inv(p["A"]).contiguous()
+    for sym in (True, False):
+        Bm = p["Bm"] if sym else (p["Bm"] + 0.3 * torch.randn_like(p["Bm"])).contiguous()
+        rows = ops.mll_grad(Lop, alpha, Kinv, p["X"], p["UH"], R, Ainv, Bm, p["ell"], p["s2"])
+        f = dict(dtype=dtype, device=DEV)
+        C = m + 1
+        pair = (torch.empty(Bt, n, **f), torch.empty(Bt, **f), torch.empty(Bt, C, C, **f), torch.empty(Bt, **f), torch.empty(Bt, n, n, **f),
+                torch.empty(Bt, C, n, **f))
+        rc = getattr(lib, "bcbf_mll_grad" + _suf(p["X"]))(_p(Lop), _p(alpha), _p(Kinv), _p(p["X"]), _p(p["UH"]), _p(R), _p(Ainv), _p(Bm),
+                                                          _p(p["ell"]), _p(p["s2"]), *(_p(o) for o in pair), Bt, N, n, m, None, _stream(p["X"]))
+        assert rc == 0
+        torch.cuda.synchronize()
+        for name, a, b in zip(("g_ell", "g_s2", "g_B", "logdetK", "RtA", "UHtA"), rows, pair):
+            scale = max(float(b.abs().max()), 1e-6)
+            err = float((a - b).abs().max()) / scale
+            assert err <= tol, "%s (B %s): %g" % (name, "symmetric" if sym else "not symmetric", err)
