@@ -137,9 +137,9 @@ class BatchedHyperFit:
         Lop, _, info, _ = ops.refit(X, UH, hp["Bm"], hp["ell"], hp["s2"], jit)
         bad = info != 0
         for ntry in range(1, max_tries):
-            if not bool(bad.any()):                           # the iteration's one look at the device
+            idx = bad.nonzero().flatten()                     # the iteration's look at the device (one per jitter level)
+            if idx.numel() == 0:
                 break
-            idx = bad.nonzero().flatten()
             level[idx] = level[idx] * 10
             sub = lambda t: t.index_select(0, idx).contiguous()
             jit_s = (level[idx][:, None] * self.jitter_rand(idx, N)).contiguous()
