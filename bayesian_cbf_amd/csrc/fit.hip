@@ -234,21 +234,27 @@ kinv_apply_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __rest
 // ... the same product with 16 bytes per lane and eight rows of K_b^-1 in flight per lane (batches; N a multiple of the vector width, nt <= 4): the form above
 // issues one 4-byte load per multiply-add group and waits for it (4096 x 512: 2.6 ms fp32 / 3.0 ms fp64 for a 4.3 / 8.6 GB read).  A lane owns V consecutive
 // columns, a wave one of four row slices (its rows of R staged in LDS as doubles), sums in fp64 as above.
+#ifndef BCBF_KA_OCC
+#define BCBF_KA_OCC 2          // (4096 x 512, ms fp32 / fp64 at 2 / 3 / 4 waves per SIMD: 0.735 / 0.89 / 1.96 (spills); 1.46 throughout)
+#endif
 template <typename T, int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BCBF_KA_OCC)
 kinv_apply_vec_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __restrict__ alpha, int N, int nt) {
-    constexpr int V = 16 / (int)sizeof(T), U = 8, PERMAX = 256;
+    constexpr int V = 16 / (int)sizeof(T), U = 8;
     using VecT = typename Vec<T>::type;
-    __shared__ double part[4][64][V][NT];
-    __shared__ double rs[4][PERMAX][NT];
+    // dynamic LDS: the four slices' rows of R as doubles ([4][per][NT]) while the sums run, the four partial sums ([4][64][V][NT])
+    // afterwards -- one buffer for both (64 KB of static arrays held a CU to two workgroups)
+    extern __shared__ __attribute__((aligned(16))) double ka_smem[];
     const int b = blockIdx.y, lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int i0 = (blockIdx.x * 64 + lane) * V;
     const T* K = Kinv + (size_t)b * N * N;
     const T* Rb = R + (size_t)b * N * nt;
     const int per = (N + 3) / 4, j0 = sl * per, j1 = min(N, j0 + per), cnt = j1 - j0;
+    double (*rs)[NT] = reinterpret_cast<double (*)[NT]>(ka_smem + (size_t)sl * per * NT);      // this wave's slice [per][NT]
+    double (*part)[64][V][NT] = reinterpret_cast<double (*)[64][V][NT]>(ka_smem);
     for (int e = lane; e < per * NT; e += 64) {
         const int jj = e / NT, c = e - jj * NT;
-        rs[sl][jj][c] = (jj < cnt && c < nt) ? (double)Rb[(size_t)(j0 + jj) * nt + c] : 0.0;
+        rs[jj][c] = (jj < cnt && c < nt) ? (double)Rb[(size_t)(j0 + jj) * nt + c] : 0.0;
     }
     __builtin_amdgcn_wave_barrier();                              // (a wave reads its own slice only)
     double acc[V][NT];
@@ -270,12 +276,13 @@ kinv_apply_vec_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __
                 const T* kv = reinterpret_cast<const T*>(&k[u]);
 #pragma unroll
                 for (int c = 0; c < NT; ++c) {
-                    const double r = in ? rs[sl][min(jj + u, PERMAX - 1)][c] : 0.0;
+                    const double r = in ? rs[min(jj + u, per - 1)][c] : 0.0;
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc[v][c] += (double)kv[v] * r;
                 }
             }
         }
+    __syncthreads();                                              // (every slice has been read: the buffer changes hands)
 #pragma unroll
     for (int v = 0; v < V; ++v)
 #pragma unroll
@@ -329,7 +336,9 @@ static int launch_kinv_apply(const T* Kinv, const T* R, T* alpha, int Bt, int N,
     if (!Kinv || !R || !alpha || (const void*)R == (const void*)alpha) return BCBF_EINVAL;
     constexpr int V = 16 / (int)sizeof(T);
     if (Bt >= 16 && N % V == 0 && nt <= 4 && (N + 3) / 4 <= 256) {      // batches: 16 bytes per lane, eight rows in flight
-        hipLaunchKernelGGL((kinv_apply_vec_kernel<T, 4>), dim3((N / V + 63) / 64, Bt), dim3(256), 0, (hipStream_t)stream, Kinv, R, alpha, N, nt);
+        const size_t rs_b = (size_t)4 * ((N + 3) / 4) * 4 * sizeof(double), part_b = (size_t)4 * 64 * V * 4 * sizeof(double);
+        hipLaunchKernelGGL((kinv_apply_vec_kernel<T, 4>), dim3((N / V + 63) / 64, Bt), dim3(256), rs_b > part_b ? rs_b : part_b,
+                           (hipStream_t)stream, Kinv, R, alpha, N, nt);
         return check_launch("bcbf_kinv_apply");
     }
     hipLaunchKernelGGL((kinv_apply_kernel<T>), dim3((N + 63) / 64, Bt), dim3(256), 0, (hipStream_t)stream, Kinv, R, alpha, N, nt);
