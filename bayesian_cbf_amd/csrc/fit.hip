@@ -237,10 +237,14 @@ kinv_apply_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __rest
 #ifndef BCBF_KA_OCC
 #define BCBF_KA_OCC 2          // (4096 x 512, ms fp32 / fp64 at 2 / 3 / 4 waves per SIMD: 0.735 / 0.89 / 1.96 (spills); 1.46 throughout)
 #endif
+#ifndef BCBF_KA_U
+#define BCBF_KA_U 8            // rows of K_b^-1 in flight per lane (4 / 8 / 16 / 32: the same 1.43 - 1.47 ms fp64, 0.735 - 0.80 fp32 at 4096 x 512: 5.9 TB/s
+                               // is what 1 KB pieces at a row's stride give; whole rows per workgroup would be the next form)
+#endif
 template <typename T, int NT>
 __global__ void __launch_bounds__(256, BCBF_KA_OCC)
 kinv_apply_vec_kernel(const T* __restrict__ Kinv, const T* __restrict__ R, T* __restrict__ alpha, int N, int nt) {
-    constexpr int V = 16 / (int)sizeof(T), U = 8;
+    constexpr int V = 16 / (int)sizeof(T), U = BCBF_KA_U;
     using VecT = typename Vec<T>::type;
     // dynamic LDS: the four slices' rows of R as doubles ([4][per][NT]) while the sums run, the four partial sums ([4][64][V][NT])
     // afterwards -- one buffer for both (64 KB of static arrays held a CU to two workgroups)
